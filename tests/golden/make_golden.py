@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, imported read-only with
+PYTHONDONTWRITEBYTECODE=1).  The fixtures are data: seeded inputs + the reference's
+outputs.  They pin oracle/ebos_oracle.py (tests/test_oracle_golden.py), which in turn is
+the checker for the HIP path on the GPU box (where /root/reference does not exist).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Reference entry points exercised (paths relative to /root/reference):
+  src/warp.py:193-383  src/event_image_converter.py:51-73,288-301,332-620
+  src/utils/stat_utils.py:48-139 (SobelTorch)  src/costs/*.py  src/solver/patch_eklt.py:70-95
+"""
+import importlib.util
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+warnings.filterwarnings("ignore")
+sys.dont_write_bytecode = True
+
+
+class _AnyModule(types.ModuleType):
+    """Empty stand-in for an absent third-party package: any attribute is a dummy class."""
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        cls = type(item, (), {"__init__": lambda self, *a, **k: None})
+        setattr(self, item, cls)
+        return cls
+
+
+def _stub(name, **attrs):
+    m = _AnyModule(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    if "." in name:  # make `from pkg import sub` resolve to the stubbed submodule
+        parent, child = name.rsplit(".", 1)
+        if parent in sys.modules:
+            setattr(sys.modules[parent], child, m)
+    return m
+
+
+def import_reference():
+    """Import the reference's hot-path modules; third-party packages that are absent from
+    the image and unused on this path are stubbed as empty modules."""
+    sys.path.insert(0, REF)
+    from src.warp import Warp  # noqa
+    from src.event_image_converter import EventImageConverter  # noqa
+
+    _stub("cv2")
+    spec = importlib.util.spec_from_file_location("ref_stat_utils", f"{REF}/src/utils/stat_utils.py")
+    stat = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stat)
+
+    # src.costs pulls src.utils / src.visualizer -> stub the absent third-party imports.
+    for n in ["openpiv", "openpiv.windef", "openpiv.tools", "openpiv.pyprocess", "openpiv.validation",
+              "openpiv.filters", "openpiv.scaling", "openpiv.preprocess", "openpiv.smoothn",
+              "ffmpeg", "skimage", "skimage.util", "skimage.metrics", "skimage.transform",
+              "h5py", "hdf5plugin", "pivpy", "torchvision", "torchvision.transforms",
+              "torchvision.transforms.functional", "plotly", "plotly.graph_objects",
+              "plotly.express", "plotly.subplots", "optuna.samplers", "optuna.distributions",
+              "optuna.storages", "optuna.study", "optuna.trial", "torch_scatter"]:
+        _stub(n)
+    op = _stub("optuna")
+    for sub in ("storages", "samplers", "distributions", "study", "trial"):
+        setattr(op, sub, sys.modules["optuna." + sub])
+    sys.modules["optuna.storages"].InMemoryStorage = type("InMemoryStorage", (), {})
+    sys.modules["optuna.storages"].BaseStorage = type("BaseStorage", (), {})
+    sys.modules["optuna.distributions"].BaseDistribution = type("BaseDistribution", (), {})
+    op.storages = sys.modules["optuna.storages"]
+    op.samplers = sys.modules["optuna.samplers"]
+    op.distributions = sys.modules["optuna.distributions"]
+    costs = None
+    try:
+        import src.costs as costs  # noqa
+    except Exception as e:  # pragma: no cover - informational
+        print("WARNING: src.costs not importable here:", repr(e))
+    return Warp, EventImageConverter, stat.SobelTorch, costs
+
+
+def synth_events(n, h, w, seed=0, tmin=0.0, tmax=0.5):
+    # recipe of src/utils/event_utils.py:40-47 with an explicit legacy RandomState
+    rs = np.random.RandomState(seed)
+    x = rs.randint(0, h, n)
+    y = rs.randint(0, w, n)
+    t = np.sort(rs.uniform(tmin, tmax, n))
+    p = rs.randint(0, 2, n)
+    return np.stack([x, y, t, p], axis=1).astype(np.float64)
+
+
+def synth_flow(h, w, seed=1, fmax=30.0):
+    return np.random.RandomState(seed).uniform(-fmax, fmax, (2, h, w))  # src/utils/flow_utils.py:29
+
+
+def main():
+    Warp, EIC, SobelTorch, costs = import_reference()
+    out = {}
+
+    # ---- G1: micro known-answer vectors ------------------------------------------------
+    ev = np.array([[1, 2], [3, 4], [3.5, 4.5], [-0.5, 0.5], [0.9999995, 1.0], [10, 10]], dtype=np.float64)
+    ev = np.concatenate([ev, np.zeros((6, 2))], axis=1)
+    im = EIC((4, 5))
+    out["g1_events"] = ev
+    out["g1_vote_torch"] = im.bilinear_vote_tensor(torch.from_numpy(ev)).numpy()
+    out["g1_vote_numpy"] = im.bilinear_vote_numpy(ev)
+    out["g1_count_numpy"] = im.count_event_numpy(ev)
+    wts = np.arange(6, dtype=np.float64)
+    out["g1_vote_weighted_torch"] = im.bilinear_vote_tensor(torch.from_numpy(ev), weight=torch.from_numpy(wts)).numpy()
+    out["g1_vote_weighted_numpy"] = im.bilinear_vote_numpy(ev, weight=wts)
+    im2 = EIC((4, 5), outer_padding=2)
+    out["g1_vote_pad2_torch"] = im2.bilinear_vote_tensor(torch.from_numpy(ev)).numpy()
+    out["g1_vote_pad2_numpy"] = im2.bilinear_vote_numpy(ev)
+    out["g1_mask_torch"] = im.create_eventmask(torch.from_numpy(ev)).numpy()
+
+    wv = np.array([[1, 1, 0, 1], [2, 3, .5, 0], [3, 4, 1, 1]], dtype=np.float64)
+    fl = np.ones((2, 4, 5)) * np.array([1.0, 2.0])[:, None, None]
+    wp = Warp((4, 5))
+    out["g1_warp_events"] = wv
+    out["g1_warp_flow"] = fl
+    for d in ["first", "middle", "last", "before", "after"]:
+        out[f"g1_warp_dense_{d}_numpy"] = wp.warp_event(wv, fl, "dense-flow", d)[0]
+        out[f"g1_warp_dense_{d}_torch"] = wp.warp_event(torch.from_numpy(wv), torch.from_numpy(fl), "dense-flow", d)[0].numpy()
+    out["g1_warp_dense_f025_numpy"] = wp.warp_event(wv, fl, "dense-flow", 0.25)[0]
+    out["g1_warp_2dof_first_numpy"] = wp.warp_event(wv, np.array([1.0, 2.0]), "2d-translation", "first")[0]
+    out["g1_warp_2dof_middle_torch"] = wp.warp_event(torch.from_numpy(wv), torch.tensor([1.0, 2.0], dtype=torch.float64),
+                                                     "rigid-optical-flow", "middle")[0].numpy()
+    wfrac = np.array([[1.9, 2.9, 0.0, 1], [0.2, 0.7, 1.0, 0]], dtype=np.float64)
+    flr = synth_flow(4, 5, seed=3, fmax=2.0)
+    out["g1_warp_frac_events"] = wfrac
+    out["g1_warp_frac_flow"] = flr
+    out["g1_warp_frac_torch"] = wp.warp_event(torch.from_numpy(wfrac), torch.from_numpy(flr), "dense-flow", "first")[0].numpy()
+    out["g1_warp_frac_numpy"] = wp.warp_event(wfrac, flr, "dense-flow", "first")[0]
+    wpn = Warp((4, 5), normalize_t=True)
+    wv_s = wv.copy()
+    wv_s[:, 2] *= 0.02
+    out["g1_warp_norm_scaled_numpy"] = wpn.warp_event(wv_s, fl, "dense-flow", "first")[0]
+    out["g1_flow_from_motion"] = wp.get_flow_from_motion(np.array([1.0, 2.0]), "2d-translation")
+
+    # ---- G2: small full-array cases (24x32, 2000 events) ---------------------------------
+    H, W, N = 24, 32, 2000
+    e2 = synth_events(N, H, W, seed=10)
+    e2[:, 0] += np.random.RandomState(11).uniform(0, 0.999, N) * (np.arange(N) % 3 == 0)  # some fractional sources
+    e2[:, 1] += np.random.RandomState(12).uniform(0, 0.999, N) * (np.arange(N) % 5 == 0)
+    f2 = synth_flow(H, W, seed=13, fmax=5.0)
+    out["g2_events"] = e2
+    out["g2_flow"] = f2
+    te, tf = torch.from_numpy(e2), torch.from_numpy(f2)
+    for norm in (False, True):
+        wq = Warp((H, W), normalize_t=norm)
+        for d in ["first", "middle", "last", 0.25, "before", "after"]:
+            tag = f"g2_warp_dense_n{int(norm)}_{d}"
+            out[tag + "_numpy"] = wq.warp_event(e2, f2, "dense-flow", d)[0]
+            out[tag + "_torch"] = wq.warp_event(te, tf, "dense-flow", d)[0].numpy()
+        out[f"g2_warp_2dof_n{int(norm)}_middle_numpy"] = wq.warp_event(e2, np.array([3.0, -2.0]), "2d-translation", "middle")[0]
+        out[f"g2_warp_2dof_n{int(norm)}_first_torch"] = wq.warp_event(te, torch.tensor([3.0, -2.0], dtype=torch.float64),
+                                                                      "2d-translation", "first")[0].numpy()
+    # float32 torch path (the dtype the HIP kernels run in)
+    wq = Warp((H, W), normalize_t=True)
+    out["g2_warp_dense_n1_first_torch_f32"] = wq.warp_event(te.float(), tf.float(), "dense-flow", "first")[0].numpy()
+    # batched
+    eb = np.stack([e2, synth_events(N, H, W, seed=20)], 0)
+    fb = np.stack([f2, synth_flow(H, W, seed=21, fmax=5.0)], 0)
+    out["g2_events_b"] = eb
+    out["g2_flow_b"] = fb
+    out["g2_warp_dense_b_n1_middle_numpy"] = wq.warp_event(eb, fb, "dense-flow", "middle")[0]
+    out["g2_warp_dense_b_n1_middle_torch"] = wq.warp_event(torch.from_numpy(eb), torch.from_numpy(fb), "dense-flow", "middle")[0].numpy()
+
+    warped = wq.warp_event(e2, f2, "dense-flow", "first")[0]
+    tw = torch.from_numpy(warped)
+    wgt = np.random.RandomState(14).uniform(0.0, 2.0, N)
+    for pad in (0, 2):
+        ic = EIC((H, W), outer_padding=pad)
+        out[f"g2_iwe_p{pad}_numpy"] = ic.bilinear_vote_numpy(warped)
+        out[f"g2_iwe_p{pad}_torch"] = ic.bilinear_vote_tensor(tw).numpy()
+        out[f"g2_iwe_p{pad}_w_numpy"] = ic.bilinear_vote_numpy(warped, weight=wgt)
+        out[f"g2_iwe_p{pad}_w_torch"] = ic.bilinear_vote_tensor(tw, weight=torch.from_numpy(wgt)).numpy()
+        out[f"g2_iwe_p{pad}_w05_torch"] = ic.bilinear_vote_tensor(tw, weight=0.5).numpy()
+        out[f"g2_count_p{pad}_numpy"] = ic.count_event_numpy(warped)
+        out[f"g2_polarity_p{pad}_numpy"] = ic.create_iwe(warped, method="polarity", sigma=0)
+        out[f"g2_mask_p{pad}_numpy"] = ic.create_eventmask(warped)
+    ic = EIC((H, W))
+    out["g2_weight"] = wgt
+    out["g2_iwe_f32_torch"] = ic.bilinear_vote_tensor(tw.float()).numpy()
+    for s in (1, 3):
+        out[f"g2_iwe_sigma{s}_numpy"] = ic.create_iwe(warped, method="bilinear_vote", sigma=s)
+    out["g2_iwe_default_numpy"] = ic.create_iwe(warped)  # default sigma = 1 (numpy)
+    out["g2_iwe_default_torch"] = ic.create_iwe(tw, sigma=0).numpy()
+    wb = wq.warp_event(eb, fb, "dense-flow", "middle")[0]
+    out["g2_iwe_b_numpy"] = ic.bilinear_vote_numpy(wb)
+    out["g2_iwe_b_torch"] = ic.bilinear_vote_tensor(torch.from_numpy(wb)).numpy()
+
+    # contrast costs + autograd gradients (fp64), built from the reference's primitives
+    sob = SobelTorch(ksize=3, in_channels=1, precision="64")
+
+    def contrast(events_t, motion_t, model, cost, omit, imager, warper, weight=1.0):
+        w_, _ = warper.warp_event(events_t, motion_t, model, "first")
+        iwe = imager.bilinear_vote_tensor(w_, weight=weight)
+        if cost == "var":
+            x = iwe[1:-1, 1:-1] if omit else iwe
+            return -torch.var(x), iwe
+        g = sob(iwe[None, None]) / 8.0
+        m = g[0, 0] ** 2 + g[0, 1] ** 2
+        m = m[1:-1, 1:-1] if omit else m
+        return -torch.mean(m), iwe
+
+    out["g2_sobel"] = sob(torch.from_numpy(out["g2_iwe_p0_torch"])[None, None])[0].detach().numpy()
+    for cost in ("var", "gm"):
+        for omit in (False, True):
+            fl_t = tf.clone().requires_grad_(True)
+            wt_t = torch.from_numpy(wgt).clone().requires_grad_(True)
+            L, iwe = contrast(te, fl_t, "dense-flow", cost, omit, ic, wq, weight=wt_t)
+            L.backward()
+            tag = f"g2_{cost}_omit{int(omit)}"
+            out[tag + "_loss"] = np.float64(L.item())
+            out[tag + "_dflow"] = fl_t.grad.numpy()
+            out[tag + "_dweight"] = wt_t.grad.numpy()
+            th = torch.tensor([3.0, -2.0], dtype=torch.float64, requires_grad=True)
+            L2, _ = contrast(te, th, "2d-translation", cost, omit, ic, wq)
+            L2.backward()
+            out[tag + "_2dof_loss"] = np.float64(L2.item())
+            out[tag + "_2dof_dtheta"] = th.grad.numpy()
+    # d(loss)/d(iwe) for the two costs (used to pin the cost kernels in isolation)
+    for cost in ("var", "gm"):
+        for omit in (False, True):
+            x = torch.from_numpy(out["g2_iwe_p0_torch"]).clone().requires_grad_(True)
+            if cost == "var":
+                L = -torch.var(x[1:-1, 1:-1] if omit else x)
+            else:
+                g = sob(x[None, None]) / 8.0
+                m = g[0, 0] ** 2 + g[0, 1] ** 2
+                L = -torch.mean(m[1:-1, 1:-1] if omit else m)
+            L.backward()
+            out[f"g2_{cost}_omit{int(omit)}_diwe"] = x.grad.numpy()
+
+    # shipped costs (A15) + hybrid through the reference's registry, if importable here
+    if costs is not None:
+        out["g2_costs_registry"] = np.array(sorted(costs.functions.keys()))
+        fn = costs.functions["flow_norm"](direction="minimize")
+        out["g2_cost_flow_norm"] = np.float64(fn.calculate({"flow": tf}).item())
+        out["g2_cost_flow_norm_numpy"] = np.float64(fn.calculate({"flow": f2}))
+        ig = costs.functions["image_gradient"](direction="minimize")
+        wmap = torch.from_numpy(np.random.RandomState(15).uniform(0.5, 1.5, (H, W)))
+        out["g2_cost_weights"] = wmap.numpy()
+        out["g2_cost_image_gradient"] = np.float64(
+            ig.calculate({"flow": tf, "omit_boundary": False, "weights": wmap}).item())
+        dn = costs.functions["diff_norm"](direction="minimize")
+        pred = torch.from_numpy(out["g2_iwe_p0_torch"])
+        meas = torch.from_numpy(out["g2_iwe_p0_w_torch"])
+        out["g2_cost_diff_norm"] = np.float64(
+            dn.calculate({"prediction": pred, "measurement": meas, "weights": None}).item())
+        hy = costs.HybridCost("minimize", {"flow_norm": 0.5, "image_gradient": "inv"}, store_history=True)
+        v = hy.calculate({"flow": tf, "omit_boundary": False, "weights": wmap})
+        out["g2_cost_hybrid"] = np.float64(v.item())
+        out["g2_cost_hybrid_history_keys"] = np.array(sorted(hy.get_history().keys()))
+
+    np.savez_compressed(os.path.join(HERE, "golden_small.npz"), **out)
+    print("golden_small.npz:", len(out), "arrays")
+
+    # ---- G3: mid-size summaries ---------------------------------
+    mid = {}
+    for (h, w, n, fmax) in [(260, 346, 100_000, 5.0), (720, 1280, 1_000_000, 30.0)]:
+        tag = f"g3_{h}x{w}_{n}"
+        e = synth_events(n, h, w, seed=0)
+        f = synth_flow(h, w, seed=1, fmax=fmax)
+        te, tf = torch.from_numpy(e), torch.from_numpy(f)
+        wq, ic = Warp((h, w), normalize_t=True), EIC((h, w))
+        stats = {}
+        for cost in ("var", "gm"):
+            fl_t = tf.clone().requires_grad_(True)
+            L, iwe = contrast(te, fl_t, "dense-flow", cost, False, ic, wq)
+            L.backward()
+            stats[cost] = (L.item(), fl_t.grad)
+        iwe = iwe.detach()
+        mid[tag + "_iwe_sum"] = np.float64(iwe.sum().item())
+        mid[tag + "_iwe_max"] = np.float64(iwe.max().item())
+        mid[tag + "_iwe_l2"] = np.float64(torch.linalg.norm(iwe).item())
+        mid[tag + "_iwe_center"] = np.float64(iwe[h // 2, w // 2].item())
+        mid[tag + "_iwe_stride"] = iwe[::13, ::17].numpy().copy()
+        mid[tag + "_iwe_rowsum"] = iwe.sum(1).numpy()
+        mid[tag + "_iwe_colsum"] = iwe.sum(0).numpy()
+        for cost in ("var", "gm"):
+            L, g = stats[cost]
+            mid[tag + f"_{cost}_loss"] = np.float64(L)
+            mid[tag + f"_{cost}_dflow_l2"] = np.float64(torch.linalg.norm(g).item())
+            mid[tag + f"_{cost}_dflow_stride"] = g[:, ::13, ::17].numpy().copy()
+        th = torch.tensor([3.0, -2.0], dtype=torch.float64, requires_grad=True)
+        L2, iwe2 = contrast(te, th, "2d-translation", "var", False, ic, wq)
+        L2.backward()
+        mid[tag + "_2dof_iwe_sum"] = np.float64(iwe2.sum().item())
+        mid[tag + "_2dof_var_loss"] = np.float64(L2.item())
+        mid[tag + "_2dof_var_dtheta"] = th.grad.numpy()
+        pol = ic.create_iwe(e, method="polarity", sigma=0)
+        mid[tag + "_polarity_sums"] = np.array([pol[0].sum(), pol[1].sum()])
+        # float32 reference run (what the reference computes when fed fp32 tensors)
+        w32, _ = wq.warp_event(te.float(), tf.float(), "dense-flow", "first")
+        i32 = ic.bilinear_vote_tensor(w32)
+        mid[tag + "_iwe_f32_rel_l2_vs_f64"] = np.float64(
+            (torch.linalg.norm(i32.double() - iwe) / torch.linalg.norm(iwe)).item())
+        print(tag, {k: (float(v) if np.ndim(v) == 0 else np.shape(v)) for k, v in mid.items() if k.startswith(tag)})
+    np.savez_compressed(os.path.join(HERE, "golden_mid.npz"), **mid)
+    print("golden_mid.npz:", len(mid), "arrays")
+
+
+if __name__ == "__main__":
+    main()

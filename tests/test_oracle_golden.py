@@ -1,0 +1,246 @@
+"""Pins oracle/ebos_oracle.py against golden vectors captured from the reference itself
+(tests/golden/make_golden.py).  CPU only.  Tolerances: the oracle restates the same fp64
+operations, so values agree to rounding (<= 1e-12 relative); elementwise warps are exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ebos_oracle as O
+
+H, W = 24, 32
+DIRS = ["first", "middle", "last", 0.25, "before", "after"]
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ---------------------------------------------------------------- G1 known answers
+def test_micro_vote_known_answer(golden_small):
+    g = golden_small
+    ev = g["g1_events"]
+    expect = np.array([[0.25, 0.25, 0, 0, 0], [0, 1.0000005, 1, 0, 0], [0, -5e-07, 0, 0, 0], [0, 0, 0, 0, 1.25]])
+    np.testing.assert_allclose(g["g1_vote_torch"], expect, atol=1e-9)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(ev), (4, 5)).numpy(), g["g1_vote_torch"], atol=1e-15)
+    np.testing.assert_allclose(O.bilinear_vote_numpy(ev, (4, 5)), g["g1_vote_numpy"], atol=1e-15)
+    np.testing.assert_array_equal(O.count_events_numpy(ev, (4, 5)), g["g1_count_numpy"])
+    w = np.arange(6, dtype=np.float64)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(ev), (4, 5), weight=T(w)).numpy(), g["g1_vote_weighted_torch"], atol=1e-15)
+    np.testing.assert_allclose(O.bilinear_vote_numpy(ev, (4, 5), weight=w), g["g1_vote_weighted_numpy"], atol=1e-15)
+    assert abs(g["g1_vote_weighted_torch"].sum() - 7.0) < 1e-9
+    size, pad = O.padded_size((4, 5), 2)
+    assert size == (8, 9) and pad == (2, 2)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(ev), size, pad).numpy(), g["g1_vote_pad2_torch"], atol=1e-15)
+    np.testing.assert_allclose(O.bilinear_vote_numpy(ev, size, pad), g["g1_vote_pad2_numpy"], atol=1e-15)
+    np.testing.assert_array_equal(O.event_mask(T(ev), (4, 5)).numpy(), g["g1_mask_torch"])
+
+
+def test_micro_warp_known_answer(golden_small):
+    g = golden_small
+    ev, fl = g["g1_warp_events"], g["g1_warp_flow"]
+    np.testing.assert_array_equal(g["g1_warp_dense_first_numpy"], [[1, 1, 0, 1], [1.5, 2, .5, 0], [2, 2, 1, 1]])
+    np.testing.assert_array_equal(g["g1_warp_dense_middle_numpy"], [[1.5, 2, -.5, 1], [2, 3, 0, 0], [2.5, 3, .5, 1]])
+    np.testing.assert_array_equal(g["g1_warp_dense_last_numpy"], [[2, 3, -1, 1], [2.5, 4, -.5, 0], [3, 4, 0, 1]])
+    np.testing.assert_array_equal(g["g1_warp_2dof_first_numpy"], [[1, 1, 0, 1], [2.5, 4, .5, 0], [4, 6, 1, 1]])
+    for d in ["first", "middle", "last", "before", "after"]:
+        np.testing.assert_array_equal(O.warp_dense_numpy(ev, fl, d), g[f"g1_warp_dense_{d}_numpy"])
+        np.testing.assert_array_equal(O.warp_dense_torch(T(ev), T(fl), d).numpy(), g[f"g1_warp_dense_{d}_torch"])
+    np.testing.assert_array_equal(O.warp_dense_numpy(ev, fl, 0.25), g["g1_warp_dense_f025_numpy"])
+    np.testing.assert_array_equal(O.warp_2dof(ev, np.array([1.0, 2.0]), "first"), g["g1_warp_2dof_first_numpy"])
+    np.testing.assert_array_equal(O.warp_2dof(T(ev), torch.tensor([1.0, 2.0], dtype=torch.float64), "middle").numpy(),
+                                  g["g1_warp_2dof_middle_torch"])
+    # fractional sources are truncated for the flow lookup (src/warp.py:334)
+    fe, ff = g["g1_warp_frac_events"], g["g1_warp_frac_flow"]
+    np.testing.assert_array_equal(O.warp_dense_torch(T(fe), T(ff)).numpy(), g["g1_warp_frac_torch"])
+    np.testing.assert_array_equal(O.warp_dense_numpy(fe, ff), g["g1_warp_frac_numpy"])
+    assert g["g1_warp_frac_torch"][0, 0] == 1.9 - 0.0 * ff[0, 1, 2]
+    # normalised time: scaling t by 0.02 reproduces the un-normalised result
+    ev_s = ev.copy()
+    ev_s[:, 2] *= 0.02
+    np.testing.assert_allclose(O.warp_dense_numpy(ev_s, fl, "first", normalize_t=True), g["g1_warp_norm_scaled_numpy"], atol=1e-15)
+    np.testing.assert_allclose(g["g1_flow_from_motion"], -fl, atol=0)  # flow == -theta (src/warp.py:186-187)
+
+
+def test_direction_type_rules():
+    ev = O.synth_events(10, 4, 5)
+    for bad in (1, np.float64(0.5), "sideways"):
+        with pytest.raises(ValueError):
+            O.reference_time(ev, bad)
+
+
+# ---------------------------------------------------------------- G2 small full arrays
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("d", DIRS)
+def test_warp_dense_small(golden_small, norm, d):
+    g = golden_small
+    ev, fl = g["g2_events"], g["g2_flow"]
+    tag = f"g2_warp_dense_n{int(norm)}_{d}"
+    np.testing.assert_array_equal(O.warp_dense_numpy(ev, fl, d, norm), g[tag + "_numpy"])
+    np.testing.assert_array_equal(O.warp_dense_torch(T(ev), T(fl), d, norm).numpy(), g[tag + "_torch"])
+
+
+def test_warp_misc_small(golden_small):
+    g = golden_small
+    ev, fl = g["g2_events"], g["g2_flow"]
+    th = np.array([3.0, -2.0])
+    for norm in (False, True):
+        np.testing.assert_array_equal(O.warp_2dof(ev, th, "middle", norm), g[f"g2_warp_2dof_n{int(norm)}_middle_numpy"])
+        np.testing.assert_array_equal(O.warp_2dof(T(ev), T(th), "first", norm).numpy(), g[f"g2_warp_2dof_n{int(norm)}_first_torch"])
+    np.testing.assert_array_equal(O.warp_dense_torch(T(ev).float(), T(fl).float(), "first", True).numpy(),
+                                  g["g2_warp_dense_n1_first_torch_f32"])
+    eb, fb = g["g2_events_b"], g["g2_flow_b"]
+    np.testing.assert_array_equal(O.warp_dense_numpy(eb, fb, "middle", True), g["g2_warp_dense_b_n1_middle_numpy"])
+    np.testing.assert_array_equal(O.warp_dense_torch(T(eb), T(fb), "middle", True).numpy(), g["g2_warp_dense_b_n1_middle_torch"])
+
+
+@pytest.mark.parametrize("pad", [0, 2])
+def test_iwe_small(golden_small, pad):
+    g = golden_small
+    warped = g["g2_warp_dense_n1_first_numpy"]
+    wgt = g["g2_weight"]
+    size, p = O.padded_size((H, W), pad)
+    tol = dict(rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(O.bilinear_vote_numpy(warped, size, p), g[f"g2_iwe_p{pad}_numpy"], **tol)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(warped), size, p).numpy(), g[f"g2_iwe_p{pad}_torch"], **tol)
+    np.testing.assert_allclose(O.bilinear_vote_numpy(warped, size, p, wgt), g[f"g2_iwe_p{pad}_w_numpy"], **tol)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(warped), size, p, T(wgt)).numpy(), g[f"g2_iwe_p{pad}_w_torch"], **tol)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(warped), size, p, 0.5).numpy(), g[f"g2_iwe_p{pad}_w05_torch"], **tol)
+    np.testing.assert_array_equal(O.count_events_numpy(warped, size, p), g[f"g2_count_p{pad}_numpy"])
+    np.testing.assert_allclose(O.polarity_numpy(warped, size, p), g[f"g2_polarity_p{pad}_numpy"], **tol)
+    np.testing.assert_array_equal(O.event_mask(warped, size, p), g[f"g2_mask_p{pad}_numpy"])
+    np.testing.assert_array_equal(O.count_events_torch(T(warped), size, p).numpy(), g[f"g2_count_p{pad}_numpy"])
+
+
+def test_iwe_variants_small(golden_small):
+    g = golden_small
+    warped = g["g2_warp_dense_n1_first_numpy"]
+    tol = dict(rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(warped).float(), (H, W)).numpy(), g["g2_iwe_f32_torch"], rtol=1e-6, atol=1e-6)
+    for s in (1, 3):
+        np.testing.assert_allclose(O.create_image_numpy(warped, (H, W), sigma=s), g[f"g2_iwe_sigma{s}_numpy"], **tol)
+    np.testing.assert_allclose(O.create_image_numpy(warped, (H, W)), g["g2_iwe_default_numpy"], **tol)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(warped), (H, W)).numpy(), g["g2_iwe_default_torch"], **tol)
+    wb = g["g2_warp_dense_b_n1_middle_numpy"]
+    np.testing.assert_allclose(O.bilinear_vote_numpy(wb, (H, W)), g["g2_iwe_b_numpy"], **tol)
+    np.testing.assert_allclose(O.bilinear_vote_torch(T(wb), (H, W)).numpy(), g["g2_iwe_b_torch"], **tol)
+    with pytest.raises(NotImplementedError):
+        O.create_image_numpy(warped, (H, W), method="nope")
+
+
+def _loss(cost, iwe, omit):
+    return O.image_variance(iwe, omit) if cost == "var" else O.gradient_magnitude(iwe, omit)
+
+
+@pytest.mark.parametrize("cost", ["var", "gm"])
+@pytest.mark.parametrize("omit", [False, True])
+def test_contrast_costs_and_gradients_small(golden_small, cost, omit):
+    g = golden_small
+    ev, fl, wgt = T(g["g2_events"]), T(g["g2_flow"]), T(g["g2_weight"])
+    tag = f"g2_{cost}_omit{int(omit)}"
+    f = fl.clone().requires_grad_(True)
+    w = wgt.clone().requires_grad_(True)
+    L = _loss(cost, O.iwe_dense(ev, f, (H, W), weight=w), omit)
+    L.backward()
+    assert abs(L.item() - g[tag + "_loss"]) <= 1e-13 * abs(g[tag + "_loss"])
+    np.testing.assert_allclose(f.grad.numpy(), g[tag + "_dflow"], rtol=1e-10, atol=1e-16)
+    np.testing.assert_allclose(w.grad.numpy(), g[tag + "_dweight"], rtol=1e-10, atol=1e-16)
+    th = torch.tensor([3.0, -2.0], dtype=torch.float64, requires_grad=True)
+    L2 = _loss(cost, O.iwe_2dof(ev, th, (H, W)), omit)
+    L2.backward()
+    assert abs(L2.item() - g[tag + "_2dof_loss"]) <= 1e-13 * abs(g[tag + "_2dof_loss"])
+    np.testing.assert_allclose(th.grad.numpy(), g[tag + "_2dof_dtheta"], rtol=1e-10)
+    x = T(g["g2_iwe_p0_torch"]).clone().requires_grad_(True)
+    _loss(cost, x, omit).backward()
+    np.testing.assert_allclose(x.grad.numpy(), g[tag + "_diwe"], rtol=1e-12, atol=1e-18)
+
+
+def test_sobel_small(golden_small):
+    g = golden_small
+    np.testing.assert_allclose(O.sobel3(T(g["g2_iwe_p0_torch"])).numpy(), g["g2_sobel"], rtol=1e-14, atol=1e-14)
+
+
+def test_shipped_costs_small(golden_small):
+    g = golden_small
+    if "g2_cost_flow_norm" not in g:
+        pytest.skip("reference costs were not importable when the fixtures were made")
+    fl = T(g["g2_flow"])
+    assert list(g["g2_costs_registry"]) == ["diff_norm", "flow_norm", "flow_norm_pxy", "image_gradient"]
+    assert abs(O.flow_norm(fl).item() - g["g2_cost_flow_norm"]) < 1e-13
+    assert abs(g["g2_cost_flow_norm_numpy"] - g["g2_cost_flow_norm"]) < 1e-12
+    wmap = T(g["g2_cost_weights"])
+    assert abs(O.image_gradient_tv(fl, wmap).item() - g["g2_cost_image_gradient"]) < 1e-13
+    dn = O.diff_norm(T(g["g2_iwe_p0_torch"]), T(g["g2_iwe_p0_w_torch"])).item()
+    assert abs(dn - g["g2_cost_diff_norm"]) < 1e-11
+    hy = 0.5 * O.flow_norm(fl).item() + 1.0 / O.image_gradient_tv(fl, wmap).item()
+    assert abs(hy - g["g2_cost_hybrid"]) < 1e-12
+    assert list(g["g2_cost_hybrid_history_keys"]) == ["flow_norm", "image_gradient", "loss"]
+
+
+# ---------------------------------------------------------------- G3 mid-size summaries
+@pytest.mark.parametrize("h,w,n,fmax", [(260, 346, 100_000, 5.0), (720, 1280, 1_000_000, 30.0)])
+def test_mid_size_summaries(golden_mid, h, w, n, fmax):
+    g = golden_mid
+    tag = f"g3_{h}x{w}_{n}"
+    ev = T(O.synth_events(n, h, w, seed=0))
+    fl = T(O.synth_dense_flow(h, w, seed=1, max_val=fmax))
+    f = fl.clone().requires_grad_(True)
+    iwe = O.iwe_dense(ev, f, (h, w))
+    L = O.image_variance(iwe)
+    L.backward()
+    d = iwe.detach()
+    assert abs(d.sum().item() - g[tag + "_iwe_sum"]) < 1e-9 * g[tag + "_iwe_sum"]
+    assert abs(d.max().item() - g[tag + "_iwe_max"]) < 1e-12
+    assert abs(d[h // 2, w // 2].item() - g[tag + "_iwe_center"]) < 1e-12
+    np.testing.assert_allclose(d[::13, ::17].numpy(), g[tag + "_iwe_stride"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(d.sum(1).numpy(), g[tag + "_iwe_rowsum"], rtol=1e-12)
+    assert abs(L.item() - g[tag + "_var_loss"]) < 1e-12
+    assert abs(torch.linalg.norm(f.grad).item() - g[tag + "_var_dflow_l2"]) < 1e-12
+    np.testing.assert_allclose(f.grad[:, ::13, ::17].numpy(), g[tag + "_var_dflow_stride"], rtol=1e-9, atol=1e-18)
+    f2 = fl.clone().requires_grad_(True)
+    L2 = O.gradient_magnitude(O.iwe_dense(ev, f2, (h, w)))
+    L2.backward()
+    assert abs(L2.item() - g[tag + "_gm_loss"]) < 1e-12
+    assert abs(torch.linalg.norm(f2.grad).item() - g[tag + "_gm_dflow_l2"]) < 1e-12
+    th = torch.tensor([3.0, -2.0], dtype=torch.float64, requires_grad=True)
+    L3 = O.image_variance(O.iwe_2dof(ev, th, (h, w)))
+    L3.backward()
+    assert abs(L3.item() - g[tag + "_2dof_var_loss"]) < 1e-12
+    np.testing.assert_allclose(th.grad.numpy(), g[tag + "_2dof_var_dtheta"], rtol=1e-9)
+    pol = O.polarity_numpy(ev.numpy(), (h, w))
+    np.testing.assert_allclose([pol[0].sum(), pol[1].sum()], g[tag + "_polarity_sums"], rtol=1e-12)
+
+
+def test_survey_published_numbers(golden_mid):
+    """The numbers quoted in SURVEY.md section 4 item 3 are what the reference produced."""
+    g = golden_mid
+    assert abs(g["g3_260x346_100000_iwe_sum"] - 99110.632902628) < 1e-6
+    assert abs(-g["g3_260x346_100000_var_loss"] - 0.679484502033) < 1e-10
+    assert abs(-g["g3_720x1280_1000000_var_loss"] - 0.524632147290) < 1e-10
+    assert abs(-g["g3_720x1280_1000000_gm_loss"] - 0.259054529385) < 1e-10
+    np.testing.assert_allclose(g["g3_260x346_100000_2dof_var_dtheta"], [-0.12365863093285404, 0.12793875413104716], rtol=1e-9)
+
+
+# ---------------------------------------------------------------- analytic pins (A16, blur)
+def test_upsample_patch_flow_analytic():
+    img, patch, slide = (720, 1280), (24, 32), (24, 32)
+    assert O.patch_grid_shape(img, patch, slide) == (30, 40)
+    const = torch.ones(2, 30, 40, dtype=torch.float64) * torch.tensor([1.5, -2.0], dtype=torch.float64)[:, None, None]
+    d = O.upsample_patch_flow(const, img, patch, slide)
+    assert d.shape == (2, 720, 1280)
+    assert torch.allclose(d[0], torch.full((720, 1280), 1.5, dtype=torch.float64))
+    # linear ramp over patch centres is reproduced exactly in the interior
+    cy = (torch.arange(40, dtype=torch.float64) * 32 + 16)
+    ramp = cy[None, None, :].expand(2, 30, 40).contiguous()
+    d = O.upsample_patch_flow(ramp, img, patch, slide)
+    cols = torch.arange(1280, dtype=torch.float64) + 0.5
+    assert torch.allclose(d[0, 100, 64:1216], cols[64:1216], atol=1e-9)
+
+
+def test_gaussian_blur3_analytic():
+    x = torch.zeros(5, 5, dtype=torch.float64)
+    x[2, 2] = 1.0
+    y = O.gaussian_blur3_torch(x, 1.0)
+    k = np.exp(-0.5 * np.array([-1.0, 0.0, 1.0]) ** 2)
+    k /= k.sum()
+    np.testing.assert_allclose(y[1:4, 1:4].numpy(), np.outer(k, k), atol=1e-15)
+    assert abs(y.sum().item() - 1.0) < 1e-14
