@@ -1,0 +1,156 @@
+"""ctypes binding of libebos_hip.so (the C ABI declared in include/ebos_hip.h).
+
+There is deliberately NO CPU fallback anywhere in this package: if the shared library or a GPU is
+missing, every compute entry point raises ``HipUnavailableError`` -- loudly, at the call site.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libebos_hip.so")
+
+# ebos_status / enums of include/ebos_hip.h
+EBOS_OK = 0
+REF_FIRST, REF_LAST, REF_FRACTION, REF_TIMEBASE = 0, 1, 2, 3
+SPLAT_BILINEAR, SPLAT_COUNT, SPLAT_POLARITY = 0, 1, 2
+GAUSS_REFLECT_SCIPY, GAUSS_REFLECT_TORCH = 0, 1
+ABI_VERSION = 1
+
+
+class HipUnavailableError(RuntimeError):
+    """The HIP extension (or a GPU to run it on) is missing.  Nothing falls back to the CPU."""
+
+
+_P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes).  Mirrors include/ebos_hip.h one to one (tests/test_abi.py checks it).
+_WARP = [_P, _P, _P, _I, _D, _I, _L, _L, _I, _I, _I, _P, _P, _P]
+_WARP_BWD = [_P, _P, _I, _D, _I, _P, _L, _L, _I, _I, _I, _P, _P]
+_W2 = [_P, _P, _P, _I, _D, _I, _P, _L, _P, _P]
+_W2_BWD = [_P, _P, _I, _D, _I, _P, _P, _L, _P, _P]
+_SPLAT = [_P, _P, _D, _I, _D, _L, _L, _I, _I, _I, _I, _P, _P]
+_SPLAT_BWD = [_P, _P, _D, _D, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P]
+_SOA = [_P, _P, _I, _D, _I, _L, _P, _P, _P, _P, _P]
+_VAR = [_P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]
+_VAR_GRAD = [_P, _I, _I, _I, _I, _P, _P, _P, _P]
+_GM = [_P, _I, _I, _I, _I, _P, _P, _Z, _P]
+_GM_GRAD = [_P, _I, _I, _I, _I, _P, _P, _P]
+_GAUSS = [_P, _P, _L, _L, _L, _P, _I, _I, _P]
+SIGNATURES = {
+    "ebos_version": (_I, []),
+    "ebos_last_error": (C.c_char_p, []),
+    "ebos_build_info": (C.c_char_p, []),
+    "ebos_time_range_f32": (_I, [_P, _L, _L, _P, _P]),
+    "ebos_time_range_f64": (_I, [_P, _L, _L, _P, _P]),
+    "ebos_warp_dense_f32": (_I, _WARP),
+    "ebos_warp_dense_f64": (_I, _WARP),
+    "ebos_warp_dense_bwd_f32": (_I, _WARP_BWD),
+    "ebos_warp_dense_bwd_f64": (_I, _WARP_BWD),
+    "ebos_warp_2dof_f32": (_I, _W2),
+    "ebos_warp_2dof_f64": (_I, _W2),
+    "ebos_warp_2dof_bwd_f32": (_I, _W2_BWD),
+    "ebos_warp_2dof_bwd_f64": (_I, _W2_BWD),
+    "ebos_splat_f32": (_I, _SPLAT),
+    "ebos_splat_f64": (_I, _SPLAT),
+    "ebos_splat_bwd_f32": (_I, _SPLAT_BWD),
+    "ebos_splat_bwd_f64": (_I, _SPLAT_BWD),
+    "ebos_events_to_soa_f32": (_I, _SOA),
+    "ebos_events_to_soa_f64": (_I, _SOA),
+    "ebos_bin_scratch_bytes": (_Z, [_L]),
+    "ebos_bin_events_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ebos_iwe_dense_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "ebos_iwe_dense_tiled_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "ebos_tiled_config": (_I, [C.POINTER(C.c_int), _I]),
+    "ebos_iwe_dense_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
+    "ebos_iwe_2dof_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "ebos_iwe_2dof_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "ebos_cost_scratch_bytes": (_Z, [_I]),
+    "ebos_image_variance_f32": (_I, _VAR),
+    "ebos_image_variance_f64": (_I, _VAR),
+    "ebos_image_variance_grad_f32": (_I, _VAR_GRAD),
+    "ebos_image_variance_grad_f64": (_I, _VAR_GRAD),
+    "ebos_image_variance_affine_f32": (_I, [_P, _P, _I, _P, _P]),
+    "ebos_gradient_magnitude_f32": (_I, _GM),
+    "ebos_gradient_magnitude_f64": (_I, _GM),
+    "ebos_gradient_magnitude_grad_f32": (_I, _GM_GRAD),
+    "ebos_gradient_magnitude_grad_f64": (_I, _GM_GRAD),
+    "ebos_upsample_patch_flow_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "ebos_upsample_patch_flow_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "ebos_gauss1d_f32": (_I, _GAUSS),
+    "ebos_gauss1d_f64": (_I, _GAUSS),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libebos_hip.so (no GPU needed for loading) and attach the prototypes."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("EBOS_HIP_LIBRARY", LIB_PATH)
+    if not os.path.exists(p):
+        raise HipUnavailableError(
+            f"libebos_hip.so not found at {p}. Build it with `python -m event_based_bos_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:
+        raise HipUnavailableError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipUnavailableError(f"{p} does not export {name}; rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ebos_version() != ABI_VERSION:
+        raise HipUnavailableError(f"{p}: ABI version {lib.ebos_version()} != expected {ABI_VERSION}; rebuild")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def require_gpu() -> C.CDLL:
+    """Library + a visible GPU, or HipUnavailableError."""
+    lib = load_library()
+    if not torch.cuda.is_available():
+        raise HipUnavailableError(
+            "no GPU visible to PyTorch-ROCm: event_based_bos_amd runs its warp/IWE/cost path on an MI355X "
+            "through libebos_hip.so only; there is no CPU fallback.")
+    return lib
+
+
+def stream_ptr(device: Optional[torch.device] = None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def check(rc: int, what: str) -> None:
+    if rc != EBOS_OK:
+        msg = load_library().ebos_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed with ebos_status {rc}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def suffix(dtype: torch.dtype) -> str:
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise TypeError(f"event_based_bos_amd kernels exist for float32 and float64 tensors, got {dtype}")
+
+
+def tiled_configs():
+    lib = load_library()
+    n = lib.ebos_tiled_config(None, 0)
+    buf = (C.c_int * (3 * n))()
+    lib.ebos_tiled_config(buf, n)
+    return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]

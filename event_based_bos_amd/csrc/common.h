@@ -1,0 +1,136 @@
+// common.h -- shared helpers for the gfx950 kernels of libebos_hip.so (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "ebos_hip.h"
+
+namespace ebos {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+void set_error(const char* fmt, ...);
+
+#define EBOS_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      ::ebos::set_error(__VA_ARGS__);           \
+      return EBOS_ERR_INVALID_ARG;              \
+    }                                           \
+  } while (0)
+
+#define EBOS_CHECK_LAUNCH(what)                                                   \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      ::ebos::set_error("%s: %s", what, hipGetErrorString(e__));                  \
+      return EBOS_ERR_LAUNCH;                                                     \
+    }                                                                             \
+  } while (0)
+
+inline hipStream_t as_stream(ebos_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// grid size for a grid-stride streaming kernel: enough workgroups to fill 256 CUs x 8, no more
+inline int stream_grid(int64_t items, int block, int max_blocks = 256 * 8) {
+  int64_t g = (items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return static_cast<int>(g);
+}
+
+// ---- wavefront reductions (64 lanes) -------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;  // valid in lane 0
+}
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    T o = __shfl_down(v, off, kWave);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    T o = __shfl_down(v, off, kWave);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// block-wide sum through LDS; result valid in thread 0.  `red` holds >= blockDim.x / 64 items.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+  v = wave_sum(v);
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  const int nw = (blockDim.x + kWave - 1) / kWave;
+  T r = (threadIdx.x < nw) ? red[threadIdx.x] : T(0);
+  if (wid == 0) r = wave_sum(r);
+  __syncthreads();
+  return r;
+}
+
+// hardware float atomics (no CAS loop): global_atomic_add_f32 / _f64, ds_add_f32 / _f64
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// reference time + period exactly as src/warp.py:245-253,283-287 evaluates them in element type T
+template <typename T>
+struct TimeBase {
+  T ref;     // t_ref
+  T period;  // max(dt) - min(dt) = (tmax - ref) - (tmin - ref), each rounded in T
+};
+template <typename T>
+__device__ __forceinline__ TimeBase<T> time_base(const T* tminmax, int ref_mode, double ref_fraction) {
+#pragma clang fp contract(off)
+  const T tmin = tminmax[0], tmax = tminmax[1];
+  TimeBase<T> tb;
+  if (ref_mode == EBOS_REF_TIMEBASE) {  // caller supplies (t_ref, period)
+    tb.ref = tmin;
+    tb.period = tmax;
+    return tb;
+  }
+  if (ref_mode == EBOS_REF_FIRST) {
+    tb.ref = tmin;
+  } else if (ref_mode == EBOS_REF_LAST) {
+    tb.ref = tmax;
+  } else {
+    const T per = tmax - tmin;                       // src/warp.py:246
+    tb.ref = tmin + per * static_cast<T>(ref_fraction);  // :247  (python float * tensor -> T)
+  }
+  tb.period = (tmax - tb.ref) - (tmin - tb.ref);     // :286 on dt = t - ref
+  return tb;
+}
+
+// Bilinear footprint of one warped event in the padded image.
+template <typename T>
+struct Footprint {
+  int R, C;     // top-left tap in padded image coordinates
+  T fr, fc;     // fractional offsets (may be slightly negative: floor(x + eps))
+  bool finite;  // false: NaN/Inf/astronomically large coordinate -> no tap is in the image
+};
+template <typename T>
+__device__ __forceinline__ Footprint<T> footprint(T xw, T yw, T eps, int pad_h, int pad_w) {
+  Footprint<T> f;
+  const T r0 = floor(xw + eps);
+  const T c0 = floor(yw + eps);
+  f.fr = xw - r0;
+  f.fc = yw - c0;
+  const T lim = T(1 << 30);
+  f.finite = (r0 > -lim) && (r0 < lim) && (c0 > -lim) && (c0 < lim);
+  f.R = f.finite ? static_cast<int>(r0) + pad_h : -4;
+  f.C = f.finite ? static_cast<int>(c0) + pad_w : -4;
+  return f;
+}
+
+}  // namespace ebos

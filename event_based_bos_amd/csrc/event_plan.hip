@@ -1,0 +1,230 @@
+// event_plan.hip -- builds the device-resident, iteration-invariant form of one event window.
+//
+// (x, y, t, p) of every event are constant across solver iterations / flow hypotheses; only the
+// motion changes.  So the window is converted ONCE to struct-of-arrays f32
+// (x, y, dt, p) with dt evaluated in fp64 (src/warp.py:264-288 semantics), and counting-sorted by
+// source pixel, tile-major, so that the fused kernels of iwe_fused.hip see
+//   - coalesced SoA loads,
+//   - all events of one image tile contiguous (LDS-privatised IWE tile per workgroup),
+//   - all events of one source pixel contiguous (flow reads broadcast; the backward pass
+//     pre-reduces d_flow across the wavefront and issues one atomic per pixel run).
+#include "common.h"
+
+namespace ebos {
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+events_to_soa_kernel(const T* __restrict__ events, const T* __restrict__ tminmax, int ref_mode, double ref_fraction,
+                     int normalize_t, int64_t n, float* __restrict__ x, float* __restrict__ y, float* __restrict__ dt,
+                     float* __restrict__ p) {
+  // reference time and period in fp64 (the f32 API path keeps the reference's own rounding;
+  // the plan is allowed to be closer to the fp64 reference)
+  const double tmin = (double)tminmax[0], tmax = (double)tminmax[1];
+  double ref;
+  if (ref_mode == EBOS_REF_FIRST) ref = tmin;
+  else if (ref_mode == EBOS_REF_LAST) ref = tmax;
+  else ref = tmin + (tmax - tmin) * ref_fraction;
+  double inv_period = normalize_t ? 1.0 / (tmax - tmin) : 1.0;
+  if (ref_mode == EBOS_REF_TIMEBASE) {  // (t_ref, period) given
+    ref = tmin;
+    inv_period = normalize_t ? 1.0 / tmax : 1.0;
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const T ex = events[4 * i], ey = events[4 * i + 1], et = events[4 * i + 2], ep = events[4 * i + 3];
+    x[i] = (float)ex;
+    y[i] = (float)ey;
+    dt[i] = (float)(((double)et - ref) * inv_period);
+    p[i] = (float)ep;
+  }
+}
+
+__device__ __forceinline__ int source_key(float x, float y, int H, int W, int tile_h, int tile_w, int tiles_x) {
+  if (!(x > -1e9f && x < 1e9f && y > -1e9f && y < 1e9f)) return -1;
+  const int r = (int)x, c = (int)y;  // truncation toward zero, src/warp.py:334
+  if (r < 0 || r >= H || c < 0 || c >= W) return -1;  // (-1, 0) truncates to pixel 0 like .long()
+  const int ty = r / tile_h, tx = c / tile_w;
+  return (ty * tiles_x + tx) * (tile_h * tile_w) + (r - ty * tile_h) * tile_w + (c - tx * tile_w);
+}
+
+__global__ void __launch_bounds__(256)
+bin_hist_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t n, int H, int W, int tile_h,
+                int tile_w, int tiles_x, int32_t* hist, int32_t* oob_count) {
+  int bad = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int key = source_key(x[i], y[i], H, W, tile_h, tile_w, tiles_x);
+    if (key >= 0) atomicAdd(&hist[key], 1);
+    else ++bad;
+  }
+  if (oob_count != nullptr && bad) atomicAdd(oob_count, bad);
+}
+
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 16;
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+// exclusive scan of one 4096-item tile in place; tile total -> block_sums[blockIdx.x]
+__global__ void __launch_bounds__(kScanBlock) scan_tiles_kernel(int32_t* data, int64_t n, int32_t* block_sums) {
+  __shared__ int32_t s_wave[kScanBlock / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int32_t v[kScanItems];
+  int32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? data[base + k] : 0;
+    sum += v[k];
+  }
+  // inclusive scan of per-thread sums across the wave, then across the 4 waves
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  int32_t inc = sum;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int32_t o = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += o;
+  }
+  if (lane == kWave - 1) s_wave[wid] = inc;
+  __syncthreads();
+  int32_t wave_off = 0;
+  for (int k = 0; k < wid; ++k) wave_off += s_wave[k];
+  int32_t run = wave_off + inc - sum;  // exclusive prefix of this thread
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) data[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == kScanBlock - 1) block_sums[blockIdx.x] = run;
+}
+
+// single workgroup: exclusive scan of the tile totals, grand total -> *total_out
+__global__ void __launch_bounds__(kScanBlock) scan_block_sums_kernel(int32_t* block_sums, int nblk, int32_t* total_out) {
+  __shared__ int32_t s_wave[kScanBlock / kWave];
+  __shared__ int32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  for (int start = 0; start < nblk; start += kScanBlock) {
+    const int i = start + threadIdx.x;
+    const int32_t v = (i < nblk) ? block_sums[i] : 0;
+    int32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int32_t o = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += o;
+    }
+    if (lane == kWave - 1) s_wave[wid] = inc;
+    __syncthreads();
+    int32_t wave_off = 0;
+    for (int k = 0; k < wid; ++k) wave_off += s_wave[k];
+    const int32_t carry = s_carry;
+    if (i < nblk) block_sums[i] = carry + wave_off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == kScanBlock - 1) s_carry = carry + wave_off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+__global__ void __launch_bounds__(kScanBlock) scan_add_offsets_kernel(int32_t* data, int64_t n, const int32_t* block_sums) {
+  const int32_t off = block_sums[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  for (int k = threadIdx.x; k < kScanTile; k += kScanBlock)
+    if (base + k < n) data[base + k] += off;
+}
+
+__global__ void __launch_bounds__(256)
+bin_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dt,
+                   const float* __restrict__ p, int64_t n, int H, int W, int tile_h, int tile_w, int tiles_x,
+                   const int32_t* __restrict__ key_offsets, int32_t* cursor, float* __restrict__ xs,
+                   float* __restrict__ ys, float* __restrict__ dts, float* __restrict__ ps, int32_t* __restrict__ perm) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float ex = x[i], ey = y[i];
+    const int key = source_key(ex, ey, H, W, tile_h, tile_w, tiles_x);
+    if (key < 0) continue;
+    const int32_t pos = key_offsets[key] + atomicAdd(&cursor[key], 1);
+    xs[pos] = ex;
+    ys[pos] = ey;
+    dts[pos] = dt[i];
+    if (ps != nullptr) ps[pos] = p ? p[i] : 0.f;
+    if (perm != nullptr) perm[pos] = (int32_t)i;
+  }
+}
+
+template <typename T>
+int events_to_soa_impl(const T* events, const T* tminmax, int ref_mode, double ref_fraction, int normalize_t,
+                       int64_t n, float* x, float* y, float* dt, float* p, ebos_stream_t stream) {
+  EBOS_REQUIRE(tminmax != nullptr, "ebos_events_to_soa: tminmax is NULL");
+  EBOS_REQUIRE((events && x && y && dt && p) || n == 0, "ebos_events_to_soa: NULL buffer");
+  EBOS_REQUIRE(ref_mode >= 0 && ref_mode <= 3 && n >= 0, "ebos_events_to_soa: bad ref_mode/n");
+  if (n == 0) return EBOS_OK;
+  events_to_soa_kernel<T><<<dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream)>>>(
+      events, tminmax, ref_mode, ref_fraction, normalize_t, n, x, y, dt, p);
+  EBOS_CHECK_LAUNCH("ebos_events_to_soa");
+  return EBOS_OK;
+}
+
+inline int64_t scan_blocks(int64_t n_keys) { return (n_keys + kScanTile - 1) / kScanTile; }
+
+}  // namespace
+}  // namespace ebos
+
+extern "C" {
+
+int ebos_events_to_soa_f32(const float* events, const float* tminmax, int ref_mode, double ref_fraction,
+                           int normalize_t, int64_t n, float* x, float* y, float* dt, float* p,
+                           ebos_stream_t stream) {
+  return ebos::events_to_soa_impl<float>(events, tminmax, ref_mode, ref_fraction, normalize_t, n, x, y, dt, p, stream);
+}
+int ebos_events_to_soa_f64(const double* events, const double* tminmax, int ref_mode, double ref_fraction,
+                           int normalize_t, int64_t n, float* x, float* y, float* dt, float* p,
+                           ebos_stream_t stream) {
+  return ebos::events_to_soa_impl<double>(events, tminmax, ref_mode, ref_fraction, normalize_t, n, x, y, dt, p, stream);
+}
+
+size_t ebos_bin_scratch_bytes(int64_t n_keys) {
+  if (n_keys < 0) return 0;
+  // cursor[n_keys] + block_sums[scan_blocks], int32 each, 256-byte aligned sections
+  const size_t a = ((size_t)n_keys * 4 + 255) & ~(size_t)255;
+  const size_t b = ((size_t)ebos::scan_blocks(n_keys) * 4 + 255) & ~(size_t)255;
+  return a + b + 256;
+}
+
+int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const float* p, int64_t n, int H, int W,
+                        int tile_h, int tile_w, float* xs, float* ys, float* dts, float* ps, int32_t* perm,
+                        int32_t* key_offsets, int32_t* oob_count, void* scratch, size_t scratch_bytes,
+                        ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && n >= 0 && n < (int64_t)1 << 31,
+               "ebos_bin_events: bad sizes n=%lld H=%d W=%d tile=%dx%d", (long long)n, H, W, tile_h, tile_w);
+  EBOS_REQUIRE(key_offsets && scratch, "ebos_bin_events: NULL key_offsets/scratch");
+  EBOS_REQUIRE((x && y && dt && xs && ys && dts) || n == 0, "ebos_bin_events: NULL event buffer");
+  const int tiles_y = (H + tile_h - 1) / tile_h, tiles_x = (W + tile_w - 1) / tile_w;
+  const int64_t n_keys = (int64_t)tiles_y * tiles_x * tile_h * tile_w;
+  if (scratch_bytes < ebos_bin_scratch_bytes(n_keys)) {
+    set_error("ebos_bin_events: scratch too small (%zu < %zu)", scratch_bytes, ebos_bin_scratch_bytes(n_keys));
+    return EBOS_ERR_SCRATCH;
+  }
+  hipStream_t s = as_stream(stream);
+  int32_t* cursor = reinterpret_cast<int32_t*>(scratch);
+  const size_t a = ((size_t)n_keys * 4 + 255) & ~(size_t)255;
+  int32_t* block_sums = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + a);
+  const int nblk = (int)scan_blocks(n_keys);
+
+  if (hipMemsetAsync(key_offsets, 0, (size_t)(n_keys + 1) * 4, s) != hipSuccess ||
+      hipMemsetAsync(cursor, 0, (size_t)n_keys * 4, s) != hipSuccess) {
+    set_error("ebos_bin_events: hipMemsetAsync failed");
+    return EBOS_ERR_LAUNCH;
+  }
+  if (n > 0)
+    bin_hist_kernel<<<dim3(stream_grid(n, 256)), dim3(256), 0, s>>>(x, y, n, H, W, tile_h, tile_w, tiles_x, key_offsets,
+                                                                   oob_count);
+  scan_tiles_kernel<<<dim3(nblk), dim3(kScanBlock), 0, s>>>(key_offsets, n_keys, block_sums);
+  scan_block_sums_kernel<<<dim3(1), dim3(kScanBlock), 0, s>>>(block_sums, nblk, key_offsets + n_keys);
+  scan_add_offsets_kernel<<<dim3(nblk), dim3(kScanBlock), 0, s>>>(key_offsets, n_keys, block_sums);
+  if (n > 0)
+    bin_scatter_kernel<<<dim3(stream_grid(n, 256)), dim3(256), 0, s>>>(x, y, dt, p, n, H, W, tile_h, tile_w, tiles_x,
+                                                                      key_offsets, cursor, xs, ys, dts, ps, perm);
+  EBOS_CHECK_LAUNCH("ebos_bin_events");
+  return EBOS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+"""EventPlan: the device-resident, iteration-invariant form of one event window, and the fused
+warp+IWE operators that run on it.
+
+In a contrast-maximisation loop the events of a window never change -- only the
+flow / motion hypothesis does.  The plan is therefore built once per window:
+
+  AoS [n,4] (f32|f64)  --ebos_events_to_soa-->  SoA f32 (x, y, dt, p), dt evaluated in fp64
+                       --ebos_bin_events---->  counting-sorted by source pixel, tile-major
+                                               (+ key_offsets per source pixel, perm back to input order)
+
+and every objective evaluation afterwards is one fused kernel over 12-16 B/event
+(``iwe_dense`` / ``iwe_2dof``), its backward, and a cost kernel over the 3.7 MB image.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import _hip, ops
+from ._hip import check, ptr, stream_ptr
+
+DEFAULT_TILE = (64, 64)
+DEFAULT_HALO = 32
+
+
+def parse_direction(direction: Union[str, float]) -> Tuple[int, float]:
+    """Reference-time mode of src/warp.py:245-262 -> (ebos_reftime_mode, fraction)."""
+    import numpy as np
+
+    if type(direction) is float:
+        return _hip.REF_FRACTION, direction
+    if direction == "first":
+        return _hip.REF_FIRST, 0.0
+    if direction == "middle":
+        return _hip.REF_FRACTION, 0.5
+    if direction == "last":
+        return _hip.REF_LAST, 1.0
+    if direction == "random":
+        return _hip.REF_FRACTION, float(np.random.uniform(low=0.0, high=1.0))
+    if direction == "before":
+        return _hip.REF_FRACTION, -1.0
+    if direction == "after":
+        return _hip.REF_FRACTION, 2.0
+    raise ValueError(f"direction argument should be first, middle, last. Or float. {direction}")
+
+
+@dataclass
+class EventPlan:
+    """SoA f32 event window on one GPU (optionally binned by source tile)."""
+
+    x: torch.Tensor
+    y: torch.Tensor
+    dt: torch.Tensor
+    p: torch.Tensor
+    image_size: Tuple[int, int]           # (H, W) of the sensor / flow field
+    n: int                                # events in the plan (out-of-image sources dropped when binned)
+    n_input: int                          # events handed to build()
+    tile: Optional[Tuple[int, int]] = None
+    key_offsets: Optional[torch.Tensor] = None   # int32 [n_keys + 1]
+    perm: Optional[torch.Tensor] = None          # int32 [n]: input index of each planned event
+    n_dropped: int = 0
+
+    @property
+    def binned(self) -> bool:
+        return self.key_offsets is not None
+
+    @property
+    def device(self) -> torch.device:
+        return self.x.device
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def build(events: torch.Tensor, image_size: Tuple[int, int], direction: Union[str, float] = "first",
+              normalize_t: bool = True, tile: Optional[Tuple[int, int]] = DEFAULT_TILE) -> "EventPlan":
+        """events: [n, 4] (x=row, y=col, t, p), float32 or float64, on the GPU.
+
+        ``tile=None`` keeps the input (time) order: only the general global-atomic kernels apply."""
+        lib = _hip.require_gpu()
+        if events.dim() != 2 or events.shape[-1] != 4:
+            raise ValueError(f"EventPlan.build expects un-batched events [n,4], got {tuple(events.shape)}")
+        if not events.is_cuda:
+            raise _hip.HipUnavailableError("EventPlan.build: events must be on the GPU")
+        events = events.contiguous()
+        H, W = int(image_size[0]), int(image_size[1])
+        n = events.shape[0]
+        ref_mode, frac = parse_direction(direction)
+        dev = events.device
+        tmm = ops.time_range(events[None])
+        x, y, dt, p = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+        with torch.cuda.device(dev):
+            fn = getattr(lib, "ebos_events_to_soa_" + _hip.suffix(events.dtype))
+            check(fn(ptr(events), ptr(tmm), ref_mode, frac, int(normalize_t), n, ptr(x), ptr(y), ptr(dt), ptr(p),
+                     stream_ptr()), "ebos_events_to_soa")
+        plan = EventPlan(x, y, dt, p, (H, W), n, n)
+        if tile is not None:
+            plan = plan.bin(tile)
+        return plan
+
+    def bin(self, tile: Tuple[int, int] = DEFAULT_TILE) -> "EventPlan":
+        """Counting-sort the plan by source pixel, tile-major (ebos_bin_events_f32)."""
+        lib = _hip.require_gpu()
+        H, W = self.image_size
+        th, tw = int(tile[0]), int(tile[1])
+        tiles_y, tiles_x = (H + th - 1) // th, (W + tw - 1) // tw
+        n_keys = tiles_y * tiles_x * th * tw
+        dev = self.device
+        n = self.n
+        xs, ys, dts, ps = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        key_offsets = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
+        oob = torch.zeros(1, dtype=torch.int32, device=dev)
+        nbytes = int(lib.ebos_bin_scratch_bytes(n_keys))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.ebos_bin_events_f32(ptr(self.x), ptr(self.y), ptr(self.dt), ptr(self.p), n, H, W, th, tw,
+                                          ptr(xs), ptr(ys), ptr(dts), ptr(ps), ptr(perm), ptr(key_offsets), ptr(oob),
+                                          ptr(scratch), nbytes, stream_ptr()), "ebos_bin_events")
+        dropped = int(oob.item())  # one-off sync at plan-build time
+        kept = n - dropped
+        src_perm = perm[:kept] if self.perm is None else self.perm[perm[:kept].long()]
+        return EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
+                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped)
+
+    # ------------------------------------------------------------------------------------------
+    def iwe_dense(self, flow: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
+                  halo: Optional[int] = DEFAULT_HALO, splits: int = 1) -> torch.Tensor:
+        """Fused dense-flow warp + bilinear IWE: flow [2, H, W] -> iwe [H + 2 pad_h, W + 2 pad_w].
+        ``halo=None`` (or an un-binned plan) selects the general global-atomic kernel."""
+        return _FusedIweDense.apply(flow, weight, self, (int(pad[0]), int(pad[1])), halo, int(splits))
+
+    def iwe_2dof(self, thetas: torch.Tensor, pad: Tuple[int, int] = (0, 0),
+                 weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Fused 2-DoF warp + bilinear IWE for K hypotheses: thetas [K, 2] -> iwes [K, h, w]."""
+        return _FusedIwe2Dof.apply(thetas, weight, self, (int(pad[0]), int(pad[1])))
+
+    def contrast_dense(self, flow: torch.Tensor, cost: str = "image_variance", omit_boundary: bool = False,
+                       pad: Tuple[int, int] = (0, 0), halo: Optional[int] = DEFAULT_HALO,
+                       splits: int = 1) -> torch.Tensor:
+        """Contrast of the IWE under ``flow`` (0-d tensor, raw contrast: callers apply the sign).
+        Same value and gradient as ``cost(iwe_dense(flow))``, but the variance gradient is folded
+        into the backward event kernel (no d_iwe image)."""
+        if cost == "image_variance":
+            return _FusedVarianceDense.apply(flow, self, (int(pad[0]), int(pad[1])), bool(omit_boundary), halo,
+                                             int(splits))
+        iwe = self.iwe_dense(flow, pad=pad, halo=halo, splits=splits)
+        if cost == "gradient_magnitude":
+            return ops.gradient_magnitude(iwe, omit_boundary)
+        raise KeyError(f"unknown contrast cost {cost!r}")
+
+
+# ----------------------------------------------------------------------------------------------
+def _check_flow(plan: EventPlan, flow: torch.Tensor) -> torch.Tensor:
+    H, W = plan.image_size
+    if tuple(flow.shape) != (2, H, W):
+        raise ValueError(f"flow must be [2, {H}, {W}], got {tuple(flow.shape)}")
+    if flow.device != plan.device:
+        raise _hip.HipUnavailableError(f"flow is on {flow.device}, the event plan on {plan.device}")
+    return flow.to(torch.float32).contiguous()
+
+
+def _launch_iwe_dense(plan: EventPlan, flow32: torch.Tensor, weight, pad, halo, splits) -> torch.Tensor:
+    lib = _hip.require_gpu()
+    H, W = plan.image_size
+    iwe = torch.zeros((H + 2 * pad[0], W + 2 * pad[1]), dtype=torch.float32, device=plan.device)
+    with torch.cuda.device(plan.device):
+        if plan.binned and halo is not None:
+            check(lib.ebos_iwe_dense_tiled_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), ptr(plan.key_offsets),
+                                               plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), splits,
+                                               pad[0], pad[1], ptr(iwe), stream_ptr()), "ebos_iwe_dense_tiled")
+        else:
+            check(lib.ebos_iwe_dense_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), plan.n, ptr(flow32), H, W,
+                                         W, pad[0], pad[1], ptr(iwe), stream_ptr()), "ebos_iwe_dense")
+    return iwe
+
+
+def _plan_weight(plan: EventPlan, weight: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Per-event weights are given in INPUT order; reorder them like the events."""
+    if weight is None:
+        return None
+    w = weight.to(device=plan.device, dtype=torch.float32).reshape(-1)
+    if w.numel() != plan.n_input:
+        raise ValueError(f"weight must have one entry per input event ({plan.n_input}), got {w.numel()}")
+    return (w if plan.perm is None else w[plan.perm.long()]).contiguous()
+
+
+def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_dweight):
+    lib = _hip.require_gpu()
+    H, W = plan.image_size
+    d_flow = torch.zeros((2, H, W), dtype=torch.float32, device=plan.device)
+    d_w = torch.empty(plan.n, dtype=torch.float32, device=plan.device) if want_dweight else None
+    with torch.cuda.device(plan.device):
+        check(lib.ebos_iwe_dense_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), plan.n, ptr(flow32), H, W,
+                                         W, pad[0], pad[1], ptr(g_image), ptr(affine), g_lo, int(plan.binned),
+                                         ptr(d_flow), ptr(d_w), stream_ptr()), "ebos_iwe_dense_bwd")
+    return d_flow, d_w
+
+
+def _unpermute(plan: EventPlan, d_w: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros(plan.n_input, dtype=d_w.dtype, device=d_w.device)
+    if plan.perm is None:
+        out.copy_(d_w)
+    else:
+        out[plan.perm.long()] = d_w
+    return out
+
+
+class _FusedIweDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow, weight, plan, pad, halo, splits):
+        flow32 = _check_flow(plan, flow)
+        wp = _plan_weight(plan, weight)
+        iwe = _launch_iwe_dense(plan, flow32, wp, pad, halo, splits)
+        ctx.save_for_backward(flow32, wp if wp is not None else torch.empty(0))
+        ctx.meta = (plan, pad, flow.dtype, weight.dtype if weight is not None else None)
+        return iwe if flow.dtype == torch.float32 else iwe.to(flow.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        flow32, wp = ctx.saved_tensors
+        plan, pad, fdt, wdt = ctx.meta
+        wp = wp if wdt is not None else None
+        need_w = wdt is not None and ctx.needs_input_grad[1]
+        d_flow, d_w = _launch_dense_bwd(plan, flow32, wp, pad, g.to(torch.float32).contiguous(), None, 0, need_w)
+        d_weight = _unpermute(plan, d_w).to(wdt) if need_w else None
+        return (d_flow.to(fdt) if ctx.needs_input_grad[0] else None), d_weight, None, None, None, None
+
+
+class _FusedVarianceDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow, plan, pad, omit, halo, splits):
+        lib = _hip.require_gpu()
+        flow32 = _check_flow(plan, flow)
+        iwe = _launch_iwe_dense(plan, flow32, None, pad, halo, splits)
+        h, w = iwe.shape
+        out = torch.empty(1, dtype=torch.float32, device=plan.device)
+        moments = torch.empty((1, 2), dtype=torch.float64, device=plan.device)
+        nbytes = int(lib.ebos_cost_scratch_bytes(1))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
+        with torch.cuda.device(plan.device):
+            check(lib.ebos_image_variance_f32(ptr(iwe), 1, h, w, int(omit), ptr(out), ptr(moments), ptr(scratch), nbytes,
+                                              stream_ptr()), "ebos_image_variance")
+        ctx.save_for_backward(flow32, iwe, moments)
+        ctx.meta = (plan, pad, int(omit), flow.dtype)
+        return out[0].to(flow.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _hip.require_gpu()
+        flow32, iwe, moments = ctx.saved_tensors
+        plan, pad, omit, fdt = ctx.meta
+        up = g.to(torch.float32).reshape(1).contiguous()
+        affine = torch.empty(2, dtype=torch.float32, device=plan.device)
+        with torch.cuda.device(plan.device):
+            check(lib.ebos_image_variance_affine_f32(ptr(moments), ptr(up), 1, ptr(affine), stream_ptr()),
+                  "ebos_image_variance_affine")
+        d_flow, _ = _launch_dense_bwd(plan, flow32, None, pad, iwe, affine, omit, False)
+        return d_flow.to(fdt), None, None, None, None, None
+
+
+class _FusedIwe2Dof(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, thetas, weight, plan, pad):
+        lib = _hip.require_gpu()
+        if thetas.dim() != 2 or thetas.shape[1] != 2:
+            raise ValueError(f"thetas must be [K, 2], got {tuple(thetas.shape)}")
+        th32 = thetas.to(device=plan.device, dtype=torch.float32).contiguous()
+        wp = _plan_weight(plan, weight)
+        K = th32.shape[0]
+        H, W = plan.image_size
+        h, w = H + 2 * pad[0], W + 2 * pad[1]
+        iwes = torch.zeros((K, h, w), dtype=torch.float32, device=plan.device)
+        with torch.cuda.device(plan.device):
+            check(lib.ebos_iwe_2dof_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), plan.n, ptr(th32), K, h, w,
+                                        pad[0], pad[1], ptr(iwes), stream_ptr()), "ebos_iwe_2dof")
+        ctx.save_for_backward(th32, wp if wp is not None else torch.empty(0))
+        ctx.meta = (plan, pad, thetas.dtype, thetas.device, weight is not None)
+        return iwes if thetas.dtype == torch.float32 else iwes.to(thetas.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _hip.require_gpu()
+        th32, wp = ctx.saved_tensors
+        plan, pad, tdt, tdev, has_w = ctx.meta
+        K = th32.shape[0]
+        H, W = plan.image_size
+        h, w = H + 2 * pad[0], W + 2 * pad[1]
+        g32 = g.to(torch.float32).contiguous()
+        d_th = torch.zeros((K, 2), dtype=torch.float32, device=plan.device)
+        with torch.cuda.device(plan.device):
+            check(lib.ebos_iwe_2dof_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp) if has_w else None, plan.n,
+                                            ptr(th32), K, h, w, pad[0], pad[1], ptr(g32), None, 0, ptr(d_th),
+                                            stream_ptr()), "ebos_iwe_2dof_bwd")
+        return d_th.to(device=tdev, dtype=tdt), None, None, None

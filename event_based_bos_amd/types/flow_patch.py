@@ -1,0 +1,47 @@
+"""FlowPatch: one cell of the patch-flow grid (reference: src/types/flow_patch.py:9-91).
+
+Field names, derived bounds and the dict-style access are the reference's; the patch grid itself
+(``prepare_patch``, src/solver/patch_eklt.py:70-95) lives in ``event_based_bos_amd.solver``.
+"""
+import copy
+import math
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+
+@dataclass
+class FlowPatch:
+    x: float            # centre, height (row) coordinate
+    y: float            # centre, width (column) coordinate
+    shape: tuple        # (height, width) of the patch
+    u: float = 0.0      # flow, height component
+    v: float = 0.0      # flow, width component
+
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+    # size
+    h = property(lambda self: self.shape[0])
+    w = property(lambda self: self.shape[1])
+    # bounds: ceil on the low side, floor on the high side (src/types/flow_patch.py:33-47)
+    x_min = property(lambda self: int(self.x - math.ceil(self.shape[0] / 2)))
+    x_max = property(lambda self: int(self.x + math.floor(self.shape[0] / 2)))
+    y_min = property(lambda self: int(self.y - math.ceil(self.shape[1] / 2)))
+    y_max = property(lambda self: int(self.y + math.floor(self.shape[1] / 2)))
+    xmin = property(lambda self: self.x_min)
+    xmax = property(lambda self: self.x_max)
+    ymin = property(lambda self: self.y_min)
+    ymax = property(lambda self: self.y_max)
+    position = property(lambda self: np.array([self.x, self.y]))
+    flow = property(lambda self: np.array([self.u, self.v]))
+
+    def update_flow(self, u: float, v: float) -> None:
+        self.u, self.v = u, v
+
+    def new_ones(self) -> np.ndarray:
+        return np.ones(self.shape)
+
+    def copy(self) -> Any:
+        return copy.deepcopy(self)

@@ -1,0 +1,299 @@
+/*
+ * ebos_hip.h -- C ABI of libebos_hip.so: the MI355X (gfx950) implementation of the
+ * contrast-maximisation inner loop of event-based BOS
+ *        warp events -> bilinear-splat image of warped events (IWE) -> contrast cost (+ gradients)
+ *
+ * The reference (tub-rip/event_based_bos) is pure Python and has no FFI for this path; its
+ * boundary is the plugin surface Warp / EventImageConverter / costs.  Every
+ * entry point below names the reference code (file:line under /root/reference) that it replaces.
+ * The Python host package event_based_bos_amd binds these symbols with ctypes
+ * (INTEGRATION.md shows the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer unless it says "host";
+ *  - nothing is allocated, freed or synchronised in here: the caller owns every buffer (torch's
+ *    caching allocator in practice) and every call is asynchronous on `stream` (a hipStream_t
+ *    passed as void*; NULL = the default stream).  All entry points are graph-capturable;
+ *  - return value: EBOS_OK (0) or a negative ebos_status; ebos_last_error() gives the message
+ *    (thread-local, valid until the next failing call on that thread);
+ *  - event = (x, y, t, p) with x = ROW coordinate and y = COLUMN coordinate
+ *    (src/data_loader/ccs.py:293-296); images are [H, W] row-major; flow is [2, H, W] with
+ *    channel 0 = row displacement (src/warp.py:333-336);
+ *  - suffix _f32 / _f64 = element type of events, flow and images.  The *_soa_* hot path is f32.
+ *  - "accumulates": the kernel ADDS into the output; the caller zeroes it (hipMemsetAsync).
+ */
+#ifndef EBOS_HIP_H
+#define EBOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EBOS_ABI_VERSION 1
+
+typedef void* ebos_stream_t; /* hipStream_t */
+
+typedef enum ebos_status {
+  EBOS_OK = 0,
+  EBOS_ERR_INVALID_ARG = -1, /* null pointer, negative size, unsupported enum value       */
+  EBOS_ERR_LAUNCH = -2,      /* hipLaunchKernel / hipMemsetAsync reported an error          */
+  EBOS_ERR_UNSUPPORTED = -3, /* valid request this build has no kernel for                  */
+  EBOS_ERR_SCRATCH = -4      /* caller-provided scratch buffer too small                    */
+} ebos_status;
+
+/* reference-time modes, src/warp.py:245-259 */
+typedef enum ebos_reftime_mode {
+  EBOS_REF_FIRST = 0,    /* t_ref = min t                                     (:248-249) */
+  EBOS_REF_LAST = 1,     /* t_ref = max t                                     (:252-253) */
+  EBOS_REF_FRACTION = 2, /* t_ref = tmin + (tmax - tmin) * fraction  (float/middle/before/after/random, :245-247) */
+  EBOS_REF_TIMEBASE = 3  /* the `tminmax` argument holds (t_ref, period) itself instead of (min t, max t):
+                            explicit reference_time / time_period of warp_event_from_optical_flow and
+                            warp_event_2dof_xy (:292-293, 344-349) */
+} ebos_reftime_mode;
+
+/* image accumulation methods, src/event_image_converter.py:351-367 */
+typedef enum ebos_splat_mode {
+  EBOS_SPLAT_BILINEAR = 0, /* bilinear_vote_*  (:503-620)                                  */
+  EBOS_SPLAT_COUNT = 1,    /* count_event_*    (:407-501): +1 on every in-bounds neighbour */
+  EBOS_SPLAT_POLARITY = 2  /* "polarity" (:355-363): image is [b,2,h,w]; channel 0 <- p > 0 */
+} ebos_splat_mode;
+
+int ebos_version(void);               /* EBOS_ABI_VERSION of the loaded library */
+const char* ebos_last_error(void);    /* host string                            */
+const char* ebos_build_info(void);    /* host string: arch, compiler, options   */
+
+/* ------------------------------------------------------------------------------------------
+ * A2  time range of an event batch.  Replaces nt_min/nt_max over events[..., 2]
+ *     (src/warp.py:245-253, 283-287; src/types/__init__.py:21-47).
+ *     events [b, n, 4] AoS; out tminmax [b, 2] = (min t, max t) per batch row.
+ * ---------------------------------------------------------------------------------------- */
+int ebos_time_range_f32(const float* events, int64_t b, int64_t n, float* tminmax, ebos_stream_t stream);
+int ebos_time_range_f64(const double* events, int64_t b, int64_t n, double* tminmax, ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A3  Warp.warp_event(..., "dense-flow")  (src/warp.py:193-228 -> :292-342, torch branch :330-342).
+ *     dt = t - t_ref; if normalize_t: dt /= (max dt - min dt)            (:283-287)
+ *     i  = trunc(x) * row_stride + trunc(y)                              (:334)
+ *     x' = x - dt * flow[0][i];  y' = y - dt * flow[1][i];  t' = dt;  p' = p   (:335-337)
+ *     Arithmetic is done in the element type with the reference's operation order and without
+ *     FMA contraction, so the result is bit-identical to the reference on the same dtype.
+ *     events/warped [b, n, 4]; flow [b, 2, H, W]; tminmax [b, 2] from ebos_time_range_*.
+ *     row_stride = Warp.image_size[1].  An event whose source index falls outside [0, H*W)
+ *     (torch.gather would raise) passes through un-displaced and increments *oob_count
+ *     (device int32, nullable).
+ * ---------------------------------------------------------------------------------------- */
+int ebos_warp_dense_f32(const float* events, const float* flow, const float* tminmax, int ref_mode,
+                        double ref_fraction, int normalize_t, int64_t b, int64_t n, int H, int W,
+                        int row_stride, float* warped, int32_t* oob_count, ebos_stream_t stream);
+int ebos_warp_dense_f64(const double* events, const double* flow, const double* tminmax, int ref_mode,
+                        double ref_fraction, int normalize_t, int64_t b, int64_t n, int H, int W,
+                        int row_stride, double* warped, int32_t* oob_count, ebos_stream_t stream);
+
+/* autograd of A3 w.r.t. the flow: d_flow[c][i] += -dt * d_warped[..., c]
+ * (accumulates; d_flow [b, 2, H, W]; d_warped [b, n, 4], columns 2,3 ignored). */
+int ebos_warp_dense_bwd_f32(const float* events, const float* tminmax, int ref_mode, double ref_fraction,
+                            int normalize_t, const float* d_warped, int64_t b, int64_t n, int H, int W,
+                            int row_stride, float* d_flow, ebos_stream_t stream);
+int ebos_warp_dense_bwd_f64(const double* events, const double* tminmax, int ref_mode, double ref_fraction,
+                            int normalize_t, const double* d_warped, int64_t b, int64_t n, int H, int W,
+                            int row_stride, double* d_flow, ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A4  Warp.warp_event(..., "2d-translation" | "rigid-optical-flow")  (src/warp.py:344-383).
+ *     x' = x + dt * theta[0]; y' = y + dt * theta[1]  (note the + sign, :368-375).  Un-batched.
+ *     theta: device [2].  time_period: device [1] or NULL (then max dt - min dt, :285-286).
+ *     bwd: d_theta[c] += sum_n dt * d_warped[n][c]  (accumulates, device [2]).
+ * ---------------------------------------------------------------------------------------- */
+int ebos_warp_2dof_f32(const float* events, const float* theta, const float* tminmax, int ref_mode,
+                       double ref_fraction, int normalize_t, const float* time_period, int64_t n,
+                       float* warped, ebos_stream_t stream);
+int ebos_warp_2dof_f64(const double* events, const double* theta, const double* tminmax, int ref_mode,
+                       double ref_fraction, int normalize_t, const double* time_period, int64_t n,
+                       double* warped, ebos_stream_t stream);
+int ebos_warp_2dof_bwd_f32(const float* events, const float* tminmax, int ref_mode, double ref_fraction,
+                           int normalize_t, const float* time_period, const float* d_warped, int64_t n,
+                           float* d_theta, ebos_stream_t stream);
+int ebos_warp_2dof_bwd_f64(const double* events, const double* tminmax, int ref_mode, double ref_fraction,
+                           int normalize_t, const double* time_period, const double* d_warped, int64_t n,
+                           double* d_theta, ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A7/A8/A10  EventImageConverter.bilinear_vote_tensor/_numpy, count_event_*, "polarity"
+ *     (src/event_image_converter.py:407-620, 355-363).
+ *     r0 = floor(x + eps), c0 = floor(y + eps); fr = x - r0, fc = y - c0;  R = r0 + pad_h, C = c0 + pad_w
+ *     (R,C) += (1-fr)(1-fc) w; (R+1,C) += fr (1-fc) w; (R,C+1) += (1-fr) fc w; (R+1,C+1) += fr fc w
+ *     each only when inside the [h, w] image (h, w = PADDED size, :34).  eps = 1e-6 for tensors
+ *     (:586), 1e-8 for numpy arrays (:528).  Out-of-image taps are skipped (the reference adds 0
+ *     to pixel 0, :617-618: identical for finite inputs).
+ *     events [b, n, 4]; weight: device [b, n] or NULL (then weight_scalar, :576-577,611-614);
+ *     image [b, h, w] ([b, 2, h, w] for EBOS_SPLAT_POLARITY).  Accumulates.
+ * ---------------------------------------------------------------------------------------- */
+int ebos_splat_f32(const float* events, const float* weight, double weight_scalar, int mode, double eps,
+                   int64_t b, int64_t n, int h, int w, int pad_h, int pad_w, float* image,
+                   ebos_stream_t stream);
+int ebos_splat_f64(const double* events, const double* weight, double weight_scalar, int mode, double eps,
+                   int64_t b, int64_t n, int h, int w, int pad_h, int pad_w, double* image,
+                   ebos_stream_t stream);
+
+/* autograd of the bilinear splat, G = d_image [b, h, w]:
+ *   d_events[..., 0] = w [(1-fc)(G[R+1,C]-G[R,C]) + fc (G[R+1,C+1]-G[R,C+1])]
+ *   d_events[..., 1] = w [(1-fr)(G[R,C+1]-G[R,C]) + fr (G[R+1,C+1]-G[R+1,C])]   (columns 2,3 = 0)
+ *   d_weight[n]      = sum_taps tap_weight * G[tap]
+ * d_events [b, n, 4] and d_weight [b, n] are overwritten; either may be NULL. */
+int ebos_splat_bwd_f32(const float* events, const float* weight, double weight_scalar, double eps,
+                       const float* d_image, int64_t b, int64_t n, int h, int w, int pad_h, int pad_w,
+                       float* d_events, float* d_weight, ebos_stream_t stream);
+int ebos_splat_bwd_f64(const double* events, const double* weight, double weight_scalar, double eps,
+                       const double* d_image, int64_t b, int64_t n, int h, int w, int pad_h, int pad_w,
+                       double* d_events, double* d_weight, ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Event plan: the device-resident, iteration-invariant form of one event window used by the
+ * fused hot path.  (x, y, t, p) of every event are constant across solver iterations and flow
+ * hypotheses: only the motion changes, so this is built once per window.
+ *
+ * ebos_events_to_soa_*: AoS [n,4] -> SoA f32 (x, y, dt, p).  dt follows src/warp.py:264-288
+ * but is evaluated in fp64 and rounded once to f32 (absolute timestamps of ~10 s do not
+ * survive f32).
+ * ---------------------------------------------------------------------------------------- */
+int ebos_events_to_soa_f32(const float* events, const float* tminmax, int ref_mode, double ref_fraction,
+                           int normalize_t, int64_t n, float* x, float* y, float* dt, float* p,
+                           ebos_stream_t stream);
+int ebos_events_to_soa_f64(const double* events, const double* tminmax, int ref_mode, double ref_fraction,
+                           int normalize_t, int64_t n, float* x, float* y, float* dt, float* p,
+                           ebos_stream_t stream);
+
+/* Source-tile binning (counting sort by source pixel, tile-major).  The image [H, W] is cut into
+ * tiles of tile_h x tile_w pixels; key(event) = tile_id * tile_h*tile_w + pixel-in-tile of
+ * (trunc(x), trunc(y)).  Events are reordered by key; events of one tile, and of one source
+ * pixel, become contiguous (coalesced flow reads forward, segmented reduction backward).
+ *   n_keys = tiles_y * tiles_x * tile_h * tile_w,  tiles_y = ceil(H / tile_h), tiles_x = ceil(W / tile_w)
+ *   key_offsets [n_keys + 1] (int32, out): exclusive prefix sum of the per-key counts;
+ *       tile t owns sorted positions [key_offsets[t * tile_h*tile_w], key_offsets[(t+1) * tile_h*tile_w])
+ *   perm [n] (int32, out): original index of the event at each sorted position
+ *   scratch: >= ebos_bin_scratch_bytes(n_keys) bytes
+ *   oob_count (device int32, nullable): events whose source pixel is outside the image; they are
+ *       dropped from the plan (torch.gather would raise for them, src/warp.py:334-336).
+ * The order of events inside one source pixel is not deterministic (atomic cursor). */
+size_t ebos_bin_scratch_bytes(int64_t n_keys);
+int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const float* p, int64_t n,
+                        int H, int W, int tile_h, int tile_w, float* xs, float* ys, float* dts, float* ps,
+                        int32_t* perm, int32_t* key_offsets, int32_t* oob_count, void* scratch,
+                        size_t scratch_bytes, ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused hot path, dense flow: A3 + A7 in one pass, nothing materialised
+ *   (src/warp.py:330-342 + src/event_image_converter.py:581-620), eps = 1e-6.
+ *   x, y, dt, weight(nullable): SoA f32 [n];  flow [2, H, W];  iwe [h, w] with h = H + 2 pad_h ...
+ *   Accumulates into iwe.
+ * ebos_iwe_dense_f32        any event order; one global float atomic per tap.
+ * ebos_iwe_dense_tiled_f32  binned events (ebos_bin_events_f32 with the same tile_h/tile_w):
+ *   one workgroup per (tile, split) accumulates into an LDS image of the tile plus `halo` pixels
+ *   on every side and flushes it once; taps beyond the halo fall back to global atomics, so the
+ *   result is correct for any flow magnitude.  halo must be one of the built values
+ *   (ebos_tiled_config lists them).  splits >= 1 workgroups share one tile's events.
+ * ---------------------------------------------------------------------------------------- */
+int ebos_iwe_dense_f32(const float* x, const float* y, const float* dt, const float* weight, int64_t n,
+                       const float* flow, int H, int W, int row_stride, int pad_h, int pad_w, float* iwe,
+                       ebos_stream_t stream);
+int ebos_iwe_dense_tiled_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
+                             int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w,
+                             float* iwe, ebos_stream_t stream);
+/* number of supported (tile_h, tile_w, halo) triples; fills up to `cap` triples into out[3*i..] (host) */
+int ebos_tiled_config(int* out, int cap);
+
+/* backward of the fused dense path: G = a * g_image + c (g_image [h, w]; pass a = 1, c = 0 for a plain
+ * upstream gradient; the variance cost folds its gradient 2 (IWE - mean)/(M-1) into (a, c) read from
+ * the device array affine[2] so that no d_iwe image is materialised; affine may be NULL).
+ *   d_flow[c][i] += -dt * dL/d(x',y')   with dL/dx', dL/dy' as in ebos_splat_bwd_*.
+ * sorted != 0 promises that events sharing a source pixel are contiguous (binned plan): contributions
+ * are pre-reduced across the wavefront with shuffles and one atomic per run is issued.
+ * g_lo/g_hi: rows/cols [g_lo, h - g_lo) x [g_lo, w - g_lo) of g_image are valid, G = 0 elsewhere
+ * (omit_boundary of the costs: g_lo = 1).  Accumulates into d_flow [2, H, W]. */
+int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, const float* weight, int64_t n,
+                           const float* flow, int H, int W, int row_stride, int pad_h, int pad_w,
+                           const float* g_image, const float* affine, int g_lo, int sorted, float* d_flow,
+                           float* d_weight, ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused hot path, 2-DoF hypotheses (solver outer loop, SURVEY.md 3.4 / BASELINE config 5):
+ *   A4 + A7 for K translations theta[k] = (theta0, theta1) in one pass over the events
+ *   (src/warp.py:364-383 + src/event_image_converter.py:581-620).  iwes [K, h, w] accumulates.
+ *   bwd: d_theta[k][c] += sum_n dt * dL/d(x',y') for upstream images g [K, h, w].
+ * ---------------------------------------------------------------------------------------- */
+int ebos_iwe_2dof_f32(const float* x, const float* y, const float* dt, const float* weight, int64_t n,
+                      const float* thetas, int K, int h, int w, int pad_h, int pad_w, float* iwes,
+                      ebos_stream_t stream);
+int ebos_iwe_2dof_bwd_f32(const float* x, const float* y, const float* dt, const float* weight, int64_t n,
+                          const float* thetas, int K, int h, int w, int pad_h, int pad_w,
+                          const float* g_images, const float* affine, int g_lo, float* d_thetas,
+                          ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A14  contrast costs on an image (absent from the release; defined in SURVEY.md A14 on the
+ *      reference's primitives torch.var and SobelTorch, src/utils/stat_utils.py:48-139;
+ *      dict keys "iwe"/"omit_boundary" per src/solver/base.py:337-339).
+ *   images [K, h, w]; omit_boundary crops one pixel on every side (iwe[..., 1:-1, 1:-1]).
+ *   variance:            out[k] = unbiased variance;  moments[k] = {mean, M} (f64, nullable)
+ *   gradient magnitude:  out[k] = mean(gx^2 + gy^2), (gx, gy) = Sobel3(replicate pad) / 8
+ *   *_grad: d_images[k] = upstream[k] * d(out[k]) / d(image[k])  (overwrites; upstream device [K], f32)
+ *   Sums are carried in f64.  scratch: >= ebos_cost_scratch_bytes(K) bytes.
+ * ---------------------------------------------------------------------------------------- */
+size_t ebos_cost_scratch_bytes(int K);
+int ebos_image_variance_f32(const float* images, int K, int h, int w, int omit_boundary, float* out,
+                            double* moments, void* scratch, size_t scratch_bytes, ebos_stream_t stream);
+int ebos_image_variance_grad_f32(const float* images, int K, int h, int w, int omit_boundary,
+                                 const double* moments, const float* upstream, float* d_images,
+                                 ebos_stream_t stream);
+/* (a, c) per image such that d(out)/d(image) * upstream = a * image + c inside the valid region:
+ * feeds ebos_iwe_*_bwd_f32's `affine` without materialising d_images.  affine [K, 2] f32. */
+int ebos_image_variance_affine_f32(const double* moments, const float* upstream, int K, float* affine,
+                                   ebos_stream_t stream);
+int ebos_gradient_magnitude_f32(const float* images, int K, int h, int w, int omit_boundary, float* out,
+                                void* scratch, size_t scratch_bytes, ebos_stream_t stream);
+int ebos_gradient_magnitude_grad_f32(const float* images, int K, int h, int w, int omit_boundary,
+                                     const float* upstream, float* d_images, ebos_stream_t stream);
+int ebos_image_variance_f64(const double* images, int K, int h, int w, int omit_boundary, double* out,
+                            double* moments, void* scratch, size_t scratch_bytes, ebos_stream_t stream);
+int ebos_image_variance_grad_f64(const double* images, int K, int h, int w, int omit_boundary,
+                                 const double* moments, const double* upstream, double* d_images,
+                                 ebos_stream_t stream);
+int ebos_gradient_magnitude_f64(const double* images, int K, int h, int w, int omit_boundary, double* out,
+                                void* scratch, size_t scratch_bytes, ebos_stream_t stream);
+int ebos_gradient_magnitude_grad_f64(const double* images, int K, int h, int w, int omit_boundary,
+                                     const double* upstream, double* d_images, ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A16  patch grid -> dense flow  (src/solver/patch_eklt.py:173-204): replicate-pad the grid by
+ *      pad = int(patch/2 // slide) + 1, bilinear resize (align_corners = False) by the sliding
+ *      window, centre-crop to [H, W].  grid [2, gh, gw] -> dense [2, H, W] (overwrites).
+ *      bwd: d_grid [2, gh, gw] += adjoint (accumulates).
+ * ---------------------------------------------------------------------------------------- */
+int ebos_upsample_patch_flow_f32(const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h,
+                                 int slide_w, int H, int W, float* dense, ebos_stream_t stream);
+int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w,
+                                     int slide_h, int slide_w, int H, int W, float* d_grid,
+                                     ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A9/K11  optional Gaussian blur of an event image (sigma > 0), one separable pass along one axis
+ *     of a tensor viewed as [outer, L, inner]; taps: device [2 radius + 1] doubles (host-computed).
+ *     boundary 0 = scipy 'reflect' (d c b a | a b c d): gaussian_filter(image, sigma) of the numpy
+ *                  branch, one pass per array axis  (src/event_image_converter.py:368-369);
+ *     boundary 1 = torch 'reflect' (d c b | a b c d): torchvision gaussian_blur(kernel_size=3) of the
+ *                  tensor branch, last two axes     (src/event_image_converter.py:399-404).
+ *     out must not alias in.
+ * ---------------------------------------------------------------------------------------- */
+int ebos_gauss1d_f32(const float* in, float* out, int64_t outer, int64_t L, int64_t inner, const double* taps,
+                     int radius, int boundary, ebos_stream_t stream);
+int ebos_gauss1d_f64(const double* in, double* out, int64_t outer, int64_t L, int64_t inner, const double* taps,
+                     int radius, int boundary, ebos_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBOS_HIP_H */

@@ -1,0 +1,100 @@
+"""CPU checks of the boundary: the C-ABI library builds, loads and exports every symbol include/ebos_hip.h
+declares; the ctypes table mirrors the header; the product fails loudly (no CPU fallback) without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ebos_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ebos_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from event_based_bos_amd import _hip
+    from event_based_bos_amd.build import build_library
+
+    build_library(verbose=False)
+    return _hip.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from event_based_bos_amd import _hip
+
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in ebos_hip.h but not exported"
+    assert sorted(_hip.SIGNATURES) == names, "ctypes table and header disagree"
+
+
+def test_argument_counts_match_header():
+    from event_based_bos_amd import _hip
+
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, args) in _hip.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), f"{name}: header has {n} parameters, ctypes table {len(args)}"
+
+
+def test_host_only_entry_points(lib):
+    from event_based_bos_amd import _hip
+
+    assert lib.ebos_version() == 1
+    assert b"gfx950" in lib.ebos_build_info()
+    cfgs = _hip.tiled_configs()
+    assert (64, 64, 32) in cfgs and all(len(c) == 3 for c in cfgs)
+    assert lib.ebos_bin_scratch_bytes(1000) >= 4000
+    assert lib.ebos_cost_scratch_bytes(4) >= 64
+    # argument validation happens before any HIP call: usable without a GPU
+    rc = lib.ebos_splat_f32(None, None, 1.0, 0, 1e-6, 1, 10, 4, 5, 0, 0, None, None)
+    assert rc == -1 and b"image is NULL" in lib.ebos_last_error()
+    rc = lib.ebos_iwe_dense_tiled_f32(None, None, None, None, None, 0, None, 4, 5, 64, 64, 32, 1, 0, 0, None, None)
+    assert rc == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    import event_based_bos_amd as ebos
+
+    ev = np.zeros((5, 4))
+    with pytest.raises(ebos.HipUnavailableError):
+        ebos.Warp((4, 5)).warp_event(ev, np.zeros((2, 4, 5)), "dense-flow")
+    with pytest.raises(ebos.HipUnavailableError):
+        ebos.EventImageConverter((4, 5)).create_iwe(ev)
+    with pytest.raises(ebos.HipUnavailableError):
+        ebos.costs.functions["image_variance"]().calculate({"iwe": torch.zeros(4, 5), "omit_boundary": False})
+    with pytest.raises(ebos.HipUnavailableError):
+        ebos.EventPlan.build(torch.zeros(5, 4), (4, 5))
+    # argument errors that the reference raises before computing anything still come first
+    with pytest.raises(ValueError):
+        ebos.Warp((4, 5)).warp_event(ev, np.zeros((2, 4, 5)), "dense-flow", direction=1)
+    with pytest.raises(ebos.MotionModelKeyError):
+        ebos.Warp((4, 5)).warp_event(ev, np.zeros((2, 4, 5)), "affine")
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from event_based_bos_amd import _hip
+
+    with pytest.raises(_hip.HipUnavailableError):
+        _hip.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "event_based_bos_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"

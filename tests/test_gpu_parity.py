@@ -1,0 +1,384 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via the plugin surface) against the CPU
+oracle on the same seeded inputs, and against the golden fixtures captured from the reference.
+
+Tolerances (stated per assertion):
+  * warped events: BIT-EXACT on equal dtype (elementwise, same op order, no FMA contraction)
+  * images, fp64 kernels: rel-L2 <= 1e-12 (float atomics reorder the sum)
+  * images, fp32 fused path vs the fp64 reference: rel-L2 < 1e-4 (north_star), typically ~1e-6
+  * costs: rel < 1e-5;  gradients (fp32 atomics): rel-L2 < 1e-3
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ebos_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+H, W = 24, 32
+DIRS = ["first", "middle", "last", 0.25, "before", "after"]
+
+
+@pytest.fixture(scope="module")
+def ebos():
+    import event_based_bos_amd as pkg
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    pkg.load_library()
+    return pkg
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def G(a, dtype=None):
+    t = torch.from_numpy(np.asarray(a)).to(dev())
+    return t if dtype is None else t.to(dtype)
+
+
+def rel(a, b):
+    return O.rel_l2(a, b)
+
+
+# ------------------------------------------------------------------------------ warp
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("d", DIRS)
+def test_warp_dense_bit_exact_vs_golden(ebos, golden_small, norm, d):
+    g = golden_small
+    ev, fl = g["g2_events"], g["g2_flow"]
+    wp = ebos.Warp((H, W), normalize_t=norm)
+    tag = f"g2_warp_dense_n{int(norm)}_{d}"
+    out_np, feat = wp.warp_event(ev, fl, "dense-flow", d)  # numpy in -> numpy out (staged through the GPU)
+    assert isinstance(out_np, np.ndarray) and out_np.dtype == np.float64
+    np.testing.assert_array_equal(out_np, g[tag + "_numpy"])
+    out_t, _ = wp.warp_event(G(ev), G(fl), "dense-flow", d)  # GPU tensors
+    assert out_t.is_cuda
+    np.testing.assert_array_equal(out_t.cpu().numpy(), g[tag + "_torch"])
+    assert set(feat) == {"determinant", "trace", "divergence", "straint", "absement"}
+    assert all(v["value"] is None for v in feat.values())
+
+
+def test_warp_misc_vs_golden(ebos, golden_small):
+    g = golden_small
+    ev, fl = g["g2_events"], g["g2_flow"]
+    th = np.array([3.0, -2.0])
+    for norm in (False, True):
+        wp = ebos.Warp((H, W), normalize_t=norm)
+        np.testing.assert_array_equal(wp.warp_event(ev, th, "2d-translation", "middle")[0],
+                                      g[f"g2_warp_2dof_n{int(norm)}_middle_numpy"])
+        np.testing.assert_array_equal(wp.warp_event(G(ev), G(th), "rigid-optical-flow", "first")[0].cpu().numpy(),
+                                      g[f"g2_warp_2dof_n{int(norm)}_first_torch"])
+    wp = ebos.Warp((H, W), normalize_t=True)
+    # float32 tensors: bit-exact with the reference's float32 run
+    out32 = wp.warp_event(G(ev).float(), G(fl).float(), "dense-flow", "first")[0]
+    assert out32.dtype == torch.float32
+    np.testing.assert_array_equal(out32.cpu().numpy(), g["g2_warp_dense_n1_first_torch_f32"])
+    # batched
+    eb, fb = g["g2_events_b"], g["g2_flow_b"]
+    np.testing.assert_array_equal(wp.warp_event(eb, fb, "dense-flow", "middle")[0], g["g2_warp_dense_b_n1_middle_numpy"])
+    np.testing.assert_array_equal(wp.warp_event(G(eb), G(fb), "dense-flow", "middle")[0].cpu().numpy(),
+                                  g["g2_warp_dense_b_n1_middle_torch"])
+    # CPU tensors are staged through the GPU and come back as CPU tensors
+    out_c = wp.warp_event(torch.from_numpy(eb), torch.from_numpy(fb), "dense-flow", "middle")[0]
+    assert not out_c.is_cuda
+    np.testing.assert_array_equal(out_c.numpy(), g["g2_warp_dense_b_n1_middle_torch"])
+
+
+def test_warp_micro_known_answers(ebos, golden_small):
+    g = golden_small
+    ev, fl = g["g1_warp_events"], g["g1_warp_flow"]
+    wp = ebos.Warp((4, 5))
+    for d in ["first", "middle", "last", "before", "after"]:
+        np.testing.assert_array_equal(wp.warp_event(ev, fl, "dense-flow", d)[0], g[f"g1_warp_dense_{d}_numpy"])
+    np.testing.assert_array_equal(wp.warp_event(ev, fl, "dense-flow", 0.25)[0], g["g1_warp_dense_f025_numpy"])
+    np.testing.assert_array_equal(wp.warp_event(ev, np.array([1.0, 2.0]), "2d-translation", "first")[0],
+                                  g["g1_warp_2dof_first_numpy"])
+    np.testing.assert_array_equal(wp.warp_event(g["g1_warp_frac_events"], g["g1_warp_frac_flow"], "dense-flow")[0],
+                                  g["g1_warp_frac_numpy"])
+    np.testing.assert_allclose(wp.get_flow_from_motion(np.array([1.0, 2.0]), "2d-translation"), g["g1_flow_from_motion"], atol=0)
+    assert wp.get_motion_vector_size("2d-translation") == 2
+    assert wp.motion_model_from_motion(np.array([1.0, 2.0]), "2d-translation") == {"trans_x": 1.0, "trans_y": 2.0}
+
+
+def test_warp_errors(ebos):
+    wp = ebos.Warp((4, 5))
+    ev = O.synth_events(10, 4, 5)
+    fl = np.zeros((2, 4, 5))
+    for bad in (1, np.float64(0.5), "sideways"):
+        with pytest.raises(ValueError):
+            wp.warp_event(ev, fl, "dense-flow", bad)
+    with pytest.raises(ebos.MotionModelKeyError):
+        wp.warp_event(ev, fl, "affine")
+    with pytest.raises(ebos.MotionModelKeyError):
+        wp.get_key_names("nope")
+    with pytest.raises(AssertionError):
+        wp.warp_event(ev, np.zeros(3), "2d-translation")
+    bad_ev = ev.copy()
+    bad_ev[3, 0] = 100.0  # source pixel outside the flow field: torch.gather raises in the reference
+    with pytest.raises(IndexError):
+        wp.warp_event(bad_ev, fl, "dense-flow")
+
+
+def test_reftime_and_dt(ebos, golden_small):
+    g = golden_small
+    ev = g["g2_events"]
+    wp = ebos.Warp((H, W), normalize_t=True)
+    for d in DIRS:
+        assert wp.calculate_reftime(ev, d) == O.reference_time(ev, d)
+        assert wp.calculate_reftime(G(ev), d).item() == O.reference_time(ev, d)
+    ref = O.reference_time(ev, "middle")
+    np.testing.assert_array_equal(wp.calculate_dt(ev, ref), O.delta_t(ev, ref, True))
+    eb = g["g2_events_b"]
+    np.testing.assert_array_equal(wp.calculate_reftime(eb, 0.25), O.reference_time(eb, 0.25))
+    out, _ = wp.warp_event_from_optical_flow(ev, g["g2_flow"], ref)
+    np.testing.assert_array_equal(out, g["g2_warp_dense_n1_middle_numpy"])
+
+
+# ------------------------------------------------------------------------------ images
+@pytest.mark.parametrize("pad", [0, 2])
+def test_iwe_vs_golden(ebos, golden_small, pad):
+    g = golden_small
+    warped, wgt = g["g2_warp_dense_n1_first_numpy"], g["g2_weight"]
+    ic = ebos.EventImageConverter((H, W), outer_padding=pad)
+    assert ic.image_size == (H + 2 * pad, W + 2 * pad)
+    tol = 1e-12
+    assert rel(ic.bilinear_vote_numpy(warped), g[f"g2_iwe_p{pad}_numpy"]) < tol
+    assert rel(ic.bilinear_vote_tensor(G(warped)).cpu().numpy(), g[f"g2_iwe_p{pad}_torch"]) < tol
+    assert rel(ic.bilinear_vote_numpy(warped, weight=wgt), g[f"g2_iwe_p{pad}_w_numpy"]) < tol
+    assert rel(ic.bilinear_vote_tensor(G(warped), weight=G(wgt)).cpu().numpy(), g[f"g2_iwe_p{pad}_w_torch"]) < tol
+    assert rel(ic.bilinear_vote_tensor(G(warped), weight=0.5).cpu().numpy(), g[f"g2_iwe_p{pad}_w05_torch"]) < tol
+    np.testing.assert_array_equal(ic.count_event_numpy(warped), g[f"g2_count_p{pad}_numpy"])
+    np.testing.assert_array_equal(ic.count_event_tensor(G(warped)).cpu().numpy(), g[f"g2_count_p{pad}_numpy"])
+    assert rel(ic.create_iwe(warped, method="polarity", sigma=0), g[f"g2_polarity_p{pad}_numpy"]) < tol
+    np.testing.assert_array_equal(ic.create_eventmask(warped), g[f"g2_mask_p{pad}_numpy"])
+
+
+def test_iwe_variants_vs_golden(ebos, golden_small):
+    g = golden_small
+    warped = g["g2_warp_dense_n1_first_numpy"]
+    ic = ebos.EventImageConverter((H, W))
+    out32 = ic.bilinear_vote_tensor(G(warped).float())
+    assert out32.dtype == torch.float32
+    assert rel(out32.cpu().numpy(), g["g2_iwe_f32_torch"]) < 1e-6
+    for s in (1, 3):
+        assert rel(ic.create_iwe(warped, method="bilinear_vote", sigma=s), g[f"g2_iwe_sigma{s}_numpy"]) < 1e-12
+    assert rel(ic.create_iwe(warped), g["g2_iwe_default_numpy"]) < 1e-12  # default sigma = 1 for numpy
+    assert rel(ic.create_iwe(G(warped), sigma=0).cpu().numpy(), g["g2_iwe_default_torch"]) < 1e-12
+    wb = g["g2_warp_dense_b_n1_middle_numpy"]
+    assert rel(ic.bilinear_vote_numpy(wb), g["g2_iwe_b_numpy"]) < 1e-12
+    assert rel(ic.bilinear_vote_tensor(G(wb)).cpu().numpy(), g["g2_iwe_b_torch"]) < 1e-12
+    with pytest.raises(NotImplementedError):
+        ic.create_iwe(warped, method="nope")
+    with pytest.raises(NotImplementedError):
+        ic.create_iwe(G(warped), method="nope")
+    with pytest.raises(RuntimeError):
+        ic.create_iwe([1, 2, 3])
+    # torch blur (3 taps, reflect) against the oracle's restatement
+    blurred = ic.create_image_from_events_tensor(G(warped), sigma=1)
+    expect = O.gaussian_blur3_torch(torch.from_numpy(g["g2_iwe_default_torch"]), 1.0)
+    assert rel(blurred.cpu().numpy(), expect.numpy()) < 1e-12
+
+
+def test_micro_vote_known_answer(ebos, golden_small):
+    g = golden_small
+    ev = g["g1_events"]
+    ic = ebos.EventImageConverter((4, 5))
+    np.testing.assert_allclose(ic.bilinear_vote_tensor(G(ev)).cpu().numpy(), g["g1_vote_torch"], atol=1e-15)
+    np.testing.assert_allclose(ic.bilinear_vote_numpy(ev), g["g1_vote_numpy"], atol=1e-15)
+    np.testing.assert_array_equal(ic.count_event_numpy(ev), g["g1_count_numpy"])
+    np.testing.assert_allclose(ic.bilinear_vote_numpy(ev, weight=np.arange(6.0)), g["g1_vote_weighted_numpy"], atol=1e-15)
+    ic2 = ebos.EventImageConverter((4, 5), outer_padding=2)
+    np.testing.assert_allclose(ic2.bilinear_vote_tensor(G(ev)).cpu().numpy(), g["g1_vote_pad2_torch"], atol=1e-15)
+    np.testing.assert_array_equal(ic.create_eventmask(G(ev)).cpu().numpy(), g["g1_mask_torch"])
+    # empty and single-event inputs
+    assert ic.bilinear_vote_numpy(np.zeros((0, 4))).sum() == 0
+    one = ic.bilinear_vote_numpy(np.array([[1.5, 2.5, 0, 1.0]]))
+    assert abs(one.sum() - 1.0) < 1e-15 and one[1, 2] == 0.25
+
+
+# ------------------------------------------------------------------------------ costs + autograd through the API path
+def _cost(ebos, name):
+    return ebos.costs.functions[name](direction="minimize")
+
+
+@pytest.mark.parametrize("cost", ["var", "gm"])
+@pytest.mark.parametrize("omit", [False, True])
+def test_api_path_costs_and_gradients_fp64(ebos, golden_small, cost, omit):
+    g = golden_small
+    tag = f"g2_{cost}_omit{int(omit)}"
+    name = {"var": "image_variance", "gm": "gradient_magnitude"}[cost]
+    wp, ic = ebos.Warp((H, W), normalize_t=True), ebos.EventImageConverter((H, W))
+    ev = G(g["g2_events"])
+    fl = G(g["g2_flow"]).requires_grad_(True)
+    wt = G(g["g2_weight"]).requires_grad_(True)
+    warped, _ = wp.warp_event(ev, fl, "dense-flow", "first")
+    iwe = ic.bilinear_vote_tensor(warped, weight=wt)
+    loss = _cost(ebos, name).calculate({"iwe": iwe, "omit_boundary": omit})
+    loss.backward()
+    assert abs(loss.item() - g[tag + "_loss"]) <= 1e-12 * abs(g[tag + "_loss"])
+    assert rel(fl.grad.cpu().numpy(), g[tag + "_dflow"]) < 1e-10
+    assert rel(wt.grad.cpu().numpy(), g[tag + "_dweight"]) < 1e-10
+    th = torch.tensor([3.0, -2.0], dtype=torch.float64, device=dev(), requires_grad=True)
+    w2, _ = wp.warp_event(ev, th, "2d-translation", "first")
+    loss2 = _cost(ebos, name).calculate({"iwe": ic.bilinear_vote_tensor(w2), "omit_boundary": omit})
+    loss2.backward()
+    assert abs(loss2.item() - g[tag + "_2dof_loss"]) <= 1e-12 * abs(g[tag + "_2dof_loss"])
+    np.testing.assert_allclose(th.grad.cpu().numpy(), g[tag + "_2dof_dtheta"], rtol=1e-9)
+    # the cost kernels in isolation: value and d(loss)/d(iwe)
+    x = G(g["g2_iwe_p0_torch"]).requires_grad_(True)
+    _cost(ebos, name).calculate({"iwe": x, "omit_boundary": omit}).backward()
+    assert rel(x.grad.cpu().numpy(), g[tag + "_diwe"]) < 1e-12
+    # numpy in -> python float out
+    v = _cost(ebos, name).calculate({"iwe": g["g2_iwe_p0_torch"], "omit_boundary": omit})
+    assert isinstance(v, float)
+
+
+def test_cost_plugin_surface(ebos, golden_small):
+    g = golden_small
+    c = ebos.costs
+    assert sorted(c.functions) == ["diff_norm", "flow_norm", "flow_norm_pxy", "gradient_magnitude", "image_gradient",
+                                   "image_variance"]
+    with pytest.raises(ValueError):
+        c.functions["image_variance"](direction="sideways")
+    cost = c.functions["image_variance"](direction="maximize", store_history=True)
+    with pytest.raises(KeyError):
+        cost.calculate({"iwe": G(g["g2_iwe_p0_torch"])})
+    v = cost.calculate({"iwe": G(g["g2_iwe_p0_torch"]), "omit_boundary": False})
+    assert v.item() > 0 and cost.get_history()["loss"] == [v.item()]
+    fl = G(g["g2_flow"])
+    wmap = G(g["g2_cost_weights"])
+    assert abs(c.functions["flow_norm"]().calculate({"flow": fl}).item() - g["g2_cost_flow_norm"]) < 1e-12
+    assert abs(c.functions["image_gradient"]().calculate({"flow": fl, "omit_boundary": False, "weights": wmap}).item()
+               - g["g2_cost_image_gradient"]) < 1e-12
+    dn = c.functions["diff_norm"]().calculate({"prediction": G(g["g2_iwe_p0_torch"]), "measurement": G(g["g2_iwe_p0_w_torch"]),
+                                               "weights": None})
+    assert abs(dn.item() - g["g2_cost_diff_norm"]) < 1e-10
+    hy = c.HybridCost("minimize", {"flow_norm": 0.5, "image_gradient": "inv"}, store_history=True)
+    v = hy.calculate({"flow": fl, "omit_boundary": False, "weights": wmap})
+    assert abs(v.item() - g["g2_cost_hybrid"]) < 1e-11
+    assert sorted(hy.get_history().keys()) == ["flow_norm", "image_gradient", "loss"]
+    hy2 = c.HybridCost("minimize", {"image_variance": 1.0, "flow_norm": 0.1})
+    assert set(hy2.required_keys) == {"iwe", "omit_boundary", "flow"}
+
+
+# ------------------------------------------------------------------------------ fused hot path (f32 SoA plan)
+def _oracle_objective(ev, fl, size, cost, omit=False, pad=(0, 0), weight=None):
+    f = torch.from_numpy(fl).clone().requires_grad_(True)
+    w = 1.0 if weight is None else torch.from_numpy(weight).clone().requires_grad_(True)
+    iwe = O.iwe_dense(torch.from_numpy(ev), f, size, pad=pad, weight=w)
+    L = O.image_variance(iwe, omit) if cost == "var" else O.gradient_magnitude(iwe, omit)
+    L.backward()
+    return iwe.detach().numpy(), L.item(), f.grad.numpy(), (None if weight is None else w.grad.numpy())
+
+
+@pytest.mark.parametrize("tile,halo", [((64, 64), 32), ((32, 64), 32), ((32, 32), 8), ((64, 64), None), (None, None)])
+def test_fused_dense_forward_backward(ebos, tile, halo):
+    h, w, n = 130, 173, 60_000
+    ev = O.synth_events(n, h, w, seed=3)
+    fl = O.synth_dense_flow(h, w, seed=4, max_val=12.0)  # exceeds halo 8: exercises the global-atomic fallback
+    iwe_ref, loss_ref, dflow_ref, _ = _oracle_objective(ev, fl, (h, w), "var")
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile=tile)
+    assert plan.n == n and plan.binned == (tile is not None)
+    flow = G(fl, torch.float32).requires_grad_(True)
+    iwe = plan.iwe_dense(flow, halo=halo)
+    loss = -ebos.ops.image_variance(iwe)
+    loss.backward()
+    assert rel(iwe.detach().cpu().numpy(), iwe_ref) < 1e-5  # bar: 1e-4
+    assert abs(loss.item() - loss_ref) < 1e-5 * abs(loss_ref)
+    assert rel(flow.grad.cpu().numpy(), dflow_ref) < 1e-3
+    # fused objective (variance gradient folded into the backward event kernel)
+    f2 = G(fl, torch.float32).requires_grad_(True)
+    l2 = -plan.contrast_dense(f2, "image_variance", halo=halo)
+    l2.backward()
+    assert abs(l2.item() - loss_ref) < 1e-5 * abs(loss_ref)
+    assert rel(f2.grad.cpu().numpy(), dflow_ref) < 1e-3
+
+
+@pytest.mark.parametrize("cost", ["var", "gm"])
+@pytest.mark.parametrize("omit", [False, True])
+def test_fused_dense_costs_padding_weights(ebos, cost, omit):
+    h, w, n = 64, 80, 20_000
+    ev = O.synth_events(n, h, w, seed=5)
+    ev[:, 0] += np.random.RandomState(6).uniform(0, 0.99, n) * (np.arange(n) % 2 == 0)
+    fl = O.synth_dense_flow(h, w, seed=7, max_val=6.0)
+    wgt = np.random.RandomState(8).uniform(0.2, 1.8, n)
+    pad = (3, 3)
+    iwe_ref, loss_ref, dflow_ref, dw_ref = _oracle_objective(ev, fl, (h, w), cost, omit, pad, wgt)
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile=(32, 32))
+    flow = G(fl, torch.float32).requires_grad_(True)
+    wt = G(wgt, torch.float32).requires_grad_(True)
+    iwe = plan.iwe_dense(flow, pad=pad, weight=wt, halo=16)
+    assert iwe.shape == (h + 6, w + 6)
+    fn = ebos.ops.image_variance if cost == "var" else ebos.ops.gradient_magnitude
+    loss = -fn(iwe, omit)
+    loss.backward()
+    assert rel(iwe.detach().cpu().numpy(), iwe_ref) < 1e-5
+    assert abs(loss.item() - loss_ref) < 1e-5 * abs(loss_ref)
+    assert rel(flow.grad.cpu().numpy(), dflow_ref) < 1e-3
+    assert rel(wt.grad.cpu().numpy(), dw_ref) < 1e-3
+
+
+def test_fused_2dof_hypotheses(ebos):
+    h, w, n = 100, 120, 50_000
+    ev = O.synth_events(n, h, w, seed=9)
+    thetas = np.array([[3.0, -2.0], [0.0, 0.0], [-7.5, 4.25], [12.0, 12.0]])
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile=None)
+    th = G(thetas, torch.float32).requires_grad_(True)
+    iwes = plan.iwe_2dof(th)
+    loss = -ebos.ops.image_variance(iwes)
+    loss.sum().backward()
+    for k in range(len(thetas)):
+        t = torch.tensor(thetas[k], dtype=torch.float64, requires_grad=True)
+        iwe_ref = O.iwe_2dof(torch.from_numpy(ev), t, (h, w))
+        L = O.image_variance(iwe_ref)
+        L.backward()
+        assert rel(iwes[k].detach().cpu().numpy(), iwe_ref.detach().numpy()) < 1e-5
+        assert abs(loss[k].item() - L.item()) < 1e-5 * abs(L.item())
+        np.testing.assert_allclose(th.grad[k].cpu().numpy(), t.grad.numpy(), rtol=2e-3, atol=1e-6)
+
+
+def test_plan_binning_properties(ebos):
+    h, w, n = 70, 90, 30_000
+    ev = O.synth_events(n, h, w, seed=11)
+    ev[5, 0] = -3.0   # source outside the image: dropped from a binned plan
+    ev[6, 1] = 1e9
+    plan = ebos.EventPlan.build(G(ev), (h, w), "middle", True, tile=(32, 32))
+    assert plan.n == n - 2 and plan.n_dropped == 2
+    perm = plan.perm.cpu().numpy()
+    assert len(np.unique(perm)) == plan.n and 5 not in perm and 6 not in perm
+    # sortedness: tile-major keys are non-decreasing
+    x, y = plan.x.cpu().numpy(), plan.y.cpu().numpy()
+    r, c = x.astype(np.int64), y.astype(np.int64)
+    tiles_x = (w + 31) // 32
+    key = ((r // 32) * tiles_x + c // 32) * 1024 + (r % 32) * 32 + (c % 32)
+    assert np.all(np.diff(key) >= 0)
+    ko = plan.key_offsets.cpu().numpy()
+    assert ko[0] == 0 and ko[-1] == plan.n and np.all(np.diff(ko) >= 0)
+    np.testing.assert_array_equal(np.bincount(key, minlength=len(ko) - 1), np.diff(ko))
+    # the permutation really maps planned events to input events; dt evaluated in fp64 then rounded
+    np.testing.assert_array_equal(x, ev[perm, 0].astype(np.float32))
+    dt_ref = O.delta_t(ev, O.reference_time(ev, "middle"), True)
+    np.testing.assert_array_equal(plan.dt.cpu().numpy(), dt_ref[perm].astype(np.float32))
+
+
+def test_upsample_patch_flow(ebos):
+    img, patch, slide = (720, 1280), (24, 32), (24, 32)
+    grid = np.random.RandomState(100).uniform(-30, 30, (2, 30, 40))
+    ref = O.upsample_patch_flow(torch.from_numpy(grid), img, patch, slide)
+    g = G(grid, torch.float32).requires_grad_(True)
+    dense = ebos.ops.upsample_patch_flow(g, patch, slide, img)
+    assert dense.shape == (2, 720, 1280)
+    assert rel(dense.detach().cpu().numpy(), ref.numpy()) < 1e-6
+    # adjoint against torch autograd of the oracle
+    up = np.random.RandomState(101).uniform(-1, 1, (2, 720, 1280))
+    (dense * G(up, torch.float32)).sum().backward()
+    gr = torch.from_numpy(grid).clone().requires_grad_(True)
+    (O.upsample_patch_flow(gr, img, patch, slide) * torch.from_numpy(up)).sum().backward()
+    assert rel(g.grad.cpu().numpy(), gr.grad.numpy()) < 1e-5
+    # overlapping windows (patch 48x64, slide 24x32)
+    gh, gw = O.patch_grid_shape(img, (48, 64), slide)
+    grid2 = np.random.RandomState(102).uniform(-5, 5, (2, gh, gw))
+    ref2 = O.upsample_patch_flow(torch.from_numpy(grid2), img, (48, 64), slide)
+    d2 = ebos.ops.upsample_patch_flow(G(grid2, torch.float32), (48, 64), slide, img)
+    assert rel(d2.cpu().numpy(), ref2.numpy()) < 1e-6
