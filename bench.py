@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mevents/s through the fused warp + IWE (+ variance contrast) pass at 1280x720.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one window of 10 M synthetic events (recipe of
+src/utils/event_utils.py:40-47, seed = rank) at 1280x720, dense per-pixel flow U(-30, 30)
+(src/utils/flow_utils.py:29), normalised time, reference time "first", variance contrast.
+One "step" = one evaluation of the contrast objective on the resident window:
+    zero IWE -> fused warp + bilinear splat (ebos_iwe_dense_tiled_f32) -> image variance.
+The window is resident in HBM in its plan form (SoA f32, binned by source tile: built once per window
+and reused by every solver iteration; its one-off build time is reported as plan_build_ms and is NOT
+in the timed region).  With N > 1 every rank owns an independent window (weak scaling, no collective
+in the data path); timing is barrier + synchronize bracketed, max over ranks.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W = 720, 1280
+N_EVENTS = 10_000_000
+FLOW_MAX = 30.0
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def synth_window(n, seed):
+    rs = np.random.RandomState(seed)
+    x = rs.randint(0, H, n)
+    y = rs.randint(0, W, n)
+    t = np.sort(rs.uniform(0.0, 0.5, n))
+    p = rs.randint(0, 2, n)
+    ev = np.stack([x, y, t, p], axis=1).astype(np.float64)
+    flow = np.random.RandomState(1000 + seed).uniform(-FLOW_MAX, FLOW_MAX, (2, H, W))
+    return ev, flow
+
+
+def cpu_baseline(ev, flow, sample):
+    """The oracle's op-for-op torch-CPU restatement of the reference path (kind 'port'), timed on this
+    host's cores on a bounded sample of the same window."""
+    from oracle import ebos_oracle as O
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    out = {}
+    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        e = torch.from_numpy(ev[:sample]).to(dt)
+        f = torch.from_numpy(flow).to(dt)
+        times = []
+        for rep in range(4):
+            t0 = time.perf_counter()
+            iwe = O.iwe_dense(e, f, (H, W))
+            O.image_variance(iwe)
+            times.append(time.perf_counter() - t0)
+        out[name] = sample / statistics.median(times[1:]) / 1e6
+    return {"value": round(out["f64"], 3), "unit": "Mevents/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample} events of the window, fwd warp+IWE+variance, torch-CPU fp64 (reference default dtype), "
+                      f"median of 3 after 1 warm-up; fp32 on the same sample: {out['f32']:.2f} Mevents/s",
+            "value_f32": round(out["f32"], 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--events", type=int, default=N_EVENTS)
+    ap.add_argument("--tile", type=int, nargs=2, default=[64, 64])
+    ap.add_argument("--halo", type=int, default=32)
+    ap.add_argument("--splits", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if distributed else 0)
+
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd import _hip
+    from event_based_bos_amd.event_plan import _launch_iwe_dense
+
+    lib = _hip.require_gpu()
+    n = args.events
+    ev, flow_np = synth_window(n, seed=rank)
+    ev_gpu = torch.from_numpy(ev).to(dev)
+    flow = torch.from_numpy(flow_np).float().to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan = ebos.EventPlan.build(ev_gpu, (H, W), "first", True, tile=tuple(args.tile))
+    torch.cuda.synchronize()
+    plan_build_ms = (time.perf_counter() - t0) * 1e3
+    del ev_gpu
+
+    pad = (0, 0)
+    scratch_n = int(lib.ebos_cost_scratch_bytes(1))
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
+    scratch = torch.empty(scratch_n, dtype=torch.uint8, device=dev)
+    iwe = torch.zeros((H, W), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+
+    def step(ev_pair=None):
+        iwe.zero_()
+        if ev_pair is not None:
+            ev_pair[0].record()
+        _hip.check(lib.ebos_iwe_dense_tiled_f32(P(plan.x), P(plan.y), P(plan.dt), None, P(plan.key_offsets), plan.n,
+                                                P(flow), H, W, args.tile[0], args.tile[1], args.halo, args.splits,
+                                                0, 0, P(iwe), stream), "ebos_iwe_dense_tiled")
+        if ev_pair is not None:
+            ev_pair[1].record()
+        _hip.check(lib.ebos_image_variance_f32(P(iwe), 1, H, W, 0, P(out), P(moments), P(scratch), scratch_n, stream),
+                   "ebos_image_variance")
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(pairs[k])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = statistics.mean(a.elapsed_time(b) for a, b in pairs)
+    contrast = float(out.item())
+
+    # extra (untimed-by-contract) measurement: forward + backward of the objective
+    flow_g = flow.clone().requires_grad_(True)
+    for _ in range(2):
+        l = -plan.contrast_dense(flow_g, "image_variance", halo=args.halo, splits=args.splits)
+        l.backward()
+        flow_g.grad = None
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    reps = max(3, args.steps // 5)
+    for _ in range(reps):
+        l = -plan.contrast_dense(flow_g, "image_variance", halo=args.halo, splits=args.splits)
+        l.backward()
+        flow_g.grad = None
+    torch.cuda.synchronize()
+    fwdbwd_ms = (time.perf_counter() - t1) / reps * 1e3
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed / 1e6
+        algo_bytes = 12.0 * plan.n + 12.0 * H * W  # x, y, dt (p unused) + flow read (8 B/px) + IWE write (4 B/px)
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("iwe_dense_tiled_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mevents/sec warped+IWE at 1280x720", "value": round(value, 2), "unit": "Mevents/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
+                                   "variance cost, fwd objective (zero IWE + fused warp/splat + variance)",
+                       "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
+                       "layout": f"SoA f32 (x,y,dt), binned by source tile {args.tile[0]}x{args.tile[1]}, halo {args.halo}, "
+                                 f"splits {args.splits}", "parallelism": f"windows sharded, {world} rank(s), no collective"},
+            "roofline": {"bound": "hbm", "kernel": "iwe_dense_tiled_kernel", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes},
+            "plan_build_ms": round(plan_build_ms, 2), "fwd_bwd_ms": round(fwdbwd_ms, 4),
+            "fwd_bwd_mevents_per_s": round(n / fwdbwd_ms / 1e3, 2), "contrast": contrast,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ev, flow_np, min(args.cpu_sample, n))
+            line["speedup_vs_cpu_port_f64"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,15 +13,37 @@
 //                             (ds_add_f32), is accumulated there and flushed once with row-contiguous
 //                             global atomics (256 B per wave instruction, the shape the memory-side
 //                             atomic unit wants).  Taps beyond the halo go straight to global atomics,
-//                             so any flow magnitude stays correct.  Coordinates are taken relative to
-//                             the tile origin before the FMA, which keeps |x'| < 256 and the f32
-//                             rounding error ~16x below that of absolute 1280-px coordinates.
+//                             so any flow magnitude stays correct.
+// All kernels evaluate the warp in source-pixel-relative coordinates (warped_taps below).
 #include "common.h"
 
 namespace ebos {
 namespace {
 
 constexpr float kEps = 1e-6f;  // src/event_image_converter.py:586
+
+// Warped footprint in SOURCE-PIXEL-RELATIVE coordinates.  x' = x + d with d = -dt * u.  Writing
+// x = rs + fx (rs = trunc(x), fx exact) gives floor(x' + eps) = rs + floor(fx + d + eps): the float
+// arithmetic only ever sees |fx + d| <~ 32, so its rounding error is ~2e-6 px instead of the ~1e-4 px
+// of absolute 1280-px coordinates.  That matters because the bilinear splat's derivative jumps at
+// integer coordinates: every event rounded across an integer flips its gradient contribution.
+struct Taps {
+  int R, C;      // top-left tap, padded image coordinates
+  float fr, fc;  // fractional offsets
+  bool ok;       // finite
+};
+__device__ __forceinline__ Taps warped_taps(float ex, float ey, float dx, float dy, int pad_h, int pad_w) {
+  const int rs = (int)ex, cs = (int)ey;
+  const float lx = (ex - (float)rs) + dx, ly = (ey - (float)cs) + dy;
+  const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
+  Taps t;
+  t.fr = lx - r0;
+  t.fc = ly - c0;
+  t.ok = (r0 > -1e9f) && (r0 < 1e9f) && (c0 > -1e9f) && (c0 < 1e9f);
+  t.R = t.ok ? rs + (int)r0 + pad_h : -4;
+  t.C = t.ok ? cs + (int)c0 + pad_w : -4;
+  return t;
+}
 
 // ---------------------------------------------------------------------------------------------
 // general forward: global atomics
@@ -37,9 +59,7 @@ iwe_dense_kernel(const float* __restrict__ x, const float* __restrict__ y, const
     if (!(ex > -1e9f && ex < 1e9f && ey > -1e9f && ey < 1e9f)) continue;
     const int64_t lin = (int64_t)(int)ex * row_stride + (int)ey;
     if (lin < 0 || lin >= hw) continue;  // torch.gather would raise (src/warp.py:334-336): dropped
-    const float xw = ex - edt * flow[lin];
-    const float yw = ey - edt * flow[hw + lin];
-    const Footprint<float> f = footprint<float>(xw, yw, kEps, pad_h, pad_w);
+    const Taps f = warped_taps(ex, ey, -edt * flow[lin], -edt * flow[hw + lin], pad_h, pad_w);
     const float wv = weight ? weight[i] : 1.0f;
     const bool r0 = f.R >= 0 && f.R < h, r1 = f.R + 1 >= 0 && f.R + 1 < h;
     const bool c0 = f.C >= 0 && f.C < w, c1 = f.C + 1 >= 0 && f.C + 1 < w;
@@ -83,29 +103,26 @@ iwe_dense_tiled_kernel(const float* __restrict__ xs, const float* __restrict__ y
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
   // LDS cell (0,0) <-> un-padded image pixel (oy, ox); padded pixel (oy + pad_h, ox + pad_w)
   const int oy = ty * TH - HALO, ox = tx * TW - HALO;
-  const float foy = (float)oy, fox = (float)ox;
 
   for (int32_t i = my_beg + threadIdx.x; i < my_end; i += kTiledBlock) {
     const float ex = xs[i], ey = ys[i], edt = dts[i];
-    const int64_t lin = (int64_t)(int)ex * W + (int)ey;  // binned events have a valid source pixel
-    const float u = flow[lin], v = flow[hw + lin];
-    const float xl = (ex - foy) - edt * u;  // tile-local warped coordinates
-    const float yl = (ey - fox) - edt * v;
-    const float r0f = floorf(xl + kEps), c0f = floorf(yl + kEps);
-    const float fr = xl - r0f, fc = yl - c0f;
+    const int rs = (int)ex, cs = (int)ey;  // binned events have a valid source pixel
+    const int64_t lin = (int64_t)rs * W + cs;
+    const Taps f = warped_taps(ex, ey, -edt * flow[lin], -edt * flow[hw + lin], 0, 0);  // un-padded coordinates
+    const float fr = f.fr, fc = f.fc;
     const float wv = weight ? weight[i] : 1.0f;
     const float a = 1.0f - fr, b = 1.0f - fc;
     const float w00 = a * b * wv, w10 = fr * b * wv, w01 = a * fc * wv, w11 = fr * fc * wv;
-    if (r0f >= 0.0f && r0f < (float)(LH - 1) && c0f >= 0.0f && c0f < (float)(LW - 1)) {
-      const int rl = (int)r0f, cl = (int)c0f;
+    const int rl = f.R - oy, cl = f.C - ox;  // LDS cell of the top-left tap
+    if (f.ok && rl >= 0 && rl < LH - 1 && cl >= 0 && cl < LW - 1) {
       float* p = &s_img[rl * LW + cl];
       atomic_add(p, w00);
       atomic_add(p + LW, w10);
       atomic_add(p + 1, w01);
       atomic_add(p + LW + 1, w11);
-    } else if (r0f > -1e9f && r0f < 1e9f && c0f > -1e9f && c0f < 1e9f) {
+    } else if (f.ok) {
       // beyond the halo: straight to the image (rare when halo >= max |dt * flow| + 1)
-      const int R = (int)r0f + oy + pad_h, C = (int)c0f + ox + pad_w;
+      const int R = f.R + pad_h, C = f.C + pad_w;
       const bool rr0 = R >= 0 && R < h, rr1 = R + 1 >= 0 && R + 1 < h;
       const bool cc0 = C >= 0 && C < w, cc1 = C + 1 >= 0 && C + 1 < w;
       const int64_t base = (int64_t)R * w + C;
@@ -195,9 +212,7 @@ iwe_dense_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, c
         if (lin < 0 || lin >= hw) lin = -1;
       }
       if (lin >= 0) {
-        const float xw = ex - edt * flow[lin];
-        const float yw = ey - edt * flow[hw + lin];
-        const Footprint<float> f = footprint<float>(xw, yw, kEps, pad_h, pad_w);
+        const Taps f = warped_taps(ex, ey, -edt * flow[lin], -edt * flow[hw + lin], pad_h, pad_w);
         const float g00 = G.at(f.R, f.C), g10 = G.at(f.R + 1, f.C);
         const float g01 = G.at(f.R, f.C + 1), g11 = G.at(f.R + 1, f.C + 1);
         const float wv = weight ? weight[i] : 1.0f;
@@ -251,9 +266,8 @@ iwe_2dof_kernel(const float* __restrict__ x, const float* __restrict__ y, const 
     const float ex = x[i], ey = y[i], edt = dt[i];
     const float wv = weight ? weight[i] : 1.0f;
     for (int k = blockIdx.y; k < K; k += gridDim.y) {
-      const float xw = ex + edt * thetas[2 * k];  // plus sign: src/warp.py:368-375
-      const float yw = ey + edt * thetas[2 * k + 1];
-      const Footprint<float> f = footprint<float>(xw, yw, kEps, pad_h, pad_w);
+      // plus sign: src/warp.py:368-375
+      const Taps f = warped_taps(ex, ey, edt * thetas[2 * k], edt * thetas[2 * k + 1], pad_h, pad_w);
       float* img = iwes + k * hw;
       const bool r0 = f.R >= 0 && f.R < h, r1 = f.R + 1 >= 0 && f.R + 1 < h;
       const bool c0 = f.C >= 0 && f.C < w, c1 = f.C + 1 >= 0 && f.C + 1 < w;
@@ -285,7 +299,7 @@ iwe_2dof_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
   float a0 = 0.0f, a1 = 0.0f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float ex = x[i], ey = y[i], edt = dt[i];
-    const Footprint<float> f = footprint<float>(ex + edt * th0, ey + edt * th1, kEps, pad_h, pad_w);
+    const Taps f = warped_taps(ex, ey, edt * th0, edt * th1, pad_h, pad_w);
     const float g00 = G.at(f.R, f.C), g10 = G.at(f.R + 1, f.C);
     const float g01 = G.at(f.R, f.C + 1), g11 = G.at(f.R + 1, f.C + 1);
     const float wv = weight ? weight[i] : 1.0f;
