@@ -15,6 +15,8 @@
 //                             atomic unit wants).  Taps beyond the halo go straight to global atomics,
 //                             so any flow magnitude stays correct.
 // All kernels evaluate the warp in source-pixel-relative coordinates (warped_taps below).
+#include <type_traits>
+
 #include "common.h"
 
 namespace ebos {
@@ -77,14 +79,19 @@ iwe_dense_kernel(const float* __restrict__ x, const float* __restrict__ y, const
 // ---------------------------------------------------------------------------------------------
 constexpr int kTiledBlock = 1024;
 
-template <int TH, int TW, int HALO>
+// ACC = accumulator type of the LDS tile.  Measured on MI355X (tools/ubench_lds_atomics.hip):
+// ds_add_f32 sustains only ~0.33 lanes/clk/CU (200 Gop/s chip-wide, any bank pattern), ds_add_f64
+// ~2.8 lanes/clk/CU (1.7 Top/s), ds_add_u32 ~6-8.  So the tile is accumulated in f64 whenever
+// tile + halo fits the 160 KiB LDS in doubles; f32 remains only for the largest halos.
+template <int TH, int TW, int HALO, typename ACC>
 __global__ void __launch_bounds__(kTiledBlock)
 iwe_dense_tiled_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
                        const float* __restrict__ weight, const int32_t* __restrict__ key_offsets,
                        const float* __restrict__ flow, int H, int W, int tiles_x, int splits, int pad_h, int pad_w,
                        float* iwe) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  extern __shared__ float s_img[];  // [LH][LW]
+  extern __shared__ double s_raw[];  // [LH][LW] of ACC
+  ACC* s_img = reinterpret_cast<ACC*>(s_raw);
 
   const int tile = blockIdx.x / splits, part = blockIdx.x - tile * splits;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -96,7 +103,7 @@ iwe_dense_tiled_kernel(const float* __restrict__ xs, const float* __restrict__ y
   const int32_t my_end = min(end, my_beg + chunk);
   if (my_beg >= my_end) return;
 
-  for (int i = threadIdx.x; i < LH * LW; i += kTiledBlock) s_img[i] = 0.0f;
+  for (int i = threadIdx.x; i < LH * LW; i += kTiledBlock) s_img[i] = ACC(0);
   __syncthreads();
 
   const int64_t hw = (int64_t)H * W;
@@ -104,32 +111,56 @@ iwe_dense_tiled_kernel(const float* __restrict__ xs, const float* __restrict__ y
   // LDS cell (0,0) <-> un-padded image pixel (oy, ox); padded pixel (oy + pad_h, ox + pad_w)
   const int oy = ty * TH - HALO, ox = tx * TW - HALO;
 
-  for (int32_t i = my_beg + threadIdx.x; i < my_end; i += kTiledBlock) {
-    const float ex = xs[i], ey = ys[i], edt = dts[i];
-    const int rs = (int)ex, cs = (int)ey;  // binned events have a valid source pixel
-    const int64_t lin = (int64_t)rs * W + cs;
-    const Taps f = warped_taps(ex, ey, -edt * flow[lin], -edt * flow[hw + lin], 0, 0);  // un-padded coordinates
-    const float fr = f.fr, fc = f.fc;
-    const float wv = weight ? weight[i] : 1.0f;
-    const float a = 1.0f - fr, b = 1.0f - fc;
-    const float w00 = a * b * wv, w10 = fr * b * wv, w01 = a * fc * wv, w11 = fr * fc * wv;
-    const int rl = f.R - oy, cl = f.C - ox;  // LDS cell of the top-left tap
-    if (f.ok && rl >= 0 && rl < LH - 1 && cl >= 0 && cl < LW - 1) {
-      float* p = &s_img[rl * LW + cl];
-      atomic_add(p, w00);
-      atomic_add(p + LW, w10);
-      atomic_add(p + 1, w01);
-      atomic_add(p + LW + 1, w11);
-    } else if (f.ok) {
-      // beyond the halo: straight to the image (rare when halo >= max |dt * flow| + 1)
-      const int R = f.R + pad_h, C = f.C + pad_w;
-      const bool rr0 = R >= 0 && R < h, rr1 = R + 1 >= 0 && R + 1 < h;
-      const bool cc0 = C >= 0 && C < w, cc1 = C + 1 >= 0 && C + 1 < w;
-      const int64_t base = (int64_t)R * w + C;
-      if (rr0 && cc0) atomic_add(&iwe[base], w00);
-      if (rr1 && cc0) atomic_add(&iwe[base + w], w10);
-      if (rr0 && cc1) atomic_add(&iwe[base + 1], w01);
-      if (rr1 && cc1) atomic_add(&iwe[base + w + 1], w11);
+  // Each thread keeps kUnroll events in flight: all coalesced SoA loads are issued first, then the
+  // flow gathers, then the LDS atomics -- an in-order wave otherwise serialises
+  // load -> gather -> atomic once per event and the kernel becomes latency-bound.
+  constexpr int kUnroll = 8;
+  for (int32_t base = my_beg + threadIdx.x; base < my_end; base += kTiledBlock * kUnroll) {
+    float ex[kUnroll], ey[kUnroll], edt[kUnroll], wv[kUnroll], fu[kUnroll], fv[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const int32_t i = base + k * kTiledBlock;
+      const bool live = i < my_end;
+      ex[k] = live ? xs[i] : -1.0f;  // -1 marks a dead slot (binned events have x >= 0 ... or trunc to 0)
+      ey[k] = live ? ys[i] : 0.0f;
+      edt[k] = live ? dts[i] : 0.0f;
+      wv[k] = (live && weight) ? weight[i] : 1.0f;
+      if (!live) wv[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const int32_t i = base + k * kTiledBlock;
+      const int64_t lin = (int64_t)(int)ex[k] * W + (int)ey[k];  // binned events have a valid source pixel
+      const bool live = i < my_end;
+      fu[k] = live ? flow[lin] : 0.0f;
+      fv[k] = live ? flow[hw + lin] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const int32_t i = base + k * kTiledBlock;
+      if (i >= my_end) break;
+      const Taps f = warped_taps(ex[k], ey[k], -edt[k] * fu[k], -edt[k] * fv[k], 0, 0);  // un-padded coordinates
+      const float fr = f.fr, fc = f.fc;
+      const float a = 1.0f - fr, b = 1.0f - fc;
+      const float w00 = a * b * wv[k], w10 = fr * b * wv[k], w01 = a * fc * wv[k], w11 = fr * fc * wv[k];
+      const int rl = f.R - oy, cl = f.C - ox;  // LDS cell of the top-left tap
+      if (f.ok && rl >= 0 && rl < LH - 1 && cl >= 0 && cl < LW - 1) {
+        ACC* p = &s_img[rl * LW + cl];
+        atomic_add(p, (ACC)w00);
+        atomic_add(p + LW, (ACC)w10);
+        atomic_add(p + 1, (ACC)w01);
+        atomic_add(p + LW + 1, (ACC)w11);
+      } else if (f.ok) {
+        // beyond the halo: straight to the image (rare when halo >= max |dt * flow| + 1)
+        const int R = f.R + pad_h, C = f.C + pad_w;
+        const bool rr0 = R >= 0 && R < h, rr1 = R + 1 >= 0 && R + 1 < h;
+        const bool cc0 = C >= 0 && C < w, cc1 = C + 1 >= 0 && C + 1 < w;
+        const int64_t gb = (int64_t)R * w + C;
+        if (rr0 && cc0) atomic_add(&iwe[gb], w00);
+        if (rr1 && cc0) atomic_add(&iwe[gb + w], w10);
+        if (rr0 && cc1) atomic_add(&iwe[gb + 1], w01);
+        if (rr1 && cc1) atomic_add(&iwe[gb + w + 1], w11);
+      }
     }
   }
   __syncthreads();
@@ -137,7 +168,7 @@ iwe_dense_tiled_kernel(const float* __restrict__ xs, const float* __restrict__ y
   // flush: consecutive lanes -> consecutive columns of one image row
   const int gy0 = oy + pad_h, gx0 = ox + pad_w;
   for (int i = threadIdx.x; i < LH * LW; i += kTiledBlock) {
-    const float v = s_img[i];
+    const float v = (float)s_img[i];
     if (v == 0.0f) continue;
     const int rl = i / LW, cl = i - rl * LW;
     const int R = gy0 + rl, C = gx0 + cl;
@@ -148,18 +179,25 @@ iwe_dense_tiled_kernel(const float* __restrict__ xs, const float* __restrict__ y
 struct TiledConfig {
   int th, tw, halo;
 };
-constexpr TiledConfig kTiledConfigs[] = {{64, 64, 32}, {32, 64, 32}, {64, 64, 16}, {32, 32, 16},
-                                         {32, 32, 8},  {64, 64, 64}, {32, 64, 48}};
+constexpr TiledConfig kTiledConfigs[] = {{64, 64, 32}, {32, 64, 32}, {32, 32, 32}, {64, 64, 16}, {32, 32, 16},
+                                         {32, 32, 8},  {64, 64, 64}, {32, 64, 48}, {16, 64, 32}};
 constexpr int kNumTiledConfigs = sizeof(kTiledConfigs) / sizeof(kTiledConfigs[0]);
+
+template <int TH, int TW, int HALO>
+struct TileAcc {  // f64 when it fits the LDS, else f32
+  static constexpr bool kF64 = (size_t)(TH + 2 * HALO) * (TW + 2 * HALO) * sizeof(double) <= 160 * 1024;
+  using type = typename std::conditional<kF64, double, float>::type;
+};
 
 template <int TH, int TW, int HALO>
 int launch_tiled(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* key_offsets,
                  const float* flow, int H, int W, int splits, int pad_h, int pad_w, float* iwe, hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  constexpr size_t lds = (size_t)LH * LW * sizeof(float);
+  using ACC = typename TileAcc<TH, TW, HALO>::type;
+  constexpr size_t lds = (size_t)LH * LW * sizeof(ACC);
   static_assert(lds <= 160 * 1024, "tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
-  auto kern = iwe_dense_tiled_kernel<TH, TW, HALO>;
+  auto kern = iwe_dense_tiled_kernel<TH, TW, HALO, ACC>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {
@@ -361,6 +399,8 @@ int ebos_iwe_dense_tiled_f32(const float* xs, const float* ys, const float* dts,
     rc = launch_tiled<TH, TW, HL>(xs, ys, dts, weight, key_offsets, flow, H, W, splits, pad_h, pad_w, iwe, s);
   EBOS_TILED_CASE(64, 64, 32)
   EBOS_TILED_CASE(32, 64, 32)
+  EBOS_TILED_CASE(32, 32, 32)
+  EBOS_TILED_CASE(16, 64, 32)
   EBOS_TILED_CASE(64, 64, 16)
   EBOS_TILED_CASE(32, 32, 16)
   EBOS_TILED_CASE(32, 32, 8)
