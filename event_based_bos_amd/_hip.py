@@ -67,6 +67,10 @@ SIGNATURES = {
     "ebos_iwe_dense_tiled_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_tiled_config": (_I, [C.POINTER(C.c_int), _I]),
     "ebos_iwe_dense_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
+    "ebos_slab_config": (_I, [C.POINTER(C.c_int), _I]),
+    "ebos_iwe_slab_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "ebos_iwe_dense_slab_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
+    "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "ebos_iwe_2dof_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_2dof_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "ebos_cost_scratch_bytes": (_Z, [_I]),
@@ -146,6 +150,14 @@ def suffix(dtype: torch.dtype) -> str:
     if dtype == torch.float64:
         return "f64"
     raise TypeError(f"event_based_bos_amd kernels exist for float32 and float64 tensors, got {dtype}")
+
+
+def slab_configs():
+    lib = load_library()
+    n = lib.ebos_slab_config(None, 0)
+    buf = (C.c_int * (3 * n))()
+    lib.ebos_slab_config(buf, n)
+    return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]
 
 
 def tiled_configs():

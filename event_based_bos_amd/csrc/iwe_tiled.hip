@@ -1,0 +1,551 @@
+// iwe_tiled.hip -- tile-private fused warp + IWE pipeline for gfx950 (the fast path of the hot loop).
+//
+// Events are binned by source tile (event_plan.hip).  One 1024-thread workgroup owns one (tile, split):
+//
+//   forward   iwe_slab_accumulate_kernel   events (SoA, coalesced, software-pipelined: the loads of batch
+//                                          k+1 are in flight while batch k's taps are accumulated) ->
+//                                          warp in registers -> ds_add_f64 into an LDS image of the tile +
+//                                          HALO px per side -> the LDS image is written ONCE as a plain,
+//                                          fully coalesced f32 "slab" (no global atomics, no memset)
+//             iwe_slab_combine_kernel      per pixel: sum the <= 9 slabs that cover it (+ the spill image of
+//                                          beyond-halo taps), write the IWE, and reduce the variance moments
+//                                          (sum, sum of squares; f64) of the row segment -> partials
+//             moments_finalize_kernel      one workgroup: partials -> (mean, M, variance); deterministic
+//   backward  iwe_dense_tiled_bwd_kernel   upstream image tile (+halo) staged in LDS, four LDS gathers per event,
+//                                          wave-level segmented sum over the events of one source pixel
+//                                          (__shfl), ds_add_f64 into a [2][TH][TW] LDS tile, then d_flow of
+//                                          the tile is written with plain stores -- every flow pixel belongs
+//                                          to exactly one tile, so no global atomics and no zero-fill.
+//
+// Why f64 in LDS: measured on MI355X (tools/ubench_lds_atomics.hip) ds_add_f32 sustains ~0.33 lanes/clk/CU
+// (200 Gop/s chip-wide, any bank pattern) but ds_add_f64 ~2.8 and ds_add_u64 ~4.6 lanes/clk/CU.
+// Why slabs: a global float atomic costs ~50 ns per 256-B wave instruction per CU at the memory side and
+// same-address atomics serialise (~88/us), whereas plain stores stream at HBM rate.
+//
+// reference semantics: src/warp.py:330-342 + src/event_image_converter.py:581-620 (forward);
+// their autograd w.r.t. the flow and the per-event weight (backward).
+#include <type_traits>
+
+#include "common.h"
+
+namespace ebos {
+namespace {
+
+constexpr float kEps = 1e-6f;  // src/event_image_converter.py:586
+constexpr int kBlock = 1024;
+constexpr int kUnroll = 4;     // events per thread per pipeline stage
+
+struct Taps {
+  int R, C;      // top-left tap (un-padded image coordinates)
+  float fr, fc;  // fractional offsets
+  bool ok;       // finite
+};
+// source-pixel-relative warp arithmetic (see iwe_fused.hip): keeps |fx + d| <~ 32 in f32
+__device__ __forceinline__ Taps warped_taps(float ex, float ey, float dx, float dy) {
+  const int rs = (int)ex, cs = (int)ey;
+  const float lx = (ex - (float)rs) + dx, ly = (ey - (float)cs) + dy;
+  const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
+  Taps t;
+  t.fr = lx - r0;
+  t.fc = ly - c0;
+  t.ok = (r0 > -1e9f) && (r0 < 1e9f) && (c0 > -1e9f) && (c0 < 1e9f);
+  t.R = t.ok ? rs + (int)r0 : -(1 << 20);
+  t.C = t.ok ? cs + (int)c0 : -(1 << 20);
+  return t;
+}
+
+struct Batch {
+  float x[kUnroll], y[kUnroll], dt[kUnroll], w[kUnroll];
+};
+
+// Branch-free: indices past the slice are clamped to its last event (the slice is non-empty) and get
+// weight 0.  Predicated loads would turn into exec-masked branches, and hipcc then waits vmcnt(0) for
+// them -- draining the prefetch of the next batch that is supposed to stay in flight (cdna guide 4(c)).
+template <bool HAS_W>
+__device__ __forceinline__ void load_batch(Batch& b, int32_t base, int32_t end, const float* __restrict__ xs,
+                                           const float* __restrict__ ys, const float* __restrict__ dts,
+                                           const float* __restrict__ weight) {
+#pragma unroll
+  for (int k = 0; k < kUnroll; ++k) {
+    const int32_t i = base + k * kBlock;
+    const int32_t j = min(i, end - 1);
+    b.x[k] = xs[j];
+    b.y[k] = ys[j];
+    b.dt[k] = dts[j];
+    const float wv = HAS_W ? weight[j] : 1.0f;
+    b.w[k] = i < end ? wv : 0.0f;
+  }
+}
+
+struct TileRange {
+  int ty, tx;
+  int32_t beg, end;  // this workgroup's slice of the tile's events
+};
+__device__ __forceinline__ TileRange tile_range(const int32_t* __restrict__ key_offsets, int tile_px, int tiles_x,
+                                                int splits) {
+  TileRange r;
+  const int tile = blockIdx.x / splits, part = blockIdx.x - tile * splits;
+  r.ty = tile / tiles_x;
+  r.tx = tile - r.ty * tiles_x;
+  const int32_t beg = key_offsets[tile * tile_px], end = key_offsets[(tile + 1) * tile_px];
+  int32_t chunk = (end - beg + splits - 1) / splits;
+  chunk = (chunk + kWave - 1) & ~(kWave - 1);
+  r.beg = min(end, beg + part * chunk);
+  r.end = min(end, r.beg + chunk);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward A: accumulate one (tile, split) in LDS, write it as a slab
+// ---------------------------------------------------------------------------------------------------
+template <int TH, int TW, int HALO, bool HAS_W>
+__global__ void __launch_bounds__(kBlock)
+iwe_slab_accumulate_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
+                           const float* __restrict__ weight, const int32_t* __restrict__ key_offsets,
+                           const float* __restrict__ flow, int H, int W, int tiles_x, int splits, int pad_h, int pad_w,
+                           float* __restrict__ slabs, float* spill) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  extern __shared__ double s_acc[];  // [LH][LW]
+  const TileRange tr = tile_range(key_offsets, TH * TW, tiles_x, splits);
+
+  for (int i = threadIdx.x; i < LH * LW; i += kBlock) s_acc[i] = 0.0;
+  __syncthreads();
+
+  const int64_t hw = (int64_t)H * W;
+  const int h = H + 2 * pad_h, w = W + 2 * pad_w;
+  const int oy = tr.ty * TH - HALO, ox = tr.tx * TW - HALO;  // LDS cell (0,0) = un-padded pixel (oy, ox)
+
+  const float* __restrict__ flow1 = flow + hw;
+  int32_t base = tr.beg + threadIdx.x;
+  Batch cur;
+  if (tr.beg < tr.end) load_batch<HAS_W>(cur, base, tr.end, xs, ys, dts, weight);
+  while (base < tr.end) {
+    float fu[kUnroll], fv[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {  // flow gathers of the current batch (sorted events: broadcast/adjacent)
+      const int lin = (int)cur.x[k] * W + (int)cur.y[k];
+      fu[k] = flow[lin];
+      fv[k] = flow1[lin];
+    }
+    Batch nxt;  // next batch's coalesced loads go out before this batch's LDS work and stay in flight
+    const int32_t nbase = base + kBlock * kUnroll;
+    load_batch<HAS_W>(nxt, nbase, tr.end, xs, ys, dts, weight);
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      if (base + k * kBlock >= tr.end) break;
+      const Taps f = warped_taps(cur.x[k], cur.y[k], -cur.dt[k] * fu[k], -cur.dt[k] * fv[k]);
+      const float a = 1.0f - f.fr, b = 1.0f - f.fc, wv = cur.w[k];
+      const float w00 = a * b * wv, w10 = f.fr * b * wv, w01 = a * f.fc * wv, w11 = f.fr * f.fc * wv;
+      const int rl = f.R - oy, cl = f.C - ox;
+      if (f.ok && rl >= 0 && rl < LH - 1 && cl >= 0 && cl < LW - 1) {
+        double* p = &s_acc[rl * LW + cl];
+        atomic_add(p, (double)w00);
+        atomic_add(p + LW, (double)w10);
+        atomic_add(p + 1, (double)w01);
+        atomic_add(p + LW + 1, (double)w11);
+      } else if (f.ok) {  // beyond the halo: spill image (zero-invariant scratch, folded in by the combine pass)
+        const int R = f.R + pad_h, C = f.C + pad_w;
+        const bool r0 = R >= 0 && R < h, r1 = R + 1 >= 0 && R + 1 < h;
+        const bool c0 = C >= 0 && C < w, c1 = C + 1 >= 0 && C + 1 < w;
+        const int64_t gb = (int64_t)R * w + C;
+        if (r0 && c0) atomic_add(&spill[gb], w00);
+        if (r1 && c0) atomic_add(&spill[gb + w], w10);
+        if (r0 && c1) atomic_add(&spill[gb + 1], w01);
+        if (r1 && c1) atomic_add(&spill[gb + w + 1], w11);
+      }
+    }
+    cur = nxt;
+    base = nbase;
+  }
+  __syncthreads();
+
+  // slab = the LDS image as f32, 16 B per lane, fully coalesced plain stores
+  float4* out = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * (LH * LW));
+  static_assert((LH * LW) % 4 == 0, "slab size must be a multiple of 4 cells");
+  for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
+    const double* p = &s_acc[4 * i];
+    out[i] = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward B: combine slabs (+ spill) -> IWE, optional variance moments of the row segment
+// ---------------------------------------------------------------------------------------------------
+constexpr int kCombineBlock = 256;
+
+template <int TH, int TW, int HALO>
+__global__ void __launch_bounds__(kCombineBlock)
+iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
+                        int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  const int h = H + 2 * pad_h, w = W + 2 * pad_w;
+  const int R = blockIdx.y, C = blockIdx.x * kCombineBlock + threadIdx.x;
+  const int r = R - pad_h, c = C - pad_w;  // un-padded coordinates (may lie in the padding ring)
+  float v = 0.0f;
+  if (C < w) {
+    // tiles whose LDS window [t*T - HALO, t*T + T + HALO) contains r (resp. c)
+    int ty0 = (r - HALO - TH + 1 >= 0) ? (r - HALO - TH + 1 + TH - 1) / TH : 0;  // ceil((r - HALO - TH + 1) / TH) clamped at 0
+    int ty1 = (r + HALO >= 0) ? (r + HALO) / TH : -1;
+    if (ty1 > tiles_y - 1) ty1 = tiles_y - 1;
+    int tx0 = (c - HALO - TW + 1 >= 0) ? (c - HALO - TW + 1 + TW - 1) / TW : 0;
+    int tx1 = (c + HALO >= 0) ? (c + HALO) / TW : -1;
+    if (tx1 > tiles_x - 1) tx1 = tiles_x - 1;
+    for (int ty = ty0; ty <= ty1; ++ty) {
+      const int rl = r - (ty * TH - HALO);
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int cl = c - (tx * TW - HALO);
+        const float* s = slabs + ((int64_t)(ty * tiles_x + tx) * splits) * (LH * LW) + rl * LW + cl;
+        for (int p = 0; p < splits; ++p) v += s[(int64_t)p * (LH * LW)];
+      }
+    }
+    const int64_t gi = (int64_t)R * w + C;
+    const float sp = spill[gi];
+    if (sp != 0.0f) {
+      v += sp;
+      spill[gi] = 0.0f;  // keep the spill image zero between calls
+    }
+    iwe[gi] = v;
+  }
+  if (partials != nullptr) {
+    const bool in = C < w && R >= g_lo && R < h - g_lo && C >= g_lo && C < w - g_lo;
+    double s = in ? (double)v : 0.0, ss = in ? (double)v * (double)v : 0.0;
+    __shared__ double red[kCombineBlock / kWave];
+    s = block_sum(s, red);
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+      const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+      partials[2 * b] = s;
+      partials[2 * b + 1] = ss;
+    }
+  }
+}
+
+// one workgroup: partials -> out (unbiased variance), moments (mean, M).  Fixed summation order.
+__global__ void __launch_bounds__(256)
+moments_finalize_kernel(const double* __restrict__ partials, int64_t nparts, int64_t m, float* out, double* moments) {
+  double s = 0.0, ss = 0.0;
+  for (int64_t i = threadIdx.x; i < nparts; i += blockDim.x) {
+    s += partials[2 * i];
+    ss += partials[2 * i + 1];
+  }
+  __shared__ double red[4];
+  s = block_sum(s, red);
+  ss = block_sum(ss, red);
+  if (threadIdx.x == 0) {
+    const double mean = m > 0 ? s / (double)m : 0.0;
+    if (out) out[0] = (float)((ss - s * mean) / (double)(m - 1));
+    if (moments) {
+      moments[0] = mean;
+      moments[1] = (double)m;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward: d_flow tile by tile, no global atomics
+// ---------------------------------------------------------------------------------------------------
+struct GradImage {
+  const float* g;
+  float a, c;  // G = a * g + c inside the valid region, 0 outside
+  int h, w, lo;
+  __device__ __forceinline__ float at(int R, int C) const {  // padded coordinates
+    if (R < lo || R >= h - lo || C < lo || C >= w - lo) return 0.0f;
+    return a * g[(int64_t)R * w + C] + c;
+  }
+};
+
+template <int TH, int TW, int HALO, bool HAS_W>
+__global__ void __launch_bounds__(kBlock)
+iwe_dense_tiled_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
+                           const float* __restrict__ weight, const int32_t* __restrict__ key_offsets,
+                           const float* __restrict__ flow, int H, int W, int tiles_x, int pad_h, int pad_w,
+                           const float* __restrict__ g_image, const float* __restrict__ affine, int g_lo,
+                           float* __restrict__ d_flow, float* __restrict__ d_weight) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  extern __shared__ double s_raw[];
+  double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
+  float* s_g = reinterpret_cast<float*>(s_raw + 2 * TH * TW);      // [LH][LW] upstream gradient tile
+  const TileRange tr = tile_range(key_offsets, TH * TW, tiles_x, 1);
+  const int64_t hw = (int64_t)H * W;
+  GradImage G;
+  G.g = g_image;
+  G.a = affine ? affine[0] : 1.0f;
+  G.c = affine ? affine[1] : 0.0f;
+  G.h = H + 2 * pad_h;
+  G.w = W + 2 * pad_w;
+  G.lo = g_lo;
+  const int oy = tr.ty * TH - HALO, ox = tr.tx * TW - HALO;
+
+  for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
+  if (tr.beg < tr.end) {
+    for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
+      const int rl = i / LW, cl = i - rl * LW;
+      s_g[i] = G.at(oy + rl + pad_h, ox + cl + pad_w);
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & (kWave - 1);
+  // whole waves iterate together (shuffles below): the wave's first lane decides
+  const int32_t wave_first = tr.beg + (threadIdx.x - lane);
+  const float* __restrict__ flow1 = flow + hw;
+  int32_t base = tr.beg + threadIdx.x;
+  Batch cur;
+  if (tr.beg < tr.end) load_batch<HAS_W>(cur, base, tr.end, xs, ys, dts, weight);
+  for (int32_t wbase = wave_first; wbase < tr.end; wbase += kBlock * kUnroll) {
+    float fu[kUnroll], fv[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const int lin = (int)cur.x[k] * W + (int)cur.y[k];
+      fu[k] = flow[lin];
+      fv[k] = flow1[lin];
+    }
+    Batch nxt;
+    const int32_t nbase = base + kBlock * kUnroll;
+    load_batch<HAS_W>(nxt, nbase, tr.end, xs, ys, dts, weight);
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      if (wbase + k * kBlock >= tr.end) break;  // wave-uniform
+      const int32_t i = base + k * kBlock;
+      const bool live = i < tr.end;
+      int pix = -1;  // tile-local source pixel
+      float gx = 0.0f, gy = 0.0f;
+      if (live) {
+        const int rs = (int)cur.x[k], cs = (int)cur.y[k];
+        pix = (rs - tr.ty * TH) * TW + (cs - tr.tx * TW);
+        const float edt = cur.dt[k];
+        const Taps f = warped_taps(cur.x[k], cur.y[k], -edt * fu[k], -edt * fv[k]);
+        const int rl = f.R - oy, cl = f.C - ox;
+        float g00, g10, g01, g11;
+        if (f.ok && rl >= 0 && rl < LH - 1 && cl >= 0 && cl < LW - 1) {
+          const float* p = &s_g[rl * LW + cl];
+          g00 = p[0];
+          g10 = p[LW];
+          g01 = p[1];
+          g11 = p[LW + 1];
+        } else {
+          const int R = f.R + pad_h, C = f.C + pad_w;
+          g00 = f.ok ? G.at(R, C) : 0.0f;
+          g10 = f.ok ? G.at(R + 1, C) : 0.0f;
+          g01 = f.ok ? G.at(R, C + 1) : 0.0f;
+          g11 = f.ok ? G.at(R + 1, C + 1) : 0.0f;
+        }
+        const float a = 1.0f - f.fr, b = 1.0f - f.fc, wv = cur.w[k];
+        const float dx = wv * (b * (g10 - g00) + f.fc * (g11 - g01));  // dL/dx'
+        const float dy = wv * (a * (g01 - g00) + f.fr * (g11 - g10));  // dL/dy'
+        gx = -edt * dx;
+        gy = -edt * dy;
+        if (d_weight) d_weight[i] = a * b * g00 + f.fr * b * g10 + a * f.fc * g01 + f.fr * f.fc * g11;
+      }
+      // segmented sum over the (contiguous) events of one source pixel inside the wave
+      const int prev = __shfl_up(pix, 1, kWave);
+      const bool head = (lane == 0) || (prev != pix);
+      const unsigned long long heads = __ballot(head);
+      const int run = __popcll(heads & (~0ull >> (63 - lane)));
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const float ox_ = __shfl_down(gx, off, kWave);
+        const float oy_ = __shfl_down(gy, off, kWave);
+        const int orun = __shfl_down(run, off, kWave);
+        if (lane + off < kWave && orun == run) {
+          gx += ox_;
+          gy += oy_;
+        }
+      }
+      if (head && pix >= 0) {
+        atomic_add(&s_d[pix], (double)gx);
+        atomic_add(&s_d[TH * TW + pix], (double)gy);
+      }
+    }
+    cur = nxt;
+    base = nbase;
+  }
+  __syncthreads();
+
+  // every flow pixel belongs to exactly one tile: plain coalesced stores, zeros where no event lives
+  for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
+    const int rl = i / TW, cl = i - rl * TW;
+    const int r = tr.ty * TH + rl, c = tr.tx * TW + cl;
+    if (r < H && c < W) {
+      d_flow[(int64_t)r * W + c] = (float)s_d[i];
+      d_flow[hw + (int64_t)r * W + c] = (float)s_d[TH * TW + i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+struct SlabConfig {
+  int th, tw, halo;
+};
+// f64 tile + halo must fit 160 KiB (forward); backward needs 16 TH TW + 4 LH LW bytes
+constexpr SlabConfig kSlabConfigs[] = {{64, 64, 32}, {32, 64, 32}, {32, 32, 32}, {64, 64, 16}, {32, 32, 16}, {32, 32, 8}};
+constexpr int kNumSlabConfigs = sizeof(kSlabConfigs) / sizeof(kSlabConfigs[0]);
+
+struct SlabLayout {
+  int tiles_y, tiles_x, nblk, h, w, combine_blocks;
+  size_t slab_cells;   // per workgroup
+  size_t off_spill, off_partials, total;
+};
+
+inline SlabLayout slab_layout(int H, int W, int th, int tw, int halo, int splits, int pad_h, int pad_w) {
+  SlabLayout L;
+  L.tiles_y = (H + th - 1) / th;
+  L.tiles_x = (W + tw - 1) / tw;
+  L.nblk = L.tiles_y * L.tiles_x * splits;
+  L.h = H + 2 * pad_h;
+  L.w = W + 2 * pad_w;
+  L.slab_cells = (size_t)(th + 2 * halo) * (tw + 2 * halo);
+  L.combine_blocks = ((L.w + kCombineBlock - 1) / kCombineBlock) * L.h;
+  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  L.off_spill = align((size_t)L.nblk * L.slab_cells * sizeof(float));
+  L.off_partials = L.off_spill + align((size_t)L.h * L.w * sizeof(float));
+  L.total = L.off_partials + align((size_t)L.combine_blocks * 2 * sizeof(double));
+  return L;
+}
+
+template <typename K>
+int reserve_lds(K kern, size_t lds, const char* what) {
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    set_error("%s: cannot reserve %zu B of LDS", what, lds);
+    return EBOS_ERR_LAUNCH;
+  }
+  return EBOS_OK;
+}
+
+template <int TH, int TW, int HALO>
+int launch_slab_fwd(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* key_offsets,
+                    const float* flow, int H, int W, int splits, int pad_h, int pad_w, char* ws, float* iwe, int want_var,
+                    int omit, float* out_var, double* moments, hipStream_t s) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr size_t lds = (size_t)LH * LW * sizeof(double);
+  static_assert(lds <= 160 * 1024, "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
+  const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
+  float* slabs = reinterpret_cast<float*>(ws);
+  float* spill = reinterpret_cast<float*>(ws + L.off_spill);
+  double* partials = reinterpret_cast<double*>(ws + L.off_partials);
+  auto ka = weight ? iwe_slab_accumulate_kernel<TH, TW, HALO, true> : iwe_slab_accumulate_kernel<TH, TW, HALO, false>;
+  if (int rc = reserve_lds(ka, lds, "ebos_iwe_dense_slab")) return rc;
+  ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(xs, ys, dts, weight, key_offsets, flow, H, W, L.tiles_x, splits, pad_h,
+                                                       pad_w, slabs, spill);
+  dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
+  iwe_slab_combine_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W, pad_h,
+                                                                          pad_w, iwe, omit ? 1 : 0, want_var ? partials : nullptr);
+  if (want_var) {
+    const int lo = omit ? 1 : 0;
+    const int64_t m = (int64_t)(L.h - 2 * lo > 0 ? L.h - 2 * lo : 0) * (L.w - 2 * lo > 0 ? L.w - 2 * lo : 0);
+    moments_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, L.combine_blocks, m, out_var, moments);
+  }
+  return EBOS_OK;
+}
+
+template <int TH, int TW, int HALO>
+int launch_tiled_bwd(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* key_offsets,
+                     const float* flow, int H, int W, int pad_h, int pad_w, const float* g_image, const float* affine, int g_lo,
+                     float* d_flow, float* d_weight, hipStream_t s) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
+  static_assert(lds <= 160 * 1024, "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
+  const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
+  auto kb = weight ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, true> : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false>;
+  if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
+  kb<<<dim3((unsigned)(tiles_y * tiles_x)), dim3(kBlock), lds, s>>>(xs, ys, dts, weight, key_offsets, flow, H, W, tiles_x, pad_h,
+                                                                    pad_w, g_image, affine, g_lo, d_flow, d_weight);
+  return EBOS_OK;
+}
+
+bool slab_config_ok(int th, int tw, int halo) {
+  for (int i = 0; i < kNumSlabConfigs; ++i)
+    if (kSlabConfigs[i].th == th && kSlabConfigs[i].tw == tw && kSlabConfigs[i].halo == halo) return true;
+  return false;
+}
+
+}  // namespace
+}  // namespace ebos
+
+#define EBOS_SLAB_DISPATCH(CALL)                                             \
+  if (tile_h == 64 && tile_w == 64 && halo == 32) { rc = CALL(64, 64, 32); } \
+  else if (tile_h == 32 && tile_w == 64 && halo == 32) { rc = CALL(32, 64, 32); } \
+  else if (tile_h == 32 && tile_w == 32 && halo == 32) { rc = CALL(32, 32, 32); } \
+  else if (tile_h == 64 && tile_w == 64 && halo == 16) { rc = CALL(64, 64, 16); } \
+  else if (tile_h == 32 && tile_w == 32 && halo == 16) { rc = CALL(32, 32, 16); } \
+  else if (tile_h == 32 && tile_w == 32 && halo == 8) { rc = CALL(32, 32, 8); }
+
+extern "C" {
+
+int ebos_slab_config(int* out, int cap) {
+  using namespace ebos;
+  for (int i = 0; i < kNumSlabConfigs && i < cap && out != nullptr; ++i) {
+    out[3 * i] = kSlabConfigs[i].th;
+    out[3 * i + 1] = kSlabConfigs[i].tw;
+    out[3 * i + 2] = kSlabConfigs[i].halo;
+  }
+  return kNumSlabConfigs;
+}
+
+size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w) {
+  using namespace ebos;
+  if (H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0 || halo < 0 || splits < 1 || pad_h < 0 || pad_w < 0) return 0;
+  return slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w).total;
+}
+
+int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+                            const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
+                            int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
+                            size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
+                            double* moments, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(flow && iwe && key_offsets && workspace, "ebos_iwe_dense_slab: NULL flow/iwe/key_offsets/workspace");
+  EBOS_REQUIRE((xs && ys && dts) || n == 0, "ebos_iwe_dense_slab: NULL event buffer");
+  EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 1 && splits <= 64,
+               "ebos_iwe_dense_slab: bad sizes (splits=%d)", splits);
+  EBOS_REQUIRE(!want_variance || out_variance || moments, "ebos_iwe_dense_slab: variance requested without an output");
+  if (!slab_config_ok(tile_h, tile_w, halo)) {
+    set_error("ebos_iwe_dense_slab: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  const size_t need = ebos_iwe_slab_workspace_bytes(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w);
+  if (workspace_bytes < need) {
+    set_error("ebos_iwe_dense_slab: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return EBOS_ERR_SCRATCH;
+  }
+  hipStream_t s = as_stream(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  int rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL)                                                                                          \
+  launch_slab_fwd<TH, TW, HL>(xs, ys, dts, weight, key_offsets, flow, H, W, splits, pad_h, pad_w, ws, iwe, want_variance, \
+                              omit_boundary, out_variance, moments, s)
+  EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+  if (rc != EBOS_OK) return rc;
+  EBOS_CHECK_LAUNCH("ebos_iwe_dense_slab");
+  return EBOS_OK;
+}
+
+int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+                                 const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
+                                 int tile_w, int halo, int pad_h, int pad_w, const float* g_image, const float* affine,
+                                 int g_lo, float* d_flow, float* d_weight, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(flow && g_image && d_flow && key_offsets, "ebos_iwe_dense_tiled_bwd: NULL flow/g_image/d_flow/key_offsets");
+  EBOS_REQUIRE((xs && ys && dts) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
+  EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_dense_tiled_bwd: bad sizes");
+  if (!slab_config_ok(tile_h, tile_w, halo)) {
+    set_error("ebos_iwe_dense_tiled_bwd: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = as_stream(stream);
+  int rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL)                                                                                       \
+  launch_tiled_bwd<TH, TW, HL>(xs, ys, dts, weight, key_offsets, flow, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, \
+                               d_weight, s)
+  EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+  if (rc != EBOS_OK) return rc;
+  EBOS_CHECK_LAUNCH("ebos_iwe_dense_tiled_bwd");
+  return EBOS_OK;
+}
+
+}  // extern "C"

@@ -160,9 +160,51 @@ def _check_flow(plan: EventPlan, flow: torch.Tensor) -> torch.Tensor:
     return flow.to(torch.float32).contiguous()
 
 
+_SLAB_CONFIGS = None
+
+
+def _slab_ok(plan: EventPlan, halo) -> bool:
+    global _SLAB_CONFIGS
+    if not plan.binned or halo is None:
+        return False
+    if _SLAB_CONFIGS is None:
+        _SLAB_CONFIGS = set(_hip.slab_configs())
+    return (plan.tile[0], plan.tile[1], int(halo)) in _SLAB_CONFIGS
+
+
+def _workspace(plan: EventPlan, pad, halo, splits) -> torch.Tensor:
+    """Zero-filled once; the kernels keep the spill section zero between calls."""
+    lib = _hip.require_gpu()
+    key = (int(halo), int(splits), int(pad[0]), int(pad[1]))
+    cache = plan.__dict__.setdefault("_workspaces", {})
+    if key not in cache:
+        H, W = plan.image_size
+        nbytes = int(lib.ebos_iwe_slab_workspace_bytes(H, W, plan.tile[0], plan.tile[1], key[0], key[1], key[2], key[3]))
+        cache[key] = torch.zeros(nbytes, dtype=torch.uint8, device=plan.device)
+    return cache[key]
+
+
+def _launch_iwe_dense_slab(plan: EventPlan, flow32, weight, pad, halo, splits, want_variance=False, omit=False):
+    """Tile-private forward: returns (iwe, variance [1] | None, moments [1, 2] | None)."""
+    lib = _hip.require_gpu()
+    H, W = plan.image_size
+    ws = _workspace(plan, pad, halo, splits)
+    iwe = torch.empty((H + 2 * pad[0], W + 2 * pad[1]), dtype=torch.float32, device=plan.device)
+    out = torch.empty(1, dtype=torch.float32, device=plan.device) if want_variance else None
+    moments = torch.empty((1, 2), dtype=torch.float64, device=plan.device) if want_variance else None
+    with torch.cuda.device(plan.device):
+        check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), ptr(plan.key_offsets), plan.n,
+                                          ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), int(splits), pad[0],
+                                          pad[1], ptr(ws), ws.numel(), ptr(iwe), int(want_variance), int(omit), ptr(out),
+                                          ptr(moments), stream_ptr()), "ebos_iwe_dense_slab")
+    return iwe, out, moments
+
+
 def _launch_iwe_dense(plan: EventPlan, flow32: torch.Tensor, weight, pad, halo, splits) -> torch.Tensor:
     lib = _hip.require_gpu()
     H, W = plan.image_size
+    if _slab_ok(plan, halo):
+        return _launch_iwe_dense_slab(plan, flow32, weight, pad, halo, splits)[0]
     iwe = torch.zeros((H + 2 * pad[0], W + 2 * pad[1]), dtype=torch.float32, device=plan.device)
     with torch.cuda.device(plan.device):
         if plan.binned and halo is not None:
@@ -185,11 +227,19 @@ def _plan_weight(plan: EventPlan, weight: Optional[torch.Tensor]) -> Optional[to
     return (w if plan.perm is None else w[plan.perm.long()]).contiguous()
 
 
-def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_dweight):
+def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_dweight, halo=DEFAULT_HALO):
     lib = _hip.require_gpu()
     H, W = plan.image_size
-    d_flow = torch.zeros((2, H, W), dtype=torch.float32, device=plan.device)
     d_w = torch.empty(plan.n, dtype=torch.float32, device=plan.device) if want_dweight else None
+    if _slab_ok(plan, halo):  # tile-private backward: d_flow written with plain stores, no zero-fill
+        d_flow = torch.empty((2, H, W), dtype=torch.float32, device=plan.device)
+        with torch.cuda.device(plan.device):
+            check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), ptr(plan.key_offsets),
+                                                   plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), pad[0],
+                                                   pad[1], ptr(g_image), ptr(affine), g_lo, ptr(d_flow), ptr(d_w),
+                                                   stream_ptr()), "ebos_iwe_dense_tiled_bwd")
+        return d_flow, d_w
+    d_flow = torch.zeros((2, H, W), dtype=torch.float32, device=plan.device)
     with torch.cuda.device(plan.device):
         check(lib.ebos_iwe_dense_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), plan.n, ptr(flow32), H, W,
                                          W, pad[0], pad[1], ptr(g_image), ptr(affine), g_lo, int(plan.binned),
@@ -213,16 +263,16 @@ class _FusedIweDense(torch.autograd.Function):
         wp = _plan_weight(plan, weight)
         iwe = _launch_iwe_dense(plan, flow32, wp, pad, halo, splits)
         ctx.save_for_backward(flow32, wp if wp is not None else torch.empty(0))
-        ctx.meta = (plan, pad, flow.dtype, weight.dtype if weight is not None else None)
+        ctx.meta = (plan, pad, flow.dtype, weight.dtype if weight is not None else None, halo)
         return iwe if flow.dtype == torch.float32 else iwe.to(flow.dtype)
 
     @staticmethod
     def backward(ctx, g):
         flow32, wp = ctx.saved_tensors
-        plan, pad, fdt, wdt = ctx.meta
+        plan, pad, fdt, wdt, halo = ctx.meta
         wp = wp if wdt is not None else None
         need_w = wdt is not None and ctx.needs_input_grad[1]
-        d_flow, d_w = _launch_dense_bwd(plan, flow32, wp, pad, g.to(torch.float32).contiguous(), None, 0, need_w)
+        d_flow, d_w = _launch_dense_bwd(plan, flow32, wp, pad, g.to(torch.float32).contiguous(), None, 0, need_w, halo)
         d_weight = _unpermute(plan, d_w).to(wdt) if need_w else None
         return (d_flow.to(fdt) if ctx.needs_input_grad[0] else None), d_weight, None, None, None, None
 
@@ -232,30 +282,33 @@ class _FusedVarianceDense(torch.autograd.Function):
     def forward(ctx, flow, plan, pad, omit, halo, splits):
         lib = _hip.require_gpu()
         flow32 = _check_flow(plan, flow)
-        iwe = _launch_iwe_dense(plan, flow32, None, pad, halo, splits)
-        h, w = iwe.shape
-        out = torch.empty(1, dtype=torch.float32, device=plan.device)
-        moments = torch.empty((1, 2), dtype=torch.float64, device=plan.device)
-        nbytes = int(lib.ebos_cost_scratch_bytes(1))
-        scratch = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
-        with torch.cuda.device(plan.device):
-            check(lib.ebos_image_variance_f32(ptr(iwe), 1, h, w, int(omit), ptr(out), ptr(moments), ptr(scratch), nbytes,
-                                              stream_ptr()), "ebos_image_variance")
+        if _slab_ok(plan, halo):  # IWE + variance in one tile-private pipeline
+            iwe, out, moments = _launch_iwe_dense_slab(plan, flow32, None, pad, halo, splits, True, omit)
+        else:
+            iwe = _launch_iwe_dense(plan, flow32, None, pad, halo, splits)
+            h, w = iwe.shape
+            out = torch.empty(1, dtype=torch.float32, device=plan.device)
+            moments = torch.empty((1, 2), dtype=torch.float64, device=plan.device)
+            nbytes = int(lib.ebos_cost_scratch_bytes(1))
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
+            with torch.cuda.device(plan.device):
+                check(lib.ebos_image_variance_f32(ptr(iwe), 1, h, w, int(omit), ptr(out), ptr(moments), ptr(scratch), nbytes,
+                                                  stream_ptr()), "ebos_image_variance")
         ctx.save_for_backward(flow32, iwe, moments)
-        ctx.meta = (plan, pad, int(omit), flow.dtype)
+        ctx.meta = (plan, pad, int(omit), flow.dtype, halo)
         return out[0].to(flow.dtype)
 
     @staticmethod
     def backward(ctx, g):
         lib = _hip.require_gpu()
         flow32, iwe, moments = ctx.saved_tensors
-        plan, pad, omit, fdt = ctx.meta
+        plan, pad, omit, fdt, halo = ctx.meta
         up = g.to(torch.float32).reshape(1).contiguous()
         affine = torch.empty(2, dtype=torch.float32, device=plan.device)
         with torch.cuda.device(plan.device):
             check(lib.ebos_image_variance_affine_f32(ptr(moments), ptr(up), 1, ptr(affine), stream_ptr()),
                   "ebos_image_variance_affine")
-        d_flow, _ = _launch_dense_bwd(plan, flow32, None, pad, iwe, affine, omit, False)
+        d_flow, _ = _launch_dense_bwd(plan, flow32, None, pad, iwe, affine, omit, False, halo)
         return d_flow.to(fdt), None, None, None, None, None
 
 

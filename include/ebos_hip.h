@@ -220,6 +220,37 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
                            float* d_weight, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Tile-private pipeline (the fast path): same mathematics as ebos_iwe_dense_tiled_f32 /
+ * ebos_iwe_dense_bwd_f32, organised so that no global float atomic and no zero-fill is left.
+ *
+ * ebos_iwe_dense_slab_f32   forward.  Each (tile, split) workgroup accumulates its tile + halo in LDS
+ *   (f64) and writes it once as a plain f32 "slab"; a combine pass sums the slabs covering each pixel,
+ *   OVERWRITES iwe [h, w] (no caller-side zeroing) and, if want_variance, also reduces the variance of
+ *   the image (omit_boundary as in the costs) into out_variance [1] (f32, nullable) and
+ *   moments [2] = (mean, M) (f64, nullable) -- the contrast cost of SURVEY.md A14 at no extra pass.
+ *   workspace: >= ebos_iwe_slab_workspace_bytes(...) bytes, ZERO-FILLED ONCE by the caller when it is
+ *   allocated; the kernels keep its spill section (taps beyond the halo) zero between calls.
+ *   Results are deterministic (fixed summation order) except for taps beyond the halo.
+ * ebos_iwe_dense_tiled_bwd_f32   backward.  One workgroup per tile: upstream image tile in LDS,
+ *   wavefront-segmented sums per source pixel, d_flow [2, H, W] OVERWRITTEN with plain stores
+ *   (binned plans only; g_image/affine/g_lo/d_weight as in ebos_iwe_dense_bwd_f32; d_weight in plan order).
+ * (tile_h, tile_w, halo) must be one of ebos_slab_config().
+ * ---------------------------------------------------------------------------------------- */
+int ebos_slab_config(int* out, int cap);
+size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h,
+                                     int pad_w);
+int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+                            const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
+                            int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
+                            size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary,
+                            float* out_variance, double* moments, ebos_stream_t stream);
+int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+                                 const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
+                                 int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
+                                 const float* affine, int g_lo, float* d_flow, float* d_weight,
+                                 ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused hot path, 2-DoF hypotheses (solver outer loop, SURVEY.md 3.4 / BASELINE config 5):
  *   A4 + A7 for K translations theta[k] = (theta0, theta1) in one pass over the events
  *   (src/warp.py:364-383 + src/event_image_converter.py:581-620).  iwes [K, h, w] accumulates.

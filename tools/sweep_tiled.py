@@ -70,6 +70,28 @@ def main():
                                                                P(iwe), stream), "plain"))
             if r:
                 times[name].append(t)
+    # tile-private slab pipeline (accumulate + combine [+ variance])
+    from event_based_bos_amd.event_plan import _launch_iwe_dense_slab, _launch_dense_bwd, _slab_ok
+    slab_times = {}
+    for c in cfgs:
+        th, tw, halo, sp = c
+        pl = plans[(th, tw)]
+        if not _slab_ok(pl, halo):
+            continue
+        for want_var in (False, True):
+            ts = []
+            for r in range(args.rounds + 1):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                out_iwe, var, _ = _launch_iwe_dense_slab(pl, flow, None, (0, 0), halo, sp, want_var, False)
+                b.record()
+                torch.cuda.synchronize()
+                if r:
+                    ts.append(a.elapsed_time(b))
+            err = (torch.linalg.norm(out_iwe - ref) / torch.linalg.norm(ref)).item()
+            assert err < 1e-5, (c, err)
+            slab_times[("slab+var" if want_var else "slab", c)] = ts
+    times.update(slab_times)
     n = args.events
     for k, v in times.items():
         med, mn = statistics.median(v), min(v)
@@ -78,6 +100,21 @@ def main():
     if args.bwd:
         g = torch.randn((H, W), dtype=torch.float32, device=dev)
         d_flow = torch.zeros((2, H, W), dtype=torch.float32, device=dev)
+        for c in cfgs:
+            th, tw, halo, sp = c
+            pl = plans[(th, tw)]
+            if sp != 1 or not _slab_ok(pl, halo):
+                continue
+            ts = []
+            for r in range(args.rounds + 1):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                df, _ = _launch_dense_bwd(pl, flow, None, (0, 0), g, None, 0, False, halo)
+                b.record()
+                torch.cuda.synchronize()
+                if r:
+                    ts.append(a.elapsed_time(b))
+            print(f"{'bwd_tiled ' + str(c):32s} median {statistics.median(ts)*1e3:9.1f} us  min {min(ts)*1e3:9.1f} us")
         for name, pl, srt in (("bwd_sorted", plans[cfgs[0][:2]], 1), ("bwd_unsorted", plain, 0)):
             ts = []
             for r in range(args.rounds + 1):
