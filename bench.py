@@ -8,8 +8,8 @@
 Workload (BASELINE.json configs[1]): one window of 10 M synthetic events (recipe of
 src/utils/event_utils.py:40-47, seed = rank) at 1280x720, dense per-pixel flow U(-30, 30)
 (src/utils/flow_utils.py:29), normalised time, reference time "first", variance contrast.
-One "step" = one evaluation of the contrast objective on the resident window:
-    zero IWE -> fused warp + bilinear splat (ebos_iwe_dense_tiled_f32) -> image variance.
+One "step" = one evaluation of the contrast objective on the resident window (ebos_iwe_dense_slab_f32):
+    fused warp + bilinear splat into tile-private LDS images -> slab combine (writes the IWE) -> variance.
 The window is resident in HBM in its plan form (SoA f32, binned by source tile: built once per window
 and reused by every solver iteration; its one-off build time is reported as plan_build_ms and is NOT
 in the timed region).  With N > 1 every rank owns an independent window (weak scaling, no collective
@@ -114,7 +114,6 @@ def main():
 
     import event_based_bos_amd as ebos
     from event_based_bos_amd import _hip
-    from event_based_bos_amd.event_plan import _launch_iwe_dense
 
     lib = _hip.require_gpu()
     n = args.events
@@ -128,26 +127,21 @@ def main():
     plan_build_ms = (time.perf_counter() - t0) * 1e3
     del ev_gpu
 
-    pad = (0, 0)
-    scratch_n = int(lib.ebos_cost_scratch_bytes(1))
+    import ctypes
+
+    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, args.tile[0], args.tile[1], args.halo, args.splits, 0, 0))
+    ws = torch.zeros(nws, dtype=torch.uint8, device=dev)  # zero-filled once (spill section stays zero)
     out = torch.empty(1, dtype=torch.float32, device=dev)
     moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
-    scratch = torch.empty(scratch_n, dtype=torch.uint8, device=dev)
-    iwe = torch.zeros((H, W), dtype=torch.float32, device=dev)
+    iwe = torch.empty((H, W), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     P = lambda t: t.data_ptr()
 
-    def step(ev_pair=None):
-        iwe.zero_()
-        if ev_pair is not None:
-            ev_pair[0].record()
-        _hip.check(lib.ebos_iwe_dense_tiled_f32(P(plan.x), P(plan.y), P(plan.dt), None, P(plan.key_offsets), plan.n,
-                                                P(flow), H, W, args.tile[0], args.tile[1], args.halo, args.splits,
-                                                0, 0, P(iwe), stream), "ebos_iwe_dense_tiled")
-        if ev_pair is not None:
-            ev_pair[1].record()
-        _hip.check(lib.ebos_image_variance_f32(P(iwe), 1, H, W, 0, P(out), P(moments), P(scratch), scratch_n, stream),
-                   "ebos_image_variance")
+    def step():
+        # one objective evaluation: tile accumulate -> slab combine (writes the IWE) -> variance
+        _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, P(plan.key_offsets), plan.n, P(flow),
+                                               H, W, args.tile[0], args.tile[1], args.halo, args.splits, 0, 0, P(ws), nws,
+                                               P(iwe), 1, 0, P(out), P(moments), stream), "ebos_iwe_dense_slab")
 
     def sync_all():
         torch.cuda.synchronize()
@@ -157,18 +151,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync_all()
+    _hip.check(lib.ebos_profile_start(args.steps), "ebos_profile_start")  # HIP events around the dominant kernel
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(pairs[k])
+        step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    buf = (ctypes.c_float * args.steps)()
+    nrec = lib.ebos_profile_stop(buf, args.steps)
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kernel_ms = statistics.mean(a.elapsed_time(b) for a, b in pairs)
+    kernel_ms = statistics.mean(buf[i] for i in range(nrec)) if nrec else float("nan")
     contrast = float(out.item())
 
     # extra (untimed-by-contract) measurement: forward + backward of the objective
@@ -196,7 +192,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("iwe_dense_tiled_hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("iwe_slab_accumulate_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -204,11 +200,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
-                                   "variance cost, fwd objective (zero IWE + fused warp/splat + variance)",
+                                   "variance cost, fwd objective (tile accumulate + slab combine + variance)",
                        "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
                        "layout": f"SoA f32 (x,y,dt), binned by source tile {args.tile[0]}x{args.tile[1]}, halo {args.halo}, "
                                  f"splits {args.splits}", "parallelism": f"windows sharded, {world} rank(s), no collective"},
-            "roofline": {"bound": "hbm", "kernel": "iwe_dense_tiled_kernel", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "iwe_slab_accumulate_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes},
             "plan_build_ms": round(plan_build_ms, 2), "fwd_bwd_ms": round(fwdbwd_ms, 4),

@@ -42,6 +42,8 @@ _GM = [_P, _I, _I, _I, _I, _P, _P, _Z, _P]
 _GM_GRAD = [_P, _I, _I, _I, _I, _P, _P, _P]
 _GAUSS = [_P, _P, _L, _L, _L, _P, _I, _I, _P]
 SIGNATURES = {
+    "ebos_profile_start": (_I, [_I]),
+    "ebos_profile_stop": (_I, [C.POINTER(C.c_float), _I]),
     "ebos_version": (_I, []),
     "ebos_last_error": (C.c_char_p, []),
     "ebos_build_info": (C.c_char_p, []),

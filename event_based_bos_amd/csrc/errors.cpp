@@ -1,6 +1,9 @@
 // errors.cpp -- thread-local error string + version/build info of libebos_hip.so.
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+
+#include <vector>
 
 #include "ebos_hip.h"
 
@@ -13,9 +16,63 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- optional in-library kernel timing (bench.py's roofline leg) -------------------------------
+// When enabled, the launcher of the dominant kernel brackets it with a HIP event pair on the very
+// stream it launches on.  Off by default: zero cost, nothing recorded.
+struct ProfileState {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  int used = 0;
+};
+static ProfileState g_prof;
+
+void profile_mark(hipStream_t s, bool begin) {
+  if (!g_prof.on) return;
+  const int pairs = (int)g_prof.ev.size() / 2;
+  if (g_prof.used >= pairs) return;
+  if (begin) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  } else {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
+    ++g_prof.used;
+  }
+}
 }  // namespace ebos
 
 extern "C" {
+int ebos_profile_start(int max_records) {
+  using namespace ebos;
+  if (max_records <= 0 || g_prof.on) {
+    set_error("ebos_profile_start: bad max_records or profiling already on");
+    return EBOS_ERR_INVALID_ARG;
+  }
+  g_prof.ev.resize(2 * (size_t)max_records);
+  for (auto& e : g_prof.ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      set_error("ebos_profile_start: hipEventCreate failed");
+      return EBOS_ERR_LAUNCH;
+    }
+  g_prof.used = 0;
+  g_prof.on = true;
+  return EBOS_OK;
+}
+int ebos_profile_stop(float* ms, int cap) {
+  using namespace ebos;
+  if (!g_prof.on) return 0;
+  g_prof.on = false;
+  int n = 0;
+  for (int i = 0; i < g_prof.used; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) == hipSuccess &&
+        hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) == hipSuccess && ms != nullptr && n < cap)
+      ms[n++] = t;
+  }
+  for (auto& e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.used = 0;
+  return n;
+}
 int ebos_version(void) { return EBOS_ABI_VERSION; }
 const char* ebos_last_error(void) { return ebos::g_err; }
 const char* ebos_build_info(void) {

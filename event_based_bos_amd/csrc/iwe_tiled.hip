@@ -24,6 +24,8 @@
 //
 // reference semantics: src/warp.py:330-342 + src/event_image_converter.py:581-620 (forward);
 // their autograd w.r.t. the flow and the per-event weight (backward).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -98,38 +100,59 @@ __device__ __forceinline__ TileRange tile_range(const int32_t* __restrict__ key_
 // ---------------------------------------------------------------------------------------------------
 // forward A: accumulate one (tile, split) in LDS, write it as a slab
 // ---------------------------------------------------------------------------------------------------
-template <int TH, int TW, int HALO, bool HAS_W>
-__global__ void __launch_bounds__(kBlock)
-iwe_slab_accumulate_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
-                           const float* __restrict__ weight, const int32_t* __restrict__ key_offsets,
-                           const float* __restrict__ flow, int H, int W, int tiles_x, int splits, int pad_h, int pad_w,
-                           float* __restrict__ slabs, float* spill) {
+// Two LDS accumulation modes (same 8 bytes per cell):
+//   F64  one double per cell, 4 ds_add_f64 per event.  Exact for any per-event weight.
+//   FX   fixed point, scale 2^kFxShift.  The two horizontally adjacent taps of a row share ONE 64-bit
+//        word as two signed 32-bit fields (hi = column c+1, lo = column c), so an event costs 2
+//        ds_add_u64 (measured ~4.6 lanes/clk/CU vs ~2.8 for ds_add_f64, and half as many of them).
+//        Plane A holds the pairs starting at even columns, plane B those starting at odd columns.
+//        Integer adds commute: the tile sum is exact and bit-reproducible.  A field overflows only if
+//        one cell collects more than 2^(31-kFxShift) = 2048 units of weight inside one workgroup; that
+//        is DETECTED exactly -- a wrapped field changes the decoded total by a multiple of 2^32 - 1,
+//        and all contributions have one sign, so sum(decoded fields) != sum(added) -- and the
+//        workgroup then redoes its slice in F64 mode.  Used for unit weights (the hot path).
+constexpr int kFxShift = 20;
+constexpr float kFxScale = (float)(1 << kFxShift);
+constexpr double kFxInv = 1.0 / (double)(1 << kFxShift);
+
+enum AccMode { ACC_F64 = 0, ACC_FX = 1 };
+
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, bool DO_SPILL>
+__device__ __forceinline__ long long accumulate_slice(const TileRange& tr, double* s_acc, const float* __restrict__ xs,
+                                                      const float* __restrict__ ys, const float* __restrict__ dts,
+                                                      const float* __restrict__ weight, const float* __restrict__ flow,
+                                                      int H, int W, int pad_h, int pad_w, float* spill) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  extern __shared__ double s_acc[];  // [LH][LW]
-  const TileRange tr = tile_range(key_offsets, TH * TW, tiles_x, splits);
-
-  for (int i = threadIdx.x; i < LH * LW; i += kBlock) s_acc[i] = 0.0;
-  __syncthreads();
-
+  unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
   const int64_t hw = (int64_t)H * W;
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
   const int oy = tr.ty * TH - HALO, ox = tr.tx * TW - HALO;  // LDS cell (0,0) = un-padded pixel (oy, ox)
-
   const float* __restrict__ flow1 = flow + hw;
+  long long added = 0;  // FX: exact integer total this thread put into LDS
+  if (tr.beg >= tr.end) return 0;
+  // 3-stage software pipeline per thread:  SoA loads of batch k+2 | flow gathers of batch k+1 | LDS adds of batch k.
+  // Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
   int32_t base = tr.beg + threadIdx.x;
-  Batch cur;
-  if (tr.beg < tr.end) load_batch<HAS_W>(cur, base, tr.end, xs, ys, dts, weight);
-  while (base < tr.end) {
-    float fu[kUnroll], fv[kUnroll];
+  Batch cur, nxt;
+  load_batch<HAS_W>(cur, base, tr.end, xs, ys, dts, weight);
+  load_batch<HAS_W>(nxt, base + kBlock * kUnroll, tr.end, xs, ys, dts, weight);
+  float fu[kUnroll], fv[kUnroll];
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {  // flow gathers of the current batch (sorted events: broadcast/adjacent)
-      const int lin = (int)cur.x[k] * W + (int)cur.y[k];
-      fu[k] = flow[lin];
-      fv[k] = flow1[lin];
+  for (int k = 0; k < kUnroll; ++k) {
+    const int lin = (int)cur.x[k] * W + (int)cur.y[k];
+    fu[k] = flow[lin];
+    fv[k] = flow1[lin];
+  }
+  while (base < tr.end) {
+    float gu[kUnroll], gv[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {  // gathers of the NEXT batch (sorted events: broadcast / adjacent addresses)
+      const int lin = (int)nxt.x[k] * W + (int)nxt.y[k];
+      gu[k] = flow[lin];
+      gv[k] = flow1[lin];
     }
-    Batch nxt;  // next batch's coalesced loads go out before this batch's LDS work and stay in flight
-    const int32_t nbase = base + kBlock * kUnroll;
-    load_batch<HAS_W>(nxt, nbase, tr.end, xs, ys, dts, weight);
+    Batch nn;  // loads two batches ahead
+    load_batch<HAS_W>(nn, base + 2 * kBlock * kUnroll, tr.end, xs, ys, dts, weight);
 #pragma unroll
     for (int k = 0; k < kUnroll; ++k) {
       if (base + k * kBlock >= tr.end) break;
@@ -138,16 +161,28 @@ iwe_slab_accumulate_kernel(const float* __restrict__ xs, const float* __restrict
       const float w00 = a * b * wv, w10 = f.fr * b * wv, w01 = a * f.fc * wv, w11 = f.fr * f.fc * wv;
       const int rl = f.R - oy, cl = f.C - ox;
       if (f.ok && rl >= 0 && rl < LH - 1 && cl >= 0 && cl < LW - 1) {
-        double* p = &s_acc[rl * LW + cl];
-        atomic_add(p, (double)w00);
-        atomic_add(p + LW, (double)w10);
-        atomic_add(p + 1, (double)w01);
-        atomic_add(p + LW + 1, (double)w11);
-      } else if (f.ok) {  // beyond the halo: spill image (zero-invariant scratch, folded in by the combine pass)
+        if (MODE == ACC_FX) {
+          const int q00 = __float2int_rn(w00 * kFxScale), q10 = __float2int_rn(w10 * kFxScale);
+          const int q01 = __float2int_rn(w01 * kFxScale), q11 = __float2int_rn(w11 * kFxScale);
+          // word = (hi << 32) + lo as a 64-bit integer: a (tiny) negative lo borrows from hi, decode undoes it
+          const long long v0 = ((long long)q01 << 32) + (long long)q00;
+          const long long v1 = ((long long)q11 << 32) + (long long)q10;
+          unsigned long long* p = s_fx + (cl & 1) * (LH * LW / 2) + rl * (LW / 2) + (cl >> 1);
+          atomicAdd(p, (unsigned long long)v0);
+          atomicAdd(p + LW / 2, (unsigned long long)v1);
+          added += (long long)q00 + q10 + q01 + q11;
+        } else {
+          double* p = &s_acc[rl * LW + cl];
+          atomic_add(p, (double)w00);
+          atomic_add(p + LW, (double)w10);
+          atomic_add(p + 1, (double)w01);
+          atomic_add(p + LW + 1, (double)w11);
+        }
+      } else if (DO_SPILL && f.ok) {  // beyond the halo: spill image (zero-invariant scratch, folded in by the combine pass)
         const int R = f.R + pad_h, C = f.C + pad_w;
         const bool r0 = R >= 0 && R < h, r1 = R + 1 >= 0 && R + 1 < h;
         const bool c0 = C >= 0 && C < w, c1 = C + 1 >= 0 && C + 1 < w;
-        const int64_t gb = (int64_t)R * w + C;
+        const int gb = R * w + C;
         if (r0 && c0) atomic_add(&spill[gb], w00);
         if (r1 && c0) atomic_add(&spill[gb + w], w10);
         if (r0 && c1) atomic_add(&spill[gb + 1], w01);
@@ -155,16 +190,104 @@ iwe_slab_accumulate_kernel(const float* __restrict__ xs, const float* __restrict
       }
     }
     cur = nxt;
-    base = nbase;
+    nxt = nn;
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      fu[k] = gu[k];
+      fv[k] = gv[k];
+    }
+    base += kBlock * kUnroll;
   }
+  return added;
+}
+
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// signed fields of a paired word
+__device__ __forceinline__ long long fx_lo(long long v) { return (long long)(int)(unsigned)(v & 0xffffffffll); }
+__device__ __forceinline__ long long fx_hi(long long v) { return (v - fx_lo(v)) >> 32; }
+
+template <int TH, int TW, int HALO, bool HAS_W, int MODE>
+__global__ void __launch_bounds__(kBlock)
+iwe_slab_accumulate_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
+                           const float* __restrict__ weight, const int32_t* __restrict__ key_offsets,
+                           const float* __restrict__ flow, int H, int W, int tiles_x, int splits, int pad_h, int pad_w,
+                           float* __restrict__ slabs, float* spill) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
+  extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words
+  __shared__ long long s_chk[2 * kBlock / kWave];
+  __shared__ int s_bad;
+  const TileRange tr = tile_range(key_offsets, TH * TW, tiles_x, splits);
+
+  for (int i = threadIdx.x; i < LH * LW; i += kBlock) s_acc[i] = 0.0;  // all-zero bits = 0 in both modes
   __syncthreads();
 
-  // slab = the LDS image as f32, 16 B per lane, fully coalesced plain stores
+  const long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, true>(tr, s_acc, xs, ys, dts, weight, flow, H, W,
+                                                                            pad_h, pad_w, spill);
+  __syncthreads();
+
   float4* out = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * (LH * LW));
-  static_assert((LH * LW) % 4 == 0, "slab size must be a multiple of 4 cells");
-  for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
-    const double* p = &s_acc[4 * i];
-    out[i] = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+  bool f64_flush = (MODE == ACC_F64);
+  if (MODE == ACC_FX) {
+    // verify: decoded total == added total (exact integers)
+    const long long* s_fx = reinterpret_cast<const long long*>(s_acc);
+    long long decoded = 0;
+    for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
+      const long long v = s_fx[i];
+      decoded += fx_lo(v) + fx_hi(v);
+    }
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    const long long a = wave_sum_ll(added), d = wave_sum_ll(decoded);
+    if (lane == 0) {
+      s_chk[2 * wid] = a;
+      s_chk[2 * wid + 1] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long ta = 0, td = 0;
+      for (int k = 0; k < kBlock / kWave; ++k) {
+        ta += s_chk[2 * k];
+        td += s_chk[2 * k + 1];
+      }
+      s_bad = (ta != td);
+    }
+    __syncthreads();
+    if (s_bad) {  // a field wrapped: redo this slice exactly in f64 (the spill taps were already issued)
+      for (int i = threadIdx.x; i < LH * LW; i += kBlock) s_acc[i] = 0.0;
+      __syncthreads();
+      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, false>(tr, s_acc, xs, ys, dts, weight, flow, H, W, pad_h, pad_w, spill);
+      __syncthreads();
+      f64_flush = true;
+    } else {
+      // decode 4 consecutive cells c0..c0+3 of one row (c0 % 4 == 0) from planes A and B
+      const long long* pa = s_fx;
+      const long long* pb = s_fx + LH * LW / 2;
+      for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
+        const int r = i / (LW / 4), j = i - r * (LW / 4);  // cells 4j..4j+3, words 2j, 2j+1
+        const int wrow = r * (LW / 2);
+        const long long a0 = pa[wrow + 2 * j], a1 = pa[wrow + 2 * j + 1];
+        const long long b0 = pb[wrow + 2 * j], b1 = pb[wrow + 2 * j + 1];
+        const long long bm = j > 0 ? pb[wrow + 2 * j - 1] : 0;  // pair (4j-1, 4j)
+        const long long c0 = fx_lo(a0) + fx_hi(bm);
+        const long long c1 = fx_hi(a0) + fx_lo(b0);
+        const long long c2 = fx_lo(a1) + fx_hi(b0);
+        const long long c3 = fx_hi(a1) + fx_lo(b1);
+        out[i] = make_float4((float)((double)c0 * kFxInv), (float)((double)c1 * kFxInv), (float)((double)c2 * kFxInv),
+                             (float)((double)c3 * kFxInv));
+      }
+    }
+  }
+  if (f64_flush) {
+    // slab = the LDS image as f32, 16 B per lane, fully coalesced plain stores
+    for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
+      const double* p = &s_acc[4 * i];
+      out[i] = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+    }
   }
 }
 
@@ -209,6 +332,76 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
   if (partials != nullptr) {
     const bool in = C < w && R >= g_lo && R < h - g_lo && C >= g_lo && C < w - g_lo;
     double s = in ? (double)v : 0.0, ss = in ? (double)v * (double)v : 0.0;
+    __shared__ double red[kCombineBlock / kWave];
+    s = block_sum(s, red);
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+      const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+      partials[2 * b] = s;
+      partials[2 * b + 1] = ss;
+    }
+  }
+}
+
+// 4 pixels per thread (float4 loads/stores), 4 rows x 256 columns per workgroup -> ~900 workgroups and as
+// many moment partials at 1280x720.  Needs w, pad_w, HALO, TW multiples of 4 (the scalar kernel covers the rest).
+constexpr int kCombineRows = 4;
+
+template <int TH, int TW, int HALO>
+__global__ void __launch_bounds__(kCombineBlock)
+iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
+                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  static_assert(HALO % 4 == 0 && TW % 4 == 0, "vector combine needs 4-aligned windows");
+  const int h = H + 2 * pad_h, w = W + 2 * pad_w;
+  const int tx_ = threadIdx.x & 63, ty_ = threadIdx.x >> 6;
+  const int R = blockIdx.y * kCombineRows + ty_, C = (blockIdx.x * 64 + tx_) * 4;
+  const int r = R - pad_h, c = C - pad_w;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool live = R < h && C < w;
+  if (live) {
+    int ty0 = (r - HALO - TH + 1 >= 0) ? (r - HALO - TH + 1 + TH - 1) / TH : 0;
+    int ty1 = (r + HALO >= 0) ? (r + HALO) / TH : -1;
+    if (ty1 > tiles_y - 1) ty1 = tiles_y - 1;
+    int tx0 = (c - HALO - TW + 1 >= 0) ? (c - HALO - TW + 1 + TW - 1) / TW : 0;
+    int tx1 = (c + HALO >= 0) ? (c + HALO) / TW : -1;
+    if (tx1 > tiles_x - 1) tx1 = tiles_x - 1;
+    for (int ty = ty0; ty <= ty1; ++ty) {
+      const int rl = r - (ty * TH - HALO);
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int cl = c - (tx * TW - HALO);
+        const float* sp = slabs + ((int64_t)(ty * tiles_x + tx) * splits) * (LH * LW) + rl * LW + cl;
+        for (int p = 0; p < splits; ++p) {
+          const float4 t = *reinterpret_cast<const float4*>(sp + (int64_t)p * (LH * LW));
+          v.x += t.x;
+          v.y += t.y;
+          v.z += t.z;
+          v.w += t.w;
+        }
+      }
+    }
+    const int64_t gi = (int64_t)R * w + C;
+    const float4 s4 = *reinterpret_cast<const float4*>(spill + gi);
+    if (s4.x != 0.f || s4.y != 0.f || s4.z != 0.f || s4.w != 0.f) {
+      v.x += s4.x;
+      v.y += s4.y;
+      v.z += s4.z;
+      v.w += s4.w;
+      *reinterpret_cast<float4*>(spill + gi) = make_float4(0.f, 0.f, 0.f, 0.f);  // keep the spill image zero
+    }
+    *reinterpret_cast<float4*>(iwe + gi) = v;
+  }
+  if (partials != nullptr) {
+    double s = 0.0, ss = 0.0;
+    if (live && R >= g_lo && R < h - g_lo) {
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (C + k >= g_lo && C + k < w - g_lo) {
+          s += (double)e[k];
+          ss += (double)e[k] * (double)e[k];
+        }
+    }
     __shared__ double red[kCombineBlock / kWave];
     s = block_sum(s, red);
     ss = block_sum(ss, red);
@@ -418,7 +611,7 @@ int reserve_lds(K kern, size_t lds, const char* what) {
 template <int TH, int TW, int HALO>
 int launch_slab_fwd(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* key_offsets,
                     const float* flow, int H, int W, int splits, int pad_h, int pad_w, char* ws, float* iwe, int want_var,
-                    int omit, float* out_var, double* moments, hipStream_t s) {
+                    int omit, float* out_var, double* moments, int acc_mode, hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr size_t lds = (size_t)LH * LW * sizeof(double);
   static_assert(lds <= 160 * 1024, "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
@@ -426,17 +619,33 @@ int launch_slab_fwd(const float* xs, const float* ys, const float* dts, const fl
   float* slabs = reinterpret_cast<float*>(ws);
   float* spill = reinterpret_cast<float*>(ws + L.off_spill);
   double* partials = reinterpret_cast<double*>(ws + L.off_partials);
-  auto ka = weight ? iwe_slab_accumulate_kernel<TH, TW, HALO, true> : iwe_slab_accumulate_kernel<TH, TW, HALO, false>;
+  // unit weights -> verified fixed point (2 ds_add_u64 per event); per-event weights -> f64 (any magnitude/sign)
+  auto ka = weight ? iwe_slab_accumulate_kernel<TH, TW, HALO, true, ACC_F64>
+                   : (acc_mode == ACC_F64 ? iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_F64>
+                                          : iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX>);
   if (int rc = reserve_lds(ka, lds, "ebos_iwe_dense_slab")) return rc;
+  profile_mark(s, true);
   ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(xs, ys, dts, weight, key_offsets, flow, H, W, L.tiles_x, splits, pad_h,
                                                        pad_w, slabs, spill);
-  dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
-  iwe_slab_combine_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W, pad_h,
-                                                                          pad_w, iwe, omit ? 1 : 0, want_var ? partials : nullptr);
+  profile_mark(s, false);
+  int64_t nparts;
+  if (L.w % 4 == 0 && pad_w % 4 == 0) {
+    dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows);
+    nparts = (int64_t)gb.x * gb.y;
+    iwe_slab_combine4_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
+                                                                             pad_h, pad_w, iwe, omit ? 1 : 0,
+                                                                             want_var ? partials : nullptr);
+  } else {
+    dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
+    nparts = (int64_t)gb.x * gb.y;
+    iwe_slab_combine_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
+                                                                            pad_h, pad_w, iwe, omit ? 1 : 0,
+                                                                            want_var ? partials : nullptr);
+  }
   if (want_var) {
     const int lo = omit ? 1 : 0;
     const int64_t m = (int64_t)(L.h - 2 * lo > 0 ? L.h - 2 * lo : 0) * (L.w - 2 * lo > 0 ? L.w - 2 * lo : 0);
-    moments_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, L.combine_blocks, m, out_var, moments);
+    moments_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, nparts, m, out_var, moments);
   }
   return EBOS_OK;
 }
@@ -513,10 +722,14 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
   }
   hipStream_t s = as_stream(stream);
   char* ws = reinterpret_cast<char*>(workspace);
+  static const int acc_mode = [] {  // EBOS_SLAB_ACC=f64 forces the f64 accumulator (debug / A-B runs)
+    const char* e = getenv("EBOS_SLAB_ACC");
+    return (e && e[0] == 'f') ? (int)ACC_F64 : (int)ACC_FX;
+  }();
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                          \
   launch_slab_fwd<TH, TW, HL>(xs, ys, dts, weight, key_offsets, flow, H, W, splits, pad_h, pad_w, ws, iwe, want_variance, \
-                              omit_boundary, out_variance, moments, s)
+                              omit_boundary, out_variance, moments, acc_mode, s)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

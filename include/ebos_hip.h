@@ -61,6 +61,14 @@ typedef enum ebos_splat_mode {
   EBOS_SPLAT_POLARITY = 2  /* "polarity" (:355-363): image is [b,2,h,w]; channel 0 <- p > 0 */
 } ebos_splat_mode;
 
+/* Optional timing of the dominant kernel (the tile accumulate pass of ebos_iwe_dense_slab_f32): between
+ * ebos_profile_start(max_records) and ebos_profile_stop() every launch of that kernel is bracketed by a
+ * HIP event pair on the stream it runs on.  ebos_profile_stop synchronises those events, writes up to
+ * `cap` durations in milliseconds to the HOST array `ms` and returns how many it wrote.  Not thread-safe;
+ * off by default. */
+int ebos_profile_start(int max_records);
+int ebos_profile_stop(float* ms, int cap);
+
 int ebos_version(void);               /* EBOS_ABI_VERSION of the loaded library */
 const char* ebos_last_error(void);    /* host string                            */
 const char* ebos_build_info(void);    /* host string: arch, compiler, options   */

@@ -319,6 +319,33 @@ def test_fused_dense_costs_padding_weights(ebos, cost, omit):
     assert rel(wt.grad.cpu().numpy(), dw_ref) < 1e-3
 
 
+def test_fixed_point_tile_overflow_falls_back_exactly(ebos):
+    """The tile-private forward accumulates unit-weight events in verified fixed point (2048 units of weight
+    per LDS cell per workgroup).  A hot pixel beyond that must be detected and redone in f64."""
+    h, w = 64, 64
+    n_hot = 20_000
+    ev = O.synth_events(30_000, h, w, seed=21)
+    hot = np.tile(np.array([[10.0, 12.0, 0.0, 1.0]]), (n_hot, 1))
+    hot[:, 2] = np.linspace(0.0, 0.5, n_hot)
+    ev = np.concatenate([ev, hot], 0)
+    ev = ev[np.argsort(ev[:, 2], kind="stable")]
+    fl = np.zeros((2, h, w))  # zero flow: all 20k hot events land on pixel (10, 12) with weight 1
+    fl[:, 40:, :] = O.synth_dense_flow(h, w, seed=22, max_val=3.0)[:, 40:, :]
+    ref = O.iwe_dense(torch.from_numpy(ev), torch.from_numpy(fl), (h, w)).numpy()
+    assert ref[10, 12] > 20_000
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile=(32, 32))
+    iwe = plan.iwe_dense(G(fl, torch.float32), halo=16)
+    assert rel(iwe.cpu().numpy(), ref) < 1e-6
+    assert abs(iwe[10, 12].item() - ref[10, 12]) < 1e-2
+    # determinism of the fixed-point path: two runs are bit-identical
+    ev2 = O.synth_events(40_000, h, w, seed=23)
+    fl2 = O.synth_dense_flow(h, w, seed=24, max_val=8.0)
+    plan2 = ebos.EventPlan.build(G(ev2), (h, w), "first", True, tile=(32, 32))
+    a = plan2.iwe_dense(G(fl2, torch.float32), halo=16)
+    b = plan2.iwe_dense(G(fl2, torch.float32), halo=16)
+    assert torch.equal(a, b)
+
+
 def test_fused_2dof_hypotheses(ebos):
     h, w, n = 100, 120, 50_000
     ev = O.synth_events(n, h, w, seed=9)
