@@ -1,0 +1,69 @@
+"""Multi-process (gloo, world size 2, CPU) test of the N>1 path: units are partitioned, evaluated
+independently and gathered; the sharded result equals the single-process result bit for bit.
+The per-unit compute here is the CPU oracle standing in for the GPU kernels (tests may use it as such)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from event_based_bos_amd.sharding import gather_results, run_sharded, shard_units
+
+
+def test_shard_units_partitions():
+    for n in (0, 1, 7, 64, 512):
+        for world in (1, 2, 3, 8):
+            for mode in ("round_robin", "block"):
+                owned = [shard_units(n, world, r, mode) for r in range(world)]
+                flat = sorted(i for o in owned for i in o)
+                assert flat == list(range(n)), (n, world, mode)
+    assert shard_units(512, 8, 3, "block") == list(range(192, 256))
+    assert shard_units(64, 8, 3) == [3, 11, 19, 27, 35, 43, 51, 59]
+    with pytest.raises(ValueError):
+        shard_units(4, 2, 2)
+    with pytest.raises(ValueError):
+        shard_units(4, 2, 0, "zigzag")
+
+
+def _unit_contrast(i, seed):
+    from oracle import ebos_oracle as O
+
+    ev = torch.from_numpy(O.synth_events(2000, 24, 32, seed=seed))
+    fl = torch.from_numpy(O.synth_dense_flow(24, 32, seed=100 + seed, max_val=4.0))
+    return float(O.image_variance(O.iwe_dense(ev, fl, (24, 32))).item())
+
+
+def _worker(rank, world, port, seeds, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = run_sharded(seeds, _unit_contrast, mode="round_robin")
+        res_b = run_sharded(seeds, _unit_contrast, mode="block")
+        assert res == res_b
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, np.array(res))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_sharded_equals_single_process(tmp_path):
+    seeds = list(range(7))
+    single = [_unit_contrast(i, s) for i, s in enumerate(seeds)]
+    assert run_sharded(seeds, _unit_contrast) == single  # world size 1: no process group needed
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(2, _free_port(), seeds, out), nprocs=2, join=True)
+    np.testing.assert_array_equal(np.load(out), np.array(single))  # bit for bit: no reduction across shards
+
+
+def test_gather_detects_duplicates():
+    assert gather_results({0: 1.0, 2: 3.0}) == {0: 1.0, 2: 3.0}
