@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--halo", type=int, default=32)
     ap.add_argument("--splits", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-compact", action="store_true", help="read the 12 B/event (x, y, dt) plan instead of 6 B/event")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     args = ap.parse_args()
 
@@ -137,9 +138,12 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     P = lambda t: t.data_ptr()
 
+    pix_ptr = plan.pix.data_ptr() if (plan.pix is not None and not args.no_compact) else None
+    bytes_per_event = 6.0 if pix_ptr else 12.0
+
     def step():
         # one objective evaluation: tile accumulate -> slab combine (writes the IWE) -> variance
-        _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, P(plan.key_offsets), plan.n, P(flow),
+        _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, pix_ptr, P(plan.key_offsets), plan.n, P(flow),
                                                H, W, args.tile[0], args.tile[1], args.halo, args.splits, 0, 0, P(ws), nws,
                                                P(iwe), 1, 0, P(out), P(moments), stream), "ebos_iwe_dense_slab")
 
@@ -186,8 +190,10 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed / 1e6
-        algo_bytes = 12.0 * plan.n + 12.0 * H * W  # x, y, dt (p unused) + flow read (8 B/px) + IWE write (4 B/px)
+        # 12 B/event (x, y, dt; p unused) + flow read (8 B/px) + IWE write (4 B/px)
+        algo_bytes = 12.0 * plan.n + 12.0 * H * W
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        format_bytes = bytes_per_event * plan.n + 12.0 * H * W  # what the plan format actually stores per event
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -202,11 +208,13 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
                                    "variance cost, fwd objective (tile accumulate + slab combine + variance)",
                        "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
-                       "layout": f"SoA f32 (x,y,dt), binned by source tile {args.tile[0]}x{args.tile[1]}, halo {args.halo}, "
-                                 f"splits {args.splits}", "parallelism": f"windows sharded, {world} rank(s), no collective"},
+                       "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if pix_ptr else "SoA f32 (x,y,dt), 12 B/event")
+                                 + f", binned by source tile {args.tile[0]}x{args.tile[1]}, halo {args.halo}, splits {args.splits}", "parallelism": f"windows sharded, {world} rank(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": "iwe_slab_accumulate_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes},
+                         "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
+                         "plan_format_bytes": format_bytes,
+                         "plan_format_GBps": round(format_bytes / (kernel_ms * 1e-3) / 1e9, 1)},
             "plan_build_ms": round(plan_build_ms, 2), "fwd_bwd_ms": round(fwdbwd_ms, 4),
             "fwd_bwd_mevents_per_s": round(n / fwdbwd_ms / 1e3, 2), "contrast": contrast,
         }

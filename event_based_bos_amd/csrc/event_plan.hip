@@ -135,7 +135,10 @@ __global__ void __launch_bounds__(256)
 bin_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dt,
                    const float* __restrict__ p, int64_t n, int H, int W, int tile_h, int tile_w, int tiles_x,
                    const int32_t* __restrict__ key_offsets, int32_t* cursor, float* __restrict__ xs,
-                   float* __restrict__ ys, float* __restrict__ dts, float* __restrict__ ps, int32_t* __restrict__ perm) {
+                   float* __restrict__ ys, float* __restrict__ dts, float* __restrict__ ps, int32_t* __restrict__ perm,
+                   uint16_t* __restrict__ pix, int32_t* frac_count) {
+  const int tile_px = tile_h * tile_w;
+  int fractional = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float ex = x[i], ey = y[i];
     const int key = source_key(ex, ey, H, W, tile_h, tile_w, tiles_x);
@@ -146,7 +149,10 @@ bin_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, con
     dts[pos] = dt[i];
     if (ps != nullptr) ps[pos] = p ? p[i] : 0.f;
     if (perm != nullptr) perm[pos] = (int32_t)i;
+    if (pix != nullptr) pix[pos] = (uint16_t)(key % tile_px);  // tile-local source pixel (compact format)
+    fractional += (ex != (float)(int)ex) || (ey != (float)(int)ey) || ex < 0.f || ey < 0.f;
   }
+  if (frac_count != nullptr && fractional) atomicAdd(frac_count, fractional);
 }
 
 template <typename T>
@@ -190,8 +196,8 @@ size_t ebos_bin_scratch_bytes(int64_t n_keys) {
 
 int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const float* p, int64_t n, int H, int W,
                         int tile_h, int tile_w, float* xs, float* ys, float* dts, float* ps, int32_t* perm,
-                        int32_t* key_offsets, int32_t* oob_count, void* scratch, size_t scratch_bytes,
-                        ebos_stream_t stream) {
+                        int32_t* key_offsets, int32_t* oob_count, uint16_t* pix, int32_t* frac_count, void* scratch,
+                        size_t scratch_bytes, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && n >= 0 && n < (int64_t)1 << 31,
                "ebos_bin_events: bad sizes n=%lld H=%d W=%d tile=%dx%d", (long long)n, H, W, tile_h, tile_w);
@@ -222,7 +228,8 @@ int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const f
   scan_add_offsets_kernel<<<dim3(nblk), dim3(kScanBlock), 0, s>>>(key_offsets, n_keys, block_sums);
   if (n > 0)
     bin_scatter_kernel<<<dim3(stream_grid(n, 256)), dim3(256), 0, s>>>(x, y, dt, p, n, H, W, tile_h, tile_w, tiles_x,
-                                                                      key_offsets, cursor, xs, ys, dts, ps, perm);
+                                                                      key_offsets, cursor, xs, ys, dts, ps, perm,
+                                                                      tile_h * tile_w <= 65536 ? pix : nullptr, frac_count);
   EBOS_CHECK_LAUNCH("ebos_bin_events");
   return EBOS_OK;
 }

@@ -35,17 +35,14 @@ namespace {
 
 constexpr float kEps = 1e-6f;  // src/event_image_converter.py:586
 constexpr int kBlock = 1024;
-constexpr int kUnroll = 4;     // events per thread per pipeline stage
 
 struct Taps {
   int R, C;      // top-left tap (un-padded image coordinates)
   float fr, fc;  // fractional offsets
   bool ok;       // finite
 };
-// source-pixel-relative warp arithmetic (see iwe_fused.hip): keeps |fx + d| <~ 32 in f32
-__device__ __forceinline__ Taps warped_taps(float ex, float ey, float dx, float dy) {
-  const int rs = (int)ex, cs = (int)ey;
-  const float lx = (ex - (float)rs) + dx, ly = (ey - (float)cs) + dy;
+// source-pixel-relative warp arithmetic (see iwe_fused.hip): x' = rs + (fx + dx) keeps the f32 operand <~ 32
+__device__ __forceinline__ Taps warped_taps(int rs, int cs, float lx, float ly) {
   const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
   Taps t;
   t.fr = lx - r0;
@@ -56,26 +53,65 @@ __device__ __forceinline__ Taps warped_taps(float ex, float ey, float dx, float 
   return t;
 }
 
-struct Batch {
-  float x[kUnroll], y[kUnroll], dt[kUnroll], w[kUnroll];
+// Event formats of a binned plan.  Both are read 4 consecutive events per lane (16-byte loads).
+//   FMT_XY       x f32, y f32, dt f32                 12 B/event   (any source coordinate)
+//   FMT_COMPACT  pix u16 (tile-local pixel), dt f32    6 B/event   (integer source coordinates: camera events)
+enum EvFormat { FMT_XY = 0, FMT_COMPACT = 1 };
+
+struct EvPtrs {
+  const float* xs;
+  const float* ys;
+  const float* dts;
+  const float* w;
+  const uint16_t* pix;
 };
 
-// Branch-free: indices past the slice are clamped to its last event (the slice is non-empty) and get
-// weight 0.  Predicated loads would turn into exec-masked branches, and hipcc then waits vmcnt(0) for
-// them -- draining the prefetch of the next batch that is supposed to stay in flight (cdna guide 4(c)).
-template <bool HAS_W>
-__device__ __forceinline__ void load_batch(Batch& b, int32_t base, int32_t end, const float* __restrict__ xs,
-                                           const float* __restrict__ ys, const float* __restrict__ dts,
-                                           const float* __restrict__ weight) {
+struct Group {  // 4 consecutive events of one lane
+  int rs[4], cs[4];   // source pixel (global)
+  float fx[4], fy[4]; // fractional part of the source coordinate (0 in the compact format)
+  float dt[4], w[4];  // w == 0 marks a dead slot (outside this workgroup's slice)
+};
+
+// Branch-free: group indices past the slice are clamped and their slots get weight 0 and the tile's first pixel.
+// Predicated loads would become exec-masked branches and hipcc then waits vmcnt(0) for them, draining the
+// prefetch that is supposed to stay in flight.
+template <int FMT, bool HAS_W, int TH, int TW>
+__device__ __forceinline__ void load_group(Group& g, int32_t grp, int32_t grp_last, int32_t beg, int32_t end,
+                                           const EvPtrs& p, int tile_r0, int tile_c0) {
+  const int32_t j = min(grp, grp_last);
+  const float4 D = reinterpret_cast<const float4*>(p.dts)[j];
+  float4 Wv = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (HAS_W) Wv = reinterpret_cast<const float4*>(p.w)[j];
+  const float dd[4] = {D.x, D.y, D.z, D.w}, ww[4] = {Wv.x, Wv.y, Wv.z, Wv.w};
+  float xx[4], yy[4];
+  int pp[4];
+  if (FMT == FMT_XY) {
+    const float4 X = reinterpret_cast<const float4*>(p.xs)[j], Y = reinterpret_cast<const float4*>(p.ys)[j];
+    xx[0] = X.x; xx[1] = X.y; xx[2] = X.z; xx[3] = X.w;
+    yy[0] = Y.x; yy[1] = Y.y; yy[2] = Y.z; yy[3] = Y.w;
+  } else {
+    const uint2 P = reinterpret_cast<const uint2*>(p.pix)[j];
+    pp[0] = P.x & 0xffff; pp[1] = P.x >> 16; pp[2] = P.y & 0xffff; pp[3] = P.y >> 16;
+  }
 #pragma unroll
-  for (int k = 0; k < kUnroll; ++k) {
-    const int32_t i = base + k * kBlock;
-    const int32_t j = min(i, end - 1);
-    b.x[k] = xs[j];
-    b.y[k] = ys[j];
-    b.dt[k] = dts[j];
-    const float wv = HAS_W ? weight[j] : 1.0f;
-    b.w[k] = i < end ? wv : 0.0f;
+  for (int e = 0; e < 4; ++e) {
+    const int32_t i = 4 * j + e;
+    const bool live = grp <= grp_last && i >= beg && i < end;
+    g.dt[e] = dd[e];
+    g.w[e] = live ? ww[e] : 0.0f;
+    if (FMT == FMT_XY) {
+      const float x = live ? xx[e] : (float)tile_r0, y = live ? yy[e] : (float)tile_c0;
+      g.rs[e] = (int)x;
+      g.cs[e] = (int)y;
+      g.fx[e] = x - (float)g.rs[e];
+      g.fy[e] = y - (float)g.cs[e];
+    } else {
+      const int q = live ? pp[e] : 0;
+      g.rs[e] = tile_r0 + q / TW;
+      g.cs[e] = tile_c0 + q % TW;
+      g.fx[e] = 0.0f;
+      g.fy[e] = 0.0f;
+    }
   }
 }
 
@@ -117,68 +153,85 @@ constexpr double kFxInv = 1.0 / (double)(1 << kFxShift);
 
 enum AccMode { ACC_F64 = 0, ACC_FX = 1 };
 
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, bool DO_SPILL>
-__device__ __forceinline__ long long accumulate_slice(const TileRange& tr, double* s_acc, const float* __restrict__ xs,
-                                                      const float* __restrict__ ys, const float* __restrict__ dts,
-                                                      const float* __restrict__ weight, const float* __restrict__ flow,
-                                                      int H, int W, int pad_h, int pad_w, float* spill) {
+// PASS_MAIN: the lean hot loop -- every tap that lands inside the LDS window is accumulated, branch-free (dead or
+//            out-of-window lanes add 0 to a dummy word); events whose taps leave the window only raise a flag.
+// PASS_SPILL: the rare second sweep over the same slice that handles exactly those events with global atomics on
+//            the spill image.  Keeping that code out of the hot loop halves its VALU count (it dragged ~90 64-bit
+//            address operations and ~30 exec-mask branches per 4 events into a loop that is VALU-bound).
+enum Pass { PASS_MAIN = 0, PASS_SPILL = 1 };
+
+// UNIFORM: one translation theta for all events (2-DoF model, src/warp.py:364-383: x' = x + dt * theta, i.e. a
+// dense flow of -theta everywhere) -- the two flow gathers disappear.
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM>
+__device__ __forceinline__ unsigned accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
+                                                     const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
+                                                     float* spill, bool* any_spill) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
-  const int64_t hw = (int64_t)H * W;
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
-  const int oy = tr.ty * TH - HALO, ox = tr.tx * TW - HALO;  // LDS cell (0,0) = un-padded pixel (oy, ox)
-  const float* __restrict__ flow1 = flow + hw;
-  long long added = 0;  // FX: exact integer total this thread put into LDS
+  const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
+  const int oy = tr0 - HALO, ox = tc0 - HALO;  // LDS cell (0,0) = un-padded pixel (oy, ox)
+  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (int64_t)H * W;
+  const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;  // flow == theta pair
+  unsigned added = 0;  // FX: integer total this thread put into LDS (mod 2^32)
+  bool spilled = false;
   if (tr.beg >= tr.end) return 0;
-  // 3-stage software pipeline per thread:  SoA loads of batch k+2 | flow gathers of batch k+1 | LDS adds of batch k.
-  // Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
-  int32_t base = tr.beg + threadIdx.x;
-  Batch cur, nxt;
-  load_batch<HAS_W>(cur, base, tr.end, xs, ys, dts, weight);
-  load_batch<HAS_W>(nxt, base + kBlock * kUnroll, tr.end, xs, ys, dts, weight);
-  float fu[kUnroll], fv[kUnroll];
+  // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
+  // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
+  const int32_t g_last = (tr.end - 1) >> 2;
+  int32_t grp = (tr.beg >> 2) + threadIdx.x;
+  Group cur, nxt;
+  load_group<FMT, HAS_W, TH, TW>(cur, grp, g_last, tr.beg, tr.end, ev, tr0, tc0);
+  load_group<FMT, HAS_W, TH, TW>(nxt, grp + kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
+  float fu[4], fv[4];
 #pragma unroll
-  for (int k = 0; k < kUnroll; ++k) {
-    const int lin = (int)cur.x[k] * W + (int)cur.y[k];
-    fu[k] = flow[lin];
-    fv[k] = flow1[lin];
+  for (int e = 0; e < 4; ++e) {
+    const int lin = cur.rs[e] * W + cur.cs[e];
+    fu[e] = UNIFORM ? uni_u : flow[lin];
+    fv[e] = UNIFORM ? uni_v : flow1[lin];
   }
-  while (base < tr.end) {
-    float gu[kUnroll], gv[kUnroll];
+  while (grp <= g_last) {
+    float gu[4], gv[4];
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {  // gathers of the NEXT batch (sorted events: broadcast / adjacent addresses)
-      const int lin = (int)nxt.x[k] * W + (int)nxt.y[k];
-      gu[k] = flow[lin];
-      gv[k] = flow1[lin];
+    for (int e = 0; e < 4; ++e) {  // gathers of the NEXT group (sorted events: broadcast / adjacent addresses)
+      const int lin = nxt.rs[e] * W + nxt.cs[e];
+      gu[e] = UNIFORM ? uni_u : flow[lin];
+      gv[e] = UNIFORM ? uni_v : flow1[lin];
     }
-    Batch nn;  // loads two batches ahead
-    load_batch<HAS_W>(nn, base + 2 * kBlock * kUnroll, tr.end, xs, ys, dts, weight);
+    Group nn;  // loads two groups ahead
+    load_group<FMT, HAS_W, TH, TW>(nn, grp + 2 * kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {
-      if (base + k * kBlock >= tr.end) break;
-      const Taps f = warped_taps(cur.x[k], cur.y[k], -cur.dt[k] * fu[k], -cur.dt[k] * fv[k]);
-      const float a = 1.0f - f.fr, b = 1.0f - f.fc, wv = cur.w[k];
-      const float w00 = a * b * wv, w10 = f.fr * b * wv, w01 = a * f.fc * wv, w11 = f.fr * f.fc * wv;
+    for (int e = 0; e < 4; ++e) {
+      const float wv = cur.w[e];  // 0 for dead slots
+      const Taps f = warped_taps(cur.rs[e], cur.cs[e], cur.fx[e] - cur.dt[e] * fu[e], cur.fy[e] - cur.dt[e] * fv[e]);
       const int rl = f.R - oy, cl = f.C - ox;
-      if (f.ok && rl >= 0 && rl < LH - 1 && cl >= 0 && cl < LW - 1) {
+      const bool inside = (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);  // f.ok false -> far outside
+      const float a = 1.0f - f.fr, b = 1.0f - f.fc;
+      if (PASS == PASS_MAIN) {
+        spilled |= (!inside) && (wv != 0.0f);
+        const float ws = inside ? wv : 0.0f;
         if (MODE == ACC_FX) {
-          const int q00 = __float2int_rn(w00 * kFxScale), q10 = __float2int_rn(w10 * kFxScale);
-          const int q01 = __float2int_rn(w01 * kFxScale), q11 = __float2int_rn(w11 * kFxScale);
+          const float as = a * (ws * kFxScale), fs = f.fr * (ws * kFxScale);
+          const int q00 = (int)floorf(as * b + 0.5f), q10 = (int)floorf(fs * b + 0.5f);
+          const int q01 = (int)floorf(as * f.fc + 0.5f), q11 = (int)floorf(fs * f.fc + 0.5f);
           // word = (hi << 32) + lo as a 64-bit integer: a (tiny) negative lo borrows from hi, decode undoes it
-          const long long v0 = ((long long)q01 << 32) + (long long)q00;
-          const long long v1 = ((long long)q11 << 32) + (long long)q10;
-          unsigned long long* p = s_fx + (cl & 1) * (LH * LW / 2) + rl * (LW / 2) + (cl >> 1);
-          atomicAdd(p, (unsigned long long)v0);
-          atomicAdd(p + LW / 2, (unsigned long long)v1);
-          added += (long long)q00 + q10 + q01 + q11;
+          const unsigned long long v0 = ((unsigned long long)(unsigned)(q01 + (q00 >> 31)) << 32) | (unsigned)q00;
+          const unsigned long long v1 = ((unsigned long long)(unsigned)(q11 + (q10 >> 31)) << 32) | (unsigned)q10;
+          const int word = inside ? (cl & 1) * (LH * LW / 2) + rl * (LW / 2) + (cl >> 1) : LH * LW;  // LH*LW = dummy pair
+          atomicAdd(s_fx + word, v0);
+          atomicAdd(s_fx + word + (inside ? LW / 2 : 1), v1);
+          added += (unsigned)(q00 + q10 + q01 + q11);
         } else {
-          double* p = &s_acc[rl * LW + cl];
-          atomic_add(p, (double)w00);
-          atomic_add(p + LW, (double)w10);
-          atomic_add(p + 1, (double)w01);
-          atomic_add(p + LW + 1, (double)w11);
+          const float as = a * ws, fs = f.fr * ws;
+          const int cell = inside ? rl * LW + cl : LH * LW;
+          const int dn = inside ? LW : 0;
+          atomic_add(&s_acc[cell], (double)(as * b));
+          atomic_add(&s_acc[cell + dn], (double)(fs * b));
+          atomic_add(&s_acc[cell + 1], (double)(as * f.fc));
+          atomic_add(&s_acc[cell + dn + 1], (double)(fs * f.fc));
         }
-      } else if (DO_SPILL && f.ok) {  // beyond the halo: spill image (zero-invariant scratch, folded in by the combine pass)
+      } else if (!inside && wv != 0.0f && f.ok) {  // beyond the halo: spill image (zero-invariant scratch)
+        const float w00 = a * b * wv, w10 = f.fr * b * wv, w01 = a * f.fc * wv, w11 = f.fr * f.fc * wv;
         const int R = f.R + pad_h, C = f.C + pad_w;
         const bool r0 = R >= 0 && R < h, r1 = R + 1 >= 0 && R + 1 < h;
         const bool c0 = C >= 0 && C < w, c1 = C + 1 >= 0 && C + 1 < w;
@@ -192,12 +245,13 @@ __device__ __forceinline__ long long accumulate_slice(const TileRange& tr, doubl
     cur = nxt;
     nxt = nn;
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {
-      fu[k] = gu[k];
-      fv[k] = gv[k];
+    for (int e = 0; e < 4; ++e) {
+      fu[e] = gu[e];
+      fv[e] = gv[e];
     }
-    base += kBlock * kUnroll;
+    grp += kBlock;
   }
+  if (any_spill) *any_spill = spilled;
   return added;
 }
 
@@ -211,56 +265,65 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 __device__ __forceinline__ long long fx_lo(long long v) { return (long long)(int)(unsigned)(v & 0xffffffffll); }
 __device__ __forceinline__ long long fx_hi(long long v) { return (v - fx_lo(v)) >> 32; }
 
-template <int TH, int TW, int HALO, bool HAS_W, int MODE>
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM>
 __global__ void __launch_bounds__(kBlock)
-iwe_slab_accumulate_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
-                           const float* __restrict__ weight, const int32_t* __restrict__ key_offsets,
-                           const float* __restrict__ flow, int H, int W, int tiles_x, int splits, int pad_h, int pad_w,
-                           float* __restrict__ slabs, float* spill) {
+iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow, int H, int W,
+                           int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr int kCells = LH * LW + 2;  // + a dummy pair that absorbs the zero adds of dead / out-of-window lanes
   static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
-  extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words
-  __shared__ long long s_chk[2 * kBlock / kWave];
-  __shared__ int s_bad;
+  extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words; + dummy
+  __shared__ unsigned s_chk[2 * kBlock / kWave];
+  __shared__ int s_flag[2];  // [0] fixed-point overflow, [1] some event left the LDS window
   const TileRange tr = tile_range(key_offsets, TH * TW, tiles_x, splits);
 
-  for (int i = threadIdx.x; i < LH * LW; i += kBlock) s_acc[i] = 0.0;  // all-zero bits = 0 in both modes
+  for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;  // all-zero bits = 0 in both modes
+  if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
   __syncthreads();
 
-  const long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, true>(tr, s_acc, xs, ys, dts, weight, flow, H, W,
-                                                                            pad_h, pad_w, spill);
+  bool spilled = false;
+  const unsigned added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h,
+                                                                                              pad_w, spill, &spilled);
+  if (spilled) s_flag[1] = 1;  // benign race: every writer stores 1
   __syncthreads();
+  if (s_flag[1])  // rare: taps beyond the halo go to the spill image with global atomics
+    accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr);
 
   float4* out = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * (LH * LW));
   bool f64_flush = (MODE == ACC_F64);
   if (MODE == ACC_FX) {
-    // verify: decoded total == added total (exact integers)
+    // verify: sum of decoded fields == sum of added units (mod 2^32; a wrapped field shifts it by k (2^32 - 1))
     const long long* s_fx = reinterpret_cast<const long long*>(s_acc);
-    long long decoded = 0;
+    unsigned decoded = 0;
     for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
       const long long v = s_fx[i];
-      decoded += fx_lo(v) + fx_hi(v);
+      decoded += (unsigned)(fx_lo(v) + fx_hi(v));
     }
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    const long long a = wave_sum_ll(added), d = wave_sum_ll(decoded);
+    unsigned a = added, d = decoded;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      a += __shfl_down(a, off, kWave);
+      d += __shfl_down(d, off, kWave);
+    }
     if (lane == 0) {
       s_chk[2 * wid] = a;
       s_chk[2 * wid + 1] = d;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      long long ta = 0, td = 0;
+      unsigned ta = 0, td = 0;
       for (int k = 0; k < kBlock / kWave; ++k) {
         ta += s_chk[2 * k];
         td += s_chk[2 * k + 1];
       }
-      s_bad = (ta != td);
+      s_flag[0] = (ta != td);
     }
     __syncthreads();
-    if (s_bad) {  // a field wrapped: redo this slice exactly in f64 (the spill taps were already issued)
-      for (int i = threadIdx.x; i < LH * LW; i += kBlock) s_acc[i] = 0.0;
+    if (s_flag[0]) {  // a field wrapped: redo this slice exactly in f64 (the spill taps were already issued)
+      for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
       __syncthreads();
-      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, false>(tr, s_acc, xs, ys, dts, weight, flow, H, W, pad_h, pad_w, spill);
+      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr);
       __syncthreads();
       f64_flush = true;
     } else {
@@ -447,13 +510,12 @@ struct GradImage {
   }
 };
 
-template <int TH, int TW, int HALO, bool HAS_W>
+template <int TH, int TW, int HALO, bool HAS_W, int FMT>
 __global__ void __launch_bounds__(kBlock)
-iwe_dense_tiled_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
-                           const float* __restrict__ weight, const int32_t* __restrict__ key_offsets,
-                           const float* __restrict__ flow, int H, int W, int tiles_x, int pad_h, int pad_w,
-                           const float* __restrict__ g_image, const float* __restrict__ affine, int g_lo,
-                           float* __restrict__ d_flow, float* __restrict__ d_weight) {
+iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow, int H, int W,
+                           int tiles_x, int pad_h, int pad_w, const float* __restrict__ g_image,
+                           const float* __restrict__ affine, int g_lo, float* __restrict__ d_flow,
+                           float* __restrict__ d_weight) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
@@ -467,7 +529,8 @@ iwe_dense_tiled_bwd_kernel(const float* __restrict__ xs, const float* __restrict
   G.h = H + 2 * pad_h;
   G.w = W + 2 * pad_w;
   G.lo = g_lo;
-  const int oy = tr.ty * TH - HALO, ox = tr.tx * TW - HALO;
+  const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
+  const int oy = tr0 - HALO, ox = tc0 - HALO;
 
   for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
   if (tr.beg < tr.end) {
@@ -478,36 +541,42 @@ iwe_dense_tiled_bwd_kernel(const float* __restrict__ xs, const float* __restrict
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & (kWave - 1);
-  // whole waves iterate together (shuffles below): the wave's first lane decides
-  const int32_t wave_first = tr.beg + (threadIdx.x - lane);
-  const float* __restrict__ flow1 = flow + hw;
-  int32_t base = tr.beg + threadIdx.x;
-  Batch cur;
-  if (tr.beg < tr.end) load_batch<HAS_W>(cur, base, tr.end, xs, ys, dts, weight);
-  for (int32_t wbase = wave_first; wbase < tr.end; wbase += kBlock * kUnroll) {
-    float fu[kUnroll], fv[kUnroll];
+  if (tr.beg < tr.end) {
+    const float* __restrict__ flow1 = flow + hw;
+    const int32_t g_last = (tr.end - 1) >> 2;
+    int32_t grp = (tr.beg >> 2) + threadIdx.x;
+    Group cur, nxt;
+    load_group<FMT, HAS_W, TH, TW>(cur, grp, g_last, tr.beg, tr.end, ev, tr0, tc0);
+    load_group<FMT, HAS_W, TH, TW>(nxt, grp + kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
+    float fu[4], fv[4];
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {
-      const int lin = (int)cur.x[k] * W + (int)cur.y[k];
-      fu[k] = flow[lin];
-      fv[k] = flow1[lin];
+    for (int e = 0; e < 4; ++e) {
+      const int lin = cur.rs[e] * W + cur.cs[e];
+      fu[e] = flow[lin];
+      fv[e] = flow1[lin];
     }
-    Batch nxt;
-    const int32_t nbase = base + kBlock * kUnroll;
-    load_batch<HAS_W>(nxt, nbase, tr.end, xs, ys, dts, weight);
+    while (grp <= g_last) {
+      float gu[4], gv[4];
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {
-      if (wbase + k * kBlock >= tr.end) break;  // wave-uniform
-      const int32_t i = base + k * kBlock;
-      const bool live = i < tr.end;
-      int pix = -1;  // tile-local source pixel
-      float gx = 0.0f, gy = 0.0f;
-      if (live) {
-        const int rs = (int)cur.x[k], cs = (int)cur.y[k];
-        pix = (rs - tr.ty * TH) * TW + (cs - tr.tx * TW);
-        const float edt = cur.dt[k];
-        const Taps f = warped_taps(cur.x[k], cur.y[k], -edt * fu[k], -edt * fv[k]);
+      for (int e = 0; e < 4; ++e) {
+        const int lin = nxt.rs[e] * W + nxt.cs[e];
+        gu[e] = flow[lin];
+        gv[e] = flow1[lin];
+      }
+      Group nn;
+      load_group<FMT, HAS_W, TH, TW>(nn, grp + 2 * kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
+      // The lane's 4 events are consecutive in the sorted plan, so they mostly share one source pixel: sum
+      // them in registers and issue one pair of LDS adds per run instead of a wave-wide shuffle reduction.
+      int run_pix = -1;
+      float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float wv = cur.w[e];
+        const int32_t i = 4 * min(grp, g_last) + e;
+        const bool live = i >= tr.beg && i < tr.end;  // (weights may legitimately be 0 here)
+        if (!live) continue;
+        const float edt = cur.dt[e];
+        const Taps f = warped_taps(cur.rs[e], cur.cs[e], cur.fx[e] - edt * fu[e], cur.fy[e] - edt * fv[e]);
         const int rl = f.R - oy, cl = f.C - ox;
         float g00, g10, g01, g11;
         if (f.ok && rl >= 0 && rl < LH - 1 && cl >= 0 && cl < LW - 1) {
@@ -523,42 +592,44 @@ iwe_dense_tiled_bwd_kernel(const float* __restrict__ xs, const float* __restrict
           g01 = f.ok ? G.at(R, C + 1) : 0.0f;
           g11 = f.ok ? G.at(R + 1, C + 1) : 0.0f;
         }
-        const float a = 1.0f - f.fr, b = 1.0f - f.fc, wv = cur.w[k];
-        const float dx = wv * (b * (g10 - g00) + f.fc * (g11 - g01));  // dL/dx'
-        const float dy = wv * (a * (g01 - g00) + f.fr * (g11 - g10));  // dL/dy'
-        gx = -edt * dx;
-        gy = -edt * dy;
+        const float a = 1.0f - f.fr, b = 1.0f - f.fc;
+        const float wl = HAS_W ? wv : 1.0f;
+        const float dx = wl * (b * (g10 - g00) + f.fc * (g11 - g01));  // dL/dx'
+        const float dy = wl * (a * (g01 - g00) + f.fr * (g11 - g10));  // dL/dy'
         if (d_weight) d_weight[i] = a * b * g00 + f.fr * b * g10 + a * f.fc * g01 + f.fr * f.fc * g11;
-      }
-      // segmented sum over the (contiguous) events of one source pixel inside the wave
-      const int prev = __shfl_up(pix, 1, kWave);
-      const bool head = (lane == 0) || (prev != pix);
-      const unsigned long long heads = __ballot(head);
-      const int run = __popcll(heads & (~0ull >> (63 - lane)));
-#pragma unroll
-      for (int off = 1; off < kWave; off <<= 1) {
-        const float ox_ = __shfl_down(gx, off, kWave);
-        const float oy_ = __shfl_down(gy, off, kWave);
-        const int orun = __shfl_down(run, off, kWave);
-        if (lane + off < kWave && orun == run) {
-          gx += ox_;
-          gy += oy_;
+        const int pix = (cur.rs[e] - tr0) * TW + (cur.cs[e] - tc0);
+        if (pix != run_pix) {
+          if (run_pix >= 0) {
+            atomic_add(&s_d[run_pix], (double)ax);
+            atomic_add(&s_d[TH * TW + run_pix], (double)ay);
+          }
+          run_pix = pix;
+          ax = 0.0f;
+          ay = 0.0f;
         }
+        ax -= edt * dx;  // dL/dflow0[src] += -dt * dL/dx'
+        ay -= edt * dy;
       }
-      if (head && pix >= 0) {
-        atomic_add(&s_d[pix], (double)gx);
-        atomic_add(&s_d[TH * TW + pix], (double)gy);
+      if (run_pix >= 0) {
+        atomic_add(&s_d[run_pix], (double)ax);
+        atomic_add(&s_d[TH * TW + run_pix], (double)ay);
       }
+      cur = nxt;
+      nxt = nn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        fu[e] = gu[e];
+        fv[e] = gv[e];
+      }
+      grp += kBlock;
     }
-    cur = nxt;
-    base = nbase;
   }
   __syncthreads();
 
   // every flow pixel belongs to exactly one tile: plain coalesced stores, zeros where no event lives
   for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
     const int rl = i / TW, cl = i - rl * TW;
-    const int r = tr.ty * TH + rl, c = tr.tx * TW + cl;
+    const int r = tr0 + rl, c = tc0 + cl;
     if (r < H && c < W) {
       d_flow[(int64_t)r * W + c] = (float)s_d[i];
       d_flow[hw + (int64_t)r * W + c] = (float)s_d[TH * TW + i];
@@ -609,24 +680,31 @@ int reserve_lds(K kern, size_t lds, const char* what) {
 }
 
 template <int TH, int TW, int HALO>
-int launch_slab_fwd(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* key_offsets,
-                    const float* flow, int H, int W, int splits, int pad_h, int pad_w, char* ws, float* iwe, int want_var,
-                    int omit, float* out_var, double* moments, int acc_mode, hipStream_t s) {
+int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int splits,
+                    int pad_h, int pad_w, char* ws, float* iwe, int want_var, int omit, float* out_var, double* moments,
+                    int acc_mode, hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  constexpr size_t lds = (size_t)LH * LW * sizeof(double);
-  static_assert(lds <= 160 * 1024, "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
+  constexpr size_t lds = ((size_t)LH * LW + 2) * sizeof(double);  // + dummy pair
+  static_assert(lds + 1024 <= 160 * 1024, "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
   const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
   float* slabs = reinterpret_cast<float*>(ws);
   float* spill = reinterpret_cast<float*>(ws + L.off_spill);
   double* partials = reinterpret_cast<double*>(ws + L.off_partials);
   // unit weights -> verified fixed point (2 ds_add_u64 per event); per-event weights -> f64 (any magnitude/sign)
-  auto ka = weight ? iwe_slab_accumulate_kernel<TH, TW, HALO, true, ACC_F64>
-                   : (acc_mode == ACC_F64 ? iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_F64>
-                                          : iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX>);
+  void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*);
+  const bool compact = ev.pix != nullptr;
+#define EBOS_PICK(HW, MD)                                                                                              \
+  (uniform ? (compact ? iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_COMPACT, true>                            \
+                      : iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_XY, true>)                                 \
+           : (compact ? iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_COMPACT, false>                           \
+                      : iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_XY, false>))
+  if (ev.w) ka = EBOS_PICK(true, ACC_F64);
+  else if (acc_mode == ACC_F64) ka = EBOS_PICK(false, ACC_F64);
+  else ka = EBOS_PICK(false, ACC_FX);
+#undef EBOS_PICK
   if (int rc = reserve_lds(ka, lds, "ebos_iwe_dense_slab")) return rc;
   profile_mark(s, true);
-  ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(xs, ys, dts, weight, key_offsets, flow, H, W, L.tiles_x, splits, pad_h,
-                                                       pad_w, slabs, spill);
+  ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill);
   profile_mark(s, false);
   int64_t nparts;
   if (L.w % 4 == 0 && pad_w % 4 == 0) {
@@ -651,17 +729,20 @@ int launch_slab_fwd(const float* xs, const float* ys, const float* dts, const fl
 }
 
 template <int TH, int TW, int HALO>
-int launch_tiled_bwd(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* key_offsets,
-                     const float* flow, int H, int W, int pad_h, int pad_w, const float* g_image, const float* affine, int g_lo,
-                     float* d_flow, float* d_weight, hipStream_t s) {
+int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, int H, int W, int pad_h, int pad_w,
+                     const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight, hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert(lds <= 160 * 1024, "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
-  auto kb = weight ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, true> : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false>;
+  const bool compact = ev.pix != nullptr;
+  auto kb = ev.w ? (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, true, FMT_COMPACT>
+                            : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, true, FMT_XY>)
+                 : (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT>
+                            : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_XY>);
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
-  kb<<<dim3((unsigned)(tiles_y * tiles_x)), dim3(kBlock), lds, s>>>(xs, ys, dts, weight, key_offsets, flow, H, W, tiles_x, pad_h,
-                                                                    pad_w, g_image, affine, g_lo, d_flow, d_weight);
+  kb<<<dim3((unsigned)(tiles_y * tiles_x)), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image,
+                                                                    affine, g_lo, d_flow, d_weight);
   return EBOS_OK;
 }
 
@@ -700,14 +781,14 @@ size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int h
   return slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w).total;
 }
 
-int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const uint16_t* pix,
                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
                             int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
                             double* moments, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(flow && iwe && key_offsets && workspace, "ebos_iwe_dense_slab: NULL flow/iwe/key_offsets/workspace");
-  EBOS_REQUIRE((xs && ys && dts) || n == 0, "ebos_iwe_dense_slab: NULL event buffer");
+  EBOS_REQUIRE((dts && ((xs && ys) || pix)) || n == 0, "ebos_iwe_dense_slab: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 1 && splits <= 64,
                "ebos_iwe_dense_slab: bad sizes (splits=%d)", splits);
   EBOS_REQUIRE(!want_variance || out_variance || moments, "ebos_iwe_dense_slab: variance requested without an output");
@@ -722,14 +803,15 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
   }
   hipStream_t s = as_stream(stream);
   char* ws = reinterpret_cast<char*>(workspace);
+  const EvPtrs evp{xs, ys, dts, weight, pix};
   static const int acc_mode = [] {  // EBOS_SLAB_ACC=f64 forces the f64 accumulator (debug / A-B runs)
     const char* e = getenv("EBOS_SLAB_ACC");
     return (e && e[0] == 'f') ? (int)ACC_F64 : (int)ACC_FX;
   }();
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                          \
-  launch_slab_fwd<TH, TW, HL>(xs, ys, dts, weight, key_offsets, flow, H, W, splits, pad_h, pad_w, ws, iwe, want_variance, \
-                              omit_boundary, out_variance, moments, acc_mode, s)
+  launch_slab_fwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, splits, pad_h, pad_w, ws, iwe, want_variance, omit_boundary, \
+                              out_variance, moments, acc_mode, s)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;
@@ -737,23 +819,61 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
   return EBOS_OK;
 }
 
+int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const uint16_t* pix,
+                           const int32_t* key_offsets, int64_t n, const float* thetas, int K, int H, int W, int tile_h,
+                           int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace, size_t workspace_bytes,
+                           float* iwes, int want_variance, int omit_boundary, float* out_variance, double* moments,
+                           ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(thetas && iwes && key_offsets && workspace, "ebos_iwe_2dof_slab: NULL thetas/iwes/key_offsets/workspace");
+  EBOS_REQUIRE((dts && ((xs && ys) || pix)) || n == 0, "ebos_iwe_2dof_slab: NULL event buffer");
+  EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 1 && splits <= 64,
+               "ebos_iwe_2dof_slab: bad sizes (K=%d splits=%d)", K, splits);
+  if (!slab_config_ok(tile_h, tile_w, halo)) {
+    set_error("ebos_iwe_2dof_slab: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  const size_t need = ebos_iwe_slab_workspace_bytes(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w);
+  if (workspace_bytes < need) {
+    set_error("ebos_iwe_2dof_slab: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return EBOS_ERR_SCRATCH;
+  }
+  hipStream_t s = as_stream(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const EvPtrs evp{xs, ys, dts, weight, pix};
+  const int64_t hw = (int64_t)(H + 2 * pad_h) * (W + 2 * pad_w);
+  for (int k = 0; k < K; ++k) {  // hypotheses reuse the workspace in stream order
+    int rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL)                                                                                            \
+  launch_slab_fwd<TH, TW, HL>(evp, key_offsets, thetas + 2 * k, true, H, W, splits, pad_h, pad_w, ws, iwes + k * hw,     \
+                              want_variance, omit_boundary, out_variance ? out_variance + k : nullptr,                   \
+                              moments ? moments + 2 * k : nullptr, (int)ACC_FX, s)
+    EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+    if (rc != EBOS_OK) return rc;
+  }
+  EBOS_CHECK_LAUNCH("ebos_iwe_2dof_slab");
+  return EBOS_OK;
+}
+
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                                 const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
+                                 const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
+                                 int tile_h,
                                  int tile_w, int halo, int pad_h, int pad_w, const float* g_image, const float* affine,
                                  int g_lo, float* d_flow, float* d_weight, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(flow && g_image && d_flow && key_offsets, "ebos_iwe_dense_tiled_bwd: NULL flow/g_image/d_flow/key_offsets");
-  EBOS_REQUIRE((xs && ys && dts) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
+  EBOS_REQUIRE((dts && ((xs && ys) || pix)) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_dense_tiled_bwd: bad sizes");
   if (!slab_config_ok(tile_h, tile_w, halo)) {
     set_error("ebos_iwe_dense_tiled_bwd: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
     return EBOS_ERR_UNSUPPORTED;
   }
   hipStream_t s = as_stream(stream);
+  const EvPtrs evp{xs, ys, dts, weight, pix};
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
-  launch_tiled_bwd<TH, TW, HL>(xs, ys, dts, weight, key_offsets, flow, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, \
-                               d_weight, s)
+  launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, s)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

@@ -61,6 +61,7 @@ class EventPlan:
     key_offsets: Optional[torch.Tensor] = None   # int32 [n_keys + 1]
     perm: Optional[torch.Tensor] = None          # int32 [n]: input index of each planned event
     n_dropped: int = 0
+    pix: Optional[torch.Tensor] = None           # int16 storage of u16 tile-local source pixels (compact format)
 
     @property
     def binned(self) -> bool:
@@ -69,6 +70,11 @@ class EventPlan:
     @property
     def device(self) -> torch.device:
         return self.x.device
+
+    @property
+    def compact(self) -> bool:
+        """True when the tile-private kernels read the 6 B/event format (u16 pixel + f32 dt)."""
+        return self.pix is not None
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -107,21 +113,26 @@ class EventPlan:
         n_keys = tiles_y * tiles_x * th * tw
         dev = self.device
         n = self.n
-        xs, ys, dts, ps = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+        n_pad = (n + 3) // 4 * 4 + 4  # the tile-private kernels read 4 events (16 B) per lane
+        xs, ys, dts, ps = (torch.zeros(n_pad, dtype=torch.float32, device=dev) for _ in range(4))
+        pix = torch.zeros(n_pad, dtype=torch.int16, device=dev) if th * tw <= 65536 else None
         perm = torch.empty(n, dtype=torch.int32, device=dev)
         key_offsets = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
-        oob = torch.zeros(1, dtype=torch.int32, device=dev)
+        counts = torch.zeros(2, dtype=torch.int32, device=dev)  # [out-of-image sources, fractional sources]
         nbytes = int(lib.ebos_bin_scratch_bytes(n_keys))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             check(lib.ebos_bin_events_f32(ptr(self.x), ptr(self.y), ptr(self.dt), ptr(self.p), n, H, W, th, tw,
-                                          ptr(xs), ptr(ys), ptr(dts), ptr(ps), ptr(perm), ptr(key_offsets), ptr(oob),
-                                          ptr(scratch), nbytes, stream_ptr()), "ebos_bin_events")
-        dropped = int(oob.item())  # one-off sync at plan-build time
+                                          ptr(xs), ptr(ys), ptr(dts), ptr(ps), ptr(perm), ptr(key_offsets), ptr(counts),
+                                          ptr(pix), counts.data_ptr() + 4, ptr(scratch), nbytes, stream_ptr()),
+                  "ebos_bin_events")
+        dropped, fractional = (int(v) for v in counts.tolist())  # one-off sync at plan-build time
         kept = n - dropped
         src_perm = perm[:kept] if self.perm is None else self.perm[perm[:kept].long()]
+        if fractional:
+            pix = None  # fractional / negative source coordinates: keep the general (x, y, dt) format
         return EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
-                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped)
+                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped, pix)
 
     # ------------------------------------------------------------------------------------------
     def iwe_dense(self, flow: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
@@ -130,10 +141,35 @@ class EventPlan:
         ``halo=None`` (or an un-binned plan) selects the general global-atomic kernel."""
         return _FusedIweDense.apply(flow, weight, self, (int(pad[0]), int(pad[1])), halo, int(splits))
 
-    def iwe_2dof(self, thetas: torch.Tensor, pad: Tuple[int, int] = (0, 0),
-                 weight: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Fused 2-DoF warp + bilinear IWE for K hypotheses: thetas [K, 2] -> iwes [K, h, w]."""
-        return _FusedIwe2Dof.apply(thetas, weight, self, (int(pad[0]), int(pad[1])))
+    def iwe_2dof(self, thetas: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
+                 halo: Optional[int] = DEFAULT_HALO, splits: int = 1) -> torch.Tensor:
+        """Fused 2-DoF warp + bilinear IWE for K hypotheses: thetas [K, 2] -> iwes [K, h, w].
+        Binned plans use the tile-private pipeline (|dt * theta| beyond ``halo`` spills, still correct)."""
+        return _FusedIwe2Dof.apply(thetas, weight, self, (int(pad[0]), int(pad[1])), halo, int(splits))
+
+    def variance_2dof(self, thetas: torch.Tensor, omit_boundary: bool = False, pad: Tuple[int, int] = (0, 0),
+                      halo: int = DEFAULT_HALO, splits: int = 1, chunk: int = 8) -> torch.Tensor:
+        """Variance contrast of K translation hypotheses (the solver's outer sweep): [K, 2] -> [K].
+        No gradient; images are produced ``chunk`` at a time into a reused buffer."""
+        lib = _hip.require_gpu()
+        if not _slab_ok(self, halo):
+            return ops.image_variance(self.iwe_2dof(thetas, pad, None, None), omit_boundary)
+        th = thetas.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        K = th.shape[0]
+        H, W = self.image_size
+        h, w = H + 2 * pad[0], W + 2 * pad[1]
+        ws = _workspace(self, pad, halo, splits)
+        out = torch.empty(K, dtype=torch.float32, device=self.device)
+        buf = torch.empty((min(chunk, K), h, w), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for k0 in range(0, K, chunk):
+                kc = min(chunk, K - k0)
+                check(lib.ebos_iwe_2dof_slab_f32(ptr(self.x), ptr(self.y), ptr(self.dt), None, ptr(self.pix),
+                                                 ptr(self.key_offsets), self.n, th.data_ptr() + 8 * k0, kc, H, W,
+                                                 self.tile[0], self.tile[1], int(halo), int(splits), pad[0], pad[1],
+                                                 ptr(ws), ws.numel(), ptr(buf), 1, int(omit_boundary),
+                                                 out.data_ptr() + 4 * k0, None, stream_ptr()), "ebos_iwe_2dof_slab")
+        return out
 
     def contrast_dense(self, flow: torch.Tensor, cost: str = "image_variance", omit_boundary: bool = False,
                        pad: Tuple[int, int] = (0, 0), halo: Optional[int] = DEFAULT_HALO,
@@ -193,7 +229,8 @@ def _launch_iwe_dense_slab(plan: EventPlan, flow32, weight, pad, halo, splits, w
     out = torch.empty(1, dtype=torch.float32, device=plan.device) if want_variance else None
     moments = torch.empty((1, 2), dtype=torch.float64, device=plan.device) if want_variance else None
     with torch.cuda.device(plan.device):
-        check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), ptr(plan.key_offsets), plan.n,
+        check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), ptr(plan.pix),
+                                          ptr(plan.key_offsets), plan.n,
                                           ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), int(splits), pad[0],
                                           pad[1], ptr(ws), ws.numel(), ptr(iwe), int(want_variance), int(omit), ptr(out),
                                           ptr(moments), stream_ptr()), "ebos_iwe_dense_slab")
@@ -224,7 +261,10 @@ def _plan_weight(plan: EventPlan, weight: Optional[torch.Tensor]) -> Optional[to
     w = weight.to(device=plan.device, dtype=torch.float32).reshape(-1)
     if w.numel() != plan.n_input:
         raise ValueError(f"weight must have one entry per input event ({plan.n_input}), got {w.numel()}")
-    return (w if plan.perm is None else w[plan.perm.long()]).contiguous()
+    w = w if plan.perm is None else w[plan.perm.long()]
+    out = torch.zeros((plan.n + 3) // 4 * 4 + 4, dtype=torch.float32, device=plan.device)  # 16-byte loads: padded
+    out[:plan.n] = w
+    return out[:plan.n]
 
 
 def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_dweight, halo=DEFAULT_HALO):
@@ -234,8 +274,8 @@ def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_d
     if _slab_ok(plan, halo):  # tile-private backward: d_flow written with plain stores, no zero-fill
         d_flow = torch.empty((2, H, W), dtype=torch.float32, device=plan.device)
         with torch.cuda.device(plan.device):
-            check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), ptr(plan.key_offsets),
-                                                   plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), pad[0],
+            check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), ptr(plan.pix),
+                                                   ptr(plan.key_offsets), plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), pad[0],
                                                    pad[1], ptr(g_image), ptr(affine), g_lo, ptr(d_flow), ptr(d_w),
                                                    stream_ptr()), "ebos_iwe_dense_tiled_bwd")
         return d_flow, d_w
@@ -314,7 +354,7 @@ class _FusedVarianceDense(torch.autograd.Function):
 
 class _FusedIwe2Dof(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, thetas, weight, plan, pad):
+    def forward(ctx, thetas, weight, plan, pad, halo, splits):
         lib = _hip.require_gpu()
         if thetas.dim() != 2 or thetas.shape[1] != 2:
             raise ValueError(f"thetas must be [K, 2], got {tuple(thetas.shape)}")
@@ -323,10 +363,18 @@ class _FusedIwe2Dof(torch.autograd.Function):
         K = th32.shape[0]
         H, W = plan.image_size
         h, w = H + 2 * pad[0], W + 2 * pad[1]
-        iwes = torch.zeros((K, h, w), dtype=torch.float32, device=plan.device)
         with torch.cuda.device(plan.device):
-            check(lib.ebos_iwe_2dof_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), plan.n, ptr(th32), K, h, w,
-                                        pad[0], pad[1], ptr(iwes), stream_ptr()), "ebos_iwe_2dof")
+            if _slab_ok(plan, halo):
+                ws = _workspace(plan, pad, halo, splits)
+                iwes = torch.empty((K, h, w), dtype=torch.float32, device=plan.device)
+                check(lib.ebos_iwe_2dof_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), ptr(plan.pix),
+                                                 ptr(plan.key_offsets), plan.n, ptr(th32), K, H, W, plan.tile[0],
+                                                 plan.tile[1], int(halo), int(splits), pad[0], pad[1], ptr(ws), ws.numel(),
+                                                 ptr(iwes), 0, 0, None, None, stream_ptr()), "ebos_iwe_2dof_slab")
+            else:
+                iwes = torch.zeros((K, h, w), dtype=torch.float32, device=plan.device)
+                check(lib.ebos_iwe_2dof_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), plan.n, ptr(th32), K, h, w,
+                                            pad[0], pad[1], ptr(iwes), stream_ptr()), "ebos_iwe_2dof")
         ctx.save_for_backward(th32, wp if wp is not None else torch.empty(0))
         ctx.meta = (plan, pad, thetas.dtype, thetas.device, weight is not None)
         return iwes if thetas.dtype == torch.float32 else iwes.to(thetas.dtype)
@@ -345,4 +393,4 @@ class _FusedIwe2Dof(torch.autograd.Function):
             check(lib.ebos_iwe_2dof_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp) if has_w else None, plan.n,
                                             ptr(th32), K, h, w, pad[0], pad[1], ptr(g32), None, 0, ptr(d_th),
                                             stream_ptr()), "ebos_iwe_2dof_bwd")
-        return d_th.to(device=tdev, dtype=tdt), None, None, None
+        return d_th.to(device=tdev, dtype=tdt), None, None, None, None, None

@@ -185,12 +185,18 @@ int ebos_events_to_soa_f64(const double* events, const double* tminmax, int ref_
  *   scratch: >= ebos_bin_scratch_bytes(n_keys) bytes
  *   oob_count (device int32, nullable): events whose source pixel is outside the image; they are
  *       dropped from the plan (torch.gather would raise for them, src/warp.py:334-336).
+ *   pix [n] (uint16, out, nullable): tile-local source pixel of every sorted event -- the COMPACT event
+ *       format (pix u16 + dt f32 = 6 B/event instead of 12) the tile-private kernels read when every
+ *       source coordinate is a non-negative integer (camera events always are);
+ *   frac_count (device int32, nullable): number of kept events with a fractional / negative source
+ *       coordinate; the compact format is valid iff it stays 0.
+ * All SoA outputs must be 16-byte aligned and padded to a multiple of 4 elements (vector loads).
  * The order of events inside one source pixel is not deterministic (atomic cursor). */
 size_t ebos_bin_scratch_bytes(int64_t n_keys);
 int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const float* p, int64_t n,
                         int H, int W, int tile_h, int tile_w, float* xs, float* ys, float* dts, float* ps,
-                        int32_t* perm, int32_t* key_offsets, int32_t* oob_count, void* scratch,
-                        size_t scratch_bytes, ebos_stream_t stream);
+                        int32_t* perm, int32_t* key_offsets, int32_t* oob_count, uint16_t* pix,
+                        int32_t* frac_count, void* scratch, size_t scratch_bytes, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused hot path, dense flow: A3 + A7 in one pass, nothing materialised
@@ -242,21 +248,35 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  * ebos_iwe_dense_tiled_bwd_f32   backward.  One workgroup per tile: upstream image tile in LDS,
  *   wavefront-segmented sums per source pixel, d_flow [2, H, W] OVERWRITTEN with plain stores
  *   (binned plans only; g_image/affine/g_lo/d_weight as in ebos_iwe_dense_bwd_f32; d_weight in plan order).
+ * pix (nullable): the compact event format of ebos_bin_events_f32; when given, xs/ys are not read
+ *   (6 B/event instead of 12).  All SoA arrays are read 4 events (16 bytes) per lane: 16-byte aligned,
+ *   padded to a multiple of 4 elements.
  * (tile_h, tile_w, halo) must be one of ebos_slab_config().
  * ---------------------------------------------------------------------------------------- */
 int ebos_slab_config(int* out, int cap);
 size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h,
                                      int pad_w);
 int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                            const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
+                            const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* flow, int H,
+                            int W, int tile_h,
                             int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary,
                             float* out_variance, double* moments, ebos_stream_t stream);
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                                 const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
+                                 const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* flow,
+                                 int H, int W,
                                  int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, float* d_flow, float* d_weight,
                                  ebos_stream_t stream);
+
+/* 2-DoF hypotheses on the tile-private pipeline (BASELINE config 5): thetas [K, 2] (device), x' = x + dt theta
+ * (src/warp.py:364-383); iwes [K, h, w] are OVERWRITTEN; out_variance [K] / moments [K, 2] as above.  The K
+ * hypotheses run back to back on the stream and share one workspace (same size as for the dense flow). */
+int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+                           const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* thetas, int K,
+                           int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w,
+                           void* workspace, size_t workspace_bytes, float* iwes, int want_variance,
+                           int omit_boundary, float* out_variance, double* moments, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused hot path, 2-DoF hypotheses (solver outer loop, SURVEY.md 3.4 / BASELINE config 5):

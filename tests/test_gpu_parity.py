@@ -365,6 +365,32 @@ def test_fused_2dof_hypotheses(ebos):
         np.testing.assert_allclose(th.grad[k].cpu().numpy(), t.grad.numpy(), rtol=2e-3, atol=1e-6)
 
 
+def test_2dof_tile_private_sweep(ebos):
+    """Hypothesis sweep on a binned plan (tile-private pipeline, uniform motion) vs the oracle."""
+    h, w, n = 96, 128, 60_000
+    ev = O.synth_events(n, h, w, seed=31)
+    grid = np.stack(np.meshgrid(np.linspace(-30, 30, 4), np.linspace(-30, 30, 3), indexing="ij"), -1).reshape(-1, 2)
+    grid = np.concatenate([grid, [[45.0, -50.0]]])  # beyond the halo: spills to global atomics
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile=(32, 32))
+    assert plan.compact
+    var = plan.variance_2dof(G(grid, torch.float32), halo=32, chunk=5)
+    iwes = plan.iwe_2dof(G(grid, torch.float32), halo=32)
+    for k, th in enumerate(grid):
+        ref = O.iwe_2dof(torch.from_numpy(ev), torch.from_numpy(th), (h, w))
+        assert rel(iwes[k].cpu().numpy(), ref.numpy()) < 1e-5, k
+        v = torch.var(ref).item()
+        assert abs(var[k].item() - v) < 1e-5 * v, k
+    # fractional source coordinates: the plan keeps the (x, y, dt) format and still agrees
+    ev2 = ev.copy()
+    ev2[::3, 0] += 0.25
+    plan2 = ebos.EventPlan.build(G(ev2), (h, w), "first", True, tile=(32, 32))
+    assert not plan2.compact
+    i2 = plan2.iwe_2dof(G(grid[:3], torch.float32), halo=32)
+    for k in range(3):
+        ref = O.iwe_2dof(torch.from_numpy(ev2), torch.from_numpy(grid[k]), (h, w))
+        assert rel(i2[k].cpu().numpy(), ref.numpy()) < 1e-5
+
+
 def test_plan_binning_properties(ebos):
     h, w, n = 70, 90, 30_000
     ev = O.synth_events(n, h, w, seed=11)

@@ -78,7 +78,10 @@ def main():
         pl = plans[(th, tw)]
         if not _slab_ok(pl, halo):
             continue
-        for want_var in (False, True):
+        for want_var, compact in ((False, True), (True, True), (False, False)):
+            saved_pix = pl.pix
+            if not compact:
+                pl.pix = None
             ts = []
             for r in range(args.rounds + 1):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -90,7 +93,8 @@ def main():
                     ts.append(a.elapsed_time(b))
             err = (torch.linalg.norm(out_iwe - ref) / torch.linalg.norm(ref)).item()
             assert err < 1e-5, (c, err)
-            slab_times[("slab+var" if want_var else "slab", c)] = ts
+            pl.pix = saved_pix
+            slab_times[(("slab+var" if want_var else "slab") + ("" if compact else "-xy12B"), c)] = ts
     times.update(slab_times)
     n = args.events
     for k, v in times.items():
