@@ -1,0 +1,9 @@
+"""Solver registry (reference: src/solver/__init__.py:11-16): ``collections[name](orig_image_shape,
+crop_image_shape, calibration_parameter=..., solver_config=..., visualize_module=...)``."""
+from .base import SolverBase
+from .contrast_maximization import ContrastMaximization, patch_grid_shape
+
+collections = {
+    "contrast_maximization": ContrastMaximization,
+    "cmax": ContrastMaximization,
+}

@@ -1,0 +1,131 @@
+"""``ContrastMaximization`` -- the solver the reference's release references but does not ship
+(configs/README.md:65 points at a missing src/solver/contrast_maximization.py).
+
+objective(theta) = - contrast(IWE(warp(events, motion(theta)))) [+ weighted regularisers on the flow]
+
+    motion_model "dense-flow"      theta = patch-flow grid [2, gh, gw] (``patch.size`` / ``patch.sliding_window``),
+                                   upsampled to a dense flow (src/solver/patch_eklt.py:173-204), optimised with Adam
+                                   (loop shape of src/solver/generative_max_likelihood.py:306-341)
+    motion_model "2d-translation"  theta = (trans_x, trans_y); exhaustive grid sweep over ``parameters`` min/max
+                                   (the optuna "uniform"/grid sampler, :238-255), optionally refined with Adam
+
+Everything per event runs in the fused tile-private HIP pipeline on an ``EventPlan`` built once per window.
+YAML keys read (same names as configs/hot_plate1.yaml:46-80 of the reference): warp_direction, motion_model,
+parameters, cost, cost_with_weight, outer_padding, iwe.{method, blur_sigma}, patch.{size, sliding_window},
+optimizer.{method, n_iter, parameters.lr, sampler}.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import costs, ops
+from .._staging import to_gpu
+from ..event_plan import EventPlan
+from .base import SolverBase
+
+logger = logging.getLogger(__name__)
+
+CONTRAST_COSTS = ("image_variance", "gradient_magnitude")
+
+
+def patch_grid_shape(image_size, patch_size, sliding_window):
+    """Number of patch centres per axis (src/solver/patch_eklt.py:85-89)."""
+    gh = len(np.arange(0, image_size[0] - patch_size[0] + sliding_window[0], sliding_window[0]))
+    gw = len(np.arange(0, image_size[1] - patch_size[1] + sliding_window[1], sliding_window[1]))
+    return gh, gw
+
+
+class ContrastMaximization(SolverBase):
+    def __init__(self, orig_image_shape, crop_image_shape, calibration_parameter=None, solver_config=None,
+                 visualize_module=None):
+        super().__init__(orig_image_shape, crop_image_shape, calibration_parameter, solver_config, visualize_module)
+        cfg = self.slv_config
+        self.cost_with_weight: Dict[str, float] = dict(cfg.get("cost_with_weight") or {cfg.get("cost", "image_variance"): 1.0})
+        self.contrast_terms = {k: w for k, w in self.cost_with_weight.items() if k in CONTRAST_COSTS}
+        self.flow_terms = {k: w for k, w in self.cost_with_weight.items() if k not in CONTRAST_COSTS}
+        if not self.contrast_terms:
+            raise ValueError(f"cost_with_weight needs at least one contrast cost of {CONTRAST_COSTS}")
+        unknown = [k for k in self.flow_terms if k not in costs.functions]
+        if unknown:
+            raise KeyError(f"unknown cost(s) {unknown}; registered: {sorted(costs.functions)}")
+        self.flow_cost = (costs.HybridCost("minimize", self.flow_terms) if self.flow_terms else None)
+        self.omit_boundary = bool(cfg.get("omit_boundary", False))
+        iwe_cfg = cfg.get("iwe") or {}
+        if iwe_cfg.get("method", "bilinear_vote") != "bilinear_vote":
+            raise NotImplementedError("the contrast objective is defined on method='bilinear_vote'")
+        if float(iwe_cfg.get("blur_sigma", 0) or 0) > 0:
+            raise NotImplementedError("iwe.blur_sigma > 0 is forward-only here; run the loop with blur_sigma = 0")
+        pcfg = cfg.get("patch") or {}
+        self.patch_size = tuple(pcfg.get("size", (24, 32)))
+        self.sliding_window = tuple(pcfg.get("sliding_window", self.patch_size))
+        ocfg = cfg.get("optimizer") or {}
+        self.opt_method = ocfg.get("method", "Adam")
+        self.n_iter = int(ocfg.get("n_iter", 100))
+        self.lr = float((ocfg.get("parameters") or {}).get("lr", 0.05))
+        self.param_ranges = cfg.get("parameters") or {}
+        self.halo = int(cfg.get("halo", 32))
+        self.history: List[float] = []
+
+    # ------------------------------------------------------------------ objective pieces
+    def _contrast(self, plan: EventPlan, flow: torch.Tensor) -> torch.Tensor:
+        total = 0.0
+        for name, wgt in self.contrast_terms.items():
+            total = total + wgt * plan.contrast_dense(flow, name, self.omit_boundary, pad=(self.pad, self.pad), halo=self.halo)
+        return total
+
+    def objective(self, plan: EventPlan, flow: torch.Tensor) -> torch.Tensor:
+        """Loss to MINIMISE: -contrast + regularisers (weights from cost_with_weight)."""
+        loss = -self._contrast(plan, flow)
+        if self.flow_cost is not None:
+            ones = torch.ones(flow.shape[-2:], dtype=flow.dtype, device=flow.device)
+            loss = loss + self.flow_cost.calculate({"flow": flow, "omit_boundary": self.omit_boundary, "weights": ones})
+        return loss
+
+    # ------------------------------------------------------------------ estimate
+    def estimate(self, events, *args, **kwargs) -> np.ndarray:
+        """events [n, 4] (x=row, y=col, t, p) -> flow [2, H, W] (numpy), like the reference's solvers."""
+        ev = to_gpu(events)
+        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True)
+        self.history = []
+        if self.motion_model == "dense-flow":
+            flow = self._estimate_patch_flow(plan)
+        elif self.motion_model in ("2d-translation", "rigid-optical-flow"):
+            theta = self._estimate_translation(plan)
+            H, W = self.orig_image_shape
+            flow = (-theta).reshape(2, 1, 1).expand(2, H, W)  # dense flow equivalent of theta (src/warp.py:186-187)
+        else:
+            raise NotImplementedError(f"motion_model {self.motion_model!r}")
+        return flow.detach().cpu().numpy().astype(np.float64)
+
+    def _estimate_patch_flow(self, plan: EventPlan) -> torch.Tensor:
+        H, W = self.orig_image_shape
+        gh, gw = patch_grid_shape((H, W), self.patch_size, self.sliding_window)
+        init = self.previous_best if self.previous_best is not None else torch.zeros((2, gh, gw))
+        theta = to_gpu(init, device=plan.device, dtype=torch.float32).reshape(2, gh, gw).clone().requires_grad_(True)
+        opt = torch.optim.Adam([theta], lr=self.lr)
+        for _ in range(self.n_iter):
+            opt.zero_grad(set_to_none=True)
+            dense = ops.upsample_patch_flow(theta, self.patch_size, self.sliding_window, (H, W))
+            loss = self.objective(plan, dense)
+            loss.backward()
+            opt.step()
+            self.history.append(loss.detach())
+        self.history = [float(v) for v in torch.stack(self.history).cpu()] if self.history else []
+        self.patch_flow = theta.detach()
+        return ops.upsample_patch_flow(theta.detach(), self.patch_size, self.sliding_window, (H, W))
+
+    def _estimate_translation(self, plan: EventPlan) -> torch.Tensor:
+        rx = self.param_ranges.get("trans_x") or {"min": -30.0, "max": 30.0}
+        ry = self.param_ranges.get("trans_y") or {"min": -30.0, "max": 30.0}
+        n = max(2, int(round(np.sqrt(max(self.n_iter, 4)))))
+        gx = torch.arange(n, dtype=torch.float32) * ((rx["max"] - rx["min"]) / n) + rx["min"]  # np.arange(min, max, step), :238-255
+        gy = torch.arange(n, dtype=torch.float32) * ((ry["max"] - ry["min"]) / n) + ry["min"]
+        grid = torch.stack(torch.meshgrid(gx, gy, indexing="ij"), -1).reshape(-1, 2).to(plan.device)
+        var = plan.variance_2dof(grid, self.omit_boundary, pad=(self.pad, self.pad), halo=self.halo)
+        self.history = [float(-v) for v in var.cpu()]
+        self.sweep_grid, self.sweep_contrast = grid, var
+        return grid[int(torch.argmax(var).item())]

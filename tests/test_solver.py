@@ -1,0 +1,101 @@
+"""The contrast-maximisation solver behind the reference's solver registry ("next" row f.1 of SURVEY 8).
+CPU part: registry, YAML keys, error behaviour.  GPU part: the solver recovers a known motion, and its
+Adam trajectory matches the same loop driven by the CPU oracle (fp64)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import ebos_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_cfg():
+    return yaml.safe_load(open(os.path.join(ROOT, "configs", "cmax_hot_plate1.yaml")))
+
+
+def moving_points(h, w, n_points, per_point, v, seed=0):
+    """Events of points translating with velocity v (px per window): the contrast peaks at flow == v."""
+    rs = np.random.RandomState(seed)
+    p0 = np.stack([rs.uniform(8, h - 16, n_points), rs.uniform(8, w - 16, n_points)], 1)
+    t = rs.uniform(0, 1, (n_points, per_point))
+    x = np.rint(p0[:, None, 0] + t * v[0]).reshape(-1)
+    y = np.rint(p0[:, None, 1] + t * v[1]).reshape(-1)
+    ev = np.stack([x, y, t.reshape(-1) * 0.02 + 10.0, rs.randint(0, 2, x.size)], 1)
+    ev = ev[(ev[:, 0] >= 0) & (ev[:, 0] < h) & (ev[:, 1] >= 0) & (ev[:, 1] < w)]
+    return ev[np.argsort(ev[:, 2], kind="stable")]
+
+
+def test_registry_and_config_keys():
+    import event_based_bos_amd as ebos
+
+    cfg = load_cfg()
+    assert set(cfg) >= {"is_dnn", "data", "common_params", "solver"}
+    cls = ebos.solver.collections[cfg["solver"]["method"]]
+    s = cls((260, 346), (260, 346), calibration_parameter=None, solver_config=cfg["solver"], visualize_module=None)
+    assert isinstance(s, ebos.solver.SolverBase)
+    assert s.contrast_terms == {"image_variance": 1.0} and s.flow_terms == {"flow_norm": 0.001}
+    assert s.orig_warper.normalize_t and s.orig_imager.image_size == (260, 346)
+    assert ebos.solver.patch_grid_shape((720, 1280), (24, 32), (24, 32)) == (30, 40)
+    with pytest.raises(ValueError):
+        cls((8, 8), (8, 8), solver_config={"cost_with_weight": {"flow_norm": 1.0}})
+    with pytest.raises(KeyError):
+        cls((8, 8), (8, 8), solver_config={"cost_with_weight": {"image_variance": 1.0, "nope": 1.0}})
+    with pytest.raises(NotImplementedError):
+        cls((8, 8), (8, 8), solver_config={"iwe": {"blur_sigma": 1}})
+
+
+@pytest.mark.gpu
+def test_solver_recovers_translation_dense_and_2dof():
+    import event_based_bos_amd as ebos
+
+    h, w = 96, 128
+    v = np.array([6.0, -4.0])
+    ev = moving_points(h, w, 600, 40, v, seed=1)
+    cfg = load_cfg()["solver"]
+    cfg.update(patch={"size": [24, 32], "sliding_window": [24, 32]}, optimizer={"method": "Adam", "n_iter": 80, "parameters": {"lr": 0.5}},
+               cost_with_weight={"image_variance": 1.0})
+    cfg["filter"] = {"parameters": {"xmin": 0, "xmax": h, "ymin": 0, "ymax": w}}
+    s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    events, period = s.preprocess(ev)
+    assert events.shape == ev.shape and abs(period - 0.02) < 1e-3
+    flow = s.estimate(events)
+    assert flow.shape == (2, h, w) and flow.dtype == np.float64
+    assert s.history[-1] < s.history[0] * 1.5  # loss (= -variance) went down (more negative)
+    med = np.median(flow.reshape(2, -1), axis=1)
+    assert np.all(np.abs(med - v) < 1.0), med
+    cfg2 = dict(cfg, motion_model="2d-translation", parameters={"trans_x": {"min": -12, "max": 12}, "trans_y": {"min": -12, "max": 12}},
+                optimizer={"method": "grid", "n_iter": 576})
+    s2 = ebos.solver.collections["cmax"]((h, w), (h, w), solver_config=cfg2)
+    flow2 = s2.estimate(ev)
+    assert np.allclose(flow2[:, 0, 0], v, atol=0.6), flow2[:, 0, 0]  # dense-flow equivalent of theta = -v
+
+
+@pytest.mark.gpu
+def test_solver_trajectory_matches_cpu_oracle():
+    """Same Adam loop, driven once by the HIP pipeline (f32) and once by the CPU oracle (fp64)."""
+    import event_based_bos_amd as ebos
+
+    h, w, n_iter = 60, 78, 6
+    ev = moving_points(h, w, 300, 30, np.array([3.0, 2.0]), seed=2)
+    cfg = load_cfg()["solver"]
+    cfg.update(patch={"size": [20, 26], "sliding_window": [20, 26]}, optimizer={"method": "Adam", "n_iter": n_iter, "parameters": {"lr": 0.3}})
+    s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    s.estimate(ev)
+    gh, gw = ebos.solver.patch_grid_shape((h, w), (20, 26), (20, 26))
+    theta = torch.zeros((2, gh, gw), dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([theta], lr=0.3)
+    ref = []
+    tev = torch.from_numpy(ev)
+    for _ in range(n_iter):
+        opt.zero_grad()
+        dense = O.upsample_patch_flow(theta, (h, w), (20, 26), (20, 26))
+        loss = O.image_variance(O.iwe_dense(tev, dense, (h, w))) + 0.001 * O.flow_norm(dense)
+        loss.backward()
+        opt.step()
+        ref.append(loss.item())
+    np.testing.assert_allclose(s.history, ref, rtol=2e-3)
+    np.testing.assert_allclose(s.patch_flow.cpu().numpy(), theta.detach().numpy(), atol=5e-2)
