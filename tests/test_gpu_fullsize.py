@@ -1,0 +1,101 @@
+"""Parity at BASELINE.json's full sizes (10 M events, 1280x720), on the GPU box.
+
+Config 2 (variance) and config 3 (gradient magnitude, cost + gradient vs CPU autograd) are compared with the
+CPU oracle directly (a few seconds of host time each), plus size-independent properties of the domain:
+mass conservation, linearity in the per-event weight, additivity over event subsets, bit-reproducibility of the
+fixed-point path, and agreement of every kernel organisation (tile-private / atomic tiled / general)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ebos_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+H, W, N = 720, 1280, 10_000_000
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import event_based_bos_amd as ebos
+
+    dev = torch.device("cuda:0")
+    ev = O.synth_events(N, H, W, seed=0)
+    fl = O.synth_dense_flow(H, W, seed=1, max_val=30.0)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True)
+    flow = torch.from_numpy(fl).float().to(dev)
+    return ebos, ev, fl, plan, flow
+
+
+def test_config2_variance_full_size_vs_oracle(setup):
+    ebos, ev, fl, plan, flow = setup
+    assert plan.n == N and plan.compact
+    f = torch.from_numpy(fl).requires_grad_(True)
+    iwe_ref = O.iwe_dense(torch.from_numpy(ev), f, (H, W))
+    loss_ref = O.image_variance(iwe_ref)
+    loss_ref.backward()
+    fg = flow.clone().requires_grad_(True)
+    loss = -plan.contrast_dense(fg, "image_variance")
+    loss.backward()
+    iwe = plan.iwe_dense(flow)
+    assert O.rel_l2(iwe.cpu().numpy(), iwe_ref.detach().numpy()) < 1e-5          # north_star bar: 1e-4
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    assert O.rel_l2(fg.grad.cpu().numpy(), f.grad.numpy()) < 1e-3                  # SURVEY 8d bar
+    # ~1.6 % of the mass leaves the image (IWE sum 9 838 422.9 of 10 M)
+    assert abs(iwe.sum().item() - 9_838_422.9) < 50.0
+
+
+def test_config3_gradient_magnitude_full_size_vs_cpu_autograd(setup):
+    ebos, ev, fl, plan, flow = setup
+    f = torch.from_numpy(fl).requires_grad_(True)
+    loss_ref = O.gradient_magnitude(O.iwe_dense(torch.from_numpy(ev), f, (H, W)))
+    loss_ref.backward()
+    fg = flow.clone().requires_grad_(True)
+    loss = -plan.contrast_dense(fg, "gradient_magnitude")
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())       # cost rel err < 1e-5
+    assert O.rel_l2(fg.grad.cpu().numpy(), f.grad.numpy()) < 1e-3                  # gradient rel-L2 < 1e-3
+
+
+def test_kernel_organisations_agree_and_are_reproducible(setup):
+    ebos, ev, fl, plan, flow = setup
+    a = plan.iwe_dense(flow, halo=32)            # tile-private slabs, fixed point
+    b = plan.iwe_dense(flow, halo=32)
+    assert torch.equal(a, b)                     # integer accumulation + fixed combine order: bit-reproducible
+    saved, plan.pix = plan.pix, None             # 12 B/event (x, y, dt) format
+    c = plan.iwe_dense(flow, halo=32)
+    plan.pix = saved
+    assert torch.equal(a, c)
+    d = plan.iwe_dense(flow, halo=64)            # atomic-flush tiled kernel (f32 LDS, 64 px halo)
+    e = plan.iwe_dense(flow, halo=None)          # general kernel, global atomics
+    for other in (d, e):
+        assert (torch.linalg.norm(other - a) / torch.linalg.norm(a)).item() < 1e-6
+    g = plan.iwe_dense(flow, halo=16)            # halo smaller than the 30 px flow: taps spill, still exact
+    assert (torch.linalg.norm(g - a) / torch.linalg.norm(a)).item() < 1e-6
+
+
+def test_domain_properties_full_size(setup):
+    ebos, ev, fl, plan, flow = setup
+    dev = flow.device
+    # mass conservation with padding wide enough to catch every tap: sum(IWE) == N
+    padded = plan.iwe_dense(flow, pad=(32, 32))
+    assert abs(padded.double().sum().item() - N) < 1e-6 * N
+    # linearity in the weight: IWE(2.5 w) == 2.5 IWE(w);  additivity: IWE(w1) + IWE(w2) == IWE(w1 + w2)
+    w1 = torch.rand(N, device=dev)
+    w2 = 1.0 - w1
+    i1, i2 = plan.iwe_dense(flow, weight=w1), plan.iwe_dense(flow, weight=w2)
+    unit = plan.iwe_dense(flow)
+    assert (torch.linalg.norm(i1 + i2 - unit) / torch.linalg.norm(unit)).item() < 1e-6
+    assert (torch.linalg.norm(plan.iwe_dense(flow, weight=2.5 * w1) - 2.5 * i1) / torch.linalg.norm(i1)).item() < 1e-6
+    # zero flow: the IWE is the event histogram (integer counts, exact)
+    hist = plan.iwe_dense(torch.zeros_like(flow))
+    counts = np.bincount((ev[:, 0].astype(np.int64) * W + ev[:, 1].astype(np.int64)), minlength=H * W).reshape(H, W)
+    assert np.array_equal(hist.cpu().numpy(), counts.astype(np.float32))
+    # d(variance)/d(flow) of the zero-weight events is zero; d/d(weight) matches finite differences in aggregate
+    wz = torch.ones(N, device=dev, requires_grad=True)
+    ebos.ops.image_variance(plan.iwe_dense(flow, weight=wz)).backward()
+    eps = 1e-2
+    up = ebos.ops.image_variance(plan.iwe_dense(flow, weight=torch.full((N,), 1.0 + eps, device=dev)))
+    dn = ebos.ops.image_variance(plan.iwe_dense(flow, weight=torch.full((N,), 1.0 - eps, device=dev)))
+    fd = (up - dn).item() / (2 * eps)
+    assert abs(wz.grad.sum().item() - fd) < 1e-3 * abs(fd)
