@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--events", type=int, default=N_EVENTS)
-    ap.add_argument("--tile", type=int, nargs=2, default=[64, 64])
+    ap.add_argument("--tile", type=int, nargs=2, default=[0, 0], help="source tile (0 0 = choose_tile: 45x80 at 1280x720)")
     ap.add_argument("--halo", type=int, default=32)
     ap.add_argument("--splits", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,7 +102,7 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    distributed = world > 1
+    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun also for a world of 1
     if distributed:
         import torch.distributed as dist
 
@@ -123,6 +123,8 @@ def main():
     flow = torch.from_numpy(flow_np).float().to(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if args.tile[0] <= 0:
+        args.tile = list(ebos.event_plan.choose_tile((H, W), args.halo))
     plan = ebos.EventPlan.build(ev_gpu, (H, W), "first", True, tile=tuple(args.tile))
     torch.cuda.synchronize()
     plan_build_ms = (time.perf_counter() - t0) * 1e3

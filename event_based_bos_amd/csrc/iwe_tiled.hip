@@ -211,9 +211,15 @@ __device__ __forceinline__ unsigned accumulate_slice(const TileRange& tr, double
         spilled |= (!inside) && (wv != 0.0f);
         const float ws = inside ? wv : 0.0f;
         if (MODE == ACC_FX) {
+          // round-to-nearest by the magic-number trick: bits(x + 1.5 * 2^23) - bits(1.5 * 2^23) == rint(x) for
+          // |x| < 2^22 -- one FMA + one integer subtract per tap instead of fma + floor + convert
+          constexpr float kMagic = 12582912.0f;
+          constexpr int kMagicBits = 0x4B400000;
           const float as = a * (ws * kFxScale), fs = f.fr * (ws * kFxScale);
-          const int q00 = (int)floorf(as * b + 0.5f), q10 = (int)floorf(fs * b + 0.5f);
-          const int q01 = (int)floorf(as * f.fc + 0.5f), q11 = (int)floorf(fs * f.fc + 0.5f);
+          const int q00 = __float_as_int(__fmaf_rn(as, b, kMagic)) - kMagicBits;
+          const int q10 = __float_as_int(__fmaf_rn(fs, b, kMagic)) - kMagicBits;
+          const int q01 = __float_as_int(__fmaf_rn(as, f.fc, kMagic)) - kMagicBits;
+          const int q11 = __float_as_int(__fmaf_rn(fs, f.fc, kMagic)) - kMagicBits;
           // word = (hi << 32) + lo as a 64-bit integer: a (tiny) negative lo borrows from hi, decode undoes it
           const unsigned long long v0 = ((unsigned long long)(unsigned)(q01 + (q00 >> 31)) << 32) | (unsigned)q00;
           const unsigned long long v1 = ((unsigned long long)(unsigned)(q11 + (q10 >> 31)) << 32) | (unsigned)q10;
@@ -277,7 +283,9 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   __shared__ int s_flag[2];  // [0] fixed-point overflow, [1] some event left the LDS window
   const TileRange tr = tile_range(key_offsets, TH * TW, tiles_x, splits);
 
-  for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;  // all-zero bits = 0 in both modes
+  static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
+  for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
+    reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
   __syncthreads();
 
@@ -292,12 +300,29 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   float4* out = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * (LH * LW));
   bool f64_flush = (MODE == ACC_F64);
   if (MODE == ACC_FX) {
-    // verify: sum of decoded fields == sum of added units (mod 2^32; a wrapped field shifts it by k (2^32 - 1))
-    const long long* s_fx = reinterpret_cast<const long long*>(s_acc);
+    // One pass: decode 4 consecutive cells (c0 % 4 == 0) of a row from planes A and B, write them to the slab
+    // optimistically, and sum the decoded fields for the overflow check
+    //   sum(decoded fields) == sum(added units)  (mod 2^32; a wrapped field shifts it by k (2^32 - 1)).
+    // Field decode in 32 bits: word = hi * 2^32 + lo with lo signed, so lo = low dword, hi = high dword - (lo >> 31).
+    const int2* pa = reinterpret_cast<const int2*>(s_acc);
+    const int2* pb = pa + LH * LW / 2;
     unsigned decoded = 0;
-    for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
-      const long long v = s_fx[i];
-      decoded += (unsigned)(fx_lo(v) + fx_hi(v));
+    constexpr float kInv = (float)kFxInv;
+    for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
+      const int r = i / (LW / 4), j = i - r * (LW / 4);  // cells 4j..4j+3 <- A words 2j, 2j+1 and B words 2j-1, 2j, 2j+1
+      const int wrow = r * (LW / 2);
+      const int2 a0 = pa[wrow + 2 * j], a1 = pa[wrow + 2 * j + 1];
+      const int2 b0 = pb[wrow + 2 * j], b1 = pb[wrow + 2 * j + 1];
+      const int a0h = a0.y - (a0.x >> 31), a1h = a1.y - (a1.x >> 31);
+      const int b0h = b0.y - (b0.x >> 31), b1h = b1.y - (b1.x >> 31);
+      int bmh = 0;
+      if (j > 0) {
+        const int2 bm = pb[wrow + 2 * j - 1];  // pair (4j-1, 4j); its lo field is summed by the previous group
+        bmh = bm.y - (bm.x >> 31);
+      }
+      decoded += (unsigned)(a0.x + a0h + a1.x + a1h + b0.x + b0h + b1.x + b1h);
+      out[i] = make_float4((float)(a0.x + bmh) * kInv, (float)(a0h + b0.x) * kInv, (float)(a1.x + b0h) * kInv,
+                           (float)(a1h + b1.x) * kInv);
     }
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     unsigned a = added, d = decoded;
@@ -320,29 +345,12 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       s_flag[0] = (ta != td);
     }
     __syncthreads();
-    if (s_flag[0]) {  // a field wrapped: redo this slice exactly in f64 (the spill taps were already issued)
+    if (s_flag[0]) {  // a field wrapped: redo this slice exactly in f64 and overwrite the slab (spill taps already issued)
       for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
       __syncthreads();
       accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr);
       __syncthreads();
       f64_flush = true;
-    } else {
-      // decode 4 consecutive cells c0..c0+3 of one row (c0 % 4 == 0) from planes A and B
-      const long long* pa = s_fx;
-      const long long* pb = s_fx + LH * LW / 2;
-      for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
-        const int r = i / (LW / 4), j = i - r * (LW / 4);  // cells 4j..4j+3, words 2j, 2j+1
-        const int wrow = r * (LW / 2);
-        const long long a0 = pa[wrow + 2 * j], a1 = pa[wrow + 2 * j + 1];
-        const long long b0 = pb[wrow + 2 * j], b1 = pb[wrow + 2 * j + 1];
-        const long long bm = j > 0 ? pb[wrow + 2 * j - 1] : 0;  // pair (4j-1, 4j)
-        const long long c0 = fx_lo(a0) + fx_hi(bm);
-        const long long c1 = fx_hi(a0) + fx_lo(b0);
-        const long long c2 = fx_lo(a1) + fx_hi(b0);
-        const long long c3 = fx_hi(a1) + fx_lo(b1);
-        out[i] = make_float4((float)((double)c0 * kFxInv), (float)((double)c1 * kFxInv), (float)((double)c2 * kFxInv),
-                             (float)((double)c3 * kFxInv));
-      }
     }
   }
   if (f64_flush) {
@@ -644,7 +652,9 @@ struct SlabConfig {
   int th, tw, halo;
 };
 // f64 tile + halo must fit 160 KiB (forward); backward needs 16 TH TW + 4 LH LW bytes
-constexpr SlabConfig kSlabConfigs[] = {{64, 64, 32}, {32, 64, 32}, {32, 32, 32}, {64, 64, 16}, {32, 32, 16}, {32, 32, 8}};
+// {45, 80, 32} cuts 720 x 1280 into exactly 16 x 16 = 256 tiles: one workgroup per CU of an MI355X
+constexpr SlabConfig kSlabConfigs[] = {{64, 64, 32}, {45, 80, 32}, {32, 64, 32}, {32, 32, 32},
+                                       {64, 64, 16}, {32, 32, 16}, {32, 32, 8}};
 constexpr int kNumSlabConfigs = sizeof(kSlabConfigs) / sizeof(kSlabConfigs[0]);
 
 struct SlabLayout {
@@ -757,6 +767,7 @@ bool slab_config_ok(int th, int tw, int halo) {
 
 #define EBOS_SLAB_DISPATCH(CALL)                                             \
   if (tile_h == 64 && tile_w == 64 && halo == 32) { rc = CALL(64, 64, 32); } \
+  else if (tile_h == 45 && tile_w == 80 && halo == 32) { rc = CALL(45, 80, 32); } \
   else if (tile_h == 32 && tile_w == 64 && halo == 32) { rc = CALL(32, 64, 32); } \
   else if (tile_h == 32 && tile_w == 32 && halo == 32) { rc = CALL(32, 32, 32); } \
   else if (tile_h == 64 && tile_w == 64 && halo == 16) { rc = CALL(64, 64, 16); } \

@@ -25,6 +25,24 @@ DEFAULT_TILE = (64, 64)
 DEFAULT_HALO = 32
 
 
+def choose_tile(image_size: Tuple[int, int], halo: int = DEFAULT_HALO, n_cu: int = 256) -> Tuple[int, int]:
+    """Tile size (among the built tile-private configurations with this halo) that fills the CUs best:
+    one workgroup owns one tile, workgroups run ~one per CU, so the cost of a pass is about
+    ceil(tiles / CUs) * (events of one tile + fixed per-tile work on its LDS window).
+    720 x 1280 -> (45, 80): exactly 16 x 16 = 256 tiles."""
+    H, W = image_size
+    best, best_cost = DEFAULT_TILE, None
+    for th, tw, hl in _hip.slab_configs():
+        if hl != halo:
+            continue
+        tiles = ((H + th - 1) // th) * ((W + tw - 1) // tw)
+        rounds = (tiles + n_cu - 1) // n_cu
+        cost = rounds * (th * tw + 0.15 * (th + 2 * hl) * (tw + 2 * hl))
+        if best_cost is None or cost < best_cost:
+            best, best_cost = (th, tw), cost
+    return best
+
+
 def parse_direction(direction: Union[str, float]) -> Tuple[int, float]:
     """Reference-time mode of src/warp.py:245-262 -> (ebos_reftime_mode, fraction)."""
     import numpy as np
@@ -82,7 +100,12 @@ class EventPlan:
               normalize_t: bool = True, tile: Optional[Tuple[int, int]] = DEFAULT_TILE) -> "EventPlan":
         """events: [n, 4] (x=row, y=col, t, p), float32 or float64, on the GPU.
 
-        ``tile=None`` keeps the input (time) order: only the general global-atomic kernels apply."""
+        ``tile=None`` keeps the input (time) order: only the general global-atomic kernels apply;
+        ``tile="auto"`` picks the tile-private configuration that fills the GPU best (``choose_tile``)."""
+        if isinstance(tile, str):
+            if tile != "auto":
+                raise ValueError("tile must be a (tile_h, tile_w) pair, None or 'auto'")
+            tile = choose_tile(image_size)
         lib = _hip.require_gpu()
         if events.dim() != 2 or events.shape[-1] != 4:
             raise ValueError(f"EventPlan.build expects un-batched events [n,4], got {tuple(events.shape)}")

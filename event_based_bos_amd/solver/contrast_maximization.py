@@ -89,7 +89,7 @@ class ContrastMaximization(SolverBase):
     def estimate(self, events, *args, **kwargs) -> np.ndarray:
         """events [n, 4] (x=row, y=col, t, p) -> flow [2, H, W] (numpy), like the reference's solvers."""
         ev = to_gpu(events)
-        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True)
+        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile="auto")
         self.history = []
         if self.motion_model == "dense-flow":
             flow = self._estimate_patch_flow(plan)

@@ -22,7 +22,8 @@ def setup():
     dev = torch.device("cuda:0")
     ev = O.synth_events(N, H, W, seed=0)
     fl = O.synth_dense_flow(H, W, seed=1, max_val=30.0)
-    plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile="auto")
+    assert plan.tile == (45, 80)  # 16 x 16 = 256 tiles: one per CU
     flow = torch.from_numpy(fl).float().to(dev)
     return ebos, ev, fl, plan, flow
 
@@ -66,12 +67,14 @@ def test_kernel_organisations_agree_and_are_reproducible(setup):
     c = plan.iwe_dense(flow, halo=32)
     plan.pix = saved
     assert torch.equal(a, c)
-    d = plan.iwe_dense(flow, halo=64)            # atomic-flush tiled kernel (f32 LDS, 64 px halo)
     e = plan.iwe_dense(flow, halo=None)          # general kernel, global atomics
-    for other in (d, e):
+    assert (torch.linalg.norm(e - a) / torch.linalg.norm(a)).item() < 1e-6
+    p64 = ebos.EventPlan.build(torch.from_numpy(ev).to(flow.device), (H, W), "first", True, tile=(64, 64))
+    d = p64.iwe_dense(flow, halo=64)             # atomic-flush tiled kernel (f32 LDS, 64 px halo)
+    g = p64.iwe_dense(flow, halo=16)             # halo smaller than the 30 px flow: taps spill, still exact
+    k = p64.iwe_dense(flow, halo=32)             # other tile size, tile-private
+    for other in (d, g, k):
         assert (torch.linalg.norm(other - a) / torch.linalg.norm(a)).item() < 1e-6
-    g = plan.iwe_dense(flow, halo=16)            # halo smaller than the 30 px flow: taps spill, still exact
-    assert (torch.linalg.norm(g - a) / torch.linalg.norm(a)).item() < 1e-6
 
 
 def test_domain_properties_full_size(setup):

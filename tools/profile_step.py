@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--events", type=int, default=10_000_000)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--tile", type=int, nargs=2, default=[64, 64])
+    ap.add_argument("--tile", type=int, nargs=2, default=[45, 80])
     ap.add_argument("--halo", type=int, default=32)
     ap.add_argument("--splits", type=int, default=1)
     ap.add_argument("--fwd-only", action="store_true")
