@@ -518,12 +518,14 @@ struct GradImage {
   }
 };
 
-template <int TH, int TW, int HALO, bool HAS_W, int FMT>
+// UNIFORM: 2-DoF model (flow == theta pair, x' = x + dt * theta): no flow gathers, and instead of a per-pixel
+// d_flow tile every lane sums dt * dL/d(x', y'); the workgroup writes one partial pair, summed over tiles afterwards.
+template <int TH, int TW, int HALO, bool HAS_W, int FMT, bool UNIFORM>
 __global__ void __launch_bounds__(kBlock)
 iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow, int H, int W,
                            int tiles_x, int pad_h, int pad_w, const float* __restrict__ g_image,
                            const float* __restrict__ affine, int g_lo, float* __restrict__ d_flow,
-                           float* __restrict__ d_weight) {
+                           float* __restrict__ d_weight, double* __restrict__ partials) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
@@ -549,8 +551,10 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   }
   __syncthreads();
 
+  double tot_x = 0.0, tot_y = 0.0;  // UNIFORM: this lane's sum of dt * dL/d(x', y')
   if (tr.beg < tr.end) {
-    const float* __restrict__ flow1 = flow + hw;
+    const float* __restrict__ flow1 = UNIFORM ? flow : flow + hw;
+    const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
     const int32_t g_last = (tr.end - 1) >> 2;
     int32_t grp = (tr.beg >> 2) + threadIdx.x;
     Group cur, nxt;
@@ -560,16 +564,16 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int lin = cur.rs[e] * W + cur.cs[e];
-      fu[e] = flow[lin];
-      fv[e] = flow1[lin];
+      fu[e] = UNIFORM ? uni_u : flow[lin];
+      fv[e] = UNIFORM ? uni_v : flow1[lin];
     }
     while (grp <= g_last) {
       float gu[4], gv[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int lin = nxt.rs[e] * W + nxt.cs[e];
-        gu[e] = flow[lin];
-        gv[e] = flow1[lin];
+        gu[e] = UNIFORM ? uni_u : flow[lin];
+        gv[e] = UNIFORM ? uni_v : flow1[lin];
       }
       Group nn;
       load_group<FMT, HAS_W, TH, TW>(nn, grp + 2 * kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
@@ -605,6 +609,11 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
         const float dx = wl * (b * (g10 - g00) + f.fc * (g11 - g01));  // dL/dx'
         const float dy = wl * (a * (g01 - g00) + f.fr * (g11 - g10));  // dL/dy'
         if (d_weight) d_weight[i] = a * b * g00 + f.fr * b * g10 + a * f.fc * g01 + f.fr * f.fc * g11;
+        if (UNIFORM) {
+          ax += edt * dx;  // dL/dtheta0 += dt * dL/dx'
+          ay += edt * dy;
+          continue;
+        }
         const int pix = (cur.rs[e] - tr0) * TW + (cur.cs[e] - tc0);
         if (pix != run_pix) {
           if (run_pix >= 0) {
@@ -618,7 +627,10 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
         ax -= edt * dx;  // dL/dflow0[src] += -dt * dL/dx'
         ay -= edt * dy;
       }
-      if (run_pix >= 0) {
+      if (UNIFORM) {
+        tot_x += (double)ax;
+        tot_y += (double)ay;
+      } else if (run_pix >= 0) {
         atomic_add(&s_d[run_pix], (double)ax);
         atomic_add(&s_d[TH * TW + run_pix], (double)ay);
       }
@@ -634,6 +646,16 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   }
   __syncthreads();
 
+  if (UNIFORM) {
+    __shared__ double red[kBlock / kWave];
+    tot_x = block_sum(tot_x, red);
+    tot_y = block_sum(tot_y, red);
+    if (threadIdx.x == 0) {
+      partials[2 * blockIdx.x] = tot_x;
+      partials[2 * blockIdx.x + 1] = tot_y;
+    }
+    return;
+  }
   // every flow pixel belongs to exactly one tile: plain coalesced stores, zeros where no event lives
   for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
     const int rl = i / TW, cl = i - rl * TW;
@@ -642,6 +664,21 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       d_flow[(int64_t)r * W + c] = (float)s_d[i];
       d_flow[hw + (int64_t)r * W + c] = (float)s_d[TH * TW + i];
     }
+  }
+}
+
+__global__ void __launch_bounds__(256) theta_grad_finalize_kernel(const double* __restrict__ partials, int ntiles, float* d_theta) {
+  double sx = 0.0, sy = 0.0;
+  for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
+    sx += partials[2 * i];
+    sy += partials[2 * i + 1];
+  }
+  __shared__ double red[4];
+  sx = block_sum(sx, red);
+  sy = block_sum(sy, red);
+  if (threadIdx.x == 0) {
+    d_theta[0] = (float)sx;
+    d_theta[1] = (float)sy;
   }
 }
 
@@ -739,20 +776,27 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
 }
 
 template <int TH, int TW, int HALO>
-int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, int H, int W, int pad_h, int pad_w,
-                     const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight, hipStream_t s) {
+int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int pad_h,
+                     int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
+                     double* partials, hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert(lds <= 160 * 1024, "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
   const bool compact = ev.pix != nullptr;
-  auto kb = ev.w ? (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, true, FMT_COMPACT>
-                            : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, true, FMT_XY>)
-                 : (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT>
-                            : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_XY>);
+  void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*);
+#define EBOS_PICK(HW)                                                                                      \
+  (uniform ? (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_COMPACT, true>                    \
+                      : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_XY, true>)                         \
+           : (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_COMPACT, false>                   \
+                      : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_XY, false>))
+  if (ev.w) kb = EBOS_PICK(true);
+  else kb = EBOS_PICK(false);
+#undef EBOS_PICK
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
   kb<<<dim3((unsigned)(tiles_y * tiles_x)), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image,
-                                                                    affine, g_lo, d_flow, d_weight);
+                                                                    affine, g_lo, d_flow, d_weight, partials);
+  if (uniform) theta_grad_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, tiles_y * tiles_x, d_flow);
   return EBOS_OK;
 }
 
@@ -867,6 +911,41 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
   return EBOS_OK;
 }
 
+int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight, const uint16_t* pix,
+                                const int32_t* key_offsets, int64_t n, const float* thetas, int K, int H, int W, int tile_h,
+                                int tile_w, int halo, int pad_h, int pad_w, const float* g_images, const float* affine,
+                                int g_lo, float* d_thetas, void* workspace, size_t workspace_bytes, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(thetas && g_images && d_thetas && key_offsets && workspace, "ebos_iwe_2dof_tiled_bwd: NULL argument");
+  EBOS_REQUIRE((dts && ((xs && ys) || pix)) || n == 0, "ebos_iwe_2dof_tiled_bwd: NULL event buffer");
+  EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_2dof_tiled_bwd: bad sizes");
+  if (!slab_config_ok(tile_h, tile_w, halo)) {
+    set_error("ebos_iwe_2dof_tiled_bwd: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  const SlabLayout L = slab_layout(H, W, tile_h, tile_w, halo, 1, pad_h, pad_w);
+  if (workspace_bytes < L.total) {
+    set_error("ebos_iwe_2dof_tiled_bwd: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+    return EBOS_ERR_SCRATCH;
+  }
+  // the tile partials live in the slab section of the (forward) workspace: it is dead once the IWE is combined
+  double* partials = reinterpret_cast<double*>(workspace);
+  hipStream_t s = as_stream(stream);
+  const EvPtrs evp{xs, ys, dts, weight, pix};
+  const int64_t hw = (int64_t)(H + 2 * pad_h) * (W + 2 * pad_w);
+  for (int k = 0; k < K; ++k) {
+    int rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL)                                                                                              \
+  launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, thetas + 2 * k, true, H, W, pad_h, pad_w, g_images + k * hw,              \
+                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, s)
+    EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+    if (rc != EBOS_OK) return rc;
+  }
+  EBOS_CHECK_LAUNCH("ebos_iwe_2dof_tiled_bwd");
+  return EBOS_OK;
+}
+
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
                                  const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
                                  int tile_h,
@@ -884,7 +963,8 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
   const EvPtrs evp{xs, ys, dts, weight, pix};
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
-  launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, s)
+  launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, \
+                               nullptr, s)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

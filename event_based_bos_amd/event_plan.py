@@ -399,20 +399,27 @@ class _FusedIwe2Dof(torch.autograd.Function):
                 check(lib.ebos_iwe_2dof_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), plan.n, ptr(th32), K, h, w,
                                             pad[0], pad[1], ptr(iwes), stream_ptr()), "ebos_iwe_2dof")
         ctx.save_for_backward(th32, wp if wp is not None else torch.empty(0))
-        ctx.meta = (plan, pad, thetas.dtype, thetas.device, weight is not None)
+        ctx.meta = (plan, pad, thetas.dtype, thetas.device, weight is not None, halo, splits)
         return iwes if thetas.dtype == torch.float32 else iwes.to(thetas.dtype)
 
     @staticmethod
     def backward(ctx, g):
         lib = _hip.require_gpu()
         th32, wp = ctx.saved_tensors
-        plan, pad, tdt, tdev, has_w = ctx.meta
+        plan, pad, tdt, tdev, has_w, halo, splits = ctx.meta
         K = th32.shape[0]
         H, W = plan.image_size
         h, w = H + 2 * pad[0], W + 2 * pad[1]
         g32 = g.to(torch.float32).contiguous()
         d_th = torch.zeros((K, 2), dtype=torch.float32, device=plan.device)
         with torch.cuda.device(plan.device):
+            if _slab_ok(plan, halo):
+                ws = _workspace(plan, pad, halo, splits)
+                check(lib.ebos_iwe_2dof_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp) if has_w else None,
+                                                      ptr(plan.pix), ptr(plan.key_offsets), plan.n, ptr(th32), K, H, W,
+                                                      plan.tile[0], plan.tile[1], int(halo), pad[0], pad[1], ptr(g32), None, 0,
+                                                      ptr(d_th), ptr(ws), ws.numel(), stream_ptr()), "ebos_iwe_2dof_tiled_bwd")
+                return d_th.to(device=tdev, dtype=tdt), None, None, None, None, None
             check(lib.ebos_iwe_2dof_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp) if has_w else None, plan.n,
                                             ptr(th32), K, h, w, pad[0], pad[1], ptr(g32), None, 0, ptr(d_th),
                                             stream_ptr()), "ebos_iwe_2dof_bwd")

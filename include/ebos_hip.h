@@ -278,6 +278,15 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
                            void* workspace, size_t workspace_bytes, float* iwes, int want_variance,
                            int omit_boundary, float* out_variance, double* moments, ebos_stream_t stream);
 
+/* backward of ebos_iwe_2dof_slab_f32: d_thetas[k] = sum_n dt * dL/d(x', y') for upstream images g_images [K, h, w]
+ * (affine [K, 2] / g_lo as in ebos_iwe_dense_bwd_f32); d_thetas [K, 2] is OVERWRITTEN.  workspace: the plan's forward
+ * workspace (its slab section is reused for the per-tile partial sums). */
+int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+                                const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* thetas,
+                                int K, int H, int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w,
+                                const float* g_images, const float* affine, int g_lo, float* d_thetas,
+                                void* workspace, size_t workspace_bytes, ebos_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused hot path, 2-DoF hypotheses (solver outer loop, SURVEY.md 3.4 / BASELINE config 5):
  *   A4 + A7 for K translations theta[k] = (theta0, theta1) in one pass over the events

@@ -380,6 +380,13 @@ def test_2dof_tile_private_sweep(ebos):
         assert rel(iwes[k].cpu().numpy(), ref.numpy()) < 1e-5, k
         v = torch.var(ref).item()
         assert abs(var[k].item() - v) < 1e-5 * v, k
+    # gradient of the hypotheses through the tile-private backward
+    th = G(grid[:5], torch.float32).requires_grad_(True)
+    (-ebos.ops.image_variance(plan.iwe_2dof(th, halo=32))).sum().backward()
+    for k in range(5):
+        t = torch.tensor(grid[k], dtype=torch.float64, requires_grad=True)
+        O.image_variance(O.iwe_2dof(torch.from_numpy(ev), t, (h, w))).backward()
+        np.testing.assert_allclose(th.grad[k].cpu().numpy(), t.grad.numpy(), rtol=2e-3, atol=2e-6)
     # fractional source coordinates: the plan keeps the (x, y, dt) format and still agrees
     ev2 = ev.copy()
     ev2[::3, 0] += 0.25
