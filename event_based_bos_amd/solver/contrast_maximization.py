@@ -68,6 +68,13 @@ class ContrastMaximization(SolverBase):
         self.lr = float((ocfg.get("parameters") or {}).get("lr", 0.05))
         self.param_ranges = cfg.get("parameters") or {}
         self.halo = int(cfg.get("halo", 32))
+        # optimizer.graph: capture one whole iteration (upsample -> fused objective -> backward -> Adam update) into a
+        # HIP graph and replay it.  Measured on MI355X / ROCm 7.2 (tools/bench_solver.py, 10 M events): replay costs
+        # <= 0.2 ms per iteration against ~0.6 ms for the eager loop (interpreter + autograd overhead around ~0.1 ms
+        # of GPU work), but capture + instantiation cost 0.7-1.1 s once -- it pays only beyond ~2000 iterations of
+        # one window, so it is off by default (hot_plate1.yaml runs 600).
+        self.use_graph = bool(ocfg.get("graph", False))
+        self.graphed = False
         self.history: List[float] = []
 
     # ------------------------------------------------------------------ objective pieces
@@ -106,17 +113,59 @@ class ContrastMaximization(SolverBase):
         gh, gw = patch_grid_shape((H, W), self.patch_size, self.sliding_window)
         init = self.previous_best if self.previous_best is not None else torch.zeros((2, gh, gw))
         theta = to_gpu(init, device=plan.device, dtype=torch.float32).reshape(2, gh, gw).clone().requires_grad_(True)
-        opt = torch.optim.Adam([theta], lr=self.lr)
-        for _ in range(self.n_iter):
+
+        def iteration(opt):
             opt.zero_grad(set_to_none=True)
             dense = ops.upsample_patch_flow(theta, self.patch_size, self.sliding_window, (H, W))
             loss = self.objective(plan, dense)
             loss.backward()
             opt.step()
-            self.history.append(loss.detach())
-        self.history = [float(v) for v in torch.stack(self.history).cpu()] if self.history else []
+            return loss.detach()
+
+        self.graphed = False
+        losses = torch.zeros(max(self.n_iter, 1), dtype=torch.float32, device=plan.device)
+        done = 0
+        if self.use_graph and self.n_iter > 4:
+            done = self._run_graphed(iteration, theta, losses)
+        if not self.graphed:
+            opt = torch.optim.Adam([theta], lr=self.lr)
+            for it in range(done, self.n_iter):
+                losses[it] = iteration(opt)
+        self.history = [float(v) for v in losses[:self.n_iter].cpu()]
         self.patch_flow = theta.detach()
         return ops.upsample_patch_flow(theta.detach(), self.patch_size, self.sliding_window, (H, W))
+
+    def _run_graphed(self, iteration, theta: torch.Tensor, losses: torch.Tensor) -> int:
+        """Adam loop as a replayed HIP graph.  The first iterations run eagerly on a side stream (they also create
+        the plan workspace and Adam state), one iteration is captured, the rest are replays.  Returns the number of
+        iterations performed; falls back to the eager loop (self.graphed = False) if capture is not possible."""
+        warm = 3
+        start = theta.detach().clone()
+        try:
+            opt = torch.optim.Adam([theta], lr=self.lr, capturable=True)
+            side = torch.cuda.Stream(device=theta.device)
+            side.wait_stream(torch.cuda.current_stream(theta.device))
+            with torch.cuda.stream(side):
+                for it in range(warm):
+                    losses[it] = iteration(opt)
+            torch.cuda.current_stream(theta.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                static_loss = iteration(opt)
+            losses[warm] = static_loss  # the capture itself does not execute: replay it for iteration `warm`
+            for it in range(warm, self.n_iter):
+                graph.replay()
+                losses[it] = static_loss
+            self.graphed = True
+            return self.n_iter
+        except Exception as err:  # capture unsupported for some op: restart the whole loop eagerly
+            logger.warning(f"HIP graph capture of the solver iteration failed ({err!r}); running eagerly")
+            with torch.no_grad():
+                theta.copy_(start)
+            theta.grad = None
+            self.graphed = False
+            return 0
 
     def _estimate_translation(self, plan: EventPlan) -> torch.Tensor:
         rx = self.param_ranges.get("trans_x") or {"min": -30.0, "max": 30.0}

@@ -82,7 +82,8 @@ def test_solver_trajectory_matches_cpu_oracle():
     h, w, n_iter = 60, 78, 6
     ev = moving_points(h, w, 300, 30, np.array([3.0, 2.0]), seed=2)
     cfg = load_cfg()["solver"]
-    cfg.update(patch={"size": [20, 26], "sliding_window": [20, 26]}, optimizer={"method": "Adam", "n_iter": n_iter, "parameters": {"lr": 0.3}})
+    cfg.update(patch={"size": [20, 26], "sliding_window": [20, 26]},
+               optimizer={"method": "Adam", "n_iter": n_iter, "parameters": {"lr": 0.3}, "graph": True})
     s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
     s.estimate(ev)
     gh, gw = ebos.solver.patch_grid_shape((h, w), (20, 26), (20, 26))
@@ -99,3 +100,10 @@ def test_solver_trajectory_matches_cpu_oracle():
         ref.append(loss.item())
     np.testing.assert_allclose(s.history, ref, rtol=2e-3)
     np.testing.assert_allclose(s.patch_flow.cpu().numpy(), theta.detach().numpy(), atol=5e-2)
+    # the HIP-graph replay of the iteration and the eager loop follow the same trajectory
+    assert s.graphed
+    cfg_e = dict(cfg, optimizer=dict(cfg["optimizer"], graph=False))
+    s_e = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_e)
+    s_e.estimate(ev)
+    assert not s_e.graphed
+    np.testing.assert_allclose(s.history, s_e.history, rtol=1e-5)
