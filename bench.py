@@ -140,12 +140,12 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     P = lambda t: t.data_ptr()
 
-    pix_ptr = plan.pix.data_ptr() if (plan.pix is not None and not args.no_compact) else None
-    bytes_per_event = 6.0 if pix_ptr else 12.0
+    cptrs = plan._compact_ptrs() if (plan.compact and not args.no_compact) else (None, None, None)
+    bytes_per_event = 6.0 if cptrs[0] else 12.0
 
     def step():
         # one objective evaluation: tile accumulate -> slab combine (writes the IWE) -> variance
-        _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, pix_ptr, P(plan.key_offsets), plan.n, P(flow),
+        _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n, P(flow),
                                                H, W, args.tile[0], args.tile[1], args.halo, args.splits, 0, 0, P(ws), nws,
                                                P(iwe), 1, 0, P(out), P(moments), stream), "ebos_iwe_dense_slab")
 
@@ -182,7 +182,7 @@ def main():
     def step_fwd_bwd():
         step()
         _hip.check(lib.ebos_image_variance_affine_f32(P(moments), P(upstream), 1, P(affine), stream), "affine")
-        _hip.check(lib.ebos_iwe_dense_tiled_bwd_f32(P(plan.x), P(plan.y), P(plan.dt), None, pix_ptr, P(plan.key_offsets), plan.n,
+        _hip.check(lib.ebos_iwe_dense_tiled_bwd_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
                                                     P(flow), H, W, args.tile[0], args.tile[1], args.halo, 0, 0, P(iwe), P(affine),
                                                     0, P(d_flow), None, stream), "ebos_iwe_dense_tiled_bwd")
 
@@ -217,7 +217,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
                                    "variance cost, fwd objective (tile accumulate + slab combine + variance)",
                        "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
-                       "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if pix_ptr else "SoA f32 (x,y,dt), 12 B/event")
+                       "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if cptrs[0] else "SoA f32 (x,y,dt), 12 B/event")
                                  + f", binned by source tile {args.tile[0]}x{args.tile[1]}, halo {args.halo}, splits {args.splits}", "parallelism": f"windows sharded, {world} rank(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": "iwe_slab_accumulate_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -64,17 +64,18 @@ SIGNATURES = {
     "ebos_events_to_soa_f32": (_I, _SOA),
     "ebos_events_to_soa_f64": (_I, _SOA),
     "ebos_bin_scratch_bytes": (_Z, [_L]),
-    "ebos_bin_events_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ebos_bin_events_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ebos_plan_compact_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _L, _P]),
     "ebos_iwe_dense_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_dense_tiled_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_tiled_config": (_I, [C.POINTER(C.c_int), _I]),
     "ebos_iwe_dense_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "ebos_slab_config": (_I, [C.POINTER(C.c_int), _I]),
     "ebos_iwe_slab_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
-    "ebos_iwe_dense_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
-    "ebos_iwe_2dof_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
-    "ebos_iwe_2dof_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
-    "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "ebos_iwe_dense_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
+    "ebos_iwe_2dof_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
+    "ebos_iwe_2dof_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
+    "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "ebos_iwe_2dof_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_2dof_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "ebos_cost_scratch_bytes": (_Z, [_I]),

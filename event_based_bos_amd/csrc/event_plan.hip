@@ -136,8 +136,7 @@ bin_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, con
                    const float* __restrict__ p, int64_t n, int H, int W, int tile_h, int tile_w, int tiles_x,
                    const int32_t* __restrict__ key_offsets, int32_t* cursor, float* __restrict__ xs,
                    float* __restrict__ ys, float* __restrict__ dts, float* __restrict__ ps, int32_t* __restrict__ perm,
-                   uint16_t* __restrict__ pix, int32_t* frac_count) {
-  const int tile_px = tile_h * tile_w;
+                   int32_t* frac_count) {
   int fractional = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float ex = x[i], ey = y[i];
@@ -149,10 +148,65 @@ bin_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y, con
     dts[pos] = dt[i];
     if (ps != nullptr) ps[pos] = p ? p[i] : 0.f;
     if (perm != nullptr) perm[pos] = (int32_t)i;
-    if (pix != nullptr) pix[pos] = (uint16_t)(key % tile_px);  // tile-local source pixel (compact format)
     fractional += (ex != (float)(int)ex) || (ey != (float)(int)ey) || ex < 0.f || ey < 0.f;
   }
   if (frac_count != nullptr && fractional) atomicAdd(frac_count, fractional);
+}
+
+// ---- compact plan: the 6 B/event layout read by the tile-private kernels --------------------------------------
+// Per tile t the events occupy groups [grp_offsets[t], grp_offsets[t+1]) of 4 slots; a slot is
+//   cpix (u16) = (row_in_tile << 8) | col_in_tile      cdt (f32) = dt, NaN in the padding slots of the last group
+// so the kernels need no liveness logic at all (a NaN dt makes every tap fall outside the LDS window).
+__global__ void __launch_bounds__(256)
+compact_offsets_kernel(const int32_t* __restrict__ key_offsets, int tile_px, int n_tiles, int32_t* grp_offsets) {
+  __shared__ int32_t s_wave[4];
+  __shared__ int32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  for (int start = 0; start < n_tiles; start += 256) {
+    const int t = start + threadIdx.x;
+    int32_t v = 0;
+    if (t < n_tiles) v = (key_offsets[(int64_t)(t + 1) * tile_px] - key_offsets[(int64_t)t * tile_px] + 3) >> 2;
+    int32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int32_t o = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += o;
+    }
+    if (lane == kWave - 1) s_wave[wid] = inc;
+    __syncthreads();
+    int32_t wave_off = 0;
+    for (int k = 0; k < wid; ++k) wave_off += s_wave[k];
+    const int32_t carry = s_carry;
+    if (t < n_tiles) grp_offsets[t] = carry + wave_off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = carry + wave_off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) grp_offsets[n_tiles] = s_carry;
+}
+
+__global__ void __launch_bounds__(256)
+compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
+                    const int32_t* __restrict__ key_offsets, int tile_h, int tile_w, int tiles_x,
+                    const int32_t* __restrict__ grp_offsets, uint16_t* __restrict__ cpix, float* __restrict__ cdt) {
+  const int t = blockIdx.x;
+  const int tile_px = tile_h * tile_w;
+  const int32_t beg = key_offsets[(int64_t)t * tile_px], end = key_offsets[(int64_t)(t + 1) * tile_px];
+  const int64_t out0 = (int64_t)grp_offsets[t] * 4, out1 = (int64_t)grp_offsets[t + 1] * 4;
+  const int r0 = (t / tiles_x) * tile_h, c0 = (t % tiles_x) * tile_w;
+  for (int64_t o = out0 + threadIdx.x; o < out1; o += blockDim.x) {
+    const int64_t src = beg + (o - out0);
+    if (src < end) {
+      const int r = (int)xs[src] - r0, c = (int)ys[src] - c0;
+      cpix[o] = (uint16_t)((r << 8) | c);
+      cdt[o] = dts[src];
+    } else {
+      cpix[o] = 0;
+      cdt[o] = __builtin_nanf("");
+    }
+  }
 }
 
 template <typename T>
@@ -196,7 +250,7 @@ size_t ebos_bin_scratch_bytes(int64_t n_keys) {
 
 int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const float* p, int64_t n, int H, int W,
                         int tile_h, int tile_w, float* xs, float* ys, float* dts, float* ps, int32_t* perm,
-                        int32_t* key_offsets, int32_t* oob_count, uint16_t* pix, int32_t* frac_count, void* scratch,
+                        int32_t* key_offsets, int32_t* oob_count, int32_t* frac_count, void* scratch,
                         size_t scratch_bytes, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && n >= 0 && n < (int64_t)1 << 31,
@@ -228,9 +282,31 @@ int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const f
   scan_add_offsets_kernel<<<dim3(nblk), dim3(kScanBlock), 0, s>>>(key_offsets, n_keys, block_sums);
   if (n > 0)
     bin_scatter_kernel<<<dim3(stream_grid(n, 256)), dim3(256), 0, s>>>(x, y, dt, p, n, H, W, tile_h, tile_w, tiles_x,
-                                                                      key_offsets, cursor, xs, ys, dts, ps, perm,
-                                                                      tile_h * tile_w <= 65536 ? pix : nullptr, frac_count);
+                                                                      key_offsets, cursor, xs, ys, dts, ps, perm, frac_count);
   EBOS_CHECK_LAUNCH("ebos_bin_events");
+  return EBOS_OK;
+}
+
+int ebos_plan_compact_f32(const float* xs, const float* ys, const float* dts, const int32_t* key_offsets, int64_t n, int H,
+                          int W, int tile_h, int tile_w, int32_t* grp_offsets, uint16_t* cpix, float* cdt,
+                          int64_t capacity_slots, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(key_offsets && grp_offsets && cpix && cdt, "ebos_plan_compact: NULL buffer");
+  EBOS_REQUIRE((xs && ys && dts) || n == 0, "ebos_plan_compact: NULL event buffer");
+  EBOS_REQUIRE(H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && tile_h <= 256 && tile_w <= 256 && n >= 0,
+               "ebos_plan_compact: bad sizes (tiles up to 256 x 256)");
+  const int tiles_y = (H + tile_h - 1) / tile_h, tiles_x = (W + tile_w - 1) / tile_w;
+  const int n_tiles = tiles_y * tiles_x;
+  if (capacity_slots < n + 3 * (int64_t)n_tiles + 4) {
+    set_error("ebos_plan_compact: capacity %lld < n + 3 tiles + 4 = %lld", (long long)capacity_slots,
+              (long long)(n + 3 * (int64_t)n_tiles + 4));
+    return EBOS_ERR_SCRATCH;
+  }
+  hipStream_t s = as_stream(stream);
+  compact_offsets_kernel<<<dim3(1), dim3(256), 0, s>>>(key_offsets, tile_h * tile_w, n_tiles, grp_offsets);
+  compact_fill_kernel<<<dim3(n_tiles), dim3(256), 0, s>>>(xs, ys, dts, key_offsets, tile_h, tile_w, tiles_x, grp_offsets, cpix,
+                                                          cdt);
+  EBOS_CHECK_LAUNCH("ebos_plan_compact");
   return EBOS_OK;
 }
 

@@ -54,8 +54,9 @@ __device__ __forceinline__ Taps warped_taps(int rs, int cs, float lx, float ly) 
 }
 
 // Event formats of a binned plan.  Both are read 4 consecutive events per lane (16-byte loads).
-//   FMT_XY       x f32, y f32, dt f32                 12 B/event   (any source coordinate)
-//   FMT_COMPACT  pix u16 (tile-local pixel), dt f32    6 B/event   (integer source coordinates: camera events)
+//   FMT_XY       x f32, y f32, dt f32 (plan order)                         12 B/event   any source coordinate
+//   FMT_COMPACT  cpix u16 = (row_in_tile << 8) | col_in_tile, cdt f32        6 B/event   integer source coordinates
+//                (camera events); tiles padded to whole groups, padding slots carry dt = NaN (ebos_plan_compact_f32)
 enum EvFormat { FMT_XY = 0, FMT_COMPACT = 1 };
 
 struct EvPtrs {
@@ -63,74 +64,92 @@ struct EvPtrs {
   const float* ys;
   const float* dts;
   const float* w;
-  const uint16_t* pix;
+  const int32_t* grp_off;  // compact plan: [tiles + 1] group offsets
+  const uint16_t* cpix;
+  const float* cdt;
 };
 
 struct Group {  // 4 consecutive events of one lane
   int rs[4], cs[4];   // source pixel (global)
   float fx[4], fy[4]; // fractional part of the source coordinate (0 in the compact format)
-  float dt[4], w[4];  // w == 0 marks a dead slot (outside this workgroup's slice)
+  float dt[4], w[4];  // w == 0 marks a dead slot (outside this workgroup's slice / padding)
 };
 
-// Branch-free: group indices past the slice are clamped and their slots get weight 0 and the tile's first pixel.
-// Predicated loads would become exec-masked branches and hipcc then waits vmcnt(0) for them, draining the
+struct TileRange {
+  int ty, tx;
+  int32_t beg, end;          // FMT_XY: this workgroup's slice of the tile's events (plan order)
+  int32_t g_first, g_last;   // groups of 4 this workgroup reads (g_first > g_last: nothing to do)
+};
+
+template <int FMT>
+__device__ __forceinline__ TileRange tile_range(const int32_t* __restrict__ key_offsets, const EvPtrs& ev, int tile_px,
+                                                int tiles_x, int splits) {
+  TileRange r;
+  const int tile = blockIdx.x / splits, part = blockIdx.x - tile * splits;
+  r.ty = tile / tiles_x;
+  r.tx = tile - r.ty * tiles_x;
+  if (FMT == FMT_COMPACT) {
+    const int32_t g0 = ev.grp_off[tile], g1 = ev.grp_off[tile + 1];
+    const int32_t chunk = (g1 - g0 + splits - 1) / splits;
+    const int32_t gb = min(g1, g0 + part * chunk), ge = min(g1, gb + chunk);
+    r.g_first = gb;
+    r.g_last = ge - 1;
+    r.beg = key_offsets[tile * tile_px] + 4 * (gb - g0);  // plan index of the first slot
+    r.end = key_offsets[(tile + 1) * tile_px];
+  } else {
+    const int32_t beg = key_offsets[tile * tile_px], end = key_offsets[(tile + 1) * tile_px];
+    int32_t chunk = (end - beg + splits - 1) / splits;
+    chunk = (chunk + kWave - 1) & ~(kWave - 1);
+    r.beg = min(end, beg + part * chunk);
+    r.end = min(end, r.beg + chunk);
+    r.g_first = r.beg >> 2;
+    r.g_last = r.beg < r.end ? (r.end - 1) >> 2 : r.g_first - 1;
+  }
+  return r;
+}
+
+// Branch-free: group indices past the slice are clamped (the loops never PROCESS such a group, they only prefetch
+// it).  Predicated loads would become exec-masked branches and hipcc then waits vmcnt(0) for them, draining the
 // prefetch that is supposed to stay in flight.
 template <int FMT, bool HAS_W, int TH, int TW>
-__device__ __forceinline__ void load_group(Group& g, int32_t grp, int32_t grp_last, int32_t beg, int32_t end,
-                                           const EvPtrs& p, int tile_r0, int tile_c0) {
-  const int32_t j = min(grp, grp_last);
-  const float4 D = reinterpret_cast<const float4*>(p.dts)[j];
-  float4 Wv = make_float4(1.f, 1.f, 1.f, 1.f);
-  if (HAS_W) Wv = reinterpret_cast<const float4*>(p.w)[j];
-  const float dd[4] = {D.x, D.y, D.z, D.w}, ww[4] = {Wv.x, Wv.y, Wv.z, Wv.w};
-  float xx[4], yy[4];
-  int pp[4];
-  if (FMT == FMT_XY) {
-    const float4 X = reinterpret_cast<const float4*>(p.xs)[j], Y = reinterpret_cast<const float4*>(p.ys)[j];
-    xx[0] = X.x; xx[1] = X.y; xx[2] = X.z; xx[3] = X.w;
-    yy[0] = Y.x; yy[1] = Y.y; yy[2] = Y.z; yy[3] = Y.w;
-  } else {
-    const uint2 P = reinterpret_cast<const uint2*>(p.pix)[j];
-    pp[0] = P.x & 0xffff; pp[1] = P.x >> 16; pp[2] = P.y & 0xffff; pp[3] = P.y >> 16;
-  }
+__device__ __forceinline__ void load_group(Group& g, int32_t grp, const TileRange& tr, const EvPtrs& p, int tile_r0,
+                                           int tile_c0) {
+  const int32_t j = max(min(grp, tr.g_last), tr.g_first);
+  if (FMT == FMT_COMPACT) {
+    const float4 D = reinterpret_cast<const float4*>(p.cdt)[j];
+    const uint2 P = reinterpret_cast<const uint2*>(p.cpix)[j];
+    const float dd[4] = {D.x, D.y, D.z, D.w};
+    const unsigned pp[4] = {P.x & 0xffffu, P.x >> 16, P.y & 0xffffu, P.y >> 16};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int32_t i = 4 * j + e;
-    const bool live = grp <= grp_last && i >= beg && i < end;
-    g.dt[e] = dd[e];
-    g.w[e] = live ? ww[e] : 0.0f;
-    if (FMT == FMT_XY) {
+    for (int e = 0; e < 4; ++e) {
+      const bool live = dd[e] == dd[e];  // padding slots carry NaN
+      g.dt[e] = live ? dd[e] : 0.0f;
+      g.w[e] = live ? 1.0f : 0.0f;
+      g.rs[e] = tile_r0 + (int)(pp[e] >> 8);
+      g.cs[e] = tile_c0 + (int)(pp[e] & 255u);
+      g.fx[e] = 0.0f;
+      g.fy[e] = 0.0f;
+    }
+  } else {
+    const float4 D = reinterpret_cast<const float4*>(p.dts)[j];
+    float4 Wv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (HAS_W) Wv = reinterpret_cast<const float4*>(p.w)[j];
+    const float4 X = reinterpret_cast<const float4*>(p.xs)[j], Y = reinterpret_cast<const float4*>(p.ys)[j];
+    const float dd[4] = {D.x, D.y, D.z, D.w}, ww[4] = {Wv.x, Wv.y, Wv.z, Wv.w};
+    const float xx[4] = {X.x, X.y, X.z, X.w}, yy[4] = {Y.x, Y.y, Y.z, Y.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int32_t i = 4 * j + e;
+      const bool live = i >= tr.beg && i < tr.end;
+      g.dt[e] = dd[e];
+      g.w[e] = live ? ww[e] : 0.0f;
       const float x = live ? xx[e] : (float)tile_r0, y = live ? yy[e] : (float)tile_c0;
       g.rs[e] = (int)x;
       g.cs[e] = (int)y;
       g.fx[e] = x - (float)g.rs[e];
       g.fy[e] = y - (float)g.cs[e];
-    } else {
-      const int q = live ? pp[e] : 0;
-      g.rs[e] = tile_r0 + q / TW;
-      g.cs[e] = tile_c0 + q % TW;
-      g.fx[e] = 0.0f;
-      g.fy[e] = 0.0f;
     }
   }
-}
-
-struct TileRange {
-  int ty, tx;
-  int32_t beg, end;  // this workgroup's slice of the tile's events
-};
-__device__ __forceinline__ TileRange tile_range(const int32_t* __restrict__ key_offsets, int tile_px, int tiles_x,
-                                                int splits) {
-  TileRange r;
-  const int tile = blockIdx.x / splits, part = blockIdx.x - tile * splits;
-  r.ty = tile / tiles_x;
-  r.tx = tile - r.ty * tiles_x;
-  const int32_t beg = key_offsets[tile * tile_px], end = key_offsets[(tile + 1) * tile_px];
-  int32_t chunk = (end - beg + splits - 1) / splits;
-  chunk = (chunk + kWave - 1) & ~(kWave - 1);
-  r.beg = min(end, beg + part * chunk);
-  r.end = min(end, r.beg + chunk);
-  return r;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -152,6 +171,101 @@ constexpr float kFxScale = (float)(1 << kFxShift);
 constexpr double kFxInv = 1.0 / (double)(1 << kFxShift);
 
 enum AccMode { ACC_F64 = 0, ACC_FX = 1 };
+
+// ---- the hot loop: compact plan, unit weights, verified fixed point --------------------------------------------
+// Written against an instruction budget (~45 VALU per event; the kernel is VALU-bound on MI355X):
+//   * compact groups need no liveness logic: padding slots carry dt = NaN, which fails the `ok` test below;
+//   * tile-local pixel is byte-packed (row << 8 | col): two bit-field extracts;
+//   * flow gathers use an unsigned 32-bit element offset off a uniform base (hardware address form, no 64-bit math);
+//   * taps outside the window are redirected to a dummy LDS region instead of being masked: the adds stay
+//     branch-free and their (garbage) values are never read;
+//   * fractions are clamped at 0, so all four fixed-point taps are non-negative and a word is simply (hi << 32) | lo;
+//   * rounding by the magic-number trick (one FMA + one integer subtract per tap).
+struct CGroup {
+  unsigned pr[4], pc[4];  // tile-local source row / column
+  float dt[4];
+};
+template <int TH, int TW>
+__device__ __forceinline__ void load_cgroup(CGroup& g, int32_t grp, const TileRange& tr, const EvPtrs& p) {
+  const int32_t j = max(min(grp, tr.g_last), tr.g_first);
+  const float4 D = reinterpret_cast<const float4*>(p.cdt)[j];
+  const uint2 P = reinterpret_cast<const uint2*>(p.cpix)[j];
+  g.dt[0] = D.x; g.dt[1] = D.y; g.dt[2] = D.z; g.dt[3] = D.w;
+  g.pr[0] = (P.x >> 8) & 255u; g.pc[0] = P.x & 255u;
+  g.pr[1] = P.x >> 24;         g.pc[1] = (P.x >> 16) & 255u;
+  g.pr[2] = (P.y >> 8) & 255u; g.pc[2] = P.y & 255u;
+  g.pr[3] = P.y >> 24;         g.pc[3] = (P.y >> 16) & 255u;
+}
+
+template <int TH, int TW, int HALO, bool UNIFORM>
+__device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
+                                                          const float* __restrict__ flow, int H, int W, bool* any_spill) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  constexpr unsigned kPlane = LH * LW / 2;  // words per plane
+  constexpr unsigned kDummy = LH * LW;      // first word of the dummy region (LW / 2 + 2 words)
+  constexpr float kMagic = 12582912.0f;     // 1.5 * 2^23
+  constexpr int kMagicBits = 0x4B400000;
+  unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
+  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (int64_t)H * W;
+  const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
+  const unsigned base_lin = (unsigned)(tr.ty * TH * W + tr.tx * TW);
+  const unsigned uW = (unsigned)W;
+  unsigned added = 0;
+  bool spilled = false;
+  const int32_t g_last = tr.g_last;
+  int32_t grp = tr.g_first + threadIdx.x;
+  CGroup cur, nxt;
+  load_cgroup<TH, TW>(cur, grp, tr, ev);
+  load_cgroup<TH, TW>(nxt, grp + kBlock, tr, ev);
+  float fu[4], fv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned lin = base_lin + cur.pr[e] * uW + cur.pc[e];
+    fu[e] = UNIFORM ? uni_u : flow[lin];
+    fv[e] = UNIFORM ? uni_v : flow1[lin];
+  }
+  while (grp <= g_last) {
+    float gu[4], gv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned lin = base_lin + nxt.pr[e] * uW + nxt.pc[e];
+      gu[e] = UNIFORM ? uni_u : flow[lin];
+      gv[e] = UNIFORM ? uni_v : flow1[lin];
+    }
+    CGroup nn;
+    load_cgroup<TH, TW>(nn, grp + 2 * kBlock, tr, ev);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lx = -cur.dt[e] * fu[e], ly = -cur.dt[e] * fv[e];  // source coordinates are integers: x' = rs + lx
+      const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
+      const float fr = fmaxf(lx - r0, 0.0f), fc = fmaxf(ly - c0, 0.0f);
+      const int rl = (int)cur.pr[e] + HALO + (int)r0, cl = (int)cur.pc[e] + HALO + (int)c0;
+      const bool ok = (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
+      const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
+      spilled |= ok && !inside;
+      const float fs = fr * kFxScale, as = kFxScale - fs, b = 1.0f - fc;
+      const unsigned q00 = (unsigned)(__float_as_int(__fmaf_rn(as, b, kMagic)) - kMagicBits);
+      const unsigned q10 = (unsigned)(__float_as_int(__fmaf_rn(fs, b, kMagic)) - kMagicBits);
+      const unsigned q01 = (unsigned)(__float_as_int(__fmaf_rn(as, fc, kMagic)) - kMagicBits);
+      const unsigned q11 = (unsigned)(__float_as_int(__fmaf_rn(fs, fc, kMagic)) - kMagicBits);
+      const unsigned t = (unsigned)(rl * LW + cl);
+      const unsigned word = inside ? (t >> 1) + (t & 1u) * kPlane : kDummy;
+      atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
+      atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
+      added += inside ? q00 + q10 + q01 + q11 : 0u;
+    }
+    cur = nxt;
+    nxt = nn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      fu[e] = gu[e];
+      fv[e] = gv[e];
+    }
+    grp += kBlock;
+  }
+  if (any_spill) *any_spill = spilled;
+  return added;
+}
 
 // PASS_MAIN: the lean hot loop -- every tap that lands inside the LDS window is accumulated, branch-free (dead or
 //            out-of-window lanes add 0 to a dummy word); events whose taps leave the window only raise a flag.
@@ -175,14 +289,16 @@ __device__ __forceinline__ unsigned accumulate_slice(const TileRange& tr, double
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;  // flow == theta pair
   unsigned added = 0;  // FX: integer total this thread put into LDS (mod 2^32)
   bool spilled = false;
-  if (tr.beg >= tr.end) return 0;
+  if (tr.g_first > tr.g_last) return 0;
+  if (FMT == FMT_COMPACT && MODE == ACC_FX && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop
+    return accumulate_compact_fx<TH, TW, HALO, UNIFORM>(tr, s_acc, ev, flow, H, W, any_spill);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
-  const int32_t g_last = (tr.end - 1) >> 2;
-  int32_t grp = (tr.beg >> 2) + threadIdx.x;
+  const int32_t g_last = tr.g_last;
+  int32_t grp = tr.g_first + threadIdx.x;
   Group cur, nxt;
-  load_group<FMT, HAS_W, TH, TW>(cur, grp, g_last, tr.beg, tr.end, ev, tr0, tc0);
-  load_group<FMT, HAS_W, TH, TW>(nxt, grp + kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
+  load_group<FMT, HAS_W, TH, TW>(cur, grp, tr, ev, tr0, tc0);
+  load_group<FMT, HAS_W, TH, TW>(nxt, grp + kBlock, tr, ev, tr0, tc0);
   float fu[4], fv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -199,42 +315,43 @@ __device__ __forceinline__ unsigned accumulate_slice(const TileRange& tr, double
       gv[e] = UNIFORM ? uni_v : flow1[lin];
     }
     Group nn;  // loads two groups ahead
-    load_group<FMT, HAS_W, TH, TW>(nn, grp + 2 * kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
+    load_group<FMT, HAS_W, TH, TW>(nn, grp + 2 * kBlock, tr, ev, tr0, tc0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float wv = cur.w[e];  // 0 for dead slots
       const Taps f = warped_taps(cur.rs[e], cur.cs[e], cur.fx[e] - cur.dt[e] * fu[e], cur.fy[e] - cur.dt[e] * fv[e]);
       const int rl = f.R - oy, cl = f.C - ox;
       const bool inside = (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);  // f.ok false -> far outside
-      const float a = 1.0f - f.fr, b = 1.0f - f.fc;
+      // FX stores unsigned fields: the (at most 1e-6) negative fractions that floor(x + eps) can produce are clamped
+      // in the fixed-point mode only (a relative change of <= 1e-6 of one event's weight)
+      const float frq = MODE == ACC_FX ? fmaxf(f.fr, 0.0f) : f.fr, fcq = MODE == ACC_FX ? fmaxf(f.fc, 0.0f) : f.fc;
+      const float a = 1.0f - frq, b = 1.0f - fcq;
       if (PASS == PASS_MAIN) {
-        spilled |= (!inside) && (wv != 0.0f);
+        spilled |= (!inside) && (wv != 0.0f) && f.ok;
         const float ws = inside ? wv : 0.0f;
         if (MODE == ACC_FX) {
           // round-to-nearest by the magic-number trick: bits(x + 1.5 * 2^23) - bits(1.5 * 2^23) == rint(x) for
           // |x| < 2^22 -- one FMA + one integer subtract per tap instead of fma + floor + convert
           constexpr float kMagic = 12582912.0f;
           constexpr int kMagicBits = 0x4B400000;
-          const float as = a * (ws * kFxScale), fs = f.fr * (ws * kFxScale);
-          const int q00 = __float_as_int(__fmaf_rn(as, b, kMagic)) - kMagicBits;
-          const int q10 = __float_as_int(__fmaf_rn(fs, b, kMagic)) - kMagicBits;
-          const int q01 = __float_as_int(__fmaf_rn(as, f.fc, kMagic)) - kMagicBits;
-          const int q11 = __float_as_int(__fmaf_rn(fs, f.fc, kMagic)) - kMagicBits;
-          // word = (hi << 32) + lo as a 64-bit integer: a (tiny) negative lo borrows from hi, decode undoes it
-          const unsigned long long v0 = ((unsigned long long)(unsigned)(q01 + (q00 >> 31)) << 32) | (unsigned)q00;
-          const unsigned long long v1 = ((unsigned long long)(unsigned)(q11 + (q10 >> 31)) << 32) | (unsigned)q10;
-          const int word = inside ? (cl & 1) * (LH * LW / 2) + rl * (LW / 2) + (cl >> 1) : LH * LW;  // LH*LW = dummy pair
-          atomicAdd(s_fx + word, v0);
-          atomicAdd(s_fx + word + (inside ? LW / 2 : 1), v1);
-          added += (unsigned)(q00 + q10 + q01 + q11);
+          const float as = a * (ws * kFxScale), fs = frq * (ws * kFxScale);
+          const unsigned q00 = (unsigned)(__float_as_int(__fmaf_rn(as, b, kMagic)) - kMagicBits);
+          const unsigned q10 = (unsigned)(__float_as_int(__fmaf_rn(fs, b, kMagic)) - kMagicBits);
+          const unsigned q01 = (unsigned)(__float_as_int(__fmaf_rn(as, fcq, kMagic)) - kMagicBits);
+          const unsigned q11 = (unsigned)(__float_as_int(__fmaf_rn(fs, fcq, kMagic)) - kMagicBits);
+          const unsigned t = (unsigned)(rl * LW + cl);
+          const int word = inside ? (int)((t >> 1) + (t & 1u) * (LH * LW / 2)) : LH * LW;  // LH*LW.. = dummy region
+          atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
+          atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
+          added += q00 + q10 + q01 + q11;
         } else {
-          const float as = a * ws, fs = f.fr * ws;
+          const float as = a * ws, fs = frq * ws;
           const int cell = inside ? rl * LW + cl : LH * LW;
           const int dn = inside ? LW : 0;
           atomic_add(&s_acc[cell], (double)(as * b));
           atomic_add(&s_acc[cell + dn], (double)(fs * b));
-          atomic_add(&s_acc[cell + 1], (double)(as * f.fc));
-          atomic_add(&s_acc[cell + dn + 1], (double)(fs * f.fc));
+          atomic_add(&s_acc[cell + 1], (double)(as * fcq));
+          atomic_add(&s_acc[cell + dn + 1], (double)(fs * fcq));
         }
       } else if (!inside && wv != 0.0f && f.ok) {  // beyond the halo: spill image (zero-invariant scratch)
         const float w00 = a * b * wv, w10 = f.fr * b * wv, w01 = a * f.fc * wv, w11 = f.fr * f.fc * wv;
@@ -276,12 +393,12 @@ __global__ void __launch_bounds__(kBlock)
 iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow, int H, int W,
                            int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  constexpr int kCells = LH * LW + 2;  // + a dummy pair that absorbs the zero adds of dead / out-of-window lanes
+  constexpr int kCells = LH * LW + LW / 2 + 2;  // + a dummy region that absorbs the adds of out-of-window lanes
   static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
   extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words; + dummy
   __shared__ unsigned s_chk[2 * kBlock / kWave];
   __shared__ int s_flag[2];  // [0] fixed-point overflow, [1] some event left the LDS window
-  const TileRange tr = tile_range(key_offsets, TH * TW, tiles_x, splits);
+  const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, splits);
 
   static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
   for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
@@ -303,26 +420,20 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     // One pass: decode 4 consecutive cells (c0 % 4 == 0) of a row from planes A and B, write them to the slab
     // optimistically, and sum the decoded fields for the overflow check
     //   sum(decoded fields) == sum(added units)  (mod 2^32; a wrapped field shifts it by k (2^32 - 1)).
-    // Field decode in 32 bits: word = hi * 2^32 + lo with lo signed, so lo = low dword, hi = high dword - (lo >> 31).
-    const int2* pa = reinterpret_cast<const int2*>(s_acc);
-    const int2* pb = pa + LH * LW / 2;
+    // Fields are unsigned 32-bit: lo = low dword (column c), hi = high dword (column c + 1).
+    const uint2* pa = reinterpret_cast<const uint2*>(s_acc);
+    const uint2* pb = pa + LH * LW / 2;
     unsigned decoded = 0;
     constexpr float kInv = (float)kFxInv;
     for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
       const int r = i / (LW / 4), j = i - r * (LW / 4);  // cells 4j..4j+3 <- A words 2j, 2j+1 and B words 2j-1, 2j, 2j+1
       const int wrow = r * (LW / 2);
-      const int2 a0 = pa[wrow + 2 * j], a1 = pa[wrow + 2 * j + 1];
-      const int2 b0 = pb[wrow + 2 * j], b1 = pb[wrow + 2 * j + 1];
-      const int a0h = a0.y - (a0.x >> 31), a1h = a1.y - (a1.x >> 31);
-      const int b0h = b0.y - (b0.x >> 31), b1h = b1.y - (b1.x >> 31);
-      int bmh = 0;
-      if (j > 0) {
-        const int2 bm = pb[wrow + 2 * j - 1];  // pair (4j-1, 4j); its lo field is summed by the previous group
-        bmh = bm.y - (bm.x >> 31);
-      }
-      decoded += (unsigned)(a0.x + a0h + a1.x + a1h + b0.x + b0h + b1.x + b1h);
-      out[i] = make_float4((float)(a0.x + bmh) * kInv, (float)(a0h + b0.x) * kInv, (float)(a1.x + b0h) * kInv,
-                           (float)(a1h + b1.x) * kInv);
+      const uint2 a0 = pa[wrow + 2 * j], a1 = pa[wrow + 2 * j + 1];
+      const uint2 b0 = pb[wrow + 2 * j], b1 = pb[wrow + 2 * j + 1];
+      const unsigned bmh = j > 0 ? pb[wrow + 2 * j - 1].y : 0u;  // pair (4j-1, 4j); its lo field belongs to the previous group
+      decoded += a0.x + a0.y + a1.x + a1.y + b0.x + b0.y + b1.x + b1.y;
+      out[i] = make_float4((float)(a0.x + bmh) * kInv, (float)(a0.y + b0.x) * kInv, (float)(a1.x + b0.y) * kInv,
+                           (float)(a1.y + b1.x) * kInv);
     }
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     unsigned a = added, d = decoded;
@@ -530,7 +641,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
   float* s_g = reinterpret_cast<float*>(s_raw + 2 * TH * TW);      // [LH][LW] upstream gradient tile
-  const TileRange tr = tile_range(key_offsets, TH * TW, tiles_x, 1);
+  const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, 1);
   const int64_t hw = (int64_t)H * W;
   GradImage G;
   G.g = g_image;
@@ -543,7 +654,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   const int oy = tr0 - HALO, ox = tc0 - HALO;
 
   for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
-  if (tr.beg < tr.end) {
+  if (tr.g_first <= tr.g_last) {
     for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
       const int rl = i / LW, cl = i - rl * LW;
       s_g[i] = G.at(oy + rl + pad_h, ox + cl + pad_w);
@@ -552,14 +663,14 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   __syncthreads();
 
   double tot_x = 0.0, tot_y = 0.0;  // UNIFORM: this lane's sum of dt * dL/d(x', y')
-  if (tr.beg < tr.end) {
+  if (tr.g_first <= tr.g_last) {
     const float* __restrict__ flow1 = UNIFORM ? flow : flow + hw;
     const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
-    const int32_t g_last = (tr.end - 1) >> 2;
-    int32_t grp = (tr.beg >> 2) + threadIdx.x;
+    const int32_t g_last = tr.g_last;
+    int32_t grp = tr.g_first + threadIdx.x;
     Group cur, nxt;
-    load_group<FMT, HAS_W, TH, TW>(cur, grp, g_last, tr.beg, tr.end, ev, tr0, tc0);
-    load_group<FMT, HAS_W, TH, TW>(nxt, grp + kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
+    load_group<FMT, HAS_W, TH, TW>(cur, grp, tr, ev, tr0, tc0);
+    load_group<FMT, HAS_W, TH, TW>(nxt, grp + kBlock, tr, ev, tr0, tc0);
     float fu[4], fv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -576,7 +687,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
         gv[e] = UNIFORM ? uni_v : flow1[lin];
       }
       Group nn;
-      load_group<FMT, HAS_W, TH, TW>(nn, grp + 2 * kBlock, g_last, tr.beg, tr.end, ev, tr0, tc0);
+      load_group<FMT, HAS_W, TH, TW>(nn, grp + 2 * kBlock, tr, ev, tr0, tc0);
       // The lane's 4 events are consecutive in the sorted plan, so they mostly share one source pixel: sum
       // them in registers and issue one pair of LDS adds per run instead of a wave-wide shuffle reduction.
       int run_pix = -1;
@@ -584,8 +695,9 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float wv = cur.w[e];
-        const int32_t i = 4 * min(grp, g_last) + e;
-        const bool live = i >= tr.beg && i < tr.end;  // (weights may legitimately be 0 here)
+        // plan index of this slot: FMT_XY groups are aligned to the plan, compact groups to the tile
+        const int32_t i = FMT == FMT_COMPACT ? tr.beg + 4 * (grp - tr.g_first) + e : 4 * grp + e;
+        const bool live = FMT == FMT_COMPACT ? (wv != 0.0f) : (i >= tr.beg && i < tr.end);  // (XY weights may be 0)
         if (!live) continue;
         const float edt = cur.dt[e];
         const Taps f = warped_taps(cur.rs[e], cur.cs[e], cur.fx[e] - edt * fu[e], cur.fy[e] - edt * fv[e]);
@@ -731,7 +843,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
                     int pad_h, int pad_w, char* ws, float* iwe, int want_var, int omit, float* out_var, double* moments,
                     int acc_mode, hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  constexpr size_t lds = ((size_t)LH * LW + 2) * sizeof(double);  // + dummy pair
+  constexpr size_t lds = ((size_t)LH * LW + LW / 2 + 2) * sizeof(double);  // + dummy region
   static_assert(lds + 1024 <= 160 * 1024, "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
   const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
   float* slabs = reinterpret_cast<float*>(ws);
@@ -739,7 +851,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   double* partials = reinterpret_cast<double*>(ws + L.off_partials);
   // unit weights -> verified fixed point (2 ds_add_u64 per event); per-event weights -> f64 (any magnitude/sign)
   void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*);
-  const bool compact = ev.pix != nullptr;
+  const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
 #define EBOS_PICK(HW, MD)                                                                                              \
   (uniform ? (compact ? iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_COMPACT, true>                            \
                       : iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_XY, true>)                                 \
@@ -783,7 +895,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   constexpr size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert(lds <= 160 * 1024, "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
-  const bool compact = ev.pix != nullptr;
+  const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*);
 #define EBOS_PICK(HW)                                                                                      \
   (uniform ? (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_COMPACT, true>                    \
@@ -836,14 +948,15 @@ size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int h
   return slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w).total;
 }
 
-int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const uint16_t* pix,
+int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
+                            const uint16_t* cpix, const float* cdt,
                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
                             int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
                             double* moments, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(flow && iwe && key_offsets && workspace, "ebos_iwe_dense_slab: NULL flow/iwe/key_offsets/workspace");
-  EBOS_REQUIRE((dts && ((xs && ys) || pix)) || n == 0, "ebos_iwe_dense_slab: NULL event buffer");
+  EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_slab: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 1 && splits <= 64,
                "ebos_iwe_dense_slab: bad sizes (splits=%d)", splits);
   EBOS_REQUIRE(!want_variance || out_variance || moments, "ebos_iwe_dense_slab: variance requested without an output");
@@ -858,7 +971,7 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
   }
   hipStream_t s = as_stream(stream);
   char* ws = reinterpret_cast<char*>(workspace);
-  const EvPtrs evp{xs, ys, dts, weight, pix};
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt};
   static const int acc_mode = [] {  // EBOS_SLAB_ACC=f64 forces the f64 accumulator (debug / A-B runs)
     const char* e = getenv("EBOS_SLAB_ACC");
     return (e && e[0] == 'f') ? (int)ACC_F64 : (int)ACC_FX;
@@ -874,14 +987,15 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
   return EBOS_OK;
 }
 
-int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const uint16_t* pix,
+int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
+                            const uint16_t* cpix, const float* cdt,
                            const int32_t* key_offsets, int64_t n, const float* thetas, int K, int H, int W, int tile_h,
                            int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace, size_t workspace_bytes,
                            float* iwes, int want_variance, int omit_boundary, float* out_variance, double* moments,
                            ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(thetas && iwes && key_offsets && workspace, "ebos_iwe_2dof_slab: NULL thetas/iwes/key_offsets/workspace");
-  EBOS_REQUIRE((dts && ((xs && ys) || pix)) || n == 0, "ebos_iwe_2dof_slab: NULL event buffer");
+  EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_2dof_slab: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 1 && splits <= 64,
                "ebos_iwe_2dof_slab: bad sizes (K=%d splits=%d)", K, splits);
   if (!slab_config_ok(tile_h, tile_w, halo)) {
@@ -895,7 +1009,7 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
   }
   hipStream_t s = as_stream(stream);
   char* ws = reinterpret_cast<char*>(workspace);
-  const EvPtrs evp{xs, ys, dts, weight, pix};
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt};
   const int64_t hw = (int64_t)(H + 2 * pad_h) * (W + 2 * pad_w);
   for (int k = 0; k < K; ++k) {  // hypotheses reuse the workspace in stream order
     int rc = EBOS_ERR_UNSUPPORTED;
@@ -911,13 +1025,14 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
   return EBOS_OK;
 }
 
-int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight, const uint16_t* pix,
+int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
+                            const uint16_t* cpix, const float* cdt,
                                 const int32_t* key_offsets, int64_t n, const float* thetas, int K, int H, int W, int tile_h,
                                 int tile_w, int halo, int pad_h, int pad_w, const float* g_images, const float* affine,
                                 int g_lo, float* d_thetas, void* workspace, size_t workspace_bytes, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(thetas && g_images && d_thetas && key_offsets && workspace, "ebos_iwe_2dof_tiled_bwd: NULL argument");
-  EBOS_REQUIRE((dts && ((xs && ys) || pix)) || n == 0, "ebos_iwe_2dof_tiled_bwd: NULL event buffer");
+  EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_2dof_tiled_bwd: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_2dof_tiled_bwd: bad sizes");
   if (!slab_config_ok(tile_h, tile_w, halo)) {
     set_error("ebos_iwe_2dof_tiled_bwd: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
@@ -931,7 +1046,7 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
   // the tile partials live in the slab section of the (forward) workspace: it is dead once the IWE is combined
   double* partials = reinterpret_cast<double*>(workspace);
   hipStream_t s = as_stream(stream);
-  const EvPtrs evp{xs, ys, dts, weight, pix};
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt};
   const int64_t hw = (int64_t)(H + 2 * pad_h) * (W + 2 * pad_w);
   for (int k = 0; k < K; ++k) {
     int rc = EBOS_ERR_UNSUPPORTED;
@@ -947,20 +1062,21 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
 }
 
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                                 const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
+                                 const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                                 const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
                                  int tile_h,
                                  int tile_w, int halo, int pad_h, int pad_w, const float* g_image, const float* affine,
                                  int g_lo, float* d_flow, float* d_weight, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(flow && g_image && d_flow && key_offsets, "ebos_iwe_dense_tiled_bwd: NULL flow/g_image/d_flow/key_offsets");
-  EBOS_REQUIRE((dts && ((xs && ys) || pix)) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
+  EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_dense_tiled_bwd: bad sizes");
   if (!slab_config_ok(tile_h, tile_w, halo)) {
     set_error("ebos_iwe_dense_tiled_bwd: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
     return EBOS_ERR_UNSUPPORTED;
   }
   hipStream_t s = as_stream(stream);
-  const EvPtrs evp{xs, ys, dts, weight, pix};
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt};
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, \

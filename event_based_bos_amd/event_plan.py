@@ -79,7 +79,9 @@ class EventPlan:
     key_offsets: Optional[torch.Tensor] = None   # int32 [n_keys + 1]
     perm: Optional[torch.Tensor] = None          # int32 [n]: input index of each planned event
     n_dropped: int = 0
-    pix: Optional[torch.Tensor] = None           # int16 storage of u16 tile-local source pixels (compact format)
+    grp_offsets: Optional[torch.Tensor] = None   # compact plan: int32 [tiles + 1] group offsets
+    cpix: Optional[torch.Tensor] = None          # compact plan: int16 storage of u16 (row << 8 | col), padded groups
+    cdt: Optional[torch.Tensor] = None           # compact plan: f32 dt, NaN in padding slots
 
     @property
     def binned(self) -> bool:
@@ -92,7 +94,10 @@ class EventPlan:
     @property
     def compact(self) -> bool:
         """True when the tile-private kernels read the 6 B/event format (u16 pixel + f32 dt)."""
-        return self.pix is not None
+        return self.cpix is not None
+
+    def _compact_ptrs(self):
+        return (ptr(self.grp_offsets), ptr(self.cpix), ptr(self.cdt)) if self.compact else (None, None, None)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -138,7 +143,6 @@ class EventPlan:
         n = self.n
         n_pad = (n + 3) // 4 * 4 + 4  # the tile-private kernels read 4 events (16 B) per lane
         xs, ys, dts, ps = (torch.zeros(n_pad, dtype=torch.float32, device=dev) for _ in range(4))
-        pix = torch.zeros(n_pad, dtype=torch.int16, device=dev) if th * tw <= 65536 else None
         perm = torch.empty(n, dtype=torch.int32, device=dev)
         key_offsets = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
         counts = torch.zeros(2, dtype=torch.int32, device=dev)  # [out-of-image sources, fractional sources]
@@ -147,15 +151,24 @@ class EventPlan:
         with torch.cuda.device(dev):
             check(lib.ebos_bin_events_f32(ptr(self.x), ptr(self.y), ptr(self.dt), ptr(self.p), n, H, W, th, tw,
                                           ptr(xs), ptr(ys), ptr(dts), ptr(ps), ptr(perm), ptr(key_offsets), ptr(counts),
-                                          ptr(pix), counts.data_ptr() + 4, ptr(scratch), nbytes, stream_ptr()),
+                                          counts.data_ptr() + 4, ptr(scratch), nbytes, stream_ptr()),
                   "ebos_bin_events")
         dropped, fractional = (int(v) for v in counts.tolist())  # one-off sync at plan-build time
         kept = n - dropped
         src_perm = perm[:kept] if self.perm is None else self.perm[perm[:kept].long()]
-        if fractional:
-            pix = None  # fractional / negative source coordinates: keep the general (x, y, dt) format
+        grp_offsets = cpix = cdt = None
+        if fractional == 0 and th <= 256 and tw <= 256:
+            # integer source coordinates (camera events): also build the compact 6 B/event plan
+            n_tiles = tiles_y * tiles_x
+            cap = kept + 3 * n_tiles + 8
+            grp_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            cpix = torch.zeros(cap, dtype=torch.int16, device=dev)
+            cdt = torch.full((cap,), float("nan"), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                check(lib.ebos_plan_compact_f32(ptr(xs), ptr(ys), ptr(dts), ptr(key_offsets), kept, H, W, th, tw,
+                                                ptr(grp_offsets), ptr(cpix), ptr(cdt), cap, stream_ptr()), "ebos_plan_compact")
         return EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
-                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped, pix)
+                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt)
 
     # ------------------------------------------------------------------------------------------
     def iwe_dense(self, flow: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
@@ -187,7 +200,7 @@ class EventPlan:
         with torch.cuda.device(self.device):
             for k0 in range(0, K, chunk):
                 kc = min(chunk, K - k0)
-                check(lib.ebos_iwe_2dof_slab_f32(ptr(self.x), ptr(self.y), ptr(self.dt), None, ptr(self.pix),
+                check(lib.ebos_iwe_2dof_slab_f32(ptr(self.x), ptr(self.y), ptr(self.dt), None, *self._compact_ptrs(),
                                                  ptr(self.key_offsets), self.n, th.data_ptr() + 8 * k0, kc, H, W,
                                                  self.tile[0], self.tile[1], int(halo), int(splits), pad[0], pad[1],
                                                  ptr(ws), ws.numel(), ptr(buf), 1, int(omit_boundary),
@@ -252,7 +265,7 @@ def _launch_iwe_dense_slab(plan: EventPlan, flow32, weight, pad, halo, splits, w
     out = torch.empty(1, dtype=torch.float32, device=plan.device) if want_variance else None
     moments = torch.empty((1, 2), dtype=torch.float64, device=plan.device) if want_variance else None
     with torch.cuda.device(plan.device):
-        check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), ptr(plan.pix),
+        check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), *plan._compact_ptrs(),
                                           ptr(plan.key_offsets), plan.n,
                                           ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), int(splits), pad[0],
                                           pad[1], ptr(ws), ws.numel(), ptr(iwe), int(want_variance), int(omit), ptr(out),
@@ -297,7 +310,7 @@ def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_d
     if _slab_ok(plan, halo):  # tile-private backward: d_flow written with plain stores, no zero-fill
         d_flow = torch.empty((2, H, W), dtype=torch.float32, device=plan.device)
         with torch.cuda.device(plan.device):
-            check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), ptr(plan.pix),
+            check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), *plan._compact_ptrs(),
                                                    ptr(plan.key_offsets), plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), pad[0],
                                                    pad[1], ptr(g_image), ptr(affine), g_lo, ptr(d_flow), ptr(d_w),
                                                    stream_ptr()), "ebos_iwe_dense_tiled_bwd")
@@ -390,7 +403,7 @@ class _FusedIwe2Dof(torch.autograd.Function):
             if _slab_ok(plan, halo):
                 ws = _workspace(plan, pad, halo, splits)
                 iwes = torch.empty((K, h, w), dtype=torch.float32, device=plan.device)
-                check(lib.ebos_iwe_2dof_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), ptr(plan.pix),
+                check(lib.ebos_iwe_2dof_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), *plan._compact_ptrs(),
                                                  ptr(plan.key_offsets), plan.n, ptr(th32), K, H, W, plan.tile[0],
                                                  plan.tile[1], int(halo), int(splits), pad[0], pad[1], ptr(ws), ws.numel(),
                                                  ptr(iwes), 0, 0, None, None, stream_ptr()), "ebos_iwe_2dof_slab")
@@ -416,7 +429,7 @@ class _FusedIwe2Dof(torch.autograd.Function):
             if _slab_ok(plan, halo):
                 ws = _workspace(plan, pad, halo, splits)
                 check(lib.ebos_iwe_2dof_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp) if has_w else None,
-                                                      ptr(plan.pix), ptr(plan.key_offsets), plan.n, ptr(th32), K, H, W,
+                                                      *plan._compact_ptrs(), ptr(plan.key_offsets), plan.n, ptr(th32), K, H, W,
                                                       plan.tile[0], plan.tile[1], int(halo), pad[0], pad[1], ptr(g32), None, 0,
                                                       ptr(d_th), ptr(ws), ws.numel(), stream_ptr()), "ebos_iwe_2dof_tiled_bwd")
                 return d_th.to(device=tdev, dtype=tdt), None, None, None, None, None

@@ -185,18 +185,25 @@ int ebos_events_to_soa_f64(const double* events, const double* tminmax, int ref_
  *   scratch: >= ebos_bin_scratch_bytes(n_keys) bytes
  *   oob_count (device int32, nullable): events whose source pixel is outside the image; they are
  *       dropped from the plan (torch.gather would raise for them, src/warp.py:334-336).
- *   pix [n] (uint16, out, nullable): tile-local source pixel of every sorted event -- the COMPACT event
- *       format (pix u16 + dt f32 = 6 B/event instead of 12) the tile-private kernels read when every
- *       source coordinate is a non-negative integer (camera events always are);
  *   frac_count (device int32, nullable): number of kept events with a fractional / negative source
- *       coordinate; the compact format is valid iff it stays 0.
+ *       coordinate; the compact plan (ebos_plan_compact_f32) is valid iff it stays 0.
  * All SoA outputs must be 16-byte aligned and padded to a multiple of 4 elements (vector loads).
  * The order of events inside one source pixel is not deterministic (atomic cursor). */
 size_t ebos_bin_scratch_bytes(int64_t n_keys);
 int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const float* p, int64_t n,
                         int H, int W, int tile_h, int tile_w, float* xs, float* ys, float* dts, float* ps,
-                        int32_t* perm, int32_t* key_offsets, int32_t* oob_count, uint16_t* pix,
-                        int32_t* frac_count, void* scratch, size_t scratch_bytes, ebos_stream_t stream);
+                        int32_t* perm, int32_t* key_offsets, int32_t* oob_count, int32_t* frac_count,
+                        void* scratch, size_t scratch_bytes, ebos_stream_t stream);
+
+/* Compact plan: the 6 B/event layout of the tile-private kernels, valid when every source coordinate is a
+ * non-negative integer (frac_count == 0; camera events always are).  Per tile t the events occupy the groups
+ * [grp_offsets[t], grp_offsets[t+1]) of 4 slots (16-byte vector loads, tiles start on a group boundary):
+ *     cpix (u16) = (row_in_tile << 8) | col_in_tile          cdt (f32) = dt, NaN in padding slots
+ * grp_offsets [tiles + 1] int32; cpix / cdt hold capacity_slots >= n + 3 tiles + 4 elements, 16-byte aligned.
+ * Inputs are the binned arrays of ebos_bin_events_f32 (same tile size, tile_h, tile_w <= 256). */
+int ebos_plan_compact_f32(const float* xs, const float* ys, const float* dts, const int32_t* key_offsets, int64_t n,
+                          int H, int W, int tile_h, int tile_w, int32_t* grp_offsets, uint16_t* cpix, float* cdt,
+                          int64_t capacity_slots, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused hot path, dense flow: A3 + A7 in one pass, nothing materialised
@@ -248,23 +255,23 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  * ebos_iwe_dense_tiled_bwd_f32   backward.  One workgroup per tile: upstream image tile in LDS,
  *   wavefront-segmented sums per source pixel, d_flow [2, H, W] OVERWRITTEN with plain stores
  *   (binned plans only; g_image/affine/g_lo/d_weight as in ebos_iwe_dense_bwd_f32; d_weight in plan order).
- * pix (nullable): the compact event format of ebos_bin_events_f32; when given, xs/ys are not read
- *   (6 B/event instead of 12).  All SoA arrays are read 4 events (16 bytes) per lane: 16-byte aligned,
- *   padded to a multiple of 4 elements.
+ * grp_offsets / cpix / cdt (nullable trio): the compact plan of ebos_plan_compact_f32; when given and weight is
+ *   NULL, xs/ys/dts are not read (6 B/event instead of 12).  All SoA arrays are read 4 events (16 bytes) per
+ *   lane: 16-byte aligned, padded to a multiple of 4 elements.
  * (tile_h, tile_w, halo) must be one of ebos_slab_config().
  * ---------------------------------------------------------------------------------------- */
 int ebos_slab_config(int* out, int cap);
 size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h,
                                      int pad_w);
 int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                            const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* flow, int H,
-                            int W, int tile_h,
+                            const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                            const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
                             int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary,
                             float* out_variance, double* moments, ebos_stream_t stream);
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                                 const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* flow,
-                                 int H, int W,
+                                 const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                                 const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
                                  int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, float* d_flow, float* d_weight,
                                  ebos_stream_t stream);
@@ -273,7 +280,8 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
  * (src/warp.py:364-383); iwes [K, h, w] are OVERWRITTEN; out_variance [K] / moments [K, 2] as above.  The K
  * hypotheses run back to back on the stream and share one workspace (same size as for the dense flow). */
 int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                           const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* thetas, int K,
+                           const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                           const int32_t* key_offsets, int64_t n, const float* thetas, int K,
                            int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w,
                            void* workspace, size_t workspace_bytes, float* iwes, int want_variance,
                            int omit_boundary, float* out_variance, double* moments, ebos_stream_t stream);
@@ -282,7 +290,8 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
  * (affine [K, 2] / g_lo as in ebos_iwe_dense_bwd_f32); d_thetas [K, 2] is OVERWRITTEN.  workspace: the plan's forward
  * workspace (its slab section is reused for the per-tile partial sums). */
 int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                                const uint16_t* pix, const int32_t* key_offsets, int64_t n, const float* thetas,
+                                const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                                const int32_t* key_offsets, int64_t n, const float* thetas,
                                 int K, int H, int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w,
                                 const float* g_images, const float* affine, int g_lo, float* d_thetas,
                                 void* workspace, size_t workspace_bytes, ebos_stream_t stream);

@@ -79,9 +79,9 @@ def main():
         if not _slab_ok(pl, halo):
             continue
         for want_var, compact in ((False, True), (True, True), (False, False)):
-            saved_pix = pl.pix
+            saved_pix = pl.cpix
             if not compact:
-                pl.pix = None
+                pl.cpix = None
             ts = []
             for r in range(args.rounds + 1):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -93,7 +93,7 @@ def main():
                     ts.append(a.elapsed_time(b))
             err = (torch.linalg.norm(out_iwe - ref) / torch.linalg.norm(ref)).item()
             assert err < 1e-5, (c, err)
-            pl.pix = saved_pix
+            pl.cpix = saved_pix
             slab_times[(("slab+var" if want_var else "slab") + ("" if compact else "-xy12B"), c)] = ts
     times.update(slab_times)
     n = args.events
