@@ -629,6 +629,113 @@ struct GradImage {
   }
 };
 
+// ---- lean backward sweep over a compact slice (unit weights) ---------------------------------------------------
+// Same budget discipline as accumulate_compact_fx.  PASS_MAIN: events whose four taps lie inside the LDS window of the
+// upstream image (others read a dummy cell and contribute 0, but raise the flag); PASS_SPILL: the rare second sweep
+// for exactly those events, reading the upstream image from global memory.
+template <int TH, int TW, int HALO, bool UNIFORM, int PASS>
+__device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s_d, const float* s_g, const EvPtrs& ev,
+                                                  const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
+                                                  const GradImage& G, double& tot_x, double& tot_y, bool* any_spill) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (int64_t)H * W;
+  const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
+  const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
+  const unsigned base_lin = (unsigned)(tr0 * W + tc0);
+  const unsigned uW = (unsigned)W;
+  bool spilled = false;
+  const int32_t g_last = tr.g_last;
+  int32_t grp = tr.g_first + threadIdx.x;
+  CGroup cur, nxt;
+  load_cgroup<TH, TW>(cur, grp, tr, ev);
+  load_cgroup<TH, TW>(nxt, grp + kBlock, tr, ev);
+  float fu[4], fv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned lin = base_lin + cur.pr[e] * uW + cur.pc[e];
+    fu[e] = UNIFORM ? uni_u : flow[lin];
+    fv[e] = UNIFORM ? uni_v : flow1[lin];
+  }
+  while (grp <= g_last) {
+    float gu[4], gv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned lin = base_lin + nxt.pr[e] * uW + nxt.pc[e];
+      gu[e] = UNIFORM ? uni_u : flow[lin];
+      gv[e] = UNIFORM ? uni_v : flow1[lin];
+    }
+    CGroup nn;
+    load_cgroup<TH, TW>(nn, grp + 2 * kBlock, tr, ev);
+    // the lane's 4 events are consecutive in the sorted plan and mostly share one source pixel: sum per run
+    unsigned run_pix = 0xffffffffu;
+    float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float edt = cur.dt[e];
+      const float lx = -edt * fu[e], ly = -edt * fv[e];
+      const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
+      const float fr = lx - r0, fc = ly - c0;
+      const int rl = (int)cur.pr[e] + HALO + (int)r0, cl = (int)cur.pc[e] + HALO + (int)c0;
+      const bool ok = (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
+      const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
+      float g00, g10, g01, g11;
+      bool use;
+      if (PASS == PASS_MAIN) {
+        spilled |= ok && !inside;
+        use = inside;
+        const float* p = &s_g[inside ? rl * LW + cl : 0];  // cell 0..LW+1 is always a valid address
+        g00 = p[0];
+        g10 = p[LW];
+        g01 = p[1];
+        g11 = p[LW + 1];
+      } else {
+        use = ok && !inside;
+        const int R = tr0 - HALO + rl + pad_h, C = tc0 - HALO + cl + pad_w;
+        g00 = use ? G.at(R, C) : 0.0f;
+        g10 = use ? G.at(R + 1, C) : 0.0f;
+        g01 = use ? G.at(R, C + 1) : 0.0f;
+        g11 = use ? G.at(R + 1, C + 1) : 0.0f;
+      }
+      const float dx = (1.0f - fc) * (g10 - g00) + fc * (g11 - g01);  // dL/dx'
+      const float dy = (1.0f - fr) * (g01 - g00) + fr * (g11 - g10);  // dL/dy'
+      const float cx = use ? edt * dx : 0.0f, cy = use ? edt * dy : 0.0f;  // (select, not multiply: dx may be NaN)
+      if (UNIFORM) {
+        ax += cx;  // dL/dtheta += dt * dL/d(x', y')
+        ay += cy;
+      } else {
+        const unsigned pix = cur.pr[e] * TW + cur.pc[e];
+        if (pix != run_pix) {
+          if (run_pix != 0xffffffffu) {
+            atomic_add(&s_d[run_pix], (double)ax);
+            atomic_add(&s_d[TH * TW + run_pix], (double)ay);
+          }
+          run_pix = pix;
+          ax = 0.0f;
+          ay = 0.0f;
+        }
+        ax -= cx;  // dL/dflow[src] += -dt * dL/d(x', y')
+        ay -= cy;
+      }
+    }
+    if (UNIFORM) {
+      tot_x += (double)ax;
+      tot_y += (double)ay;
+    } else if (run_pix != 0xffffffffu) {
+      atomic_add(&s_d[run_pix], (double)ax);
+      atomic_add(&s_d[TH * TW + run_pix], (double)ay);
+    }
+    cur = nxt;
+    nxt = nn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      fu[e] = gu[e];
+      fv[e] = gv[e];
+    }
+    grp += kBlock;
+  }
+  if (any_spill) *any_spill = spilled;
+}
+
 // UNIFORM: 2-DoF model (flow == theta pair, x' = x + dt * theta): no flow gathers, and instead of a per-pixel
 // d_flow tile every lane sums dt * dL/d(x', y'); the workgroup writes one partial pair, summed over tiles afterwards.
 template <int TH, int TW, int HALO, bool HAS_W, int FMT, bool UNIFORM>
@@ -653,6 +760,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
   const int oy = tr0 - HALO, ox = tc0 - HALO;
 
+  __shared__ int s_spill;  // some event's taps left the LDS window of the upstream image
+  if (threadIdx.x == 0) s_spill = 0;
   for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
   if (tr.g_first <= tr.g_last) {
     for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
@@ -663,7 +772,16 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   __syncthreads();
 
   double tot_x = 0.0, tot_y = 0.0;  // UNIFORM: this lane's sum of dt * dL/d(x', y')
-  if (tr.g_first <= tr.g_last) {
+  constexpr bool kLean = (FMT == FMT_COMPACT) && !HAS_W;
+  if (kLean) {
+    bool spilled = false;
+    if (tr.g_first <= tr.g_last)
+      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, &spilled);
+    if (spilled) s_spill = 1;
+    __syncthreads();
+    if (s_spill && tr.g_first <= tr.g_last)
+      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, nullptr);
+  } else if (tr.g_first <= tr.g_last) {
     const float* __restrict__ flow1 = UNIFORM ? flow : flow + hw;
     const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
     const int32_t g_last = tr.g_last;
