@@ -174,17 +174,15 @@ def main():
     contrast = float(out.item())
 
     # extra (outside the timed region): forward + backward of the objective, direct C-ABI calls
-    #   slab forward + variance -> affine (variance gradient folded into the backward) -> tile-private backward
-    affine = torch.empty(2, dtype=torch.float32, device=dev)
+    #   slab forward + variance -> tile-private backward (variance gradient folded in from the moments)
     upstream = torch.full((1,), -1.0, dtype=torch.float32, device=dev)  # loss = -variance
     d_flow = torch.empty((2, H, W), dtype=torch.float32, device=dev)
 
     def step_fwd_bwd():
         step()
-        _hip.check(lib.ebos_image_variance_affine_f32(P(moments), P(upstream), 1, P(affine), stream), "affine")
         _hip.check(lib.ebos_iwe_dense_tiled_bwd_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
-                                                    P(flow), H, W, args.tile[0], args.tile[1], args.halo, 0, 0, P(iwe), P(affine),
-                                                    0, P(d_flow), None, stream), "ebos_iwe_dense_tiled_bwd")
+                                                    P(flow), H, W, args.tile[0], args.tile[1], args.halo, 0, 0, P(iwe), None,
+                                                    0, P(d_flow), None, P(moments), P(upstream), stream), "ebos_iwe_dense_tiled_bwd")
 
     for _ in range(3):
         step_fwd_bwd()

@@ -743,7 +743,8 @@ __global__ void __launch_bounds__(kBlock)
 iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow, int H, int W,
                            int tiles_x, int pad_h, int pad_w, const float* __restrict__ g_image,
                            const float* __restrict__ affine, int g_lo, float* __restrict__ d_flow,
-                           float* __restrict__ d_weight, double* __restrict__ partials) {
+                           float* __restrict__ d_weight, double* __restrict__ partials,
+                           const double* __restrict__ var_moments, const float* __restrict__ upstream) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
@@ -754,6 +755,13 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   G.g = g_image;
   G.a = affine ? affine[0] : 1.0f;
   G.c = affine ? affine[1] : 0.0f;
+  if (var_moments != nullptr) {
+    // g_image is the IWE itself and the loss is upstream * var(IWE): d var / d IWE = 2 (IWE - mean) / (M - 1), folded
+    // in as an affine map (no d_iwe image, no separate affine kernel)
+    const double a = 2.0 * (double)upstream[0] / (var_moments[1] - 1.0);
+    G.a = (float)a;
+    G.c = (float)(-a * var_moments[0]);
+  }
   G.h = H + 2 * pad_h;
   G.w = W + 2 * pad_w;
   G.lo = g_lo;
@@ -1008,13 +1016,14 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
 template <int TH, int TW, int HALO>
 int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int pad_h,
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
-                     double* partials, hipStream_t s) {
+                     double* partials, const double* var_moments, const float* upstream, hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert(lds <= 160 * 1024, "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
-  void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*);
+  void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
+             const double*, const float*);
 #define EBOS_PICK(HW)                                                                                      \
   (uniform ? (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_COMPACT, true>                    \
                       : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_XY, true>)                         \
@@ -1025,7 +1034,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
 #undef EBOS_PICK
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
   kb<<<dim3((unsigned)(tiles_y * tiles_x)), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image,
-                                                                    affine, g_lo, d_flow, d_weight, partials);
+                                                                    affine, g_lo, d_flow, d_weight, partials, var_moments, upstream);
   if (uniform) theta_grad_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, tiles_y * tiles_x, d_flow);
   return EBOS_OK;
 }
@@ -1170,7 +1179,7 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
     int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                              \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, thetas + 2 * k, true, H, W, pad_h, pad_w, g_images + k * hw,              \
-                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, s)
+                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, nullptr, nullptr, s)
     EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
     if (rc != EBOS_OK) return rc;
@@ -1184,11 +1193,13 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
                                  const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
                                  int tile_h,
                                  int tile_w, int halo, int pad_h, int pad_w, const float* g_image, const float* affine,
-                                 int g_lo, float* d_flow, float* d_weight, ebos_stream_t stream) {
+                                 int g_lo, float* d_flow, float* d_weight, const double* var_moments,
+                                 const float* upstream, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(flow && g_image && d_flow && key_offsets, "ebos_iwe_dense_tiled_bwd: NULL flow/g_image/d_flow/key_offsets");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_dense_tiled_bwd: bad sizes");
+  EBOS_REQUIRE((var_moments == nullptr) == (upstream == nullptr), "ebos_iwe_dense_tiled_bwd: var_moments and upstream go together");
   if (!slab_config_ok(tile_h, tile_w, halo)) {
     set_error("ebos_iwe_dense_tiled_bwd: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
     return EBOS_ERR_UNSUPPORTED;
@@ -1198,7 +1209,7 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, \
-                               nullptr, s)
+                               nullptr, var_moments, upstream, s)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

@@ -303,7 +303,8 @@ def _plan_weight(plan: EventPlan, weight: Optional[torch.Tensor]) -> Optional[to
     return out[:plan.n]
 
 
-def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_dweight, halo=DEFAULT_HALO):
+def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_dweight, halo=DEFAULT_HALO,
+                      var_moments=None, upstream=None):
     lib = _hip.require_gpu()
     H, W = plan.image_size
     d_w = torch.empty(plan.n, dtype=torch.float32, device=plan.device) if want_dweight else None
@@ -313,8 +314,13 @@ def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_d
             check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), *plan._compact_ptrs(),
                                                    ptr(plan.key_offsets), plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), pad[0],
                                                    pad[1], ptr(g_image), ptr(affine), g_lo, ptr(d_flow), ptr(d_w),
-                                                   stream_ptr()), "ebos_iwe_dense_tiled_bwd")
+                                                   ptr(var_moments), ptr(upstream), stream_ptr()), "ebos_iwe_dense_tiled_bwd")
         return d_flow, d_w
+    if var_moments is not None:  # general kernels take the affine form
+        affine = torch.empty(2, dtype=torch.float32, device=plan.device)
+        with torch.cuda.device(plan.device):
+            check(lib.ebos_image_variance_affine_f32(ptr(var_moments), ptr(upstream), 1, ptr(affine), stream_ptr()),
+                  "ebos_image_variance_affine")
     d_flow = torch.zeros((2, H, W), dtype=torch.float32, device=plan.device)
     with torch.cuda.device(plan.device):
         check(lib.ebos_iwe_dense_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), plan.n, ptr(flow32), H, W,
@@ -380,11 +386,7 @@ class _FusedVarianceDense(torch.autograd.Function):
         flow32, iwe, moments = ctx.saved_tensors
         plan, pad, omit, fdt, halo = ctx.meta
         up = g.to(torch.float32).reshape(1).contiguous()
-        affine = torch.empty(2, dtype=torch.float32, device=plan.device)
-        with torch.cuda.device(plan.device):
-            check(lib.ebos_image_variance_affine_f32(ptr(moments), ptr(up), 1, ptr(affine), stream_ptr()),
-                  "ebos_image_variance_affine")
-        d_flow, _ = _launch_dense_bwd(plan, flow32, None, pad, iwe, affine, omit, False, halo)
+        d_flow, _ = _launch_dense_bwd(plan, flow32, None, pad, iwe, None, omit, False, halo, moments, up)
         return d_flow.to(fdt), None, None, None, None, None
 
 

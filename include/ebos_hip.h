@@ -255,6 +255,9 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  * ebos_iwe_dense_tiled_bwd_f32   backward.  One workgroup per tile: upstream image tile in LDS,
  *   wavefront-segmented sums per source pixel, d_flow [2, H, W] OVERWRITTEN with plain stores
  *   (binned plans only; g_image/affine/g_lo/d_weight as in ebos_iwe_dense_bwd_f32; d_weight in plan order).
+ *   var_moments [2] (f64: mean, M of ebos_iwe_dense_slab_f32) + upstream [1] (f32), both nullable together: the
+ *   loss is upstream * var(g_image) with g_image = the IWE itself; its gradient 2 (IWE - mean) / (M - 1) is folded
+ *   into the kernel (no d_iwe image, no affine launch).
  * grp_offsets / cpix / cdt (nullable trio): the compact plan of ebos_plan_compact_f32; when given and weight is
  *   NULL, xs/ys/dts are not read (6 B/event instead of 12).  All SoA arrays are read 4 events (16 bytes) per
  *   lane: 16-byte aligned, padded to a multiple of 4 elements.
@@ -274,7 +277,7 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
                                  const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
                                  int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, float* d_flow, float* d_weight,
-                                 ebos_stream_t stream);
+                                 const double* var_moments, const float* upstream, ebos_stream_t stream);
 
 /* 2-DoF hypotheses on the tile-private pipeline (BASELINE config 5): thetas [K, 2] (device), x' = x + dt theta
  * (src/warp.py:364-383); iwes [K, h, w] are OVERWRITTEN; out_variance [K] / moments [K, 2] as above.  The K
