@@ -25,7 +25,7 @@ from typing import Optional, Tuple, Union
 import numpy as np
 import torch
 
-from . import _hip, ops
+from . import _hip, fusion, ops
 from ._staging import GPU, NUMPY, back, kind_of, to_gpu
 from .types import FLOAT_TORCH, NUMPY_TORCH, is_numpy, is_torch
 
@@ -109,8 +109,17 @@ class EventImageConverter(object):
         coordinates and ``weight``.  :562-620"""
         if type(weight) == torch.Tensor:
             assert weight.shape == events.shape[:-1]
+        fused = self._try_fused(events, weight)
+        if fused is not None:
+            return fused.squeeze()
         img = self._accumulate(events, weight, _hip.SPLAT_BILINEAR, EPS_TENSOR, None)
         return self._finish(img, kind_of(events))
+
+    def _try_fused(self, events, weight):
+        """Warped events that still carry their provenance (fusion.py) and unit weight: fused warp + IWE."""
+        if not (is_torch(events) and type(weight) in (float, int) and float(weight) == 1.0):
+            return None
+        return fusion.fused_iwe(events, self.image_size, self.outer_padding)
 
     def count_event_numpy(self, events: np.ndarray):
         """+1 on each in-bounds neighbour of every event (no bilinear weights).  :407-453"""
@@ -152,7 +161,11 @@ class EventImageConverter(object):
         elif method == "bilinear_vote":
             if type(weight) == torch.Tensor:
                 assert weight.shape == events.shape[:-1]
-            img = self._accumulate(events, weight, _hip.SPLAT_BILINEAR, EPS_TENSOR, None).squeeze()
+            img = self._try_fused(events, weight)
+            if img is None:
+                img = self._accumulate(events, weight, _hip.SPLAT_BILINEAR, EPS_TENSOR, None).squeeze()
+            else:
+                img = img.squeeze()
         elif method == "polarity":
             img = self._polarity(events, weight, EPS_TENSOR, None)
         else:

@@ -24,7 +24,7 @@ from typing import Optional, Tuple, Union
 import numpy as np
 import torch
 
-from . import _hip, ops
+from . import _hip, fusion, ops
 from ._staging import CPU, GPU, NUMPY, back, kind_of, to_gpu
 from .event_plan import parse_direction
 from .types import FLOAT_TORCH, NUMPY_TORCH, is_numpy, is_torch
@@ -154,7 +154,13 @@ class Warp(object):
         """Warp events [(b,) n, 4] with ``motion`` under ``motion_model``; returns (warped, feature dict)."""
         ref_mode, frac = parse_direction(direction)  # ValueError first, like calculate_reftime (:218)
         if motion_model == "dense-flow":
-            return self._warp_dense(events, motion, ref_mode, frac, None)
+            warped, feat = self._warp_dense(events, motion, ref_mode, frac, None)
+            if is_torch(events) and is_torch(motion) and fusion.eligible(events, motion, self.image_size):
+                # remember where these coordinates came from: EventImageConverter can then build the image with the
+                # fused kernels instead of splatting the materialised coordinates (see fusion.py)
+                fusion.tag(warped, fusion.Provenance(events, events._version, motion, ref_mode, frac, direction,
+                                                     bool(self.normalize_t), (int(self.image_size[0]), int(self.image_size[1]))))
+            return warped, feat
         if motion_model in TRANSLATION_MODELS:
             assert motion.shape[-1] == 2
             return self._warp_2dof(events, motion, ref_mode, frac, None, None)

@@ -319,6 +319,52 @@ def test_fused_dense_costs_padding_weights(ebos, cost, omit):
     assert rel(wt.grad.cpu().numpy(), dw_ref) < 1e-3
 
 
+def test_reference_idiom_is_fused_lazily(ebos, monkeypatch):
+    """warp_event + create_iwe, written exactly as against the reference, run on the fused kernels for float32
+    GPU tensors: same image and flow gradient as the unfused path, plan built once per event window."""
+    h, w, n = 120, 160, 80_000
+    ev = G(O.synth_events(n, h, w, seed=41), torch.float32)
+    fl_np = O.synth_dense_flow(h, w, seed=42, max_val=9.0)
+    wp, ic = ebos.Warp((h, w), normalize_t=True), ebos.EventImageConverter((h, w), outer_padding=2)
+    cost = ebos.costs.functions["image_variance"]()
+
+    def run():
+        fl = G(fl_np, torch.float32).requires_grad_(True)
+        warped, _ = wp.warp_event(ev, fl, "dense-flow", "middle")
+        iwe = ic.create_iwe(warped, "bilinear_vote", sigma=0)
+        loss = cost.calculate({"iwe": iwe, "omit_boundary": False})
+        loss.backward()
+        return warped, iwe.detach(), loss.item(), fl.grad
+
+    ebos.fusion.clear_cache()
+    before = dict(ebos.fusion.stats)
+    monkeypatch.setenv("EBOS_FUSE_API", "off")
+    w0, iwe0, l0, g0 = run()
+    assert ebos.fusion.stats == before
+    monkeypatch.setenv("EBOS_FUSE_API", "f32")
+    for _ in range(3):
+        w1, iwe1, l1, g1 = run()
+    assert ebos.fusion.stats["plan_builds"] == before["plan_builds"] + 1
+    assert ebos.fusion.stats["plan_hits"] == before["plan_hits"] + 2
+    assert ebos.fusion.stats["fused_images"] == before["fused_images"] + 3
+    assert torch.equal(w0, w1)  # the materialised warped events are the same public result
+    assert iwe1.shape == iwe0.shape == (h + 4, w + 4)
+    assert rel(iwe1.cpu().numpy(), iwe0.cpu().numpy()) < 1e-5
+    assert abs(l1 - l0) < 1e-5 * abs(l0)
+    assert rel(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-3
+    # a modified copy of the warped events loses the provenance and is splatted as given
+    fl = G(fl_np, torch.float32)
+    warped, _ = wp.warp_event(ev, fl, "dense-flow", "middle")
+    warped[:, 0] += 1.0
+    n_fused = ebos.fusion.stats["fused_images"]
+    shifted = ic.create_iwe(warped, "bilinear_vote", sigma=0)
+    assert ebos.fusion.stats["fused_images"] == n_fused
+    assert rel(shifted[3:-1, 2:-2].cpu().numpy(), iwe0[2:-2, 2:-2].cpu().numpy()) < 1e-5
+    # float64 callers keep the float64 kernels unless EBOS_FUSE_API=all
+    w64, _ = wp.warp_event(ev.double(), fl.double(), "dense-flow", "middle")
+    assert not hasattr(w64, "_ebos_provenance")
+
+
 def test_fixed_point_tile_overflow_falls_back_exactly(ebos):
     """The tile-private forward accumulates unit-weight events in verified fixed point (2048 units of weight
     per LDS cell per workgroup).  A hot pixel beyond that must be detected and redone in f64."""
