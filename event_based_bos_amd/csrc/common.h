@@ -11,7 +11,7 @@ namespace ebos {
 constexpr int kWave = 64;  // CDNA wavefront width
 
 void set_error(const char* fmt, ...);
-void profile_mark(hipStream_t s, bool begin);  // no-op unless ebos_profile_start() is active
+bool profile_next_pair(hipEvent_t* start, hipEvent_t* stop);  // false unless ebos_profile_start() is active
 
 #define EBOS_REQUIRE(cond, ...)                 \
   do {                                          \

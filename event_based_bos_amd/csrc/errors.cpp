@@ -18,8 +18,8 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- optional in-library kernel timing (bench.py's roofline leg) -------------------------------
-// When enabled, the launcher of the dominant kernel brackets it with a HIP event pair on the very
-// stream it launches on.  Off by default: zero cost, nothing recorded.
+// When enabled, the launcher of the dominant kernel attaches a HIP event pair to the dispatch itself
+// (hipExtLaunchKernelGGL start/stop events on the stream it launches on).  Off by default: zero cost.
 struct ProfileState {
   bool on = false;
   std::vector<hipEvent_t> ev;  // pairs
@@ -27,16 +27,16 @@ struct ProfileState {
 };
 static ProfileState g_prof;
 
-void profile_mark(hipStream_t s, bool begin) {
-  if (!g_prof.on) return;
+// Next free (start, stop) event pair, or false when profiling is off / the pairs are used up.  The launcher hands the
+// pair to hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end timestamps.
+bool profile_next_pair(hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof.on) return false;
   const int pairs = (int)g_prof.ev.size() / 2;
-  if (g_prof.used >= pairs) return;
-  if (begin) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  } else {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
-    ++g_prof.used;
-  }
+  if (g_prof.used >= pairs) return false;
+  *start = g_prof.ev[2 * g_prof.used];
+  *stop = g_prof.ev[2 * g_prof.used + 1];
+  ++g_prof.used;
+  return true;
 }
 }  // namespace ebos
 

@@ -28,6 +28,8 @@
 
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace ebos {
@@ -988,9 +990,12 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   else ka = EBOS_PICK(false, ACC_FX);
 #undef EBOS_PICK
   if (int rc = reserve_lds(ka, lds, "ebos_iwe_dense_slab")) return rc;
-  profile_mark(s, true);
-  ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill);
-  profile_mark(s, false);
+  hipEvent_t t0, t1;
+  if (profile_next_pair(&t0, &t1))  // bench.py's roofline leg: events stamped with this dispatch's begin / end
+    hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, L.tiles_x,
+                          splits, pad_h, pad_w, slabs, spill);
+  else
+    ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill);
   int64_t nparts;
   if (L.w % 4 == 0 && pad_w % 4 == 0) {
     dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows);

@@ -62,8 +62,8 @@ typedef enum ebos_splat_mode {
 } ebos_splat_mode;
 
 /* Optional timing of the dominant kernel (the tile accumulate pass of ebos_iwe_dense_slab_f32): between
- * ebos_profile_start(max_records) and ebos_profile_stop() every launch of that kernel is bracketed by a
- * HIP event pair on the stream it runs on.  ebos_profile_stop synchronises those events, writes up to
+ * ebos_profile_start(max_records) and ebos_profile_stop() every launch of that kernel carries a HIP event pair
+ * stamped with the dispatch's own begin / end (hipExtLaunchKernelGGL) on the stream it runs on.  ebos_profile_stop synchronises those events, writes up to
  * `cap` durations in milliseconds to the HOST array `ms` and returns how many it wrote.  Not thread-safe;
  * off by default. */
 int ebos_profile_start(int max_records);
