@@ -294,6 +294,34 @@ def gaussian_blur3_torch(img: torch.Tensor, sigma: float) -> torch.Tensor:
     return F.conv2d(x, k2).reshape(*lead, *img.shape[-2:])
 
 
+def averaged_image(events, values, base, image_size, pad=(0, 0), sigma=1):
+    """create_iwa (base 1) / create_iwd (base 0) / create_iwt (base 2), src/event_image_converter.py:75-234:
+    (splat weighted by values - base) / (unit splat + 1e-2) + base; numpy branch blurs with scipy's
+    gaussian_filter, torch branch returns [1, 1, H, W] (blur needs torchvision: sigma = 0 only here)."""
+    if isinstance(events, np.ndarray):
+        from scipy.ndimage import gaussian_filter
+
+        num = create_image_numpy(events, image_size, pad, weight=values - base, sigma=0)
+        den = create_image_numpy(events, image_size, pad, sigma=0)
+        out = np.divide(num, den + 1e-2) + base
+        return gaussian_filter(out, sigma) if sigma > 0 else out
+    num = bilinear_vote_torch(events, image_size, pad, values - base)
+    den = bilinear_vote_torch(events, image_size, pad)
+    out = torch.divide(num, den + 1e-2) + base
+    out = out[None, None] if out.dim() == 2 else out[:, None]
+    if sigma > 0:
+        out = gaussian_blur3_torch(out, sigma)
+    return out
+
+
+def weighted_image(events, values, image_size, pad=(0, 0), sigma=1):
+    """create_timeimage / create_probability_iwe, src/event_image_converter.py:239-286: a splat weighted per event."""
+    if isinstance(events, np.ndarray):
+        return create_image_numpy(events, image_size, pad, weight=values, sigma=sigma)
+    out = bilinear_vote_torch(events, image_size, pad, values)
+    return gaussian_blur3_torch(out, sigma) if sigma > 0 else out
+
+
 def event_mask(events, image_size, pad=(0, 0)):
     """src/event_image_converter.py:288-301."""
     if isinstance(events, np.ndarray):

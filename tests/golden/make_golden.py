@@ -199,6 +199,15 @@ def main():
     out["g2_iwe_b_numpy"] = ic.bilinear_vote_numpy(wb)
     out["g2_iwe_b_torch"] = ic.bilinear_vote_tensor(torch.from_numpy(wb)).numpy()
 
+    # derived images (A12): weighted / averaged splats, numpy (sigma 0 and 1) and torch (sigma 0) branches
+    val = np.random.RandomState(16).uniform(0.5, 1.5, N)
+    for name, fn in (("iwa", ic.create_iwa), ("iwd", ic.create_iwd), ("iwt", ic.create_iwt),
+                     ("timeimage", ic.create_timeimage), ("prob", ic.create_probability_iwe)):
+        out[f"g2_{name}_s0_numpy"] = fn(warped, val, sigma=0)
+        out[f"g2_{name}_s1_numpy"] = fn(warped, val, sigma=1)
+        out[f"g2_{name}_s0_torch"] = fn(tw, torch.from_numpy(val), sigma=0).numpy()
+    out["g2_derived_values"] = val
+
     # contrast costs + autograd gradients (fp64), built from the reference's primitives
     sob = SobelTorch(ksize=3, in_channels=1, precision="64")
 

@@ -180,6 +180,28 @@ def test_iwe_variants_vs_golden(ebos, golden_small):
     assert rel(blurred.cpu().numpy(), expect.numpy()) < 1e-12
 
 
+def test_derived_images_vs_golden(ebos, golden_small):
+    """A12 through the plugin surface: averaged (iwa / iwd / iwt) and weighted (timeimage / probability) images."""
+    g = golden_small
+    warped, val = g["g2_warp_dense_n1_first_numpy"], g["g2_derived_values"]
+    ic = ebos.EventImageConverter((H, W))
+    fns = {"iwa": ic.create_iwa, "iwd": ic.create_iwd, "iwt": ic.create_iwt, "timeimage": ic.create_timeimage,
+           "prob": ic.create_probability_iwe}
+    for name, fn in fns.items():
+        for s in (0, 1):
+            out = fn(warped, val, sigma=s)
+            assert isinstance(out, np.ndarray)
+            assert rel(out, g[f"g2_{name}_s{s}_numpy"]) < 1e-12, (name, s)
+        out_t = fn(G(warped), G(val), sigma=0)
+        assert out_t.is_cuda and tuple(out_t.shape) == g[f"g2_{name}_s0_torch"].shape
+        assert rel(out_t.cpu().numpy(), g[f"g2_{name}_s0_torch"]) < 1e-12, name
+    assert ic.create_iat(warped, val, 0) is None
+    with pytest.raises(NotImplementedError):
+        ic.create_eventrate(warped)
+    with pytest.raises(RuntimeError):
+        ic.create_timeimage([1, 2], val)
+
+
 def test_micro_vote_known_answer(ebos, golden_small):
     g = golden_small
     ev = g["g1_events"]

@@ -127,6 +127,23 @@ def test_iwe_variants_small(golden_small):
         O.create_image_numpy(warped, (H, W), method="nope")
 
 
+def test_derived_images_small(golden_small):
+    """A12: create_iwa / iwd / iwt (averaged) and create_timeimage / create_probability_iwe (weighted)."""
+    g = golden_small
+    warped, val = g["g2_warp_dense_n1_first_numpy"], g["g2_derived_values"]
+    tol = dict(rtol=1e-12, atol=1e-12)
+    for name, base in (("iwa", 1), ("iwd", 0), ("iwt", 2)):
+        for s in (0, 1):
+            np.testing.assert_allclose(O.averaged_image(warped, val, base, (H, W), sigma=s), g[f"g2_{name}_s{s}_numpy"], **tol)
+        out = O.averaged_image(T(warped), T(val), base, (H, W), sigma=0)
+        assert out.shape == (1, 1, H, W)
+        np.testing.assert_allclose(out.numpy(), g[f"g2_{name}_s0_torch"], **tol)
+    for name in ("timeimage", "prob"):
+        for s in (0, 1):
+            np.testing.assert_allclose(O.weighted_image(warped, val, (H, W), sigma=s), g[f"g2_{name}_s{s}_numpy"], **tol)
+        np.testing.assert_allclose(O.weighted_image(T(warped), T(val), (H, W), sigma=0).numpy(), g[f"g2_{name}_s0_torch"], **tol)
+
+
 def _loss(cost, iwe, omit):
     return O.image_variance(iwe, omit) if cost == "var" else O.gradient_magnitude(iwe, omit)
 
