@@ -265,9 +265,26 @@ class EventImageConverter(object):
         raise RuntimeError
 
     def create_eventrate(self, events: NUMPY_TORCH, stat: str = "max") -> NUMPY_TORCH:
-        """The reference evaluates this with a per-event Python loop on numpy input only (:304-327); it is
-        a cold visualisation helper outside the accelerated path."""
-        raise NotImplementedError("create_eventrate is outside the accelerated warp/IWE/cost path (SURVEY.md A12)")
+        """Per-pixel maximum event rate: max over consecutive events of one pixel (in input order) of 1 / dt for
+        dt > 0 (:304-327; numpy input only, like the reference).  A cold visualisation helper outside the accelerated
+        path: the reference's per-event Python loop becomes a stable sort by pixel + a segmented maximum, as plain
+        tensor operations on the GPU."""
+        if not is_numpy(events):
+            raise RuntimeError
+        h, w = self.image_size
+        rate = torch.zeros(h * w, dtype=torch.float64, device=to_gpu(np.zeros(1)).device)
+        if stat != "max" or len(events) == 0:
+            return rate.reshape(h, w).cpu().numpy()
+        ev = to_gpu(events, dtype=torch.float64)
+        pix = ev[:, 0].long() * w + ev[:, 1].long()  # int() truncation of the reference; raises IndexError like it
+        if int(pix.min()) < 0 or int(pix.max()) >= h * w:
+            raise IndexError("event outside the image in create_eventrate")
+        order = torch.sort(pix, stable=True).indices
+        ps, ts = pix[order], ev[order, 2]
+        dt = ts[1:] - ts[:-1]
+        ok = (ps[1:] == ps[:-1]) & (dt > 0)
+        rate.scatter_reduce_(0, ps[1:][ok], 1.0 / dt[ok], reduce="amax", include_self=True)
+        return rate.reshape(h, w).cpu().numpy()
 
     # ------------------------------------------------------------------ blur (K11)
     @staticmethod

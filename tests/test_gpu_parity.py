@@ -196,10 +196,23 @@ def test_derived_images_vs_golden(ebos, golden_small):
         assert out_t.is_cuda and tuple(out_t.shape) == g[f"g2_{name}_s0_torch"].shape
         assert rel(out_t.cpu().numpy(), g[f"g2_{name}_s0_torch"]) < 1e-12, name
     assert ic.create_iat(warped, val, 0) is None
-    with pytest.raises(NotImplementedError):
-        ic.create_eventrate(warped)
     with pytest.raises(RuntimeError):
         ic.create_timeimage([1, 2], val)
+    # create_eventrate against the reference's per-event loop (src/event_image_converter.py:304-327), restated inline
+    ev = g["g2_events"].copy()
+    ev[:, :2] = np.floor(ev[:, :2])
+    ev[::7, 2] = ev[1::7, 2][: len(ev[::7])]  # some equal timestamps: dt == 0 pairs are ignored
+    rate, last = np.zeros((H, W)), np.full((H, W), np.inf)
+    for e in ev:
+        r, c = int(e[0]), int(e[1])
+        d = e[2] - last[r, c]
+        if d > 0:
+            rate[r, c] = max(rate[r, c], 1.0 / d)
+        last[r, c] = e[2]
+    out = ic.create_eventrate(ev)
+    np.testing.assert_allclose(out, rate, rtol=1e-12)
+    with pytest.raises(RuntimeError):
+        ic.create_eventrate(G(ev))
 
 
 def test_micro_vote_known_answer(ebos, golden_small):
