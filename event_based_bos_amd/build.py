@@ -64,6 +64,7 @@ def build_library(force: bool = False, keep_temps: bool = False, verbose: bool =
         for f in os.listdir(OBJ_DIR):
             os.remove(os.path.join(OBJ_DIR, f))
     extra = ["-save-temps=obj"] if keep_temps else []
+    extra += os.environ.get("EBOS_EXTRA_FLAGS", "").split()  # e.g. -DEBOS_STAMPS for the diagnostic build
     with cf.ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, extra), SOURCES))
     if force or _needs_rebuild(LIB_PATH, objs):

@@ -38,6 +38,22 @@ namespace {
 constexpr float kEps = 1e-6f;  // src/event_image_converter.py:586
 constexpr int kBlock = 1024;
 
+// In-kernel phase stamps of the accumulate kernel: diagnostic builds only (python -m event_based_bos_amd.build with
+// EBOS_EXTRA_FLAGS=-DEBOS_STAMPS); values leave through a buffer nothing else reads (cdna guide, In-kernel stamps).
+#ifdef EBOS_STAMPS
+}  // namespace
+__device__ unsigned long long g_stamps[4096 * 8];
+namespace {
+#define EBOS_STAMP(k)                                                                   \
+  do {                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define EBOS_STAMP(k) \
+  do {                \
+  } while (0)
+#endif
+
 struct Taps {
   int R, C;      // top-left tap (un-padded image coordinates)
   float fr, fc;  // fractional offsets
@@ -199,9 +215,23 @@ __device__ __forceinline__ void load_cgroup(CGroup& g, int32_t grp, const TileRa
   g.pr[3] = P.y >> 24;         g.pc[3] = (P.y >> 16) & 255u;
 }
 
+// Work distribution inside the workgroup is DYNAMIC: a wave processes one chunk of 64 groups (one group per lane) at a
+// time and draws its next chunk from an LDS counter.  With a static stride the 16 waves finish far apart -- the SIMD
+// arbiter favours older waves, so wave 0 was done after 9 us and then sat 7 us at the barrier (in-kernel stamps) --
+// and the tail runs at low occupancy.
+struct ChunkQueue {
+  unsigned* next;  // LDS counter, initialised to 2 * waves (chunks 0 .. 2 * waves - 1 are pre-assigned)
+  __device__ __forceinline__ int pull() const {
+    unsigned c = 0;
+    if ((threadIdx.x & (kWave - 1)) == 0) c = atomicAdd(next, 1u);
+    return (int)__builtin_amdgcn_readfirstlane(c);
+  }
+};
+
 template <int TH, int TW, int HALO, bool UNIFORM>
 __device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
-                                                          const float* __restrict__ flow, int H, int W, bool* any_spill) {
+                                                          const float* __restrict__ flow, int H, int W, bool* any_spill,
+                                                          const ChunkQueue& queue) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr unsigned kPlane = LH * LW / 2;  // words per plane
   constexpr unsigned kDummy = LH * LW;      // first word of the dummy region (LW / 2 + 2 words)
@@ -215,10 +245,13 @@ __device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, d
   unsigned added = 0;
   bool spilled = false;
   const int32_t g_last = tr.g_last;
-  int32_t grp = tr.g_first + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  constexpr int kWaves = kBlock / kWave;
+  // chunk c covers groups [g_first + 64 c, g_first + 64 c + 64); this wave starts with chunks `wave` and `wave + 16`
+  int c_cur = wave, c_nxt = wave + kWaves;
   CGroup cur, nxt;
-  load_cgroup<TH, TW>(cur, grp, tr, ev);
-  load_cgroup<TH, TW>(nxt, grp + kBlock, tr, ev);
+  load_cgroup<TH, TW>(cur, tr.g_first + c_cur * kWave + lane, tr, ev);
+  load_cgroup<TH, TW>(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev);
   float fu[4], fv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -226,7 +259,8 @@ __device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, d
     fu[e] = UNIFORM ? uni_u : flow[lin];
     fv[e] = UNIFORM ? uni_v : flow1[lin];
   }
-  while (grp <= g_last) {
+  while (tr.g_first + c_cur * kWave <= g_last) {  // wave-uniform
+    const int32_t grp = tr.g_first + c_cur * kWave + lane;
     float gu[4], gv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -234,15 +268,17 @@ __device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, d
       gu[e] = UNIFORM ? uni_u : flow[lin];
       gv[e] = UNIFORM ? uni_v : flow1[lin];
     }
+    const int c_nn = queue.pull();
     CGroup nn;
-    load_cgroup<TH, TW>(nn, grp + 2 * kBlock, tr, ev);
+    load_cgroup<TH, TW>(nn, tr.g_first + c_nn * kWave + lane, tr, ev);
+    const bool lane_live = grp <= g_last;  // the last chunk of the slice may be partial
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float lx = -cur.dt[e] * fu[e], ly = -cur.dt[e] * fv[e];  // source coordinates are integers: x' = rs + lx
       const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
       const float fr = fmaxf(lx - r0, 0.0f), fc = fmaxf(ly - c0, 0.0f);
       const int rl = (int)cur.pr[e] + HALO + (int)r0, cl = (int)cur.pc[e] + HALO + (int)c0;
-      const bool ok = (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
+      const bool ok = lane_live && (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
       const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
       spilled |= ok && !inside;
       const float fs = fr * kFxScale, as = kFxScale - fs, b = 1.0f - fc;
@@ -258,12 +294,13 @@ __device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, d
     }
     cur = nxt;
     nxt = nn;
+    c_cur = c_nxt;
+    c_nxt = c_nn;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       fu[e] = gu[e];
       fv[e] = gv[e];
     }
-    grp += kBlock;
   }
   if (any_spill) *any_spill = spilled;
   return added;
@@ -281,7 +318,7 @@ enum Pass { PASS_MAIN = 0, PASS_SPILL = 1 };
 template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM>
 __device__ __forceinline__ unsigned accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                      const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
-                                                     float* spill, bool* any_spill) {
+                                                     float* spill, bool* any_spill, const ChunkQueue& queue) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
@@ -293,7 +330,7 @@ __device__ __forceinline__ unsigned accumulate_slice(const TileRange& tr, double
   bool spilled = false;
   if (tr.g_first > tr.g_last) return 0;
   if (FMT == FMT_COMPACT && MODE == ACC_FX && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop
-    return accumulate_compact_fx<TH, TW, HALO, UNIFORM>(tr, s_acc, ev, flow, H, W, any_spill);
+    return accumulate_compact_fx<TH, TW, HALO, UNIFORM>(tr, s_acc, ev, flow, H, W, any_spill, queue);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
   const int32_t g_last = tr.g_last;
@@ -400,21 +437,29 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words; + dummy
   __shared__ unsigned s_chk[2 * kBlock / kWave];
   __shared__ int s_flag[2];  // [0] fixed-point overflow, [1] some event left the LDS window
+  __shared__ unsigned s_next;  // chunk queue of the lean loop
+  const ChunkQueue queue{&s_next};
+  EBOS_STAMP(0);
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, splits);
 
   static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
   for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
     reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
   __syncthreads();
+  EBOS_STAMP(1);
 
   bool spilled = false;
   const unsigned added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h,
-                                                                                              pad_w, spill, &spilled);
+                                                                                              pad_w, spill, &spilled, queue);
   if (spilled) s_flag[1] = 1;  // benign race: every writer stores 1
+  EBOS_STAMP(2);
   __syncthreads();
+  EBOS_STAMP(3);
   if (s_flag[1])  // rare: taps beyond the halo go to the spill image with global atomics
-    accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr);
+    accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr,
+                                                                          queue);
 
   float4* out = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * (LH * LW));
   bool f64_flush = (MODE == ACC_F64);
@@ -461,7 +506,8 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     if (s_flag[0]) {  // a field wrapped: redo this slice exactly in f64 and overwrite the slab (spill taps already issued)
       for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
       __syncthreads();
-      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr);
+      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr,
+                                                                              queue);
       __syncthreads();
       f64_flush = true;
     }
@@ -473,6 +519,7 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       out[i] = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
     }
   }
+  EBOS_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1063,6 +1110,12 @@ bool slab_config_ok(int th, int tw, int halo) {
   else if (tile_h == 32 && tile_w == 32 && halo == 8) { rc = CALL(32, 32, 8); }
 
 extern "C" {
+
+#ifdef EBOS_STAMPS
+int ebos_debug_read_stamps(unsigned long long* host, int count) {  // diagnostic builds only
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_stamps), sizeof(unsigned long long) * count);
+}
+#endif
 
 int ebos_slab_config(int* out, int cap) {
   using namespace ebos;
