@@ -92,6 +92,8 @@ SIGNATURES = {
     "ebos_upsample_patch_flow_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_gauss1d_f32": (_I, _GAUSS),
     "ebos_gauss1d_f64": (_I, _GAUSS),
+    "ebos_gauss1d_bwd_f32": (_I, _GAUSS),
+    "ebos_gauss1d_bwd_f64": (_I, _GAUSS),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -35,6 +35,19 @@ EPS_TENSOR = 1e-6  # :586
 EPS_NUMPY = 1e-8   # :528
 
 
+_TAPS_ON_DEVICE: dict = {}
+
+
+def _taps_on(kind: str, sigma, device: torch.device) -> torch.Tensor:
+    """Blur taps resident on ``device`` (uploaded once per (kind, sigma, device): a per-call host-to-device copy
+    would synchronise, and is not allowed inside a HIP-graph capture of the solver iteration)."""
+    key = (kind, float(sigma), str(device))
+    if key not in _TAPS_ON_DEVICE:
+        taps = _scipy_gaussian_taps(sigma) if kind == "scipy" else _torchvision_taps3(sigma)
+        _TAPS_ON_DEVICE[key] = taps.to(device)
+    return _TAPS_ON_DEVICE[key]
+
+
 def _scipy_gaussian_taps(sigma: float, truncate: float = 4.0) -> torch.Tensor:
     radius = int(truncate * float(sigma) + 0.5)
     x = torch.arange(-radius, radius + 1, dtype=torch.float64)
@@ -290,7 +303,7 @@ class EventImageConverter(object):
     @staticmethod
     def _gaussian_filter(img: torch.Tensor, sigma) -> torch.Tensor:
         """scipy.ndimage.gaussian_filter(img, sigma) semantics: every axis, 'reflect', truncate 4 (:368-369)."""
-        taps = _scipy_gaussian_taps(sigma)
+        taps = _taps_on("scipy", sigma, img.device)
         for axis in range(img.dim()):
             img = ops.gauss1d(img, axis, taps, _hip.GAUSS_REFLECT_SCIPY)
         return img
@@ -298,6 +311,6 @@ class EventImageConverter(object):
     @staticmethod
     def _gaussian_blur3(img: torch.Tensor, sigma) -> torch.Tensor:
         """torchvision gaussian_blur(img, kernel_size=3, sigma) semantics on the last two axes (:399-404)."""
-        taps = _torchvision_taps3(sigma)
+        taps = _taps_on("torch3", sigma, img.device)
         img = ops.gauss1d(img, -2, taps, _hip.GAUSS_REFLECT_TORCH)
         return ops.gauss1d(img, -1, taps, _hip.GAUSS_REFLECT_TORCH)

@@ -343,17 +343,23 @@ def upsample_patch_flow(grid: torch.Tensor, patch_size, sliding_window, image_si
 
 
 # ----------------------------------------------------------------------------------------------
-# K11  Gaussian blur passes (forward only)
+# K11  Gaussian blur passes
 # ----------------------------------------------------------------------------------------------
-def gauss1d(x: torch.Tensor, axis: int, taps: torch.Tensor, boundary: int) -> torch.Tensor:
-    """One separable blur pass along ``axis``; taps = [2r+1] float64 (any device)."""
+class _Gauss1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, axis, taps, boundary):
+        ctx.save_for_backward(taps)
+        ctx.axis, ctx.boundary = axis, boundary
+        return _gauss1d_launch(x, axis, taps, boundary, "ebos_gauss1d_")
+
+    @staticmethod
+    def backward(ctx, g):
+        (taps,) = ctx.saved_tensors
+        return _gauss1d_launch(_cuda_contig(g, "grad"), ctx.axis, taps, ctx.boundary, "ebos_gauss1d_bwd_"), None, None, None
+
+
+def _gauss1d_launch(x: torch.Tensor, axis: int, taps: torch.Tensor, boundary: int, entry: str) -> torch.Tensor:
     lib = _hip.require_gpu()
-    if x.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("the Gaussian blur pass is forward-only: use sigma = 0 inside a differentiated "
-                                  "objective (the contrast-maximisation loop runs with iwe.blur_sigma = 0)")
-    x = _cuda_contig(x, "image")
-    taps = taps.to(device=x.device, dtype=torch.float64).contiguous()
-    axis = axis % x.dim()
     L = x.shape[axis]
     outer = 1
     for s in x.shape[:axis]:
@@ -365,7 +371,15 @@ def gauss1d(x: torch.Tensor, axis: int, taps: torch.Tensor, boundary: int) -> to
     if x.numel() == 0:
         return out
     with torch.cuda.device(x.device):
-        fn = getattr(lib, "ebos_gauss1d_" + suffix(x.dtype))
+        fn = getattr(lib, entry + suffix(x.dtype))
         check(fn(ptr(x), ptr(out), outer, L, inner, ptr(taps), (taps.numel() - 1) // 2, boundary, stream_ptr()),
-              "ebos_gauss1d")
+              entry.rstrip("_"))
     return out
+
+
+def gauss1d(x: torch.Tensor, axis: int, taps: torch.Tensor, boundary: int) -> torch.Tensor:
+    """One separable blur pass along ``axis``; taps = [2r+1] float64 (any device).  Differentiable in x."""
+    _hip.require_gpu()
+    x = _cuda_contig(x, "image")
+    taps = taps.detach().to(device=x.device, dtype=torch.float64).contiguous()
+    return _Gauss1d.apply(x, axis % x.dim(), taps, int(boundary))

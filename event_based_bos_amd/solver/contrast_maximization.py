@@ -24,6 +24,7 @@ import torch
 
 from .. import costs, ops
 from .._staging import to_gpu
+from ..event_image_converter import EventImageConverter
 from ..event_plan import EventPlan
 from .base import SolverBase
 
@@ -57,8 +58,10 @@ class ContrastMaximization(SolverBase):
         iwe_cfg = cfg.get("iwe") or {}
         if iwe_cfg.get("method", "bilinear_vote") != "bilinear_vote":
             raise NotImplementedError("the contrast objective is defined on method='bilinear_vote'")
-        if float(iwe_cfg.get("blur_sigma", 0) or 0) > 0:
-            raise NotImplementedError("iwe.blur_sigma > 0 is forward-only here; run the loop with blur_sigma = 0")
+        # iwe.blur_sigma > 0: the contrast is taken on create_iwe(events, sigma=blur_sigma) of the tensor branch
+        # (3-tap blur, src/event_image_converter.py:399-404).  It removes the spurious optimum at zero flow that
+        # integer sensor coordinates create (un-warped events hit single pixels, any sub-pixel warp spreads them).
+        self.blur_sigma = float(iwe_cfg.get("blur_sigma", 0) or 0)
         pcfg = cfg.get("patch") or {}
         self.patch_size = tuple(pcfg.get("size", (24, 32)))
         self.sliding_window = tuple(pcfg.get("sliding_window", self.patch_size))
@@ -80,6 +83,13 @@ class ContrastMaximization(SolverBase):
     # ------------------------------------------------------------------ objective pieces
     def _contrast(self, plan: EventPlan, flow: torch.Tensor) -> torch.Tensor:
         total = 0.0
+        if self.blur_sigma > 0:
+            iwe = plan.iwe_dense(flow, pad=(self.pad, self.pad), halo=self.halo)
+            iwe = EventImageConverter._gaussian_blur3(iwe, self.blur_sigma)
+            for name, wgt in self.contrast_terms.items():
+                fn = ops.image_variance if name == "image_variance" else ops.gradient_magnitude
+                total = total + wgt * fn(iwe, self.omit_boundary)
+            return total
         for name, wgt in self.contrast_terms.items():
             total = total + wgt * plan.contrast_dense(flow, name, self.omit_boundary, pad=(self.pad, self.pad), halo=self.halo)
         return total

@@ -372,6 +372,13 @@ int ebos_gauss1d_f32(const float* in, float* out, int64_t outer, int64_t L, int6
                      int radius, int boundary, ebos_stream_t stream);
 int ebos_gauss1d_f64(const double* in, double* out, int64_t outer, int64_t L, int64_t inner, const double* taps,
                      int radius, int boundary, ebos_stream_t stream);
+/* Adjoint of one pass: g_in = (d loss / d in) from g_out = (d loss / d out).  What torch autograd
+ * derives for gaussian_blur in the tensor branch (src/event_image_converter.py:399-404); gather
+ * form, deterministic.  g_in must not alias g_out. */
+int ebos_gauss1d_bwd_f32(const float* g_out, float* g_in, int64_t outer, int64_t L, int64_t inner,
+                         const double* taps, int radius, int boundary, ebos_stream_t stream);
+int ebos_gauss1d_bwd_f64(const double* g_out, double* g_in, int64_t outer, int64_t L, int64_t inner,
+                         const double* taps, int radius, int boundary, ebos_stream_t stream);
 
 #ifdef __cplusplus
 }

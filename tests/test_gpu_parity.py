@@ -479,6 +479,32 @@ def test_2dof_tile_private_sweep(ebos):
         assert rel(i2[k].cpu().numpy(), ref.numpy()) < 1e-5
 
 
+def test_non_finite_events_are_contained(ebos):
+    """NaN / Inf coordinates and timestamps: the reference poisons pixel 0 (NaN * 0 in the masked scatter); here
+    such taps are dropped and every other pixel is unaffected."""
+    h, w, n = 40, 48, 5000
+    ev = O.synth_events(n, h, w, seed=51)
+    fl = O.synth_dense_flow(h, w, seed=52, max_val=4.0)
+    ref = O.iwe_dense(torch.from_numpy(ev), torch.from_numpy(fl), (h, w)).numpy()
+    warped = O.warp_dense_numpy(ev, fl, "first", True)
+    bad = warped.copy()
+    bad = np.concatenate([bad, [[np.nan, 3.0, 0.1, 1], [5.0, np.inf, 0.2, 0], [-np.inf, np.nan, 0.3, 1], [1e30, 2.0, 0.4, 0]]])
+    ic = ebos.EventImageConverter((h, w))
+    img = ic.bilinear_vote_numpy(bad)
+    assert np.isfinite(img).all() and rel(img, ic.bilinear_vote_numpy(warped)) < 1e-14
+    img_t = ic.bilinear_vote_tensor(G(bad, torch.float32))
+    assert torch.isfinite(img_t).all()
+    # fused path: NaN timestamp on one event must not leak beyond that event
+    ev2 = ev.copy()
+    plan = ebos.EventPlan.build(G(ev2), (h, w), "first", True, tile=(32, 32))
+    plan.dt[7] = float("nan")
+    if plan.compact:
+        plan.cdt[7] = float("nan")
+    out = plan.iwe_dense(G(fl, torch.float32), halo=8)
+    assert torch.isfinite(out).all()
+    assert abs(out.sum().item() - ref.sum()) < 1.5  # at most that one event is missing
+
+
 def test_plan_binning_properties(ebos):
     h, w, n = 70, 90, 30_000
     ev = O.synth_events(n, h, w, seed=11)
@@ -523,3 +549,56 @@ def test_upsample_patch_flow(ebos):
     ref2 = O.upsample_patch_flow(torch.from_numpy(grid2), img, (48, 64), slide)
     d2 = ebos.ops.upsample_patch_flow(G(grid2, torch.float32), (48, 64), slide, img)
     assert rel(d2.cpu().numpy(), ref2.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("shape,axis,radius,boundary", [
+    ((24, 32), 0, 1, 1), ((24, 32), 1, 1, 1), ((2, 3, 9, 7), 2, 1, 1),      # torch 'reflect', 3 taps
+    ((24, 32), 0, 4, 0), ((24, 32), 1, 12, 0), ((5, 6), 0, 12, 0),           # scipy 'reflect'; radius > 2L too
+    ((1, 8), 0, 2, 0), ((3, 2, 5), 1, 3, 0),
+])
+def test_blur_pass_adjoint(ebos, shape, axis, radius, boundary):
+    """ebos_gauss1d_bwd is the exact transpose of ebos_gauss1d: checked against the dense operator matrix built from
+    the library the reference calls (scipy correlate1d 'reflect' = gaussian_filter's pass; torch reflect pad + conv
+    for the tensor branch).  fp64, rel-L2 <= 1e-13."""
+    from scipy.ndimage import correlate1d
+
+    rng = np.random.default_rng(5)
+    taps = rng.uniform(0.1, 1.0, 2 * radius + 1)
+    taps = (taps + taps[::-1]) / 2
+    L = shape[axis]
+    eye = np.eye(L)
+    if boundary == 0:
+        A = correlate1d(eye, taps, axis=0, mode="reflect")                  # A[i, j] = d out[i] / d in[j]
+    else:
+        pad = torch.nn.functional.pad(torch.from_numpy(eye.T)[None], (radius, radius), mode="reflect")[0]
+        A = torch.nn.functional.conv1d(pad[:, None], torch.from_numpy(taps)[None, None])[:, 0].numpy().T
+    x = rng.normal(size=shape)
+    gy = rng.normal(size=shape)
+    xt = G(x).requires_grad_(True)
+    y = ebos.ops.gauss1d(xt, axis, torch.from_numpy(taps), boundary)
+    expect_y = np.moveaxis(np.tensordot(A, np.moveaxis(x, axis, 0), axes=1), 0, axis)
+    assert rel(y.detach().cpu().numpy(), expect_y) <= 1e-13
+    y.backward(G(gy))
+    expect_gx = np.moveaxis(np.tensordot(A.T, np.moveaxis(gy, axis, 0), axes=1), 0, axis)
+    assert rel(xt.grad.cpu().numpy(), expect_gx) <= 1e-13
+
+
+def test_blurred_iwe_is_differentiable(ebos):
+    """create_iwe(warped, sigma=1) under autograd, as the reference's tensor branch allows
+    (src/event_image_converter.py:399-404): gradient of var(blur(IWE)) w.r.t. the flow against the oracle's
+    torch-CPU autograd through the same chain (fp64 general path, rel-L2 <= 1e-9)."""
+    ev = O.synth_events(3000, H, W, seed=21)
+    flow = O.synth_dense_flow(H, W, seed=22, max_val=2.0)
+    ft = torch.from_numpy(flow).requires_grad_(True)
+    w_ref = O.warp_dense_torch(torch.from_numpy(ev), ft, "first", True)
+    img = O.gaussian_blur3_torch(O.bilinear_vote_torch(w_ref, (H, W)), 1.0)
+    O.image_variance(img, False, "minimize").backward()
+
+    fg = G(flow).requires_grad_(True)
+    warper = ebos.Warp((H, W), normalize_t=True)
+    ic = ebos.EventImageConverter((H, W))
+    warped, _ = warper.warp_event(G(ev), fg, "dense-flow", direction="first")
+    iwe = ic.create_iwe(warped, method="bilinear_vote", sigma=1)
+    cost = ebos.costs.functions["image_variance"](direction="minimize")
+    cost.calculate({"iwe": iwe, "omit_boundary": False}).backward()
+    assert rel(fg.grad.cpu().numpy(), ft.grad.numpy()) <= 1e-9

@@ -44,8 +44,9 @@ def test_registry_and_config_keys():
         cls((8, 8), (8, 8), solver_config={"cost_with_weight": {"flow_norm": 1.0}})
     with pytest.raises(KeyError):
         cls((8, 8), (8, 8), solver_config={"cost_with_weight": {"image_variance": 1.0, "nope": 1.0}})
+    assert cls((8, 8), (8, 8), solver_config={"iwe": {"blur_sigma": 1}}).blur_sigma == 1.0
     with pytest.raises(NotImplementedError):
-        cls((8, 8), (8, 8), solver_config={"iwe": {"blur_sigma": 1}})
+        cls((8, 8), (8, 8), solver_config={"iwe": {"method": "count"}})
 
 
 @pytest.mark.gpu
@@ -57,7 +58,7 @@ def test_solver_recovers_translation_dense_and_2dof():
     ev = moving_points(h, w, 600, 40, v, seed=1)
     cfg = load_cfg()["solver"]
     cfg.update(patch={"size": [24, 32], "sliding_window": [24, 32]}, optimizer={"method": "Adam", "n_iter": 80, "parameters": {"lr": 0.5}},
-               cost_with_weight={"image_variance": 1.0})
+               cost_with_weight={"image_variance": 1.0}, iwe={"method": "bilinear_vote", "blur_sigma": 0})
     cfg["filter"] = {"parameters": {"xmin": 0, "xmax": h, "ymin": 0, "ymax": w}}
     s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
     events, period = s.preprocess(ev)
@@ -75,15 +76,18 @@ def test_solver_recovers_translation_dense_and_2dof():
 
 
 @pytest.mark.gpu
-def test_solver_trajectory_matches_cpu_oracle():
-    """Same Adam loop, driven once by the HIP pipeline (f32) and once by the CPU oracle (fp64)."""
+@pytest.mark.parametrize("blur", [0, 1])
+def test_solver_trajectory_matches_cpu_oracle(blur):
+    """Same Adam loop, driven once by the HIP pipeline (f32) and once by the CPU oracle (fp64);
+    blur = 1 takes the contrast on the 3-tap blurred IWE (the un-fused objective through the blur adjoint)."""
     import event_based_bos_amd as ebos
 
     h, w, n_iter = 60, 78, 6
     ev = moving_points(h, w, 300, 30, np.array([3.0, 2.0]), seed=2)
     cfg = load_cfg()["solver"]
     cfg.update(patch={"size": [20, 26], "sliding_window": [20, 26]},
-               optimizer={"method": "Adam", "n_iter": n_iter, "parameters": {"lr": 0.3}, "graph": True})
+               optimizer={"method": "Adam", "n_iter": n_iter, "parameters": {"lr": 0.3}, "graph": True},
+               iwe={"method": "bilinear_vote", "blur_sigma": blur})
     s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
     s.estimate(ev)
     gh, gw = ebos.solver.patch_grid_shape((h, w), (20, 26), (20, 26))
@@ -94,7 +98,9 @@ def test_solver_trajectory_matches_cpu_oracle():
     for _ in range(n_iter):
         opt.zero_grad()
         dense = O.upsample_patch_flow(theta, (h, w), (20, 26), (20, 26))
-        loss = O.image_variance(O.iwe_dense(tev, dense, (h, w))) + 0.001 * O.flow_norm(dense)
+        iwe = O.iwe_dense(tev, dense, (h, w))
+        iwe = O.gaussian_blur3_torch(iwe, float(blur)) if blur else iwe
+        loss = O.image_variance(iwe) + 0.001 * O.flow_norm(dense)
         loss.backward()
         opt.step()
         ref.append(loss.item())
