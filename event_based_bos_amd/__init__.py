@@ -10,6 +10,7 @@ tub-rip/event_based_bos:
     costs                drop-in for src/costs (+ image_variance, gradient_magnitude)
     EventPlan            device-resident SoA event window + the fused warp/IWE kernels
     solver               contrast-maximisation solver behind the reference's solver registry
+    data_loader          raw-column event store (the CCS raw_events layout) feeding EventPlan.build_raw
 
 All arithmetic of the path runs in hand-written HIP kernels reached through the C ABI of
 libebos_hip.so (include/ebos_hip.h).  There is no CPU fallback: without the library or a GPU the
@@ -19,6 +20,6 @@ from ._hip import HipUnavailableError, load_library  # noqa: F401
 from .warp import MotionModelKeyError, Warp  # noqa: F401
 from .event_image_converter import EventImageConverter  # noqa: F401
 from .event_plan import EventPlan  # noqa: F401
-from . import costs, fusion, ops, solver, types  # noqa: F401
+from . import costs, data_loader, fusion, ops, solver, types  # noqa: F401
 
 __version__ = "0.1.0"

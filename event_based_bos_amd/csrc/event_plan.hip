@@ -39,6 +39,62 @@ events_to_soa_kernel(const T* __restrict__ events, const T* __restrict__ tminmax
   }
 }
 
+// ---- raw sensor columns -> SoA (the event-ingest format) ----------------------------
+// The CCS recordings store raw_events/{x: int16 column, y: int16 row, t: int32 microseconds, p: bool}
+// (src/data_loader/ccs.py:57-66); the reference expands a window to float64 [n, 4] =
+// (y, x, t / 1e6, p) on the host (:289-297).  Here the window stays in its 9 B/event raw form on the
+// device and is expanded to the SoA plan directly, with the same fp64 time arithmetic.
+template <typename TT>
+__global__ void __launch_bounds__(256)
+raw_time_range_kernel(const TT* __restrict__ t, int64_t n, long long* __restrict__ tminmax_ticks) {
+  long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long v = (long long)t[i];
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    __hip_atomic_fetch_min(&tminmax_ticks[0], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(&tminmax_ticks[1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ void raw_time_range_init_kernel(long long* tminmax_ticks) {
+  tminmax_ticks[0] = 0x7fffffffffffffffLL;
+  tminmax_ticks[1] = -0x7fffffffffffffffLL - 1;
+}
+
+__global__ void raw_time_range_seconds_kernel(const long long* tminmax_ticks, double ticks_per_second, double* tminmax) {
+  tminmax[0] = (double)tminmax_ticks[0] / ticks_per_second;  // t / 1e6, src/data_loader/ccs.py:295
+  tminmax[1] = (double)tminmax_ticks[1] / ticks_per_second;
+}
+
+template <typename TT>
+__global__ void __launch_bounds__(256)
+raw_to_soa_kernel(const int16_t* __restrict__ col, const int16_t* __restrict__ row, const TT* __restrict__ t,
+                  const uint8_t* __restrict__ pol, double ticks_per_second, const double* __restrict__ tminmax,
+                  int ref_mode, double ref_fraction, int normalize_t, int64_t n, float* __restrict__ x,
+                  float* __restrict__ y, float* __restrict__ dt, float* __restrict__ p) {
+  const double tmin = tminmax[0], tmax = tminmax[1];
+  double ref;
+  if (ref_mode == EBOS_REF_FIRST) ref = tmin;
+  else if (ref_mode == EBOS_REF_LAST) ref = tmax;
+  else ref = tmin + (tmax - tmin) * ref_fraction;
+  double inv_period = normalize_t ? 1.0 / (tmax - tmin) : 1.0;
+  if (ref_mode == EBOS_REF_TIMEBASE) {
+    ref = tmin;
+    inv_period = normalize_t ? 1.0 / tmax : 1.0;
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    x[i] = (float)row[i];  // events[:, 0] = y (row), :293
+    y[i] = (float)col[i];  // events[:, 1] = x (column), :294
+    dt[i] = (float)(((double)t[i] / ticks_per_second - ref) * inv_period);
+    p[i] = pol[i] ? 1.0f : 0.0f;
+  }
+}
+
 __device__ __forceinline__ int source_key(float x, float y, int H, int W, int tile_h, int tile_w, int tiles_x) {
   if (!(x > -1e9f && x < 1e9f && y > -1e9f && y < 1e9f)) return -1;
   const int r = (int)x, c = (int)y;  // truncation toward zero, src/warp.py:334
@@ -238,6 +294,43 @@ int ebos_events_to_soa_f64(const double* events, const double* tminmax, int ref_
                            int normalize_t, int64_t n, float* x, float* y, float* dt, float* p,
                            ebos_stream_t stream) {
   return ebos::events_to_soa_impl<double>(events, tminmax, ref_mode, ref_fraction, normalize_t, n, x, y, dt, p, stream);
+}
+
+int ebos_raw_time_range(const void* t, int t_bytes, int64_t n, double ticks_per_second, int64_t* scratch_ticks,
+                        double* tminmax, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE((t && scratch_ticks && tminmax) && n >= 1, "ebos_raw_time_range: NULL buffer or empty window");
+  EBOS_REQUIRE((t_bytes == 4 || t_bytes == 8) && ticks_per_second > 0.0, "ebos_raw_time_range: bad time format");
+  hipStream_t s = as_stream(stream);
+  long long* ticks = reinterpret_cast<long long*>(scratch_ticks);
+  raw_time_range_init_kernel<<<dim3(1), dim3(1), 0, s>>>(ticks);
+  const dim3 grid(stream_grid(n, 256, 1024));
+  if (t_bytes == 4) raw_time_range_kernel<int32_t><<<grid, dim3(256), 0, s>>>(static_cast<const int32_t*>(t), n, ticks);
+  else raw_time_range_kernel<int64_t><<<grid, dim3(256), 0, s>>>(static_cast<const int64_t*>(t), n, ticks);
+  raw_time_range_seconds_kernel<<<dim3(1), dim3(1), 0, s>>>(ticks, ticks_per_second, tminmax);
+  EBOS_CHECK_LAUNCH("ebos_raw_time_range");
+  return EBOS_OK;
+}
+
+int ebos_raw_events_to_soa(const int16_t* col, const int16_t* row, const void* t, int t_bytes, const uint8_t* pol,
+                           double ticks_per_second, const double* tminmax, int ref_mode, double ref_fraction,
+                           int normalize_t, int64_t n, float* x, float* y, float* dt, float* p, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(tminmax != nullptr, "ebos_raw_events_to_soa: tminmax is NULL");
+  EBOS_REQUIRE((col && row && t && pol && x && y && dt && p) || n == 0, "ebos_raw_events_to_soa: NULL buffer");
+  EBOS_REQUIRE((t_bytes == 4 || t_bytes == 8) && ticks_per_second > 0.0, "ebos_raw_events_to_soa: bad time format");
+  EBOS_REQUIRE(ref_mode >= 0 && ref_mode <= 3 && n >= 0, "ebos_raw_events_to_soa: bad ref_mode/n");
+  if (n == 0) return EBOS_OK;
+  const dim3 grid(stream_grid(n, 256));
+  hipStream_t s = as_stream(stream);
+  if (t_bytes == 4)
+    raw_to_soa_kernel<int32_t><<<grid, dim3(256), 0, s>>>(col, row, static_cast<const int32_t*>(t), pol, ticks_per_second,
+                                                        tminmax, ref_mode, ref_fraction, normalize_t, n, x, y, dt, p);
+  else
+    raw_to_soa_kernel<int64_t><<<grid, dim3(256), 0, s>>>(col, row, static_cast<const int64_t*>(t), pol, ticks_per_second,
+                                                        tminmax, ref_mode, ref_fraction, normalize_t, n, x, y, dt, p);
+  EBOS_CHECK_LAUNCH("ebos_raw_events_to_soa");
+  return EBOS_OK;
 }
 
 size_t ebos_bin_scratch_bytes(int64_t n_keys) {

@@ -132,6 +132,48 @@ class EventPlan:
             plan = plan.bin(tile)
         return plan
 
+    @staticmethod
+    def build_raw(col: torch.Tensor, row: torch.Tensor, t: torch.Tensor, pol: torch.Tensor, image_size: Tuple[int, int],
+                  direction: Union[str, float] = "first", normalize_t: bool = True,
+                  tile: Optional[Tuple[int, int]] = DEFAULT_TILE, ticks_per_second: float = 1e6) -> "EventPlan":
+        """Plan of a window given as raw sensor columns on the GPU -- ``raw_events/{x, y, t, p}`` of the CCS
+        recordings: col int16 (sensor x), row int16 (sensor y), t int32/int64 ticks, pol bool/uint8
+        (src/data_loader/ccs.py:57-66).  Same plan, bit for bit, as ``build`` on the float64 [n, 4] array the
+        reference's loader makes of the window (:289-297), without materialising that array (32 B/event) anywhere."""
+        if isinstance(tile, str):
+            if tile != "auto":
+                raise ValueError("tile must be a (tile_h, tile_w) pair, None or 'auto'")
+            tile = choose_tile(image_size)
+        lib = _hip.require_gpu()
+        n = int(t.shape[0])
+        for name, v, dts in (("col", col, (torch.int16,)), ("row", row, (torch.int16,)), ("t", t, (torch.int32, torch.int64)),
+                             ("pol", pol, (torch.bool, torch.uint8))):
+            if v.dim() != 1 or v.shape[0] != n or v.dtype not in dts:
+                raise ValueError(f"EventPlan.build_raw: {name} must be a 1-D tensor of {n} elements, dtype in {dts}; "
+                                 f"got {tuple(v.shape)} {v.dtype}")
+            if not v.is_cuda:
+                raise _hip.HipUnavailableError(f"EventPlan.build_raw: {name} must be on the GPU")
+        if n == 0:
+            raise IndexError("EventPlan.build_raw: empty window")  # the loader raises IndexError too (ccs.py:262-265)
+        col, row, t = col.contiguous(), row.contiguous(), t.contiguous()
+        pol = pol.contiguous().view(torch.uint8)
+        H, W = int(image_size[0]), int(image_size[1])
+        ref_mode, frac = parse_direction(direction)
+        dev = t.device
+        ticks = torch.empty(2, dtype=torch.int64, device=dev)
+        tmm = torch.empty(2, dtype=torch.float64, device=dev)
+        x, y, dt, p = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+        with torch.cuda.device(dev):
+            check(lib.ebos_raw_time_range(ptr(t), t.element_size(), n, float(ticks_per_second), ptr(ticks), ptr(tmm),
+                                          stream_ptr()), "ebos_raw_time_range")
+            check(lib.ebos_raw_events_to_soa(ptr(col), ptr(row), ptr(t), t.element_size(), ptr(pol), float(ticks_per_second),
+                                             ptr(tmm), ref_mode, frac, int(normalize_t), n, ptr(x), ptr(y), ptr(dt), ptr(p),
+                                             stream_ptr()), "ebos_raw_events_to_soa")
+        plan = EventPlan(x, y, dt, p, (H, W), n, n)
+        if tile is not None:
+            plan = plan.bin(tile)
+        return plan
+
     def bin(self, tile: Tuple[int, int] = DEFAULT_TILE) -> "EventPlan":
         """Counting-sort the plan by source pixel, tile-major (ebos_bin_events_f32)."""
         lib = _hip.require_gpu()

@@ -174,6 +174,23 @@ int ebos_events_to_soa_f64(const double* events, const double* tminmax, int ref_
                            int normalize_t, int64_t n, float* x, float* y, float* dt, float* p,
                            ebos_stream_t stream);
 
+/* Raw sensor columns -> SoA (event ingest).  The CCS recordings hold
+ * raw_events/{x: int16 column, y: int16 row, t: int32 microseconds, p: bool}
+ * (src/data_loader/ccs.py:57-66); the reference expands a window on the host to float64 [n, 4] =
+ * (y, x, t / 1e6, p) (src/data_loader/ccs.py:289-297) before Warp sees it.  These two entry points
+ * take the 9 B/event raw window as it is on the device and produce the same SoA plan as
+ * ebos_events_to_soa_f64 on that float64 array (bit-identical: the same fp64 time arithmetic).
+ *   t_bytes: 4 (int32) or 8 (int64) ticks; ticks_per_second: 1e6 for microseconds.
+ *   ebos_raw_time_range: tminmax[2] (device, seconds) = (min t, max t) / ticks_per_second;
+ *     scratch_ticks: device int64[2].  n >= 1.
+ *   ebos_raw_events_to_soa: ref_mode / ref_fraction / normalize_t as ebos_events_to_soa_*. */
+int ebos_raw_time_range(const void* t, int t_bytes, int64_t n, double ticks_per_second, int64_t* scratch_ticks,
+                        double* tminmax, ebos_stream_t stream);
+int ebos_raw_events_to_soa(const int16_t* col, const int16_t* row, const void* t, int t_bytes,
+                           const uint8_t* pol, double ticks_per_second, const double* tminmax, int ref_mode,
+                           double ref_fraction, int normalize_t, int64_t n, float* x, float* y, float* dt,
+                           float* p, ebos_stream_t stream);
+
 /* Source-tile binning (counting sort by source pixel, tile-major).  The image [H, W] is cut into
  * tiles of tile_h x tile_w pixels; key(event) = tile_id * tile_h*tile_w + pixel-in-tile of
  * (trunc(x), trunc(y)).  Events are reordered by key; events of one tile, and of one source

@@ -435,6 +435,32 @@ def iwe_2dof(events: torch.Tensor, theta: torch.Tensor, image_size, pad=(0, 0),
 # --------------------------------------------------------------------------------------
 # Synthetic inputs (legacy RandomState: identical streams on every numpy version)
 # --------------------------------------------------------------------------------------
+def events_from_raw_columns(x, y, t, p, start_index: int, end_index: int) -> np.ndarray:
+    """CcsDataLoader.load_event_from_hdf, src/data_loader/ccs.py:275-297, on the raw columns of
+    h5py_loader (:57-66: x int16 = column, y int16 = row, t int32 microseconds, p bool).
+    PARITY UNPINNED against the reference loader itself (it needs h5py and a recording; neither is
+    in this image) -- the restatement is the five assignments of :292-296."""
+    n_events = end_index - start_index
+    events = np.zeros((n_events, 4), dtype=np.float64)
+    if len(x) <= start_index:
+        raise IndexError
+    events[:, 0] = y[start_index:end_index]
+    events[:, 1] = x[start_index:end_index]
+    events[:, 2] = t[start_index:end_index] / 1e6  # from micro sec to sec
+    events[:, 3] = p[start_index:end_index]
+    return events
+
+
+def synth_raw_columns(n: int, height: int, width: int, seed: int = 0, t0_us: int = 10_000_000, span_us: int = 8300):
+    """Synthetic raw_events columns with the dtypes of src/data_loader/ccs.py:63-66."""
+    rs = np.random.RandomState(seed)
+    x = rs.randint(0, width, n).astype(np.int16)
+    y = rs.randint(0, height, n).astype(np.int16)
+    t = np.sort(rs.randint(t0_us, t0_us + span_us, n)).astype(np.int32)
+    p = rs.randint(0, 2, n).astype(bool)
+    return x, y, t, p
+
+
 def synth_events(n: int, height: int, width: int, seed: int = 0, tmin=0.0, tmax=0.5) -> np.ndarray:
     """Distribution of src/utils/event_utils.py:40-47 with an explicit seed."""
     rs = np.random.RandomState(seed)
