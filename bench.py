@@ -121,13 +121,16 @@ def main():
     ev, flow_np = synth_window(n, seed=rank)
     ev_gpu = torch.from_numpy(ev).to(dev)
     flow = torch.from_numpy(flow_np).float().to(dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     if args.tile[0] <= 0:
         args.tile = list(ebos.event_plan.choose_tile((H, W), args.halo))
-    plan = ebos.EventPlan.build(ev_gpu, (H, W), "first", True, tile=tuple(args.tile))
-    torch.cuda.synchronize()
-    plan_build_ms = (time.perf_counter() - t0) * 1e3
+    plan_first_ms = plan_build_ms = 0.0
+    for attempt in range(2):  # the first build also pays one-off allocator / code-object costs: report the second
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan = ebos.EventPlan.build(ev_gpu, (H, W), "first", True, tile=tuple(args.tile))
+        torch.cuda.synchronize()
+        plan_build_ms = (time.perf_counter() - t0) * 1e3
+        plan_first_ms = plan_first_ms or plan_build_ms
     del ev_gpu
 
     import ctypes
@@ -222,7 +225,7 @@ def main():
                          "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
                          "plan_format_bytes": format_bytes,
                          "plan_format_GBps": round(format_bytes / (kernel_ms * 1e-3) / 1e9, 1)},
-            "plan_build_ms": round(plan_build_ms, 2), "fwd_bwd_ms": round(fwdbwd_ms, 4),
+            "plan_build_ms": round(plan_build_ms, 2), "plan_build_first_call_ms": round(plan_first_ms, 2), "fwd_bwd_ms": round(fwdbwd_ms, 4),
             "fwd_bwd_mevents_per_s": round(n / fwdbwd_ms / 1e3, 2), "contrast": contrast,
         }
         if world == 1 and not args.no_cpu_baseline:
