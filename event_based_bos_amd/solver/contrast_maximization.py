@@ -11,8 +11,8 @@ objective(theta) = - contrast(IWE(warp(events, motion(theta)))) [+ weighted regu
 
 Everything per event runs in the fused tile-private HIP pipeline on an ``EventPlan`` built once per window.
 YAML keys read (same names as configs/hot_plate1.yaml:46-80 of the reference): warp_direction, motion_model,
-parameters, cost, cost_with_weight, outer_padding, iwe.{method, blur_sigma}, patch.{size, sliding_window},
-optimizer.{method, n_iter, parameters.lr, sampler}.
+parameters, cost, cost_with_weight, outer_padding, iwe.{method, blur_sigma}, patch.{size, sliding_window, pyramid.{coarsest, finest}},
+optimizer.{method (Adam | CG | BFGS | L-BFGS-B | TNC | SLSQP | grid), n_iter, parameters.lr, options, graph}.
 """
 from __future__ import annotations
 
@@ -31,6 +31,7 @@ from .base import SolverBase
 logger = logging.getLogger(__name__)
 
 CONTRAST_COSTS = ("image_variance", "gradient_magnitude")
+SCIPY_METHODS = ("CG", "BFGS", "L-BFGS-B", "TNC", "SLSQP")  # first-order methods of scipy.optimize.minimize
 
 
 def patch_grid_shape(image_size, patch_size, sliding_window):
@@ -65,10 +66,14 @@ class ContrastMaximization(SolverBase):
         pcfg = cfg.get("patch") or {}
         self.patch_size = tuple(pcfg.get("size", (24, 32)))
         self.sliding_window = tuple(pcfg.get("sliding_window", self.patch_size))
+        self.pyramid = pcfg.get("pyramid") or None
+        if self.pyramid and not (int(self.pyramid["coarsest"]) >= int(self.pyramid["finest"]) >= 1):
+            raise ValueError("patch.pyramid needs coarsest >= finest >= 1")
         ocfg = cfg.get("optimizer") or {}
         self.opt_method = ocfg.get("method", "Adam")
         self.n_iter = int(ocfg.get("n_iter", 100))
         self.lr = float((ocfg.get("parameters") or {}).get("lr", 0.05))
+        self.scipy_options = dict(ocfg.get("options") or {})
         self.param_ranges = cfg.get("parameters") or {}
         self.halo = int(cfg.get("halo", 32))
         # optimizer.graph: capture one whole iteration (upsample -> fused objective -> backward -> Adam update) into a
@@ -118,34 +123,99 @@ class ContrastMaximization(SolverBase):
             raise NotImplementedError(f"motion_model {self.motion_model!r}")
         return flow.detach().cpu().numpy().astype(np.float64)
 
+    def pyramid_scales(self):
+        """[(patch_size, sliding_window, n_iter)] coarse to fine.  Without ``patch.pyramid`` one scale (``patch.size``);
+        with ``patch.pyramid: {coarsest: c, finest: f}`` the square patches c, c/2, ... of
+        src/solver/patch_eklt_pyramid2.py:55-83 (scales 1 .. int(log2(c / f)) + 1, slide = patch) and its
+        iteration split ``n_iter // (finest_scale - scale + 1)`` (:260)."""
+        if not self.pyramid:
+            return [(self.patch_size, self.sliding_window, self.n_iter)]
+        c, f = int(self.pyramid["coarsest"]), int(self.pyramid["finest"])
+        finest_scale = int(np.log2(c / f)) + 2
+        out = []
+        for i in range(1, finest_scale):
+            size = (c // (2 ** (i - 1)),) * 2
+            out.append((size, size, max(1, self.n_iter // (finest_scale - i + 1))))
+        return out
+
     def _estimate_patch_flow(self, plan: EventPlan) -> torch.Tensor:
         H, W = self.orig_image_shape
-        gh, gw = patch_grid_shape((H, W), self.patch_size, self.sliding_window)
-        init = self.previous_best if self.previous_best is not None else torch.zeros((2, gh, gw))
-        theta = to_gpu(init, device=plan.device, dtype=torch.float32).reshape(2, gh, gw).clone().requires_grad_(True)
+        self.history, self.patch_flow_per_scale = [], []
+        theta = None
+        for patch_size, sliding_window, n_iter in self.pyramid_scales():
+            gh, gw = patch_grid_shape((H, W), patch_size, sliding_window)
+            if theta is not None:  # initialise from the coarser scale: resize(x0, patch_image_size), pyramid2.py:253-255
+                init = torch.nn.functional.interpolate(theta[None], size=(gh, gw), mode="bilinear", align_corners=False)[0]
+            elif self.previous_best is not None:
+                init = to_gpu(self.previous_best, device=plan.device, dtype=torch.float32).reshape(2, gh, gw)
+            else:
+                init = torch.zeros((2, gh, gw), dtype=torch.float32, device=plan.device)
+            theta = self._optimise_patch_grid(plan, init.clone(), patch_size, sliding_window, n_iter)
+            self.patch_flow_per_scale.append(theta)
+        self.patch_flow = theta
+        self.patch_size_used, self.sliding_window_used = patch_size, sliding_window
+        return ops.upsample_patch_flow(theta, patch_size, sliding_window, (H, W))
+
+    def _optimise_patch_grid(self, plan: EventPlan, theta: torch.Tensor, patch_size, sliding_window, n_iter: int) -> torch.Tensor:
+        H, W = self.orig_image_shape
+        theta = theta.requires_grad_(True)
+
+        def evaluate():
+            dense = ops.upsample_patch_flow(theta, patch_size, sliding_window, (H, W))
+            return self.objective(plan, dense)
+
+        if self.opt_method in SCIPY_METHODS:
+            return self._run_scipy(evaluate, theta, n_iter)
+        if self.opt_method != "Adam":
+            raise NotImplementedError(f"optimizer.method {self.opt_method!r}: Adam or one of {SCIPY_METHODS}")
 
         def iteration(opt):
             opt.zero_grad(set_to_none=True)
-            dense = ops.upsample_patch_flow(theta, self.patch_size, self.sliding_window, (H, W))
-            loss = self.objective(plan, dense)
+            loss = evaluate()
             loss.backward()
             opt.step()
             return loss.detach()
 
         self.graphed = False
-        losses = torch.zeros(max(self.n_iter, 1), dtype=torch.float32, device=plan.device)
+        losses = torch.zeros(max(n_iter, 1), dtype=torch.float32, device=plan.device)
         done = 0
-        if self.use_graph and self.n_iter > 4:
-            done = self._run_graphed(iteration, theta, losses)
+        if self.use_graph and n_iter > 4:
+            done = self._run_graphed(iteration, theta, losses, n_iter)
         if not self.graphed:
             opt = torch.optim.Adam([theta], lr=self.lr)
-            for it in range(done, self.n_iter):
+            for it in range(done, n_iter):
                 losses[it] = iteration(opt)
-        self.history = [float(v) for v in losses[:self.n_iter].cpu()]
-        self.patch_flow = theta.detach()
-        return ops.upsample_patch_flow(theta.detach(), self.patch_size, self.sliding_window, (H, W))
+        self.history += [float(v) for v in losses[:n_iter].cpu()]
+        return theta.detach()
 
-    def _run_graphed(self, iteration, theta: torch.Tensor, losses: torch.Tensor) -> int:
+    def _run_scipy(self, evaluate, theta: torch.Tensor, n_iter: int) -> torch.Tensor:
+        """Gradient-based scipy optimisers on the GPU objective, the role of the reference's
+        ``scipy_autograd.minimize`` (src/solver/scipy_autograd/scipy_minimize.py:6-125): scipy drives float64 numpy
+        parameters on the host; every function/gradient evaluation is one fused forward + backward on the device.
+        Line searches need a differentiable start: with integer sensor coordinates the all-zero flow sits on the kink
+        of the bilinear vote (every event exactly on a pixel centre), so warm-start these methods
+        (``set_previous_frame_best_estimation``) or use Adam, which does not care."""
+        import scipy.optimize as sopt
+
+        shape = tuple(theta.shape)
+
+        def fun(x):
+            with torch.no_grad():
+                theta.copy_(torch.from_numpy(x.reshape(shape)).to(theta))
+            theta.grad = None
+            loss = evaluate()
+            loss.backward()
+            self.history.append(float(loss.detach()))
+            return self.history[-1], theta.grad.detach().double().cpu().numpy().reshape(-1)
+
+        x0 = theta.detach().double().cpu().numpy().reshape(-1)
+        res = sopt.minimize(fun, x0, jac=True, method=self.opt_method, options={"maxiter": int(n_iter), **self.scipy_options})
+        if not res.success:
+            logger.warning(f"Unsuccessful optimization step! ({res.message})")
+        self.scipy_result = res
+        return torch.from_numpy(res.x.reshape(shape)).to(theta).detach()
+
+    def _run_graphed(self, iteration, theta: torch.Tensor, losses: torch.Tensor, n_iter: int) -> int:
         """Adam loop as a replayed HIP graph.  The first iterations run eagerly on a side stream (they also create
         the plan workspace and Adam state), one iteration is captured, the rest are replays.  Returns the number of
         iterations performed; falls back to the eager loop (self.graphed = False) if capture is not possible."""
@@ -164,11 +234,11 @@ class ContrastMaximization(SolverBase):
             with torch.cuda.graph(graph):
                 static_loss = iteration(opt)
             losses[warm] = static_loss  # the capture itself does not execute: replay it for iteration `warm`
-            for it in range(warm, self.n_iter):
+            for it in range(warm, n_iter):
                 graph.replay()
                 losses[it] = static_loss
             self.graphed = True
-            return self.n_iter
+            return n_iter
         except Exception as err:  # capture unsupported for some op: restart the whole loop eagerly
             logger.warning(f"HIP graph capture of the solver iteration failed ({err!r}); running eagerly")
             with torch.no_grad():
