@@ -26,7 +26,7 @@ class HipUnavailableError(RuntimeError):
     """The HIP extension (or a GPU to run it on) is missing.  Nothing falls back to the CPU."""
 
 
-_P, _I, _L, _D, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+_P, _I, _L, _D, _Z, _F = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t, C.c_float
 
 # name -> (restype, argtypes).  Mirrors include/ebos_hip.h one to one (tests/test_abi.py checks it).
 _WARP = [_P, _P, _P, _I, _D, _I, _L, _L, _I, _I, _I, _P, _P, _P]
@@ -77,7 +77,7 @@ SIGNATURES = {
     "ebos_iwe_dense_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
     "ebos_iwe_2dof_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
     "ebos_iwe_2dof_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
-    "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "ebos_iwe_2dof_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_2dof_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "ebos_cost_scratch_bytes": (_Z, [_I]),
@@ -91,12 +91,31 @@ SIGNATURES = {
     "ebos_gradient_magnitude_grad_f32": (_I, _GM_GRAD),
     "ebos_gradient_magnitude_grad_f64": (_I, _GM_GRAD),
     "ebos_upsample_patch_flow_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "ebos_upsample_patch_flow_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "ebos_upsample_bwd_scratch_bytes": (_Z, [_I, _I]),
+    "ebos_upsample_patch_flow_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "ebos_flow_regularisers_partials": (_I, []),
+    "ebos_flow_regularisers_f32": (_I, [_P, _I, _I, _F, _F, _P, _P, _P]),
+    "ebos_cmax_adam_step_f32": (_I, [_P, _P, _P, _P, _I, _D, _D, _D, _D, _P, _P, _F, _P, _I, _P, _I, _P]),
+    "ebos_cmax_patch_solve_f32": (_I, [_P, _I, _P]),
     "ebos_gauss1d_f32": (_I, _GAUSS),
     "ebos_gauss1d_f64": (_I, _GAUSS),
     "ebos_gauss1d_bwd_f32": (_I, _GAUSS),
     "ebos_gauss1d_bwd_f64": (_I, _GAUSS),
 }
+
+
+
+class CmaxPatchProblem(C.Structure):
+    """``ebos_cmax_patch_problem`` of include/ebos_hip.h (same field order)."""
+    _fields_ = ([(k, _P) for k in ("xs", "ys", "dts", "grp_offsets", "cpix", "cdt", "key_offsets")] + [("n", _L)] +
+                [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "pad_h", "pad_w", "omit_boundary",
+                                   "gh", "gw", "patch_h", "patch_w", "slide_h", "slide_w")] +
+                [(k, _F) for k in ("w_variance", "w_flow_norm", "w_image_gradient")] +
+                [(k, _D) for k in ("lr", "beta1", "beta2", "eps")] +
+                [(k, _P) for k in ("theta", "d_theta", "exp_avg", "exp_avg_sq", "step", "dense", "d_dense", "d_reg", "iwe",
+                                   "variance", "moments", "upstream", "reg_partials", "upsample_scratch", "workspace")] +
+                [("workspace_bytes", _Z), ("losses", _P), ("losses_cap", _I)])
+
 
 _lib: Optional[C.CDLL] = None
 

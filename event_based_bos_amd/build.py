@@ -23,7 +23,7 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libebos_hip.so")
 
 SOURCES = ["errors.cpp", "warp_kernels.hip", "splat_kernels.hip", "event_plan.hip", "iwe_fused.hip", "iwe_tiled.hip",
-           "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip"]
+           "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip", "solver_kernels.hip"]
 
 # -munsafe-fp-atomics: hardware global_atomic_add_f32/f64 and ds_add_f32 instead of CAS loops.
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC",

@@ -54,51 +54,86 @@ __device__ __forceinline__ Lerp lerp_at(const Axis& a, int r) {
   return l;
 }
 
+// forward: one thread = 4 consecutive columns of one row (one 16-byte store); the row's vertical lerp is uniform
+// per workgroup row, the grid (a few KB) is read through L1.
+template <bool VEC4>
 __global__ void __launch_bounds__(256)
 upsample_kernel(const float* __restrict__ grid, Axis ay, Axis ax, int H, int W, float* __restrict__ dense) {
-  const int ch = blockIdx.y;
+  const int ch = blockIdx.z, r = blockIdx.y;
+  const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c0 >= W) return;
   const float* g = grid + (int64_t)ch * ay.g * ax.g;
-  float* out = dense + (int64_t)ch * H * W;
-  const int64_t hw = (int64_t)H * W;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / W), c = (int)(i % W);
-    const Lerp ly = lerp_at(ay, r), lx = lerp_at(ax, c);
-    const float top = lx.w0 * g[ly.i0 * ax.g + lx.i0] + lx.w1 * g[ly.i0 * ax.g + lx.i1];
-    const float bot = lx.w0 * g[ly.i1 * ax.g + lx.i0] + lx.w1 * g[ly.i1 * ax.g + lx.i1];
-    out[i] = ly.w0 * top + ly.w1 * bot;
+  float* out = dense + (int64_t)ch * H * W + (int64_t)r * W + c0;
+  const Lerp ly = lerp_at(ay, r);
+  const float* g0 = g + ly.i0 * ax.g;
+  const float* g1 = g + ly.i1 * ax.g;
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const Lerp lx = lerp_at(ax, c0 + k < W ? c0 + k : W - 1);
+    const float top = lx.w0 * g0[lx.i0] + lx.w1 * g0[lx.i1];
+    const float bot = lx.w0 * g1[lx.i0] + lx.w1 * g1[lx.i1];
+    v[k] = ly.w0 * top + ly.w1 * bot;
+  }
+  if (VEC4) {
+    *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c0 + k < W) out[k] = v[k];
   }
 }
 
-// adjoint: one workgroup per grid cell gathers every dense pixel whose 2x2 footprint touches it
-// (the weights are separable: w(r, i) * w(c, j)), reduces in registers/LDS, one plain add.
+// adjoint, separable (the bilinear weight of pixel (r, c) on cell (i, j) is wy(r, i) * wx(c, j)):
+//   pass 1  S[ch, i, c]      = sum_r wy(r, i) * d_dense[ch, r, c]     coalesced row reads
+//   pass 2  d_grid[ch, i, j] = sum_c wx(c, j) * S[ch, i, c]
+// Rows/columns outside a cell's conservative support are skipped; every pixel is read twice (cells i and i + 1).
+__device__ __forceinline__ void support(const Axis& a, int gi, int n_out, int* lo, int* hi) {
+  // padded indices that clamp onto this cell, +-1 cell of bilinear support, in output pixels
+  const int p_lo = gi == 0 ? 0 : gi + a.pad, p_hi = gi == a.g - 1 ? a.n_in - 1 : gi + a.pad;
+  int l = (p_lo - 1) * a.slide - a.off - 1, h = (p_hi + 2) * a.slide - a.off + 1;
+  *lo = l < 0 ? 0 : l;
+  *hi = h > n_out ? n_out : h;
+}
+
+__device__ __forceinline__ float weight_on(const Axis& a, int r, int gi) {
+  const Lerp l = lerp_at(a, r);
+  return (l.i0 == gi ? l.w0 : 0.0f) + (l.i1 == gi ? l.w1 : 0.0f);
+}
+
+// pass 1: workgroup = 64 columns x 4 row phases (wave k takes rows r_lo + k, r_lo + k + 4, ...), lane = column
 __global__ void __launch_bounds__(256)
-upsample_bwd_kernel(const float* __restrict__ d_dense, Axis ay, Axis ax, int H, int W, float* d_grid) {
-  const int cell = blockIdx.x, ch = blockIdx.y;
-  const int gi = cell / ax.g, gj = cell % ax.g;
-  const float* dd = d_dense + (int64_t)ch * H * W;
-  // conservative pixel ranges: padded indices that clamp to this cell, +-1 cell of bilinear support
-  const int pi_lo = gi == 0 ? 0 : gi + ay.pad, pi_hi = gi == ay.g - 1 ? ay.n_in - 1 : gi + ay.pad;
-  const int pj_lo = gj == 0 ? 0 : gj + ax.pad, pj_hi = gj == ax.g - 1 ? ax.n_in - 1 : gj + ax.pad;
-  int r_lo = (pi_lo - 1) * ay.slide - ay.off - 1, r_hi = (pi_hi + 2) * ay.slide - ay.off + 1;
-  int c_lo = (pj_lo - 1) * ax.slide - ax.off - 1, c_hi = (pj_hi + 2) * ax.slide - ax.off + 1;
-  r_lo = r_lo < 0 ? 0 : r_lo;
-  c_lo = c_lo < 0 ? 0 : c_lo;
-  r_hi = r_hi > H ? H : r_hi;
-  c_hi = c_hi > W ? W : c_hi;
-  const int nr = r_hi - r_lo, nc = c_hi - c_lo;
+upsample_bwd_rows_kernel(const float* __restrict__ d_dense, Axis ay, int H, int W, float* __restrict__ S) {
+  const int gi = blockIdx.y, ch = blockIdx.z;
+  const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  int r_lo, r_hi;
+  support(ay, gi, H, &r_lo, &r_hi);
   float acc = 0.0f;
-  if (nr > 0 && nc > 0) {
-    for (int i = threadIdx.x; i < nr * nc; i += blockDim.x) {
-      const int r = r_lo + i / nc, c = c_lo + i % nc;
-      const Lerp ly = lerp_at(ay, r), lx = lerp_at(ax, c);
-      const float wy = (ly.i0 == gi ? ly.w0 : 0.0f) + (ly.i1 == gi ? ly.w1 : 0.0f);
-      const float wx = (lx.i0 == gj ? lx.w0 : 0.0f) + (lx.i1 == gj ? lx.w1 : 0.0f);
-      if (wy != 0.0f && wx != 0.0f) acc += wy * wx * dd[(int64_t)r * W + c];
-    }
+  if (c < W) {
+    const float* dd = d_dense + (int64_t)ch * H * W + c;
+#pragma unroll 4
+    for (int r = r_lo + phase; r < r_hi; r += 4) acc += weight_on(ay, r, gi) * dd[(int64_t)r * W];  // weight uniform per wave
   }
-  __shared__ float red[4];
-  acc = block_sum(acc, red);
-  if (threadIdx.x == 0) d_grid[(int64_t)ch * ay.g * ax.g + cell] += acc;
+  __shared__ float part[4][64];
+  part[phase][lane] = acc;
+  __syncthreads();
+  if (phase == 0 && c < W) S[((int64_t)ch * ay.g + gi) * W + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// pass 2: one wavefront per grid cell, lanes stride over the cell's column support
+__global__ void __launch_bounds__(256)
+upsample_bwd_cols_kernel(const float* __restrict__ S, Axis ay, Axis ax, int W, float* __restrict__ d_grid) {
+  const int lane = threadIdx.x & 63;
+  const int gj = blockIdx.x * 4 + (threadIdx.x >> 6), gi = blockIdx.y, ch = blockIdx.z;
+  if (gj >= ax.g) return;
+  int c_lo, c_hi;
+  support(ax, gj, W, &c_lo, &c_hi);
+  const float* s = S + ((int64_t)ch * ay.g + gi) * W;
+  float acc = 0.0f;
+  for (int c = c_lo + lane; c < c_hi; c += 64) acc += weight_on(ax, c, gj) * s[c];
+  acc = wave_sum(acc);
+  if (lane == 0) d_grid[((int64_t)ch * ay.g + gi) * ax.g + gj] = acc;
 }
 
 }  // namespace
@@ -116,22 +151,28 @@ int ebos_upsample_patch_flow_f32(const float* grid, int gh, int gw, int patch_h,
   EBOS_REQUIRE(ay.off >= 0 && ax.off >= 0 && ay.off + H <= ay.n_in * slide_h && ax.off + W <= ax.n_in * slide_w,
                "ebos_upsample_patch_flow: image %dx%d larger than the resized grid %dx%d", H, W, ay.n_in * slide_h,
                ax.n_in * slide_w);
-  dim3 g(stream_grid((int64_t)H * W, 256, 2048), 2);
-  upsample_kernel<<<g, dim3(256), 0, as_stream(stream)>>>(grid, ay, ax, H, W, dense);
+  dim3 g((W + 1023) / 1024, H, 2);
+  if (W % 4 == 0) upsample_kernel<true><<<g, dim3(256), 0, as_stream(stream)>>>(grid, ay, ax, H, W, dense);
+  else upsample_kernel<false><<<g, dim3(256), 0, as_stream(stream)>>>(grid, ay, ax, H, W, dense);
   EBOS_CHECK_LAUNCH("ebos_upsample_patch_flow");
   return EBOS_OK;
 }
 
+size_t ebos_upsample_bwd_scratch_bytes(int gh, int W) {
+  return gh > 0 && W > 0 ? (size_t)2 * gh * W * sizeof(float) : 0;
+}
+
 int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w, int slide_h,
-                                     int slide_w, int H, int W, float* d_grid, ebos_stream_t stream) {
+                                     int slide_w, int H, int W, float* scratch, float* d_grid, ebos_stream_t stream) {
   using namespace ebos;
-  EBOS_REQUIRE(d_dense && d_grid, "ebos_upsample_patch_flow_bwd: NULL d_dense/d_grid");
+  EBOS_REQUIRE(d_dense && d_grid && scratch, "ebos_upsample_patch_flow_bwd: NULL d_dense/d_grid/scratch");
   EBOS_REQUIRE(gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 && slide_h > 0 && slide_w > 0 && H > 0 && W > 0,
                "ebos_upsample_patch_flow_bwd: bad sizes");
   const Axis ay = make_axis(gh, patch_h, slide_h, H), ax = make_axis(gw, patch_w, slide_w, W);
   EBOS_REQUIRE(ay.off >= 0 && ax.off >= 0, "ebos_upsample_patch_flow_bwd: image larger than the resized grid");
-  dim3 g(gh * gw, 2);
-  upsample_bwd_kernel<<<g, dim3(256), 0, as_stream(stream)>>>(d_dense, ay, ax, H, W, d_grid);
+  hipStream_t s = as_stream(stream);
+  upsample_bwd_rows_kernel<<<dim3((W + 63) / 64, gh, 2), dim3(256), 0, s>>>(d_dense, ay, H, W, scratch);
+  upsample_bwd_cols_kernel<<<dim3((gw + 3) / 4, gh, 2), dim3(256), 0, s>>>(scratch, ay, ax, W, d_grid);
   EBOS_CHECK_LAUNCH("ebos_upsample_patch_flow_bwd");
   return EBOS_OK;
 }

@@ -793,7 +793,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
                            int tiles_x, int pad_h, int pad_w, const float* __restrict__ g_image,
                            const float* __restrict__ affine, int g_lo, float* __restrict__ d_flow,
                            float* __restrict__ d_weight, double* __restrict__ partials,
-                           const double* __restrict__ var_moments, const float* __restrict__ upstream) {
+                           const double* __restrict__ var_moments, const float* __restrict__ upstream,
+                           const float* __restrict__ addend) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
@@ -948,8 +949,10 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     const int rl = i / TW, cl = i - rl * TW;
     const int r = tr0 + rl, c = tc0 + cl;
     if (r < H && c < W) {
-      d_flow[(int64_t)r * W + c] = (float)s_d[i];
-      d_flow[hw + (int64_t)r * W + c] = (float)s_d[TH * TW + i];
+      const int64_t o = (int64_t)r * W + c;
+      // addend: gradient of the flow regularisers, summed here instead of in a separate pass over [2, H, W]
+      d_flow[o] = (float)s_d[i] + (addend ? addend[o] : 0.0f);
+      d_flow[hw + o] = (float)s_d[TH * TW + i] + (addend ? addend[hw + o] : 0.0f);
     }
   }
 }
@@ -1068,14 +1071,14 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
 template <int TH, int TW, int HALO>
 int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int pad_h,
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
-                     double* partials, const double* var_moments, const float* upstream, hipStream_t s) {
+                     double* partials, const double* var_moments, const float* upstream, const float* addend, hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert(lds <= 160 * 1024, "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
-             const double*, const float*);
+             const double*, const float*, const float*);
 #define EBOS_PICK(HW)                                                                                      \
   (uniform ? (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_COMPACT, true>                    \
                       : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_XY, true>)                         \
@@ -1086,7 +1089,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
 #undef EBOS_PICK
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
   kb<<<dim3((unsigned)(tiles_y * tiles_x)), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image,
-                                                                    affine, g_lo, d_flow, d_weight, partials, var_moments, upstream);
+                                                                    affine, g_lo, d_flow, d_weight, partials, var_moments, upstream, addend);
   if (uniform) theta_grad_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, tiles_y * tiles_x, d_flow);
   return EBOS_OK;
 }
@@ -1237,7 +1240,7 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
     int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                              \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, thetas + 2 * k, true, H, W, pad_h, pad_w, g_images + k * hw,              \
-                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, nullptr, nullptr, s)
+                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, nullptr, nullptr, nullptr, s)
     EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
     if (rc != EBOS_OK) return rc;
@@ -1252,7 +1255,7 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
                                  int tile_h,
                                  int tile_w, int halo, int pad_h, int pad_w, const float* g_image, const float* affine,
                                  int g_lo, float* d_flow, float* d_weight, const double* var_moments,
-                                 const float* upstream, ebos_stream_t stream) {
+                                 const float* upstream, const float* addend, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(flow && g_image && d_flow && key_offsets, "ebos_iwe_dense_tiled_bwd: NULL flow/g_image/d_flow/key_offsets");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
@@ -1267,7 +1270,7 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, \
-                               nullptr, var_moments, upstream, s)
+                               nullptr, var_moments, upstream, addend, s)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

@@ -1,0 +1,232 @@
+// solver_kernels.hip -- the pieces of one contrast-maximisation iteration that are not the event kernels:
+// the flow regularisers (value + gradient in one pass over the dense flow) and the Adam update of the patch grid.
+//
+// Why these exist: a solver iteration on a 2 M-event window is ~70 us of event-kernel time, but expressed through
+// autograd it is ~35 kernel launches (a dozen for a capturable Adam, ten for `norm(flow, dim=0).mean()` and its
+// backward, scalar glue) and every launch -- even as a HIP-graph node -- costs 3.5-7 us on this stack
+// (profiles/r01g_solver_iteration.txt).  With these two kernels the iteration is 10 launches.
+//
+// reference semantics:
+//   flow_norm       src/costs/flow_norm.py:45-56      mean over pixels of the per-pixel L2 norm of the flow
+//   image_gradient  src/costs/image_gradient.py:60-75 mean(|d flow/d row| + |d flow/d col|), torch.gradient
+//                                                      (central differences, one-sided at the borders), unit weights
+//   Adam            torch.optim.Adam (defaults: amsgrad = False, weight_decay = 0), the optimiser of the loop in
+//                   src/solver/generative_max_likelihood.py:306-341
+#include "common.h"
+
+namespace ebos {
+namespace {
+
+constexpr int kRegGrid = 1024;
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// torch.gradient along one axis (spacing 1, edge_order 1) at index i of a line of n samples with stride st
+__device__ __forceinline__ float central(const float* f, int i, int n, int64_t st) {
+  if (i == 0) return f[st] - f[0];
+  if (i == n - 1) return f[(int64_t)(n - 1) * st] - f[(int64_t)(n - 2) * st];
+  return (f[(int64_t)(i + 1) * st] - f[(int64_t)(i - 1) * st]) * 0.5f;
+}
+
+// d/d f[i] of sum_k |central(f, k)|  (f: a line of n >= 2 samples)
+__device__ __forceinline__ float tv_adjoint(const float* f, int i, int n, int64_t st) {
+  float g = 0.0f;
+  if (i >= 1) g += sgn(central(f, i - 1, n, st)) * (i - 1 == 0 ? 1.0f : 0.5f);          // k = i - 1 reads f[i] with +
+  if (i + 1 <= n - 1) g -= sgn(central(f, i + 1, n, st)) * (i + 1 == n - 1 ? 1.0f : 0.5f);  // k = i + 1 reads f[i] with -
+  if (i == 0) g -= sgn(central(f, 0, n, st));
+  if (i == n - 1) g += sgn(central(f, n - 1, n, st));
+  return g;
+}
+
+struct RegGrad {
+  float gu, gv;
+  double val;
+};
+
+__device__ __forceinline__ RegGrad reg_at(const float* __restrict__ flow, int r, int c, int H, int W, int64_t hw, float u, float v,
+                                          float s_norm, float s_tv) {
+  RegGrad o{0.0f, 0.0f, 0.0};
+  if (s_norm != 0.0f) {
+    const float nrm = sqrtf(u * u + v * v);
+    o.val += (double)(s_norm * nrm);
+    if (nrm > 0.0f) {  // torch: the sub-gradient of the norm at 0 is 0
+      const float inv = s_norm / nrm;
+      o.gu += inv * u;
+      o.gv += inv * v;
+    }
+  }
+  if (s_tv != 0.0f) {
+    const float* col_u = flow + c;               // the column through (r, c): stride W
+    const float* col_v = flow + hw + c;
+    const float* row_u = flow + (int64_t)r * W;  // the row through (r, c): stride 1
+    const float* row_v = flow + hw + (int64_t)r * W;
+    o.val += (double)(s_tv * (fabsf(central(col_u, r, H, W)) + fabsf(central(row_u, c, W, 1)) +
+                              fabsf(central(col_v, r, H, W)) + fabsf(central(row_v, c, W, 1))));
+    o.gu += s_tv * (tv_adjoint(col_u, r, H, W) + tv_adjoint(row_u, c, W, 1));
+    o.gv += s_tv * (tv_adjoint(col_v, r, H, W) + tv_adjoint(row_v, c, W, 1));
+  }
+  return o;
+}
+
+// thread = 4 consecutive pixels of one row (16-byte loads / stores when W % 4 == 0); workgroups stride over the
+// (row, column-block) work items; one f64 partial per workgroup.
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+flow_regularisers_kernel(const float* __restrict__ flow, int H, int W, float w_norm, float w_tv, float* __restrict__ d_flow,
+                         double* __restrict__ partials) {
+  const int64_t hw = (int64_t)H * W;
+  const float s_norm = w_norm / (float)hw, s_tv = w_tv / (float)(2 * hw);
+  const int col_blocks = (W + 1023) / 1024;
+  double acc = 0.0;
+  for (int item = blockIdx.x; item < H * col_blocks; item += gridDim.x) {
+    const int r = item / col_blocks, c0 = ((item - r * col_blocks) * 256 + threadIdx.x) * 4;
+    if (c0 >= W) continue;
+    const int64_t o = (int64_t)r * W + c0;
+    float u[4], v[4], gu[4], gv[4];
+    if (VEC4) {
+      const float4 u4 = *reinterpret_cast<const float4*>(flow + o), v4 = *reinterpret_cast<const float4*>(flow + hw + o);
+      u[0] = u4.x, u[1] = u4.y, u[2] = u4.z, u[3] = u4.w;
+      v[0] = v4.x, v[1] = v4.y, v[2] = v4.z, v[3] = v4.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u[k] = c0 + k < W ? flow[o + k] : 0.0f;
+        v[k] = c0 + k < W ? flow[hw + o + k] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gu[k] = gv[k] = 0.0f;
+      if (c0 + k < W) {
+        const RegGrad g = reg_at(flow, r, c0 + k, H, W, hw, u[k], v[k], s_norm, s_tv);
+        gu[k] = g.gu, gv[k] = g.gv;
+        acc += g.val;
+      }
+    }
+    if (VEC4) {
+      *reinterpret_cast<float4*>(d_flow + o) = make_float4(gu[0], gu[1], gu[2], gu[3]);
+      *reinterpret_cast<float4*>(d_flow + hw + o) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c0 + k < W) {
+          d_flow[o + k] = gu[k];
+          d_flow[hw + o + k] = gv[k];
+        }
+    }
+  }
+  __shared__ double red[256 / kWave];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// One workgroup.  loss[t] = contrast_scale * contrast + sum(reg_partials) is recorded for the parameters BEFORE the
+// update (what the torch loop records), then Adam advances theta and the step counter.
+__global__ void __launch_bounds__(1024)
+cmax_adam_step_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                      int n, double lr, double beta1, double beta2, double eps, int* __restrict__ step,
+                      const float* __restrict__ contrast, float contrast_scale, const double* __restrict__ reg_partials,
+                      int n_reg, float* __restrict__ losses, int losses_cap) {
+  const int t = step[0] + 1;
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const float b2 = (float)beta2, w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2), e = (float)eps;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float g = grad[i];
+    const float mi = m[i] + w1 * (g - m[i]);        // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + w2 * (g * g);      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + e;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    theta[i] = theta[i] - step_size * (mi / denom); // param.addcdiv_(exp_avg, denom, value = -step_size)
+  }
+  double reg = 0.0;
+  for (int i = threadIdx.x; i < n_reg; i += blockDim.x) reg += reg_partials[i];
+  __shared__ double red[1024 / kWave];
+  reg = block_sum(reg, red);
+  __syncthreads();  // every thread has read step[0]
+  if (threadIdx.x == 0) {
+    if (losses != nullptr && t - 1 < losses_cap)
+      losses[t - 1] = (float)((double)contrast_scale * (double)(contrast ? contrast[0] : 0.0f) + reg);
+    step[0] = t;
+  }
+}
+
+}  // namespace
+}  // namespace ebos
+
+extern "C" {
+
+int ebos_flow_regularisers_partials(void) { return ebos::kRegGrid; }
+
+int ebos_flow_regularisers_f32(const float* flow, int H, int W, float w_flow_norm, float w_image_gradient, float* d_flow,
+                               double* partials, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(flow && d_flow && partials && flow != d_flow, "ebos_flow_regularisers: NULL or aliased buffers");
+  EBOS_REQUIRE(H >= 1 && W >= 1, "ebos_flow_regularisers: bad sizes");
+  EBOS_REQUIRE(w_image_gradient == 0.0f || (H >= 2 && W >= 2),
+               "ebos_flow_regularisers: image_gradient needs at least 2 samples per axis (torch.gradient)");
+  if (W % 4 == 0)
+    flow_regularisers_kernel<true><<<dim3(kRegGrid), dim3(256), 0, as_stream(stream)>>>(flow, H, W, w_flow_norm, w_image_gradient,
+                                                                                       d_flow, partials);
+  else
+    flow_regularisers_kernel<false><<<dim3(kRegGrid), dim3(256), 0, as_stream(stream)>>>(flow, H, W, w_flow_norm,
+                                                                                        w_image_gradient, d_flow, partials);
+  EBOS_CHECK_LAUNCH("ebos_flow_regularisers");
+  return EBOS_OK;
+}
+
+int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int n, double lr,
+                            double beta1, double beta2, double eps, int* step, const float* contrast,
+                            float contrast_scale, const double* reg_partials, int n_reg, float* losses, int losses_cap,
+                            ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(theta && grad && exp_avg && exp_avg_sq && step, "ebos_cmax_adam_step: NULL buffer");
+  EBOS_REQUIRE(n >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
+               "ebos_cmax_adam_step: bad hyper-parameters");
+  EBOS_REQUIRE(n_reg >= 0 && (n_reg == 0 || reg_partials) && losses_cap >= 0, "ebos_cmax_adam_step: bad loss bookkeeping");
+  cmax_adam_step_kernel<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(theta, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                                                                      eps, step, contrast, contrast_scale, reg_partials,
+                                                                      n_reg, losses, losses_cap);
+  EBOS_CHECK_LAUNCH("ebos_cmax_adam_step");
+  return EBOS_OK;
+}
+
+int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* q, int n_iter, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(q != nullptr && n_iter >= 0, "ebos_cmax_patch_solve: NULL problem or negative n_iter");
+  EBOS_REQUIRE(q->theta && q->d_theta && q->exp_avg && q->exp_avg_sq && q->step && q->dense && q->d_dense && q->iwe &&
+                   q->variance && q->moments && q->upstream && q->upsample_scratch && q->workspace && q->reg_partials,
+               "ebos_cmax_patch_solve: NULL buffer");
+  const bool has_reg = q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f;
+  EBOS_REQUIRE(!has_reg || q->d_reg, "ebos_cmax_patch_solve: regulariser weights given but d_reg is NULL");
+  const int n_reg = has_reg ? kRegGrid : 0;
+  for (int it = 0; it < n_iter; ++it) {
+    int rc = ebos_upsample_patch_flow_f32(q->theta, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
+                                          q->dense, stream);
+    if (rc) return rc;
+    rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
+                                 q->H, q->W, q->tile_h, q->tile_w, q->halo, 1, q->pad_h, q->pad_w, q->workspace,
+                                 q->workspace_bytes, q->iwe, 1, q->omit_boundary, q->variance, q->moments, stream);
+    if (rc) return rc;
+    if (has_reg) {
+      rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials, stream);
+      if (rc) return rc;
+    }
+    rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
+                                      q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w, q->iwe, nullptr,
+                                      q->omit_boundary ? 1 : 0, q->d_dense, nullptr, q->moments, q->upstream,
+                                      has_reg ? q->d_reg : nullptr, stream);
+    if (rc) return rc;
+    rc = ebos_upsample_patch_flow_bwd_f32(q->d_dense, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
+                                          q->upsample_scratch, q->d_theta, stream);
+    if (rc) return rc;
+    rc = ebos_cmax_adam_step_f32(q->theta, q->d_theta, q->exp_avg, q->exp_avg_sq, 2 * q->gh * q->gw, q->lr, q->beta1, q->beta2,
+                                 q->eps, q->step, q->variance, -q->w_variance, q->reg_partials, n_reg, q->losses, q->losses_cap,
+                                 stream);
+    if (rc) return rc;
+  }
+  return EBOS_OK;
+}
+
+}  // extern "C"

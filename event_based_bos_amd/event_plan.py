@@ -356,7 +356,7 @@ def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_d
             check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), *plan._compact_ptrs(),
                                                    ptr(plan.key_offsets), plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), pad[0],
                                                    pad[1], ptr(g_image), ptr(affine), g_lo, ptr(d_flow), ptr(d_w),
-                                                   ptr(var_moments), ptr(upstream), stream_ptr()), "ebos_iwe_dense_tiled_bwd")
+                                                   ptr(var_moments), ptr(upstream), None, stream_ptr()), "ebos_iwe_dense_tiled_bwd")
         return d_flow, d_w
     if var_moments is not None:  # general kernels take the affine form
         affine = torch.empty(2, dtype=torch.float32, device=plan.device)

@@ -324,10 +324,11 @@ class _UpsamplePatchFlow(torch.autograd.Function):
         lib = _hip.require_gpu()
         gh, gw, patch, slide, H, W = ctx.meta
         g = _cuda_contig(g.float(), "grad")
-        d = torch.zeros((2, gh, gw), dtype=torch.float32, device=g.device)
+        d = torch.empty((2, gh, gw), dtype=torch.float32, device=g.device)
+        scratch = torch.empty(int(lib.ebos_upsample_bwd_scratch_bytes(gh, W)) // 4, dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(g), gh, gw, patch[0], patch[1], slide[0], slide[1], H, W,
-                                                       ptr(d), stream_ptr()), "ebos_upsample_patch_flow_bwd")
+                                                       ptr(scratch), ptr(d), stream_ptr()), "ebos_upsample_patch_flow_bwd")
         return d, None, None, None
 
 

@@ -26,6 +26,7 @@ from .. import costs, ops
 from .._staging import to_gpu
 from ..event_image_converter import EventImageConverter
 from ..event_plan import EventPlan
+from . import fused_loop
 from .base import SolverBase
 
 logger = logging.getLogger(__name__)
@@ -77,12 +78,17 @@ class ContrastMaximization(SolverBase):
         self.param_ranges = cfg.get("parameters") or {}
         self.halo = int(cfg.get("halo", 32))
         # optimizer.graph: capture one whole iteration (upsample -> fused objective -> backward -> Adam update) into a
-        # HIP graph and replay it.  Measured on MI355X / ROCm 7.2 (tools/bench_solver.py, 10 M events): replay costs
-        # <= 0.2 ms per iteration against ~0.6 ms for the eager loop (interpreter + autograd overhead around ~0.1 ms
-        # of GPU work), but capture + instantiation cost 0.7-1.1 s once -- it pays only beyond ~2000 iterations of
-        # one window, so it is off by default (hot_plate1.yaml runs 600).
-        self.use_graph = bool(ocfg.get("graph", False))
+        # HIP graph and replay it.  Measured on MI355X / ROCm 7.2 (tools/bench_solver.py, 2 M events at 1280x720):
+        # 0.195 ms per replayed iteration against 0.68 ms for the eager loop (interpreter + autograd overhead around
+        # ~0.1 ms of GPU work); capture + instantiation cost 1-8 ms, i.e. ~10 iterations -- on by default, and any
+        # capture failure falls back to the eager loop.
+        self.use_graph = bool(ocfg.get("graph", True))
         self.graphed = False
+        # optimizer.fused (default on): objectives of the family -w var(IWE) + w_n flow_norm + w_g image_gradient run as
+        # a fixed pipeline of HIP kernels (solver/fused_loop.py) instead of through autograd
+        self.fused_loop = bool(ocfg.get("fused", True))
+        self.graph_fused = bool(ocfg.get("graph_fused", False))  # graph replay of the fixed pipeline: slower than launches
+        self.fused = False
         self.history: List[float] = []
 
     # ------------------------------------------------------------------ objective pieces
@@ -164,6 +170,16 @@ class ContrastMaximization(SolverBase):
             dense = ops.upsample_patch_flow(theta, patch_size, sliding_window, (H, W))
             return self.objective(plan, dense)
 
+        if self.fused_loop and fused_loop.supported(self.contrast_terms, self.flow_terms, self.blur_sigma, self.opt_method,
+                                                    plan, self.halo):
+            loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms["image_variance"],
+                                             self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
+                                             self.omit_boundary, self.pad, self.halo, self.lr, capacity=n_iter)
+            losses = loop.run(n_iter, graph=self.graph_fused)
+            self.graphed, self.fused = loop.graphed, True
+            self.history += [float(v) for v in losses.cpu()]
+            return loop.theta
+        self.fused = False
         if self.opt_method in SCIPY_METHODS:
             return self._run_scipy(evaluate, theta, n_iter)
         if self.opt_method != "Adam":
@@ -231,10 +247,16 @@ class ContrastMaximization(SolverBase):
             torch.cuda.current_stream(theta.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                static_loss = iteration(opt)
-            losses[warm] = static_loss  # the capture itself does not execute: replay it for iteration `warm`
-            for it in range(warm, n_iter):
+            # capture_begin/capture_end directly: the torch.cuda.graph() context adds gc.collect() + empty_cache()
+            side.wait_stream(torch.cuda.current_stream(theta.device))
+            with torch.cuda.stream(side):
+                graph.capture_begin()
+                try:
+                    static_loss = iteration(opt)
+                finally:
+                    graph.capture_end()
+            torch.cuda.current_stream(theta.device).wait_stream(side)
+            for it in range(warm, n_iter):  # the capture itself executed nothing: iteration `warm` is the first replay
                 graph.replay()
                 losses[it] = static_loss
             self.graphed = True

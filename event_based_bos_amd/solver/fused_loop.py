@@ -1,0 +1,153 @@
+"""The Adam loop of the patch-flow contrast maximisation as a fixed pipeline of HIP kernels (no autograd graph).
+
+One iteration of the loop in src/solver/generative_max_likelihood.py:306-341 (zero_grad -> objective -> backward ->
+optimizer.step) for the objective  ``-w * var(IWE(dense(theta))) + w_n * flow_norm(dense) + w_g * image_gradient(dense)``
+is six C-ABI calls / ten kernels on one stream, all on buffers allocated once per window:
+
+    ebos_upsample_patch_flow_f32      theta [2, gh, gw] -> dense [2, H, W]
+    ebos_iwe_dense_slab_f32           dense -> IWE, variance, (mean, M)          (3 kernels)
+    ebos_flow_regularisers_f32        dense -> regulariser value partials + gradient image
+    ebos_iwe_dense_tiled_bwd_f32      -> d loss / d dense  (variance gradient folded in, regulariser gradient added)
+    ebos_upsample_patch_flow_bwd_f32  -> d loss / d theta                        (2 kernels)
+    ebos_cmax_adam_step_f32           loss[it] recorded, theta / exp_avg / exp_avg_sq / step updated
+
+Expressed through autograd the same iteration is ~35 launches (capturable Adam alone is a dozen) and runs at ~235 us
+even as a replayed HIP graph; this pipeline is bounded by its event kernels.  Anything outside this objective family
+(other costs, blurred IWE, scipy optimisers) takes the general autograd path of ``ContrastMaximization``.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .. import _hip
+from .._hip import check, ptr, stream_ptr
+from ..event_plan import EventPlan, _slab_ok, _workspace
+
+FLOW_TERMS = ("flow_norm", "image_gradient")
+
+
+def supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], blur_sigma: float, method: str,
+              plan: EventPlan, halo) -> bool:
+    return (set(contrast_terms) == {"image_variance"} and set(flow_terms) <= set(FLOW_TERMS) and not blur_sigma
+            and method == "Adam" and halo is not None and _slab_ok(plan, halo))
+
+
+class FusedPatchLoop(object):
+    def __init__(self, plan: EventPlan, patch_size: Tuple[int, int], sliding_window: Tuple[int, int], theta0: torch.Tensor,
+                 w_variance: float, w_flow_norm: float = 0.0, w_image_gradient: float = 0.0, omit_boundary: bool = False,
+                 pad: int = 0, halo: int = 32, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, capacity: int = 1024):
+        self.lib = _hip.require_gpu()
+        self.plan, self.patch, self.slide = plan, tuple(int(v) for v in patch_size), tuple(int(v) for v in sliding_window)
+        self.w_var, self.w_norm, self.w_tv = float(w_variance), float(w_flow_norm), float(w_image_gradient)
+        self.omit, self.pad, self.halo = bool(omit_boundary), (int(pad), int(pad)), int(halo)
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        dev = plan.device
+        H, W = plan.image_size
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.theta = theta0.detach().to(**f32).contiguous().clone()
+        _, self.gh, self.gw = self.theta.shape
+        self.d_theta = torch.empty_like(self.theta)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.theta), torch.zeros_like(self.theta)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dense, self.d_dense = torch.empty((2, H, W), **f32), torch.empty((2, H, W), **f32)
+        self.has_reg = self.w_norm != 0.0 or self.w_tv != 0.0
+        self.n_reg = int(self.lib.ebos_flow_regularisers_partials()) if self.has_reg else 0
+        self.d_reg = torch.empty((2, H, W), **f32) if self.has_reg else None
+        self.reg_partials = torch.zeros(max(self.n_reg, 1), dtype=torch.float64, device=dev)
+        self.iwe = torch.empty((H + 2 * self.pad[0], W + 2 * self.pad[1]), **f32)
+        self.variance = torch.empty(1, **f32)
+        self.moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
+        self.upstream = torch.full((1,), -self.w_var, **f32)  # loss = -w * variance
+        self.losses = torch.zeros(max(int(capacity), 1), **f32)
+        self.scratch_up = torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32)
+        self.ws = _workspace(plan, self.pad, self.halo, 1)
+        self.graphed = False
+
+    def iteration(self) -> None:
+        lib, plan, s = self.lib, self.plan, stream_ptr()
+        H, W = plan.image_size
+        gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
+        check(lib.ebos_upsample_patch_flow_f32(ptr(self.theta), gh, gw, ph, pw, sh, sw, H, W, ptr(self.dense), s),
+              "ebos_upsample_patch_flow")
+        check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
+                                          ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
+                                          self.halo, 1, self.pad[0], self.pad[1], ptr(self.ws), self.ws.numel(), ptr(self.iwe),
+                                          1, int(self.omit), ptr(self.variance), ptr(self.moments), s), "ebos_iwe_dense_slab")
+        if self.has_reg:
+            check(lib.ebos_flow_regularisers_f32(ptr(self.dense), H, W, self.w_norm, self.w_tv, ptr(self.d_reg),
+                                                 ptr(self.reg_partials), s), "ebos_flow_regularisers")
+        check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
+                                               ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
+                                               self.halo, self.pad[0], self.pad[1], ptr(self.iwe), None, int(self.omit),
+                                               ptr(self.d_dense), None, ptr(self.moments), ptr(self.upstream), ptr(self.d_reg), s),
+              "ebos_iwe_dense_tiled_bwd")
+        check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
+                                                   ptr(self.d_theta), s), "ebos_upsample_patch_flow_bwd")
+        check(lib.ebos_cmax_adam_step_f32(ptr(self.theta), ptr(self.d_theta), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                          self.theta.numel(), self.lr, self.betas[0], self.betas[1], self.eps, ptr(self.step),
+                                          ptr(self.variance), -self.w_var, ptr(self.reg_partials), self.n_reg, ptr(self.losses),
+                                          self.losses.numel(), s), "ebos_cmax_adam_step")
+
+    def problem(self) -> "_hip.CmaxPatchProblem":
+        """The loop's buffers as the ``ebos_cmax_patch_problem`` struct of the C ABI."""
+        plan = self.plan
+        H, W = plan.image_size
+        gp, cp, cd = plan._compact_ptrs()
+        q = _hip.CmaxPatchProblem()
+        q.xs, q.ys, q.dts, q.grp_offsets, q.cpix, q.cdt = ptr(plan.x), ptr(plan.y), ptr(plan.dt), gp, cp, cd
+        q.key_offsets, q.n = ptr(plan.key_offsets), plan.n
+        q.H, q.W, q.tile_h, q.tile_w, q.halo = H, W, plan.tile[0], plan.tile[1], self.halo
+        q.pad_h, q.pad_w, q.omit_boundary = self.pad[0], self.pad[1], int(self.omit)
+        q.gh, q.gw, (q.patch_h, q.patch_w), (q.slide_h, q.slide_w) = self.gh, self.gw, self.patch, self.slide
+        q.w_variance, q.w_flow_norm, q.w_image_gradient = self.w_var, self.w_norm, self.w_tv
+        q.lr, q.beta1, q.beta2, q.eps = self.lr, self.betas[0], self.betas[1], self.eps
+        q.theta, q.d_theta, q.exp_avg, q.exp_avg_sq = ptr(self.theta), ptr(self.d_theta), ptr(self.exp_avg), ptr(self.exp_avg_sq)
+        q.step, q.dense, q.d_dense, q.d_reg = ptr(self.step), ptr(self.dense), ptr(self.d_dense), ptr(self.d_reg)
+        q.iwe, q.variance, q.moments, q.upstream = ptr(self.iwe), ptr(self.variance), ptr(self.moments), ptr(self.upstream)
+        q.reg_partials, q.upsample_scratch = ptr(self.reg_partials), ptr(self.scratch_up)
+        q.workspace, q.workspace_bytes = ptr(self.ws), self.ws.numel()
+        q.losses, q.losses_cap = ptr(self.losses), self.losses.numel()
+        return q
+
+    def run(self, n_iter: int, graph: bool = False, native: bool = True) -> torch.Tensor:
+        """``n_iter`` iterations; returns their losses [n_iter] (device).
+        ``native`` (default): one C call enqueues the whole loop (ebos_cmax_patch_solve_f32).  ``graph``: replay one
+        captured iteration instead -- measured SLOWER than plain launches on ROCm 7.2 for this 10-node graph
+        (172 vs 111 us per iteration at 2 M events), kept for comparison."""
+        n_iter = int(n_iter)
+        if n_iter > self.losses.numel():
+            raise ValueError(f"capacity {self.losses.numel()} < n_iter {n_iter}")
+        dev = self.plan.device
+        self.graphed = False
+        done = 0
+        with torch.cuda.device(dev):
+            if native and not graph:
+                import ctypes
+
+                check(self.lib.ebos_cmax_patch_solve_f32(ctypes.byref(self.problem()), n_iter, stream_ptr()),
+                      "ebos_cmax_patch_solve")
+                return self.losses[:n_iter]
+            if graph and n_iter > 8:
+                try:
+                    self.iteration()  # eager once: reserves the kernels' LDS attributes outside the capture
+                    done = 1
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(side):
+                        g.capture_begin()
+                        try:
+                            self.iteration()
+                        finally:
+                            g.capture_end()
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                    for _ in range(done, n_iter):
+                        g.replay()
+                    done, self.graphed = n_iter, True
+                except Exception:  # capture not possible: the eager loop below finishes the job
+                    self.graphed = False
+            for _ in range(done, n_iter):
+                self.iteration()
+        return self.losses[:n_iter]

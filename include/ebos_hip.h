@@ -275,6 +275,8 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  *   var_moments [2] (f64: mean, M of ebos_iwe_dense_slab_f32) + upstream [1] (f32), both nullable together: the
  *   loss is upstream * var(g_image) with g_image = the IWE itself; its gradient 2 (IWE - mean) / (M - 1) is folded
  *   into the kernel (no d_iwe image, no affine launch).
+ *   addend [2, H, W] (nullable): added to the result as it is stored -- the gradient of the flow regularisers
+ *   (ebos_flow_regularisers_f32), so that d_flow is the gradient of the whole objective without another pass.
  * grp_offsets / cpix / cdt (nullable trio): the compact plan of ebos_plan_compact_f32; when given and weight is
  *   NULL, xs/ys/dts are not read (6 B/event instead of 12).  All SoA arrays are read 4 events (16 bytes) per
  *   lane: 16-byte aligned, padded to a multiple of 4 elements.
@@ -294,7 +296,8 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
                                  const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
                                  int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, float* d_flow, float* d_weight,
-                                 const double* var_moments, const float* upstream, ebos_stream_t stream);
+                                 const double* var_moments, const float* upstream, const float* addend,
+                                 ebos_stream_t stream);
 
 /* 2-DoF hypotheses on the tile-private pipeline (BASELINE config 5): thetas [K, 2] (device), x' = x + dt theta
  * (src/warp.py:364-383); iwes [K, h, w] are OVERWRITTEN; out_variance [K] / moments [K, 2] as above.  The K
@@ -368,12 +371,14 @@ int ebos_gradient_magnitude_grad_f64(const double* images, int K, int h, int w, 
  * A16  patch grid -> dense flow  (src/solver/patch_eklt.py:173-204): replicate-pad the grid by
  *      pad = int(patch/2 // slide) + 1, bilinear resize (align_corners = False) by the sliding
  *      window, centre-crop to [H, W].  grid [2, gh, gw] -> dense [2, H, W] (overwrites).
- *      bwd: d_grid [2, gh, gw] += adjoint (accumulates).
+ *      bwd: the adjoint, as two separable passes through a [2, gh, W] scratch.
  * ---------------------------------------------------------------------------------------- */
 int ebos_upsample_patch_flow_f32(const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h,
                                  int slide_w, int H, int W, float* dense, ebos_stream_t stream);
+/* adjoint: d_grid [2, gh, gw] is OVERWRITTEN.  scratch: device, ebos_upsample_bwd_scratch_bytes(gh, W). */
+size_t ebos_upsample_bwd_scratch_bytes(int gh, int W);
 int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w,
-                                     int slide_h, int slide_w, int H, int W, float* d_grid,
+                                     int slide_h, int slide_w, int H, int W, float* scratch, float* d_grid,
                                      ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -396,6 +401,68 @@ int ebos_gauss1d_bwd_f32(const float* g_out, float* g_in, int64_t outer, int64_t
                          const double* taps, int radius, int boundary, ebos_stream_t stream);
 int ebos_gauss1d_bwd_f64(const double* g_out, double* g_in, int64_t outer, int64_t L, int64_t inner,
                          const double* taps, int radius, int boundary, ebos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One contrast-maximisation iteration without autograd glue.  The loop of
+ * src/solver/generative_max_likelihood.py:306-341 (zero_grad -> objective -> backward -> Adam step)
+ * becomes 6 calls / 10 kernels on one stream:
+ *     ebos_upsample_patch_flow_f32 -> ebos_iwe_dense_slab_f32 (want_variance) -> ebos_flow_regularisers_f32
+ *     -> ebos_iwe_dense_tiled_bwd_f32 (var_moments, upstream = -weight, addend = regulariser gradient)
+ *     -> ebos_upsample_patch_flow_bwd_f32 -> ebos_cmax_adam_step_f32
+ *
+ * ebos_flow_regularisers_f32: value and gradient of
+ *       w_flow_norm * mean_px |flow|_2                                   (src/costs/flow_norm.py:45-56)
+ *     + w_image_gradient * mean(|d flow/d row| + |d flow/d col|)         (src/costs/image_gradient.py:60-75,
+ *                                                                         torch.gradient, unit weights)
+ *   flow [2, H, W]; d_flow [2, H, W] is OVERWRITTEN with the gradient; partials: device doubles,
+ *   ebos_flow_regularisers_partials() of them, whose sum is the value (ebos_cmax_adam_step sums them).
+ * ebos_cmax_adam_step_f32: torch.optim.Adam (amsgrad off, no weight decay) on theta[n] given grad[n],
+ *   with state exp_avg[n], exp_avg_sq[n] and a device step counter step[1] (all zero-initialised by the
+ *   caller); records losses[step] = contrast_scale * contrast[0] + sum(reg_partials) for the parameters
+ *   BEFORE the update (contrast / reg_partials / losses nullable) and increments step.  One workgroup.
+ * ---------------------------------------------------------------------------------------- */
+int ebos_flow_regularisers_partials(void);
+int ebos_flow_regularisers_f32(const float* flow, int H, int W, float w_flow_norm, float w_image_gradient,
+                               float* d_flow, double* partials, ebos_stream_t stream);
+int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int n, double lr,
+                            double beta1, double beta2, double eps, int* step, const float* contrast,
+                            float contrast_scale, const double* reg_partials, int n_reg, float* losses,
+                            int losses_cap, ebos_stream_t stream);
+
+/* The whole loop natively: n_iter iterations of the six calls above, enqueued back to back on `stream` by one
+ * C call (no interpreter between launches; asynchronous like everything else).  All buffers are the caller's:
+ *   plan:     xs/ys/dts (nullable when the compact trio is given), grp_offsets/cpix/cdt, key_offsets, n, H, W, tile,
+ *             halo, pad, omit_boundary -- as ebos_iwe_dense_slab_f32 / ebos_iwe_dense_tiled_bwd_f32
+ *   grid:     theta/d_theta/exp_avg/exp_avg_sq [2, gh, gw], step [1] int32, patch and sliding window
+ *   images:   dense/d_dense [2, H, W], d_reg [2, H, W] (nullable iff both regulariser weights are 0),
+ *             iwe [H + 2 pad_h, W + 2 pad_w], variance [1] f32, moments [2] f64, upstream [1] f32 = -w_variance
+ *   scratch:  reg_partials [ebos_flow_regularisers_partials()] f64, upsample_scratch
+ *             (ebos_upsample_bwd_scratch_bytes), workspace (ebos_iwe_slab_workspace_bytes, zero-filled once)
+ *   losses:   [losses_cap] f32, entry `step` written per iteration (nullable)                                  */
+typedef struct ebos_cmax_patch_problem {
+  const float *xs, *ys, *dts;
+  const int32_t* grp_offsets;
+  const uint16_t* cpix;
+  const float* cdt;
+  const int32_t* key_offsets;
+  int64_t n;
+  int H, W, tile_h, tile_w, halo, pad_h, pad_w, omit_boundary;
+  int gh, gw, patch_h, patch_w, slide_h, slide_w;
+  float w_variance, w_flow_norm, w_image_gradient;
+  double lr, beta1, beta2, eps;
+  float *theta, *d_theta, *exp_avg, *exp_avg_sq;
+  int* step;
+  float *dense, *d_dense, *d_reg, *iwe, *variance;
+  double* moments;
+  const float* upstream;
+  double* reg_partials;
+  float* upsample_scratch;
+  void* workspace;
+  size_t workspace_bytes;
+  float* losses;
+  int losses_cap;
+} ebos_cmax_patch_problem;
+int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* problem, int n_iter, ebos_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -602,3 +602,79 @@ def test_blurred_iwe_is_differentiable(ebos):
     cost = ebos.costs.functions["image_variance"](direction="minimize")
     cost.calculate({"iwe": iwe, "omit_boundary": False}).backward()
     assert rel(fg.grad.cpu().numpy(), ft.grad.numpy()) <= 1e-9
+
+
+@pytest.mark.parametrize("shape,w_norm,w_tv", [((24, 32), 0.7, 0.0), ((24, 32), 0.0, 1.3), ((7, 5), 0.4, 0.9),
+                                                ((2, 2), 0.0, 1.0), ((720, 1280), 0.01, 0.5)])
+def test_flow_regularisers_value_and_gradient(ebos, shape, w_norm, w_tv):
+    """ebos_flow_regularisers_f32 (through the C ABI) against torch-CPU autograd of the oracle's flow_norm /
+    image_gradient restatements (fp64).  Value rel < 1e-5; gradient rel-L2 < 1e-5 (f32 kernel; sign() of an exactly
+    zero difference is 0 on both sides: the inputs contain flat runs and exact zeros on purpose)."""
+    from event_based_bos_amd._hip import check, ptr, stream_ptr
+
+    lib = ebos.load_library()
+    h, w = shape
+    rng = np.random.default_rng(8)
+    flow = rng.uniform(-3, 3, (2, h, w)).astype(np.float32)
+    flow[:, : h // 3, : w // 2] = 1.25      # flat patch: zero differences
+    flow[:, -1, -1] = 0.0                    # exact zero vector: norm sub-gradient 0
+    ft = torch.from_numpy(flow.astype(np.float64)).requires_grad_(True)
+    val = w_norm * O.flow_norm(ft) + w_tv * O.image_gradient_tv(ft, torch.ones(h, w, dtype=torch.float64))
+    val.backward()
+    fg = G(flow)
+    d = torch.empty_like(fg)
+    n_part = lib.ebos_flow_regularisers_partials()
+    parts = torch.zeros(n_part, dtype=torch.float64, device=dev())
+    check(lib.ebos_flow_regularisers_f32(ptr(fg), h, w, w_norm, w_tv, ptr(d), ptr(parts), stream_ptr()), "reg")
+    assert abs(parts.sum().item() - val.item()) <= 1e-5 * abs(val.item())
+    assert rel(d.cpu().numpy(), ft.grad.numpy()) < 1e-5
+
+
+def test_adam_step_kernel_matches_torch_adam(ebos):
+    """ebos_cmax_adam_step_f32 against torch.optim.Adam (CPU, f32) over 25 steps with a changing gradient:
+    parameters agree to 1e-6 absolute (same update formula; f32 rounding of the bias corrections differs), the step
+    counter advances and losses[t] = scale * contrast + sum(partials) is recorded."""
+    from event_based_bos_amd._hip import check, ptr, stream_ptr
+
+    lib = ebos.load_library()
+    rng = np.random.default_rng(9)
+    n, steps, lr = 2 * 7 * 9, 25, 0.05
+    x0 = rng.normal(size=n).astype(np.float32)
+    grads = rng.normal(size=(steps, n)).astype(np.float32) * np.linspace(1.0, 0.01, steps, dtype=np.float32)[:, None]
+    ref = torch.from_numpy(x0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=lr)
+    theta, m, v = G(x0.copy()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    losses = torch.zeros(steps, device=dev())
+    contrast = torch.zeros(1, device=dev())
+    parts = torch.zeros(4, dtype=torch.float64, device=dev())
+    for t in range(steps):
+        ref.grad = torch.from_numpy(grads[t].copy())
+        opt.step()
+        contrast.fill_(float(t))
+        parts.fill_(0.25 * t)
+        check(lib.ebos_cmax_adam_step_f32(ptr(theta), ptr(G(grads[t])), ptr(m), ptr(v), n, lr, 0.9, 0.999, 1e-8, ptr(step),
+                                          ptr(contrast), -2.0, ptr(parts), 4, ptr(losses), steps, stream_ptr()), "adam")
+        assert np.abs(theta.cpu().numpy() - ref.detach().numpy()).max() < 1e-6, t
+    assert step.item() == steps
+    np.testing.assert_allclose(losses.cpu().numpy(), [-2.0 * t + t for t in range(steps)], rtol=1e-6)
+
+
+def test_tiled_backward_addend(ebos):
+    """addend [2, H, W] of ebos_iwe_dense_tiled_bwd_f32 is added to d_flow exactly once (bit-exact: one f32 add)."""
+    from event_based_bos_amd import event_plan as EP
+
+    ev = O.synth_events(20000, 64, 96, seed=31)
+    flow = G(O.synth_dense_flow(64, 96, seed=32, max_val=5.0)).float()
+    plan = ebos.EventPlan.build(G(ev), (64, 96), "first", True, tile="auto")
+    iwe, var, mom = EP._launch_iwe_dense_slab(plan, flow, None, (0, 0), 32, 1, True, False)
+    up = torch.full((1,), -1.0, device=dev())
+    base, _ = EP._launch_dense_bwd(plan, flow, None, (0, 0), iwe, None, 0, False, 32, mom, up)
+    addend = torch.randn(2, 64, 96, device=dev())
+    lib = ebos.load_library()
+    out = torch.empty_like(base)
+    EP.check(lib.ebos_iwe_dense_tiled_bwd_f32(EP.ptr(plan.x), EP.ptr(plan.y), EP.ptr(plan.dt), None, *plan._compact_ptrs(),
+                                              EP.ptr(plan.key_offsets), plan.n, EP.ptr(flow), 64, 96, plan.tile[0], plan.tile[1],
+                                              32, 0, 0, EP.ptr(iwe), None, 0, EP.ptr(out), None, EP.ptr(mom), EP.ptr(up),
+                                              EP.ptr(addend), EP.stream_ptr()), "bwd")
+    assert torch.equal(out, base + addend)

@@ -100,6 +100,54 @@ def test_solver_pyramid_and_scipy_optimisers(optimizer, patch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("terms", [{"image_variance": 1.0}, {"image_variance": 2.0, "flow_norm": 0.01, "image_gradient": 0.05}])
+def test_fused_loop_follows_the_autograd_loop(terms):
+    """The fixed kernel pipeline (solver/fused_loop.py) and the autograd loop minimise the same objective with the same
+    Adam: loss histories agree to 1e-4 relative and the patch flows to 2e-3 px over 40 iterations (both f32)."""
+    import event_based_bos_amd as ebos
+
+    h, w = 96, 128
+    ev = moving_points(h, w, 500, 40, np.array([4.0, -2.5]), seed=5)
+    out = {}
+    for fused in (True, False):
+        cfg = load_cfg()["solver"]
+        cfg.update(patch={"size": [24, 32], "sliding_window": [24, 32]}, cost_with_weight=terms,
+                   iwe={"method": "bilinear_vote", "blur_sigma": 0},
+                   optimizer={"method": "Adam", "n_iter": 40, "parameters": {"lr": 0.2}, "graph": True, "fused": fused})
+        s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+        s.estimate(ev)
+        assert s.fused == fused and s.graphed == (not fused)
+        out[fused] = (np.array(s.history), s.patch_flow.cpu().numpy())
+    rel_dev = np.abs(out[True][0] - out[False][0]) / np.abs(out[False][0])
+    print("max relative deviation per iteration", np.round(rel_dev, 6), "flow", np.abs(out[True][1] - out[False][1]).max())
+    assert rel_dev[:10].max() < 1e-4 and rel_dev.max() < 2e-2
+    assert np.abs(out[True][1] - out[False][1]).max() < 0.25
+
+
+@pytest.mark.gpu
+def test_fused_loop_run_modes_agree():
+    """FusedPatchLoop: the native loop (ebos_cmax_patch_solve_f32), the per-call Python loop and the graph replay run
+    the same kernels in the same order: losses agree to 1e-5 relative over 30 iterations."""
+    import torch
+
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w = 96, 128
+    ev = moving_points(h, w, 500, 40, np.array([4.0, -2.5]), seed=6)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto")
+    hist = {}
+    for mode in ("native", "python", "graph"):
+        loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, 4, 4)), 1.0, 0.01, 0.02, lr=0.1, capacity=30)
+        hist[mode] = loop.run(30, graph=mode == "graph", native=mode == "native").cpu().numpy()
+        assert loop.graphed == (mode == "graph") and int(loop.step.item()) == 30
+    np.testing.assert_allclose(hist["python"], hist["native"], rtol=1e-5)
+    np.testing.assert_allclose(hist["graph"], hist["native"], rtol=1e-5)
+    with pytest.raises(ValueError):
+        loop.run(31)
+
+
+@pytest.mark.gpu
 def test_solver_recovers_translation_dense_and_2dof():
     import event_based_bos_amd as ebos
 
@@ -156,8 +204,8 @@ def test_solver_trajectory_matches_cpu_oracle(blur):
         ref.append(loss.item())
     np.testing.assert_allclose(s.history, ref, rtol=2e-3)
     np.testing.assert_allclose(s.patch_flow.cpu().numpy(), theta.detach().numpy(), atol=5e-2)
-    # the HIP-graph replay of the iteration and the eager loop follow the same trajectory
-    assert s.graphed
+    # blur = 0 runs the fixed kernel pipeline (one native call for the loop); blur = 1 the autograd loop, graph-replayed
+    assert s.fused == (blur == 0) and s.graphed == (blur == 1)
     cfg_e = dict(cfg, optimizer=dict(cfg["optimizer"], graph=False))
     s_e = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_e)
     s_e.estimate(ev)

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Profiling target: the fused contrast-maximisation loop (solver/fused_loop.py) on one synthetic window.
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/profile_solver.py --events 2000000"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import H, W, synth_window  # noqa: E402
+
+import event_based_bos_amd as ebos  # noqa: E402
+from event_based_bos_amd.solver.fused_loop import FusedPatchLoop  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--events", type=int, default=2_000_000)
+ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--patch", type=int, nargs=2, default=[24, 32])
+a = ap.parse_args()
+ev, _ = synth_window(a.events, 0)
+plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto")
+gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
+loop = FusedPatchLoop(plan, a.patch, a.patch, torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, lr=0.1, capacity=a.iters)
+loop.run(3)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+loop.step.zero_()
+losses = loop.run(a.iters)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"{a.events} events, {a.iters} iterations: {dt / a.iters * 1e6:.1f} us/iteration; loss {losses[0].item():.5f} -> {losses[-1].item():.5f}")
