@@ -211,3 +211,20 @@ def test_solver_trajectory_matches_cpu_oracle(blur):
     s_e.estimate(ev)
     assert not s_e.graphed
     np.testing.assert_allclose(s.history, s_e.history, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_yaml_driven_run_improves_contrast():
+    """BASELINE configs[0] plumbing: configs/cmax_hot_plate1.yaml (key names of the reference's hot_plate1.yaml) ->
+    solver registry -> preprocess -> estimate, as the reference's driver does (bos_event.py:190-194); the estimated
+    flow must sharpen the un-blurred IWE of the 346x260, 100 k-event synthetic window."""
+    import json
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_cmax.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["image"] == [260, 346] and rep["iterations"] == 200
+    assert rep["loss_last"] < rep["loss_first"]
+    assert rep["variance_warped"] > 1.3 * rep["variance_unwarped"], rep
