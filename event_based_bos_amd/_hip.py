@@ -97,6 +97,7 @@ SIGNATURES = {
     "ebos_flow_regularisers_f32": (_I, [_P, _I, _I, _F, _F, _P, _P, _P]),
     "ebos_cmax_adam_step_f32": (_I, [_P, _P, _P, _P, _I, _D, _D, _D, _D, _P, _P, _F, _P, _I, _P, _I, _P]),
     "ebos_cmax_patch_solve_f32": (_I, [_P, _I, _P]),
+    "ebos_cmax_patch_solve_many_f32": (_I, [_P, _P, _I, _I]),
     "ebos_gauss1d_f32": (_I, _GAUSS),
     "ebos_gauss1d_f64": (_I, _GAUSS),
     "ebos_gauss1d_bwd_f32": (_I, _GAUSS),

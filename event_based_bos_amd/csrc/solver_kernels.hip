@@ -192,40 +192,65 @@ int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, flo
   return EBOS_OK;
 }
 
-int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* q, int n_iter, ebos_stream_t stream) {
+static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
   using namespace ebos;
-  EBOS_REQUIRE(q != nullptr && n_iter >= 0, "ebos_cmax_patch_solve: NULL problem or negative n_iter");
+  EBOS_REQUIRE(q != nullptr, "ebos_cmax_patch_solve: NULL problem");
   EBOS_REQUIRE(q->theta && q->d_theta && q->exp_avg && q->exp_avg_sq && q->step && q->dense && q->d_dense && q->iwe &&
                    q->variance && q->moments && q->upstream && q->upsample_scratch && q->workspace && q->reg_partials,
                "ebos_cmax_patch_solve: NULL buffer");
+  EBOS_REQUIRE((q->w_flow_norm == 0.0f && q->w_image_gradient == 0.0f) || q->d_reg,
+               "ebos_cmax_patch_solve: regulariser weights given but d_reg is NULL");
+  return EBOS_OK;
+}
+
+static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, ebos_stream_t stream) {
+  using namespace ebos;
   const bool has_reg = q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f;
-  EBOS_REQUIRE(!has_reg || q->d_reg, "ebos_cmax_patch_solve: regulariser weights given but d_reg is NULL");
-  const int n_reg = has_reg ? kRegGrid : 0;
-  for (int it = 0; it < n_iter; ++it) {
-    int rc = ebos_upsample_patch_flow_f32(q->theta, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
-                                          q->dense, stream);
-    if (rc) return rc;
-    rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
-                                 q->H, q->W, q->tile_h, q->tile_w, q->halo, 1, q->pad_h, q->pad_w, q->workspace,
-                                 q->workspace_bytes, q->iwe, 1, q->omit_boundary, q->variance, q->moments, stream);
-    if (rc) return rc;
-    if (has_reg) {
-      rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials, stream);
-      if (rc) return rc;
-    }
-    rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
-                                      q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w, q->iwe, nullptr,
-                                      q->omit_boundary ? 1 : 0, q->d_dense, nullptr, q->moments, q->upstream,
-                                      has_reg ? q->d_reg : nullptr, stream);
-    if (rc) return rc;
-    rc = ebos_upsample_patch_flow_bwd_f32(q->d_dense, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
-                                          q->upsample_scratch, q->d_theta, stream);
-    if (rc) return rc;
-    rc = ebos_cmax_adam_step_f32(q->theta, q->d_theta, q->exp_avg, q->exp_avg_sq, 2 * q->gh * q->gw, q->lr, q->beta1, q->beta2,
-                                 q->eps, q->step, q->variance, -q->w_variance, q->reg_partials, n_reg, q->losses, q->losses_cap,
-                                 stream);
+  int rc = ebos_upsample_patch_flow_f32(q->theta, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
+                                        q->dense, stream);
+  if (rc) return rc;
+  rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
+                               q->H, q->W, q->tile_h, q->tile_w, q->halo, 1, q->pad_h, q->pad_w, q->workspace,
+                               q->workspace_bytes, q->iwe, 1, q->omit_boundary, q->variance, q->moments, stream);
+  if (rc) return rc;
+  if (has_reg) {
+    rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials, stream);
     if (rc) return rc;
   }
+  rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
+                                    q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w, q->iwe, nullptr,
+                                    q->omit_boundary ? 1 : 0, q->d_dense, nullptr, q->moments, q->upstream,
+                                    has_reg ? q->d_reg : nullptr, stream);
+  if (rc) return rc;
+  rc = ebos_upsample_patch_flow_bwd_f32(q->d_dense, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
+                                        q->upsample_scratch, q->d_theta, stream);
+  if (rc) return rc;
+  return ebos_cmax_adam_step_f32(q->theta, q->d_theta, q->exp_avg, q->exp_avg_sq, 2 * q->gh * q->gw, q->lr, q->beta1, q->beta2,
+                                 q->eps, q->step, q->variance, -q->w_variance, q->reg_partials, has_reg ? ebos::kRegGrid : 0,
+                                 q->losses, q->losses_cap, stream);
+}
+
+int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* q, int n_iter, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(n_iter >= 0, "ebos_cmax_patch_solve: negative n_iter");
+  if (int rc = cmax_check_problem(q)) return rc;
+  for (int it = 0; it < n_iter; ++it)
+    if (int rc = cmax_enqueue_iteration(q, stream)) return rc;
+  return EBOS_OK;
+}
+
+int ebos_cmax_patch_solve_many_f32(const ebos_cmax_patch_problem* problems, const ebos_stream_t* streams, int n_problems,
+                                   int n_iter) {
+  using namespace ebos;
+  EBOS_REQUIRE(problems && streams && n_problems >= 1 && n_iter >= 0, "ebos_cmax_patch_solve_many: bad arguments");
+  for (int w = 0; w < n_problems; ++w)
+    if (int rc = cmax_check_problem(problems + w)) return rc;
+  // iteration-major: the windows' kernels alternate in the launch order, so that the small kernels of one window
+  // (combine, finalize, regularisers, upsample, Adam) find free wave slots next to the one-workgroup-per-CU event
+  // kernels of another
+  for (int it = 0; it < n_iter; ++it)
+    for (int w = 0; w < n_problems; ++w)
+      if (int rc = cmax_enqueue_iteration(problems + w, streams[w])) return rc;
   return EBOS_OK;
 }
 

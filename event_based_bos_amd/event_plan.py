@@ -135,7 +135,8 @@ class EventPlan:
     @staticmethod
     def build_raw(col: torch.Tensor, row: torch.Tensor, t: torch.Tensor, pol: torch.Tensor, image_size: Tuple[int, int],
                   direction: Union[str, float] = "first", normalize_t: bool = True,
-                  tile: Optional[Tuple[int, int]] = DEFAULT_TILE, ticks_per_second: float = 1e6) -> "EventPlan":
+                  tile: Optional[Tuple[int, int]] = DEFAULT_TILE, ticks_per_second: float = 1e6,
+                  deferred: bool = False) -> "EventPlan":
         """Plan of a window given as raw sensor columns on the GPU -- ``raw_events/{x, y, t, p}`` of the CCS
         recordings: col int16 (sensor x), row int16 (sensor y), t int32/int64 ticks, pol bool/uint8
         (src/data_loader/ccs.py:57-66).  Same plan, bit for bit, as ``build`` on the float64 [n, 4] array the
@@ -171,11 +172,17 @@ class EventPlan:
                                              stream_ptr()), "ebos_raw_events_to_soa")
         plan = EventPlan(x, y, dt, p, (H, W), n, n)
         if tile is not None:
-            plan = plan.bin(tile)
+            plan = plan.bin(tile, deferred=deferred)  # int16 columns: integer coordinates by construction
         return plan
 
-    def bin(self, tile: Tuple[int, int] = DEFAULT_TILE) -> "EventPlan":
-        """Counting-sort the plan by source pixel, tile-major (ebos_bin_events_f32)."""
+    def bin(self, tile: Tuple[int, int] = DEFAULT_TILE, deferred: bool = False) -> "EventPlan":
+        """Counting-sort the plan by source pixel, tile-major (ebos_bin_events_f32).
+
+        ``deferred=True`` skips the one host read-back of the build (how many events lie outside the image / have
+        fractional coordinates), so that a whole window can be planned without the host ever waiting for the GPU
+        (``solver.WindowPipeline``).  Only valid when every source coordinate is an integer -- raw sensor columns are --
+        because the compact plan is then built unconditionally; ``n`` stays an upper bound (out-of-image events are in
+        no tile range and are never read) and ``counts()`` reports the numbers later."""
         lib = _hip.require_gpu()
         H, W = self.image_size
         th, tw = int(tile[0]), int(tile[1])
@@ -195,7 +202,10 @@ class EventPlan:
                                           ptr(xs), ptr(ys), ptr(dts), ptr(ps), ptr(perm), ptr(key_offsets), ptr(counts),
                                           counts.data_ptr() + 4, ptr(scratch), nbytes, stream_ptr()),
                   "ebos_bin_events")
-        dropped, fractional = (int(v) for v in counts.tolist())  # one-off sync at plan-build time
+        if deferred:
+            dropped, fractional = 0, 0
+        else:
+            dropped, fractional = (int(v) for v in counts.tolist())  # one-off sync at plan-build time
         kept = n - dropped
         src_perm = perm[:kept] if self.perm is None else self.perm[perm[:kept].long()]
         grp_offsets = cpix = cdt = None
@@ -209,8 +219,21 @@ class EventPlan:
             with torch.cuda.device(dev):
                 check(lib.ebos_plan_compact_f32(ptr(xs), ptr(ys), ptr(dts), ptr(key_offsets), kept, H, W, th, tw,
                                                 ptr(grp_offsets), ptr(cpix), ptr(cdt), cap, stream_ptr()), "ebos_plan_compact")
-        return EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
-                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt)
+        out = EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
+                        (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt)
+        out.__dict__["_counts"], out.__dict__["_deferred"] = counts, bool(deferred)
+        return out
+
+    def counts(self) -> Tuple[int, int]:
+        """(events outside the image, events with fractional source coordinates) seen by ``bin`` -- a host read-back;
+        a ``deferred`` plan with fractional sources is invalid and raises here."""
+        c = self.__dict__.get("_counts")
+        if c is None:
+            return self.n_dropped, 0
+        dropped, fractional = (int(v) for v in c.tolist())
+        if fractional and self.__dict__.get("_deferred"):
+            raise ValueError(f"{fractional} events have fractional source coordinates: a deferred plan needs integer ones")
+        return dropped, fractional
 
     # ------------------------------------------------------------------------------------------
     def iwe_dense(self, flow: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,

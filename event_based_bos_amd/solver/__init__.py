@@ -2,6 +2,7 @@
 crop_image_shape, calibration_parameter=..., solver_config=..., visualize_module=...)``."""
 from .base import SolverBase
 from .contrast_maximization import ContrastMaximization, patch_grid_shape
+from .window_pipeline import WindowPipeline
 
 collections = {
     "contrast_maximization": ContrastMaximization,

@@ -463,6 +463,10 @@ typedef struct ebos_cmax_patch_problem {
   int losses_cap;
 } ebos_cmax_patch_problem;
 int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* problem, int n_iter, ebos_stream_t stream);
+/* Several independent windows at once (windows are the unit that shards): problem w runs on
+ * streams[w]; launches are enqueued iteration-major so that the windows' kernels interleave on the GPU. */
+int ebos_cmax_patch_solve_many_f32(const ebos_cmax_patch_problem* problems, const ebos_stream_t* streams,
+                                   int n_problems, int n_iter);
 
 #ifdef __cplusplus
 }

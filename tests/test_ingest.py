@@ -87,3 +87,31 @@ def test_raw_plan_rejects_bad_input():
         ebos.EventPlan.build_raw(z16, z16, t[:3], pol, (H, W))
     with pytest.raises(IndexError):
         ebos.EventPlan.build_raw(z16[:0], z16[:0], t[:0], pol[:0], (H, W))
+
+
+@pytest.mark.gpu
+def test_deferred_plan_equals_synchronous_plan():
+    """bin(deferred=True) never reads back to the host; with out-of-image events present it must give the same IWE
+    (those events are in no tile range) and report them through counts()."""
+    import event_based_bos_amd as ebos
+
+    x, y, t, p = O.synth_raw_columns(30000, H, W, seed=9)
+    x[::97] = W + 3          # outside the sensor: dropped by the binning
+    y[5::101] = -2
+    store = ebos.data_loader.RawEventStore({"x": x, "y": y, "t": t, "p": p})
+    flow = torch.from_numpy(O.synth_dense_flow(H, W, seed=5, max_val=6.0)).float().cuda()
+    sync = store.plan(0, 30000, (H, W), "first", True, tile="auto")
+    lazy = store.plan(0, 30000, (H, W), "first", True, tile="auto", deferred=True)
+    dropped = int(((x >= W) | (y < 0)).sum())
+    assert sync.n == 30000 - dropped and lazy.n == 30000 and lazy.compact
+    assert lazy.counts() == (dropped, 0) and sync.counts() == (dropped, 0)
+    assert torch.equal(lazy.iwe_dense(flow), sync.iwe_dense(flow))  # BIT-EXACT (fixed-point accumulation)
+    f1, f2 = flow.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    lazy.contrast_dense(f1).backward()
+    sync.contrast_dense(f2).backward()
+    assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 1e-6
+    # a float plan with fractional coordinates cannot be deferred
+    ev = np.stack([y + 0.25, x, t / 1e6, p], 1).astype(np.float64)
+    frac = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=None).bin((32, 32), deferred=True)
+    with pytest.raises(ValueError):
+        frac.counts()

@@ -228,3 +228,43 @@ def test_yaml_driven_run_improves_contrast():
     assert rep["image"] == [260, 346] and rep["iterations"] == 200
     assert rep["loss_last"] < rep["loss_first"]
     assert rep["variance_warped"] > 1.3 * rep["variance_unwarped"], rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_concurrent,pyramid", [(1, False), (2, False), (3, True)])
+def test_window_pipeline_matches_per_window_estimates(n_concurrent, pyramid):
+    """WindowPipeline (raw-column ingest on its own stream, n_concurrent windows solved at once on separate streams by
+    ebos_cmax_patch_solve_many_f32) against solver.estimate on the reference-format window, window by window:
+    same losses (1e-4 relative over the first 10 iterations, 2e-2 over all) and flows within 0.05 px."""
+    import event_based_bos_amd as ebos
+
+    h, w = 96, 128
+    rs = np.random.RandomState(11)
+    cols, rows, ts, ps, bounds = [], [], [], [], [0]
+    for k in range(5):  # five windows of one "recording", each with its own translation
+        ev = moving_points(h, w, 400, 30, np.array([3.0 + k, -2.0 + 0.5 * k]), seed=20 + k)
+        rows.append(ev[:, 0]); cols.append(ev[:, 1]); ps.append(ev[:, 3])
+        ts.append(np.sort(rs.randint(0, 20000, len(ev))) + 1_000_000 + 30000 * k)
+        bounds.append(bounds[-1] + len(ev))
+    store = ebos.data_loader.RawEventStore({"x": np.concatenate(cols), "y": np.concatenate(rows), "t": np.concatenate(ts),
+                                            "p": np.concatenate(ps)})
+    windows = [(bounds[k], bounds[k + 1]) for k in range(5)]
+    cfg = load_cfg()["solver"]
+    patch = {"pyramid": {"coarsest": 32, "finest": 16}} if pyramid else {"size": [24, 32], "sliding_window": [24, 32]}
+    cfg.update(patch=patch, cost_with_weight={"image_variance": 1.0, "flow_norm": 0.01},
+               iwe={"method": "bilinear_vote", "blur_sigma": 0},
+               optimizer={"method": "Adam", "n_iter": 36, "parameters": {"lr": 0.2}})
+    solver = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    pipe = ebos.solver.WindowPipeline(solver, n_concurrent=n_concurrent)
+    flows = pipe.run(store, windows)
+    assert len(flows) == 5 and all(f.shape == (2, h, w) and f.dtype == np.float64 for f in flows)
+    for k, wnd in enumerate(windows):
+        ref = solver.estimate(store.load_event(*wnd))
+        assert solver.fused
+        dev = np.abs(np.array(pipe.histories[k]) - np.array(solver.history)) / np.abs(np.array(solver.history))
+        assert len(pipe.histories[k]) == len(solver.history) and dev[:10].max() < 1e-4 and dev.max() < 2e-2, dev
+        assert np.abs(flows[k] - ref).max() < 0.05
+    # configurations outside the fused objective family are refused, not silently run differently
+    cfg2 = dict(cfg, iwe={"method": "bilinear_vote", "blur_sigma": 1})
+    with pytest.raises(NotImplementedError):
+        ebos.solver.WindowPipeline(ebos.solver.collections["cmax"]((h, w), (h, w), solver_config=cfg2)).run(store, windows[:1])
