@@ -150,7 +150,7 @@ def main():
         # one objective evaluation: tile accumulate -> slab combine (writes the IWE) -> variance
         _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n, P(flow),
                                                H, W, args.tile[0], args.tile[1], args.halo, args.splits, 0, 0, P(ws), nws,
-                                               P(iwe), 1, 0, P(out), P(moments), stream), "ebos_iwe_dense_slab")
+                                               P(iwe), 1, 0, P(out), P(moments), P(plan.part_table), stream), "ebos_iwe_dense_slab")
 
     def sync_all():
         torch.cuda.synchronize()

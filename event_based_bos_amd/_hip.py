@@ -74,8 +74,9 @@ SIGNATURES = {
     "ebos_iwe_dense_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "ebos_slab_config": (_I, [C.POINTER(C.c_int), _I]),
     "ebos_iwe_slab_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
-    "ebos_iwe_dense_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
-    "ebos_iwe_2dof_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P]),
+    "ebos_iwe_dense_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P, _P]),
+    "ebos_iwe_2dof_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P, _P]),
+    "ebos_plan_parts": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_2dof_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "ebos_iwe_2dof_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
@@ -109,8 +110,9 @@ SIGNATURES = {
 class CmaxPatchProblem(C.Structure):
     """``ebos_cmax_patch_problem`` of include/ebos_hip.h (same field order)."""
     _fields_ = ([(k, _P) for k in ("xs", "ys", "dts", "grp_offsets", "cpix", "cdt", "key_offsets")] + [("n", _L)] +
-                [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "pad_h", "pad_w", "omit_boundary",
-                                   "gh", "gw", "patch_h", "patch_w", "slide_h", "slide_w")] +
+                [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "pad_h", "pad_w", "omit_boundary", "splits")] +
+                [("part_table", _P)] +
+                [(k, _I) for k in ("gh", "gw", "patch_h", "patch_w", "slide_h", "slide_w")] +
                 [(k, _F) for k in ("w_variance", "w_flow_norm", "w_image_gradient")] +
                 [(k, _D) for k in ("lr", "beta1", "beta2", "eps")] +
                 [(k, _P) for k in ("theta", "d_theta", "exp_avg", "exp_avg_sq", "step", "dense", "d_dense", "d_reg", "iwe",

@@ -265,6 +265,95 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
   }
 }
 
+// Adaptive work items: cut heavy tiles into parts of at most tau events, parts(t) = max(1, ceil(load(t) / tau)).
+// A work item is one workgroup and a CU holds one of them at a time (LDS), so with F = the fixed work of an item
+// (LDS clear, decode, slab store) expressed in events, a pass lasts about
+//     max( tau + F ,  (N + items(tau) * F) / n_cu )        -- the longest item vs the average load of a CU.
+// The first term grows with tau, the second falls: tau is the smallest value where the first reaches the second
+// (and for which the parts fit the 2 x tiles budget) -- if that beats one part per tile by 20 % or more.  A uniform
+// window keeps one part per tile, while a window whose events sit in a few tiles (a schlieren object in front of a
+// static background) spreads those tiles over the otherwise idle CUs.  One workgroup; runs once per plan.
+__global__ void __launch_bounds__(1024)
+plan_parts_kernel(const int32_t* __restrict__ key_offsets, int n_tiles, int tile_px, int n_items, int n_cu, int fixed_events,
+                  int32_t* __restrict__ part_table) {
+  __shared__ long long red[1024 / kWave];
+  __shared__ long long s_bcast;
+  __shared__ int s_max;
+  auto load_of = [&](int t) { return key_offsets[(int64_t)(t + 1) * tile_px] - key_offsets[(int64_t)t * tile_px]; };
+  auto items_at = [&](int tau) {  // block-uniform result
+    long long cnt = 0;
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) cnt += max(1, (load_of(t) + tau - 1) / tau);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) s_bcast = cnt;
+    __syncthreads();
+    cnt = s_bcast;
+    __syncthreads();
+    return cnt;
+  };
+  int lmax = 1;
+  for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) lmax = max(lmax, load_of(t));
+  if (threadIdx.x == 0) s_max = 1;
+  __syncthreads();
+  atomicMax(&s_max, lmax);
+  __syncthreads();
+  lmax = s_max;
+  const long long total = (long long)key_offsets[(int64_t)n_tiles * tile_px] - key_offsets[0];
+  int lo = 1, hi = lmax;
+  while (lo < hi) {  // smallest tau whose parts fit the budget
+    const int mid = lo + (hi - lo) / 2;
+    if (items_at(mid) <= n_items) hi = mid;
+    else lo = mid + 1;
+  }
+  hi = lmax;
+  while (lo < hi) {  // smallest tau with  tau + F >= (N + items F) / n_cu
+    const int mid = lo + (hi - lo) / 2;
+    const long long items = items_at(mid);
+    if ((long long)(mid + fixed_events) * n_cu >= total + items * fixed_events) hi = mid;
+    else lo = mid + 1;
+  }
+  // Workgroups are dealt to the 8 XCDs round-robin and queue there, so a handful of extra items behind 256 equal
+  // ones costs a whole extra round on some XCD (measured: 24.9 -> 35.2 us on a uniform window with two tiles halved).
+  // Split only when the model promises a clear gain over one part per tile.
+  if ((long long)(lo + fixed_events) * 100 > (long long)(lmax + fixed_events) * 80) lo = lmax;
+  int32_t* part_off = part_table;
+  int32_t* item_tile = part_table + n_tiles + 1;
+  int32_t* item_part = item_tile + n_items;
+  __shared__ int s_used;
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+      part_off[t] = off;
+      off += max(1, (load_of(t) + lo - 1) / lo);
+    }
+    part_off[n_tiles] = off;
+    s_used = off;
+  }
+  __syncthreads();  // part_off is read below by other threads (global memory written by this workgroup: fence not needed
+  __threadfence_block();  // across a barrier within one workgroup, kept explicit)
+  // work items heaviest first (greedy longest-processing-time order of the dispatcher): rank sort, one (tile, part)
+  // per thread-iteration.  The item load is the events of that part; ties break on the slab index.
+  const int used = s_used;
+  for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    const int parts = part_off[t + 1] - part_off[t], load = load_of(t);
+    for (int k = 0; k < parts; ++k) {
+      const int slab = part_off[t] + k;
+      const int mine = (load + parts - 1) / parts;
+      int rank = 0;
+      for (int u = 0; u < n_tiles; ++u) {
+        const int pu = part_off[u + 1] - part_off[u], lu = (load_of(u) + pu - 1) / pu;
+        if (lu > mine) rank += pu;
+        else if (lu == mine) rank += max(0, min(pu, slab - part_off[u]));  // equal load: earlier slabs first
+      }
+      item_tile[rank] = t;
+      item_part[rank] = k;
+    }
+  }
+  for (int i = used + threadIdx.x; i < n_items; i += blockDim.x) {
+    item_tile[i] = -1;
+    item_part[i] = 0;
+  }
+}
+
 template <typename T>
 int events_to_soa_impl(const T* events, const T* tminmax, int ref_mode, double ref_fraction, int normalize_t,
                        int64_t n, float* x, float* y, float* dt, float* p, ebos_stream_t stream) {
@@ -330,6 +419,18 @@ int ebos_raw_events_to_soa(const int16_t* col, const int16_t* row, const void* t
     raw_to_soa_kernel<int64_t><<<grid, dim3(256), 0, s>>>(col, row, static_cast<const int64_t*>(t), pol, ticks_per_second,
                                                         tminmax, ref_mode, ref_fraction, normalize_t, n, x, y, dt, p);
   EBOS_CHECK_LAUNCH("ebos_raw_events_to_soa");
+  return EBOS_OK;
+}
+
+int ebos_plan_parts(const int32_t* key_offsets, int H, int W, int tile_h, int tile_w, int n_cu, int fixed_events,
+                    int32_t* part_table, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(key_offsets && part_table, "ebos_plan_parts: NULL buffer");
+  EBOS_REQUIRE(H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && n_cu >= 1 && fixed_events >= 0, "ebos_plan_parts: bad sizes");
+  const int n_tiles = ((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w);
+  plan_parts_kernel<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(key_offsets, n_tiles, tile_h * tile_w, 2 * n_tiles, n_cu,
+                                                                  fixed_events, part_table);
+  EBOS_CHECK_LAUNCH("ebos_plan_parts");
   return EBOS_OK;
 }
 

@@ -85,6 +85,12 @@ struct EvPtrs {
   const int32_t* grp_off;  // compact plan: [tiles + 1] group offsets
   const uint16_t* cpix;
   const float* cdt;
+  // adaptive work items (splits == 0, ebos_plan_parts): heavy tiles are cut into several parts.  part_off [tiles + 1]
+  // = first slab of each tile; work item i (= workgroup i, heaviest first) is part item_part[i] of tile item_tile[i],
+  // item_tile[i] = -1 for an unused one
+  const int32_t* part_off;
+  const int32_t* item_tile;
+  const int32_t* item_part;
 };
 
 struct Group {  // 4 consecutive events of one lane
@@ -95,6 +101,7 @@ struct Group {  // 4 consecutive events of one lane
 
 struct TileRange {
   int ty, tx;
+  int slab;                  // index of the slab this workgroup writes
   int32_t beg, end;          // FMT_XY: this workgroup's slice of the tile's events (plan order)
   int32_t g_first, g_last;   // groups of 4 this workgroup reads (g_first > g_last: nothing to do)
 };
@@ -103,7 +110,23 @@ template <int FMT>
 __device__ __forceinline__ TileRange tile_range(const int32_t* __restrict__ key_offsets, const EvPtrs& ev, int tile_px,
                                                 int tiles_x, int splits) {
   TileRange r;
-  const int tile = blockIdx.x / splits, part = blockIdx.x - tile * splits;
+  int tile, part;
+  if (splits == 0) {  // adaptive: this workgroup is one work item of the plan's part table
+    tile = ev.item_tile[blockIdx.x];
+    if (tile < 0) {  // unused item
+      r.ty = r.tx = -1;
+      r.slab = r.beg = r.end = r.g_first = 0;
+      r.g_last = -1;
+      return r;
+    }
+    part = ev.item_part[blockIdx.x];
+    splits = ev.part_off[tile + 1] - ev.part_off[tile];
+    r.slab = ev.part_off[tile] + part;
+  } else {
+    tile = blockIdx.x / splits;
+    part = blockIdx.x - tile * splits;
+    r.slab = blockIdx.x;
+  }
   r.ty = tile / tiles_x;
   r.tx = tile - r.ty * tiles_x;
   if (FMT == FMT_COMPACT) {
@@ -441,6 +464,7 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   const ChunkQueue queue{&s_next};
   EBOS_STAMP(0);
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, splits);
+  if (tr.ty < 0) return;  // unused work item of an adaptive plan: its slab is never read
 
   static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
   for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
@@ -461,7 +485,7 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr,
                                                                           queue);
 
-  float4* out = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * (LH * LW));
+  float4* out = reinterpret_cast<float4*>(slabs + (int64_t)tr.slab * (LH * LW));
   bool f64_flush = (MODE == ACC_F64);
   if (MODE == ACC_FX) {
     // One pass: decode 4 consecutive cells (c0 % 4 == 0) of a row from planes A and B, write them to the slab
@@ -530,7 +554,8 @@ constexpr int kCombineBlock = 256;
 template <int TH, int TW, int HALO>
 __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
-                        int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials) {
+                        int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
+                        const int32_t* __restrict__ part_off) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
   const int R = blockIdx.y, C = blockIdx.x * kCombineBlock + threadIdx.x;
@@ -548,8 +573,10 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
       const int rl = r - (ty * TH - HALO);
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int cl = c - (tx * TW - HALO);
-        const float* s = slabs + ((int64_t)(ty * tiles_x + tx) * splits) * (LH * LW) + rl * LW + cl;
-        for (int p = 0; p < splits; ++p) v += s[(int64_t)p * (LH * LW)];
+        const int tile = ty * tiles_x + tx;
+        const int s0 = part_off ? part_off[tile] : tile * splits, np = part_off ? part_off[tile + 1] - s0 : splits;
+        const float* s = slabs + (int64_t)s0 * (LH * LW) + rl * LW + cl;
+        for (int p = 0; p < np; ++p) v += s[(int64_t)p * (LH * LW)];
       }
     }
     const int64_t gi = (int64_t)R * w + C;
@@ -581,7 +608,8 @@ constexpr int kCombineRows = 4;
 template <int TH, int TW, int HALO>
 __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
-                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials) {
+                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
+                         const int32_t* __restrict__ part_off) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   static_assert(HALO % 4 == 0 && TW % 4 == 0, "vector combine needs 4-aligned windows");
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
@@ -601,8 +629,10 @@ iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tile
       const int rl = r - (ty * TH - HALO);
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int cl = c - (tx * TW - HALO);
-        const float* sp = slabs + ((int64_t)(ty * tiles_x + tx) * splits) * (LH * LW) + rl * LW + cl;
-        for (int p = 0; p < splits; ++p) {
+        const int tile = ty * tiles_x + tx;
+        const int s0 = part_off ? part_off[tile] : tile * splits, np = part_off ? part_off[tile + 1] - s0 : splits;
+        const float* sp = slabs + (int64_t)s0 * (LH * LW) + rl * LW + cl;
+        for (int p = 0; p < np; ++p) {
           const float4 t = *reinterpret_cast<const float4*>(sp + (int64_t)p * (LH * LW));
           v.x += t.x;
           v.y += t.y;
@@ -990,11 +1020,13 @@ struct SlabLayout {
   size_t off_spill, off_partials, total;
 };
 
+constexpr int kAdaptiveItemsPerTile = 2;  // work items of an adaptive plan = 2 x tiles (ebos_plan_parts)
+
 inline SlabLayout slab_layout(int H, int W, int th, int tw, int halo, int splits, int pad_h, int pad_w) {
   SlabLayout L;
   L.tiles_y = (H + th - 1) / th;
   L.tiles_x = (W + tw - 1) / tw;
-  L.nblk = L.tiles_y * L.tiles_x * splits;
+  L.nblk = L.tiles_y * L.tiles_x * (splits == 0 ? kAdaptiveItemsPerTile : splits);  // splits == 0: adaptive work items
   L.h = H + 2 * pad_h;
   L.w = W + 2 * pad_w;
   L.slab_cells = (size_t)(th + 2 * halo) * (tw + 2 * halo);
@@ -1052,13 +1084,15 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
     nparts = (int64_t)gb.x * gb.y;
     iwe_slab_combine4_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
                                                                              pad_h, pad_w, iwe, omit ? 1 : 0,
-                                                                             want_var ? partials : nullptr);
+                                                                             want_var ? partials : nullptr,
+                                                                             splits == 0 ? ev.part_off : nullptr);
   } else {
     dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
     nparts = (int64_t)gb.x * gb.y;
     iwe_slab_combine_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
                                                                             pad_h, pad_w, iwe, omit ? 1 : 0,
-                                                                            want_var ? partials : nullptr);
+                                                                            want_var ? partials : nullptr,
+                                                                            splits == 0 ? ev.part_off : nullptr);
   }
   if (want_var) {
     const int lo = omit ? 1 : 0;
@@ -1132,7 +1166,7 @@ int ebos_slab_config(int* out, int cap) {
 
 size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w) {
   using namespace ebos;
-  if (H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0 || halo < 0 || splits < 1 || pad_h < 0 || pad_w < 0) return 0;
+  if (H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0 || halo < 0 || splits < 0 || pad_h < 0 || pad_w < 0) return 0;
   return slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w).total;
 }
 
@@ -1141,12 +1175,13 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
                             int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
-                            double* moments, ebos_stream_t stream) {
+                            double* moments, const int32_t* part_table, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(flow && iwe && key_offsets && workspace, "ebos_iwe_dense_slab: NULL flow/iwe/key_offsets/workspace");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_slab: NULL event buffer");
-  EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 1 && splits <= 64,
+  EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64,
                "ebos_iwe_dense_slab: bad sizes (splits=%d)", splits);
+  EBOS_REQUIRE(splits != 0 || part_table, "ebos_iwe_dense_slab: splits = 0 (adaptive work items) needs the plan's part_table");
   EBOS_REQUIRE(!want_variance || out_variance || moments, "ebos_iwe_dense_slab: variance requested without an output");
   if (!slab_config_ok(tile_h, tile_w, halo)) {
     set_error("ebos_iwe_dense_slab: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
@@ -1159,7 +1194,9 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
   }
   hipStream_t s = as_stream(stream);
   char* ws = reinterpret_cast<char*>(workspace);
-  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt};
+  const int n_tiles_ = ((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w);
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt, part_table, part_table ? part_table + n_tiles_ + 1 : nullptr,
+                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
   static const int acc_mode = [] {  // EBOS_SLAB_ACC=f64 forces the f64 accumulator (debug / A-B runs)
     const char* e = getenv("EBOS_SLAB_ACC");
     return (e && e[0] == 'f') ? (int)ACC_F64 : (int)ACC_FX;
@@ -1180,12 +1217,13 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
                            const int32_t* key_offsets, int64_t n, const float* thetas, int K, int H, int W, int tile_h,
                            int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace, size_t workspace_bytes,
                            float* iwes, int want_variance, int omit_boundary, float* out_variance, double* moments,
-                           ebos_stream_t stream) {
+                           const int32_t* part_table, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(thetas && iwes && key_offsets && workspace, "ebos_iwe_2dof_slab: NULL thetas/iwes/key_offsets/workspace");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_2dof_slab: NULL event buffer");
-  EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 1 && splits <= 64,
+  EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64,
                "ebos_iwe_2dof_slab: bad sizes (K=%d splits=%d)", K, splits);
+  EBOS_REQUIRE(splits != 0 || part_table, "ebos_iwe_2dof_slab: splits = 0 (adaptive work items) needs the plan's part_table");
   if (!slab_config_ok(tile_h, tile_w, halo)) {
     set_error("ebos_iwe_2dof_slab: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
     return EBOS_ERR_UNSUPPORTED;
@@ -1197,7 +1235,9 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
   }
   hipStream_t s = as_stream(stream);
   char* ws = reinterpret_cast<char*>(workspace);
-  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt};
+  const int n_tiles_ = ((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w);
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt, part_table, part_table ? part_table + n_tiles_ + 1 : nullptr,
+                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
   const int64_t hw = (int64_t)(H + 2 * pad_h) * (W + 2 * pad_w);
   for (int k = 0; k < K; ++k) {  // hypotheses reuse the workspace in stream order
     int rc = EBOS_ERR_UNSUPPORTED;
@@ -1234,7 +1274,7 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
   // the tile partials live in the slab section of the (forward) workspace: it is dead once the IWE is combined
   double* partials = reinterpret_cast<double*>(workspace);
   hipStream_t s = as_stream(stream);
-  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt};
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt, nullptr, nullptr, nullptr};
   const int64_t hw = (int64_t)(H + 2 * pad_h) * (W + 2 * pad_w);
   for (int k = 0; k < K; ++k) {
     int rc = EBOS_ERR_UNSUPPORTED;
@@ -1266,7 +1306,7 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
     return EBOS_ERR_UNSUPPORTED;
   }
   hipStream_t s = as_stream(stream);
-  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt};
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt, nullptr, nullptr, nullptr};
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, \

@@ -210,8 +210,8 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, ebos_stream_
                                         q->dense, stream);
   if (rc) return rc;
   rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
-                               q->H, q->W, q->tile_h, q->tile_w, q->halo, 1, q->pad_h, q->pad_w, q->workspace,
-                               q->workspace_bytes, q->iwe, 1, q->omit_boundary, q->variance, q->moments, stream);
+                               q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->workspace,
+                               q->workspace_bytes, q->iwe, 1, q->omit_boundary, q->variance, q->moments, q->part_table, stream);
   if (rc) return rc;
   if (has_reg) {
     rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials, stream);

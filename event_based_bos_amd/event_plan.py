@@ -64,6 +64,10 @@ def parse_direction(direction: Union[str, float]) -> Tuple[int, float]:
     raise ValueError(f"direction argument should be first, middle, last. Or float. {direction}")
 
 
+# per-work-item fixed work of the accumulate kernel (LDS clear, decode, slab store ~3.5 us) in events (~0.4 ns each)
+PART_FIXED_EVENTS = 8192
+
+
 @dataclass
 class EventPlan:
     """SoA f32 event window on one GPU (optionally binned by source tile)."""
@@ -82,6 +86,7 @@ class EventPlan:
     grp_offsets: Optional[torch.Tensor] = None   # compact plan: int32 [tiles + 1] group offsets
     cpix: Optional[torch.Tensor] = None          # compact plan: int16 storage of u16 (row << 8 | col), padded groups
     cdt: Optional[torch.Tensor] = None           # compact plan: f32 dt, NaN in padding slots
+    part_table: Optional[torch.Tensor] = None    # adaptive work items (ebos_plan_parts): int32 [5 tiles + 1]
 
     @property
     def binned(self) -> bool:
@@ -95,6 +100,19 @@ class EventPlan:
     def compact(self) -> bool:
         """True when the tile-private kernels read the 6 B/event format (u16 pixel + f32 dt)."""
         return self.cpix is not None
+
+    def resolve_splits(self, splits: Optional[int]) -> int:
+        """``splits`` of the tile-private forward kernels: k >= 1 cuts every tile into k equal parts, 0 uses the plan's
+        adaptive work items (heavy tiles cut into parts, ``ebos_plan_parts``).  ``None`` picks 0 when the plan has a
+        split tile -- or cannot know, having been built without a host read-back -- and 1 otherwise (a plan whose tiles
+        are even gains nothing from the 2x work-item grid)."""
+        if splits is not None:
+            return int(splits)
+        if self.part_table is None:
+            return 1
+        used = self.__dict__.get("_parts_used")
+        n_tiles = (self.part_table.numel() - 1) // 5
+        return 1 if used is not None and used <= n_tiles else 0
 
     def _compact_ptrs(self):
         return (ptr(self.grp_offsets), ptr(self.cpix), ptr(self.cdt)) if self.compact else (None, None, None)
@@ -219,9 +237,15 @@ class EventPlan:
             with torch.cuda.device(dev):
                 check(lib.ebos_plan_compact_f32(ptr(xs), ptr(ys), ptr(dts), ptr(key_offsets), kept, H, W, th, tw,
                                                 ptr(grp_offsets), ptr(cpix), ptr(cdt), cap, stream_ptr()), "ebos_plan_compact")
+        part_table = torch.empty(5 * tiles_y * tiles_x + 1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, n_cu, PART_FIXED_EVENTS, ptr(part_table), stream_ptr()),
+                  "ebos_plan_parts")
         out = EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
-                        (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt)
+                        (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt, part_table)
         out.__dict__["_counts"], out.__dict__["_deferred"] = counts, bool(deferred)
+        out.__dict__["_parts_used"] = None if deferred else int(part_table[tiles_y * tiles_x].item())
         return out
 
     def counts(self) -> Tuple[int, int]:
@@ -237,19 +261,19 @@ class EventPlan:
 
     # ------------------------------------------------------------------------------------------
     def iwe_dense(self, flow: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
-                  halo: Optional[int] = DEFAULT_HALO, splits: int = 1) -> torch.Tensor:
+                  halo: Optional[int] = DEFAULT_HALO, splits: Optional[int] = None) -> torch.Tensor:
         """Fused dense-flow warp + bilinear IWE: flow [2, H, W] -> iwe [H + 2 pad_h, W + 2 pad_w].
         ``halo=None`` (or an un-binned plan) selects the general global-atomic kernel."""
-        return _FusedIweDense.apply(flow, weight, self, (int(pad[0]), int(pad[1])), halo, int(splits))
+        return _FusedIweDense.apply(flow, weight, self, (int(pad[0]), int(pad[1])), halo, self.resolve_splits(splits))
 
     def iwe_2dof(self, thetas: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
-                 halo: Optional[int] = DEFAULT_HALO, splits: int = 1) -> torch.Tensor:
+                 halo: Optional[int] = DEFAULT_HALO, splits: Optional[int] = None) -> torch.Tensor:
         """Fused 2-DoF warp + bilinear IWE for K hypotheses: thetas [K, 2] -> iwes [K, h, w].
         Binned plans use the tile-private pipeline (|dt * theta| beyond ``halo`` spills, still correct)."""
-        return _FusedIwe2Dof.apply(thetas, weight, self, (int(pad[0]), int(pad[1])), halo, int(splits))
+        return _FusedIwe2Dof.apply(thetas, weight, self, (int(pad[0]), int(pad[1])), halo, self.resolve_splits(splits))
 
     def variance_2dof(self, thetas: torch.Tensor, omit_boundary: bool = False, pad: Tuple[int, int] = (0, 0),
-                      halo: int = DEFAULT_HALO, splits: int = 1, chunk: int = 8) -> torch.Tensor:
+                      halo: int = DEFAULT_HALO, splits: Optional[int] = None, chunk: int = 8) -> torch.Tensor:
         """Variance contrast of K translation hypotheses (the solver's outer sweep): [K, 2] -> [K].
         No gradient; images are produced ``chunk`` at a time into a reused buffer."""
         lib = _hip.require_gpu()
@@ -259,6 +283,7 @@ class EventPlan:
         K = th.shape[0]
         H, W = self.image_size
         h, w = H + 2 * pad[0], W + 2 * pad[1]
+        splits = self.resolve_splits(splits)
         ws = _workspace(self, pad, halo, splits)
         out = torch.empty(K, dtype=torch.float32, device=self.device)
         buf = torch.empty((min(chunk, K), h, w), dtype=torch.float32, device=self.device)
@@ -269,18 +294,19 @@ class EventPlan:
                                                  ptr(self.key_offsets), self.n, th.data_ptr() + 8 * k0, kc, H, W,
                                                  self.tile[0], self.tile[1], int(halo), int(splits), pad[0], pad[1],
                                                  ptr(ws), ws.numel(), ptr(buf), 1, int(omit_boundary),
-                                                 out.data_ptr() + 4 * k0, None, stream_ptr()), "ebos_iwe_2dof_slab")
+                                                 out.data_ptr() + 4 * k0, None, ptr(self.part_table), stream_ptr()),
+                      "ebos_iwe_2dof_slab")
         return out
 
     def contrast_dense(self, flow: torch.Tensor, cost: str = "image_variance", omit_boundary: bool = False,
                        pad: Tuple[int, int] = (0, 0), halo: Optional[int] = DEFAULT_HALO,
-                       splits: int = 1) -> torch.Tensor:
+                       splits: Optional[int] = None) -> torch.Tensor:
         """Contrast of the IWE under ``flow`` (0-d tensor, raw contrast: callers apply the sign).
         Same value and gradient as ``cost(iwe_dense(flow))``, but the variance gradient is folded
         into the backward event kernel (no d_iwe image)."""
         if cost == "image_variance":
             return _FusedVarianceDense.apply(flow, self, (int(pad[0]), int(pad[1])), bool(omit_boundary), halo,
-                                             int(splits))
+                                             self.resolve_splits(splits))
         iwe = self.iwe_dense(flow, pad=pad, halo=halo, splits=splits)
         if cost == "gradient_magnitude":
             return ops.gradient_magnitude(iwe, omit_boundary)
@@ -334,7 +360,7 @@ def _launch_iwe_dense_slab(plan: EventPlan, flow32, weight, pad, halo, splits, w
                                           ptr(plan.key_offsets), plan.n,
                                           ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), int(splits), pad[0],
                                           pad[1], ptr(ws), ws.numel(), ptr(iwe), int(want_variance), int(omit), ptr(out),
-                                          ptr(moments), stream_ptr()), "ebos_iwe_dense_slab")
+                                          ptr(moments), ptr(plan.part_table), stream_ptr()), "ebos_iwe_dense_slab")
     return iwe, out, moments
 
 
@@ -347,7 +373,7 @@ def _launch_iwe_dense(plan: EventPlan, flow32: torch.Tensor, weight, pad, halo, 
     with torch.cuda.device(plan.device):
         if plan.binned and halo is not None:
             check(lib.ebos_iwe_dense_tiled_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), ptr(plan.key_offsets),
-                                               plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), splits,
+                                               plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), max(1, splits),
                                                pad[0], pad[1], ptr(iwe), stream_ptr()), "ebos_iwe_dense_tiled")
         else:
             check(lib.ebos_iwe_dense_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight), plan.n, ptr(flow32), H, W,
@@ -473,7 +499,8 @@ class _FusedIwe2Dof(torch.autograd.Function):
                 check(lib.ebos_iwe_2dof_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), *plan._compact_ptrs(),
                                                  ptr(plan.key_offsets), plan.n, ptr(th32), K, H, W, plan.tile[0],
                                                  plan.tile[1], int(halo), int(splits), pad[0], pad[1], ptr(ws), ws.numel(),
-                                                 ptr(iwes), 0, 0, None, None, stream_ptr()), "ebos_iwe_2dof_slab")
+                                                 ptr(iwes), 0, 0, None, None, ptr(plan.part_table), stream_ptr()),
+                      "ebos_iwe_2dof_slab")
             else:
                 iwes = torch.zeros((K, h, w), dtype=torch.float32, device=plan.device)
                 check(lib.ebos_iwe_2dof_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), plan.n, ptr(th32), K, h, w,

@@ -37,7 +37,8 @@ def supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], bl
 class FusedPatchLoop(object):
     def __init__(self, plan: EventPlan, patch_size: Tuple[int, int], sliding_window: Tuple[int, int], theta0: torch.Tensor,
                  w_variance: float, w_flow_norm: float = 0.0, w_image_gradient: float = 0.0, omit_boundary: bool = False,
-                 pad: int = 0, halo: int = 32, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, capacity: int = 1024):
+                 pad: int = 0, halo: int = 32, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, capacity: int = 1024,
+                 splits: Optional[int] = None):
         self.lib = _hip.require_gpu()
         self.plan, self.patch, self.slide = plan, tuple(int(v) for v in patch_size), tuple(int(v) for v in sliding_window)
         self.w_var, self.w_norm, self.w_tv = float(w_variance), float(w_flow_norm), float(w_image_gradient)
@@ -62,7 +63,8 @@ class FusedPatchLoop(object):
         self.upstream = torch.full((1,), -self.w_var, **f32)  # loss = -w * variance
         self.losses = torch.zeros(max(int(capacity), 1), **f32)
         self.scratch_up = torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32)
-        self.ws = _workspace(plan, self.pad, self.halo, 1)
+        self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
+        self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.graphed = False
 
     def iteration(self) -> None:
@@ -73,8 +75,9 @@ class FusedPatchLoop(object):
               "ebos_upsample_patch_flow")
         check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                           ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
-                                          self.halo, 1, self.pad[0], self.pad[1], ptr(self.ws), self.ws.numel(), ptr(self.iwe),
-                                          1, int(self.omit), ptr(self.variance), ptr(self.moments), s), "ebos_iwe_dense_slab")
+                                          self.halo, self.splits, self.pad[0], self.pad[1], ptr(self.ws), self.ws.numel(),
+                                          ptr(self.iwe), 1, int(self.omit), ptr(self.variance), ptr(self.moments),
+                                          ptr(plan.part_table), s), "ebos_iwe_dense_slab")
         if self.has_reg:
             check(lib.ebos_flow_regularisers_f32(ptr(self.dense), H, W, self.w_norm, self.w_tv, ptr(self.d_reg),
                                                  ptr(self.reg_partials), s), "ebos_flow_regularisers")
@@ -100,6 +103,7 @@ class FusedPatchLoop(object):
         q.key_offsets, q.n = ptr(plan.key_offsets), plan.n
         q.H, q.W, q.tile_h, q.tile_w, q.halo = H, W, plan.tile[0], plan.tile[1], self.halo
         q.pad_h, q.pad_w, q.omit_boundary = self.pad[0], self.pad[1], int(self.omit)
+        q.splits, q.part_table = self.splits, ptr(plan.part_table)
         q.gh, q.gw, (q.patch_h, q.patch_w), (q.slide_h, q.slide_w) = self.gh, self.gw, self.patch, self.slide
         q.w_variance, q.w_flow_norm, q.w_image_gradient = self.w_var, self.w_norm, self.w_tv
         q.lr, q.beta1, q.beta2, q.eps = self.lr, self.betas[0], self.betas[1], self.eps

@@ -95,7 +95,8 @@ class WindowPipeline(object):
                     losses[w].append(lp.losses[:n_iter].clone())
             last = (patch_size, sliding_window)
         for w, plan in enumerate(plans):  # the plan was built on the ingest stream and read on streams[w]
-            for t in (plan.x, plan.y, plan.dt, plan.p, plan.key_offsets, plan.perm, plan.grp_offsets, plan.cpix, plan.cdt):
+            for t in (plan.x, plan.y, plan.dt, plan.p, plan.key_offsets, plan.perm, plan.grp_offsets, plan.cpix, plan.cdt,
+                      plan.part_table):
                 if t is not None:
                     t.record_stream(streams[w])
         return [dict(theta=thetas[w], losses=losses[w], patch=last, counts=plans[w].__dict__.get("_counts"))

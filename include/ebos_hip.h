@@ -212,6 +212,20 @@ int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const f
                         int32_t* perm, int32_t* key_offsets, int32_t* oob_count, int32_t* frac_count,
                         void* scratch, size_t scratch_bytes, ebos_stream_t stream);
 
+/* Adaptive work items for the tile-private forward kernels.  With one workgroup per tile the pass lasts as long as
+ * the fullest tile; real windows are far from uniform (a schlieren object in front of a static background).
+ * ebos_plan_parts cuts heavy tiles into parts: parts(t) = max(1, ceil(load(t) / tau)), where tau balances the
+ * longest work item against the average load of a CU:  tau + F = (N + items(tau) F) / n_cu  (n_cu = CUs of the
+ * device, F = fixed_events = the per-item fixed work in events, ~8192 measured), within a budget of 2 x tiles work
+ * items.  A uniform window keeps one part per tile.  part_table (int32, out, 5 tiles + 1 entries):
+ *     [0, tiles]               part_off: first slab of each tile (part_off[tiles] = work items in use)
+ *     [tiles + 1, 3 tiles]     item_tile: tile of each of the 2 x tiles work items, heaviest first (the dispatcher
+ *                              then schedules longest-processing-time first), -1 = unused
+ *     [3 tiles + 1, 5 tiles]   item_part: which part of that tile
+ * Pass it with splits = 0 to ebos_iwe_dense_slab_f32 / ebos_iwe_2dof_slab_f32 (workspace sized with splits = 0). */
+int ebos_plan_parts(const int32_t* key_offsets, int H, int W, int tile_h, int tile_w, int n_cu, int fixed_events,
+                    int32_t* part_table, ebos_stream_t stream);
+
 /* Compact plan: the 6 B/event layout of the tile-private kernels, valid when every source coordinate is a
  * non-negative integer (frac_count == 0; camera events always are).  Per tile t the events occupy the groups
  * [grp_offsets[t], grp_offsets[t+1]) of 4 slots (16-byte vector loads, tiles start on a group boundary):
@@ -269,6 +283,8 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  *   workspace: >= ebos_iwe_slab_workspace_bytes(...) bytes, ZERO-FILLED ONCE by the caller when it is
  *   allocated; the kernels keep its spill section (taps beyond the halo) zero between calls.
  *   Results are deterministic (fixed summation order) except for taps beyond the halo.
+ *   splits >= 1: every tile is cut into `splits` equal parts (workgroups); splits = 0: the adaptive work items of
+ *   part_table (ebos_plan_parts; NULL otherwise).
  * ebos_iwe_dense_tiled_bwd_f32   backward.  One workgroup per tile: upstream image tile in LDS,
  *   wavefront-segmented sums per source pixel, d_flow [2, H, W] OVERWRITTEN with plain stores
  *   (binned plans only; g_image/affine/g_lo/d_weight as in ebos_iwe_dense_bwd_f32; d_weight in plan order).
@@ -290,7 +306,8 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
                             int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary,
-                            float* out_variance, double* moments, ebos_stream_t stream);
+                            float* out_variance, double* moments, const int32_t* part_table,
+                            ebos_stream_t stream);
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
                                  const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
                                  const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
@@ -307,7 +324,8 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
                            const int32_t* key_offsets, int64_t n, const float* thetas, int K,
                            int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w,
                            void* workspace, size_t workspace_bytes, float* iwes, int want_variance,
-                           int omit_boundary, float* out_variance, double* moments, ebos_stream_t stream);
+                           int omit_boundary, float* out_variance, double* moments, const int32_t* part_table,
+                           ebos_stream_t stream);
 
 /* backward of ebos_iwe_2dof_slab_f32: d_thetas[k] = sum_n dt * dL/d(x', y') for upstream images g_images [K, h, w]
  * (affine [K, 2] / g_lo as in ebos_iwe_dense_bwd_f32); d_thetas [K, 2] is OVERWRITTEN.  workspace: the plan's forward
@@ -432,7 +450,7 @@ int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, flo
 /* The whole loop natively: n_iter iterations of the six calls above, enqueued back to back on `stream` by one
  * C call (no interpreter between launches; asynchronous like everything else).  All buffers are the caller's:
  *   plan:     xs/ys/dts (nullable when the compact trio is given), grp_offsets/cpix/cdt, key_offsets, n, H, W, tile,
- *             halo, pad, omit_boundary -- as ebos_iwe_dense_slab_f32 / ebos_iwe_dense_tiled_bwd_f32
+ *             halo, pad, omit_boundary, splits, part_table -- as ebos_iwe_dense_slab_f32 / ebos_iwe_dense_tiled_bwd_f32
  *   grid:     theta/d_theta/exp_avg/exp_avg_sq [2, gh, gw], step [1] int32, patch and sliding window
  *   images:   dense/d_dense [2, H, W], d_reg [2, H, W] (nullable iff both regulariser weights are 0),
  *             iwe [H + 2 pad_h, W + 2 pad_w], variance [1] f32, moments [2] f64, upstream [1] f32 = -w_variance
@@ -447,6 +465,8 @@ typedef struct ebos_cmax_patch_problem {
   const int32_t* key_offsets;
   int64_t n;
   int H, W, tile_h, tile_w, halo, pad_h, pad_w, omit_boundary;
+  int splits;                  /* as ebos_iwe_dense_slab_f32; 0 = adaptive work items of part_table */
+  const int32_t* part_table;   /* nullable unless splits == 0 */
   int gh, gw, patch_h, patch_w, slide_h, slide_w;
   float w_variance, w_flow_norm, w_image_gradient;
   double lr, beta1, beta2, eps;

@@ -678,3 +678,55 @@ def test_tiled_backward_addend(ebos):
                                               32, 0, 0, EP.ptr(iwe), None, 0, EP.ptr(out), None, EP.ptr(mom), EP.ptr(up),
                                               EP.ptr(addend), EP.stream_ptr()), "bwd")
     assert torch.equal(out, base + addend)
+
+
+def _blob_events(n, h, w, sigma, seed):
+    rs = np.random.RandomState(seed)
+    r = np.clip(np.rint(rs.normal(h / 2, sigma, n)), 0, h - 1)
+    c = np.clip(np.rint(rs.normal(w / 2, sigma, n)), 0, w - 1)
+    return np.stack([r, c, np.sort(rs.uniform(0, 0.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
+
+
+@pytest.mark.parametrize("shape,sigma,n", [((96, 128), 9.0, 60000), ((260, 346), 20.0, 200000), ((96, 128), 1000.0, 40000)])
+def test_adaptive_work_items(ebos, shape, sigma, n):
+    """Windows whose events sit in a few tiles: ebos_plan_parts cuts the heavy tiles into parts (splits = 0).  The part
+    table must be a consistent partition, and IWE / variance / 2-DoF images must equal the one-part-per-tile result
+    (fixed-point tile sums are exact; only the f32 slab combine order differs: rel-L2 < 1e-6) and the oracle (< 1e-4)."""
+    h, w = shape
+    ev = _blob_events(n, h, w, sigma, seed=41) if sigma < 100 else O.synth_events(n, h, w, seed=41)  # blob | uniform
+    plan = ebos.EventPlan.build(G(ev), shape, "first", True, tile="auto")
+    th, tw = plan.tile
+    n_tiles = -(-h // th) * -(-w // tw)
+    pt = plan.part_table.cpu().numpy()
+    part_off, item_tile, item_part = pt[:n_tiles + 1], pt[n_tiles + 1:3 * n_tiles + 1], pt[3 * n_tiles + 1:]
+    used = part_off[-1]
+    assert part_off[0] == 0 and np.all(np.diff(part_off) >= 1) and n_tiles <= used <= 2 * n_tiles
+    assert np.all(item_tile[used:] == -1) and np.all(item_tile[:used] >= 0)
+    slabs = part_off[item_tile[:used]] + item_part[:used]
+    assert sorted(slabs.tolist()) == list(range(used))                       # every (tile, part) exactly once
+    assert np.all(item_part[:used] < np.diff(part_off)[item_tile[:used]])
+    loads = np.diff(plan.key_offsets.cpu().numpy()[::th * tw])
+    per_item = np.ceil(loads[item_tile[:used]] / np.diff(part_off)[item_tile[:used]])
+    assert np.all(np.diff(per_item) <= 0)                                    # heaviest first
+    if sigma < 100:
+        assert used > n_tiles and plan.resolve_splits(None) == 0             # the blob's tiles are split ...
+        assert per_item.max() < 0.5 * loads.max()
+    else:
+        assert used == n_tiles and plan.resolve_splits(None) == 1            # ... a uniform window is not
+    flow = G(O.synth_dense_flow(h, w, seed=42, max_val=6.0)).float()
+    one = plan.iwe_dense(flow, splits=1)
+    ada = plan.iwe_dense(flow, splits=0)
+    assert rel(ada.cpu().numpy(), one.cpu().numpy()) < 1e-6
+    expect = O.iwe_dense(torch.from_numpy(ev), torch.from_numpy(flow.cpu().numpy().astype(np.float64)), shape)
+    assert rel(ada.cpu().numpy(), expect.numpy()) < 1e-4
+    v0, v1 = plan.contrast_dense(flow, splits=0).item(), plan.contrast_dense(flow, splits=1).item()
+    assert abs(v0 - v1) <= 1e-6 * abs(v1)
+    thetas = G(np.array([[2.0, -1.0], [-4.0, 3.0]])).float()
+    assert rel(plan.iwe_2dof(thetas, splits=0).cpu().numpy(), plan.iwe_2dof(thetas, splits=1).cpu().numpy()) < 1e-6
+    assert rel(plan.variance_2dof(thetas, splits=0).cpu().numpy(), plan.variance_2dof(thetas, splits=1).cpu().numpy()) < 1e-6
+    # gradient through the default (adaptive) path against the oracle's autograd
+    ft = torch.from_numpy(flow.cpu().numpy().astype(np.float64)).requires_grad_(True)
+    torch.var(O.iwe_dense(torch.from_numpy(ev), ft, shape)).backward()
+    fg = flow.clone().requires_grad_(True)
+    plan.contrast_dense(fg).backward()
+    assert rel(fg.grad.cpu().numpy(), ft.grad.numpy()) < 1e-3
