@@ -185,7 +185,8 @@ def main():
         step()
         _hip.check(lib.ebos_iwe_dense_tiled_bwd_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
                                                     P(flow), H, W, args.tile[0], args.tile[1], args.halo, 0, 0, P(iwe), None,
-                                                    0, P(d_flow), None, P(moments), P(upstream), None, stream), "ebos_iwe_dense_tiled_bwd")
+                                                    0, P(d_flow), None, P(moments), P(upstream), None, P(ws), nws,
+                                                    P(plan.part_table) if args.splits == 0 else None, stream), "ebos_iwe_dense_tiled_bwd")
 
     for _ in range(3):
         step_fwd_bwd()

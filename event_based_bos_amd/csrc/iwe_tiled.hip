@@ -824,12 +824,15 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
                            const float* __restrict__ affine, int g_lo, float* __restrict__ d_flow,
                            float* __restrict__ d_weight, double* __restrict__ partials,
                            const double* __restrict__ var_moments, const float* __restrict__ upstream,
-                           const float* __restrict__ addend) {
+                           const float* __restrict__ addend, float* __restrict__ part_out) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
   float* s_g = reinterpret_cast<float*>(s_raw + 2 * TH * TW);      // [LH][LW] upstream gradient tile
-  const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, 1);
+  // part_out != nullptr: adaptive work items -- this workgroup is one part of a tile and writes its partial d_flow tile
+  // to slab tr.slab of part_out; bwd_parts_combine_kernel sums the parts
+  const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, part_out ? 0 : 1);
+  if (tr.ty < 0) return;  // unused work item
   const int64_t hw = (int64_t)H * W;
   GradImage G;
   G.g = g_image;
@@ -974,6 +977,11 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
     return;
   }
+  if (part_out != nullptr) {  // partial tile [2][TH * TW] of this part, plain stores
+    float* out = part_out + (int64_t)tr.slab * (LH * LW);
+    for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) out[i] = (float)s_d[i];
+    return;
+  }
   // every flow pixel belongs to exactly one tile: plain coalesced stores, zeros where no event lives
   for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
     const int rl = i / TW, cl = i - rl * TW;
@@ -999,6 +1007,32 @@ __global__ void __launch_bounds__(256) theta_grad_finalize_kernel(const double* 
   if (threadIdx.x == 0) {
     d_theta[0] = (float)sx;
     d_theta[1] = (float)sy;
+  }
+}
+
+// adaptive backward, second step: d_flow of a tile = sum of its parts' partial tiles (+ the regulariser gradient)
+template <int TH, int TW, int HALO>
+__global__ void __launch_bounds__(256)
+bwd_parts_combine_kernel(const float* __restrict__ parts, const int32_t* __restrict__ part_off, int tiles_x, int H, int W,
+                         const float* __restrict__ addend, float* __restrict__ d_flow) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  static_assert(2 * TH * TW <= LH * LW, "a partial d_flow tile fits one slab");
+  const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int s0 = part_off[tile], np = part_off[tile + 1] - s0;
+  const int64_t hw = (int64_t)H * W;
+  for (int i = threadIdx.x; i < TH * TW; i += blockDim.x) {
+    const int rl = i / TW, cl = i - rl * TW;
+    const int r = ty * TH + rl, c = tx * TW + cl;
+    if (r >= H || c >= W) continue;
+    float gx = 0.0f, gy = 0.0f;
+    for (int p = 0; p < np; ++p) {
+      const float* q = parts + (int64_t)(s0 + p) * (LH * LW);
+      gx += q[i];
+      gy += q[TH * TW + i];
+    }
+    const int64_t o = (int64_t)r * W + c;
+    d_flow[o] = gx + (addend ? addend[o] : 0.0f);
+    d_flow[hw + o] = gy + (addend ? addend[hw + o] : 0.0f);
   }
 }
 
@@ -1105,14 +1139,15 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
 template <int TH, int TW, int HALO>
 int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int pad_h,
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
-                     double* partials, const double* var_moments, const float* upstream, const float* addend, hipStream_t s) {
+                     double* partials, const double* var_moments, const float* upstream, const float* addend, float* part_out,
+                     hipStream_t s) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert(lds <= 160 * 1024, "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
-             const double*, const float*, const float*);
+             const double*, const float*, const float*, float*);
 #define EBOS_PICK(HW)                                                                                      \
   (uniform ? (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_COMPACT, true>                    \
                       : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_XY, true>)                         \
@@ -1122,8 +1157,12 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   else kb = EBOS_PICK(false);
 #undef EBOS_PICK
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
-  kb<<<dim3((unsigned)(tiles_y * tiles_x)), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image,
-                                                                    affine, g_lo, d_flow, d_weight, partials, var_moments, upstream, addend);
+  const unsigned grid = (unsigned)(tiles_y * tiles_x * (part_out ? kAdaptiveItemsPerTile : 1));
+  kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
+                                           partials, var_moments, upstream, part_out ? nullptr : addend, part_out);
+  if (part_out)
+    bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
+                                                                                                  addend, d_flow);
   if (uniform) theta_grad_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, tiles_y * tiles_x, d_flow);
   return EBOS_OK;
 }
@@ -1280,7 +1319,7 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
     int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                              \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, thetas + 2 * k, true, H, W, pad_h, pad_w, g_images + k * hw,              \
-                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, nullptr, nullptr, nullptr, s)
+                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, nullptr, nullptr, nullptr, nullptr, s)
     EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
     if (rc != EBOS_OK) return rc;
@@ -1295,22 +1334,35 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
                                  int tile_h,
                                  int tile_w, int halo, int pad_h, int pad_w, const float* g_image, const float* affine,
                                  int g_lo, float* d_flow, float* d_weight, const double* var_moments,
-                                 const float* upstream, const float* addend, ebos_stream_t stream) {
+                                 const float* upstream, const float* addend, void* workspace, size_t workspace_bytes,
+                                 const int32_t* part_table, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(flow && g_image && d_flow && key_offsets, "ebos_iwe_dense_tiled_bwd: NULL flow/g_image/d_flow/key_offsets");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_dense_tiled_bwd: bad sizes");
   EBOS_REQUIRE((var_moments == nullptr) == (upstream == nullptr), "ebos_iwe_dense_tiled_bwd: var_moments and upstream go together");
+  float* part_out = nullptr;
+  if (part_table != nullptr) {  // adaptive work items: partial tiles go through the slab section of the forward workspace
+    const size_t need = ebos_iwe_slab_workspace_bytes(H, W, tile_h, tile_w, halo, 0, pad_h, pad_w);
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("ebos_iwe_dense_tiled_bwd: part_table given but the workspace is missing or too small (%zu < %zu)",
+                workspace_bytes, need);
+      return EBOS_ERR_SCRATCH;
+    }
+    part_out = reinterpret_cast<float*>(workspace);
+  }
   if (!slab_config_ok(tile_h, tile_w, halo)) {
     set_error("ebos_iwe_dense_tiled_bwd: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
     return EBOS_ERR_UNSUPPORTED;
   }
   hipStream_t s = as_stream(stream);
-  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt, nullptr, nullptr, nullptr};
+  const int n_tiles_ = ((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w);
+  const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt, part_table, part_table ? part_table + n_tiles_ + 1 : nullptr,
+                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, \
-                               nullptr, var_moments, upstream, addend, s)
+                               nullptr, var_moments, upstream, addend, part_out, s)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

@@ -220,7 +220,8 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, ebos_stream_
   rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
                                     q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w, q->iwe, nullptr,
                                     q->omit_boundary ? 1 : 0, q->d_dense, nullptr, q->moments, q->upstream,
-                                    has_reg ? q->d_reg : nullptr, stream);
+                                    has_reg ? q->d_reg : nullptr, q->workspace, q->workspace_bytes,
+                                    q->splits == 0 ? q->part_table : nullptr, stream);
   if (rc) return rc;
   rc = ebos_upsample_patch_flow_bwd_f32(q->d_dense, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
                                         q->upsample_scratch, q->d_theta, stream);

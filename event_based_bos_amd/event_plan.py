@@ -395,17 +395,21 @@ def _plan_weight(plan: EventPlan, weight: Optional[torch.Tensor]) -> Optional[to
 
 
 def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_dweight, halo=DEFAULT_HALO,
-                      var_moments=None, upstream=None):
+                      var_moments=None, upstream=None, splits=1):
     lib = _hip.require_gpu()
     H, W = plan.image_size
     d_w = torch.empty(plan.n, dtype=torch.float32, device=plan.device) if want_dweight else None
     if _slab_ok(plan, halo):  # tile-private backward: d_flow written with plain stores, no zero-fill
         d_flow = torch.empty((2, H, W), dtype=torch.float32, device=plan.device)
+        adaptive = splits == 0 and plan.part_table is not None
+        ws = _workspace(plan, pad, halo, 0) if adaptive else None
         with torch.cuda.device(plan.device):
             check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(weight_p), *plan._compact_ptrs(),
                                                    ptr(plan.key_offsets), plan.n, ptr(flow32), H, W, plan.tile[0], plan.tile[1], int(halo), pad[0],
                                                    pad[1], ptr(g_image), ptr(affine), g_lo, ptr(d_flow), ptr(d_w),
-                                                   ptr(var_moments), ptr(upstream), None, stream_ptr()), "ebos_iwe_dense_tiled_bwd")
+                                                   ptr(var_moments), ptr(upstream), None, ptr(ws), ws.numel() if adaptive else 0,
+                                                   ptr(plan.part_table) if adaptive else None, stream_ptr()),
+                  "ebos_iwe_dense_tiled_bwd")
         return d_flow, d_w
     if var_moments is not None:  # general kernels take the affine form
         affine = torch.empty(2, dtype=torch.float32, device=plan.device)
@@ -436,16 +440,17 @@ class _FusedIweDense(torch.autograd.Function):
         wp = _plan_weight(plan, weight)
         iwe = _launch_iwe_dense(plan, flow32, wp, pad, halo, splits)
         ctx.save_for_backward(flow32, wp if wp is not None else torch.empty(0))
-        ctx.meta = (plan, pad, flow.dtype, weight.dtype if weight is not None else None, halo)
+        ctx.meta = (plan, pad, flow.dtype, weight.dtype if weight is not None else None, halo, splits)
         return iwe if flow.dtype == torch.float32 else iwe.to(flow.dtype)
 
     @staticmethod
     def backward(ctx, g):
         flow32, wp = ctx.saved_tensors
-        plan, pad, fdt, wdt, halo = ctx.meta
+        plan, pad, fdt, wdt, halo, splits = ctx.meta
         wp = wp if wdt is not None else None
         need_w = wdt is not None and ctx.needs_input_grad[1]
-        d_flow, d_w = _launch_dense_bwd(plan, flow32, wp, pad, g.to(torch.float32).contiguous(), None, 0, need_w, halo)
+        d_flow, d_w = _launch_dense_bwd(plan, flow32, wp, pad, g.to(torch.float32).contiguous(), None, 0, need_w, halo,
+                                        splits=splits)
         d_weight = _unpermute(plan, d_w).to(wdt) if need_w else None
         return (d_flow.to(fdt) if ctx.needs_input_grad[0] else None), d_weight, None, None, None, None
 
@@ -468,16 +473,16 @@ class _FusedVarianceDense(torch.autograd.Function):
                 check(lib.ebos_image_variance_f32(ptr(iwe), 1, h, w, int(omit), ptr(out), ptr(moments), ptr(scratch), nbytes,
                                                   stream_ptr()), "ebos_image_variance")
         ctx.save_for_backward(flow32, iwe, moments)
-        ctx.meta = (plan, pad, int(omit), flow.dtype, halo)
+        ctx.meta = (plan, pad, int(omit), flow.dtype, halo, splits)
         return out[0].to(flow.dtype)
 
     @staticmethod
     def backward(ctx, g):
         lib = _hip.require_gpu()
         flow32, iwe, moments = ctx.saved_tensors
-        plan, pad, omit, fdt, halo = ctx.meta
+        plan, pad, omit, fdt, halo, splits = ctx.meta
         up = g.to(torch.float32).reshape(1).contiguous()
-        d_flow, _ = _launch_dense_bwd(plan, flow32, None, pad, iwe, None, omit, False, halo, moments, up)
+        d_flow, _ = _launch_dense_bwd(plan, flow32, None, pad, iwe, None, omit, False, halo, moments, up, splits=splits)
         return d_flow.to(fdt), None, None, None, None, None
 
 

@@ -84,7 +84,8 @@ class FusedPatchLoop(object):
         check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                                ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
                                                self.halo, self.pad[0], self.pad[1], ptr(self.iwe), None, int(self.omit),
-                                               ptr(self.d_dense), None, ptr(self.moments), ptr(self.upstream), ptr(self.d_reg), s),
+                                               ptr(self.d_dense), None, ptr(self.moments), ptr(self.upstream), ptr(self.d_reg),
+                                               ptr(self.ws), self.ws.numel(), ptr(plan.part_table) if self.splits == 0 else None, s),
               "ebos_iwe_dense_tiled_bwd")
         check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
                                                    ptr(self.d_theta), s), "ebos_upsample_patch_flow_bwd")

@@ -293,6 +293,9 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  *   into the kernel (no d_iwe image, no affine launch).
  *   addend [2, H, W] (nullable): added to the result as it is stored -- the gradient of the flow regularisers
  *   (ebos_flow_regularisers_f32), so that d_flow is the gradient of the whole objective without another pass.
+ *   part_table (nullable): the adaptive work items of ebos_plan_parts -- every part of a tile writes a partial d_flow
+ *   tile into the slab section of `workspace` (the forward workspace sized with splits = 0; its slabs are dead once
+ *   the IWE is combined) and a second small kernel sums the parts.  workspace may be NULL when part_table is.
  * grp_offsets / cpix / cdt (nullable trio): the compact plan of ebos_plan_compact_f32; when given and weight is
  *   NULL, xs/ys/dts are not read (6 B/event instead of 12).  All SoA arrays are read 4 events (16 bytes) per
  *   lane: 16-byte aligned, padded to a multiple of 4 elements.
@@ -314,6 +317,7 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
                                  int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, float* d_flow, float* d_weight,
                                  const double* var_moments, const float* upstream, const float* addend,
+                                 void* workspace, size_t workspace_bytes, const int32_t* part_table,
                                  ebos_stream_t stream);
 
 /* 2-DoF hypotheses on the tile-private pipeline (BASELINE config 5): thetas [K, 2] (device), x' = x + dt theta

@@ -676,8 +676,16 @@ def test_tiled_backward_addend(ebos):
     EP.check(lib.ebos_iwe_dense_tiled_bwd_f32(EP.ptr(plan.x), EP.ptr(plan.y), EP.ptr(plan.dt), None, *plan._compact_ptrs(),
                                               EP.ptr(plan.key_offsets), plan.n, EP.ptr(flow), 64, 96, plan.tile[0], plan.tile[1],
                                               32, 0, 0, EP.ptr(iwe), None, 0, EP.ptr(out), None, EP.ptr(mom), EP.ptr(up),
-                                              EP.ptr(addend), EP.stream_ptr()), "bwd")
+                                              EP.ptr(addend), None, 0, None, EP.stream_ptr()), "bwd")
     assert torch.equal(out, base + addend)
+    # the same through the adaptive work items (partial tiles + combine): the addend is applied by the combine kernel
+    ws = EP._workspace(plan, (0, 0), 32, 0)
+    out2 = torch.empty_like(base)
+    EP.check(lib.ebos_iwe_dense_tiled_bwd_f32(EP.ptr(plan.x), EP.ptr(plan.y), EP.ptr(plan.dt), None, *plan._compact_ptrs(),
+                                              EP.ptr(plan.key_offsets), plan.n, EP.ptr(flow), 64, 96, plan.tile[0], plan.tile[1],
+                                              32, 0, 0, EP.ptr(iwe), None, 0, EP.ptr(out2), None, EP.ptr(mom), EP.ptr(up),
+                                              EP.ptr(addend), EP.ptr(ws), ws.numel(), EP.ptr(plan.part_table), EP.stream_ptr()), "bwd")
+    assert rel(out2.cpu().numpy(), (base + addend).cpu().numpy()) < 1e-6
 
 
 def _blob_events(n, h, w, sigma, seed):
