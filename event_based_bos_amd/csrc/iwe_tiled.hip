@@ -203,10 +203,11 @@ __device__ __forceinline__ void load_group(Group& g, int32_t grp, const TileRang
 //        ds_add_u64 (measured ~4.6 lanes/clk/CU vs ~2.8 for ds_add_f64, and half as many of them).
 //        Plane A holds the pairs starting at even columns, plane B those starting at odd columns.
 //        Integer adds commute: the tile sum is exact and bit-reproducible.  A field overflows only if
-//        one cell collects more than 2^(31-kFxShift) = 2048 units of weight inside one workgroup; that
-//        is DETECTED exactly -- a wrapped field changes the decoded total by a multiple of 2^32 - 1,
-//        and all contributions have one sign, so sum(decoded fields) != sum(added) -- and the
-//        workgroup then redoes its slice in F64 mode.  Used for unit weights (the hot path).
+//        one cell collects more than 2^(32-kFxShift) = 4096 units of weight inside one workgroup; that
+//        is DETECTED exactly -- every wrap lowers the 64-bit sum of the decoded fields by 2^32 - 1 (low
+//        field, carry into the neighbour) or 2^32 (high field, carry out of the word), never raises it,
+//        so sum(decoded fields) != sum(added) -- and the workgroup then redoes its slice in F64 mode.
+//        Used for unit weights (the hot path).
 constexpr int kFxShift = 20;
 constexpr float kFxScale = (float)(1 << kFxShift);
 constexpr double kFxInv = 1.0 / (double)(1 << kFxShift);
@@ -251,8 +252,10 @@ struct ChunkQueue {
   }
 };
 
-template <int TH, int TW, int HALO, bool UNIFORM>
-__device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
+// MODE == ACC_F64: the same loop with four ds_add_f64 per event -- the exact redo of a slice whose fixed-point fields
+// overflowed (hot pixels, or a flow that piles thousands of events onto one cell).
+template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX>
+__device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                           const float* __restrict__ flow, int H, int W, bool* any_spill,
                                                           const ChunkQueue& queue) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
@@ -265,7 +268,7 @@ __device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, d
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
   const unsigned base_lin = (unsigned)(tr.ty * TH * W + tr.tx * TW);
   const unsigned uW = (unsigned)W;
-  unsigned added = 0;
+  unsigned long long added = 0;  // 64-bit: see the overflow check in the kernel
   bool spilled = false;
   const int32_t g_last = tr.g_last;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -304,6 +307,15 @@ __device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, d
       const bool ok = lane_live && (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
       const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
       spilled |= ok && !inside;
+      if (MODE == ACC_F64) {  // one double per cell; out-of-window / padding lanes add +0.0 to cell (0, 0) (select, not
+        const float a = 1.0f - fr, b = 1.0f - fc;  // multiply: their weights may be NaN)
+        double* cell = s_acc + (inside ? rl * LW + cl : 0);
+        atomic_add(cell, (double)(inside ? a * b : 0.0f));
+        atomic_add(cell + 1, (double)(inside ? a * fc : 0.0f));
+        atomic_add(cell + LW, (double)(inside ? fr * b : 0.0f));
+        atomic_add(cell + LW + 1, (double)(inside ? fr * fc : 0.0f));
+        continue;
+      }
       const float fs = fr * kFxScale, as = kFxScale - fs, b = 1.0f - fc;
       const unsigned q00 = (unsigned)(__float_as_int(__fmaf_rn(as, b, kMagic)) - kMagicBits);
       const unsigned q10 = (unsigned)(__float_as_int(__fmaf_rn(fs, b, kMagic)) - kMagicBits);
@@ -313,7 +325,7 @@ __device__ __forceinline__ unsigned accumulate_compact_fx(const TileRange& tr, d
       const unsigned word = inside ? (t >> 1) + (t & 1u) * kPlane : kDummy;
       atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
       atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
-      added += inside ? q00 + q10 + q01 + q11 : 0u;
+      added += inside ? q00 + q10 + q01 + q11 : 0u;  // four taps < 2^22: the 32-bit sum of one event cannot wrap
     }
     cur = nxt;
     nxt = nn;
@@ -339,7 +351,7 @@ enum Pass { PASS_MAIN = 0, PASS_SPILL = 1 };
 // UNIFORM: one translation theta for all events (2-DoF model, src/warp.py:364-383: x' = x + dt * theta, i.e. a
 // dense flow of -theta everywhere) -- the two flow gathers disappear.
 template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM>
-__device__ __forceinline__ unsigned accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
+__device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                      const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                      float* spill, bool* any_spill, const ChunkQueue& queue) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
@@ -349,11 +361,11 @@ __device__ __forceinline__ unsigned accumulate_slice(const TileRange& tr, double
   const int oy = tr0 - HALO, ox = tc0 - HALO;  // LDS cell (0,0) = un-padded pixel (oy, ox)
   const float* __restrict__ flow1 = UNIFORM ? flow : flow + (int64_t)H * W;
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;  // flow == theta pair
-  unsigned added = 0;  // FX: integer total this thread put into LDS (mod 2^32)
+  unsigned long long added = 0;  // FX: integer total this thread put into LDS
   bool spilled = false;
   if (tr.g_first > tr.g_last) return 0;
-  if (FMT == FMT_COMPACT && MODE == ACC_FX && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop
-    return accumulate_compact_fx<TH, TW, HALO, UNIFORM>(tr, s_acc, ev, flow, H, W, any_spill, queue);
+  if (FMT == FMT_COMPACT && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop (fixed point, or its exact f64 redo)
+    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE>(tr, s_acc, ev, flow, H, W, any_spill, queue);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
   const int32_t g_last = tr.g_last;
@@ -458,7 +470,7 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   constexpr int kCells = LH * LW + LW / 2 + 2;  // + a dummy region that absorbs the adds of out-of-window lanes
   static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
   extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words; + dummy
-  __shared__ unsigned s_chk[2 * kBlock / kWave];
+  __shared__ unsigned long long s_chk[2 * kBlock / kWave];
   __shared__ int s_flag[2];  // [0] fixed-point overflow, [1] some event left the LDS window
   __shared__ unsigned s_next;  // chunk queue of the lean loop
   const ChunkQueue queue{&s_next};
@@ -475,7 +487,7 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   EBOS_STAMP(1);
 
   bool spilled = false;
-  const unsigned added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h,
+  const unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h,
                                                                                               pad_w, spill, &spilled, queue);
   if (spilled) s_flag[1] = 1;  // benign race: every writer stores 1
   EBOS_STAMP(2);
@@ -490,11 +502,15 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   if (MODE == ACC_FX) {
     // One pass: decode 4 consecutive cells (c0 % 4 == 0) of a row from planes A and B, write them to the slab
     // optimistically, and sum the decoded fields for the overflow check
-    //   sum(decoded fields) == sum(added units)  (mod 2^32; a wrapped field shifts it by k (2^32 - 1)).
-    // Fields are unsigned 32-bit: lo = low dword (column c), hi = high dword (column c + 1).
+    //   sum(decoded fields) == sum(added units), both in 64-bit arithmetic.  A low field that wraps loses 2^32 and
+    //   carries 1 into its high neighbour (the sum drops by 2^32 - 1); a high field that wraps carries out of the word
+    //   (the sum drops by 2^32) -- so the sums must be wider than 32 bits: modulo 2^32 the second case is invisible
+    //   (it was, until a 40 000-event hot pixel showed it).  Both changes are negative: they cannot cancel.
+    // Fields are unsigned 32-bit: lo = low dword (column c), hi = high dword (column c + 1).  The two fields that make
+    // up one pixel (plane A + plane B) are added as floats: their integer sum could pass 2^32 although neither did.
     const uint2* pa = reinterpret_cast<const uint2*>(s_acc);
     const uint2* pb = pa + LH * LW / 2;
-    unsigned decoded = 0;
+    unsigned long long decoded = 0;
     constexpr float kInv = (float)kFxInv;
     for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
       const int r = i / (LW / 4), j = i - r * (LW / 4);  // cells 4j..4j+3 <- A words 2j, 2j+1 and B words 2j-1, 2j, 2j+1
@@ -502,12 +518,13 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const uint2 a0 = pa[wrow + 2 * j], a1 = pa[wrow + 2 * j + 1];
       const uint2 b0 = pb[wrow + 2 * j], b1 = pb[wrow + 2 * j + 1];
       const unsigned bmh = j > 0 ? pb[wrow + 2 * j - 1].y : 0u;  // pair (4j-1, 4j); its lo field belongs to the previous group
-      decoded += a0.x + a0.y + a1.x + a1.y + b0.x + b0.y + b1.x + b1.y;
-      out[i] = make_float4((float)(a0.x + bmh) * kInv, (float)(a0.y + b0.x) * kInv, (float)(a1.x + b0.y) * kInv,
-                           (float)(a1.y + b1.x) * kInv);
+      decoded += ((unsigned long long)a0.x + a0.y) + ((unsigned long long)a1.x + a1.y) + ((unsigned long long)b0.x + b0.y) +
+                 ((unsigned long long)b1.x + b1.y);
+      out[i] = make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv,
+                           ((float)a1.x + (float)b0.y) * kInv, ((float)a1.y + (float)b1.x) * kInv);
     }
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    unsigned a = added, d = decoded;
+    unsigned long long a = added, d = decoded;
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
       a += __shfl_down(a, off, kWave);
@@ -519,7 +536,7 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      unsigned ta = 0, td = 0;
+      unsigned long long ta = 0, td = 0;
       for (int k = 0; k < kBlock / kWave; ++k) {
         ta += s_chk[2 * k];
         td += s_chk[2 * k + 1];
@@ -529,6 +546,7 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     __syncthreads();
     if (s_flag[0]) {  // a field wrapped: redo this slice exactly in f64 and overwrite the slab (spill taps already issued)
       for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
+      if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);  // the redo draws its chunks afresh
       __syncthreads();
       accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr,
                                                                               queue);

@@ -738,3 +738,30 @@ def test_adaptive_work_items(ebos, shape, sigma, n):
     fg = flow.clone().requires_grad_(True)
     plan.contrast_dense(fg).backward()
     assert rel(fg.grad.cpu().numpy(), ft.grad.numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("splits", [1, 0, 3])
+def test_hot_pixels_overflow_high_and_low_fields(ebos, splits):
+    """Cells that collect tens of thousands of events wrap the 32-bit fixed-point fields many times over, in the low
+    AND in the high field of a paired word (a high-field wrap carries out of the 64-bit word and is invisible to a
+    checksum modulo 2^32 -- the bug this test pins).  The exact f64 redo must take over: rel-L2 < 1e-6 vs the oracle,
+    mass conserved."""
+    h, w = 96, 128
+    rs = np.random.RandomState(13)
+    n = 300000
+    r, c = rs.randint(0, h, n), rs.randint(0, w, n)
+    hot = [(40, 61), (40, 62), (17, 100), (70, 7)]            # even and odd columns: both planes, both fields
+    idx = rs.choice(n, 4 * 50000, replace=False)
+    r[idx] = np.repeat([p[0] for p in hot], 50000)
+    c[idx] = np.repeat([p[1] for p in hot], 50000)
+    ev = np.stack([r, c, np.sort(rs.uniform(0, 0.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
+    flow = rs.uniform(-1.5, 1.5, (2, h, w))
+    flow[:, 40, 61] = 0.0                                       # all 50 000 events of this pixel land on one cell
+    expect = O.iwe_dense(torch.from_numpy(ev), torch.from_numpy(flow), (h, w)).numpy()
+    assert expect.max() >= 50000
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile="auto")
+    got = plan.iwe_dense(G(flow).float(), splits=splits).cpu().numpy()
+    assert rel(got, expect) < 1e-6
+    assert abs(got.sum() - expect.sum()) < 1e-6 * expect.sum()
+    var = plan.contrast_dense(G(flow).float(), splits=splits).item()
+    assert abs(var - expect.var(ddof=1)) < 1e-5 * expect.var(ddof=1)
