@@ -765,3 +765,62 @@ def test_hot_pixels_overflow_high_and_low_fields(ebos, splits):
     assert abs(got.sum() - expect.sum()) < 1e-6 * expect.sum()
     var = plan.contrast_dense(G(flow).float(), splits=splits).item()
     assert abs(var - expect.var(ddof=1)) < 1e-5 * expect.var(ddof=1)
+
+
+def test_fuzz_fused_path_against_oracle(ebos):
+    """Seeded fuzz over the knobs that interact in the tile-private pipeline: image size (tiles cut by the border), tile
+    configuration, halo (taps beyond it spill), event clustering (hot pixels, blobs, borders), flow magnitude (beyond the
+    halo, out of the image), padding, omit_boundary, splits (uniform, adaptive).  IWE rel-L2 < 1e-4, variance rel
+    < 1e-5, flow gradient rel-L2 < 1e-3 against the fp64 oracle -- the north_star tolerances."""
+    from event_based_bos_amd import _hip
+
+    configs = _hip.slab_configs()
+    rs = np.random.RandomState(2024)
+    for case in range(64):
+        h, w = int(rs.randint(20, 150)), int(rs.randint(20, 200))
+        th, tw, halo = configs[rs.randint(len(configs))]
+        n = int(rs.choice([2, 7, 500, 5000, 60000]))  # (a single event trips the squeeze() quirk of the reference path)
+        kind = rs.randint(4)
+        if kind == 0:
+            r, c = rs.randint(0, h, n), rs.randint(0, w, n)
+        elif kind == 1:   # blob
+            r = np.clip(np.rint(rs.normal(h / 2, 4, n)), 0, h - 1)
+            c = np.clip(np.rint(rs.normal(w / 3, 6, n)), 0, w - 1)
+        elif kind == 2:   # a few hot pixels
+            k = rs.randint(0, 5, n)
+            r, c = np.array([0, h - 1, h // 2, 3, h // 2])[k], np.array([0, w - 1, w // 2, w - 2, w // 2 + 1])[k]
+        else:             # borders
+            r = rs.choice([0, 1, h - 2, h - 1], n)
+            c = rs.randint(0, w, n)
+        t = np.sort(rs.uniform(3.0, 3.5, n))
+        ev = np.stack([r, c, t, rs.randint(0, 2, n)], 1).astype(np.float64)
+        amp = float(rs.choice([0.0, 0.7, 5.0, 40.0, 90.0]))
+        flow = rs.uniform(-amp, amp, (2, h, w))
+        pad = int(rs.choice([0, 0, 4]))
+        omit = bool(rs.randint(2))
+        splits = int(rs.choice([0, 1, 2, 5]))
+        direction = ["first", "middle", "last", 0.3][rs.randint(4)]
+        tag = f"case {case}: {h}x{w} tile {th}x{tw} halo {halo} n {n} kind {kind} amp {amp} pad {pad} splits {splits} {direction}"
+        tev = torch.from_numpy(ev)
+        ft = torch.from_numpy(flow).requires_grad_(True)
+        expect = O.iwe_dense(tev, ft, (h, w), pad=(pad, pad), direction=direction)
+        crop = expect[1:-1, 1:-1] if omit else expect
+        v_ref = torch.var(crop) if crop.numel() > 1 else None
+        plan = ebos.EventPlan.build(G(ev), (h, w), direction, True, tile=(th, tw))
+        fg = G(flow).float().requires_grad_(True)
+        got = plan.iwe_dense(fg, pad=(pad, pad), halo=halo, splits=splits)
+        scale = max(float(expect.detach().norm()), 1e-12)
+        assert float((got.detach().cpu().double() - expect.detach()).norm()) / scale < 1e-4, tag
+        if v_ref is not None and float(v_ref) > 0:
+            v = plan.contrast_dense(fg, "image_variance", omit, pad=(pad, pad), halo=halo, splits=splits)
+            assert abs(v.item() - v_ref.item()) <= 1e-5 * abs(v_ref.item()) + 1e-9, tag
+            v.backward()
+            v_ref.backward()
+            gn = float(ft.grad.detach().norm())
+            if gn > 0 and amp > 0:  # at zero flow every event sits on the kink of the bilinear vote
+                assert float((fg.grad.cpu().double() - ft.grad).norm()) / gn < 1e-3, tag
+        # the 2-DoF model through the same tile-private kernels (UNIFORM variant)
+        theta = rs.uniform(-amp - 1, amp + 1, 2)
+        exp2 = O.iwe_2dof(tev, torch.from_numpy(theta), (h, w), pad=(pad, pad), direction=direction)
+        got2 = plan.iwe_2dof(G(theta[None]).float(), pad=(pad, pad), halo=halo, splits=splits)[0]
+        assert float((got2.cpu().double() - exp2).norm()) / max(float(exp2.norm()), 1e-12) < 1e-4, tag
