@@ -268,7 +268,7 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
   const unsigned base_lin = (unsigned)(tr.ty * TH * W + tr.tx * TW);
   const unsigned uW = (unsigned)W;
-  unsigned long long added = 0;  // 64-bit: see the overflow check in the kernel
+  unsigned n_inside = 0;  // events of this wave whose taps went into the window (wave-uniform)
   bool spilled = false;
   const int32_t g_last = tr.g_last;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -316,16 +316,23 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
         atomic_add(cell + LW + 1, (double)(inside ? fr * fc : 0.0f));
         continue;
       }
-      const float fs = fr * kFxScale, as = kFxScale - fs, b = 1.0f - fc;
-      const unsigned q00 = (unsigned)(__float_as_int(__fmaf_rn(as, b, kMagic)) - kMagicBits);
-      const unsigned q10 = (unsigned)(__float_as_int(__fmaf_rn(fs, b, kMagic)) - kMagicBits);
-      const unsigned q01 = (unsigned)(__float_as_int(__fmaf_rn(as, fc, kMagic)) - kMagicBits);
-      const unsigned q11 = (unsigned)(__float_as_int(__fmaf_rn(fs, fc, kMagic)) - kMagicBits);
+      // The event's unit of weight (2^20) is split exactly: first between the two rows, then each row between its two
+      // columns -- every tap is a non-negative integer and the four sum to 2^20 whatever the rounding, so the checksum
+      // of a wave is 2^20 x (events it put inside the window): a mask population count, no per-event arithmetic.
+      const float b = 1.0f - fc;
+      const float t0 = __fmaf_rn(fr, -kFxScale, kFxScale + kMagic);  // magic + A0,  A0 = rint(2^20 (1 - fr))
+      const float a0 = t0 - kMagic, a1 = kFxScale - a0;               // A0, A1 = 2^20 - A0 as floats (exact)
+      const float u0 = __fmaf_rn(a0, b, kMagic), u1 = __fmaf_rn(a1, b, kMagic);
+      const float t1 = a1 + kMagic;
+      const unsigned q00 = (unsigned)(__float_as_int(u0) - kMagicBits);
+      const unsigned q01 = (unsigned)(__float_as_int(t0) - __float_as_int(u0));  // A0 - q00
+      const unsigned q10 = (unsigned)(__float_as_int(u1) - kMagicBits);
+      const unsigned q11 = (unsigned)(__float_as_int(t1) - __float_as_int(u1));  // A1 - q10
       const unsigned t = (unsigned)(rl * LW + cl);
       const unsigned word = inside ? (t >> 1) + (t & 1u) * kPlane : kDummy;
       atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
       atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
-      added += inside ? q00 + q10 + q01 + q11 : 0u;  // four taps < 2^22: the 32-bit sum of one event cannot wrap
+      n_inside += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside));  // wave-uniform: s_bcnt1 on the mask
     }
     cur = nxt;
     nxt = nn;
@@ -338,7 +345,8 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
     }
   }
   if (any_spill) *any_spill = spilled;
-  return added;
+  // this wave's share of the checksum, reported by its first lane (the kernel sums over lanes)
+  return MODE == ACC_FX && lane == 0 ? (unsigned long long)n_inside << kFxShift : 0ull;
 }
 
 // PASS_MAIN: the lean hot loop -- every tap that lands inside the LDS window is accumulated, branch-free (dead or
