@@ -741,7 +741,8 @@ struct GradImage {
 template <int TH, int TW, int HALO, bool UNIFORM, int PASS>
 __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s_d, const float* s_g, const EvPtrs& ev,
                                                   const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
-                                                  const GradImage& G, double& tot_x, double& tot_y, bool* any_spill) {
+                                                  const GradImage& G, double& tot_x, double& tot_y, bool* any_spill,
+                                                  const ChunkQueue& queue) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   const float* __restrict__ flow1 = UNIFORM ? flow : flow + (int64_t)H * W;
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
@@ -750,10 +751,14 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
   const unsigned uW = (unsigned)W;
   bool spilled = false;
   const int32_t g_last = tr.g_last;
-  int32_t grp = tr.g_first + threadIdx.x;
+  // dynamic chunks of 64 groups per wave, as in the forward loop: with a static stride the first wave was done 5.9 us
+  // before the last one (in-kernel stamps)
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  constexpr int kWaves = kBlock / kWave;
+  int c_cur = wave, c_nxt = wave + kWaves;
   CGroup cur, nxt;
-  load_cgroup<TH, TW>(cur, grp, tr, ev);
-  load_cgroup<TH, TW>(nxt, grp + kBlock, tr, ev);
+  load_cgroup<TH, TW>(cur, tr.g_first + c_cur * kWave + lane, tr, ev);
+  load_cgroup<TH, TW>(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev);
   float fu[4], fv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -761,7 +766,8 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
     fu[e] = UNIFORM ? uni_u : flow[lin];
     fv[e] = UNIFORM ? uni_v : flow1[lin];
   }
-  while (grp <= g_last) {
+  while (tr.g_first + c_cur * kWave <= g_last) {  // wave-uniform
+    const bool lane_live = tr.g_first + c_cur * kWave + lane <= g_last;  // the last chunk may be partial
     float gu[4], gv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -769,8 +775,9 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
       gu[e] = UNIFORM ? uni_u : flow[lin];
       gv[e] = UNIFORM ? uni_v : flow1[lin];
     }
+    const int c_nn = queue.pull();
     CGroup nn;
-    load_cgroup<TH, TW>(nn, grp + 2 * kBlock, tr, ev);
+    load_cgroup<TH, TW>(nn, tr.g_first + c_nn * kWave + lane, tr, ev);
     // the lane's 4 events are consecutive in the sorted plan and mostly share one source pixel: sum per run
     unsigned run_pix = 0xffffffffu;
     float ax = 0.0f, ay = 0.0f;
@@ -781,7 +788,7 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
       const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
       const float fr = lx - r0, fc = ly - c0;
       const int rl = (int)cur.pr[e] + HALO + (int)r0, cl = (int)cur.pc[e] + HALO + (int)c0;
-      const bool ok = (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
+      const bool ok = lane_live && (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
       const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
       float g00, g10, g01, g11;
       bool use;
@@ -831,12 +838,13 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
     }
     cur = nxt;
     nxt = nn;
+    c_cur = c_nxt;
+    c_nxt = c_nn;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       fu[e] = gu[e];
       fv[e] = gv[e];
     }
-    grp += kBlock;
   }
   if (any_spill) *any_spill = spilled;
 }
@@ -878,7 +886,12 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   const int oy = tr0 - HALO, ox = tc0 - HALO;
 
   __shared__ int s_spill;  // some event's taps left the LDS window of the upstream image
-  if (threadIdx.x == 0) s_spill = 0;
+  __shared__ unsigned s_next;  // chunk queue of the lean loop
+  const ChunkQueue queue{&s_next};
+  if (threadIdx.x == 0) {
+    s_spill = 0;
+    s_next = 2 * (kBlock / kWave);
+  }
   for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
   if (tr.g_first <= tr.g_last) {
     for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
@@ -893,11 +906,16 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   if (kLean) {
     bool spilled = false;
     if (tr.g_first <= tr.g_last)
-      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, &spilled);
+      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, &spilled, queue);
     if (spilled) s_spill = 1;
     __syncthreads();
-    if (s_spill && tr.g_first <= tr.g_last)
-      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, nullptr);
+    if (s_spill) {  // rare second sweep; it draws its chunks afresh
+      if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
+      __syncthreads();
+      if (tr.g_first <= tr.g_last)
+        bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, nullptr,
+                                                             queue);
+    }
   } else if (tr.g_first <= tr.g_last) {
     const float* __restrict__ flow1 = UNIFORM ? flow : flow + hw;
     const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
