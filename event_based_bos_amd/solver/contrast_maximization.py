@@ -12,7 +12,8 @@ objective(theta) = - contrast(IWE(warp(events, motion(theta)))) [+ weighted regu
 Everything per event runs in the fused tile-private HIP pipeline on an ``EventPlan`` built once per window.
 YAML keys read (same names as configs/hot_plate1.yaml:46-80 of the reference): warp_direction, motion_model,
 parameters, cost, cost_with_weight, outer_padding, iwe.{method, blur_sigma}, patch.{size, sliding_window, pyramid.{coarsest, finest}},
-optimizer.{method (Adam | CG | BFGS | L-BFGS-B | TNC | SLSQP | grid), n_iter, parameters.lr, options, graph}.
+optimizer.{method (Adam | CG | BFGS | L-BFGS-B | TNC | SLSQP | grid), n_iter, parameters.lr, options, graph, fused,
+refine_iters}.
 """
 from __future__ import annotations
 
@@ -75,6 +76,7 @@ class ContrastMaximization(SolverBase):
         self.n_iter = int(ocfg.get("n_iter", 100))
         self.lr = float((ocfg.get("parameters") or {}).get("lr", 0.05))
         self.scipy_options = dict(ocfg.get("options") or {})
+        self.refine_iters = int(ocfg.get("refine_iters", 0))  # 2-DoF models: Adam steps after the grid sweep
         self.param_ranges = cfg.get("parameters") or {}
         self.halo = int(cfg.get("halo", 32))
         # optimizer.graph: capture one whole iteration (upsample -> fused objective -> backward -> Adam update) into a
@@ -279,4 +281,16 @@ class ContrastMaximization(SolverBase):
         var = plan.variance_2dof(grid, self.omit_boundary, pad=(self.pad, self.pad), halo=self.halo)
         self.history = [float(-v) for v in var.cpu()]
         self.sweep_grid, self.sweep_contrast = grid, var
-        return grid[int(torch.argmax(var).item())]
+        theta = grid[int(torch.argmax(var).item())]
+        if self.refine_iters > 0:  # optimizer.refine_iters: Adam from the best grid point (gradient of the 2-DoF kernels)
+            theta = theta.clone().requires_grad_(True)
+            opt = torch.optim.Adam([theta], lr=self.lr)
+            for _ in range(self.refine_iters):
+                opt.zero_grad(set_to_none=True)
+                iwe = plan.iwe_2dof(theta[None], pad=(self.pad, self.pad), halo=self.halo)[0]
+                loss = -ops.image_variance(iwe, self.omit_boundary)
+                loss.backward()
+                opt.step()
+                self.history.append(float(loss.detach()))
+            theta = theta.detach()
+        return theta

@@ -171,6 +171,12 @@ def test_solver_recovers_translation_dense_and_2dof():
     s2 = ebos.solver.collections["cmax"]((h, w), (h, w), solver_config=cfg2)
     flow2 = s2.estimate(ev)
     assert np.allclose(flow2[:, 0, 0], v, atol=0.6), flow2[:, 0, 0]  # dense-flow equivalent of theta = -v
+    # a coarse sweep (6 x 6 over +-12: 4 px steps) refined with Adam on the gradient of the 2-DoF kernels
+    cfg3 = dict(cfg2, optimizer={"method": "grid", "n_iter": 36, "refine_iters": 40, "parameters": {"lr": 0.2}})
+    s3 = ebos.solver.collections["cmax"]((h, w), (h, w), solver_config=cfg3)
+    flow3 = s3.estimate(ev)
+    assert len(s3.history) == 36 + 40 and min(s3.history[36:]) <= min(s3.history[:36])
+    assert np.allclose(flow3[:, 0, 0], v, atol=0.6), flow3[:, 0, 0]
 
 
 @pytest.mark.gpu
