@@ -98,3 +98,24 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+@pytest.mark.gpu
+def test_c_abi_is_usable_without_python(tmp_path, lib):
+    """examples/c_abi_window.cpp: a plain host program (hipcc, no torch) drives the library through include/ebos_hip.h --
+    raw sensor columns -> plan -> objective -> gradient -- and checks mass conservation and a finite-difference
+    derivative itself."""
+    import shutil
+    import subprocess
+
+    from event_based_bos_amd import _hip
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "c_abi_window")
+    libdir = os.path.dirname(_hip.LIB_PATH)
+    build = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", "c_abi_window.cpp"), "-L" + libdir, "-lebos_hip",
+                            "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "150000"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.strip().endswith("OK"), (run.stdout[-1000:], run.stderr[-1000:])
