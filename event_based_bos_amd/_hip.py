@@ -66,6 +66,7 @@ SIGNATURES = {
     "ebos_raw_time_range": (_I, [_P, _I, _L, _D, _P, _P, _P]),
     "ebos_raw_events_to_soa": (_I, [_P, _P, _P, _I, _P, _D, _P, _I, _D, _I, _L, _P, _P, _P, _P, _P]),
     "ebos_bin_scratch_bytes": (_Z, [_L]),
+    "ebos_bin_scratch_bytes_events": (_Z, [_L, _I, _I, _I, _I]),
     "ebos_bin_events_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "ebos_plan_compact_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _L, _P]),
     "ebos_iwe_dense_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -213,7 +213,7 @@ class EventPlan:
         perm = torch.empty(n, dtype=torch.int32, device=dev)
         key_offsets = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
         counts = torch.zeros(2, dtype=torch.int32, device=dev)  # [out-of-image sources, fractional sources]
-        nbytes = int(lib.ebos_bin_scratch_bytes(n_keys))
+        nbytes = int(lib.ebos_bin_scratch_bytes_events(n, H, W, th, tw))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             check(lib.ebos_bin_events_f32(ptr(self.x), ptr(self.y), ptr(self.dt), ptr(self.p), n, H, W, th, tw,

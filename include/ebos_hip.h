@@ -207,6 +207,10 @@ int ebos_raw_events_to_soa(const int16_t* col, const int16_t* row, const void* t
  * All SoA outputs must be 16-byte aligned and padded to a multiple of 4 elements (vector loads).
  * The order of events inside one source pixel is not deterministic (atomic cursor). */
 size_t ebos_bin_scratch_bytes(int64_t n_keys);
+/* scratch size that lets ebos_bin_events_f32 scatter one aligned 32-byte record per event (then unpacked to the SoA
+ * arrays by a streaming pass) instead of five 4-byte stores to five arrays; with only ebos_bin_scratch_bytes(n_keys)
+ * the five-store form runs.  Never smaller than ebos_bin_scratch_bytes(n_keys). */
+size_t ebos_bin_scratch_bytes_events(int64_t n, int H, int W, int tile_h, int tile_w);
 int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const float* p, int64_t n,
                         int H, int W, int tile_h, int tile_w, float* xs, float* ys, float* dts, float* ps,
                         int32_t* perm, int32_t* key_offsets, int32_t* oob_count, int32_t* frac_count,
