@@ -348,6 +348,9 @@ plan_parts_kernel(const int32_t* __restrict__ key_offsets, int n_tiles, int tile
   lmax = s_max;
   const long long total = (long long)key_offsets[(int64_t)n_tiles * tile_px] - key_offsets[0];
   int lo = 1, hi = lmax;
+  // no tau can beat one part per tile by 20 % when even the average CU load does not (the common, even window):
+  // skip the two searches (~35 workgroup-wide reductions)
+  if ((long long)(lmax + fixed_events) * 80 * n_cu <= (total + (long long)n_tiles * fixed_events) * 100) lo = hi;
   while (lo < hi) {  // smallest tau whose parts fit the budget
     const int mid = lo + (hi - lo) / 2;
     if (items_at(mid) <= n_items) hi = mid;
