@@ -105,12 +105,18 @@ __device__ __forceinline__ int source_key(float x, float y, int H, int W, int ti
 
 __global__ void __launch_bounds__(256)
 bin_hist_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t n, int H, int W, int tile_h,
-                int tile_w, int tiles_x, int32_t* hist, int32_t* oob_count) {
+                int tile_w, int tiles_x, int32_t* hist, int32_t* oob_count, int32_t* __restrict__ rank) {
+  // rank (nullable): the value the histogram atomic returns is the event's rank inside its key -- kept, it saves the
+  // scatter pass its own 10 M atomics on a cursor array
   int bad = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int key = source_key(x[i], y[i], H, W, tile_h, tile_w, tiles_x);
-    if (key >= 0) atomicAdd(&hist[key], 1);
-    else ++bad;
+    if (key >= 0) {
+      const int32_t r = atomicAdd(&hist[key], 1);
+      if (rank != nullptr) rank[i] = r;
+    } else {
+      ++bad;
+    }
   }
   if (oob_count != nullptr && bad) atomicAdd(oob_count, bad);
 }
@@ -223,14 +229,14 @@ struct alignas(32) EventRecord {
 __global__ void __launch_bounds__(256)
 bin_scatter_records_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dt,
                            const float* __restrict__ p, int64_t n, int H, int W, int tile_h, int tile_w, int tiles_x,
-                           const int32_t* __restrict__ key_offsets, int32_t* cursor, EventRecord* __restrict__ rec,
-                           int32_t* frac_count) {
+                           const int32_t* __restrict__ key_offsets, const int32_t* __restrict__ rank,
+                           EventRecord* __restrict__ rec, int32_t* frac_count) {
   int fractional = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float ex = x[i], ey = y[i];
     const int key = source_key(ex, ey, H, W, tile_h, tile_w, tiles_x);
     if (key < 0) continue;
-    const int32_t pos = key_offsets[key] + atomicAdd(&cursor[key], 1);
+    const int32_t pos = key_offsets[key] + rank[i];
     EventRecord r;
     r.x = ex;
     r.y = ey;
@@ -497,7 +503,8 @@ size_t ebos_bin_scratch_bytes(int64_t n_keys) {
 size_t ebos_bin_scratch_bytes_events(int64_t n, int H, int W, int tile_h, int tile_w) {
   if (n < 0 || H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0) return 0;
   const int64_t n_keys = (int64_t)((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w) * tile_h * tile_w;
-  return ebos_bin_scratch_bytes(n_keys) + (size_t)(n > 0 ? n : 1) * sizeof(ebos::EventRecord) + 256;
+  // + one 32-byte record and one 4-byte rank per event
+  return ebos_bin_scratch_bytes(n_keys) + (size_t)(n > 0 ? n : 1) * (sizeof(ebos::EventRecord) + 4) + 512;
 }
 
 int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const float* p, int64_t n, int H, int W,
@@ -526,19 +533,22 @@ int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const f
     set_error("ebos_bin_events: hipMemsetAsync failed");
     return EBOS_ERR_LAUNCH;
   }
+  // with the larger scratch of ebos_bin_scratch_bytes_events: ranks from the histogram pass, 32-byte records scattered
+  // without atomics, then unpacked to the SoA arrays
+  const size_t rec_off = (ebos_bin_scratch_bytes(n_keys) + 255) & ~(size_t)255;
+  const bool records = scratch_bytes >= ebos_bin_scratch_bytes_events(n, H, W, tile_h, tile_w);
+  EventRecord* rec = reinterpret_cast<EventRecord*>(reinterpret_cast<char*>(scratch) + rec_off);
+  int32_t* rank = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + rec_off +
+                                             (((size_t)(n > 0 ? n : 1) * sizeof(EventRecord) + 255) & ~(size_t)255));
   if (n > 0)
     bin_hist_kernel<<<dim3(stream_grid(n, 256)), dim3(256), 0, s>>>(x, y, n, H, W, tile_h, tile_w, tiles_x, key_offsets,
-                                                                   oob_count);
+                                                                   oob_count, records ? rank : nullptr);
   scan_tiles_kernel<<<dim3(nblk), dim3(kScanBlock), 0, s>>>(key_offsets, n_keys, block_sums);
   scan_block_sums_kernel<<<dim3(1), dim3(kScanBlock), 0, s>>>(block_sums, nblk, key_offsets + n_keys);
   scan_add_offsets_kernel<<<dim3(nblk), dim3(kScanBlock), 0, s>>>(key_offsets, n_keys, block_sums);
-  // with the larger scratch of ebos_bin_scratch_bytes_events: scatter 32-byte records, then unpack them to the SoA arrays
-  const size_t rec_off = (ebos_bin_scratch_bytes(n_keys) + 255) & ~(size_t)255;
-  const bool records = scratch_bytes >= ebos_bin_scratch_bytes_events(n, H, W, tile_h, tile_w);
   if (n > 0 && records) {
-    EventRecord* rec = reinterpret_cast<EventRecord*>(reinterpret_cast<char*>(scratch) + rec_off);
     bin_scatter_records_kernel<<<dim3(stream_grid(n, 256)), dim3(256), 0, s>>>(x, y, dt, p, n, H, W, tile_h, tile_w, tiles_x,
-                                                                              key_offsets, cursor, rec, frac_count);
+                                                                              key_offsets, rank, rec, frac_count);
     unpack_records_kernel<<<dim3(stream_grid(n, 256)), dim3(256), 0, s>>>(rec, key_offsets + n_keys, xs, ys, dts, ps, perm);
   } else if (n > 0) {
     bin_scatter_kernel<<<dim3(stream_grid(n, 256)), dim3(256), 0, s>>>(x, y, dt, p, n, H, W, tile_h, tile_w, tiles_x,
