@@ -92,7 +92,7 @@ class RawEventStore(object):
         """Page-lock the four columns once (9 B/event of host memory): every later window upload is then a plain
         asynchronous DMA from the recording itself -- no per-window staging buffer, no pinned allocation (tens of
         milliseconds each) on the ingest path."""
-        if self._pinned is None:
+        if not self._pinned:
             _hip.require_gpu()
             self._pinned = {k: torch.from_numpy(self.event_data[k].view(np.uint8) if k == "p" else self.event_data[k]).pin_memory()
                             for k in ("x", "y", "t", "p")}
@@ -102,9 +102,18 @@ class RawEventStore(object):
         """(col int16, row int16, t int32|int64, pol uint8) of the window on ``device``: asynchronous copies on the
         current stream straight from the page-locked columns (9 B/event)."""
         self._check(start_index, end_index)
-        self.pin()
         dev = torch.device(device)
-        return tuple(self._pinned[k][start_index:end_index].to(dev, non_blocking=True) for k in ("x", "y", "t", "p"))
+        if self._pinned is None:
+            try:
+                self.pin()
+            except RuntimeError as err:  # recording too large to page-lock whole: stage window by window instead
+                logger.warning(f"could not page-lock the recording ({err}); staging every window separately")
+                self._pinned = False
+        if self._pinned:
+            return tuple(self._pinned[k][start_index:end_index].to(dev, non_blocking=True) for k in ("x", "y", "t", "p"))
+        sl = slice(start_index, end_index)
+        cols = (torch.from_numpy(self.event_data[k][sl].view(np.uint8) if k == "p" else self.event_data[k][sl]) for k in "xytp")
+        return tuple(c.pin_memory().to(dev, non_blocking=True) for c in cols)
 
     def plan(self, start_index: int, end_index: int, image_size: Tuple[int, int], direction="first",
              normalize_t: bool = True, tile="auto", device="cuda", deferred: bool = False) -> EventPlan:
