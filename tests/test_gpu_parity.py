@@ -824,6 +824,25 @@ def test_fuzz_fused_path_against_oracle(ebos):
             gn = float(ft.grad.detach().norm())
             if gn > 0 and amp > 0:  # at zero flow every event sits on the kink of the bilinear vote
                 assert float((fg.grad.cpu().double() - ft.grad).norm()) / gn < 1e-3, tag
+        # per-event weights (f64 LDS accumulators, weights and their gradient in input order)
+        if case % 3 == 0:
+            wts = rs.uniform(-1.0, 2.0, n)
+            wt = torch.from_numpy(wts).requires_grad_(True)
+            ft2 = torch.from_numpy(flow).requires_grad_(True)
+            exp_w = O.iwe_dense(tev, ft2, (h, w), pad=(pad, pad), direction=direction, weight=wt)
+            probe = torch.from_numpy(rs.normal(size=tuple(exp_w.shape)))
+            (exp_w * probe).sum().backward()
+            wg = G(wts).float().requires_grad_(True)
+            fg2 = G(flow).float().requires_grad_(True)
+            got_w = plan.iwe_dense(fg2, pad=(pad, pad), weight=wg, halo=halo, splits=splits)
+            assert float((got_w.detach().cpu().double() - exp_w.detach()).norm()) / max(float(exp_w.detach().norm()), 1e-12) < 1e-4, tag
+            (got_w * G(probe.numpy()).float()).sum().backward()
+            assert float((wg.grad.cpu().double() - wt.grad).norm()) / max(float(wt.grad.norm()), 1e-12) < 1e-3, tag
+            if amp > 0 and float(ft2.grad.norm()) > 0:
+                # a random upstream image makes every f32 floor flip visible; beyond the +-30 px of the benchmark
+                # configurations the f32 displacement carries ~1e-5 px of rounding: allow 5e-3 there
+                tol = 1e-3 if amp <= 40.0 else 5e-3
+                assert float((fg2.grad.cpu().double() - ft2.grad).norm()) / float(ft2.grad.norm()) < tol, tag
         # the 2-DoF model through the same tile-private kernels (UNIFORM variant)
         theta = rs.uniform(-amp - 1, amp + 1, 2)
         exp2 = O.iwe_2dof(tev, torch.from_numpy(theta), (h, w), pad=(pad, pad), direction=direction)
