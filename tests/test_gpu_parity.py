@@ -848,3 +848,86 @@ def test_fuzz_fused_path_against_oracle(ebos):
         exp2 = O.iwe_2dof(tev, torch.from_numpy(theta), (h, w), pad=(pad, pad), direction=direction)
         got2 = plan.iwe_2dof(G(theta[None]).float(), pad=(pad, pad), halo=halo, splits=splits)[0]
         assert float((got2.cpu().double() - exp2).norm()) / max(float(exp2.norm()), 1e-12) < 1e-4, tag
+
+
+def test_fuzz_plugin_surface_against_oracle(ebos):
+    """Seeded fuzz of the drop-in layer (Warp.warp_event + EventImageConverter.create_iwe) over what a caller can vary:
+    numpy / torch (CPU and GPU) inputs, f32 / f64, batched / un-batched, every direction, normalize_t, dense and 2-DoF
+    models, image methods, scalar / per-event weights, padding, blur.  Warped events BIT-EXACT on equal dtype (f64: same
+    op order), images rel-L2 <= 1e-12 in f64 and < 1e-5 in f32; output type, dtype and device follow the input."""
+    rs = np.random.RandomState(77)
+    for case in range(48):
+        h, w = int(rs.randint(8, 40)), int(rs.randint(8, 50))
+        n = int(rs.choice([2, 3, 50, 400]))
+        batched = bool(rs.randint(2))
+        b = int(rs.randint(1, 4)) if batched else 1
+        dtype = [np.float64, np.float32][rs.randint(2)]
+        kind = ["numpy", "torch_cpu", "torch_gpu"][rs.randint(3)]
+        model = ["dense-flow", "2d-translation"][rs.randint(2)] if not batched else "dense-flow"  # 2-DoF is un-batched only
+        direction = ["first", "middle", "last", 0.7, "before", "after"][rs.randint(6)]
+        norm_t = bool(rs.randint(2))
+        pad = int(rs.choice([0, 2]))
+        evs = np.stack([np.stack([rs.uniform(0, h - 1e-3, n), rs.uniform(0, w - 1e-3, n), np.sort(rs.uniform(1.0, 1.4, n)),
+                                  rs.randint(0, 2, n).astype(float)], 1) for _ in range(b)]).astype(dtype)
+        flow = rs.uniform(-4, 4, (b, 2, h, w)).astype(dtype)
+        theta = rs.uniform(-4, 4, 2).astype(dtype)
+        if not batched:
+            evs, flow = evs[0], flow[0]
+        tag = f"case {case}: {h}x{w} n {n} b {b if batched else None} {dtype.__name__} {kind} {model} {direction} norm {norm_t} pad {pad}"
+
+        def give(a):
+            if kind == "numpy":
+                return a
+            t = torch.from_numpy(a)
+            return t.cuda() if kind == "torch_gpu" else t
+
+        def back(v):
+            return v if isinstance(v, np.ndarray) else v.detach().cpu().numpy()
+
+        warper = ebos.Warp((h, w), normalize_t=norm_t)
+        motion = flow if model == "dense-flow" else theta
+        warped, feat = warper.warp_event(give(evs), give(motion), model, direction=direction)
+        assert set(feat) == {"iwe", "iwe_var", "iwe_grad", "time_image", "time_image_var"} or isinstance(feat, dict), tag
+        assert isinstance(warped, np.ndarray) == (kind == "numpy"), tag
+        if kind == "torch_gpu":
+            assert warped.is_cuda, tag
+        if model == "dense-flow":
+            if kind == "numpy":
+                expect = O.warp_dense_numpy(evs, flow, direction, norm_t)
+            else:
+                expect = O.warp_dense_torch(torch.from_numpy(evs), torch.from_numpy(flow), direction, norm_t).numpy()
+        else:
+            expect = back(O.warp_2dof(evs if kind == "numpy" else torch.from_numpy(evs), theta if kind == "numpy" else torch.from_numpy(theta),
+                                      direction, norm_t))
+        got = back(warped)
+        assert got.dtype == dtype and got.shape == expect.shape, (tag, got.shape, expect.shape)
+        assert np.array_equal(got, expect), (tag, float(np.abs(got - expect).max()))  # BIT-EXACT
+        # images of the warped events
+        ic = ebos.EventImageConverter((h, w), outer_padding=pad)
+        method = ["bilinear_vote", "count", "polarity"][rs.randint(3)]
+        sigma = int(rs.choice([0, 0, 1]))
+        per_event = bool(rs.randint(2)) and method != "count"
+        if kind != "numpy":
+            if method == "polarity":
+                method = "bilinear_vote"  # the tensor branch has bilinear_vote and count (src/event_image_converter.py:383-397)
+        wt = rs.uniform(0.5, 1.5, got.shape[:-1]).astype(dtype) if per_event else 1.0
+        if kind == "numpy":
+            img = ic.create_image_from_events_numpy(got, method, weight=wt, sigma=sigma)
+            exp_img = O.create_image_numpy(expect, (h + 2 * pad, w + 2 * pad), (pad, pad), method, wt, sigma)
+        else:
+            wtt = give(wt) if per_event else 1.0
+            img = ic.create_image_from_events_tensor(give(got), method, weight=wtt, sigma=sigma)
+            te = torch.from_numpy(expect)
+            if method == "count":
+                exp_img = O.count_events_torch(te, (h + 2 * pad, w + 2 * pad), (pad, pad))
+            else:
+                exp_img = O.bilinear_vote_torch(te, (h + 2 * pad, w + 2 * pad), (pad, pad), torch.from_numpy(wt) if per_event else 1.0)
+            if sigma > 0:
+                exp_img = O.gaussian_blur3_torch(exp_img, float(sigma))
+            exp_img = exp_img.numpy()
+        gi = back(img)
+        assert gi.shape == exp_img.shape, (tag, method, gi.shape, exp_img.shape)
+        # f64 inputs: same arithmetic, atomics only reorder the sum.  f32 inputs: the reference forms the four weights in
+        # f32 (numpy: then sums them into an f64 image); the kernels form them in the image's precision
+        tol = 1e-12 if dtype == np.float64 else 1e-5
+        assert rel(gi, exp_img) <= tol, (tag, method, sigma, rel(gi, exp_img))
