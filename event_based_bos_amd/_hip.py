@@ -96,7 +96,8 @@ SIGNATURES = {
     "ebos_upsample_bwd_scratch_bytes": (_Z, [_I, _I]),
     "ebos_upsample_patch_flow_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "ebos_flow_regularisers_partials": (_I, []),
-    "ebos_flow_regularisers_f32": (_I, [_P, _I, _I, _F, _F, _P, _P, _P]),
+    "ebos_flow_regularisers_f32": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _L, _L, _P, _P, _P]),
+    "ebos_iwe_slab_partials": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "ebos_cmax_adam_step_f32": (_I, [_P, _P, _P, _P, _I, _D, _D, _D, _D, _P, _P, _F, _P, _I, _P, _I, _P]),
     "ebos_cmax_patch_solve_f32": (_I, [_P, _I, _P]),
     "ebos_cmax_patch_solve_many_f32": (_I, [_P, _P, _I, _I]),

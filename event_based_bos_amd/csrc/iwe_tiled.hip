@@ -1172,7 +1172,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
                                                                             want_var ? partials : nullptr,
                                                                             splits == 0 ? ev.part_off : nullptr);
   }
-  if (want_var) {
+  if (want_var == 1) {  // want_var == 2: the caller reduces the partials itself (ebos_iwe_slab_partials)
     const int lo = omit ? 1 : 0;
     const int64_t m = (int64_t)(L.h - 2 * lo > 0 ? L.h - 2 * lo : 0) * (L.w - 2 * lo > 0 ? L.w - 2 * lo : 0);
     moments_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, nparts, m, out_var, moments);
@@ -1247,6 +1247,22 @@ int ebos_slab_config(int* out, int cap) {
   return kNumSlabConfigs;
 }
 
+int ebos_iwe_slab_partials(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w, int omit_boundary,
+                           size_t* offset_bytes, int64_t* n_partials, int64_t* n_pixels) {
+  using namespace ebos;
+  EBOS_REQUIRE(offset_bytes && n_partials && n_pixels, "ebos_iwe_slab_partials: NULL output");
+  EBOS_REQUIRE(H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && halo >= 0 && splits >= 0 && pad_h >= 0 && pad_w >= 0,
+               "ebos_iwe_slab_partials: bad sizes");
+  const SlabLayout L = slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w);
+  *offset_bytes = L.off_partials;
+  // the grid of the combine pass that ebos_iwe_*_slab_f32 launches for this geometry (one partial pair per workgroup)
+  if (L.w % 4 == 0 && pad_w % 4 == 0) *n_partials = (int64_t)((L.w / 4 + 63) / 64) * ((L.h + kCombineRows - 1) / kCombineRows);
+  else *n_partials = (int64_t)((L.w + kCombineBlock - 1) / kCombineBlock) * L.h;
+  const int lo = omit_boundary ? 1 : 0;
+  *n_pixels = (int64_t)(L.h - 2 * lo > 0 ? L.h - 2 * lo : 0) * (L.w - 2 * lo > 0 ? L.w - 2 * lo : 0);
+  return EBOS_OK;
+}
+
 size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w) {
   using namespace ebos;
   if (H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0 || halo < 0 || splits < 0 || pad_h < 0 || pad_w < 0) return 0;
@@ -1265,7 +1281,7 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64,
                "ebos_iwe_dense_slab: bad sizes (splits=%d)", splits);
   EBOS_REQUIRE(splits != 0 || part_table, "ebos_iwe_dense_slab: splits = 0 (adaptive work items) needs the plan's part_table");
-  EBOS_REQUIRE(!want_variance || out_variance || moments, "ebos_iwe_dense_slab: variance requested without an output");
+  EBOS_REQUIRE(want_variance != 1 || out_variance || moments, "ebos_iwe_dense_slab: variance requested without an output");
   if (!slab_config_ok(tile_h, tile_w, halo)) {
     set_error("ebos_iwe_dense_slab: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
     return EBOS_ERR_UNSUPPORTED;

@@ -38,6 +38,16 @@ __device__ __forceinline__ float tv_adjoint(const float* f, int i, int n, int64_
   return g;
 }
 
+// Optional side job of the regulariser pass: turn the (sum, sum of squares) partials that the slab combine pass left
+// (ebos_iwe_dense_slab_f32 with want_variance = 2) into the variance and (mean, M) -- what moments_finalize_kernel does
+// in a launch of its own (4.7 us at the launch floor, plus a gap).  Same summation order: same result.
+struct MomentsJob {
+  const double* partials;  // nullptr = no side job
+  int64_t n_partials, n_pixels;
+  float* out_var;
+  double* moments;
+};
+
 struct RegGrad {
   float gu, gv;
   double val;
@@ -73,7 +83,7 @@ __device__ __forceinline__ RegGrad reg_at(const float* __restrict__ flow, int r,
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
 flow_regularisers_kernel(const float* __restrict__ flow, int H, int W, float w_norm, float w_tv, float* __restrict__ d_flow,
-                         double* __restrict__ partials) {
+                         double* __restrict__ partials, MomentsJob mj) {
   const int64_t hw = (int64_t)H * W;
   const float s_norm = w_norm / (float)hw, s_tv = w_tv / (float)(2 * hw);
   const int col_blocks = (W + 1023) / 1024;
@@ -118,6 +128,24 @@ flow_regularisers_kernel(const float* __restrict__ flow, int H, int W, float w_n
   __shared__ double red[256 / kWave];
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  if (mj.partials != nullptr && blockIdx.x == gridDim.x - 1) {  // side job of one workgroup: the variance of the IWE
+    double s = 0.0, ss = 0.0;
+    for (int64_t i = threadIdx.x; i < mj.n_partials; i += blockDim.x) {
+      s += mj.partials[2 * i];
+      ss += mj.partials[2 * i + 1];
+    }
+    __syncthreads();
+    s = block_sum(s, red);
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+      const double mean = mj.n_pixels > 0 ? s / (double)mj.n_pixels : 0.0;
+      if (mj.out_var) mj.out_var[0] = (float)((ss - s * mean) / (double)(mj.n_pixels - 1));
+      if (mj.moments) {
+        mj.moments[0] = mean;
+        mj.moments[1] = (double)mj.n_pixels;
+      }
+    }
+  }
 }
 
 // One workgroup.  loss[t] = contrast_scale * contrast + sum(reg_partials) is recorded for the parameters BEFORE the
@@ -160,18 +188,22 @@ extern "C" {
 int ebos_flow_regularisers_partials(void) { return ebos::kRegGrid; }
 
 int ebos_flow_regularisers_f32(const float* flow, int H, int W, float w_flow_norm, float w_image_gradient, float* d_flow,
-                               double* partials, ebos_stream_t stream) {
+                               double* partials, const double* var_partials, int64_t n_var_partials, int64_t n_var_pixels,
+                               float* out_variance, double* moments, ebos_stream_t stream) {
   using namespace ebos;
+  EBOS_REQUIRE(var_partials == nullptr || (n_var_partials >= 1 && n_var_pixels >= 2 && (out_variance || moments)),
+               "ebos_flow_regularisers: bad variance side job");
+  const MomentsJob mj{var_partials, n_var_partials, n_var_pixels, out_variance, moments};
   EBOS_REQUIRE(flow && d_flow && partials && flow != d_flow, "ebos_flow_regularisers: NULL or aliased buffers");
   EBOS_REQUIRE(H >= 1 && W >= 1, "ebos_flow_regularisers: bad sizes");
   EBOS_REQUIRE(w_image_gradient == 0.0f || (H >= 2 && W >= 2),
                "ebos_flow_regularisers: image_gradient needs at least 2 samples per axis (torch.gradient)");
   if (W % 4 == 0)
     flow_regularisers_kernel<true><<<dim3(kRegGrid), dim3(256), 0, as_stream(stream)>>>(flow, H, W, w_flow_norm, w_image_gradient,
-                                                                                       d_flow, partials);
+                                                                                       d_flow, partials, mj);
   else
     flow_regularisers_kernel<false><<<dim3(kRegGrid), dim3(256), 0, as_stream(stream)>>>(flow, H, W, w_flow_norm,
-                                                                                        w_image_gradient, d_flow, partials);
+                                                                                        w_image_gradient, d_flow, partials, mj);
   EBOS_CHECK_LAUNCH("ebos_flow_regularisers");
   return EBOS_OK;
 }
@@ -211,10 +243,18 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, ebos_stream_
   if (rc) return rc;
   rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
                                q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->workspace,
-                               q->workspace_bytes, q->iwe, 1, q->omit_boundary, q->variance, q->moments, q->part_table, stream);
+                               q->workspace_bytes, q->iwe, has_reg ? 2 : 1, q->omit_boundary, q->variance, q->moments, q->part_table,
+                               stream);
   if (rc) return rc;
-  if (has_reg) {
-    rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials, stream);
+  if (has_reg) {  // the regulariser pass also reduces the variance moments the combine pass left (no finalize launch)
+    size_t off = 0;
+    int64_t n_parts = 0, n_px = 0;
+    rc = ebos_iwe_slab_partials(q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->omit_boundary, &off,
+                                &n_parts, &n_px);
+    if (rc) return rc;
+    rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials,
+                                    reinterpret_cast<const double*>(static_cast<const char*>(q->workspace) + off), n_parts, n_px,
+                                    q->variance, q->moments, stream);
     if (rc) return rc;
   }
   rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,

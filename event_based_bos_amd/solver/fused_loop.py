@@ -2,11 +2,11 @@
 
 One iteration of the loop in src/solver/generative_max_likelihood.py:306-341 (zero_grad -> objective -> backward ->
 optimizer.step) for the objective  ``-w * var(IWE(dense(theta))) + w_n * flow_norm(dense) + w_g * image_gradient(dense)``
-is six C-ABI calls / ten kernels on one stream, all on buffers allocated once per window:
+is six C-ABI calls / nine kernels on one stream, all on buffers allocated once per window:
 
     ebos_upsample_patch_flow_f32      theta [2, gh, gw] -> dense [2, H, W]
-    ebos_iwe_dense_slab_f32           dense -> IWE, variance, (mean, M)          (3 kernels)
-    ebos_flow_regularisers_f32        dense -> regulariser value partials + gradient image
+    ebos_iwe_dense_slab_f32           dense -> IWE + variance partials           (2 kernels; 3 without regularisers)
+    ebos_flow_regularisers_f32        dense -> regulariser value partials + gradient image; variance, (mean, M)
     ebos_iwe_dense_tiled_bwd_f32      -> d loss / d dense  (variance gradient folded in, regulariser gradient added)
     ebos_upsample_patch_flow_bwd_f32  -> d loss / d theta                        (2 kernels)
     ebos_cmax_adam_step_f32           loss[it] recorded, theta / exp_avg / exp_avg_sq / step updated
@@ -66,6 +66,12 @@ class FusedPatchLoop(object):
         self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.graphed = False
+        import ctypes as C
+        off, n_parts, n_px = C.c_size_t(), C.c_int64(), C.c_int64()
+        check(self.lib.ebos_iwe_slab_partials(H, W, plan.tile[0], plan.tile[1], self.halo, self.splits, self.pad[0], self.pad[1],
+                                              int(self.omit), C.byref(off), C.byref(n_parts), C.byref(n_px)),
+              "ebos_iwe_slab_partials")
+        self._var_partials = (off.value, n_parts.value, n_px.value)
 
     def iteration(self) -> None:
         lib, plan, s = self.lib, self.plan, stream_ptr()
@@ -76,11 +82,13 @@ class FusedPatchLoop(object):
         check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                           ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
                                           self.halo, self.splits, self.pad[0], self.pad[1], ptr(self.ws), self.ws.numel(),
-                                          ptr(self.iwe), 1, int(self.omit), ptr(self.variance), ptr(self.moments),
-                                          ptr(plan.part_table), s), "ebos_iwe_dense_slab")
-        if self.has_reg:
+                                          ptr(self.iwe), 2 if self.has_reg else 1, int(self.omit), ptr(self.variance),
+                                          ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_dense_slab")
+        if self.has_reg:  # ... which also reduces the variance partials of the combine pass (no finalize launch)
+            off, n_parts, n_px = self._var_partials
             check(lib.ebos_flow_regularisers_f32(ptr(self.dense), H, W, self.w_norm, self.w_tv, ptr(self.d_reg),
-                                                 ptr(self.reg_partials), s), "ebos_flow_regularisers")
+                                                 ptr(self.reg_partials), self.ws.data_ptr() + off, n_parts, n_px,
+                                                 ptr(self.variance), ptr(self.moments), s), "ebos_flow_regularisers")
         check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                                ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
                                                self.halo, self.pad[0], self.pad[1], ptr(self.iwe), None, int(self.omit),

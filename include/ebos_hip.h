@@ -284,6 +284,8 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  *   OVERWRITES iwe [h, w] (no caller-side zeroing) and, if want_variance, also reduces the variance of
  *   the image (omit_boundary as in the costs) into out_variance [1] (f32, nullable) and
  *   moments [2] = (mean, M) (f64, nullable) -- the contrast cost of SURVEY.md A14 at no extra pass.
+ *   want_variance = 2: only the (sum, sum of squares) partials are left in the workspace (ebos_iwe_slab_partials),
+ *   no finalize launch; out_variance / moments are not touched.
  *   workspace: >= ebos_iwe_slab_workspace_bytes(...) bytes, ZERO-FILLED ONCE by the caller when it is
  *   allocated; the kernels keep its spill section (taps beyond the halo) zero between calls.
  *   Results are deterministic (fixed summation order) except for taps beyond the halo.
@@ -308,6 +310,11 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
 int ebos_slab_config(int* out, int cap);
 size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h,
                                      int pad_w);
+/* want_variance = 2 in ebos_iwe_dense_slab_f32 / ebos_iwe_2dof_slab_f32 leaves the variance as (sum, sum of squares)
+ * partials in the workspace and skips the finalize launch; this (host-only) call tells where they are: byte offset
+ * inside the workspace, number of partial pairs, and the pixel count M the variance refers to. */
+int ebos_iwe_slab_partials(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w,
+                           int omit_boundary, size_t* offset_bytes, int64_t* n_partials, int64_t* n_pixels);
 int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight,
                             const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
@@ -442,6 +449,9 @@ int ebos_gauss1d_bwd_f64(const double* g_out, double* g_in, int64_t outer, int64
  *                                                                         torch.gradient, unit weights)
  *   flow [2, H, W]; d_flow [2, H, W] is OVERWRITTEN with the gradient; partials: device doubles,
  *   ebos_flow_regularisers_partials() of them, whose sum is the value (ebos_cmax_adam_step sums them).
+ *   var_partials (nullable) .. moments: a side job for one of its workgroups -- reduce the variance partials that
+ *   ebos_iwe_dense_slab_f32(want_variance = 2) left in its workspace (ebos_iwe_slab_partials locates them) into
+ *   out_variance / moments, instead of a finalize launch of its own.
  * ebos_cmax_adam_step_f32: torch.optim.Adam (amsgrad off, no weight decay) on theta[n] given grad[n],
  *   with state exp_avg[n], exp_avg_sq[n] and a device step counter step[1] (all zero-initialised by the
  *   caller); records losses[step] = contrast_scale * contrast[0] + sum(reg_partials) for the parameters
@@ -449,7 +459,8 @@ int ebos_gauss1d_bwd_f64(const double* g_out, double* g_in, int64_t outer, int64
  * ---------------------------------------------------------------------------------------- */
 int ebos_flow_regularisers_partials(void);
 int ebos_flow_regularisers_f32(const float* flow, int H, int W, float w_flow_norm, float w_image_gradient,
-                               float* d_flow, double* partials, ebos_stream_t stream);
+                               float* d_flow, double* partials, const double* var_partials, int64_t n_var_partials,
+                               int64_t n_var_pixels, float* out_variance, double* moments, ebos_stream_t stream);
 int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int n, double lr,
                             double beta1, double beta2, double eps, int* step, const float* contrast,
                             float contrast_scale, const double* reg_partials, int n_reg, float* losses,

@@ -625,7 +625,7 @@ def test_flow_regularisers_value_and_gradient(ebos, shape, w_norm, w_tv):
     d = torch.empty_like(fg)
     n_part = lib.ebos_flow_regularisers_partials()
     parts = torch.zeros(n_part, dtype=torch.float64, device=dev())
-    check(lib.ebos_flow_regularisers_f32(ptr(fg), h, w, w_norm, w_tv, ptr(d), ptr(parts), stream_ptr()), "reg")
+    check(lib.ebos_flow_regularisers_f32(ptr(fg), h, w, w_norm, w_tv, ptr(d), ptr(parts), None, 0, 0, None, None, stream_ptr()), "reg")
     assert abs(parts.sum().item() - val.item()) <= 1e-5 * abs(val.item())
     assert rel(d.cpu().numpy(), ft.grad.numpy()) < 1e-5
 
@@ -931,3 +931,38 @@ def test_fuzz_plugin_surface_against_oracle(ebos):
         # f32 (numpy: then sums them into an f64 image); the kernels form them in the image's precision
         tol = 1e-12 if dtype == np.float64 else 1e-5
         assert rel(gi, exp_img) <= tol, (tag, method, sigma, rel(gi, exp_img))
+
+
+@pytest.mark.parametrize("omit,pad", [(False, 0), (True, 2)])
+def test_variance_finalize_as_side_job_of_the_regulariser_pass(ebos, omit, pad):
+    """ebos_iwe_dense_slab_f32(want_variance = 2) leaves (sum, sum of squares) partials in the workspace
+    (ebos_iwe_slab_partials locates them); ebos_flow_regularisers_f32 reduces them as a side job.  Same summation order
+    as the finalize kernel: variance and (mean, M) BIT-EXACT."""
+    import ctypes as C
+
+    from event_based_bos_amd import event_plan as EP
+
+    h, w = 96, 128
+    ev = O.synth_events(40000, h, w, seed=61)
+    flow = G(O.synth_dense_flow(h, w, seed=62, max_val=5.0)).float()
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile="auto")
+    lib = ebos.load_library()
+    _, var1, mom1 = EP._launch_iwe_dense_slab(plan, flow, None, (pad, pad), 32, 1, True, omit)
+    ws = EP._workspace(plan, (pad, pad), 32, 1)
+    iwe = torch.empty((h + 2 * pad, w + 2 * pad), device=dev())
+    EP.check(lib.ebos_iwe_dense_slab_f32(EP.ptr(plan.x), EP.ptr(plan.y), EP.ptr(plan.dt), None, *plan._compact_ptrs(),
+                                         EP.ptr(plan.key_offsets), plan.n, EP.ptr(flow), h, w, plan.tile[0], plan.tile[1], 32, 1,
+                                         pad, pad, EP.ptr(ws), ws.numel(), EP.ptr(iwe), 2, int(omit), None, None, None,
+                                         EP.stream_ptr()), "slab")
+    off, n_parts, n_px = C.c_size_t(), C.c_int64(), C.c_int64()
+    EP.check(lib.ebos_iwe_slab_partials(h, w, plan.tile[0], plan.tile[1], 32, 1, pad, pad, int(omit), C.byref(off),
+                                        C.byref(n_parts), C.byref(n_px)), "partials")
+    lo = 1 if omit else 0
+    assert n_px.value == (h + 2 * pad - 2 * lo) * (w + 2 * pad - 2 * lo) and n_parts.value >= 1
+    d = torch.empty_like(flow)
+    parts = torch.zeros(lib.ebos_flow_regularisers_partials(), dtype=torch.float64, device=dev())
+    var2 = torch.zeros(1, device=dev())
+    mom2 = torch.zeros((1, 2), dtype=torch.float64, device=dev())
+    EP.check(lib.ebos_flow_regularisers_f32(EP.ptr(flow), h, w, 0.5, 0.25, EP.ptr(d), EP.ptr(parts), ws.data_ptr() + off.value,
+                                            n_parts.value, n_px.value, EP.ptr(var2), EP.ptr(mom2), EP.stream_ptr()), "reg")
+    assert torch.equal(var2, var1) and torch.equal(mom2, mom1)
