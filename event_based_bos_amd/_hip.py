@@ -95,6 +95,8 @@ SIGNATURES = {
     "ebos_upsample_patch_flow_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_upsample_bwd_scratch_bytes": (_Z, [_I, _I]),
     "ebos_upsample_patch_flow_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "ebos_upsample_patch_flow_bwd_adam_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _D, _D, _D, _D, _I, _P,
+                                                   _P, _F, _P, _I, _P, _I, _P]),
     "ebos_flow_regularisers_partials": (_I, []),
     "ebos_flow_regularisers_f32": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _L, _L, _P, _P, _P]),
     "ebos_iwe_slab_partials": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
@@ -117,7 +119,8 @@ class CmaxPatchProblem(C.Structure):
                 [(k, _I) for k in ("gh", "gw", "patch_h", "patch_w", "slide_h", "slide_w")] +
                 [(k, _F) for k in ("w_variance", "w_flow_norm", "w_image_gradient")] +
                 [(k, _D) for k in ("lr", "beta1", "beta2", "eps")] +
-                [(k, _P) for k in ("theta", "d_theta", "exp_avg", "exp_avg_sq", "step", "dense", "d_dense", "d_reg", "iwe",
+                [(k, _P) for k in ("theta", "d_theta", "exp_avg", "exp_avg_sq", "step")] + [("steps_done", _I)] +
+                [(k, _P) for k in ("dense", "d_dense", "d_reg", "iwe",
                                    "variance", "moments", "upstream", "reg_partials", "upsample_scratch", "workspace")] +
                 [("workspace_bytes", _Z), ("losses", _P), ("losses_cap", _I)])
 

@@ -9,6 +9,8 @@
 //     padded index i -> grid index clamp(i - pad, 0, g - 1)                      (replicate pad)
 // with R = r + (n_full / 2 - H / 2) the row in the un-cropped resize output.
 // The 2 x 30 x 40 grid of BASELINE config 4 lives in L1/L2; the kernel is a pure 7.4 MB store.
+#include <math.h>
+
 #include "common.h"
 
 namespace ebos {
@@ -121,11 +123,39 @@ upsample_bwd_rows_kernel(const float* __restrict__ d_dense, Axis ay, int H, int 
   if (phase == 0 && c < W) S[((int64_t)ch * ay.g + gi) * W + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// Adam is element-wise: the wavefront that has just produced d loss / d theta[i] can apply the update of theta[i] on
+// the spot -- the optimiser step of the solver loop costs no launch of its own (torch.optim.Adam semantics, amsgrad off,
+// no weight decay; the bias corrections of step t are computed on the host in double, as torch does).  One wavefront
+// also records the loss of the iteration.
+struct AdamJob {
+  float *theta, *exp_avg, *exp_avg_sq;  // theta == nullptr: plain adjoint
+  float step_size, bc2_sqrt, beta2, w1, w2, eps;
+  int t;
+  int* step;
+  const float* contrast;
+  float contrast_scale;
+  const double* reg_partials;
+  int n_reg;
+  float* losses;
+  int losses_cap;
+};
+
 // pass 2: one wavefront per grid cell, lanes stride over the cell's column support
 __global__ void __launch_bounds__(256)
-upsample_bwd_cols_kernel(const float* __restrict__ S, Axis ay, Axis ax, int W, float* __restrict__ d_grid) {
+upsample_bwd_cols_kernel(const float* __restrict__ S, Axis ay, Axis ax, int W, float* __restrict__ d_grid, AdamJob job) {
   const int lane = threadIdx.x & 63;
   const int gj = blockIdx.x * 4 + (threadIdx.x >> 6), gi = blockIdx.y, ch = blockIdx.z;
+  if (job.theta != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
+    // loss of this iteration (parameters BEFORE the update) = contrast_scale * contrast + sum(regulariser partials)
+    double reg = 0.0;
+    for (int i = lane; i < job.n_reg; i += 64) reg += job.reg_partials[i];
+    reg = wave_sum(reg);
+    if (lane == 0) {
+      if (job.losses != nullptr && job.t - 1 < job.losses_cap)
+        job.losses[job.t - 1] = (float)((double)job.contrast_scale * (double)(job.contrast ? job.contrast[0] : 0.0f) + reg);
+      job.step[0] = job.t;
+    }
+  }
   if (gj >= ax.g) return;
   int c_lo, c_hi;
   support(ax, gj, W, &c_lo, &c_hi);
@@ -133,7 +163,19 @@ upsample_bwd_cols_kernel(const float* __restrict__ S, Axis ay, Axis ax, int W, f
   float acc = 0.0f;
   for (int c = c_lo + lane; c < c_hi; c += 64) acc += weight_on(ax, c, gj) * s[c];
   acc = wave_sum(acc);
-  if (lane == 0) d_grid[((int64_t)ch * ay.g + gi) * ax.g + gj] = acc;
+  if (lane == 0) {
+    const int64_t i = ((int64_t)ch * ay.g + gi) * ax.g + gj;
+    d_grid[i] = acc;
+    if (job.theta != nullptr) {
+      const float g = acc;
+      const float mi = job.exp_avg[i] + job.w1 * (g - job.exp_avg[i]);      // exp_avg.lerp_(grad, 1 - beta1)
+      const float vi = job.exp_avg_sq[i] * job.beta2 + job.w2 * (g * g);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      job.exp_avg[i] = mi;
+      job.exp_avg_sq[i] = vi;
+      const float denom = sqrtf(vi) / job.bc2_sqrt + job.eps;               // (exp_avg_sq.sqrt() / sqrt(bias_correction2)) + eps
+      job.theta[i] = job.theta[i] - job.step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value = -step_size)
+    }
+  }
 }
 
 }  // namespace
@@ -162,8 +204,8 @@ size_t ebos_upsample_bwd_scratch_bytes(int gh, int W) {
   return gh > 0 && W > 0 ? (size_t)2 * gh * W * sizeof(float) : 0;
 }
 
-int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w, int slide_h,
-                                     int slide_w, int H, int W, float* scratch, float* d_grid, ebos_stream_t stream) {
+static int upsample_bwd_impl(const float* d_dense, int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w, int H,
+                            int W, float* scratch, float* d_grid, const ebos::AdamJob& job, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(d_dense && d_grid && scratch, "ebos_upsample_patch_flow_bwd: NULL d_dense/d_grid/scratch");
   EBOS_REQUIRE(gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 && slide_h > 0 && slide_w > 0 && H > 0 && W > 0,
@@ -172,9 +214,46 @@ int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int p
   EBOS_REQUIRE(ay.off >= 0 && ax.off >= 0, "ebos_upsample_patch_flow_bwd: image larger than the resized grid");
   hipStream_t s = as_stream(stream);
   upsample_bwd_rows_kernel<<<dim3((W + 63) / 64, gh, 2), dim3(256), 0, s>>>(d_dense, ay, H, W, scratch);
-  upsample_bwd_cols_kernel<<<dim3((gw + 3) / 4, gh, 2), dim3(256), 0, s>>>(scratch, ay, ax, W, d_grid);
+  upsample_bwd_cols_kernel<<<dim3((gw + 3) / 4, gh, 2), dim3(256), 0, s>>>(scratch, ay, ax, W, d_grid, job);
   EBOS_CHECK_LAUNCH("ebos_upsample_patch_flow_bwd");
   return EBOS_OK;
+}
+
+int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w, int slide_h,
+                                     int slide_w, int H, int W, float* scratch, float* d_grid, ebos_stream_t stream) {
+  return upsample_bwd_impl(d_dense, gh, gw, patch_h, patch_w, slide_h, slide_w, H, W, scratch, d_grid, ebos::AdamJob{}, stream);
+}
+
+int ebos_upsample_patch_flow_bwd_adam_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w, int slide_h,
+                                          int slide_w, int H, int W, float* scratch, float* d_grid, float* theta, float* exp_avg,
+                                          float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int t, int* step,
+                                          const float* contrast, float contrast_scale, const double* reg_partials, int n_reg,
+                                          float* losses, int losses_cap, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(theta && exp_avg && exp_avg_sq && step, "ebos_upsample_patch_flow_bwd_adam: NULL optimiser buffer");
+  EBOS_REQUIRE(t >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
+               "ebos_upsample_patch_flow_bwd_adam: bad hyper-parameters (t = %d)", t);
+  EBOS_REQUIRE(n_reg >= 0 && (n_reg == 0 || reg_partials) && losses_cap >= 0, "ebos_upsample_patch_flow_bwd_adam: bad loss bookkeeping");
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  AdamJob job{};
+  job.theta = theta;
+  job.exp_avg = exp_avg;
+  job.exp_avg_sq = exp_avg_sq;
+  job.step_size = (float)(lr / bc1);
+  job.bc2_sqrt = (float)sqrt(bc2);
+  job.beta2 = (float)beta2;
+  job.w1 = (float)(1.0 - beta1);
+  job.w2 = (float)(1.0 - beta2);
+  job.eps = (float)eps;
+  job.t = t;
+  job.step = step;
+  job.contrast = contrast;
+  job.contrast_scale = contrast_scale;
+  job.reg_partials = reg_partials;
+  job.n_reg = n_reg;
+  job.losses = losses;
+  job.losses_cap = losses_cap;
+  return upsample_bwd_impl(d_dense, gh, gw, patch_h, patch_w, slide_h, slide_w, H, W, scratch, d_grid, job, stream);
 }
 
 }  // extern "C"

@@ -226,7 +226,7 @@ int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, flo
 
 static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
   using namespace ebos;
-  EBOS_REQUIRE(q != nullptr, "ebos_cmax_patch_solve: NULL problem");
+  EBOS_REQUIRE(q != nullptr && q->steps_done >= 0, "ebos_cmax_patch_solve: NULL problem or negative steps_done");
   EBOS_REQUIRE(q->theta && q->d_theta && q->exp_avg && q->exp_avg_sq && q->step && q->dense && q->d_dense && q->iwe &&
                    q->variance && q->moments && q->upstream && q->upsample_scratch && q->workspace && q->reg_partials,
                "ebos_cmax_patch_solve: NULL buffer");
@@ -235,7 +235,7 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
   return EBOS_OK;
 }
 
-static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, ebos_stream_t stream) {
+static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_stream_t stream) {
   using namespace ebos;
   const bool has_reg = q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f;
   int rc = ebos_upsample_patch_flow_f32(q->theta, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
@@ -263,12 +263,11 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, ebos_stream_
                                     has_reg ? q->d_reg : nullptr, q->workspace, q->workspace_bytes,
                                     q->splits == 0 ? q->part_table : nullptr, stream);
   if (rc) return rc;
-  rc = ebos_upsample_patch_flow_bwd_f32(q->d_dense, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
-                                        q->upsample_scratch, q->d_theta, stream);
-  if (rc) return rc;
-  return ebos_cmax_adam_step_f32(q->theta, q->d_theta, q->exp_avg, q->exp_avg_sq, 2 * q->gh * q->gw, q->lr, q->beta1, q->beta2,
-                                 q->eps, q->step, q->variance, -q->w_variance, q->reg_partials, has_reg ? ebos::kRegGrid : 0,
-                                 q->losses, q->losses_cap, stream);
+  // adjoint of the upsample + the Adam step of every grid element where its gradient appears + the loss of the iteration
+  return ebos_upsample_patch_flow_bwd_adam_f32(q->d_dense, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
+                                               q->upsample_scratch, q->d_theta, q->theta, q->exp_avg, q->exp_avg_sq, q->lr, q->beta1,
+                                               q->beta2, q->eps, t, q->step, q->variance, -q->w_variance, q->reg_partials,
+                                               has_reg ? ebos::kRegGrid : 0, q->losses, q->losses_cap, stream);
 }
 
 int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* q, int n_iter, ebos_stream_t stream) {
@@ -276,7 +275,7 @@ int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* q, int n_iter, ebos
   EBOS_REQUIRE(n_iter >= 0, "ebos_cmax_patch_solve: negative n_iter");
   if (int rc = cmax_check_problem(q)) return rc;
   for (int it = 0; it < n_iter; ++it)
-    if (int rc = cmax_enqueue_iteration(q, stream)) return rc;
+    if (int rc = cmax_enqueue_iteration(q, q->steps_done + it + 1, stream)) return rc;
   return EBOS_OK;
 }
 
@@ -291,7 +290,7 @@ int ebos_cmax_patch_solve_many_f32(const ebos_cmax_patch_problem* problems, cons
   // kernels of another
   for (int it = 0; it < n_iter; ++it)
     for (int w = 0; w < n_problems; ++w)
-      if (int rc = cmax_enqueue_iteration(problems + w, streams[w])) return rc;
+      if (int rc = cmax_enqueue_iteration(problems + w, problems[w].steps_done + it + 1, streams[w])) return rc;
   return EBOS_OK;
 }
 

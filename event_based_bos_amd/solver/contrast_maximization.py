@@ -89,7 +89,6 @@ class ContrastMaximization(SolverBase):
         # optimizer.fused (default on): objectives of the family -w var(IWE) + w_n flow_norm + w_g image_gradient run as
         # a fixed pipeline of HIP kernels (solver/fused_loop.py) instead of through autograd
         self.fused_loop = bool(ocfg.get("fused", True))
-        self.graph_fused = bool(ocfg.get("graph_fused", False))  # graph replay of the fixed pipeline: slower than launches
         self.fused = False
         self.history: List[float] = []
 
@@ -177,7 +176,7 @@ class ContrastMaximization(SolverBase):
             loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms["image_variance"],
                                              self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
                                              self.omit_boundary, self.pad, self.halo, self.lr, capacity=n_iter)
-            losses = loop.run(n_iter, graph=self.graph_fused)
+            losses = loop.run(n_iter)
             self.graphed, self.fused = loop.graphed, True
             self.history += [float(v) for v in losses.cpu()]
             return loop.theta

@@ -2,14 +2,14 @@
 
 One iteration of the loop in src/solver/generative_max_likelihood.py:306-341 (zero_grad -> objective -> backward ->
 optimizer.step) for the objective  ``-w * var(IWE(dense(theta))) + w_n * flow_norm(dense) + w_g * image_gradient(dense)``
-is six C-ABI calls / nine kernels on one stream, all on buffers allocated once per window:
+is five C-ABI calls / eight kernels on one stream, all on buffers allocated once per window:
 
     ebos_upsample_patch_flow_f32      theta [2, gh, gw] -> dense [2, H, W]
     ebos_iwe_dense_slab_f32           dense -> IWE + variance partials           (2 kernels; 3 without regularisers)
     ebos_flow_regularisers_f32        dense -> regulariser value partials + gradient image; variance, (mean, M)
     ebos_iwe_dense_tiled_bwd_f32      -> d loss / d dense  (variance gradient folded in, regulariser gradient added)
-    ebos_upsample_patch_flow_bwd_f32  -> d loss / d theta                        (2 kernels)
-    ebos_cmax_adam_step_f32           loss[it] recorded, theta / exp_avg / exp_avg_sq / step updated
+    ebos_upsample_patch_flow_bwd_adam_f32  -> d loss / d theta (2 kernels); the second one applies the Adam step of every
+                                      grid element where its gradient appears and records loss[it]
 
 Expressed through autograd the same iteration is ~35 launches (capturable Adam alone is a dozen) and runs at ~235 us
 even as a replayed HIP graph; this pipeline is bounded by its event kernels.  Anything outside this objective family
@@ -51,7 +51,8 @@ class FusedPatchLoop(object):
         _, self.gh, self.gw = self.theta.shape
         self.d_theta = torch.empty_like(self.theta)
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.theta), torch.zeros_like(self.theta)
-        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)  # device mirror of self.t
+        self.t = 0  # Adam steps applied so far (host side: the bias corrections of a step are kernel arguments)
         self.dense, self.d_dense = torch.empty((2, H, W), **f32), torch.empty((2, H, W), **f32)
         self.has_reg = self.w_norm != 0.0 or self.w_tv != 0.0
         self.n_reg = int(self.lib.ebos_flow_regularisers_partials()) if self.has_reg else 0
@@ -65,7 +66,7 @@ class FusedPatchLoop(object):
         self.scratch_up = torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32)
         self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
-        self.graphed = False
+        self.graphed = False  # kept for callers that report it: this loop is never graph-replayed
         import ctypes as C
         off, n_parts, n_px = C.c_size_t(), C.c_int64(), C.c_int64()
         check(self.lib.ebos_iwe_slab_partials(H, W, plan.tile[0], plan.tile[1], self.halo, self.splits, self.pad[0], self.pad[1],
@@ -95,12 +96,12 @@ class FusedPatchLoop(object):
                                                ptr(self.d_dense), None, ptr(self.moments), ptr(self.upstream), ptr(self.d_reg),
                                                ptr(self.ws), self.ws.numel(), ptr(plan.part_table) if self.splits == 0 else None, s),
               "ebos_iwe_dense_tiled_bwd")
-        check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
-                                                   ptr(self.d_theta), s), "ebos_upsample_patch_flow_bwd")
-        check(lib.ebos_cmax_adam_step_f32(ptr(self.theta), ptr(self.d_theta), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                          self.theta.numel(), self.lr, self.betas[0], self.betas[1], self.eps, ptr(self.step),
-                                          ptr(self.variance), -self.w_var, ptr(self.reg_partials), self.n_reg, ptr(self.losses),
-                                          self.losses.numel(), s), "ebos_cmax_adam_step")
+        self.t += 1
+        check(lib.ebos_upsample_patch_flow_bwd_adam_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
+                                                        ptr(self.d_theta), ptr(self.theta), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                                        self.lr, self.betas[0], self.betas[1], self.eps, self.t, ptr(self.step),
+                                                        ptr(self.variance), -self.w_var, ptr(self.reg_partials), self.n_reg,
+                                                        ptr(self.losses), self.losses.numel(), s), "ebos_upsample_patch_flow_bwd_adam")
 
     def problem(self) -> "_hip.CmaxPatchProblem":
         """The loop's buffers as the ``ebos_cmax_patch_problem`` struct of the C ABI."""
@@ -118,49 +119,30 @@ class FusedPatchLoop(object):
         q.lr, q.beta1, q.beta2, q.eps = self.lr, self.betas[0], self.betas[1], self.eps
         q.theta, q.d_theta, q.exp_avg, q.exp_avg_sq = ptr(self.theta), ptr(self.d_theta), ptr(self.exp_avg), ptr(self.exp_avg_sq)
         q.step, q.dense, q.d_dense, q.d_reg = ptr(self.step), ptr(self.dense), ptr(self.d_dense), ptr(self.d_reg)
+        q.steps_done = self.t
         q.iwe, q.variance, q.moments, q.upstream = ptr(self.iwe), ptr(self.variance), ptr(self.moments), ptr(self.upstream)
         q.reg_partials, q.upsample_scratch = ptr(self.reg_partials), ptr(self.scratch_up)
         q.workspace, q.workspace_bytes = ptr(self.ws), self.ws.numel()
         q.losses, q.losses_cap = ptr(self.losses), self.losses.numel()
         return q
 
-    def run(self, n_iter: int, graph: bool = False, native: bool = True) -> torch.Tensor:
-        """``n_iter`` iterations; returns their losses [n_iter] (device).
-        ``native`` (default): one C call enqueues the whole loop (ebos_cmax_patch_solve_f32).  ``graph``: replay one
-        captured iteration instead -- measured SLOWER than plain launches on ROCm 7.2 for this 10-node graph
-        (172 vs 111 us per iteration at 2 M events), kept for comparison."""
+    def run(self, n_iter: int, native: bool = True) -> torch.Tensor:
+        """``n_iter`` more iterations; returns their losses [n_iter] (device).
+        ``native`` (default): one C call enqueues the whole loop (ebos_cmax_patch_solve_f32); otherwise one Python call
+        per kernel group.  (A HIP-graph replay of the iteration was measured slower than plain launches on ROCm 7.2 --
+        172 vs 111 us at 2 M events -- and cannot carry the step number, which is a kernel argument.)"""
         n_iter = int(n_iter)
-        if n_iter > self.losses.numel():
-            raise ValueError(f"capacity {self.losses.numel()} < n_iter {n_iter}")
-        dev = self.plan.device
-        self.graphed = False
-        done = 0
-        with torch.cuda.device(dev):
-            if native and not graph:
+        if self.t + n_iter > self.losses.numel():
+            raise ValueError(f"capacity {self.losses.numel()} < {self.t} steps done + {n_iter}")
+        t0 = self.t
+        with torch.cuda.device(self.plan.device):
+            if native:
                 import ctypes
 
                 check(self.lib.ebos_cmax_patch_solve_f32(ctypes.byref(self.problem()), n_iter, stream_ptr()),
                       "ebos_cmax_patch_solve")
-                return self.losses[:n_iter]
-            if graph and n_iter > 8:
-                try:
-                    self.iteration()  # eager once: reserves the kernels' LDS attributes outside the capture
-                    done = 1
-                    side = torch.cuda.Stream(device=dev)
-                    side.wait_stream(torch.cuda.current_stream(dev))
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.stream(side):
-                        g.capture_begin()
-                        try:
-                            self.iteration()
-                        finally:
-                            g.capture_end()
-                    torch.cuda.current_stream(dev).wait_stream(side)
-                    for _ in range(done, n_iter):
-                        g.replay()
-                    done, self.graphed = n_iter, True
-                except Exception:  # capture not possible: the eager loop below finishes the job
-                    self.graphed = False
-            for _ in range(done, n_iter):
-                self.iteration()
-        return self.losses[:n_iter]
+                self.t += n_iter
+            else:
+                for _ in range(n_iter):
+                    self.iteration()
+        return self.losses[t0:t0 + n_iter]

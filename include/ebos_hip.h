@@ -413,6 +413,18 @@ size_t ebos_upsample_bwd_scratch_bytes(int gh, int W);
 int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w,
                                      int slide_h, int slide_w, int H, int W, float* scratch, float* d_grid,
                                      ebos_stream_t stream);
+/* The same adjoint with the Adam step of the patch grid applied where each gradient element is produced (Adam is
+ * element-wise): theta / exp_avg / exp_avg_sq [2, gh, gw] are updated in place with the gradient of step t (t >= 1,
+ * counted by the caller; bias corrections in double on the host like torch.optim.Adam), d_grid still receives the
+ * gradient, step[0] := t, and losses[t - 1] := contrast_scale * contrast[0] + sum(reg_partials) (the loss of the
+ * parameters before the update; contrast / reg_partials / losses nullable).  Replaces ebos_upsample_patch_flow_bwd_f32 +
+ * ebos_cmax_adam_step_f32 in the solver loop: one launch less per iteration. */
+int ebos_upsample_patch_flow_bwd_adam_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w,
+                                          int slide_h, int slide_w, int H, int W, float* scratch, float* d_grid,
+                                          float* theta, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                                          double beta2, double eps, int t, int* step, const float* contrast,
+                                          float contrast_scale, const double* reg_partials, int n_reg, float* losses,
+                                          int losses_cap, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A9/K11  optional Gaussian blur of an event image (sigma > 0), one separable pass along one axis
@@ -438,10 +450,10 @@ int ebos_gauss1d_bwd_f64(const double* g_out, double* g_in, int64_t outer, int64
 /* ------------------------------------------------------------------------------------------
  * One contrast-maximisation iteration without autograd glue.  The loop of
  * src/solver/generative_max_likelihood.py:306-341 (zero_grad -> objective -> backward -> Adam step)
- * becomes 6 calls / 10 kernels on one stream:
+ * becomes 5 calls / 8 kernels on one stream (7 without regularisers + 1 finalize):
  *     ebos_upsample_patch_flow_f32 -> ebos_iwe_dense_slab_f32 (want_variance) -> ebos_flow_regularisers_f32
  *     -> ebos_iwe_dense_tiled_bwd_f32 (var_moments, upstream = -weight, addend = regulariser gradient)
- *     -> ebos_upsample_patch_flow_bwd_f32 -> ebos_cmax_adam_step_f32
+ *     -> ebos_upsample_patch_flow_bwd_adam_f32   (ebos_cmax_adam_step_f32 is the stand-alone form of the step)
  *
  * ebos_flow_regularisers_f32: value and gradient of
  *       w_flow_norm * mean_px |flow|_2                                   (src/costs/flow_norm.py:45-56)
@@ -491,6 +503,7 @@ typedef struct ebos_cmax_patch_problem {
   double lr, beta1, beta2, eps;
   float *theta, *d_theta, *exp_avg, *exp_avg_sq;
   int* step;
+  int steps_done;              /* Adam steps already applied to theta (the first iteration of a solve is step steps_done + 1) */
   float *dense, *d_dense, *d_reg, *iwe, *variance;
   double* moments;
   const float* upstream;

@@ -126,8 +126,8 @@ def test_fused_loop_follows_the_autograd_loop(terms):
 
 @pytest.mark.gpu
 def test_fused_loop_run_modes_agree():
-    """FusedPatchLoop: the native loop (ebos_cmax_patch_solve_f32), the per-call Python loop and the graph replay run
-    the same kernels in the same order: losses agree to 1e-5 relative over 30 iterations."""
+    """FusedPatchLoop: the native loop (ebos_cmax_patch_solve_f32) and the per-call Python loop run the same kernels in
+    the same order: losses agree to 1e-5 relative over 30 iterations; a loop can be continued (10 + 20 steps)."""
     import torch
 
     import event_based_bos_amd as ebos
@@ -137,14 +137,17 @@ def test_fused_loop_run_modes_agree():
     ev = moving_points(h, w, 500, 40, np.array([4.0, -2.5]), seed=6)
     plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto")
     hist = {}
-    for mode in ("native", "python", "graph"):
+    for mode in ("native", "python", "split"):
         loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, 4, 4)), 1.0, 0.01, 0.02, lr=0.1, capacity=30)
-        hist[mode] = loop.run(30, graph=mode == "graph", native=mode == "native").cpu().numpy()
-        assert loop.graphed == (mode == "graph") and int(loop.step.item()) == 30
+        if mode == "split":
+            hist[mode] = np.concatenate([loop.run(10).cpu().numpy(), loop.run(20, native=False).cpu().numpy()])
+        else:
+            hist[mode] = loop.run(30, native=mode == "native").cpu().numpy()
+        assert loop.t == 30 and int(loop.step.item()) == 30
     np.testing.assert_allclose(hist["python"], hist["native"], rtol=1e-5)
-    np.testing.assert_allclose(hist["graph"], hist["native"], rtol=1e-5)
+    np.testing.assert_allclose(hist["split"], hist["native"], rtol=1e-5)
     with pytest.raises(ValueError):
-        loop.run(31)
+        loop.run(1)
 
 
 @pytest.mark.gpu

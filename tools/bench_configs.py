@@ -94,13 +94,12 @@ def main():
         t_fb = timed(lambda: sweep(True), args.reps)
         # the solver's own form of the same work: one Adam iteration of the fixed kernel pipeline per window
         from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
-        loops = [FusedPatchLoop(p, (24, 32), (24, 32), g.detach(), 1.0, lr=0.05, capacity=64) for p, g in zip(plans, grids)]
+        loops = [FusedPatchLoop(p, (24, 32), (24, 32), g.detach(), 1.0, lr=0.05, capacity=58) for p, g in zip(plans, grids)]
         for lp in loops:
             lp.run(8)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for lp in loops:
-            lp.step.zero_()
             lp.run(50)
         torch.cuda.synchronize()
         t_iter = (time.perf_counter() - t0) / (50 * len(loops))
