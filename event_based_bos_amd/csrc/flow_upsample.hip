@@ -56,33 +56,42 @@ __device__ __forceinline__ Lerp lerp_at(const Axis& a, int r) {
   return l;
 }
 
-// forward: one thread = 4 consecutive columns of one row (one 16-byte store); the row's vertical lerp is uniform
-// per workgroup row, the grid (a few KB) is read through L1.
+// forward: one thread = 4 consecutive columns (one 16-byte store per row) of kUpRows consecutive rows: the horizontal
+// lerps are computed once per thread, the vertical one is uniform per row; the grid (a few KB) is read through L1.
+constexpr int kUpRows = 4;
+
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
 upsample_kernel(const float* __restrict__ grid, Axis ay, Axis ax, int H, int W, float* __restrict__ dense) {
-  const int ch = blockIdx.z, r = blockIdx.y;
+  const int ch = blockIdx.z, r0 = blockIdx.y * kUpRows;
   const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c0 >= W) return;
   const float* g = grid + (int64_t)ch * ay.g * ax.g;
-  float* out = dense + (int64_t)ch * H * W + (int64_t)r * W + c0;
-  const Lerp ly = lerp_at(ay, r);
-  const float* g0 = g + ly.i0 * ax.g;
-  const float* g1 = g + ly.i1 * ax.g;
-  float v[4];
+  Lerp lx[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const Lerp lx = lerp_at(ax, c0 + k < W ? c0 + k : W - 1);
-    const float top = lx.w0 * g0[lx.i0] + lx.w1 * g0[lx.i1];
-    const float bot = lx.w0 * g1[lx.i0] + lx.w1 * g1[lx.i1];
-    v[k] = ly.w0 * top + ly.w1 * bot;
-  }
-  if (VEC4) {
-    *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
-  } else {
+  for (int k = 0; k < 4; ++k) lx[k] = lerp_at(ax, c0 + k < W ? c0 + k : W - 1);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (c0 + k < W) out[k] = v[k];
+  for (int j = 0; j < kUpRows; ++j) {
+    const int r = r0 + j;
+    if (r >= H) break;
+    float* out = dense + (int64_t)ch * H * W + (int64_t)r * W + c0;
+    const Lerp ly = lerp_at(ay, r);
+    const float* g0 = g + ly.i0 * ax.g;
+    const float* g1 = g + ly.i1 * ax.g;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float top = lx[k].w0 * g0[lx[k].i0] + lx[k].w1 * g0[lx[k].i1];
+      const float bot = lx[k].w0 * g1[lx[k].i0] + lx[k].w1 * g1[lx[k].i1];
+      v[k] = ly.w0 * top + ly.w1 * bot;
+    }
+    if (VEC4) {
+      *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c0 + k < W) out[k] = v[k];
+    }
   }
 }
 
@@ -193,7 +202,7 @@ int ebos_upsample_patch_flow_f32(const float* grid, int gh, int gw, int patch_h,
   EBOS_REQUIRE(ay.off >= 0 && ax.off >= 0 && ay.off + H <= ay.n_in * slide_h && ax.off + W <= ax.n_in * slide_w,
                "ebos_upsample_patch_flow: image %dx%d larger than the resized grid %dx%d", H, W, ay.n_in * slide_h,
                ax.n_in * slide_w);
-  dim3 g((W + 1023) / 1024, H, 2);
+  dim3 g((W + 1023) / 1024, (H + kUpRows - 1) / kUpRows, 2);
   if (W % 4 == 0) upsample_kernel<true><<<g, dim3(256), 0, as_stream(stream)>>>(grid, ay, ax, H, W, dense);
   else upsample_kernel<false><<<g, dim3(256), 0, as_stream(stream)>>>(grid, ay, ax, H, W, dense);
   EBOS_CHECK_LAUNCH("ebos_upsample_patch_flow");
