@@ -117,11 +117,12 @@ class CmaxPatchProblem(C.Structure):
                 [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "pad_h", "pad_w", "omit_boundary", "splits")] +
                 [("part_table", _P)] +
                 [(k, _I) for k in ("gh", "gw", "patch_h", "patch_w", "slide_h", "slide_w")] +
-                [(k, _F) for k in ("w_variance", "w_flow_norm", "w_image_gradient")] +
+                [(k, _F) for k in ("w_variance", "w_flow_norm", "w_image_gradient", "w_gradient_magnitude")] +
                 [(k, _D) for k in ("lr", "beta1", "beta2", "eps")] +
                 [(k, _P) for k in ("theta", "d_theta", "exp_avg", "exp_avg_sq", "step")] + [("steps_done", _I)] +
-                [(k, _P) for k in ("dense", "d_dense", "d_reg", "iwe",
-                                   "variance", "moments", "upstream", "reg_partials", "upsample_scratch", "workspace")] +
+                [(k, _P) for k in ("dense", "d_dense", "d_reg", "iwe", "variance", "d_iwe", "cost_scratch")] +
+                [("cost_scratch_bytes", _Z)] +
+                [(k, _P) for k in ("moments", "upstream", "reg_partials", "upsample_scratch", "workspace")] +
                 [("workspace_bytes", _Z), ("losses", _P), ("losses_cap", _I)])
 
 

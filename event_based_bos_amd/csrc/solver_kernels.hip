@@ -232,6 +232,10 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
                "ebos_cmax_patch_solve: NULL buffer");
   EBOS_REQUIRE((q->w_flow_norm == 0.0f && q->w_image_gradient == 0.0f) || q->d_reg,
                "ebos_cmax_patch_solve: regulariser weights given but d_reg is NULL");
+  EBOS_REQUIRE((q->w_variance != 0.0f) != (q->w_gradient_magnitude != 0.0f),
+               "ebos_cmax_patch_solve: exactly one of w_variance / w_gradient_magnitude must be non-zero");
+  EBOS_REQUIRE(q->w_gradient_magnitude == 0.0f || (q->d_iwe && q->cost_scratch),
+               "ebos_cmax_patch_solve: the gradient-magnitude contrast needs d_iwe and cost_scratch");
   return EBOS_OK;
 }
 
@@ -241,11 +245,20 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
   int rc = ebos_upsample_patch_flow_f32(q->theta, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
                                         q->dense, stream);
   if (rc) return rc;
+  const bool use_gm = q->w_gradient_magnitude != 0.0f;
+  const int h = q->H + 2 * q->pad_h, w = q->W + 2 * q->pad_w;
+  const float contrast_weight = use_gm ? q->w_gradient_magnitude : q->w_variance;
   rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
                                q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->workspace,
-                               q->workspace_bytes, q->iwe, has_reg ? 2 : 1, q->omit_boundary, q->variance, q->moments, q->part_table,
-                               stream);
+                               q->workspace_bytes, q->iwe, use_gm ? 0 : (has_reg ? 2 : 1), q->omit_boundary, q->variance,
+                               q->moments, q->part_table, stream);
   if (rc) return rc;
+  if (use_gm) {  // contrast = mean squared Sobel gradient of the IWE; its gradient image feeds the backward event kernel
+    rc = ebos_gradient_magnitude_f32(q->iwe, 1, h, w, q->omit_boundary, q->variance, q->cost_scratch, q->cost_scratch_bytes, stream);
+    if (rc) return rc;
+    rc = ebos_gradient_magnitude_grad_f32(q->iwe, 1, h, w, q->omit_boundary, q->upstream, q->d_iwe, stream);
+    if (rc) return rc;
+  }
   if (has_reg) {  // the regulariser pass also reduces the variance moments the combine pass left (no finalize launch)
     size_t off = 0;
     int64_t n_parts = 0, n_px = 0;
@@ -253,20 +266,21 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
                                 &n_parts, &n_px);
     if (rc) return rc;
     rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials,
-                                    reinterpret_cast<const double*>(static_cast<const char*>(q->workspace) + off), n_parts, n_px,
-                                    q->variance, q->moments, stream);
+                                    use_gm ? nullptr : reinterpret_cast<const double*>(static_cast<const char*>(q->workspace) + off),
+                                    n_parts, n_px, q->variance, q->moments, stream);
     if (rc) return rc;
   }
   rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
-                                    q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w, q->iwe, nullptr,
-                                    q->omit_boundary ? 1 : 0, q->d_dense, nullptr, q->moments, q->upstream,
+                                    q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,
+                                    use_gm ? q->d_iwe : q->iwe, nullptr, use_gm ? 0 : (q->omit_boundary ? 1 : 0), q->d_dense, nullptr,
+                                    use_gm ? nullptr : q->moments, use_gm ? nullptr : q->upstream,
                                     has_reg ? q->d_reg : nullptr, q->workspace, q->workspace_bytes,
                                     q->splits == 0 ? q->part_table : nullptr, stream);
   if (rc) return rc;
   // adjoint of the upsample + the Adam step of every grid element where its gradient appears + the loss of the iteration
   return ebos_upsample_patch_flow_bwd_adam_f32(q->d_dense, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
                                                q->upsample_scratch, q->d_theta, q->theta, q->exp_avg, q->exp_avg_sq, q->lr, q->beta1,
-                                               q->beta2, q->eps, t, q->step, q->variance, -q->w_variance, q->reg_partials,
+                                               q->beta2, q->eps, t, q->step, q->variance, -contrast_weight, q->reg_partials,
                                                has_reg ? ebos::kRegGrid : 0, q->losses, q->losses_cap, stream);
 }
 

@@ -173,9 +173,10 @@ class ContrastMaximization(SolverBase):
 
         if self.fused_loop and fused_loop.supported(self.contrast_terms, self.flow_terms, self.blur_sigma, self.opt_method,
                                                     plan, self.halo):
-            loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms["image_variance"],
+            loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms.get("image_variance", 0.0),
                                              self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
-                                             self.omit_boundary, self.pad, self.halo, self.lr, capacity=n_iter)
+                                             self.omit_boundary, self.pad, self.halo, self.lr, capacity=n_iter,
+                                             w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0))
             losses = loop.run(n_iter)
             self.graphed, self.fused = loop.graphed, True
             self.history += [float(v) for v in losses.cpu()]

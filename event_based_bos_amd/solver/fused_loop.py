@@ -1,7 +1,8 @@
 """The Adam loop of the patch-flow contrast maximisation as a fixed pipeline of HIP kernels (no autograd graph).
 
 One iteration of the loop in src/solver/generative_max_likelihood.py:306-341 (zero_grad -> objective -> backward ->
-optimizer.step) for the objective  ``-w * var(IWE(dense(theta))) + w_n * flow_norm(dense) + w_g * image_gradient(dense)``
+optimizer.step) for the objective  ``-w * contrast(IWE(dense(theta))) + w_n * flow_norm(dense) + w_g * image_gradient(dense)``
+(contrast = image variance, or the gradient magnitude with two more cost kernels)
 is five C-ABI calls / eight kernels on one stream, all on buffers allocated once per window:
 
     ebos_upsample_patch_flow_f32      theta [2, gh, gw] -> dense [2, H, W]
@@ -30,7 +31,8 @@ FLOW_TERMS = ("flow_norm", "image_gradient")
 
 def supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], blur_sigma: float, method: str,
               plan: EventPlan, halo) -> bool:
-    return (set(contrast_terms) == {"image_variance"} and set(flow_terms) <= set(FLOW_TERMS) and not blur_sigma
+    return (len(contrast_terms) == 1 and set(contrast_terms) <= {"image_variance", "gradient_magnitude"}
+            and set(flow_terms) <= set(FLOW_TERMS) and not blur_sigma
             and method == "Adam" and halo is not None and _slab_ok(plan, halo))
 
 
@@ -38,10 +40,13 @@ class FusedPatchLoop(object):
     def __init__(self, plan: EventPlan, patch_size: Tuple[int, int], sliding_window: Tuple[int, int], theta0: torch.Tensor,
                  w_variance: float, w_flow_norm: float = 0.0, w_image_gradient: float = 0.0, omit_boundary: bool = False,
                  pad: int = 0, halo: int = 32, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, capacity: int = 1024,
-                 splits: Optional[int] = None):
+                 splits: Optional[int] = None, w_gradient_magnitude: float = 0.0):
         self.lib = _hip.require_gpu()
         self.plan, self.patch, self.slide = plan, tuple(int(v) for v in patch_size), tuple(int(v) for v in sliding_window)
         self.w_var, self.w_norm, self.w_tv = float(w_variance), float(w_flow_norm), float(w_image_gradient)
+        self.w_gm = float(w_gradient_magnitude)
+        if (self.w_var != 0.0) == (self.w_gm != 0.0):
+            raise ValueError("exactly one contrast weight (variance or gradient magnitude) must be non-zero")
         self.omit, self.pad, self.halo = bool(omit_boundary), (int(pad), int(pad)), int(halo)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         dev = plan.device
@@ -61,7 +66,10 @@ class FusedPatchLoop(object):
         self.iwe = torch.empty((H + 2 * self.pad[0], W + 2 * self.pad[1]), **f32)
         self.variance = torch.empty(1, **f32)
         self.moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
-        self.upstream = torch.full((1,), -self.w_var, **f32)  # loss = -w * variance
+        self.upstream = torch.full((1,), -(self.w_gm or self.w_var), **f32)  # loss = -w * contrast
+        self.d_iwe = torch.empty_like(self.iwe) if self.w_gm else None
+        self.cost_scratch = (torch.empty(int(self.lib.ebos_cost_scratch_bytes(1)), dtype=torch.uint8, device=dev)
+                             if self.w_gm else None)
         self.losses = torch.zeros(max(int(capacity), 1), **f32)
         self.scratch_up = torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32)
         self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
@@ -80,27 +88,36 @@ class FusedPatchLoop(object):
         gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
         check(lib.ebos_upsample_patch_flow_f32(ptr(self.theta), gh, gw, ph, pw, sh, sw, H, W, ptr(self.dense), s),
               "ebos_upsample_patch_flow")
+        use_gm = self.w_gm != 0.0
+        h, w = self.iwe.shape
         check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                           ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
                                           self.halo, self.splits, self.pad[0], self.pad[1], ptr(self.ws), self.ws.numel(),
-                                          ptr(self.iwe), 2 if self.has_reg else 1, int(self.omit), ptr(self.variance),
-                                          ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_dense_slab")
+                                          ptr(self.iwe), 0 if use_gm else (2 if self.has_reg else 1), int(self.omit),
+                                          ptr(self.variance), ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_dense_slab")
+        if use_gm:  # contrast = mean squared Sobel gradient; its gradient image is the upstream of the backward kernel
+            check(lib.ebos_gradient_magnitude_f32(ptr(self.iwe), 1, h, w, int(self.omit), ptr(self.variance), ptr(self.cost_scratch),
+                                                  self.cost_scratch.numel(), s), "ebos_gradient_magnitude")
+            check(lib.ebos_gradient_magnitude_grad_f32(ptr(self.iwe), 1, h, w, int(self.omit), ptr(self.upstream), ptr(self.d_iwe), s),
+                  "ebos_gradient_magnitude_grad")
         if self.has_reg:  # ... which also reduces the variance partials of the combine pass (no finalize launch)
             off, n_parts, n_px = self._var_partials
             check(lib.ebos_flow_regularisers_f32(ptr(self.dense), H, W, self.w_norm, self.w_tv, ptr(self.d_reg),
-                                                 ptr(self.reg_partials), self.ws.data_ptr() + off, n_parts, n_px,
+                                                 ptr(self.reg_partials), None if use_gm else self.ws.data_ptr() + off, n_parts, n_px,
                                                  ptr(self.variance), ptr(self.moments), s), "ebos_flow_regularisers")
         check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                                ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
-                                               self.halo, self.pad[0], self.pad[1], ptr(self.iwe), None, int(self.omit),
-                                               ptr(self.d_dense), None, ptr(self.moments), ptr(self.upstream), ptr(self.d_reg),
-                                               ptr(self.ws), self.ws.numel(), ptr(plan.part_table) if self.splits == 0 else None, s),
+                                               self.halo, self.pad[0], self.pad[1], ptr(self.d_iwe if use_gm else self.iwe), None,
+                                               0 if use_gm else int(self.omit), ptr(self.d_dense), None,
+                                               None if use_gm else ptr(self.moments), None if use_gm else ptr(self.upstream),
+                                               ptr(self.d_reg), ptr(self.ws), self.ws.numel(),
+                                               ptr(plan.part_table) if self.splits == 0 else None, s),
               "ebos_iwe_dense_tiled_bwd")
         self.t += 1
         check(lib.ebos_upsample_patch_flow_bwd_adam_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
                                                         ptr(self.d_theta), ptr(self.theta), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                                         self.lr, self.betas[0], self.betas[1], self.eps, self.t, ptr(self.step),
-                                                        ptr(self.variance), -self.w_var, ptr(self.reg_partials), self.n_reg,
+                                                        ptr(self.variance), -(self.w_gm or self.w_var), ptr(self.reg_partials), self.n_reg,
                                                         ptr(self.losses), self.losses.numel(), s), "ebos_upsample_patch_flow_bwd_adam")
 
     def problem(self) -> "_hip.CmaxPatchProblem":
@@ -116,6 +133,8 @@ class FusedPatchLoop(object):
         q.splits, q.part_table = self.splits, ptr(plan.part_table)
         q.gh, q.gw, (q.patch_h, q.patch_w), (q.slide_h, q.slide_w) = self.gh, self.gw, self.patch, self.slide
         q.w_variance, q.w_flow_norm, q.w_image_gradient = self.w_var, self.w_norm, self.w_tv
+        q.w_gradient_magnitude, q.d_iwe, q.cost_scratch = self.w_gm, ptr(self.d_iwe), ptr(self.cost_scratch)
+        q.cost_scratch_bytes = self.cost_scratch.numel() if self.cost_scratch is not None else 0
         q.lr, q.beta1, q.beta2, q.eps = self.lr, self.betas[0], self.betas[1], self.eps
         q.theta, q.d_theta, q.exp_avg, q.exp_avg_sq = ptr(self.theta), ptr(self.d_theta), ptr(self.exp_avg), ptr(self.exp_avg_sq)
         q.step, q.dense, q.d_dense, q.d_reg = ptr(self.step), ptr(self.dense), ptr(self.d_dense), ptr(self.d_reg)

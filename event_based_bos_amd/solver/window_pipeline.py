@@ -81,9 +81,9 @@ class WindowPipeline(object):
                         init = torch.nn.functional.interpolate(thetas[w][None], size=(gh, gw), mode="bilinear",
                                                                align_corners=False)[0]
                     loops.append(fused_loop.FusedPatchLoop(
-                        plan, patch_size, sliding_window, init, s.contrast_terms["image_variance"],
+                        plan, patch_size, sliding_window, init, s.contrast_terms.get("image_variance", 0.0),
                         s.flow_terms.get("flow_norm", 0.0), s.flow_terms.get("image_gradient", 0.0), s.omit_boundary, s.pad,
-                        s.halo, s.lr, capacity=n_iter))
+                        s.halo, s.lr, capacity=n_iter, w_gradient_magnitude=s.contrast_terms.get("gradient_magnitude", 0.0)))
             problems = (_hip.CmaxPatchProblem * len(loops))(*[lp.problem() for lp in loops])
             handles = (ctypes.c_void_p * len(loops))(*[st.cuda_stream for st in streams[:len(loops)]])
             with torch.cuda.device(self.device):

@@ -500,11 +500,17 @@ typedef struct ebos_cmax_patch_problem {
   const int32_t* part_table;   /* nullable unless splits == 0 */
   int gh, gw, patch_h, patch_w, slide_h, slide_w;
   float w_variance, w_flow_norm, w_image_gradient;
+  float w_gradient_magnitude;  /* contrast = gradient magnitude instead of variance: exactly one of the two
+                                  contrast weights is non-zero; then `variance` receives the contrast value, `upstream` holds
+                                  -w_gradient_magnitude, and d_iwe / cost_scratch below are needed */
   double lr, beta1, beta2, eps;
   float *theta, *d_theta, *exp_avg, *exp_avg_sq;
   int* step;
   int steps_done;              /* Adam steps already applied to theta (the first iteration of a solve is step steps_done + 1) */
   float *dense, *d_dense, *d_reg, *iwe, *variance;
+  float* d_iwe;                /* [H + 2 pad_h, W + 2 pad_w]; nullable unless w_gradient_magnitude != 0 */
+  void* cost_scratch;          /* ebos_cost_scratch_bytes(1); nullable unless w_gradient_magnitude != 0 */
+  size_t cost_scratch_bytes;
   double* moments;
   const float* upstream;
   double* reg_partials;

@@ -100,7 +100,8 @@ def test_solver_pyramid_and_scipy_optimisers(optimizer, patch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("terms", [{"image_variance": 1.0}, {"image_variance": 2.0, "flow_norm": 0.01, "image_gradient": 0.05}])
+@pytest.mark.parametrize("terms", [{"image_variance": 1.0}, {"image_variance": 2.0, "flow_norm": 0.01, "image_gradient": 0.05},
+                                   {"gradient_magnitude": 3.0, "flow_norm": 0.02}, {"gradient_magnitude": 1.0}])
 def test_fused_loop_follows_the_autograd_loop(terms):
     """The fixed kernel pipeline (solver/fused_loop.py) and the autograd loop minimise the same objective with the same
     Adam: loss histories agree to 1e-4 relative and the patch flows to 2e-3 px over 40 iterations (both f32)."""
