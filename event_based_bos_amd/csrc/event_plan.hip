@@ -376,6 +376,14 @@ plan_parts_kernel(const int32_t* __restrict__ key_offsets, int n_tiles, int tile
   int32_t* part_off = part_table;
   int32_t* item_tile = part_table + n_tiles + 1;
   int32_t* item_part = item_tile + n_items;
+  if (lo >= lmax) {  // one part per tile: the work items are the tiles, in order (no ranking needed)
+    for (int t = threadIdx.x; t <= n_tiles; t += blockDim.x) part_off[t] = t;
+    for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+      item_tile[i] = i < n_tiles ? i : -1;
+      item_part[i] = 0;
+    }
+    return;
+  }
   __shared__ int s_used;
   if (threadIdx.x == 0) {
     int off = 0;

@@ -715,8 +715,8 @@ def test_adaptive_work_items(ebos, shape, sigma, n):
     assert np.all(item_part[:used] < np.diff(part_off)[item_tile[:used]])
     loads = np.diff(plan.key_offsets.cpu().numpy()[::th * tw])
     per_item = np.ceil(loads[item_tile[:used]] / np.diff(part_off)[item_tile[:used]])
-    assert np.all(np.diff(per_item) <= 0)                                    # heaviest first
     if sigma < 100:
+        assert np.all(np.diff(per_item) <= 0)                                # heaviest first (the launch order is the schedule)
         assert used > n_tiles and plan.resolve_splits(None) == 0             # the blob's tiles are split ...
         assert per_item.max() < 0.5 * loads.max()
     else:
