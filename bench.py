@@ -222,6 +222,19 @@ def main():
     torch.cuda.synchronize()
     overlapped_ms = (time.perf_counter() - t2) / (3 * max(10, args.steps)) * 1e3
 
+    # next to the nominal peak, a bandwidth this box actually delivers -- a device-to-device copy of 1 GiB
+    # (read + write bytes counted), best of 5
+    a_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    b_buf = torch.empty_like(a_buf)
+    copy_gbs = 0.0
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        b_buf.copy_(a_buf)
+        torch.cuda.synchronize()
+        copy_gbs = max(copy_gbs, 2.0 * a_buf.numel() * 4 / (time.perf_counter() - t3) / 1e9)
+    del a_buf, b_buf
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed / 1e6
@@ -248,6 +261,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "iwe_slab_accumulate_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
+                         "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                          "plan_format_bytes": format_bytes,
                          "plan_format_GBps": round(format_bytes / (kernel_ms * 1e-3) / 1e9, 1)},
             "plan_build_ms": round(plan_build_ms, 2), "plan_build_first_call_ms": round(plan_first_ms, 2), "fwd_bwd_ms": round(fwdbwd_ms, 4),
