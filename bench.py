@@ -79,7 +79,14 @@ def cpu_baseline(ev, flow, sample):
             O.image_variance(iwe)
             times.append(time.perf_counter() - t0)
         out[name] = sample / statistics.median(times[1:]) / 1e6
-    return {"value": round(out["f64"], 3), "unit": "Mevents/s", "cores": threads, "host_cpus": avail, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": round(out["f64"], 3), "unit": "Mevents/s", "cores": threads, "host_cpus": avail, "cpu_model": model,
+            "kind": "port",
             "sample": f"first {sample} events of the window, fwd warp+IWE+variance, torch-CPU fp64 (reference default dtype), "
                       f"median of 3 after 1 warm-up; fp32 on the same sample: {out['f32']:.2f} Mevents/s",
             "value_f32": round(out["f32"], 3)}
