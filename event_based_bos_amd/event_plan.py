@@ -402,6 +402,9 @@ def _plan_weight(plan: EventPlan, weight: Optional[torch.Tensor]) -> Optional[to
     """Per-event weights are given in INPUT order; reorder them like the events."""
     if weight is None:
         return None
+    if plan.__dict__.get("_deferred"):
+        # a deferred plan does not know how many events it kept: the tail of `perm` is not defined
+        raise NotImplementedError("per-event weights need a plan built with the host read-back (deferred=False)")
     w = weight.to(device=plan.device, dtype=torch.float32).reshape(-1)
     if w.numel() != plan.n_input:
         raise ValueError(f"weight must have one entry per input event ({plan.n_input}), got {w.numel()}")

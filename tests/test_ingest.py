@@ -110,6 +110,8 @@ def test_deferred_plan_equals_synchronous_plan():
     lazy.contrast_dense(f1).backward()
     sync.contrast_dense(f2).backward()
     assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 1e-6
+    with pytest.raises(NotImplementedError):  # per-event weights need the exact event count of a synchronous build
+        lazy.iwe_dense(flow, weight=torch.ones(30000, device="cuda"))
     # a float plan with fractional coordinates cannot be deferred
     ev = np.stack([y + 0.25, x, t / 1e6, p], 1).astype(np.float64)
     frac = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=None).bin((32, 32), deferred=True)
