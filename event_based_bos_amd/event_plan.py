@@ -315,6 +315,46 @@ class EventPlan:
             th.record_stream(cur)
         return out
 
+    def variance_dense_many(self, flows: torch.Tensor, omit_boundary: bool = False, pad: Tuple[int, int] = (0, 0),
+                            halo: int = DEFAULT_HALO, splits: Optional[int] = None, n_streams: int = 3) -> torch.Tensor:
+        """Variance contrast of K independent dense-flow hypotheses (the trial loop of a sampler-driven search,
+        src/solver/generative_max_likelihood.py:229-236): flows [K, 2, H, W] -> [K].  No gradient.  The evaluations are
+        dealt to ``n_streams`` HIP streams with a workspace and an image buffer each, like ``variance_2dof``."""
+        lib = _hip.require_gpu()
+        if flows.dim() != 4 or tuple(flows.shape[1:]) != (2,) + tuple(self.image_size):
+            raise ValueError(f"flows must be [K, 2, {self.image_size[0]}, {self.image_size[1]}], got {tuple(flows.shape)}")
+        if not _slab_ok(self, halo):
+            return torch.stack([self.contrast_dense(f, "image_variance", omit_boundary, pad, halo).detach() for f in flows])
+        fl = flows.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        K = fl.shape[0]
+        H, W = self.image_size
+        h, w = H + 2 * pad[0], W + 2 * pad[1]
+        splits = self.resolve_splits(splits)
+        out = torch.empty(K, dtype=torch.float32, device=self.device)
+        n_streams = max(1, min(int(n_streams), K))
+        key = ("dense_many", int(halo), int(splits), int(pad[0]), int(pad[1]), h, w)
+        lanes = self.__dict__.setdefault("_sweep_lanes", {}).get(key)
+        with torch.cuda.device(self.device):
+            if lanes is None or len(lanes) < n_streams:
+                lanes = [(torch.cuda.Stream(device=self.device),
+                          torch.zeros(_workspace(self, pad, halo, splits).numel(), dtype=torch.uint8, device=self.device),
+                          torch.empty((h, w), dtype=torch.float32, device=self.device)) for _ in range(n_streams)]
+                self.__dict__["_sweep_lanes"][key] = lanes
+            cur = torch.cuda.current_stream(self.device)
+            for st, _, _ in lanes[:n_streams]:
+                st.wait_stream(cur)
+            for k in range(K):
+                st, ws, buf = lanes[k % n_streams]
+                check(lib.ebos_iwe_dense_slab_f32(ptr(self.x), ptr(self.y), ptr(self.dt), None, *self._compact_ptrs(),
+                                                  ptr(self.key_offsets), self.n, fl.data_ptr() + 8 * H * W * k, H, W, self.tile[0],
+                                                  self.tile[1], int(halo), int(splits), pad[0], pad[1], ptr(ws), ws.numel(),
+                                                  ptr(buf), 1, int(omit_boundary), out.data_ptr() + 4 * k, None,
+                                                  ptr(self.part_table), st.cuda_stream), "ebos_iwe_dense_slab")
+            for st, _, _ in lanes[:n_streams]:
+                cur.wait_stream(st)
+            fl.record_stream(cur)
+        return out
+
     def contrast_dense(self, flow: torch.Tensor, cost: str = "image_variance", omit_boundary: bool = False,
                        pad: Tuple[int, int] = (0, 0), halo: Optional[int] = DEFAULT_HALO,
                        splits: Optional[int] = None) -> torch.Tensor:

@@ -966,3 +966,18 @@ def test_variance_finalize_as_side_job_of_the_regulariser_pass(ebos, omit, pad):
     EP.check(lib.ebos_flow_regularisers_f32(EP.ptr(flow), h, w, 0.5, 0.25, EP.ptr(d), EP.ptr(parts), ws.data_ptr() + off.value,
                                             n_parts.value, n_px.value, EP.ptr(var2), EP.ptr(mom2), EP.stream_ptr()), "reg")
     assert torch.equal(var2, var1) and torch.equal(mom2, mom1)
+
+
+def test_many_dense_hypotheses_on_streams(ebos):
+    """variance_dense_many (K independent dense flows dealt to 3 HIP streams) == K single evaluations, bit for bit."""
+    h, w = 96, 128
+    ev = O.synth_events(50000, h, w, seed=71)
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile="auto")
+    flows = torch.stack([G(O.synth_dense_flow(h, w, seed=80 + k, max_val=3.0 + 4 * k)).float() for k in range(7)])
+    many = plan.variance_dense_many(flows)
+    many2 = plan.variance_dense_many(flows, omit_boundary=True, n_streams=2)
+    for k in range(7):
+        assert many[k].item() == plan.contrast_dense(flows[k]).item()
+        assert many2[k].item() == plan.contrast_dense(flows[k], omit_boundary=True).item()
+    with pytest.raises(ValueError):
+        plan.variance_dense_many(flows[:, :, :-1])
