@@ -119,3 +119,18 @@ def test_c_abi_is_usable_without_python(tmp_path, lib):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe, "150000"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.strip().endswith("OK"), (run.stdout[-1000:], run.stderr[-1000:])
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ebos_hip.h is the FFI contract: it must be valid C99 (what a cgo / JNI / ctypes binding consumes), not only C++."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "ebos_hip.h"\nint main(void) { ebos_cmax_patch_problem p; (void)p; return 0; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I" + os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
