@@ -157,13 +157,21 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
+_gpu_checked = False
+
+
 def require_gpu() -> C.CDLL:
-    """Library + a visible GPU, or HipUnavailableError."""
+    """Library + a visible GPU, or HipUnavailableError.  (Called on every operator launch: the positive answer of
+    ``torch.cuda.is_available()`` -- ~3 us of environment look-ups per call -- is remembered.)"""
+    global _gpu_checked
+    if _gpu_checked and _lib is not None:
+        return _lib
     lib = load_library()
     if not torch.cuda.is_available():
         raise HipUnavailableError(
             "no GPU visible to PyTorch-ROCm: event_based_bos_amd runs its warp/IWE/cost path on an MI355X "
             "through libebos_hip.so only; there is no CPU fallback.")
+    _gpu_checked = True
     return lib
 
 
