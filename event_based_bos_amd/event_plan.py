@@ -315,6 +315,25 @@ class EventPlan:
             th.record_stream(cur)
         return out
 
+    def variance_and_grad_dense(self, flow: torch.Tensor, omit_boundary: bool = False, pad: Tuple[int, int] = (0, 0),
+                                halo: int = DEFAULT_HALO, splits: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(variance [1], d variance / d flow [2, H, W]) in two launches' worth of Python, without building an autograd
+        graph -- for callers that drive their own optimiser (the autograd engine alone costs more per backward() than
+        both event kernels take).  Same kernels and results as ``contrast_dense(flow).backward()``."""
+        flow32 = _check_flow(self, flow.detach())
+        splits = self.resolve_splits(splits)
+        pad = (int(pad[0]), int(pad[1]))
+        if not _slab_ok(self, halo):
+            f = flow32.clone().requires_grad_(True)
+            v = self.contrast_dense(f, "image_variance", omit_boundary, pad, halo)
+            v.backward()
+            return v.detach().reshape(1), f.grad
+        iwe, var, moments = _launch_iwe_dense_slab(self, flow32, None, pad, halo, splits, True, omit_boundary)
+        one = self.__dict__.setdefault("_one", torch.ones(1, dtype=torch.float32, device=self.device))
+        d_flow, _ = _launch_dense_bwd(self, flow32, None, pad, iwe, None, int(omit_boundary), False, halo, moments, one,
+                                      splits=splits)
+        return var, d_flow
+
     def variance_dense_many(self, flows: torch.Tensor, omit_boundary: bool = False, pad: Tuple[int, int] = (0, 0),
                             halo: int = DEFAULT_HALO, splits: Optional[int] = None, n_streams: int = 3) -> torch.Tensor:
         """Variance contrast of K independent dense-flow hypotheses (the trial loop of a sampler-driven search,

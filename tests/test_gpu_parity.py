@@ -981,3 +981,19 @@ def test_many_dense_hypotheses_on_streams(ebos):
         assert many2[k].item() == plan.contrast_dense(flows[k], omit_boundary=True).item()
     with pytest.raises(ValueError):
         plan.variance_dense_many(flows[:, :, :-1])
+
+
+def test_variance_and_grad_without_autograd(ebos):
+    """variance_and_grad_dense == contrast_dense(flow) + backward(), same kernels: value bit-exact, gradient to 1e-6
+    (the f64 LDS adds of the backward kernel are not ordered)."""
+    h, w = 96, 128
+    ev = O.synth_events(50000, h, w, seed=91)
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile="auto")
+    for omit, pad in ((False, 0), (True, 2)):
+        flow = G(O.synth_dense_flow(h, w, seed=92, max_val=6.0)).float()
+        f = flow.clone().requires_grad_(True)
+        v = plan.contrast_dense(f, "image_variance", omit, pad=(pad, pad))
+        v.backward()
+        var, grad = plan.variance_and_grad_dense(flow, omit, pad=(pad, pad))
+        assert var.item() == v.item() and not grad.requires_grad
+        assert rel(grad.cpu().numpy(), f.grad.cpu().numpy()) < 1e-6
