@@ -183,6 +183,14 @@ class ContrastMaximization(SolverBase):
             return loop.theta
         self.fused = False
         if self.opt_method in SCIPY_METHODS:
+            if self.fused_loop and fused_loop.objective_supported(self.contrast_terms, self.flow_terms, self.blur_sigma, plan,
+                                                                  self.halo):
+                loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms.get("image_variance", 0.0),
+                                                 self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
+                                                 self.omit_boundary, self.pad, self.halo, self.lr, capacity=1,
+                                                 w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0))
+                self.fused = True
+                return self._run_scipy(None, theta, n_iter, value_and_grad=loop.value_and_grad)
             return self._run_scipy(evaluate, theta, n_iter)
         if self.opt_method != "Adam":
             raise NotImplementedError(f"optimizer.method {self.opt_method!r}: Adam or one of {SCIPY_METHODS}")
@@ -206,7 +214,7 @@ class ContrastMaximization(SolverBase):
         self.history += [float(v) for v in losses[:n_iter].cpu()]
         return theta.detach()
 
-    def _run_scipy(self, evaluate, theta: torch.Tensor, n_iter: int) -> torch.Tensor:
+    def _run_scipy(self, evaluate, theta: torch.Tensor, n_iter: int, value_and_grad=None) -> torch.Tensor:
         """Gradient-based scipy optimisers on the GPU objective, the role of the reference's
         ``scipy_autograd.minimize`` (src/solver/scipy_autograd/scipy_minimize.py:6-125): scipy drives float64 numpy
         parameters on the host; every function/gradient evaluation is one fused forward + backward on the device.
@@ -218,6 +226,10 @@ class ContrastMaximization(SolverBase):
         shape = tuple(theta.shape)
 
         def fun(x):
+            if value_and_grad is not None:  # fixed kernel pipeline, no autograd graph
+                loss, grad = value_and_grad(torch.from_numpy(x.reshape(shape)))
+                self.history.append(float(loss))
+                return self.history[-1], grad.double().cpu().numpy().reshape(-1)
             with torch.no_grad():
                 theta.copy_(torch.from_numpy(x.reshape(shape)).to(theta))
             theta.grad = None

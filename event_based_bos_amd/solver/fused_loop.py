@@ -29,11 +29,16 @@ from ..event_plan import EventPlan, _slab_ok, _workspace
 FLOW_TERMS = ("flow_norm", "image_gradient")
 
 
+def objective_supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], blur_sigma: float, plan: EventPlan,
+                        halo) -> bool:
+    """The objective family of the fixed kernel pipeline: one contrast term + the two flow regularisers, no blur."""
+    return (len(contrast_terms) == 1 and set(contrast_terms) <= {"image_variance", "gradient_magnitude"}
+            and set(flow_terms) <= set(FLOW_TERMS) and not blur_sigma and halo is not None and _slab_ok(plan, halo))
+
+
 def supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], blur_sigma: float, method: str,
               plan: EventPlan, halo) -> bool:
-    return (len(contrast_terms) == 1 and set(contrast_terms) <= {"image_variance", "gradient_magnitude"}
-            and set(flow_terms) <= set(FLOW_TERMS) and not blur_sigma
-            and method == "Adam" and halo is not None and _slab_ok(plan, halo))
+    return method == "Adam" and objective_supported(contrast_terms, flow_terms, blur_sigma, plan, halo)
 
 
 class FusedPatchLoop(object):
@@ -82,8 +87,8 @@ class FusedPatchLoop(object):
               "ebos_iwe_slab_partials")
         self._var_partials = (off.value, n_parts.value, n_px.value)
 
-    def iteration(self) -> None:
-        lib, plan, s = self.lib, self.plan, stream_ptr()
+    def _forward_backward(self, lib, plan, s) -> None:
+        """upsample -> IWE + contrast -> regularisers -> d loss / d dense (shared by iteration() and value_and_grad())."""
         H, W = plan.image_size
         gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
         check(lib.ebos_upsample_patch_flow_f32(ptr(self.theta), gh, gw, ph, pw, sh, sw, H, W, ptr(self.dense), s),
@@ -113,12 +118,34 @@ class FusedPatchLoop(object):
                                                ptr(self.d_reg), ptr(self.ws), self.ws.numel(),
                                                ptr(plan.part_table) if self.splits == 0 else None, s),
               "ebos_iwe_dense_tiled_bwd")
+
+    def iteration(self) -> None:
+        lib, plan, s = self.lib, self.plan, stream_ptr()
+        H, W = plan.image_size
+        gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
+        self._forward_backward(lib, plan, s)
         self.t += 1
         check(lib.ebos_upsample_patch_flow_bwd_adam_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
                                                         ptr(self.d_theta), ptr(self.theta), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                                         self.lr, self.betas[0], self.betas[1], self.eps, self.t, ptr(self.step),
                                                         ptr(self.variance), -(self.w_gm or self.w_var), ptr(self.reg_partials), self.n_reg,
                                                         ptr(self.losses), self.losses.numel(), s), "ebos_upsample_patch_flow_bwd_adam")
+
+    def value_and_grad(self, theta: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(loss [0-d], d loss / d theta [2, gh, gw]) at ``theta`` through the same kernels, without the Adam update --
+        for optimisers that live on the host (scipy)."""
+        lib, plan, s = self.lib, self.plan, stream_ptr()
+        H, W = plan.image_size
+        gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
+        with torch.cuda.device(plan.device):
+            self.theta.copy_(theta.detach().to(self.theta))
+            self._forward_backward(lib, plan, s)
+            check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
+                                                       ptr(self.d_theta), s), "ebos_upsample_patch_flow_bwd")
+            loss = -(self.w_gm or self.w_var) * self.variance[0]
+            if self.has_reg:
+                loss = loss + self.reg_partials.sum().to(torch.float32)
+        return loss, self.d_theta.clone()
 
     def problem(self) -> "_hip.CmaxPatchProblem":
         """The loop's buffers as the ``ebos_cmax_patch_problem`` struct of the C ABI."""
