@@ -7,6 +7,8 @@ Tolerances (stated per assertion):
   * images, fp32 fused path vs the fp64 reference: rel-L2 < 1e-4 (north_star), typically ~1e-6
   * costs: rel < 1e-5;  gradients (fp32 atomics): rel-L2 < 1e-3
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -775,7 +777,7 @@ def test_fuzz_fused_path_against_oracle(ebos):
     from event_based_bos_amd import _hip
 
     configs = _hip.slab_configs()
-    rs = np.random.RandomState(2024)
+    rs = np.random.RandomState(int(os.environ.get("EBOS_FUZZ_SEED", 2024)))  # soak runs override the seed
     for case in range(64):
         h, w = int(rs.randint(20, 150)), int(rs.randint(20, 200))
         th, tw, halo = configs[rs.randint(len(configs))]
@@ -855,7 +857,7 @@ def test_fuzz_plugin_surface_against_oracle(ebos):
     numpy / torch (CPU and GPU) inputs, f32 / f64, batched / un-batched, every direction, normalize_t, dense and 2-DoF
     models, image methods, scalar / per-event weights, padding, blur.  Warped events BIT-EXACT on equal dtype (f64: same
     op order), images rel-L2 <= 1e-12 in f64 and < 1e-5 in f32; output type, dtype and device follow the input."""
-    rs = np.random.RandomState(77)
+    rs = np.random.RandomState(int(os.environ.get("EBOS_FUZZ_SEED", 77)))
     for case in range(48):
         h, w = int(rs.randint(8, 40)), int(rs.randint(8, 50))
         n = int(rs.choice([2, 3, 50, 400]))
