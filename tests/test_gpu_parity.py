@@ -769,11 +769,33 @@ def test_hot_pixels_overflow_high_and_low_fields(ebos, splits):
     assert abs(var - expect.var(ddof=1)) < 1e-5 * expect.var(ddof=1)
 
 
+def _off_the_kinks(ev, flow, direction, amp, margin=5e-4):
+    """Drop the events whose f64-warped coordinate lies within ``margin`` px of an integer.  The bilinear vote is
+    piecewise linear in the warped coordinate: AT an integer its value is continuous but its gradient jumps (and the
+    inside-the-image test switches), so there an f32 warp (~1e-5 px of rounding at +-90 px) and the f64 oracle
+    legitimately report the two different one-sided gradients -- one such event in 60000 is 2e-3..1e-2 of the flow
+    gradient of these small images.  Everything else about the case (clustering, borders, out-of-image) is untouched;
+    ~0.2 % of the events go.  Iterated because dropping the first / last event moves the reference time."""
+    if amp == 0.0:
+        return ev   # zero flow: every event sits on a kink, the gradient is not compared
+    for _ in range(16):
+        warped = O.warp_dense_torch(torch.from_numpy(ev), torch.from_numpy(flow), direction, True).numpy().reshape(-1, 4)
+        near = (np.abs(warped[:, :2] - np.rint(warped[:, :2])) < margin).any(1)
+        # t == t_ref leaves the source coordinate untouched (an integer for the compact kinds): those events stay, their
+        # displacement is exactly zero in f32 and in f64 alike
+        near &= warped[:, 2] != 0.0
+        if not near.any() or len(ev) - int(near.sum()) < 2:
+            return ev
+        ev = ev[~near]
+    return ev
+
+
 def test_fuzz_fused_path_against_oracle(ebos):
     """Seeded fuzz over the knobs that interact in the tile-private pipeline: image size (tiles cut by the border), tile
     configuration, halo (taps beyond it spill), event clustering (hot pixels, blobs, borders), flow magnitude (beyond the
     halo, out of the image), padding, omit_boundary, splits (uniform, adaptive).  IWE rel-L2 < 1e-4, variance rel
-    < 1e-5, flow gradient rel-L2 < 1e-3 against the fp64 oracle -- the north_star tolerances."""
+    < 1e-5, flow gradient rel-L2 < 1e-3 against the fp64 oracle -- the north_star tolerances, at every flow amplitude
+    (events ON a kink of the piecewise-linear vote are taken out first, see _off_the_kinks)."""
     from event_based_bos_amd import _hip
 
     configs = _hip.slab_configs()
@@ -807,6 +829,8 @@ def test_fuzz_fused_path_against_oracle(ebos):
         splits = int(rs.choice([0, 1, 2, 5]))
         direction = ["first", "middle", "last", 0.3][rs.randint(4)]
         tag = f"case {case}: {h}x{w} tile {th}x{tw} halo {halo} n {n} kind {kind} amp {amp} pad {pad} splits {splits} {direction}"
+        ev = _off_the_kinks(ev, flow, direction, amp)
+        n = len(ev)
         tev = torch.from_numpy(ev)
         ft = torch.from_numpy(flow).requires_grad_(True)
         expect = O.iwe_dense(tev, ft, (h, w), pad=(pad, pad), direction=direction)
@@ -841,10 +865,7 @@ def test_fuzz_fused_path_against_oracle(ebos):
             (got_w * G(probe.numpy()).float()).sum().backward()
             assert float((wg.grad.cpu().double() - wt.grad).norm()) / max(float(wt.grad.norm()), 1e-12) < 1e-3, tag
             if amp > 0 and float(ft2.grad.norm()) > 0:
-                # a random upstream image makes every f32 floor flip visible; beyond the +-30 px of the benchmark
-                # configurations the f32 displacement carries ~1e-5 px of rounding: allow 5e-3 there
-                tol = 1e-3 if amp <= 40.0 else 5e-3
-                assert float((fg2.grad.cpu().double() - ft2.grad).norm()) / float(ft2.grad.norm()) < tol, tag
+                assert float((fg2.grad.cpu().double() - ft2.grad).norm()) / float(ft2.grad.norm()) < 1e-3, tag
         # the 2-DoF model through the same tile-private kernels (UNIFORM variant)
         theta = rs.uniform(-amp - 1, amp + 1, 2)
         exp2 = O.iwe_2dof(tev, torch.from_numpy(theta), (h, w), pad=(pad, pad), direction=direction)
