@@ -20,6 +20,6 @@ from ._hip import HipUnavailableError, load_library  # noqa: F401
 from .warp import MotionModelKeyError, Warp  # noqa: F401
 from .event_image_converter import EventImageConverter  # noqa: F401
 from .event_plan import EventPlan  # noqa: F401
-from . import costs, data_loader, fusion, ops, solver, types  # noqa: F401
+from . import costs, data_loader, fusion, ops, solver, types, utils  # noqa: F401
 
 __version__ = "0.1.0"

@@ -147,6 +147,7 @@ struct AdamJob {
   int n_reg;
   float* losses;
   int losses_cap;
+  const float* grad_mask;  // [gh, gw], nullable: patches whose flow is not estimated (too few events) keep their value
 };
 
 // pass 2: one wavefront per grid cell, lanes stride over the cell's column support
@@ -174,6 +175,7 @@ upsample_bwd_cols_kernel(const float* __restrict__ S, Axis ay, Axis ax, int W, f
   acc = wave_sum(acc);
   if (lane == 0) {
     const int64_t i = ((int64_t)ch * ay.g + gi) * ax.g + gj;
+    if (job.grad_mask != nullptr) acc *= job.grad_mask[(int64_t)gi * ax.g + gj];
     d_grid[i] = acc;
     if (job.theta != nullptr) {
       const float g = acc;
@@ -237,7 +239,7 @@ int ebos_upsample_patch_flow_bwd_adam_f32(const float* d_dense, int gh, int gw, 
                                           int slide_w, int H, int W, float* scratch, float* d_grid, float* theta, float* exp_avg,
                                           float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int t, int* step,
                                           const float* contrast, float contrast_scale, const double* reg_partials, int n_reg,
-                                          float* losses, int losses_cap, ebos_stream_t stream) {
+                                          float* losses, int losses_cap, const float* grad_mask, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(theta && exp_avg && exp_avg_sq && step, "ebos_upsample_patch_flow_bwd_adam: NULL optimiser buffer");
   EBOS_REQUIRE(t >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
@@ -262,6 +264,7 @@ int ebos_upsample_patch_flow_bwd_adam_f32(const float* d_dense, int gh, int gw, 
   job.n_reg = n_reg;
   job.losses = losses;
   job.losses_cap = losses_cap;
+  job.grad_mask = grad_mask;
   return upsample_bwd_impl(d_dense, gh, gw, patch_h, patch_w, slide_h, slide_w, H, W, scratch, d_grid, job, stream);
 }
 

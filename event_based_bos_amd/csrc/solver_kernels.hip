@@ -281,7 +281,7 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
   return ebos_upsample_patch_flow_bwd_adam_f32(q->d_dense, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
                                                q->upsample_scratch, q->d_theta, q->theta, q->exp_avg, q->exp_avg_sq, q->lr, q->beta1,
                                                q->beta2, q->eps, t, q->step, q->variance, -contrast_weight, q->reg_partials,
-                                               has_reg ? ebos::kRegGrid : 0, q->losses, q->losses_cap, stream);
+                                               has_reg ? ebos::kRegGrid : 0, q->losses, q->losses_cap, q->theta_mask, stream);
 }
 
 int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* q, int n_iter, ebos_stream_t stream) {

@@ -260,6 +260,37 @@ class EventPlan:
         return dropped, fractional
 
     # ------------------------------------------------------------------------------------------
+    def pixel_event_counts(self) -> torch.Tensor:
+        """Events per source pixel [H, W] int64 (device), read off the plan's counting sort: the histogram of
+        ``(trunc(x), trunc(y))`` that ``crop_event`` with integer bounds counts in.  No kernel of its own, no host read."""
+        if not self.binned:
+            raise ValueError("pixel_event_counts needs a binned plan (EventPlan.build(..., tile=...))")
+        H, W = self.image_size
+        th, tw = self.tile
+        ty, tx = -(-H // th), -(-W // tw)
+        per_key = (self.key_offsets[1:] - self.key_offsets[:-1]).to(torch.int64)       # keys are tile-major
+        return per_key.reshape(ty, tx, th, tw).permute(0, 2, 1, 3).reshape(ty * th, tx * tw)[:H, :W]
+
+    def patch_event_counts(self, patch_size: Tuple[int, int], sliding_window: Tuple[int, int]) -> torch.Tensor:
+        """``len(crop_event(events, p.x_min, p.x_max, p.y_min, p.y_max))`` for every patch p of the grid at once:
+        [gh, gw] int64 on the device.  Replaces the per-patch loop over the whole event array of the reference's
+        patch solvers (src/solver/patch_eklt.py:118-126, src/solver/patch_eklt_pyramid2.py:215-228: O(n_patch * n))
+        by box sums over the per-pixel histogram the plan already holds.  Exact for events inside the image, which is
+        all a binned plan keeps (``n_dropped`` counts the others)."""
+        import numpy as np
+
+        from .types import patch_bounds
+
+        H, W = self.image_size
+        x0, x1, y0, y1 = (torch.from_numpy(np.clip(b, 0, lim)).to(self.device)
+                          for b, lim in zip(patch_bounds((H, W), patch_size, sliding_window), (H, H, W, W)))
+        x1, y1 = torch.maximum(x1, x0), torch.maximum(y1, y0)
+        integral = torch.zeros((H + 1, W + 1), dtype=torch.int64, device=self.device)
+        integral[1:, 1:] = self.pixel_event_counts().cumsum(0).cumsum(1)
+        return (integral[x1[:, None], y1[None, :]] - integral[x0[:, None], y1[None, :]]
+                - integral[x1[:, None], y0[None, :]] + integral[x0[:, None], y0[None, :]])
+
+    # ------------------------------------------------------------------------------------------
     def iwe_dense(self, flow: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
                   halo: Optional[int] = DEFAULT_HALO, splits: Optional[int] = None) -> torch.Tensor:
         """Fused dense-flow warp + bilinear IWE: flow [2, H, W] -> iwe [H + 2 pad_h, W + 2 pad_w].

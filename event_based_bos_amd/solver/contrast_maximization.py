@@ -69,6 +69,10 @@ class ContrastMaximization(SolverBase):
         self.patch_size = tuple(pcfg.get("size", (24, 32)))
         self.sliding_window = tuple(pcfg.get("sliding_window", self.patch_size))
         self.pyramid = pcfg.get("pyramid") or None
+        # patch.do_event_thresholding / patch.event_thres (src/solver/patch_eklt.py:62-67): a patch is estimated only
+        # when more than event_thres events fall inside it (:118-126); the others keep zero flow
+        self.do_event_thresholding = bool(pcfg.get("do_event_thresholding", False))
+        self.event_thres = int(pcfg.get("event_thres", 0) or 0)
         if self.pyramid and not (int(self.pyramid["coarsest"]) >= int(self.pyramid["finest"]) >= 1):
             raise ValueError("patch.pyramid needs coarsest >= finest >= 1")
         ocfg = cfg.get("optimizer") or {}
@@ -145,6 +149,15 @@ class ContrastMaximization(SolverBase):
             out.append((size, size, max(1, self.n_iter // (finest_scale - i + 1))))
         return out
 
+    def patch_mask(self, plan: EventPlan, patch_size, sliding_window) -> Optional[torch.Tensor]:
+        """[gh, gw] float32 on the device: 1 where the patch holds more than ``event_thres`` events, else 0 -- or None
+        when thresholding is off.  The reference crops the whole event array once per patch
+        (src/solver/patch_eklt.py:118-126); here the counts are box sums over the plan's per-pixel histogram
+        (``EventPlan.patch_event_counts``), without a host read-back."""
+        if not self.do_event_thresholding:
+            return None
+        return (plan.patch_event_counts(patch_size, sliding_window) > self.event_thres).to(torch.float32)
+
     def _estimate_patch_flow(self, plan: EventPlan) -> torch.Tensor:
         H, W = self.orig_image_shape
         self.history, self.patch_flow_per_scale = [], []
@@ -157,18 +170,22 @@ class ContrastMaximization(SolverBase):
                 init = to_gpu(self.previous_best, device=plan.device, dtype=torch.float32).reshape(2, gh, gw)
             else:
                 init = torch.zeros((2, gh, gw), dtype=torch.float32, device=plan.device)
-            theta = self._optimise_patch_grid(plan, init.clone(), patch_size, sliding_window, n_iter)
+            mask = self.patch_mask(plan, patch_size, sliding_window)
+            if mask is not None:
+                init = init * mask
+            theta = self._optimise_patch_grid(plan, init.clone(), patch_size, sliding_window, n_iter, mask)
             self.patch_flow_per_scale.append(theta)
         self.patch_flow = theta
         self.patch_size_used, self.sliding_window_used = patch_size, sliding_window
         return ops.upsample_patch_flow(theta, patch_size, sliding_window, (H, W))
 
-    def _optimise_patch_grid(self, plan: EventPlan, theta: torch.Tensor, patch_size, sliding_window, n_iter: int) -> torch.Tensor:
+    def _optimise_patch_grid(self, plan: EventPlan, theta: torch.Tensor, patch_size, sliding_window, n_iter: int,
+                             mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         H, W = self.orig_image_shape
         theta = theta.requires_grad_(True)
 
-        def evaluate():
-            dense = ops.upsample_patch_flow(theta, patch_size, sliding_window, (H, W))
+        def evaluate():  # (mask: the gradient of a patch that is not estimated is zero, so it keeps its masked start)
+            dense = ops.upsample_patch_flow(theta if mask is None else theta * mask, patch_size, sliding_window, (H, W))
             return self.objective(plan, dense)
 
         if self.fused_loop and fused_loop.supported(self.contrast_terms, self.flow_terms, self.blur_sigma, self.opt_method,
@@ -176,7 +193,7 @@ class ContrastMaximization(SolverBase):
             loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms.get("image_variance", 0.0),
                                              self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
                                              self.omit_boundary, self.pad, self.halo, self.lr, capacity=n_iter,
-                                             w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0))
+                                             w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0), theta_mask=mask)
             losses = loop.run(n_iter)
             self.graphed, self.fused = loop.graphed, True
             self.history += [float(v) for v in losses.cpu()]
@@ -188,7 +205,7 @@ class ContrastMaximization(SolverBase):
                 loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms.get("image_variance", 0.0),
                                                  self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
                                                  self.omit_boundary, self.pad, self.halo, self.lr, capacity=1,
-                                                 w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0))
+                                                 w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0), theta_mask=mask)
                 self.fused = True
                 return self._run_scipy(None, theta, n_iter, value_and_grad=loop.value_and_grad)
             return self._run_scipy(evaluate, theta, n_iter)

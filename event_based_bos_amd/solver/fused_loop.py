@@ -45,7 +45,7 @@ class FusedPatchLoop(object):
     def __init__(self, plan: EventPlan, patch_size: Tuple[int, int], sliding_window: Tuple[int, int], theta0: torch.Tensor,
                  w_variance: float, w_flow_norm: float = 0.0, w_image_gradient: float = 0.0, omit_boundary: bool = False,
                  pad: int = 0, halo: int = 32, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, capacity: int = 1024,
-                 splits: Optional[int] = None, w_gradient_magnitude: float = 0.0):
+                 splits: Optional[int] = None, w_gradient_magnitude: float = 0.0, theta_mask: Optional[torch.Tensor] = None):
         self.lib = _hip.require_gpu()
         self.plan, self.patch, self.slide = plan, tuple(int(v) for v in patch_size), tuple(int(v) for v in sliding_window)
         self.w_var, self.w_norm, self.w_tv = float(w_variance), float(w_flow_norm), float(w_image_gradient)
@@ -59,6 +59,9 @@ class FusedPatchLoop(object):
         f32 = dict(dtype=torch.float32, device=dev)
         self.theta = theta0.detach().to(**f32).contiguous().clone()
         _, self.gh, self.gw = self.theta.shape
+        # theta_mask [gh, gw] (optional): 0 = patch not estimated (event thresholding, src/solver/patch_eklt.py:118-126);
+        # its gradient is zeroed, so the patch keeps its initial flow
+        self.theta_mask = None if theta_mask is None else theta_mask.detach().to(**f32).reshape(self.gh, self.gw).contiguous()
         self.d_theta = torch.empty_like(self.theta)
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.theta), torch.zeros_like(self.theta)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)  # device mirror of self.t
@@ -129,7 +132,8 @@ class FusedPatchLoop(object):
                                                         ptr(self.d_theta), ptr(self.theta), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                                         self.lr, self.betas[0], self.betas[1], self.eps, self.t, ptr(self.step),
                                                         ptr(self.variance), -(self.w_gm or self.w_var), ptr(self.reg_partials), self.n_reg,
-                                                        ptr(self.losses), self.losses.numel(), s), "ebos_upsample_patch_flow_bwd_adam")
+                                                        ptr(self.losses), self.losses.numel(), ptr(self.theta_mask), s),
+              "ebos_upsample_patch_flow_bwd_adam")
 
     def value_and_grad(self, theta: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """(loss [0-d], d loss / d theta [2, gh, gw]) at ``theta`` through the same kernels, without the Adam update --
@@ -145,7 +149,7 @@ class FusedPatchLoop(object):
             loss = -(self.w_gm or self.w_var) * self.variance[0]
             if self.has_reg:
                 loss = loss + self.reg_partials.sum().to(torch.float32)
-        return loss, self.d_theta.clone()
+        return loss, (self.d_theta.clone() if self.theta_mask is None else self.d_theta * self.theta_mask)
 
     def problem(self) -> "_hip.CmaxPatchProblem":
         """The loop's buffers as the ``ebos_cmax_patch_problem`` struct of the C ABI."""
@@ -170,6 +174,7 @@ class FusedPatchLoop(object):
         q.reg_partials, q.upsample_scratch = ptr(self.reg_partials), ptr(self.scratch_up)
         q.workspace, q.workspace_bytes = ptr(self.ws), self.ws.numel()
         q.losses, q.losses_cap = ptr(self.losses), self.losses.numel()
+        q.theta_mask = ptr(self.theta_mask)
         return q
 
     def run(self, n_iter: int, native: bool = True) -> torch.Tensor:

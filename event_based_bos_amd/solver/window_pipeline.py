@@ -80,10 +80,14 @@ class WindowPipeline(object):
                     else:
                         init = torch.nn.functional.interpolate(thetas[w][None], size=(gh, gw), mode="bilinear",
                                                                align_corners=False)[0]
+                    mask = s.patch_mask(plan, patch_size, sliding_window)
+                    if mask is not None:
+                        init = init * mask
                     loops.append(fused_loop.FusedPatchLoop(
                         plan, patch_size, sliding_window, init, s.contrast_terms.get("image_variance", 0.0),
                         s.flow_terms.get("flow_norm", 0.0), s.flow_terms.get("image_gradient", 0.0), s.omit_boundary, s.pad,
-                        s.halo, s.lr, capacity=n_iter, w_gradient_magnitude=s.contrast_terms.get("gradient_magnitude", 0.0)))
+                        s.halo, s.lr, capacity=n_iter, w_gradient_magnitude=s.contrast_terms.get("gradient_magnitude", 0.0),
+                        theta_mask=mask))
             problems = (_hip.CmaxPatchProblem * len(loops))(*[lp.problem() for lp in loops])
             handles = (ctypes.c_void_p * len(loops))(*[st.cuda_stream for st in streams[:len(loops)]])
             with torch.cuda.device(self.device):

@@ -8,12 +8,12 @@ from typing import Union
 import numpy as np
 import torch
 
-from .flow_patch import FlowPatch
+from .flow_patch import FlowPatch, patch_bounds
 
 NUMPY_TORCH = Union[np.ndarray, torch.Tensor]
 FLOAT_TORCH = Union[float, torch.Tensor]
 
-__all__ = ["NUMPY_TORCH", "FLOAT_TORCH", "FlowPatch", "is_torch", "is_numpy", "nt_max", "nt_min"]
+__all__ = ["NUMPY_TORCH", "FLOAT_TORCH", "FlowPatch", "patch_bounds", "is_torch", "is_numpy", "nt_max", "nt_min"]
 
 
 def is_torch(obj) -> bool:

@@ -45,3 +45,16 @@ class FlowPatch:
 
     def copy(self) -> Any:
         return copy.deepcopy(self)
+
+
+def patch_bounds(image_size, patch_size, sliding_window):
+    """(x_min [gh], x_max [gh], y_min [gw], y_max [gw]) int64 numpy: the crop window of every patch row / column of the
+    grid -- centres ``arange(0, size - patch + slide, slide) + patch / 2`` (src/solver/patch_eklt.py:85-86) with the
+    bounds of FlowPatch (src/types/flow_patch.py:33-47: ``int(c - ceil(h / 2))`` .. ``int(c + floor(h / 2))``, int()
+    truncating toward zero)."""
+    out = []
+    for size, patch, slide in zip(image_size, patch_size, sliding_window):
+        centre = np.arange(0, size - patch + slide, slide) + patch / 2
+        out.append(np.trunc(centre - np.ceil(patch / 2)).astype(np.int64))
+        out.append(np.trunc(centre + np.floor(patch / 2)).astype(np.int64))
+    return tuple(out)

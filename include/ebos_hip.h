@@ -418,13 +418,16 @@ int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int p
  * counted by the caller; bias corrections in double on the host like torch.optim.Adam), d_grid still receives the
  * gradient, step[0] := t, and losses[t - 1] := contrast_scale * contrast[0] + sum(reg_partials) (the loss of the
  * parameters before the update; contrast / reg_partials / losses nullable).  Replaces ebos_upsample_patch_flow_bwd_f32 +
- * ebos_cmax_adam_step_f32 in the solver loop: one launch less per iteration. */
+ * ebos_cmax_adam_step_f32 in the solver loop: one launch less per iteration.
+ * grad_mask [gh, gw] (nullable) multiplies the gradient of both flow components before the step: 0 for the patches that
+ * are not estimated -- the event thresholding of src/solver/patch_eklt.py:118-126 (`len(crop_event(...)) > event_thres`),
+ * whose patch flow stays where it is (Adam with a zero gradient and zero moments does not move). */
 int ebos_upsample_patch_flow_bwd_adam_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w,
                                           int slide_h, int slide_w, int H, int W, float* scratch, float* d_grid,
                                           float* theta, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
                                           double beta2, double eps, int t, int* step, const float* contrast,
                                           float contrast_scale, const double* reg_partials, int n_reg, float* losses,
-                                          int losses_cap, ebos_stream_t stream);
+                                          int losses_cap, const float* grad_mask, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A9/K11  optional Gaussian blur of an event image (sigma > 0), one separable pass along one axis
@@ -487,7 +490,8 @@ int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, flo
  *             iwe [H + 2 pad_h, W + 2 pad_w], variance [1] f32, moments [2] f64, upstream [1] f32 = -w_variance
  *   scratch:  reg_partials [ebos_flow_regularisers_partials()] f64, upsample_scratch
  *             (ebos_upsample_bwd_scratch_bytes), workspace (ebos_iwe_slab_workspace_bytes, zero-filled once)
- *   losses:   [losses_cap] f32, entry `step` written per iteration (nullable)                                  */
+ *   losses:   [losses_cap] f32, entry `step` written per iteration (nullable)
+ *   theta_mask: [gh, gw] f32, 0 = patch not estimated (nullable = all patches)                                 */
 typedef struct ebos_cmax_patch_problem {
   const float *xs, *ys, *dts;
   const int32_t* grp_offsets;
@@ -519,6 +523,7 @@ typedef struct ebos_cmax_patch_problem {
   size_t workspace_bytes;
   float* losses;
   int losses_cap;
+  const float* theta_mask;     /* [gh, gw], nullable: grad_mask of ebos_upsample_patch_flow_bwd_adam_f32 */
 } ebos_cmax_patch_problem;
 int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* problem, int n_iter, ebos_stream_t stream);
 /* Several independent windows at once (windows are the unit that shards): problem w runs on

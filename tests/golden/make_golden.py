@@ -102,7 +102,43 @@ def synth_flow(h, w, seed=1, fmax=30.0):
     return np.random.RandomState(seed).uniform(-fmax, fmax, (2, h, w))  # src/utils/flow_utils.py:29
 
 
+def make_patches():
+    """golden_patches.npz: the reference's patch grid (src/solver/patch_eklt.py:70-95), FlowPatch bounds
+    (src/types/flow_patch.py:33-47) and per-patch ``len(crop_event(...))`` (src/utils/event_utils.py:109-129, the loop of
+    src/solver/patch_eklt.py:118-124) on seeded events -- pins types.patch_bounds / utils.crop_event /
+    EventPlan.patch_event_counts."""
+    import_reference()
+    import src.utils as rutils
+    from src.solver.patch_eklt import PatchEklt
+
+    out = {}
+    cases = [((60, 80), (10, 16), (10, 16)), ((60, 80), (15, 21), (7, 9)), ((50, 70), (16, 16), (8, 8)),
+             ((45, 64), (9, 13), (9, 13)), ((33, 47), (8, 8), (5, 3))]
+    for k, (size, patch, slide) in enumerate(cases):
+        patches, shape = PatchEklt.prepare_patch(None, size, patch, slide)
+        ev = synth_events(4000, size[0], size[1], seed=300 + k)
+        ev[::7, 0] += 0.5   # fractional (undistorted) coordinates too
+        ev[::5, 1] += 0.25
+        counts = np.array([len(rutils.crop_event(ev, patches[i].x_min, patches[i].x_max, patches[i].y_min, patches[i].y_max))
+                           for i in range(len(patches))]).reshape(shape)
+        bounds = np.array([[patches[i].x_min, patches[i].x_max, patches[i].y_min, patches[i].y_max] for i in range(len(patches))])
+        tag = f"p{k}"
+        out[tag + "_cfg"] = np.array([*size, *patch, *slide])
+        out[tag + "_events"] = ev
+        out[tag + "_grid_shape"] = np.array(shape)
+        out[tag + "_bounds"] = bounds.reshape(shape + (4,))
+        out[tag + "_counts"] = counts
+        i0 = len(patches) // 2
+        out[tag + "_crop_mid"] = rutils.crop_event(ev, patches[i0].x_min, patches[i0].x_max, patches[i0].y_min, patches[i0].y_max)
+        out[tag + "_crop_mid_torch"] = rutils.crop_event(torch.from_numpy(ev), patches[i0].x_min, patches[i0].x_max,
+                                                         patches[i0].y_min, patches[i0].y_max).numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_patches.npz"), **out)
+    print("golden_patches.npz:", len(out), "arrays")
+
+
 def main():
+    if "--patches" in sys.argv:   # the other fixtures stay byte-identical
+        return make_patches()
     Warp, EIC, SobelTorch, costs = import_reference()
     out = {}
 

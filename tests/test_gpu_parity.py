@@ -662,6 +662,43 @@ def test_adam_step_kernel_matches_torch_adam(ebos):
     np.testing.assert_allclose(losses.cpu().numpy(), [-2.0 * t + t for t in range(steps)], rtol=1e-6)
 
 
+def test_upsample_adjoint_adam_with_grad_mask(ebos):
+    """ebos_upsample_patch_flow_bwd_adam_f32 with grad_mask [gh, gw]: d_grid == mask * (adjoint of the oracle's upsample)
+    (rel-L2 < 1e-5, zeros exact), masked grid cells keep their value bit-exactly over 10 steps, the others follow
+    torch.optim.Adam fed the masked gradient (1e-5 absolute)."""
+    from event_based_bos_amd._hip import check, ptr, stream_ptr
+
+    lib = ebos.load_library()
+    rng = np.random.default_rng(21)
+    H, W, patch, slide = 70, 90, (16, 20), (8, 10)
+    gh, gw = len(np.arange(0, H - patch[0] + slide[0], slide[0])), len(np.arange(0, W - patch[1] + slide[1], slide[1]))
+    mask = (rng.uniform(size=(gh, gw)) > 0.4).astype(np.float32)
+    x0 = rng.normal(size=(2, gh, gw)).astype(np.float32)
+    ref = torch.from_numpy(x0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=0.1)
+    theta, m, v = G(x0.copy()), torch.zeros((2, gh, gw), device=dev()), torch.zeros((2, gh, gw), device=dev())
+    d_grid = torch.empty((2, gh, gw), device=dev())
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    scratch = torch.empty(int(lib.ebos_upsample_bwd_scratch_bytes(gh, W)) // 4, device=dev())
+    gmask = G(mask)
+    for t in range(1, 11):
+        up = rng.normal(size=(2, H, W)).astype(np.float32)
+        probe = torch.zeros((2, gh, gw), dtype=torch.float64, requires_grad=True)
+        (O.upsample_patch_flow(probe, (H, W), patch, slide) * torch.from_numpy(up).double()).sum().backward()
+        want = probe.grad.numpy() * mask
+        ref.grad = torch.from_numpy(want.astype(np.float32))
+        opt.step()
+        check(lib.ebos_upsample_patch_flow_bwd_adam_f32(ptr(G(up)), gh, gw, patch[0], patch[1], slide[0], slide[1], H, W, ptr(scratch),
+                                                        ptr(d_grid), ptr(theta), ptr(m), ptr(v), 0.1, 0.9, 0.999, 1e-8, t, ptr(step),
+                                                        None, 0.0, None, 0, None, 0, ptr(gmask), stream_ptr()), "bwd_adam")
+        got = d_grid.cpu().numpy()
+        assert np.all(got[:, mask == 0] == 0.0) and rel(got, want) < 1e-5, t
+        th = theta.cpu().numpy()
+        assert np.array_equal(th[:, mask == 0], x0[:, mask == 0]), t
+        assert np.abs(th - ref.detach().numpy()).max() < 1e-5, t
+    assert step.item() == 10
+
+
 def test_tiled_backward_addend(ebos):
     """addend [2, H, W] of ebos_iwe_dense_tiled_bwd_f32 is added to d_flow exactly once (bit-exact: one f32 add)."""
     from event_based_bos_amd import event_plan as EP

@@ -311,3 +311,60 @@ def test_fused_value_and_grad_matches_autograd_and_drives_scipy(terms):
     s.set_previous_frame_best_estimation(np.full((2, 4, 4), 0.25))
     s.estimate(ev)
     assert s.fused and min(s.history) < s.history[0]
+
+
+@pytest.mark.gpu
+def test_event_thresholding_freezes_sparse_patches():
+    """patch.do_event_thresholding / event_thres (src/solver/patch_eklt.py:62-67,118-126): a patch is estimated only when
+    MORE than event_thres events fall inside its crop window; the others keep zero flow.  The mask comes from the plan's
+    histogram (no per-patch crop_event pass) and equals the reference's loop; the fused loop (grad_mask of the Adam
+    kernel), the autograd loop, the scipy path and the window pipeline freeze the same patches."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd import types, utils
+
+    h, w = 96, 128
+    ev = moving_points(h, w, 500, 40, np.array([4.0, -2.5]), seed=5)
+    ev = ev[~((ev[:, 0] < 48) & (ev[:, 1] >= 64))]          # empty the top-right quadrant ...
+    ev = np.concatenate([ev, [[10.0, 100.0, 10.01, 1.0], [30.0, 90.0, 10.012, 0.0]]])  # ... but for two events
+    ev = ev[np.argsort(ev[:, 2], kind="stable")]
+    patch = slide = (24, 32)
+    x0, x1, y0, y1 = types.patch_bounds((h, w), patch, slide)
+    counts = np.array([[len(utils.crop_event(ev, x0[a], x1[a], y0[b], y1[b])) for b in range(len(y0))] for a in range(len(x0))])
+    thres = 50
+    want = counts > thres
+    assert 0 < want.sum() < want.size
+    flows = {}
+    for name, opt in [("fused", {"method": "Adam", "n_iter": 30, "parameters": {"lr": 0.2}, "fused": True}),
+                      ("autograd", {"method": "Adam", "n_iter": 30, "parameters": {"lr": 0.2}, "fused": False}),
+                      ("scipy", {"method": "L-BFGS-B", "n_iter": 5, "fused": True})]:
+        cfg = load_cfg()["solver"]
+        cfg.update(patch={"size": list(patch), "sliding_window": list(slide), "do_event_thresholding": True, "event_thres": thres},
+                   cost_with_weight={"image_variance": 1.0, "flow_norm": 0.01}, iwe={"method": "bilinear_vote", "blur_sigma": 0},
+                   optimizer=opt)
+        s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+        if name == "scipy":
+            s.set_previous_frame_best_estimation(np.full((2,) + want.shape, 0.25))  # off the kink at zero flow
+        s.estimate(ev)
+        plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto")
+        assert np.array_equal(s.patch_mask(plan, patch, slide).cpu().numpy() > 0, want)
+        pf = s.patch_flow.cpu().numpy()
+        assert np.all(pf[:, ~want] == 0.0), name                       # frozen patches: exactly zero
+        assert np.all(np.abs(pf[:, want]).max(0) > 0.0), name          # the others moved
+        flows[name] = pf
+    assert np.abs(flows["fused"] - flows["autograd"]).max() < 0.25
+    # no thresholding: every patch is estimated
+    cfg["patch"]["do_event_thresholding"] = False
+    cfg["optimizer"] = {"method": "Adam", "n_iter": 5, "parameters": {"lr": 0.2}}
+    s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    s.estimate(ev)
+    assert np.all(np.abs(s.patch_flow.cpu().numpy()).max(0) > 0.0)
+    # the window pipeline applies the same mask
+    cfg["patch"]["do_event_thresholding"] = True
+    cfg["optimizer"] = {"method": "Adam", "n_iter": 30, "parameters": {"lr": 0.2}}
+    solver = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    us = np.round((ev[:, 2] - 10.0) * 1e6).astype(np.int64) + 1_000_000
+    store = ebos.data_loader.RawEventStore({"x": ev[:, 1], "y": ev[:, 0], "t": us, "p": ev[:, 3]})
+    pipe = ebos.solver.WindowPipeline(solver, n_concurrent=2)
+    pipe.run(store, [(0, len(ev))])
+    pf = pipe.patch_flows[0].cpu().numpy() if hasattr(pipe.patch_flows[0], "cpu") else np.asarray(pipe.patch_flows[0])
+    assert np.all(pf[:, ~want] == 0.0) and np.all(np.abs(pf[:, want]).max(0) > 0.0)
