@@ -97,6 +97,14 @@ SIGNATURES = {
     "ebos_upsample_patch_flow_bwd_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "ebos_upsample_patch_flow_bwd_adam_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _D, _D, _D, _D, _I, _P,
                                                    _P, _F, _P, _I, _P, _I, _P, _P]),
+    "ebos_patch_fused_supported": (_I, [_I, _I, _I, _I, _I]),
+    "ebos_iwe_patch_slab_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I,
+                                     _P, _P, _P, _P]),
+    "ebos_patch_grad_partials_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "ebos_iwe_patch_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P,
+                                          _P, _P, _P, _Z, _P, _P]),
+    "ebos_patch_grad_combine_adam_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _I, _P, _P,
+                                              _F, _P, _I, _P, _I, _P, _P]),
     "ebos_flow_regularisers_partials": (_I, []),
     "ebos_flow_regularisers_f32": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _L, _L, _P, _P, _P]),
     "ebos_iwe_slab_partials": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
@@ -123,7 +131,8 @@ class CmaxPatchProblem(C.Structure):
                 [(k, _P) for k in ("dense", "d_dense", "d_reg", "iwe", "variance", "d_iwe", "cost_scratch")] +
                 [("cost_scratch_bytes", _Z)] +
                 [(k, _P) for k in ("moments", "upstream", "reg_partials", "upsample_scratch", "workspace")] +
-                [("workspace_bytes", _Z), ("losses", _P), ("losses_cap", _I), ("theta_mask", _P)])
+                [("workspace_bytes", _Z), ("losses", _P), ("losses_cap", _I), ("theta_mask", _P), ("grad_partials", _P),
+                 ("grad_partials_bytes", _Z)])
 
 
 _lib: Optional[C.CDLL] = None

@@ -12,49 +12,10 @@
 #include <math.h>
 
 #include "common.h"
+#include "patch_grid.h"
 
 namespace ebos {
 namespace {
-
-struct Axis {
-  int g;      // grid cells on this axis
-  int pad;    // replicate padding (cells)
-  int slide;  // integer scale
-  int off;    // first row/col of the crop in the un-cropped resize output
-  int n_in;   // g + 2 pad
-};
-
-__host__ __device__ inline Axis make_axis(int g, int patch, int slide, int out) {
-  Axis a;
-  a.g = g;
-  a.pad = (int)((patch / 2.0) / slide) + 1;  // int(patch / 2 // slide) + 1, src/solver/patch_eklt.py:183-184
-  a.slide = slide;
-  a.n_in = g + 2 * a.pad;
-  const int n_full = a.n_in * slide;
-  a.off = n_full / 2 - out / 2;              // :196-199
-  return a;
-}
-
-struct Lerp {
-  int i0, i1;  // grid indices (after un-padding + clamping)
-  float w0, w1;
-};
-
-__device__ __forceinline__ Lerp lerp_at(const Axis& a, int r) {
-  const int R = r + a.off;
-  float src = ((float)R + 0.5f) / (float)a.slide - 0.5f;  // align_corners = False
-  if (src < 0.0f) src = 0.0f;
-  int p0 = (int)src;
-  if (p0 > a.n_in - 1) p0 = a.n_in - 1;
-  const int p1 = p0 < a.n_in - 1 ? p0 + 1 : p0;
-  Lerp l;
-  l.w1 = src - (float)p0;
-  l.w0 = 1.0f - l.w1;
-  int i0 = p0 - a.pad, i1 = p1 - a.pad;
-  l.i0 = i0 < 0 ? 0 : (i0 > a.g - 1 ? a.g - 1 : i0);
-  l.i1 = i1 < 0 ? 0 : (i1 > a.g - 1 ? a.g - 1 : i1);
-  return l;
-}
 
 // forward: one thread = 4 consecutive columns (one 16-byte store per row) of kUpRows consecutive rows: the horizontal
 // lerps are computed once per thread, the vertical one is uniform per row; the grid (a few KB) is read through L1.
@@ -81,9 +42,7 @@ upsample_kernel(const float* __restrict__ grid, Axis ay, Axis ax, int H, int W, 
     float v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float top = lx[k].w0 * g0[lx[k].i0] + lx[k].w1 * g0[lx[k].i1];
-      const float bot = lx[k].w0 * g1[lx[k].i0] + lx[k].w1 * g1[lx[k].i1];
-      v[k] = ly.w0 * top + ly.w1 * bot;
+      v[k] = grid_bilerp(g0, g1, ly, lx[k]);
     }
     if (VEC4) {
       *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
@@ -99,19 +58,6 @@ upsample_kernel(const float* __restrict__ grid, Axis ay, Axis ax, int H, int W, 
 //   pass 1  S[ch, i, c]      = sum_r wy(r, i) * d_dense[ch, r, c]     coalesced row reads
 //   pass 2  d_grid[ch, i, j] = sum_c wx(c, j) * S[ch, i, c]
 // Rows/columns outside a cell's conservative support are skipped; every pixel is read twice (cells i and i + 1).
-__device__ __forceinline__ void support(const Axis& a, int gi, int n_out, int* lo, int* hi) {
-  // padded indices that clamp onto this cell, +-1 cell of bilinear support, in output pixels
-  const int p_lo = gi == 0 ? 0 : gi + a.pad, p_hi = gi == a.g - 1 ? a.n_in - 1 : gi + a.pad;
-  int l = (p_lo - 1) * a.slide - a.off - 1, h = (p_hi + 2) * a.slide - a.off + 1;
-  *lo = l < 0 ? 0 : l;
-  *hi = h > n_out ? n_out : h;
-}
-
-__device__ __forceinline__ float weight_on(const Axis& a, int r, int gi) {
-  const Lerp l = lerp_at(a, r);
-  return (l.i0 == gi ? l.w0 : 0.0f) + (l.i1 == gi ? l.w1 : 0.0f);
-}
-
 // pass 1: workgroup = 64 columns x 4 row phases (wave k takes rows r_lo + k, r_lo + k + 4, ...), lane = column
 __global__ void __launch_bounds__(256)
 upsample_bwd_rows_kernel(const float* __restrict__ d_dense, Axis ay, int H, int W, float* __restrict__ S) {
@@ -150,22 +96,69 @@ struct AdamJob {
   const float* grad_mask;  // [gh, gw], nullable: patches whose flow is not estimated (too few events) keep their value
 };
 
+// loss of this iteration (parameters BEFORE the update) = contrast_scale * contrast + sum(regulariser partials); one wavefront
+__device__ __forceinline__ void adam_record_loss(const AdamJob& job, int lane) {
+  double reg = 0.0;
+  for (int i = lane; i < job.n_reg; i += 64) reg += job.reg_partials[i];
+  reg = wave_sum(reg);
+  if (lane == 0) {
+    if (job.losses != nullptr && job.t - 1 < job.losses_cap)
+      job.losses[job.t - 1] = (float)((double)job.contrast_scale * (double)(job.contrast ? job.contrast[0] : 0.0f) + reg);
+    job.step[0] = job.t;
+  }
+}
+
+// gradient element i (grid cell `cell` of one flow component): mask, store, Adam step
+__device__ __forceinline__ void adam_apply(const AdamJob& job, int64_t i, int64_t cell, float g, float* __restrict__ d_grid) {
+  if (job.grad_mask != nullptr) g *= job.grad_mask[cell];
+  d_grid[i] = g;
+  if (job.theta != nullptr) {
+    const float mi = job.exp_avg[i] + job.w1 * (g - job.exp_avg[i]);      // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = job.exp_avg_sq[i] * job.beta2 + job.w2 * (g * g);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    job.exp_avg[i] = mi;
+    job.exp_avg_sq[i] = vi;
+    const float denom = sqrtf(vi) / job.bc2_sqrt + job.eps;               // (exp_avg_sq.sqrt() / sqrt(bias_correction2)) + eps
+    job.theta[i] = job.theta[i] - job.step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value = -step_size)
+  }
+}
+
+// Partial cell gradients of the GRID backward kernel (iwe_tiled.hip) -> d_grid (+ Adam): one thread per grid element sums
+// the <= 3 x 3 source tiles (and their work items) whose cell block contains it.
+__global__ void __launch_bounds__(256)
+patch_grad_combine_kernel(const float* __restrict__ partials, const int32_t* __restrict__ part_off, int th, int tw, int tiles_x,
+                          int H, int W, Axis ay, Axis ax, float* __restrict__ d_grid, AdamJob job) {
+  if (job.theta != nullptr && blockIdx.x == 0 && threadIdx.x < 64) adam_record_loss(job, threadIdx.x);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * ay.g * ax.g) return;
+  const int ch = idx / (ay.g * ax.g), cell = idx - ch * (ay.g * ax.g);
+  const int gi = cell / ax.g, gj = cell - gi * ax.g;
+  int r_lo, r_hi, c_lo, c_hi;
+  support(ay, gi, H, &r_lo, &r_hi);
+  support(ax, gj, W, &c_lo, &c_hi);
+  float acc = 0.0f;
+  if (r_lo < r_hi && c_lo < c_hi) {
+    for (int ty = r_lo / th; ty <= (r_hi - 1) / th; ++ty) {
+      const int gi0 = lerp_at(ay, ty * th).i0, gi1 = lerp_at(ay, min(ty * th + th, H) - 1).i1;
+      if (gi < gi0 || gi > gi1) continue;
+      for (int tx = c_lo / tw; tx <= (c_hi - 1) / tw; ++tx) {
+        const int gj0 = lerp_at(ax, tx * tw).i0, gj1 = lerp_at(ax, min(tx * tw + tw, W) - 1).i1;
+        if (gj < gj0 || gj > gj1) continue;
+        const int tile = ty * tiles_x + tx;
+        const int it0 = part_off ? part_off[tile] : tile, it1 = part_off ? part_off[tile + 1] : tile + 1;
+        for (int it = it0; it < it1; ++it)
+          acc += partials[(((int64_t)it * 2 + ch) * kGridCells + (gi - gi0)) * kGridCells + (gj - gj0)];
+      }
+    }
+  }
+  adam_apply(job, idx, cell, acc, d_grid);
+}
+
 // pass 2: one wavefront per grid cell, lanes stride over the cell's column support
 __global__ void __launch_bounds__(256)
 upsample_bwd_cols_kernel(const float* __restrict__ S, Axis ay, Axis ax, int W, float* __restrict__ d_grid, AdamJob job) {
   const int lane = threadIdx.x & 63;
   const int gj = blockIdx.x * 4 + (threadIdx.x >> 6), gi = blockIdx.y, ch = blockIdx.z;
-  if (job.theta != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
-    // loss of this iteration (parameters BEFORE the update) = contrast_scale * contrast + sum(regulariser partials)
-    double reg = 0.0;
-    for (int i = lane; i < job.n_reg; i += 64) reg += job.reg_partials[i];
-    reg = wave_sum(reg);
-    if (lane == 0) {
-      if (job.losses != nullptr && job.t - 1 < job.losses_cap)
-        job.losses[job.t - 1] = (float)((double)job.contrast_scale * (double)(job.contrast ? job.contrast[0] : 0.0f) + reg);
-      job.step[0] = job.t;
-    }
-  }
+  if (job.theta != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) adam_record_loss(job, lane);
   if (gj >= ax.g) return;
   int c_lo, c_hi;
   support(ax, gj, W, &c_lo, &c_hi);
@@ -175,17 +168,7 @@ upsample_bwd_cols_kernel(const float* __restrict__ S, Axis ay, Axis ax, int W, f
   acc = wave_sum(acc);
   if (lane == 0) {
     const int64_t i = ((int64_t)ch * ay.g + gi) * ax.g + gj;
-    if (job.grad_mask != nullptr) acc *= job.grad_mask[(int64_t)gi * ax.g + gj];
-    d_grid[i] = acc;
-    if (job.theta != nullptr) {
-      const float g = acc;
-      const float mi = job.exp_avg[i] + job.w1 * (g - job.exp_avg[i]);      // exp_avg.lerp_(grad, 1 - beta1)
-      const float vi = job.exp_avg_sq[i] * job.beta2 + job.w2 * (g * g);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-      job.exp_avg[i] = mi;
-      job.exp_avg_sq[i] = vi;
-      const float denom = sqrtf(vi) / job.bc2_sqrt + job.eps;               // (exp_avg_sq.sqrt() / sqrt(bias_correction2)) + eps
-      job.theta[i] = job.theta[i] - job.step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value = -step_size)
-    }
+    adam_apply(job, i, (int64_t)gi * ax.g + gj, acc, d_grid);
   }
 }
 
@@ -235,16 +218,14 @@ int ebos_upsample_patch_flow_bwd_f32(const float* d_dense, int gh, int gw, int p
   return upsample_bwd_impl(d_dense, gh, gw, patch_h, patch_w, slide_h, slide_w, H, W, scratch, d_grid, ebos::AdamJob{}, stream);
 }
 
-int ebos_upsample_patch_flow_bwd_adam_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w, int slide_h,
-                                          int slide_w, int H, int W, float* scratch, float* d_grid, float* theta, float* exp_avg,
-                                          float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int t, int* step,
-                                          const float* contrast, float contrast_scale, const double* reg_partials, int n_reg,
-                                          float* losses, int losses_cap, const float* grad_mask, ebos_stream_t stream) {
+static int make_adam_job(ebos::AdamJob* out, float* theta, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                         double eps, int t, int* step, const float* contrast, float contrast_scale, const double* reg_partials,
+                         int n_reg, float* losses, int losses_cap, const float* grad_mask, const char* who) {
   using namespace ebos;
-  EBOS_REQUIRE(theta && exp_avg && exp_avg_sq && step, "ebos_upsample_patch_flow_bwd_adam: NULL optimiser buffer");
+  EBOS_REQUIRE(theta && exp_avg && exp_avg_sq && step, "%s: NULL optimiser buffer", who);
   EBOS_REQUIRE(t >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
-               "ebos_upsample_patch_flow_bwd_adam: bad hyper-parameters (t = %d)", t);
-  EBOS_REQUIRE(n_reg >= 0 && (n_reg == 0 || reg_partials) && losses_cap >= 0, "ebos_upsample_patch_flow_bwd_adam: bad loss bookkeeping");
+               "%s: bad hyper-parameters (t = %d)", who, t);
+  EBOS_REQUIRE(n_reg >= 0 && (n_reg == 0 || reg_partials) && losses_cap >= 0, "%s: bad loss bookkeeping", who);
   const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
   AdamJob job{};
   job.theta = theta;
@@ -265,7 +246,45 @@ int ebos_upsample_patch_flow_bwd_adam_f32(const float* d_dense, int gh, int gw, 
   job.losses = losses;
   job.losses_cap = losses_cap;
   job.grad_mask = grad_mask;
+  *out = job;
+  return EBOS_OK;
+}
+
+int ebos_upsample_patch_flow_bwd_adam_f32(const float* d_dense, int gh, int gw, int patch_h, int patch_w, int slide_h,
+                                          int slide_w, int H, int W, float* scratch, float* d_grid, float* theta, float* exp_avg,
+                                          float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int t, int* step,
+                                          const float* contrast, float contrast_scale, const double* reg_partials, int n_reg,
+                                          float* losses, int losses_cap, const float* grad_mask, ebos_stream_t stream) {
+  ebos::AdamJob job{};
+  if (int rc = make_adam_job(&job, theta, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, t, step, contrast, contrast_scale, reg_partials,
+                             n_reg, losses, losses_cap, grad_mask, "ebos_upsample_patch_flow_bwd_adam"))
+    return rc;
   return upsample_bwd_impl(d_dense, gh, gw, patch_h, patch_w, slide_h, slide_w, H, W, scratch, d_grid, job, stream);
+}
+
+int ebos_patch_grad_combine_adam_f32(const float* grad_partials, const int32_t* part_table, int tile_h, int tile_w, int gh, int gw,
+                                     int patch_h, int patch_w, int slide_h, int slide_w, int H, int W, float* d_grid, float* theta,
+                                     float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int t,
+                                     int* step, const float* contrast, float contrast_scale, const double* reg_partials, int n_reg,
+                                     float* losses, int losses_cap, const float* grad_mask, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(grad_partials && d_grid, "ebos_patch_grad_combine_adam: NULL grad_partials/d_grid");
+  EBOS_REQUIRE(gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 && slide_h > 0 && slide_w > 0 && H > 0 && W > 0 && tile_h > 0 && tile_w > 0,
+               "ebos_patch_grad_combine_adam: bad sizes");
+  AdamJob job{};
+  job.grad_mask = grad_mask;
+  if (theta != nullptr) {  // theta == NULL: plain gradient, no optimiser step
+    if (int rc = make_adam_job(&job, theta, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, t, step, contrast, contrast_scale, reg_partials,
+                               n_reg, losses, losses_cap, grad_mask, "ebos_patch_grad_combine_adam"))
+      return rc;
+  }
+  const Axis ay = make_axis(gh, patch_h, slide_h, H), ax = make_axis(gw, patch_w, slide_w, W);
+  EBOS_REQUIRE(ay.off >= 0 && ax.off >= 0, "ebos_patch_grad_combine_adam: image larger than the resized grid");
+  const int tiles_x = (W + tile_w - 1) / tile_w;
+  patch_grad_combine_kernel<<<dim3((2 * gh * gw + 255) / 256), dim3(256), 0, as_stream(stream)>>>(grad_partials, part_table, tile_h, tile_w,
+                                                                                              tiles_x, H, W, ay, ax, d_grid, job);
+  EBOS_CHECK_LAUNCH("ebos_patch_grad_combine_adam");
+  return EBOS_OK;
 }
 
 }  // extern "C"

@@ -31,6 +31,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.h"
+#include "patch_grid.h"
 
 namespace ebos {
 namespace {
@@ -102,6 +103,7 @@ struct Group {  // 4 consecutive events of one lane
 struct TileRange {
   int ty, tx;
   int slab;                  // index of the slab this workgroup writes
+  int part;                  // which part of its tile this workgroup is (0 when tiles are not split)
   int32_t beg, end;          // FMT_XY: this workgroup's slice of the tile's events (plan order)
   int32_t g_first, g_last;   // groups of 4 this workgroup reads (g_first > g_last: nothing to do)
 };
@@ -115,7 +117,7 @@ __device__ __forceinline__ TileRange tile_range(const int32_t* __restrict__ key_
     tile = ev.item_tile[blockIdx.x];
     if (tile < 0) {  // unused item
       r.ty = r.tx = -1;
-      r.slab = r.beg = r.end = r.g_first = 0;
+      r.slab = r.part = r.beg = r.end = r.g_first = 0;
       r.g_last = -1;
       return r;
     }
@@ -129,6 +131,7 @@ __device__ __forceinline__ TileRange tile_range(const int32_t* __restrict__ key_
   }
   r.ty = tile / tiles_x;
   r.tx = tile - r.ty * tiles_x;
+  r.part = part;
   if (FMT == FMT_COMPACT) {
     const int32_t g0 = ev.grp_off[tile], g1 = ev.grp_off[tile + 1];
     const int32_t chunk = (g1 - g0 + splits - 1) / splits;
@@ -223,6 +226,26 @@ enum AccMode { ACC_F64 = 0, ACC_FX = 1 };
 //     branch-free and their (garbage) values are never read;
 //   * fractions are clamped at 0, so all four fixed-point taps are non-negative and a word is simply (hi << 32) | lo;
 //   * rounding by the magic-number trick (one FMA + one integer subtract per tap).
+// GRID kernels: the flow is a patch grid [2, gh, gw] (src/solver/patch_eklt.py:173-204); every workgroup evaluates the
+// grid -> dense map for its own source tile into LDS ([2][TH * TW] floats behind the accumulators) and the event loop
+// fetches the flow from there -- no dense [2, H, W] field in memory, no upsample launch, LDS reads instead of L2 gathers.
+struct GridSrc {
+  Axis ay, ax;
+};
+
+template <int TH, int TW>
+__device__ __forceinline__ void tile_flow_from_grid(const float* __restrict__ grid, const GridSrc& gs, int tr0, int tc0, int H, int W,
+                                                    float* s_flow) {
+  const float* gu = grid;
+  const float* gv = grid + gs.ay.g * gs.ax.g;
+  for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
+    const int rl = i / TW, cl = i - rl * TW;
+    const Lerp ly = lerp_at(gs.ay, min(tr0 + rl, H - 1)), lx = lerp_at(gs.ax, min(tc0 + cl, W - 1));
+    s_flow[i] = grid_bilerp(gu + ly.i0 * gs.ax.g, gu + ly.i1 * gs.ax.g, ly, lx);
+    s_flow[TH * TW + i] = grid_bilerp(gv + ly.i0 * gs.ax.g, gv + ly.i1 * gs.ax.g, ly, lx);
+  }
+}
+
 struct CGroup {
   unsigned pr[4], pc[4];  // tile-local source row / column
   float dt[4];
@@ -254,7 +277,7 @@ struct ChunkQueue {
 
 // MODE == ACC_F64: the same loop with four ds_add_f64 per event -- the exact redo of a slice whose fixed-point fields
 // overflowed (hot pixels, or a flow that piles thousands of events onto one cell).
-template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX>
+template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false>
 __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                           const float* __restrict__ flow, int H, int W, bool* any_spill,
                                                           const ChunkQueue& queue) {
@@ -264,10 +287,11 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   constexpr float kMagic = 12582912.0f;     // 1.5 * 2^23
   constexpr int kMagicBits = 0x4B400000;
   unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
-  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (int64_t)H * W;
+  // GRID: `flow` is the tile's own [2][TH * TW] flow in LDS
+  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)TH * TW : (int64_t)H * W);
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
-  const unsigned base_lin = (unsigned)(tr.ty * TH * W + tr.tx * TW);
-  const unsigned uW = (unsigned)W;
+  const unsigned base_lin = GRID ? 0u : (unsigned)(tr.ty * TH * W + tr.tx * TW);
+  const unsigned uW = GRID ? (unsigned)TW : (unsigned)W;
   unsigned n_inside = 0;  // events of this wave whose taps went into the window (wave-uniform)
   bool spilled = false;
   const int32_t g_last = tr.g_last;
@@ -358,7 +382,7 @@ enum Pass { PASS_MAIN = 0, PASS_SPILL = 1 };
 
 // UNIFORM: one translation theta for all events (2-DoF model, src/warp.py:364-383: x' = x + dt * theta, i.e. a
 // dense flow of -theta everywhere) -- the two flow gathers disappear.
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM>
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM, bool GRID = false>
 __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                      const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                      float* spill, bool* any_spill, const ChunkQueue& queue) {
@@ -367,13 +391,14 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
   const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
   const int oy = tr0 - HALO, ox = tc0 - HALO;  // LDS cell (0,0) = un-padded pixel (oy, ox)
-  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (int64_t)H * W;
+  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)TH * TW : (int64_t)H * W);
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;  // flow == theta pair
+  const int fl_r0 = GRID ? tr0 : 0, fl_c0 = GRID ? tc0 : 0, fl_w = GRID ? TW : W;  // GRID: tile-local flow in LDS
   unsigned long long added = 0;  // FX: integer total this thread put into LDS
   bool spilled = false;
   if (tr.g_first > tr.g_last) return 0;
   if (FMT == FMT_COMPACT && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop (fixed point, or its exact f64 redo)
-    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE>(tr, s_acc, ev, flow, H, W, any_spill, queue);
+    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID>(tr, s_acc, ev, flow, H, W, any_spill, queue);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
   const int32_t g_last = tr.g_last;
@@ -384,7 +409,7 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
   float fu[4], fv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int lin = cur.rs[e] * W + cur.cs[e];
+    const int lin = (cur.rs[e] - fl_r0) * fl_w + (cur.cs[e] - fl_c0);
     fu[e] = UNIFORM ? uni_u : flow[lin];
     fv[e] = UNIFORM ? uni_v : flow1[lin];
   }
@@ -392,7 +417,7 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
     float gu[4], gv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {  // gathers of the NEXT group (sorted events: broadcast / adjacent addresses)
-      const int lin = nxt.rs[e] * W + nxt.cs[e];
+      const int lin = (nxt.rs[e] - fl_r0) * fl_w + (nxt.cs[e] - fl_c0);
       gu[e] = UNIFORM ? uni_u : flow[lin];
       gv[e] = UNIFORM ? uni_v : flow1[lin];
     }
@@ -470,10 +495,10 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 __device__ __forceinline__ long long fx_lo(long long v) { return (long long)(int)(unsigned)(v & 0xffffffffll); }
 __device__ __forceinline__ long long fx_hi(long long v) { return (v - fx_lo(v)) >> 32; }
 
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM>
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false>
 __global__ void __launch_bounds__(kBlock)
-iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow, int H, int W,
-                           int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill) {
+iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
+                           int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill, GridSrc gs) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr int kCells = LH * LW + LW / 2 + 2;  // + a dummy region that absorbs the adds of out-of-window lanes
   static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
@@ -491,19 +516,25 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
   if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
+  const float* flow = flow_arg;
+  if (GRID) {  // flow_arg is the patch grid: this tile's dense flow goes to LDS, behind the accumulators
+    float* s_flow = reinterpret_cast<float*>(s_acc + kCells);
+    tile_flow_from_grid<TH, TW>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_flow);
+    flow = s_flow;
+  }
   __syncthreads();
   EBOS_STAMP(1);
 
   bool spilled = false;
-  const unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h,
-                                                                                              pad_w, spill, &spilled, queue);
+  const unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID>(
+      tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue);
   if (spilled) s_flag[1] = 1;  // benign race: every writer stores 1
   EBOS_STAMP(2);
   __syncthreads();
   EBOS_STAMP(3);
   if (s_flag[1])  // rare: taps beyond the halo go to the spill image with global atomics
-    accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr,
-                                                                          queue);
+    accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
+                                                                                nullptr, queue);
 
   float4* out = reinterpret_cast<float4*>(slabs + (int64_t)tr.slab * (LH * LW));
   bool f64_flush = (MODE == ACC_F64);
@@ -556,8 +587,8 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
       if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);  // the redo draws its chunks afresh
       __syncthreads();
-      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, nullptr,
-                                                                              queue);
+      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM, GRID>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
+                                                                                    nullptr, queue);
       __syncthreads();
       f64_flush = true;
     }
@@ -738,17 +769,17 @@ struct GradImage {
 // Same budget discipline as accumulate_compact_fx.  PASS_MAIN: events whose four taps lie inside the LDS window of the
 // upstream image (others read a dummy cell and contribute 0, but raise the flag); PASS_SPILL: the rare second sweep
 // for exactly those events, reading the upstream image from global memory.
-template <int TH, int TW, int HALO, bool UNIFORM, int PASS>
+template <int TH, int TW, int HALO, bool UNIFORM, int PASS, bool GRID = false>
 __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s_d, const float* s_g, const EvPtrs& ev,
                                                   const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                   const GradImage& G, double& tot_x, double& tot_y, bool* any_spill,
                                                   const ChunkQueue& queue) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (int64_t)H * W;
+  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)TH * TW : (int64_t)H * W);  // GRID: tile flow in LDS
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
   const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
-  const unsigned base_lin = (unsigned)(tr0 * W + tc0);
-  const unsigned uW = (unsigned)W;
+  const unsigned base_lin = GRID ? 0u : (unsigned)(tr0 * W + tc0);
+  const unsigned uW = GRID ? (unsigned)TW : (unsigned)W;
   bool spilled = false;
   const int32_t g_last = tr.g_last;
   // dynamic chunks of 64 groups per wave, as in the forward loop: with a static stride the first wave was done 5.9 us
@@ -851,22 +882,29 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
 
 // UNIFORM: 2-DoF model (flow == theta pair, x' = x + dt * theta): no flow gathers, and instead of a per-pixel
 // d_flow tile every lane sums dt * dL/d(x', y'); the workgroup writes one partial pair, summed over tiles afterwards.
-template <int TH, int TW, int HALO, bool HAS_W, int FMT, bool UNIFORM>
+// GRID: `flow_arg` is the patch grid [2, gh, gw]; the tile's dense flow is evaluated into LDS, and instead of a d_flow tile
+// the workgroup writes the adjoint of the grid -> dense map restricted to its tile: a block of <= kGridCells x kGridCells
+// partial cell gradients per flow component (part_out [items][2][kGridCells][kGridCells]); patch_grad_combine_kernel
+// (flow_upsample.hip) sums the tiles that touch a cell.  `adaptive`: work items of the plan's part table.
+template <int TH, int TW, int HALO, bool HAS_W, int FMT, bool UNIFORM, bool GRID = false>
 __global__ void __launch_bounds__(kBlock)
-iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow, int H, int W,
+iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
                            int tiles_x, int pad_h, int pad_w, const float* __restrict__ g_image,
                            const float* __restrict__ affine, int g_lo, float* __restrict__ d_flow,
                            float* __restrict__ d_weight, double* __restrict__ partials,
                            const double* __restrict__ var_moments, const float* __restrict__ upstream,
-                           const float* __restrict__ addend, float* __restrict__ part_out) {
+                           const float* __restrict__ addend, float* __restrict__ part_out, GridSrc gs, int adaptive) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
   float* s_g = reinterpret_cast<float*>(s_raw + 2 * TH * TW);      // [LH][LW] upstream gradient tile
-  // part_out != nullptr: adaptive work items -- this workgroup is one part of a tile and writes its partial d_flow tile
-  // to slab tr.slab of part_out; bwd_parts_combine_kernel sums the parts
-  const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, part_out ? 0 : 1);
+  float* s_flow = s_g + LH * LW;                                   // GRID: [2][TH*TW] flow of this tile
+  Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * TH * TW);    // GRID: [TH + TW] row / column interpolation of the tile
+  // part_out != nullptr (dense): adaptive work items -- this workgroup is one part of a tile and writes its partial d_flow
+  // tile to slab tr.slab of part_out; bwd_parts_combine_kernel sums the parts
+  const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, GRID ? (adaptive ? 0 : 1) : (part_out ? 0 : 1));
   if (tr.ty < 0) return;  // unused work item
+  const float* flow = flow_arg;
   const int64_t hw = (int64_t)H * W;
   GradImage G;
   G.g = g_image;
@@ -899,6 +937,12 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       s_g[i] = G.at(oy + rl + pad_h, ox + cl + pad_w);
     }
   }
+  if (GRID) {
+    tile_flow_from_grid<TH, TW>(flow_arg, gs, tr0, tc0, H, W, s_flow);
+    for (int i = threadIdx.x; i < TH + TW; i += kBlock)
+      s_lerp[i] = i < TH ? lerp_at(gs.ay, min(tr0 + i, H - 1)) : lerp_at(gs.ax, min(tc0 + i - TH, W - 1));
+    flow = s_flow;
+  }
   __syncthreads();
 
   double tot_x = 0.0, tot_y = 0.0;  // UNIFORM: this lane's sum of dt * dL/d(x', y')
@@ -906,15 +950,16 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   if (kLean) {
     bool spilled = false;
     if (tr.g_first <= tr.g_last)
-      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, &spilled, queue);
+      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN, GRID>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, &spilled,
+                                                                queue);
     if (spilled) s_spill = 1;
     __syncthreads();
     if (s_spill) {  // rare second sweep; it draws its chunks afresh
       if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
       __syncthreads();
       if (tr.g_first <= tr.g_last)
-        bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, nullptr,
-                                                             queue);
+        bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL, GRID>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
+                                                                   nullptr, queue);
     }
   } else if (tr.g_first <= tr.g_last) {
     const float* __restrict__ flow1 = UNIFORM ? flow : flow + hw;
@@ -1018,6 +1063,44 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     if (threadIdx.x == 0) {
       partials[2 * blockIdx.x] = tot_x;
       partials[2 * blockIdx.x + 1] = tot_y;
+    }
+    return;
+  }
+  if (GRID) {
+    // adjoint of the grid -> dense map on this tile, separable like the stand-alone adjoint: rows first
+    //   S[ch][i][c] = sum_r wy(r, gi0 + i) * (d[ch][r][c] + addend),   then   P[ch][i][j] = sum_c wx(c, gj0 + j) * S[ch][i][c]
+    const int rows = min(TH, H - tr0), cols = min(TW, W - tc0);
+    const int gi0 = s_lerp[0].i0, ni = s_lerp[rows - 1].i1 - gi0 + 1;
+    const int gj0 = s_lerp[TH].i0, nj = s_lerp[TH + cols - 1].i1 - gj0 + 1;
+    float* s_S = s_g;  // the upstream tile is dead by now
+    const bool add = addend != nullptr && tr.part == 0;  // the regulariser gradient enters once per tile
+    for (int idx = threadIdx.x; idx < 2 * ni * TW; idx += kBlock) {
+      const int ch = idx / (ni * TW), rem = idx - ch * (ni * TW);
+      const int i = rem / TW, c = rem - i * TW, gi = gi0 + i;
+      float acc = 0.0f;
+      if (c < cols) {
+        const double* d = s_d + ch * TH * TW + c;
+        const float* ad = add ? addend + ch * hw + (int64_t)tr0 * W + tc0 + c : nullptr;
+        for (int r = 0; r < rows; ++r) {
+          const Lerp l = s_lerp[r];
+          const float wy = (l.i0 == gi ? l.w0 : 0.0f) + (l.i1 == gi ? l.w1 : 0.0f);
+          if (wy != 0.0f) acc += wy * ((float)d[r * TW] + (add ? ad[(int64_t)r * W] : 0.0f));
+        }
+      }
+      s_S[idx] = acc;
+    }
+    __syncthreads();
+    float* out = part_out + (int64_t)tr.slab * (2 * kGridCells * kGridCells);
+    for (int idx = threadIdx.x; idx < 2 * ni * nj; idx += kBlock) {
+      const int ch = idx / (ni * nj), rem = idx - ch * (ni * nj);
+      const int i = rem / nj, j = rem - i * nj, gj = gj0 + j;
+      const float* S = s_S + (ch * ni + i) * TW;
+      float acc = 0.0f;
+      for (int c = 0; c < cols; ++c) {
+        const Lerp l = s_lerp[TH + c];
+        acc += ((l.i0 == gj ? l.w0 : 0.0f) + (l.i1 == gj ? l.w1 : 0.0f)) * S[c];
+      }
+      out[(ch * kGridCells + i) * kGridCells + j] = acc;
     }
     return;
   }
@@ -1126,20 +1209,29 @@ int reserve_lds(K kern, size_t lds, const char* what) {
   return EBOS_OK;
 }
 
+// LDS of the GRID accumulate kernel: accumulators + the tile's own flow; some tile configurations do not fit
+template <int TH, int TW, int HALO>
+constexpr bool grid_fwd_fits() {
+  return ((size_t)(TH + 2 * HALO) * (TW + 2 * HALO) + (TW + 2 * HALO) / 2 + 2) * sizeof(double) + (size_t)2 * TH * TW * sizeof(float) + 1024 <=
+         160 * 1024;
+}
+
 template <int TH, int TW, int HALO>
 int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int splits,
                     int pad_h, int pad_w, char* ws, float* iwe, int want_var, int omit, float* out_var, double* moments,
-                    int acc_mode, hipStream_t s) {
+                    int acc_mode, hipStream_t s, const GridSrc* grid_src = nullptr) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  constexpr size_t lds = ((size_t)LH * LW + LW / 2 + 2) * sizeof(double);  // + dummy region
-  static_assert(lds + 1024 <= 160 * 1024, "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
+  size_t lds = ((size_t)LH * LW + LW / 2 + 2) * sizeof(double);  // + dummy region
+  static_assert(((size_t)LH * LW + LW / 2 + 2) * sizeof(double) + 1024 <= 160 * 1024,
+                "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
   const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
   float* slabs = reinterpret_cast<float*>(ws);
   float* spill = reinterpret_cast<float*>(ws + L.off_spill);
   double* partials = reinterpret_cast<double*>(ws + L.off_partials);
   // unit weights -> verified fixed point (2 ds_add_u64 per event); per-event weights -> f64 (any magnitude/sign)
-  void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*);
+  void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*, GridSrc);
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
+  GridSrc gs{};
 #define EBOS_PICK(HW, MD)                                                                                              \
   (uniform ? (compact ? iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_COMPACT, true>                            \
                       : iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_XY, true>)                                 \
@@ -1149,13 +1241,27 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   else if (acc_mode == ACC_F64) ka = EBOS_PICK(false, ACC_F64);
   else ka = EBOS_PICK(false, ACC_FX);
 #undef EBOS_PICK
+  if (grid_src != nullptr) {  // `flow` is a patch grid, sampled per tile inside the kernel (compact unit-weight plans)
+    if constexpr (grid_fwd_fits<TH, TW, HALO>()) {
+      if (!compact || uniform) {
+        set_error("ebos_iwe_patch_slab: needs the compact plan format and unit weights");
+        return EBOS_ERR_UNSUPPORTED;
+      }
+      ka = iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true>;
+      lds += (size_t)2 * TH * TW * sizeof(float);
+      gs = *grid_src;
+    } else {
+      set_error("ebos_iwe_patch_slab: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
+      return EBOS_ERR_UNSUPPORTED;
+    }
+  }
   if (int rc = reserve_lds(ka, lds, "ebos_iwe_dense_slab")) return rc;
   hipEvent_t t0, t1;
   if (profile_next_pair(&t0, &t1))  // bench.py's roofline leg: events stamped with this dispatch's begin / end
     hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, L.tiles_x,
-                          splits, pad_h, pad_w, slabs, spill);
+                          splits, pad_h, pad_w, slabs, spill, gs);
   else
-    ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill);
+    ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill, gs);
   int64_t nparts;
   if (L.w % 4 == 0 && pad_w % 4 == 0) {
     dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows);
@@ -1181,17 +1287,49 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
 }
 
 template <int TH, int TW, int HALO>
+constexpr size_t grid_bwd_lds() {
+  return (size_t)2 * TH * TW * sizeof(double) + (size_t)(TH + 2 * HALO) * (TW + 2 * HALO) * sizeof(float) +
+         (size_t)2 * TH * TW * sizeof(float) + (size_t)(TH + TW) * sizeof(Lerp);
+}
+template <int TH, int TW, int HALO>
+constexpr bool grid_bwd_fits() {
+  return grid_bwd_lds<TH, TW, HALO>() + 1024 <= 160 * 1024 &&
+         (size_t)2 * kGridCells * TW <= (size_t)(TH + 2 * HALO) * (TW + 2 * HALO);  // row sums reuse the upstream tile
+}
+
+// grid_src != nullptr: `flow` is the patch grid and `part_out` receives the per-item partial cell gradients
+// ([items][2][kGridCells][kGridCells]); `adaptive` then selects the plan's work items
+template <int TH, int TW, int HALO>
 int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int pad_h,
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
                      double* partials, const double* var_moments, const float* upstream, const float* addend, float* part_out,
-                     hipStream_t s) {
+                     hipStream_t s, const GridSrc* grid_src = nullptr, int adaptive = 0) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  constexpr size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
-  static_assert(lds <= 160 * 1024, "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
+  size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
+  static_assert((size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float) <= 160 * 1024,
+                "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
-             const double*, const float*, const float*, float*);
+             const double*, const float*, const float*, float*, GridSrc, int);
+  if (grid_src != nullptr) {
+    if constexpr (grid_bwd_fits<TH, TW, HALO>()) {
+      if (!compact || uniform || part_out == nullptr) {
+        set_error("ebos_iwe_patch_tiled_bwd: needs the compact plan format, unit weights and a partials buffer");
+        return EBOS_ERR_UNSUPPORTED;
+      }
+      kb = iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, true>;
+      lds = grid_bwd_lds<TH, TW, HALO>();
+      if (int rc = reserve_lds(kb, lds, "ebos_iwe_patch_tiled_bwd")) return rc;
+      const unsigned grid = (unsigned)(tiles_y * tiles_x * (adaptive ? kAdaptiveItemsPerTile : 1));
+      kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr,
+                                               nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive);
+      return EBOS_OK;
+    } else {
+      set_error("ebos_iwe_patch_tiled_bwd: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
+      return EBOS_ERR_UNSUPPORTED;
+    }
+  }
 #define EBOS_PICK(HW)                                                                                      \
   (uniform ? (compact ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_COMPACT, true>                    \
                       : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, HW, FMT_XY, true>)                         \
@@ -1203,7 +1341,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
   const unsigned grid = (unsigned)(tiles_y * tiles_x * (part_out ? kAdaptiveItemsPerTile : 1));
   kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
-                                           partials, var_moments, upstream, part_out ? nullptr : addend, part_out);
+                                           partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0);
   if (part_out)
     bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
                                                                                                   addend, d_flow);
@@ -1269,7 +1407,7 @@ size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int h
   return slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w).total;
 }
 
-int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
+static int iwe_slab_entry(const ebos::GridSrc* grid_src, const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
                             const uint16_t* cpix, const float* cdt,
                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
                             int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
@@ -1303,12 +1441,49 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                          \
   launch_slab_fwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, splits, pad_h, pad_w, ws, iwe, want_variance, omit_boundary, \
-                              out_variance, moments, acc_mode, s)
+                              out_variance, moments, acc_mode, s, grid_src)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;
   EBOS_CHECK_LAUNCH("ebos_iwe_dense_slab");
   return EBOS_OK;
+}
+
+int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
+                            const uint16_t* cpix, const float* cdt,
+                            const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
+                            int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
+                            size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
+                            double* moments, const int32_t* part_table, ebos_stream_t stream) {
+  return iwe_slab_entry(nullptr, xs, ys, dts, weight, grp_offsets, cpix, cdt, key_offsets, n, flow, H, W, tile_h, tile_w, halo, splits,
+                        pad_h, pad_w, workspace, workspace_bytes, iwe, want_variance, omit_boundary, out_variance, moments, part_table,
+                        stream);
+}
+
+int ebos_patch_fused_supported(int tile_h, int tile_w, int halo, int slide_h, int slide_w) {
+  using namespace ebos;
+  int rc = 0;
+#define EBOS_CALL(TH, TW, HL) \
+  ((grid_fwd_fits<TH, TW, HL>() && grid_bwd_fits<TH, TW, HL>() && TH / slide_h + 3 <= kGridCells && TW / slide_w + 3 <= kGridCells) ? 1 : 0)
+  if (slide_h <= 0 || slide_w <= 0) return 0;
+  EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+  return rc;
+}
+
+int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const int32_t* key_offsets,
+                            int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w, int H,
+                            int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
+                            size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
+                            double* moments, const int32_t* part_table, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(grid && gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 && slide_h > 0 && slide_w > 0,
+               "ebos_iwe_patch_slab: bad patch grid (%dx%d, patch %dx%d, slide %dx%d)", gh, gw, patch_h, patch_w, slide_h, slide_w);
+  EBOS_REQUIRE(grp_offsets && cpix && cdt, "ebos_iwe_patch_slab: needs the compact plan (grp_offsets / cpix / cdt)");
+  const GridSrc gs{make_axis(gh, patch_h, slide_h, H), make_axis(gw, patch_w, slide_w, W)};
+  return iwe_slab_entry(&gs, nullptr, nullptr, nullptr, nullptr, grp_offsets, cpix, cdt, key_offsets, n, grid, H, W, tile_h, tile_w, halo,
+                        splits, pad_h, pad_w, workspace, workspace_bytes, iwe, want_variance, omit_boundary, out_variance, moments,
+                        part_table, stream);
 }
 
 int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
@@ -1427,6 +1602,53 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;
   EBOS_CHECK_LAUNCH("ebos_iwe_dense_tiled_bwd");
+  return EBOS_OK;
+}
+
+size_t ebos_patch_grad_partials_bytes(int H, int W, int tile_h, int tile_w, int adaptive) {
+  using namespace ebos;
+  if (H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0) return 0;
+  const size_t items = (size_t)((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w) * (adaptive ? kAdaptiveItemsPerTile : 1);
+  return items * 2 * kGridCells * kGridCells * sizeof(float);
+}
+
+int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const int32_t* key_offsets,
+                                 int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w,
+                                 int H, int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
+                                 const float* affine, int g_lo, const double* var_moments, const float* upstream,
+                                 const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
+                                 ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(grid && g_image && grad_partials && key_offsets && grp_offsets && cpix && cdt,
+               "ebos_iwe_patch_tiled_bwd: NULL grid/g_image/grad_partials/plan buffer");
+  EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0 && gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 &&
+                   slide_h > 0 && slide_w > 0,
+               "ebos_iwe_patch_tiled_bwd: bad sizes");
+  EBOS_REQUIRE((var_moments == nullptr) == (upstream == nullptr), "ebos_iwe_patch_tiled_bwd: var_moments and upstream go together");
+  if (!slab_config_ok(tile_h, tile_w, halo) || !ebos_patch_fused_supported(tile_h, tile_w, halo, slide_h, slide_w)) {
+    set_error("ebos_iwe_patch_tiled_bwd: tile %dx%d halo %d with sliding window %dx%d is outside ebos_patch_fused_supported", tile_h,
+              tile_w, halo, slide_h, slide_w);
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  const int adaptive = part_table != nullptr;
+  const size_t need = ebos_patch_grad_partials_bytes(H, W, tile_h, tile_w, adaptive);
+  if (grad_partials_bytes < need) {
+    set_error("ebos_iwe_patch_tiled_bwd: grad_partials too small (%zu < %zu)", grad_partials_bytes, need);
+    return EBOS_ERR_SCRATCH;
+  }
+  hipStream_t s = as_stream(stream);
+  const int n_tiles_ = ((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w);
+  const EvPtrs evp{nullptr, nullptr, nullptr, nullptr, grp_offsets, cpix, cdt, part_table, part_table ? part_table + n_tiles_ + 1 : nullptr,
+                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
+  const GridSrc gs{make_axis(gh, patch_h, slide_h, H), make_axis(gw, patch_w, slide_w, W)};
+  int rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL)                                                                                              \
+  launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, grid, false, H, W, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr, nullptr, \
+                               var_moments, upstream, addend, grad_partials, s, &gs, adaptive)
+  EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+  if (rc != EBOS_OK) return rc;
+  EBOS_CHECK_LAUNCH("ebos_iwe_patch_tiled_bwd");
   return EBOS_OK;
 }
 

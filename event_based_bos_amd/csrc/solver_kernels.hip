@@ -227,9 +227,19 @@ int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, flo
 static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
   using namespace ebos;
   EBOS_REQUIRE(q != nullptr && q->steps_done >= 0, "ebos_cmax_patch_solve: NULL problem or negative steps_done");
-  EBOS_REQUIRE(q->theta && q->d_theta && q->exp_avg && q->exp_avg_sq && q->step && q->dense && q->d_dense && q->iwe &&
-                   q->variance && q->moments && q->upstream && q->upsample_scratch && q->workspace && q->reg_partials,
+  EBOS_REQUIRE(q->theta && q->d_theta && q->exp_avg && q->exp_avg_sq && q->step && q->iwe && q->variance && q->moments &&
+                   q->upstream && q->workspace && q->reg_partials,
                "ebos_cmax_patch_solve: NULL buffer");
+  const bool has_reg_ = q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f;
+  if (q->grad_partials != nullptr) {  // the event kernels sample the patch grid: dense only feeds the regulariser pass
+    EBOS_REQUIRE(!has_reg_ || q->dense, "ebos_cmax_patch_solve: regulariser weights given but dense is NULL");
+    EBOS_REQUIRE(q->grp_offsets && q->cpix && q->cdt, "ebos_cmax_patch_solve: grad_partials (grid-sampling kernels) needs the compact plan");
+    EBOS_REQUIRE(ebos_patch_fused_supported(q->tile_h, q->tile_w, q->halo, q->slide_h, q->slide_w),
+                 "ebos_cmax_patch_solve: grad_partials given but tile %dx%d halo %d / sliding window %dx%d is outside "
+                 "ebos_patch_fused_supported", q->tile_h, q->tile_w, q->halo, q->slide_h, q->slide_w);
+  } else {
+    EBOS_REQUIRE(q->dense && q->d_dense && q->upsample_scratch, "ebos_cmax_patch_solve: NULL dense / d_dense / upsample_scratch");
+  }
   EBOS_REQUIRE((q->w_flow_norm == 0.0f && q->w_image_gradient == 0.0f) || q->d_reg,
                "ebos_cmax_patch_solve: regulariser weights given but d_reg is NULL");
   EBOS_REQUIRE((q->w_variance != 0.0f) != (q->w_gradient_magnitude != 0.0f),
@@ -242,16 +252,26 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
 static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_stream_t stream) {
   using namespace ebos;
   const bool has_reg = q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f;
-  int rc = ebos_upsample_patch_flow_f32(q->theta, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W,
-                                        q->dense, stream);
-  if (rc) return rc;
+  const bool grid = q->grad_partials != nullptr;  // the event kernels evaluate the grid -> dense map per tile themselves
+  int rc = EBOS_OK;
+  if (!grid || has_reg) {  // (the regulariser pass reads the dense field)
+    rc = ebos_upsample_patch_flow_f32(q->theta, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->dense,
+                                      stream);
+    if (rc) return rc;
+  }
   const bool use_gm = q->w_gradient_magnitude != 0.0f;
   const int h = q->H + 2 * q->pad_h, w = q->W + 2 * q->pad_w;
   const float contrast_weight = use_gm ? q->w_gradient_magnitude : q->w_variance;
-  rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
-                               q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->workspace,
-                               q->workspace_bytes, q->iwe, use_gm ? 0 : (has_reg ? 2 : 1), q->omit_boundary, q->variance,
-                               q->moments, q->part_table, stream);
+  if (grid)
+    rc = ebos_iwe_patch_slab_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h, q->patch_w,
+                                 q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w,
+                                 q->workspace, q->workspace_bytes, q->iwe, use_gm ? 0 : (has_reg ? 2 : 1), q->omit_boundary,
+                                 q->variance, q->moments, q->part_table, stream);
+  else
+    rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
+                                 q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->workspace,
+                                 q->workspace_bytes, q->iwe, use_gm ? 0 : (has_reg ? 2 : 1), q->omit_boundary, q->variance,
+                                 q->moments, q->part_table, stream);
   if (rc) return rc;
   if (use_gm) {  // contrast = mean squared Sobel gradient of the IWE; its gradient image feeds the backward event kernel
     rc = ebos_gradient_magnitude_f32(q->iwe, 1, h, w, q->omit_boundary, q->variance, q->cost_scratch, q->cost_scratch_bytes, stream);
@@ -269,6 +289,20 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
                                     use_gm ? nullptr : reinterpret_cast<const double*>(static_cast<const char*>(q->workspace) + off),
                                     n_parts, n_px, q->variance, q->moments, stream);
     if (rc) return rc;
+  }
+  if (grid) {
+    rc = ebos_iwe_patch_tiled_bwd_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h,
+                                      q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,
+                                      use_gm ? q->d_iwe : q->iwe, nullptr, use_gm ? 0 : (q->omit_boundary ? 1 : 0),
+                                      use_gm ? nullptr : q->moments, use_gm ? nullptr : q->upstream, has_reg ? q->d_reg : nullptr,
+                                      q->grad_partials, q->grad_partials_bytes, q->splits == 0 ? q->part_table : nullptr, stream);
+    if (rc) return rc;
+    // partial cell gradients -> d_theta, the Adam step of every grid element and the loss of the iteration
+    return ebos_patch_grad_combine_adam_f32(q->grad_partials, q->splits == 0 ? q->part_table : nullptr, q->tile_h, q->tile_w, q->gh,
+                                            q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->d_theta, q->theta,
+                                            q->exp_avg, q->exp_avg_sq, q->lr, q->beta1, q->beta2, q->eps, t, q->step, q->variance,
+                                            -contrast_weight, q->reg_partials, has_reg ? ebos::kRegGrid : 0, q->losses, q->losses_cap,
+                                            q->theta_mask, stream);
   }
   rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
                                     q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,

@@ -45,7 +45,8 @@ class FusedPatchLoop(object):
     def __init__(self, plan: EventPlan, patch_size: Tuple[int, int], sliding_window: Tuple[int, int], theta0: torch.Tensor,
                  w_variance: float, w_flow_norm: float = 0.0, w_image_gradient: float = 0.0, omit_boundary: bool = False,
                  pad: int = 0, halo: int = 32, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, capacity: int = 1024,
-                 splits: Optional[int] = None, w_gradient_magnitude: float = 0.0, theta_mask: Optional[torch.Tensor] = None):
+                 splits: Optional[int] = None, w_gradient_magnitude: float = 0.0, theta_mask: Optional[torch.Tensor] = None,
+                 sample_grid: Optional[bool] = None):
         self.lib = _hip.require_gpu()
         self.plan, self.patch, self.slide = plan, tuple(int(v) for v in patch_size), tuple(int(v) for v in sliding_window)
         self.w_var, self.w_norm, self.w_tv = float(w_variance), float(w_flow_norm), float(w_image_gradient)
@@ -66,8 +67,17 @@ class FusedPatchLoop(object):
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.theta), torch.zeros_like(self.theta)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)  # device mirror of self.t
         self.t = 0  # Adam steps applied so far (host side: the bias corrections of a step are kernel arguments)
-        self.dense, self.d_dense = torch.empty((2, H, W), **f32), torch.empty((2, H, W), **f32)
         self.has_reg = self.w_norm != 0.0 or self.w_tv != 0.0
+        # sample_grid (default: whenever supported): the event kernels evaluate the patch grid -> dense map per tile
+        # themselves (ebos_iwe_patch_*): no upsample / adjoint launches, no [2, H, W] flow and gradient fields
+        can = bool(plan.compact and self.lib.ebos_patch_fused_supported(plan.tile[0], plan.tile[1], self.halo, self.slide[0],
+                                                                        self.slide[1]))
+        if sample_grid and not can:
+            raise ValueError(f"sample_grid: tile {plan.tile} / halo {self.halo} / sliding window {self.slide} is outside "
+                             "ebos_patch_fused_supported (or the plan is not compact)")
+        self.sample_grid = can if sample_grid is None else bool(sample_grid)
+        self.dense = torch.empty((2, H, W), **f32) if (self.has_reg or not self.sample_grid) else None
+        self.d_dense = None if self.sample_grid else torch.empty((2, H, W), **f32)
         self.n_reg = int(self.lib.ebos_flow_regularisers_partials()) if self.has_reg else 0
         self.d_reg = torch.empty((2, H, W), **f32) if self.has_reg else None
         self.reg_partials = torch.zeros(max(self.n_reg, 1), dtype=torch.float64, device=dev)
@@ -79,8 +89,12 @@ class FusedPatchLoop(object):
         self.cost_scratch = (torch.empty(int(self.lib.ebos_cost_scratch_bytes(1)), dtype=torch.uint8, device=dev)
                              if self.w_gm else None)
         self.losses = torch.zeros(max(int(capacity), 1), **f32)
-        self.scratch_up = torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32)
         self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
+        self.scratch_up = (None if self.sample_grid else
+                           torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32))
+        self.grad_partials = (torch.empty(int(self.lib.ebos_patch_grad_partials_bytes(H, W, plan.tile[0], plan.tile[1],
+                                                                                     int(self.splits == 0))) // 4, **f32)
+                              if self.sample_grid else None)
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.graphed = False  # kept for callers that report it: this loop is never graph-replayed
         import ctypes as C
@@ -94,15 +108,24 @@ class FusedPatchLoop(object):
         """upsample -> IWE + contrast -> regularisers -> d loss / d dense (shared by iteration() and value_and_grad())."""
         H, W = plan.image_size
         gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
-        check(lib.ebos_upsample_patch_flow_f32(ptr(self.theta), gh, gw, ph, pw, sh, sw, H, W, ptr(self.dense), s),
-              "ebos_upsample_patch_flow")
+        grid = self.sample_grid
+        if self.dense is not None:  # (with sample_grid only the regulariser pass reads the dense field)
+            check(lib.ebos_upsample_patch_flow_f32(ptr(self.theta), gh, gw, ph, pw, sh, sw, H, W, ptr(self.dense), s),
+                  "ebos_upsample_patch_flow")
         use_gm = self.w_gm != 0.0
         h, w = self.iwe.shape
-        check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
-                                          ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
-                                          self.halo, self.splits, self.pad[0], self.pad[1], ptr(self.ws), self.ws.numel(),
-                                          ptr(self.iwe), 0 if use_gm else (2 if self.has_reg else 1), int(self.omit),
-                                          ptr(self.variance), ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_dense_slab")
+        want_var = 0 if use_gm else (2 if self.has_reg else 1)
+        if grid:
+            check(lib.ebos_iwe_patch_slab_f32(*plan._compact_ptrs(), ptr(plan.key_offsets), plan.n, ptr(self.theta), gh, gw, ph, pw,
+                                              sh, sw, H, W, plan.tile[0], plan.tile[1], self.halo, self.splits, self.pad[0],
+                                              self.pad[1], ptr(self.ws), self.ws.numel(), ptr(self.iwe), want_var, int(self.omit),
+                                              ptr(self.variance), ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_patch_slab")
+        else:
+            check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
+                                              ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
+                                              self.halo, self.splits, self.pad[0], self.pad[1], ptr(self.ws), self.ws.numel(),
+                                              ptr(self.iwe), want_var, int(self.omit),
+                                              ptr(self.variance), ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_dense_slab")
         if use_gm:  # contrast = mean squared Sobel gradient; its gradient image is the upstream of the backward kernel
             check(lib.ebos_gradient_magnitude_f32(ptr(self.iwe), 1, h, w, int(self.omit), ptr(self.variance), ptr(self.cost_scratch),
                                                   self.cost_scratch.numel(), s), "ebos_gradient_magnitude")
@@ -113,6 +136,14 @@ class FusedPatchLoop(object):
             check(lib.ebos_flow_regularisers_f32(ptr(self.dense), H, W, self.w_norm, self.w_tv, ptr(self.d_reg),
                                                  ptr(self.reg_partials), None if use_gm else self.ws.data_ptr() + off, n_parts, n_px,
                                                  ptr(self.variance), ptr(self.moments), s), "ebos_flow_regularisers")
+        if grid:  # -> partial cell gradients per tile; _grid_gradient() sums them (and applies Adam)
+            check(lib.ebos_iwe_patch_tiled_bwd_f32(*plan._compact_ptrs(), ptr(plan.key_offsets), plan.n, ptr(self.theta), gh, gw, ph, pw,
+                                                   sh, sw, H, W, plan.tile[0], plan.tile[1], self.halo, self.pad[0], self.pad[1],
+                                                   ptr(self.d_iwe if use_gm else self.iwe), None, 0 if use_gm else int(self.omit),
+                                                   None if use_gm else ptr(self.moments), None if use_gm else ptr(self.upstream),
+                                                   ptr(self.d_reg), ptr(self.grad_partials), self.grad_partials.numel() * 4,
+                                                   ptr(plan.part_table) if self.splits == 0 else None, s), "ebos_iwe_patch_tiled_bwd")
+            return
         check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                                ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
                                                self.halo, self.pad[0], self.pad[1], ptr(self.d_iwe if use_gm else self.iwe), None,
@@ -128,6 +159,14 @@ class FusedPatchLoop(object):
         gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
         self._forward_backward(lib, plan, s)
         self.t += 1
+        if self.sample_grid:
+            check(lib.ebos_patch_grad_combine_adam_f32(ptr(self.grad_partials), ptr(plan.part_table) if self.splits == 0 else None,
+                                                       plan.tile[0], plan.tile[1], gh, gw, ph, pw, sh, sw, H, W, ptr(self.d_theta),
+                                                       ptr(self.theta), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.lr, self.betas[0],
+                                                       self.betas[1], self.eps, self.t, ptr(self.step), ptr(self.variance),
+                                                       -(self.w_gm or self.w_var), ptr(self.reg_partials), self.n_reg, ptr(self.losses),
+                                                       self.losses.numel(), ptr(self.theta_mask), s), "ebos_patch_grad_combine_adam")
+            return
         check(lib.ebos_upsample_patch_flow_bwd_adam_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
                                                         ptr(self.d_theta), ptr(self.theta), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                                         self.lr, self.betas[0], self.betas[1], self.eps, self.t, ptr(self.step),
@@ -144,8 +183,14 @@ class FusedPatchLoop(object):
         with torch.cuda.device(plan.device):
             self.theta.copy_(theta.detach().to(self.theta))
             self._forward_backward(lib, plan, s)
-            check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
-                                                       ptr(self.d_theta), s), "ebos_upsample_patch_flow_bwd")
+            if self.sample_grid:  # plain gradient: theta = NULL, no optimiser step
+                check(lib.ebos_patch_grad_combine_adam_f32(ptr(self.grad_partials), ptr(plan.part_table) if self.splits == 0 else None,
+                                                           plan.tile[0], plan.tile[1], gh, gw, ph, pw, sh, sw, H, W, ptr(self.d_theta),
+                                                           None, None, None, 0.0, 0.0, 0.0, 0.0, 0, None, None, 0.0, None, 0, None, 0,
+                                                           None, s), "ebos_patch_grad_combine_adam")
+            else:
+                check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
+                                                           ptr(self.d_theta), s), "ebos_upsample_patch_flow_bwd")
             loss = -(self.w_gm or self.w_var) * self.variance[0]
             if self.has_reg:
                 loss = loss + self.reg_partials.sum().to(torch.float32)
@@ -175,6 +220,8 @@ class FusedPatchLoop(object):
         q.workspace, q.workspace_bytes = ptr(self.ws), self.ws.numel()
         q.losses, q.losses_cap = ptr(self.losses), self.losses.numel()
         q.theta_mask = ptr(self.theta_mask)
+        q.grad_partials = ptr(self.grad_partials)
+        q.grad_partials_bytes = self.grad_partials.numel() * 4 if self.grad_partials is not None else 0
         return q
 
     def run(self, n_iter: int, native: bool = True) -> torch.Tensor:

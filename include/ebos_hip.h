@@ -331,6 +331,48 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
                                  void* workspace, size_t workspace_bytes, const int32_t* part_table,
                                  ebos_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The same pipeline with the flow given as a PATCH GRID [2, gh, gw] (the parameters of the patch solvers,
+ * src/solver/patch_eklt.py:173-204: dense = crop(resize(replicate_pad(grid)))): every workgroup evaluates the
+ * grid -> dense map for its own source tile into LDS and the event loop takes the flow from there -- no dense
+ * [2, H, W] field, no upsample launch, LDS reads instead of L2 gathers ("fused into the warp's flow
+ * fetch").  Same results as ebos_upsample_patch_flow_f32 + ebos_iwe_dense_slab_f32 (one shared expression).
+ *
+ * ebos_patch_fused_supported   1 when (tile, halo) leaves LDS for the tile's flow and a tile touches at most 16 x 16
+ *   grid cells (tile / slide + 3 <= 16 per axis); 0 otherwise (use the upsample + dense entry points).
+ * ebos_iwe_patch_slab_f32      forward; arguments as ebos_iwe_dense_slab_f32 with (grid, gh, gw, patch, slide) in place
+ *   of flow; compact plans with unit weights only.
+ * ebos_iwe_patch_tiled_bwd_f32 backward; instead of d_flow every work item writes the adjoint of the grid -> dense map
+ *   restricted to its tile: <= 16 x 16 partial cell gradients per flow component into grad_partials
+ *   (ebos_patch_grad_partials_bytes; adaptive = part_table != NULL).  addend [2, H, W] (nullable) enters once per tile.
+ * ebos_patch_grad_combine_adam_f32   d_grid [2, gh, gw] := sum of the partials of the tiles touching each cell, times
+ *   grad_mask (nullable); with theta != NULL also the Adam step and loss bookkeeping of
+ *   ebos_upsample_patch_flow_bwd_adam_f32 (same arguments).  theta == NULL: plain gradient (optimiser arguments unused).
+ * Together they replace upsample -> dense slab -> dense tiled bwd -> adjoint rows -> adjoint cols (+ Adam): five
+ * launches become three and the [2, H, W] flow / gradient fields disappear.
+ * ---------------------------------------------------------------------------------------- */
+int ebos_patch_fused_supported(int tile_h, int tile_w, int halo, int slide_h, int slide_w);
+int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                            const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw, int patch_h,
+                            int patch_w, int slide_h, int slide_w, int H, int W, int tile_h, int tile_w, int halo,
+                            int splits, int pad_h, int pad_w, void* workspace, size_t workspace_bytes, float* iwe,
+                            int want_variance, int omit_boundary, float* out_variance, double* moments,
+                            const int32_t* part_table, ebos_stream_t stream);
+size_t ebos_patch_grad_partials_bytes(int H, int W, int tile_h, int tile_w, int adaptive);
+int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                                 const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw,
+                                 int patch_h, int patch_w, int slide_h, int slide_w, int H, int W, int tile_h,
+                                 int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
+                                 const float* affine, int g_lo, const double* var_moments, const float* upstream,
+                                 const float* addend, float* grad_partials, size_t grad_partials_bytes,
+                                 const int32_t* part_table, ebos_stream_t stream);
+int ebos_patch_grad_combine_adam_f32(const float* grad_partials, const int32_t* part_table, int tile_h, int tile_w,
+                                     int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w, int H, int W,
+                                     float* d_grid, float* theta, float* exp_avg, float* exp_avg_sq, double lr,
+                                     double beta1, double beta2, double eps, int t, int* step, const float* contrast,
+                                     float contrast_scale, const double* reg_partials, int n_reg, float* losses,
+                                     int losses_cap, const float* grad_mask, ebos_stream_t stream);
+
 /* 2-DoF hypotheses on the tile-private pipeline (BASELINE config 5): thetas [K, 2] (device), x' = x + dt theta
  * (src/warp.py:364-383); iwes [K, h, w] are OVERWRITTEN; out_variance [K] / moments [K, 2] as above.  The K
  * hypotheses run back to back on the stream and share one workspace (same size as for the dense flow). */
@@ -524,6 +566,10 @@ typedef struct ebos_cmax_patch_problem {
   float* losses;
   int losses_cap;
   const float* theta_mask;     /* [gh, gw], nullable: grad_mask of ebos_upsample_patch_flow_bwd_adam_f32 */
+  float* grad_partials;        /* non-NULL: the event kernels sample the patch grid themselves (ebos_iwe_patch_*; needs
+                                  ebos_patch_fused_supported and the compact plan); `dense` is then only written when a flow
+                                  regulariser is on, d_dense / upsample_scratch are not used */
+  size_t grad_partials_bytes;  /* ebos_patch_grad_partials_bytes(H, W, tile_h, tile_w, splits == 0) */
 } ebos_cmax_patch_problem;
 int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* problem, int n_iter, ebos_stream_t stream);
 /* Several independent windows at once (windows are the unit that shards): problem w runs on

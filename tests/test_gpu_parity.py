@@ -1057,3 +1057,88 @@ def test_variance_and_grad_without_autograd(ebos):
         var, grad = plan.variance_and_grad_dense(flow, omit, pad=(pad, pad))
         assert var.item() == v.item() and not grad.requires_grad
         assert rel(grad.cpu().numpy(), f.grad.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("case", [
+    # (H, W, tile, halo, patch, slide, n, blob, splits)
+    (135, 240, (45, 80), 32, (24, 32), (24, 32), 60000, False, 1),
+    (135, 240, (45, 80), 32, (30, 40), (15, 20), 60000, False, 1),      # overlapping patches
+    (100, 150, (45, 80), 32, (17, 23), (17, 23), 30000, False, 1),      # odd sizes, tiles cut by the border
+    (96, 128, (32, 64), 32, (16, 16), (16, 16), 30000, False, 1),
+    (96, 128, (32, 32), 16, (24, 32), (8, 8), 30000, False, 1),         # many cells per tile
+    (135, 240, (45, 80), 32, (24, 32), (24, 32), 120000, True, 0),      # adaptive work items (clustered events)
+    (135, 240, (45, 80), 32, (24, 32), (24, 32), 2, False, 1),          # nearly empty
+])
+@pytest.mark.parametrize("terms", ["var", "var+reg", "gm"])
+def test_grid_sampling_kernels_match_upsample_then_dense(ebos, case, terms):
+    """ebos_iwe_patch_slab_f32 / ebos_iwe_patch_tiled_bwd_f32 / ebos_patch_grad_combine_adam_f32 (the event kernels evaluate
+    the patch grid -> dense map per tile in LDS) against (a) the materialised route upsample -> dense kernels -> adjoint
+    (IWE and loss rel 1e-6, gradient rel-L2 1e-5) and (b) the fp64 oracle, autograd through upsample_patch_flow + iwe_dense +
+    cost (IWE rel-L2 < 1e-4, loss < 1e-5, d loss / d theta rel-L2 < 1e-3)."""
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    H, W, tile, halo, patch, slide, n, blob, splits = case
+    lib = ebos.load_library()
+    if not lib.ebos_patch_fused_supported(tile[0], tile[1], halo, slide[0], slide[1]):
+        pytest.skip("configuration outside ebos_patch_fused_supported")
+    rs = np.random.RandomState(123 + H + n)
+    if blob:
+        r = np.clip(np.rint(rs.normal(H / 2, 6, n)), 0, H - 1)
+        c = np.clip(np.rint(rs.normal(W / 3, 9, n)), 0, W - 1)
+    else:
+        r, c = rs.randint(0, H, n), rs.randint(0, W, n)
+    ev = np.stack([r, c, np.sort(rs.uniform(1.0, 1.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
+    gh, gw = len(np.arange(0, H - patch[0] + slide[0], slide[0])), len(np.arange(0, W - patch[1] + slide[1], slide[1]))
+    theta = rs.uniform(-12, 12, (2, gh, gw))
+    w_var, w_gm = (0.0, 1.5) if terms == "gm" else (2.0, 0.0)
+    w_norm, w_tv = (0.02, 0.03) if terms == "var+reg" else (0.0, 0.0)
+    ev = _off_the_kinks_patch(ev, theta, (H, W), patch, slide)
+    plan = ebos.EventPlan.build(G(ev), (H, W), "first", True, tile=tile)
+    if splits == 0:
+        assert plan.resolve_splits(None) == 0, "the clustered window should have split a tile"
+    out = {}
+    for grid in (True, False):
+        loop = FusedPatchLoop(plan, patch, slide, G(theta).float(), w_var, w_norm, w_tv, halo=halo, capacity=1, splits=splits,
+                              w_gradient_magnitude=w_gm, sample_grid=grid)
+        assert loop.sample_grid == grid and (loop.d_dense is None) == grid
+        loss, grad = loop.value_and_grad(G(theta).float())
+        out[grid] = (loop.iwe.cpu().double().numpy(), float(loss), grad.cpu().double().numpy())
+    assert rel(out[True][0], out[False][0]) < 1e-6
+    assert abs(out[True][1] - out[False][1]) <= 1e-6 * abs(out[False][1])
+    assert rel(out[True][2], out[False][2]) < 1e-5
+    # the oracle
+    tt = torch.from_numpy(theta).requires_grad_(True)
+    dense = O.upsample_patch_flow(tt, (H, W), patch, slide)
+    iwe = O.iwe_dense(torch.from_numpy(ev), dense, (H, W), direction="first")
+    sob = O.sobel3(iwe) / 8.0
+    loss = -(w_gm * torch.mean(sob[0] ** 2 + sob[1] ** 2) if w_gm else w_var * torch.var(iwe))
+    if w_norm or w_tv:
+        loss = loss + w_norm * O.flow_norm(dense) + w_tv * O.image_gradient_tv(dense, torch.ones((H, W), dtype=torch.float64))
+    loss.backward()
+    assert rel(out[True][0], iwe.detach().numpy()) < 1e-4
+    assert abs(out[True][1] - loss.item()) <= 1e-5 * abs(loss.item()) + 1e-9
+    if n > 100:
+        assert rel(out[True][2], tt.grad.numpy()) < 1e-3
+
+
+def _off_the_kinks_patch(ev, theta, size, patch, slide, margin=5e-4):
+    """_off_the_kinks for a patch-grid flow (the fp64 dense field of the oracle's upsample)."""
+    dense = O.upsample_patch_flow(torch.from_numpy(theta), size, patch, slide).numpy()
+    return _off_the_kinks(ev, dense, "first", 1.0, margin)
+
+
+def test_grid_sampling_refuses_unsupported_configurations(ebos):
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    lib = ebos.load_library()
+    assert lib.ebos_patch_fused_supported(45, 80, 32, 24, 32) == 1
+    assert lib.ebos_patch_fused_supported(45, 80, 32, 2, 2) == 0      # too many cells per tile
+    assert lib.ebos_patch_fused_supported(64, 64, 32, 24, 32) == 0    # no LDS left for the tile's flow
+    assert lib.ebos_patch_fused_supported(45, 80, 16, 24, 32) == 0    # not a built configuration
+    ev = O.synth_events(5000, 128, 128, seed=3)
+    plan = ebos.EventPlan.build(G(ev), (128, 128), "first", True, tile=(64, 64))
+    with pytest.raises(ValueError):
+        FusedPatchLoop(plan, (32, 32), (32, 32), torch.zeros((2, 4, 4)), 1.0, sample_grid=True)
+    loop = FusedPatchLoop(plan, (32, 32), (32, 32), torch.zeros((2, 4, 4)), 1.0)   # default: falls back to the dense route
+    assert loop.sample_grid is False
+    loop.run(1)
