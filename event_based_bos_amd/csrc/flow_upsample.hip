@@ -127,16 +127,50 @@ __device__ __forceinline__ void adam_apply(const AdamJob& job, int64_t i, int64_
 __global__ void __launch_bounds__(256)
 patch_grad_combine_kernel(const float* __restrict__ partials, const int32_t* __restrict__ part_off, int th, int tw, int tiles_x,
                           int H, int W, Axis ay, Axis ax, float* __restrict__ d_grid, AdamJob job) {
-  if (job.theta != nullptr && blockIdx.x == 0 && threadIdx.x < 64) adam_record_loss(job, threadIdx.x);
+  if (blockIdx.x == gridDim.x - 1) {  // one extra workgroup only records the loss: its serial partials read overlaps the rest
+    if (job.theta != nullptr && threadIdx.x < 64) adam_record_loss(job, threadIdx.x);
+    return;
+  }
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= 2 * ay.g * ax.g) return;
   const int ch = idx / (ay.g * ax.g), cell = idx - ch * (ay.g * ax.g);
   const int gi = cell / ax.g, gj = cell - gi * ax.g;
+  // candidate tiles per axis (<= kSpan, the conservative pixel support of the cell) and the first cell of each one's block
+  constexpr int kSpan = 4;
   int r_lo, r_hi, c_lo, c_hi;
   support(ay, gi, H, &r_lo, &r_hi);
   support(ax, gj, W, &c_lo, &c_hi);
+  const int ty_a = r_lo / th, tx_a = c_lo / tw;
+  const int ty_n = r_lo < r_hi ? (r_hi - 1) / th - ty_a + 1 : 0, tx_n = c_lo < c_hi ? (c_hi - 1) / tw - tx_a + 1 : 0;
   float acc = 0.0f;
-  if (r_lo < r_hi && c_lo < c_hi) {
+  if (ty_n <= kSpan && tx_n <= kSpan && part_off == nullptr) {
+    // all loads unconditional (clamped), validity as a 0 / 1 factor: the <= 16 reads are in flight together
+    int li[kSpan], lj[kSpan], tyv[kSpan], txv[kSpan];
+    bool oky[kSpan], okx[kSpan];
+    const int tiles_y = (H + th - 1) / th;
+#pragma unroll
+    for (int k = 0; k < kSpan; ++k) {
+      const int ty = min(ty_a + k, tiles_y - 1), tx = min(tx_a + k, tiles_x - 1);
+      const int gi0 = lerp_at(ay, ty * th).i0, gi1 = lerp_at(ay, min(ty * th + th, H) - 1).i1;
+      const int gj0 = lerp_at(ax, tx * tw).i0, gj1 = lerp_at(ax, min(tx * tw + tw, W) - 1).i1;
+      oky[k] = k < ty_n && gi >= gi0 && gi <= gi1;
+      okx[k] = k < tx_n && gj >= gj0 && gj <= gj1;
+      li[k] = oky[k] ? gi - gi0 : 0;
+      lj[k] = okx[k] ? gj - gj0 : 0;
+      tyv[k] = ty;
+      txv[k] = tx;
+    }
+    float v[kSpan][kSpan];
+#pragma unroll
+    for (int a = 0; a < kSpan; ++a)
+#pragma unroll
+      for (int b = 0; b < kSpan; ++b)
+        v[a][b] = partials[(((int64_t)(tyv[a] * tiles_x + txv[b]) * 2 + ch) * kGridCells + li[a]) * kGridCells + lj[b]];
+#pragma unroll
+    for (int a = 0; a < kSpan; ++a)
+#pragma unroll
+      for (int b = 0; b < kSpan; ++b) acc += (oky[a] && okx[b]) ? v[a][b] : 0.0f;
+  } else if (r_lo < r_hi && c_lo < c_hi) {  // adaptive work items, or a cell that spans many tiles: plain loops
     for (int ty = r_lo / th; ty <= (r_hi - 1) / th; ++ty) {
       const int gi0 = lerp_at(ay, ty * th).i0, gi1 = lerp_at(ay, min(ty * th + th, H) - 1).i1;
       if (gi < gi0 || gi > gi1) continue;
@@ -281,7 +315,7 @@ int ebos_patch_grad_combine_adam_f32(const float* grad_partials, const int32_t* 
   const Axis ay = make_axis(gh, patch_h, slide_h, H), ax = make_axis(gw, patch_w, slide_w, W);
   EBOS_REQUIRE(ay.off >= 0 && ax.off >= 0, "ebos_patch_grad_combine_adam: image larger than the resized grid");
   const int tiles_x = (W + tile_w - 1) / tile_w;
-  patch_grad_combine_kernel<<<dim3((2 * gh * gw + 255) / 256), dim3(256), 0, as_stream(stream)>>>(grad_partials, part_table, tile_h, tile_w,
+  patch_grad_combine_kernel<<<dim3((2 * gh * gw + 255) / 256 + 1), dim3(256), 0, as_stream(stream)>>>(grad_partials, part_table, tile_h, tile_w,
                                                                                               tiles_x, H, W, ay, ax, d_grid, job);
   EBOS_CHECK_LAUNCH("ebos_patch_grad_combine_adam");
   return EBOS_OK;

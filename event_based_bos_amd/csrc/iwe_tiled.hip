@@ -1072,34 +1072,50 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     const int rows = min(TH, H - tr0), cols = min(TW, W - tc0);
     const int gi0 = s_lerp[0].i0, ni = s_lerp[rows - 1].i1 - gi0 + 1;
     const int gj0 = s_lerp[TH].i0, nj = s_lerp[TH + cols - 1].i1 - gj0 + 1;
-    float* s_S = s_g;  // the upstream tile is dead by now
-    const bool add = addend != nullptr && tr.part == 0;  // the regulariser gradient enters once per tile
-    for (int idx = threadIdx.x; idx < 2 * ni * TW; idx += kBlock) {
-      const int ch = idx / (ni * TW), rem = idx - ch * (ni * TW);
-      const int i = rem / TW, c = rem - i * TW, gi = gi0 + i;
-      float acc = 0.0f;
-      if (c < cols) {
-        const double* d = s_d + ch * TH * TW + c;
-        const float* ad = add ? addend + ch * hw + (int64_t)tr0 * W + tc0 + c : nullptr;
-        for (int r = 0; r < rows; ++r) {
-          const Lerp l = s_lerp[r];
-          const float wy = (l.i0 == gi ? l.w0 : 0.0f) + (l.i1 == gi ? l.w1 : 0.0f);
-          if (wy != 0.0f) acc += wy * ((float)d[r * TW] + (add ? ad[(int64_t)r * W] : 0.0f));
+    float* s_S = s_g;                          // the upstream tile is dead by now: [2][ni][TW] row sums,
+    float* s_wy = s_g + 2 * kGridCells * TW;   // [ni][TH] row weights (0 beyond the image),
+    float* s_wx = s_wy + kGridCells * TH;      // [nj][TW] column weights
+    for (int idx = threadIdx.x; idx < ni * TH; idx += kBlock) {
+      const int i = idx / TH, r = idx - i * TH;
+      const Lerp l = s_lerp[r];
+      s_wy[idx] = r < rows ? (l.i0 == gi0 + i ? l.w0 : 0.0f) + (l.i1 == gi0 + i ? l.w1 : 0.0f) : 0.0f;
+    }
+    for (int idx = threadIdx.x; idx < nj * TW; idx += kBlock) {
+      const int j = idx / TW, c = idx - j * TW;
+      const Lerp l = s_lerp[TH + c];
+      s_wx[idx] = c < cols ? (l.i0 == gj0 + j ? l.w0 : 0.0f) + (l.i1 == gj0 + j ? l.w1 : 0.0f) : 0.0f;
+    }
+    if (addend != nullptr && tr.part == 0) {  // the regulariser gradient enters once per tile (coalesced row reads)
+      for (int idx = threadIdx.x; idx < TH * TW; idx += kBlock) {
+        const int rl = idx / TW, cl = idx - rl * TW;
+        if (rl < rows && cl < cols) {
+          const int64_t o = (int64_t)(tr0 + rl) * W + tc0 + cl;
+          s_d[idx] += (double)addend[o];
+          s_d[TH * TW + idx] += (double)addend[hw + o];
         }
       }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * ni * TW; idx += kBlock) {
+      const int ch = idx / (ni * TW), rem = idx - ch * (ni * TW);
+      const int i = rem / TW, c = rem - i * TW;
+      const double* d = s_d + ch * TH * TW + c;
+      const float* wy = s_wy + i * TH;
+      float acc = 0.0f;
+#pragma unroll 9
+      for (int r = 0; r < TH; ++r) acc += wy[r] * (float)d[r * TW];
       s_S[idx] = acc;
     }
     __syncthreads();
     float* out = part_out + (int64_t)tr.slab * (2 * kGridCells * kGridCells);
     for (int idx = threadIdx.x; idx < 2 * ni * nj; idx += kBlock) {
       const int ch = idx / (ni * nj), rem = idx - ch * (ni * nj);
-      const int i = rem / nj, j = rem - i * nj, gj = gj0 + j;
+      const int i = rem / nj, j = rem - i * nj;
       const float* S = s_S + (ch * ni + i) * TW;
+      const float* wx = s_wx + j * TW;
       float acc = 0.0f;
-      for (int c = 0; c < cols; ++c) {
-        const Lerp l = s_lerp[TH + c];
-        acc += ((l.i0 == gj ? l.w0 : 0.0f) + (l.i1 == gj ? l.w1 : 0.0f)) * S[c];
-      }
+#pragma unroll 8
+      for (int c = 0; c < TW; ++c) acc += wx[c] * S[c];
       out[(ch * kGridCells + i) * kGridCells + j] = acc;
     }
     return;
@@ -1294,7 +1310,7 @@ constexpr size_t grid_bwd_lds() {
 template <int TH, int TW, int HALO>
 constexpr bool grid_bwd_fits() {
   return grid_bwd_lds<TH, TW, HALO>() + 1024 <= 160 * 1024 &&
-         (size_t)2 * kGridCells * TW <= (size_t)(TH + 2 * HALO) * (TW + 2 * HALO);  // row sums reuse the upstream tile
+         (size_t)kGridCells * (3 * TW + TH) <= (size_t)(TH + 2 * HALO) * (TW + 2 * HALO);  // row sums + weights reuse the upstream tile
 }
 
 // grid_src != nullptr: `flow` is the patch grid and `part_out` receives the per-item partial cell gradients

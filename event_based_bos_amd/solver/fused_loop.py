@@ -18,6 +18,7 @@ even as a replayed HIP graph; this pipeline is bounded by its event kernels.  An
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -75,6 +76,8 @@ class FusedPatchLoop(object):
         if sample_grid and not can:
             raise ValueError(f"sample_grid: tile {plan.tile} / halo {self.halo} / sliding window {self.slide} is outside "
                              "ebos_patch_fused_supported (or the plan is not compact)")
+        if sample_grid is None and os.environ.get("EBOS_SAMPLE_GRID", "1") == "0":  # A/B switch for measurements
+            can = False
         self.sample_grid = can if sample_grid is None else bool(sample_grid)
         self.dense = torch.empty((2, H, W), **f32) if (self.has_reg or not self.sample_grid) else None
         self.d_dense = None if self.sample_grid else torch.empty((2, H, W), **f32)

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--windows", type=int, default=8)
     ap.add_argument("--events", type=int, default=2_000_000)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--nc", type=int, nargs="+", default=[1, 2, 3, 4], help="windows in flight to try")
+    ap.add_argument("--repeat", type=int, default=1, help="timed runs per setting (the minimum is reported)")
     a = ap.parse_args()
     n = a.windows * a.events
     rs = np.random.RandomState(0)
@@ -46,14 +48,19 @@ def main():
         solver.estimate(ev)
     torch.cuda.synchronize()
     res["per_window_estimate_ms"] = (time.perf_counter() - t0) / len(host_windows) * 1e3
-    for nc in (1, 2, 3, 4):
+    for nc in a.nc:
         pipe = ebos.solver.WindowPipeline(solver, n_concurrent=nc)
         pipe.run(store, windows)  # warm: streams, allocator pools, pinned staging
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pipe.run(store, windows)
-        torch.cuda.synchronize()
-        res[f"pipeline_{nc}_ms_per_window"] = (time.perf_counter() - t0) / a.windows * 1e3
+        times = []
+        for _ in range(a.repeat):
+            t0 = time.perf_counter()
+            pipe.run(store, windows)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / a.windows * 1e3)
+        res[f"pipeline_{nc}_ms_per_window"] = min(times)
+        if a.repeat > 1:
+            res[f"pipeline_{nc}_all"] = [round(t, 2) for t in times]
     print(json.dumps(res))
 
 
