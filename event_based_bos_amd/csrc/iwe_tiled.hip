@@ -893,7 +893,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
                            const float* __restrict__ affine, int g_lo, float* __restrict__ d_flow,
                            float* __restrict__ d_weight, double* __restrict__ partials,
                            const double* __restrict__ var_moments, const float* __restrict__ upstream,
-                           const float* __restrict__ addend, float* __restrict__ part_out, GridSrc gs, int adaptive) {
+                           const float* __restrict__ addend, float* __restrict__ part_out, GridSrc gs, int adaptive,
+                           float s_norm, double* __restrict__ reg_partials) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
@@ -1094,6 +1095,29 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
           s_d[TH * TW + idx] += (double)addend[hw + o];
         }
       }
+    }
+    if (reg_partials != nullptr) {
+      // flow_norm regulariser (src/costs/flow_norm.py:45-56: mean |flow|, s_norm = weight / (H W)) is pointwise in the dense
+      // flow, and this tile's flow is in LDS: value partial + gradient here, no dense field and no regulariser launch
+      double val = 0.0;
+      if (tr.part == 0) {
+        for (int idx = threadIdx.x; idx < TH * TW; idx += kBlock) {
+          const int rl = idx / TW, cl = idx - rl * TW;
+          if (rl < rows && cl < cols) {
+            const float u = s_flow[idx], v = s_flow[TH * TW + idx];
+            const float nrm = sqrtf(u * u + v * v);
+            val += (double)(s_norm * nrm);
+            if (nrm > 0.0f) {  // torch: the sub-gradient of the norm at 0 is 0
+              const float inv = s_norm / nrm;
+              s_d[idx] += (double)(inv * u);
+              s_d[TH * TW + idx] += (double)(inv * v);
+            }
+          }
+        }
+      }
+      __shared__ double red_norm[kBlock / kWave];
+      val = block_sum(val, red_norm);
+      if (threadIdx.x == 0) reg_partials[blockIdx.x] = val;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 2 * ni * TW; idx += kBlock) {
@@ -1319,7 +1343,8 @@ template <int TH, int TW, int HALO>
 int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int pad_h,
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
                      double* partials, const double* var_moments, const float* upstream, const float* addend, float* part_out,
-                     hipStream_t s, const GridSrc* grid_src = nullptr, int adaptive = 0) {
+                     hipStream_t s, const GridSrc* grid_src = nullptr, int adaptive = 0, float s_norm = 0.0f,
+                     double* reg_partials = nullptr) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert((size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float) <= 160 * 1024,
@@ -1327,7 +1352,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
-             const double*, const float*, const float*, float*, GridSrc, int);
+             const double*, const float*, const float*, float*, GridSrc, int, float, double*);
   if (grid_src != nullptr) {
     if constexpr (grid_bwd_fits<TH, TW, HALO>()) {
       if (!compact || uniform || part_out == nullptr) {
@@ -1339,7 +1364,8 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
       if (int rc = reserve_lds(kb, lds, "ebos_iwe_patch_tiled_bwd")) return rc;
       const unsigned grid = (unsigned)(tiles_y * tiles_x * (adaptive ? kAdaptiveItemsPerTile : 1));
       kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr,
-                                               nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive);
+                                               nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive, s_norm,
+                                               reg_partials);
       return EBOS_OK;
     } else {
       set_error("ebos_iwe_patch_tiled_bwd: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
@@ -1357,7 +1383,8 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
   const unsigned grid = (unsigned)(tiles_y * tiles_x * (part_out ? kAdaptiveItemsPerTile : 1));
   kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
-                                           partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0);
+                                           partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0, 0.0f,
+                                           nullptr);
   if (part_out)
     bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
                                                                                                   addend, d_flow);
@@ -1633,8 +1660,9 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
                                  int H, int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, const double* var_moments, const float* upstream,
                                  const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
-                                 ebos_stream_t stream) {
+                                 float w_flow_norm, double* reg_partials, ebos_stream_t stream) {
   using namespace ebos;
+  EBOS_REQUIRE(w_flow_norm == 0.0f || reg_partials, "ebos_iwe_patch_tiled_bwd: w_flow_norm given but reg_partials is NULL");
   EBOS_REQUIRE(grid && g_image && grad_partials && key_offsets && grp_offsets && cpix && cdt,
                "ebos_iwe_patch_tiled_bwd: NULL grid/g_image/grad_partials/plan buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0 && gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 &&
@@ -1660,7 +1688,8 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                              \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, grid, false, H, W, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr, nullptr, \
-                               var_moments, upstream, addend, grad_partials, s, &gs, adaptive)
+                               var_moments, upstream, addend, grad_partials, s, &gs, adaptive,                                     \
+                               w_flow_norm / (float)((int64_t)H * W), w_flow_norm != 0.0f ? reg_partials : nullptr)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

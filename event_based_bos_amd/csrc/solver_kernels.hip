@@ -232,7 +232,7 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
                "ebos_cmax_patch_solve: NULL buffer");
   const bool has_reg_ = q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f;
   if (q->grad_partials != nullptr) {  // the event kernels sample the patch grid: dense only feeds the regulariser pass
-    EBOS_REQUIRE(!has_reg_ || q->dense, "ebos_cmax_patch_solve: regulariser weights given but dense is NULL");
+    EBOS_REQUIRE(q->w_image_gradient == 0.0f || q->dense, "ebos_cmax_patch_solve: image_gradient weight given but dense is NULL");
     EBOS_REQUIRE(q->grp_offsets && q->cpix && q->cdt, "ebos_cmax_patch_solve: grad_partials (grid-sampling kernels) needs the compact plan");
     EBOS_REQUIRE(ebos_patch_fused_supported(q->tile_h, q->tile_w, q->halo, q->slide_h, q->slide_w),
                  "ebos_cmax_patch_solve: grad_partials given but tile %dx%d halo %d / sliding window %dx%d is outside "
@@ -240,7 +240,8 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
   } else {
     EBOS_REQUIRE(q->dense && q->d_dense && q->upsample_scratch, "ebos_cmax_patch_solve: NULL dense / d_dense / upsample_scratch");
   }
-  EBOS_REQUIRE((q->w_flow_norm == 0.0f && q->w_image_gradient == 0.0f) || q->d_reg,
+  // (grid sampling with flow_norm only: the backward kernel evaluates that term from the tile's flow, no d_reg image)
+  EBOS_REQUIRE(!has_reg_ || q->d_reg || (q->grad_partials != nullptr && q->w_image_gradient == 0.0f),
                "ebos_cmax_patch_solve: regulariser weights given but d_reg is NULL");
   EBOS_REQUIRE((q->w_variance != 0.0f) != (q->w_gradient_magnitude != 0.0f),
                "ebos_cmax_patch_solve: exactly one of w_variance / w_gradient_magnitude must be non-zero");
@@ -251,8 +252,10 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
 
 static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_stream_t stream) {
   using namespace ebos;
-  const bool has_reg = q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f;
   const bool grid = q->grad_partials != nullptr;  // the event kernels evaluate the grid -> dense map per tile themselves
+  // flow_norm alone is pointwise in the dense flow: with grid sampling the backward kernel evaluates it from the tile's flow
+  const bool fuse_norm = grid && q->w_image_gradient == 0.0f && q->w_flow_norm != 0.0f;
+  const bool has_reg = (q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f) && !fuse_norm;  // regulariser LAUNCH needed
   int rc = EBOS_OK;
   if (!grid || has_reg) {  // (the regulariser pass reads the dense field)
     rc = ebos_upsample_patch_flow_f32(q->theta, q->gh, q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->dense,
@@ -295,14 +298,16 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
                                       q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,
                                       use_gm ? q->d_iwe : q->iwe, nullptr, use_gm ? 0 : (q->omit_boundary ? 1 : 0),
                                       use_gm ? nullptr : q->moments, use_gm ? nullptr : q->upstream, has_reg ? q->d_reg : nullptr,
-                                      q->grad_partials, q->grad_partials_bytes, q->splits == 0 ? q->part_table : nullptr, stream);
+                                      q->grad_partials, q->grad_partials_bytes, q->splits == 0 ? q->part_table : nullptr,
+                                      fuse_norm ? q->w_flow_norm : 0.0f, q->reg_partials, stream);
     if (rc) return rc;
+    const int n_items = (int)(ebos_patch_grad_partials_bytes(q->H, q->W, q->tile_h, q->tile_w, q->splits == 0) / 2048);
     // partial cell gradients -> d_theta, the Adam step of every grid element and the loss of the iteration
     return ebos_patch_grad_combine_adam_f32(q->grad_partials, q->splits == 0 ? q->part_table : nullptr, q->tile_h, q->tile_w, q->gh,
                                             q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->d_theta, q->theta,
                                             q->exp_avg, q->exp_avg_sq, q->lr, q->beta1, q->beta2, q->eps, t, q->step, q->variance,
-                                            -contrast_weight, q->reg_partials, has_reg ? ebos::kRegGrid : 0, q->losses, q->losses_cap,
-                                            q->theta_mask, stream);
+                                            -contrast_weight, q->reg_partials, fuse_norm ? n_items : (has_reg ? ebos::kRegGrid : 0),
+                                            q->losses, q->losses_cap, q->theta_mask, stream);
   }
   rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
                                     q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,

@@ -79,11 +79,13 @@ class FusedPatchLoop(object):
         if sample_grid is None and os.environ.get("EBOS_SAMPLE_GRID", "1") == "0":  # A/B switch for measurements
             can = False
         self.sample_grid = can if sample_grid is None else bool(sample_grid)
+        # flow_norm alone is pointwise in the dense flow: with grid sampling the backward kernel evaluates it per tile
+        self.fuse_norm = self.sample_grid and self.w_tv == 0.0 and self.w_norm != 0.0
+        self.has_reg = self.has_reg and not self.fuse_norm  # from here on: "the regulariser LAUNCH is needed"
         self.dense = torch.empty((2, H, W), **f32) if (self.has_reg or not self.sample_grid) else None
         self.d_dense = None if self.sample_grid else torch.empty((2, H, W), **f32)
         self.n_reg = int(self.lib.ebos_flow_regularisers_partials()) if self.has_reg else 0
         self.d_reg = torch.empty((2, H, W), **f32) if self.has_reg else None
-        self.reg_partials = torch.zeros(max(self.n_reg, 1), dtype=torch.float64, device=dev)
         self.iwe = torch.empty((H + 2 * self.pad[0], W + 2 * self.pad[1]), **f32)
         self.variance = torch.empty(1, **f32)
         self.moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
@@ -98,6 +100,9 @@ class FusedPatchLoop(object):
         self.grad_partials = (torch.empty(int(self.lib.ebos_patch_grad_partials_bytes(H, W, plan.tile[0], plan.tile[1],
                                                                                      int(self.splits == 0))) // 4, **f32)
                               if self.sample_grid else None)
+        if self.fuse_norm:  # one value partial per work item of the backward kernel
+            self.n_reg = self.grad_partials.numel() // 512
+        self.reg_partials = torch.zeros(max(self.n_reg, 1), dtype=torch.float64, device=dev)
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.graphed = False  # kept for callers that report it: this loop is never graph-replayed
         import ctypes as C
@@ -145,7 +150,9 @@ class FusedPatchLoop(object):
                                                    ptr(self.d_iwe if use_gm else self.iwe), None, 0 if use_gm else int(self.omit),
                                                    None if use_gm else ptr(self.moments), None if use_gm else ptr(self.upstream),
                                                    ptr(self.d_reg), ptr(self.grad_partials), self.grad_partials.numel() * 4,
-                                                   ptr(plan.part_table) if self.splits == 0 else None, s), "ebos_iwe_patch_tiled_bwd")
+                                                   ptr(plan.part_table) if self.splits == 0 else None,
+                                                   self.w_norm if self.fuse_norm else 0.0, ptr(self.reg_partials), s),
+                  "ebos_iwe_patch_tiled_bwd")
             return
         check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                                ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
@@ -195,7 +202,7 @@ class FusedPatchLoop(object):
                 check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(self.d_dense), gh, gw, ph, pw, sh, sw, H, W, ptr(self.scratch_up),
                                                            ptr(self.d_theta), s), "ebos_upsample_patch_flow_bwd")
             loss = -(self.w_gm or self.w_var) * self.variance[0]
-            if self.has_reg:
+            if self.n_reg:
                 loss = loss + self.reg_partials.sum().to(torch.float32)
         return loss, (self.d_theta.clone() if self.theta_mask is None else self.d_theta * self.theta_mask)
 

@@ -345,6 +345,10 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
  * ebos_iwe_patch_tiled_bwd_f32 backward; instead of d_flow every work item writes the adjoint of the grid -> dense map
  *   restricted to its tile: <= 16 x 16 partial cell gradients per flow component into grad_partials
  *   (ebos_patch_grad_partials_bytes; adaptive = part_table != NULL).  addend [2, H, W] (nullable) enters once per tile.
+ *   w_flow_norm != 0: the flow_norm regulariser w * mean |flow| (src/costs/flow_norm.py:45-56) is pointwise in the dense
+ *   flow, which the tile holds in LDS: its gradient is added here and its value leaves as one f64 partial per work item in
+ *   reg_partials [ebos_patch_grad_partials_bytes / 2048] (slots of unused work items are not written: zero the buffer
+ *   once) -- no dense field and no ebos_flow_regularisers_f32 launch for this term.
  * ebos_patch_grad_combine_adam_f32   d_grid [2, gh, gw] := sum of the partials of the tiles touching each cell, times
  *   grad_mask (nullable); with theta != NULL also the Adam step and loss bookkeeping of
  *   ebos_upsample_patch_flow_bwd_adam_f32 (same arguments).  theta == NULL: plain gradient (optimiser arguments unused).
@@ -365,7 +369,8 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
                                  int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, const double* var_moments, const float* upstream,
                                  const float* addend, float* grad_partials, size_t grad_partials_bytes,
-                                 const int32_t* part_table, ebos_stream_t stream);
+                                 const int32_t* part_table, float w_flow_norm, double* reg_partials,
+                                 ebos_stream_t stream);
 int ebos_patch_grad_combine_adam_f32(const float* grad_partials, const int32_t* part_table, int tile_h, int tile_w,
                                      int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w, int H, int W,
                                      float* d_grid, float* theta, float* exp_avg, float* exp_avg_sq, double lr,
@@ -530,7 +535,8 @@ int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, flo
  *   grid:     theta/d_theta/exp_avg/exp_avg_sq [2, gh, gw], step [1] int32, patch and sliding window
  *   images:   dense/d_dense [2, H, W], d_reg [2, H, W] (nullable iff both regulariser weights are 0),
  *             iwe [H + 2 pad_h, W + 2 pad_w], variance [1] f32, moments [2] f64, upstream [1] f32 = -w_variance
- *   scratch:  reg_partials [ebos_flow_regularisers_partials()] f64, upsample_scratch
+ *   scratch:  reg_partials [max(ebos_flow_regularisers_partials(), work items = ebos_patch_grad_partials_bytes / 2048)] f64,
+ *             zero-filled once; upsample_scratch
  *             (ebos_upsample_bwd_scratch_bytes), workspace (ebos_iwe_slab_workspace_bytes, zero-filled once)
  *   losses:   [losses_cap] f32, entry `step` written per iteration (nullable)
  *   theta_mask: [gh, gw] f32, 0 = patch not estimated (nullable = all patches)                                 */

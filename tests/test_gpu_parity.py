@@ -1069,7 +1069,7 @@ def test_variance_and_grad_without_autograd(ebos):
     (135, 240, (45, 80), 32, (24, 32), (24, 32), 120000, True, 0),      # adaptive work items (clustered events)
     (135, 240, (45, 80), 32, (24, 32), (24, 32), 2, False, 1),          # nearly empty
 ])
-@pytest.mark.parametrize("terms", ["var", "var+reg", "gm"])
+@pytest.mark.parametrize("terms", ["var", "var+norm", "var+reg", "gm"])
 def test_grid_sampling_kernels_match_upsample_then_dense(ebos, case, terms):
     """ebos_iwe_patch_slab_f32 / ebos_iwe_patch_tiled_bwd_f32 / ebos_patch_grad_combine_adam_f32 (the event kernels evaluate
     the patch grid -> dense map per tile in LDS) against (a) the materialised route upsample -> dense kernels -> adjoint
@@ -1091,7 +1091,8 @@ def test_grid_sampling_kernels_match_upsample_then_dense(ebos, case, terms):
     gh, gw = len(np.arange(0, H - patch[0] + slide[0], slide[0])), len(np.arange(0, W - patch[1] + slide[1], slide[1]))
     theta = rs.uniform(-12, 12, (2, gh, gw))
     w_var, w_gm = (0.0, 1.5) if terms == "gm" else (2.0, 0.0)
-    w_norm, w_tv = (0.02, 0.03) if terms == "var+reg" else (0.0, 0.0)
+    # "var+norm": flow_norm alone is evaluated inside the backward kernel from the tile's flow (no regulariser launch)
+    w_norm, w_tv = {"var+reg": (0.02, 0.03), "var+norm": (0.05, 0.0)}.get(terms, (0.0, 0.0))
     ev = _off_the_kinks_patch(ev, theta, (H, W), patch, slide)
     plan = ebos.EventPlan.build(G(ev), (H, W), "first", True, tile=tile)
     if splits == 0:
@@ -1101,6 +1102,7 @@ def test_grid_sampling_kernels_match_upsample_then_dense(ebos, case, terms):
         loop = FusedPatchLoop(plan, patch, slide, G(theta).float(), w_var, w_norm, w_tv, halo=halo, capacity=1, splits=splits,
                               w_gradient_magnitude=w_gm, sample_grid=grid)
         assert loop.sample_grid == grid and (loop.d_dense is None) == grid
+        assert loop.fuse_norm == (grid and terms == "var+norm") and (loop.dense is None) == (grid and terms != "var+reg")
         loss, grad = loop.value_and_grad(G(theta).float())
         out[grid] = (loop.iwe.cpu().double().numpy(), float(loss), grad.cpu().double().numpy())
     assert rel(out[True][0], out[False][0]) < 1e-6
