@@ -233,17 +233,62 @@ struct GridSrc {
   Axis ay, ax;
 };
 
+// variance of the IWE as the (sum, sum of squares) partials the combine pass left (want_variance = 2): the GRID backward
+// kernel reduces them itself -- every workgroup, redundantly, ~14 KB of L2 reads -- instead of waiting for a finalize launch
+struct MomentsIn {
+  const double* partials;  // nullptr: not used
+  int64_t n_partials, n_pixels;
+  float* out_var;          // written by workgroup 0 (nullable)
+  double* moments;         // (mean, M), written by workgroup 0 (nullable)
+};
+
+// s_lerp [TH + TW]: row / column interpolation of the tile; s_cells [2][kGridCells][kGridCells]: the block of grid cells the
+// tile touches.  Two halves with ONE global round trip (the cell block) between them, which the caller fills with its own
+// set-up work (LDS clear, upstream-tile staging) -- sampling the grid straight from global memory cost 3-4 dependent L2
+// round trips per workgroup.  2 * kGridCells^2 <= kBlock: one cell value per thread.
+struct TileGrid {
+  int gi0, ni, gj0, nj;
+  float cell;  // this thread's value of the cell block (threads >= 2 ni nj: unused)
+};
+
 template <int TH, int TW>
-__device__ __forceinline__ void tile_flow_from_grid(const float* __restrict__ grid, const GridSrc& gs, int tr0, int tc0, int H, int W,
-                                                    float* s_flow) {
-  const float* gu = grid;
-  const float* gv = grid + gs.ay.g * gs.ax.g;
+__device__ __forceinline__ TileGrid tile_grid_begin(const float* __restrict__ grid, const GridSrc& gs, int tr0, int tc0, int H, int W,
+                                                    Lerp* s_lerp) {
+  static_assert(2 * kGridCells * kGridCells <= kBlock, "one cell value per thread");
+  for (int i = threadIdx.x; i < TH + TW; i += kBlock)
+    s_lerp[i] = i < TH ? lerp_at(gs.ay, min(tr0 + i, H - 1)) : lerp_at(gs.ax, min(tc0 + i - TH, W - 1));
+  __syncthreads();
+  const int rows = min(TH, H - tr0), cols = min(TW, W - tc0);
+  TileGrid t;
+  t.gi0 = s_lerp[0].i0, t.ni = s_lerp[rows - 1].i1 - t.gi0 + 1;
+  t.gj0 = s_lerp[TH].i0, t.nj = s_lerp[TH + cols - 1].i1 - t.gj0 + 1;
+  const int idx = min((int)threadIdx.x, 2 * t.ni * t.nj - 1);  // clamped: the load is unconditional
+  const int ch = idx / (t.ni * t.nj), rem = idx - ch * (t.ni * t.nj);
+  const int i = rem / t.nj, j = rem - i * t.nj;
+  t.cell = grid[((int64_t)ch * gs.ay.g + t.gi0 + i) * gs.ax.g + t.gj0 + j];
+  return t;
+}
+
+// second half: cell block -> LDS, then the tile's flow [2][TH * TW].  Ends with a barrier.
+template <int TH, int TW>
+__device__ __forceinline__ void tile_grid_finish(const TileGrid& t, float* s_flow, const Lerp* s_lerp, float* s_cells) {
+  if ((int)threadIdx.x < 2 * t.ni * t.nj) {
+    const int ch = threadIdx.x / (t.ni * t.nj), rem = threadIdx.x - ch * (t.ni * t.nj);
+    const int i = rem / t.nj, j = rem - i * t.nj;
+    s_cells[(ch * kGridCells + i) * kGridCells + j] = t.cell;
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
     const int rl = i / TW, cl = i - rl * TW;
-    const Lerp ly = lerp_at(gs.ay, min(tr0 + rl, H - 1)), lx = lerp_at(gs.ax, min(tc0 + cl, W - 1));
-    s_flow[i] = grid_bilerp(gu + ly.i0 * gs.ax.g, gu + ly.i1 * gs.ax.g, ly, lx);
-    s_flow[TH * TW + i] = grid_bilerp(gv + ly.i0 * gs.ax.g, gv + ly.i1 * gs.ax.g, ly, lx);
+    Lerp ly = s_lerp[rl], lx = s_lerp[TH + cl];
+    lx.i0 -= t.gj0;  // indices into the cell block
+    lx.i1 -= t.gj0;
+    const float* u0 = s_cells + (ly.i0 - t.gi0) * kGridCells;
+    const float* u1 = s_cells + (ly.i1 - t.gi0) * kGridCells;
+    s_flow[i] = grid_bilerp(u0, u1, ly, lx);
+    s_flow[TH * TW + i] = grid_bilerp(u0 + kGridCells * kGridCells, u1 + kGridCells * kGridCells, ly, lx);
   }
+  __syncthreads();
 }
 
 struct CGroup {
@@ -512,14 +557,17 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   if (tr.ty < 0) return;  // unused work item of an adaptive plan: its slab is never read
 
   static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
+  const float* flow = flow_arg;
+  float* s_flow = reinterpret_cast<float*>(s_acc + kCells);  // GRID: the tile's dense flow, behind the accumulators
+  Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * TH * TW);
+  TileGrid tg{};
+  if (GRID) tg = tile_grid_begin<TH, TW>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);  // (its cell load flies over the clear)
   for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
     reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
   if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
-  const float* flow = flow_arg;
-  if (GRID) {  // flow_arg is the patch grid: this tile's dense flow goes to LDS, behind the accumulators
-    float* s_flow = reinterpret_cast<float*>(s_acc + kCells);
-    tile_flow_from_grid<TH, TW>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_flow);
+  if (GRID) {
+    tile_grid_finish<TH, TW>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
     flow = s_flow;
   }
   __syncthreads();
@@ -894,7 +942,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
                            float* __restrict__ d_weight, double* __restrict__ partials,
                            const double* __restrict__ var_moments, const float* __restrict__ upstream,
                            const float* __restrict__ addend, float* __restrict__ part_out, GridSrc gs, int adaptive,
-                           float s_norm, double* __restrict__ reg_partials) {
+                           float s_norm, double* __restrict__ reg_partials, MomentsIn mj) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
@@ -904,6 +952,29 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   // part_out != nullptr (dense): adaptive work items -- this workgroup is one part of a tile and writes its partial d_flow
   // tile to slab tr.slab of part_out; bwd_parts_combine_kernel sums the parts
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, GRID ? (adaptive ? 0 : 1) : (part_out ? 0 : 1));
+  __shared__ double s_mom[2];
+  if (GRID && mj.partials != nullptr && (blockIdx.x == 0 || tr.ty >= 0)) {
+    double sm = 0.0, sq = 0.0;
+    for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
+      sm += mj.partials[2 * i];
+      sq += mj.partials[2 * i + 1];
+    }
+    __shared__ double red_m[kBlock / kWave];
+    sm = block_sum(sm, red_m);
+    sq = block_sum(sq, red_m);
+    if (threadIdx.x == 0) {
+      const double mean = mj.n_pixels > 0 ? sm / (double)mj.n_pixels : 0.0;
+      s_mom[0] = mean;
+      if (blockIdx.x == 0) {
+        if (mj.out_var) mj.out_var[0] = (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
+        if (mj.moments) {
+          mj.moments[0] = mean;
+          mj.moments[1] = (double)mj.n_pixels;
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (tr.ty < 0) return;  // unused work item
   const float* flow = flow_arg;
   const int64_t hw = (int64_t)H * W;
@@ -918,6 +989,11 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     G.a = (float)a;
     G.c = (float)(-a * var_moments[0]);
   }
+  if (GRID && mj.partials != nullptr) {  // the same map from the partials reduced above
+    const double a = 2.0 * (double)upstream[0] / ((double)mj.n_pixels - 1.0);
+    G.a = (float)a;
+    G.c = (float)(-a * s_mom[0]);
+  }
   G.h = H + 2 * pad_h;
   G.w = W + 2 * pad_w;
   G.lo = g_lo;
@@ -931,6 +1007,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     s_spill = 0;
     s_next = 2 * (kBlock / kWave);
   }
+  TileGrid tg{};
+  if (GRID) tg = tile_grid_begin<TH, TW>(flow_arg, gs, tr0, tc0, H, W, s_lerp);  // (its cell load flies over the staging below)
   for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
   if (tr.g_first <= tr.g_last) {
     for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
@@ -939,9 +1017,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
   }
   if (GRID) {
-    tile_flow_from_grid<TH, TW>(flow_arg, gs, tr0, tc0, H, W, s_flow);
-    for (int i = threadIdx.x; i < TH + TW; i += kBlock)
-      s_lerp[i] = i < TH ? lerp_at(gs.ay, min(tr0 + i, H - 1)) : lerp_at(gs.ax, min(tc0 + i - TH, W - 1));
+    tile_grid_finish<TH, TW>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
     flow = s_flow;
   }
   __syncthreads();
@@ -1249,11 +1325,16 @@ int reserve_lds(K kern, size_t lds, const char* what) {
   return EBOS_OK;
 }
 
+// what the GRID kernels add to the LDS of their dense twins: the tile's flow, its row / column interpolation and the cell block
+template <int TH, int TW>
+constexpr size_t grid_lds_extra() {
+  return (size_t)2 * TH * TW * sizeof(float) + (size_t)(TH + TW) * sizeof(Lerp) + (size_t)2 * kGridCells * kGridCells * sizeof(float);
+}
+
 // LDS of the GRID accumulate kernel: accumulators + the tile's own flow; some tile configurations do not fit
 template <int TH, int TW, int HALO>
 constexpr bool grid_fwd_fits() {
-  return ((size_t)(TH + 2 * HALO) * (TW + 2 * HALO) + (TW + 2 * HALO) / 2 + 2) * sizeof(double) + (size_t)2 * TH * TW * sizeof(float) + 1024 <=
-         160 * 1024;
+  return ((size_t)(TH + 2 * HALO) * (TW + 2 * HALO) + (TW + 2 * HALO) / 2 + 2) * sizeof(double) + grid_lds_extra<TH, TW>() + 1024 <= 160 * 1024;
 }
 
 template <int TH, int TW, int HALO>
@@ -1288,7 +1369,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
         return EBOS_ERR_UNSUPPORTED;
       }
       ka = iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true>;
-      lds += (size_t)2 * TH * TW * sizeof(float);
+      lds += grid_lds_extra<TH, TW>();
       gs = *grid_src;
     } else {
       set_error("ebos_iwe_patch_slab: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
@@ -1328,8 +1409,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
 
 template <int TH, int TW, int HALO>
 constexpr size_t grid_bwd_lds() {
-  return (size_t)2 * TH * TW * sizeof(double) + (size_t)(TH + 2 * HALO) * (TW + 2 * HALO) * sizeof(float) +
-         (size_t)2 * TH * TW * sizeof(float) + (size_t)(TH + TW) * sizeof(Lerp);
+  return (size_t)2 * TH * TW * sizeof(double) + (size_t)(TH + 2 * HALO) * (TW + 2 * HALO) * sizeof(float) + grid_lds_extra<TH, TW>();
 }
 template <int TH, int TW, int HALO>
 constexpr bool grid_bwd_fits() {
@@ -1344,7 +1424,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
                      double* partials, const double* var_moments, const float* upstream, const float* addend, float* part_out,
                      hipStream_t s, const GridSrc* grid_src = nullptr, int adaptive = 0, float s_norm = 0.0f,
-                     double* reg_partials = nullptr) {
+                     double* reg_partials = nullptr, MomentsIn mj = MomentsIn{}) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert((size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float) <= 160 * 1024,
@@ -1352,7 +1432,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
-             const double*, const float*, const float*, float*, GridSrc, int, float, double*);
+             const double*, const float*, const float*, float*, GridSrc, int, float, double*, MomentsIn);
   if (grid_src != nullptr) {
     if constexpr (grid_bwd_fits<TH, TW, HALO>()) {
       if (!compact || uniform || part_out == nullptr) {
@@ -1365,7 +1445,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
       const unsigned grid = (unsigned)(tiles_y * tiles_x * (adaptive ? kAdaptiveItemsPerTile : 1));
       kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr,
                                                nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive, s_norm,
-                                               reg_partials);
+                                               reg_partials, mj);
       return EBOS_OK;
     } else {
       set_error("ebos_iwe_patch_tiled_bwd: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
@@ -1384,7 +1464,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   const unsigned grid = (unsigned)(tiles_y * tiles_x * (part_out ? kAdaptiveItemsPerTile : 1));
   kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
                                            partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0, 0.0f,
-                                           nullptr);
+                                           nullptr, MomentsIn{});
   if (part_out)
     bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
                                                                                                   addend, d_flow);
@@ -1523,6 +1603,11 @@ int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, co
   EBOS_REQUIRE(grid && gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 && slide_h > 0 && slide_w > 0,
                "ebos_iwe_patch_slab: bad patch grid (%dx%d, patch %dx%d, slide %dx%d)", gh, gw, patch_h, patch_w, slide_h, slide_w);
   EBOS_REQUIRE(grp_offsets && cpix && cdt, "ebos_iwe_patch_slab: needs the compact plan (grp_offsets / cpix / cdt)");
+  if (!ebos_patch_fused_supported(tile_h, tile_w, halo, slide_h, slide_w)) {
+    set_error("ebos_iwe_patch_slab: tile %dx%d halo %d with sliding window %dx%d is outside ebos_patch_fused_supported", tile_h, tile_w,
+              halo, slide_h, slide_w);
+    return EBOS_ERR_UNSUPPORTED;
+  }
   const GridSrc gs{make_axis(gh, patch_h, slide_h, H), make_axis(gw, patch_w, slide_w, W)};
   return iwe_slab_entry(&gs, nullptr, nullptr, nullptr, nullptr, grp_offsets, cpix, cdt, key_offsets, n, grid, H, W, tile_h, tile_w, halo,
                         splits, pad_h, pad_w, workspace, workspace_bytes, iwe, want_variance, omit_boundary, out_variance, moments,
@@ -1660,15 +1745,20 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
                                  int H, int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, const double* var_moments, const float* upstream,
                                  const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
-                                 float w_flow_norm, double* reg_partials, ebos_stream_t stream) {
+                                 float w_flow_norm, double* reg_partials, const double* var_partials, int64_t n_var_partials,
+                                 int64_t n_var_pixels, float* out_variance, double* out_moments, ebos_stream_t stream) {
   using namespace ebos;
+  EBOS_REQUIRE(var_partials == nullptr || (var_moments == nullptr && upstream != nullptr && n_var_partials >= 1 && n_var_pixels >= 2),
+               "ebos_iwe_patch_tiled_bwd: var_partials needs upstream, no var_moments, and sane counts");
+  const MomentsIn mj{var_partials, n_var_partials, n_var_pixels, out_variance, out_moments};
   EBOS_REQUIRE(w_flow_norm == 0.0f || reg_partials, "ebos_iwe_patch_tiled_bwd: w_flow_norm given but reg_partials is NULL");
   EBOS_REQUIRE(grid && g_image && grad_partials && key_offsets && grp_offsets && cpix && cdt,
                "ebos_iwe_patch_tiled_bwd: NULL grid/g_image/grad_partials/plan buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0 && gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 &&
                    slide_h > 0 && slide_w > 0,
                "ebos_iwe_patch_tiled_bwd: bad sizes");
-  EBOS_REQUIRE((var_moments == nullptr) == (upstream == nullptr), "ebos_iwe_patch_tiled_bwd: var_moments and upstream go together");
+  EBOS_REQUIRE(var_partials != nullptr || (var_moments == nullptr) == (upstream == nullptr),
+               "ebos_iwe_patch_tiled_bwd: var_moments and upstream go together");
   if (!slab_config_ok(tile_h, tile_w, halo) || !ebos_patch_fused_supported(tile_h, tile_w, halo, slide_h, slide_w)) {
     set_error("ebos_iwe_patch_tiled_bwd: tile %dx%d halo %d with sliding window %dx%d is outside ebos_patch_fused_supported", tile_h,
               tile_w, halo, slide_h, slide_w);
@@ -1689,7 +1779,7 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
 #define EBOS_CALL(TH, TW, HL)                                                                                              \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, grid, false, H, W, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr, nullptr, \
                                var_moments, upstream, addend, grad_partials, s, &gs, adaptive,                                     \
-                               w_flow_norm / (float)((int64_t)H * W), w_flow_norm != 0.0f ? reg_partials : nullptr)
+                               w_flow_norm / (float)((int64_t)H * W), w_flow_norm != 0.0f ? reg_partials : nullptr, mj)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

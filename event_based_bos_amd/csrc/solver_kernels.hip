@@ -268,8 +268,8 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
   if (grid)
     rc = ebos_iwe_patch_slab_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h, q->patch_w,
                                  q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w,
-                                 q->workspace, q->workspace_bytes, q->iwe, use_gm ? 0 : (has_reg ? 2 : 1), q->omit_boundary,
-                                 q->variance, q->moments, q->part_table, stream);
+                                 q->workspace, q->workspace_bytes, q->iwe, use_gm ? 0 : 2, q->omit_boundary, q->variance, q->moments,
+                                 q->part_table, stream);  // (variance: partials only; the regulariser or backward kernel reduces them)
   else
     rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
                                  q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->workspace,
@@ -282,24 +282,27 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
     rc = ebos_gradient_magnitude_grad_f32(q->iwe, 1, h, w, q->omit_boundary, q->upstream, q->d_iwe, stream);
     if (rc) return rc;
   }
-  if (has_reg) {  // the regulariser pass also reduces the variance moments the combine pass left (no finalize launch)
-    size_t off = 0;
-    int64_t n_parts = 0, n_px = 0;
+  size_t off = 0;
+  int64_t n_parts = 0, n_px = 0;
+  if (has_reg || (grid && !use_gm)) {
     rc = ebos_iwe_slab_partials(q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->omit_boundary, &off,
                                 &n_parts, &n_px);
     if (rc) return rc;
+  }
+  const double* var_partials = reinterpret_cast<const double*>(static_cast<const char*>(q->workspace) + off);
+  if (has_reg) {  // the regulariser pass also reduces the variance moments the combine pass left (no finalize launch)
     rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials,
-                                    use_gm ? nullptr : reinterpret_cast<const double*>(static_cast<const char*>(q->workspace) + off),
-                                    n_parts, n_px, q->variance, q->moments, stream);
+                                    use_gm ? nullptr : var_partials, n_parts, n_px, q->variance, q->moments, stream);
     if (rc) return rc;
   }
   if (grid) {
     rc = ebos_iwe_patch_tiled_bwd_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h,
                                       q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,
                                       use_gm ? q->d_iwe : q->iwe, nullptr, use_gm ? 0 : (q->omit_boundary ? 1 : 0),
-                                      use_gm ? nullptr : q->moments, use_gm ? nullptr : q->upstream, has_reg ? q->d_reg : nullptr,
-                                      q->grad_partials, q->grad_partials_bytes, q->splits == 0 ? q->part_table : nullptr,
-                                      fuse_norm ? q->w_flow_norm : 0.0f, q->reg_partials, stream);
+                                      (use_gm || !has_reg) ? nullptr : q->moments, use_gm ? nullptr : q->upstream,
+                                      has_reg ? q->d_reg : nullptr, q->grad_partials, q->grad_partials_bytes,
+                                      q->splits == 0 ? q->part_table : nullptr, fuse_norm ? q->w_flow_norm : 0.0f, q->reg_partials,
+                                      (use_gm || has_reg) ? nullptr : var_partials, n_parts, n_px, q->variance, q->moments, stream);
     if (rc) return rc;
     const int n_items = (int)(ebos_patch_grad_partials_bytes(q->H, q->W, q->tile_h, q->tile_w, q->splits == 0) / 2048);
     // partial cell gradients -> d_theta, the Adam step of every grid element and the loss of the iteration

@@ -122,7 +122,10 @@ class FusedPatchLoop(object):
                   "ebos_upsample_patch_flow")
         use_gm = self.w_gm != 0.0
         h, w = self.iwe.shape
-        want_var = 0 if use_gm else (2 if self.has_reg else 1)
+        # variance: with a regulariser launch that kernel reduces the combine pass's partials; with grid sampling the backward
+        # kernel does; otherwise a finalize launch
+        want_var = 0 if use_gm else (2 if (self.has_reg or grid) else 1)
+        off, n_parts, n_px = self._var_partials
         if grid:
             check(lib.ebos_iwe_patch_slab_f32(*plan._compact_ptrs(), ptr(plan.key_offsets), plan.n, ptr(self.theta), gh, gw, ph, pw,
                                               sh, sw, H, W, plan.tile[0], plan.tile[1], self.halo, self.splits, self.pad[0],
@@ -140,7 +143,6 @@ class FusedPatchLoop(object):
             check(lib.ebos_gradient_magnitude_grad_f32(ptr(self.iwe), 1, h, w, int(self.omit), ptr(self.upstream), ptr(self.d_iwe), s),
                   "ebos_gradient_magnitude_grad")
         if self.has_reg:  # ... which also reduces the variance partials of the combine pass (no finalize launch)
-            off, n_parts, n_px = self._var_partials
             check(lib.ebos_flow_regularisers_f32(ptr(self.dense), H, W, self.w_norm, self.w_tv, ptr(self.d_reg),
                                                  ptr(self.reg_partials), None if use_gm else self.ws.data_ptr() + off, n_parts, n_px,
                                                  ptr(self.variance), ptr(self.moments), s), "ebos_flow_regularisers")
@@ -148,11 +150,13 @@ class FusedPatchLoop(object):
             check(lib.ebos_iwe_patch_tiled_bwd_f32(*plan._compact_ptrs(), ptr(plan.key_offsets), plan.n, ptr(self.theta), gh, gw, ph, pw,
                                                    sh, sw, H, W, plan.tile[0], plan.tile[1], self.halo, self.pad[0], self.pad[1],
                                                    ptr(self.d_iwe if use_gm else self.iwe), None, 0 if use_gm else int(self.omit),
-                                                   None if use_gm else ptr(self.moments), None if use_gm else ptr(self.upstream),
+                                                   ptr(self.moments) if (self.has_reg and not use_gm) else None,
+                                                   None if use_gm else ptr(self.upstream),
                                                    ptr(self.d_reg), ptr(self.grad_partials), self.grad_partials.numel() * 4,
                                                    ptr(plan.part_table) if self.splits == 0 else None,
-                                                   self.w_norm if self.fuse_norm else 0.0, ptr(self.reg_partials), s),
-                  "ebos_iwe_patch_tiled_bwd")
+                                                   self.w_norm if self.fuse_norm else 0.0, ptr(self.reg_partials),
+                                                   None if (use_gm or self.has_reg) else self.ws.data_ptr() + off, n_parts, n_px,
+                                                   ptr(self.variance), ptr(self.moments), s), "ebos_iwe_patch_tiled_bwd")
             return
         check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                                ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],

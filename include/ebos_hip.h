@@ -349,6 +349,10 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
  *   flow, which the tile holds in LDS: its gradient is added here and its value leaves as one f64 partial per work item in
  *   reg_partials [ebos_patch_grad_partials_bytes / 2048] (slots of unused work items are not written: zero the buffer
  *   once) -- no dense field and no ebos_flow_regularisers_f32 launch for this term.
+ *   var_partials (nullable; then var_moments must be NULL and upstream given): the (sum, sum of squares) partials that the
+ *   forward call left with want_variance = 2 (ebos_iwe_slab_partials tells where).  Every workgroup reduces them itself
+ *   (14 KB of L2 reads) and folds the variance gradient in; workgroup 0 also writes out_variance [1] / out_moments [2]
+ *   (nullable) -- the finalize launch between forward and backward disappears.
  * ebos_patch_grad_combine_adam_f32   d_grid [2, gh, gw] := sum of the partials of the tiles touching each cell, times
  *   grad_mask (nullable); with theta != NULL also the Adam step and loss bookkeeping of
  *   ebos_upsample_patch_flow_bwd_adam_f32 (same arguments).  theta == NULL: plain gradient (optimiser arguments unused).
@@ -370,7 +374,8 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
                                  const float* affine, int g_lo, const double* var_moments, const float* upstream,
                                  const float* addend, float* grad_partials, size_t grad_partials_bytes,
                                  const int32_t* part_table, float w_flow_norm, double* reg_partials,
-                                 ebos_stream_t stream);
+                                 const double* var_partials, int64_t n_var_partials, int64_t n_var_pixels,
+                                 float* out_variance, double* out_moments, ebos_stream_t stream);
 int ebos_patch_grad_combine_adam_f32(const float* grad_partials, const int32_t* part_table, int tile_h, int tile_w,
                                      int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w, int H, int W,
                                      float* d_grid, float* theta, float* exp_avg, float* exp_avg_sq, double lr,
