@@ -12,6 +12,16 @@ is five C-ABI calls / eight kernels on one stream, all on buffers allocated once
     ebos_upsample_patch_flow_bwd_adam_f32  -> d loss / d theta (2 kernels); the second one applies the Adam step of every
                                       grid element where its gradient appears and records loss[it]
 
+Grid-sampling route (``sample_grid``, the default whenever ``ebos_patch_fused_supported``): the event kernels take theta
+itself and evaluate the grid -> dense map per source tile in LDS, so the iteration shrinks to
+
+    ebos_iwe_patch_slab_f32           theta -> IWE + variance partials                         (2 kernels)
+    ebos_iwe_patch_tiled_bwd_f32      reduces the variance partials, folds the variance gradient in, evaluates flow_norm from the
+                                      tile's flow, and leaves partial CELL gradients per tile    (1 kernel)
+    ebos_patch_grad_combine_adam_f32  -> d loss / d theta, Adam step, loss[it]                  (1 kernel)
+
+(4 launches, 49.8 us at 2 M events against 64.9 us; with image_gradient on, the dense field and the regulariser launch stay.)
+
 Expressed through autograd the same iteration is ~35 launches (capturable Adam alone is a dozen) and runs at ~235 us
 even as a replayed HIP graph; this pipeline is bounded by its event kernels.  Anything outside this objective family
 (other costs, blurred IWE, scipy optimisers) takes the general autograd path of ``ContrastMaximization``.
