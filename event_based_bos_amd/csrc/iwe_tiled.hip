@@ -44,14 +44,22 @@ constexpr int kBlock = 1024;
 #ifdef EBOS_STAMPS
 }  // namespace
 __device__ unsigned long long g_stamps[4096 * 8];
+__device__ unsigned long long g_stamps_bwd[4096 * 8];
 namespace {
 #define EBOS_STAMP(k)                                                                   \
   do {                                                                                  \
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); \
   } while (0)
+#define EBOS_STAMP_BWD(k)                                                                   \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps_bwd[blockIdx.x * 8 + (k)] = wall_clock64(); \
+  } while (0)
 #else
 #define EBOS_STAMP(k) \
   do {                \
+  } while (0)
+#define EBOS_STAMP_BWD(k) \
+  do {                    \
   } while (0)
 #endif
 
@@ -953,74 +961,101 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   // tile to slab tr.slab of part_out; bwd_parts_combine_kernel sums the parts
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, GRID ? (adaptive ? 0 : 1) : (part_out ? 0 : 1));
   __shared__ double s_mom[2];
-  if (GRID && mj.partials != nullptr && (blockIdx.x == 0 || tr.ty >= 0)) {
-    double sm = 0.0, sq = 0.0;
-    for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
-      sm += mj.partials[2 * i];
-      sq += mj.partials[2 * i + 1];
-    }
-    __shared__ double red_m[kBlock / kWave];
-    sm = block_sum(sm, red_m);
-    sq = block_sum(sq, red_m);
-    if (threadIdx.x == 0) {
-      const double mean = mj.n_pixels > 0 ? sm / (double)mj.n_pixels : 0.0;
-      s_mom[0] = mean;
-      if (blockIdx.x == 0) {
-        if (mj.out_var) mj.out_var[0] = (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
-        if (mj.moments) {
-          mj.moments[0] = mean;
-          mj.moments[1] = (double)mj.n_pixels;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (tr.ty < 0) return;  // unused work item
+  __shared__ int s_spill;  // some event's taps left the LDS window of the upstream image
+  __shared__ unsigned s_next;  // chunk queue of the lean loop
+  const ChunkQueue queue{&s_next};
+  EBOS_STAMP_BWD(0);
+  if (tr.ty < 0 && !(GRID && mj.partials != nullptr && blockIdx.x == 0)) return;  // unused work item
   const float* flow = flow_arg;
   const int64_t hw = (int64_t)H * W;
   GradImage G;
   G.g = g_image;
   G.a = affine ? affine[0] : 1.0f;
   G.c = affine ? affine[1] : 0.0f;
-  if (var_moments != nullptr) {
-    // g_image is the IWE itself and the loss is upstream * var(IWE): d var / d IWE = 2 (IWE - mean) / (M - 1), folded
-    // in as an affine map (no d_iwe image, no separate affine kernel)
-    const double a = 2.0 * (double)upstream[0] / (var_moments[1] - 1.0);
-    G.a = (float)a;
-    G.c = (float)(-a * var_moments[0]);
-  }
-  if (GRID && mj.partials != nullptr) {  // the same map from the partials reduced above
-    const double a = 2.0 * (double)upstream[0] / ((double)mj.n_pixels - 1.0);
-    G.a = (float)a;
-    G.c = (float)(-a * s_mom[0]);
-  }
   G.h = H + 2 * pad_h;
   G.w = W + 2 * pad_w;
   G.lo = g_lo;
-  const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
+  const int tr0 = max(tr.ty, 0) * TH, tc0 = max(tr.tx, 0) * TW;
   const int oy = tr0 - HALO, ox = tc0 - HALO;
-
-  __shared__ int s_spill;  // some event's taps left the LDS window of the upstream image
-  __shared__ unsigned s_next;  // chunk queue of the lean loop
-  const ChunkQueue queue{&s_next};
   if (threadIdx.x == 0) {
     s_spill = 0;
     s_next = 2 * (kBlock / kWave);
   }
-  TileGrid tg{};
-  if (GRID) tg = tile_grid_begin<TH, TW>(flow_arg, gs, tr0, tc0, H, W, s_lerp);  // (its cell load flies over the staging below)
-  for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
-  if (tr.g_first <= tr.g_last) {
-    for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
-      const int rl = i / LW, cl = i - rl * LW;
-      s_g[i] = G.at(oy + rl + pad_h, ox + cl + pad_w);
-    }
-  }
   if (GRID) {
+    // Set-up with every global read in flight at once: (1) the raw upstream tile into registers -- unconditional, clamped
+    // loads, fully unrolled (predicated loads are waited for one by one) -- (2) the tile's block of grid cells, (3) the
+    // variance partials; then the LDS work: accumulator clear, affine map + store of the upstream tile, the tile's flow.
+    constexpr int kStage = (LH * LW + kBlock - 1) / kBlock;
+    float raw[kStage];
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+      const int i = min((int)threadIdx.x + k * kBlock, LH * LW - 1);
+      const int rl = i / LW, cl = i - rl * LW;
+      const int R = min(max(oy + rl + pad_h, 0), G.h - 1), C = min(max(ox + cl + pad_w, 0), G.w - 1);
+      raw[k] = g_image[(int64_t)R * G.w + C];
+    }
+    const TileGrid tg = tile_grid_begin<TH, TW>(flow_arg, gs, tr0, tc0, H, W, s_lerp);
+    if (mj.partials != nullptr) {
+      double sm = 0.0, sq = 0.0;
+      for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
+        sm += mj.partials[2 * i];
+        sq += mj.partials[2 * i + 1];
+      }
+      __shared__ double red_m[kBlock / kWave];
+      sm = block_sum(sm, red_m);
+      sq = block_sum(sq, red_m);
+      if (threadIdx.x == 0) {
+        const double mean = mj.n_pixels > 0 ? sm / (double)mj.n_pixels : 0.0;
+        s_mom[0] = mean;
+        if (blockIdx.x == 0) {
+          if (mj.out_var) mj.out_var[0] = (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
+          if (mj.moments) {
+            mj.moments[0] = mean;
+            mj.moments[1] = (double)mj.n_pixels;
+          }
+        }
+      }
+      __syncthreads();
+      if (tr.ty < 0) return;  // (workgroup 0 of an adaptive plan may be an unused item: it only reports the variance)
+      // d var / d IWE = 2 (IWE - mean) / (M - 1) as an affine map of the IWE, from the partials reduced above
+      const double a = 2.0 * (double)upstream[0] / ((double)mj.n_pixels - 1.0);
+      G.a = (float)a;
+      G.c = (float)(-a * s_mom[0]);
+    } else if (var_moments != nullptr) {
+      const double a = 2.0 * (double)upstream[0] / (var_moments[1] - 1.0);
+      G.a = (float)a;
+      G.c = (float)(-a * var_moments[0]);
+    }
+    EBOS_STAMP_BWD(1);
+    for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+      const int i = threadIdx.x + k * kBlock;
+      const int rl = i / LW, cl = i - rl * LW;
+      const int R = oy + rl + pad_h, C = ox + cl + pad_w;
+      const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
+      if (i < LH * LW) s_g[i] = valid ? G.a * raw[k] + G.c : 0.0f;
+    }
     tile_grid_finish<TH, TW>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
     flow = s_flow;
+  } else {
+    if (var_moments != nullptr) {
+      // g_image is the IWE itself and the loss is upstream * var(IWE): d var / d IWE = 2 (IWE - mean) / (M - 1), folded
+      // in as an affine map (no d_iwe image, no separate affine kernel)
+      const double a = 2.0 * (double)upstream[0] / (var_moments[1] - 1.0);
+      G.a = (float)a;
+      G.c = (float)(-a * var_moments[0]);
+    }
+    for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
+    if (tr.g_first <= tr.g_last) {
+      for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
+        const int rl = i / LW, cl = i - rl * LW;
+        s_g[i] = G.at(oy + rl + pad_h, ox + cl + pad_w);
+      }
+    }
   }
   __syncthreads();
+  EBOS_STAMP_BWD(2);
 
   double tot_x = 0.0, tot_y = 0.0;  // UNIFORM: this lane's sum of dt * dL/d(x', y')
   constexpr bool kLean = (FMT == FMT_COMPACT) && !HAS_W;
@@ -1030,7 +1065,9 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN, GRID>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, &spilled,
                                                                 queue);
     if (spilled) s_spill = 1;
+    EBOS_STAMP_BWD(3);
     __syncthreads();
+    EBOS_STAMP_BWD(4);
     if (s_spill) {  // rare second sweep; it draws its chunks afresh
       if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
       __syncthreads();
@@ -1172,6 +1209,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
         }
       }
     }
+    __shared__ double s_red_norm[kBlock / kWave];
     if (reg_partials != nullptr) {
       // flow_norm regulariser (src/costs/flow_norm.py:45-56: mean |flow|, s_norm = weight / (H W)) is pointwise in the dense
       // flow, and this tile's flow is in LDS: value partial + gradient here, no dense field and no regulariser launch
@@ -1191,33 +1229,41 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
           }
         }
       }
-      __shared__ double red_norm[kBlock / kWave];
-      val = block_sum(val, red_norm);
-      if (threadIdx.x == 0) reg_partials[blockIdx.x] = val;
+      val = wave_sum(val);  // per-wave partials, summed in wave order by one thread after the barrier below (deterministic)
+      if ((threadIdx.x & (kWave - 1)) == 0) s_red_norm[threadIdx.x / kWave] = val;
     }
     __syncthreads();
+    EBOS_STAMP_BWD(5);
+    if (reg_partials != nullptr && threadIdx.x == 0) {
+      double val = 0.0;
+      for (int k = 0; k < kBlock / kWave; ++k) val += s_red_norm[k];
+      reg_partials[blockIdx.x] = val;
+    }
     for (int idx = threadIdx.x; idx < 2 * ni * TW; idx += kBlock) {
       const int ch = idx / (ni * TW), rem = idx - ch * (ni * TW);
       const int i = rem / TW, c = rem - i * TW;
       const double* d = s_d + ch * TH * TW + c;
       const float* wy = s_wy + i * TH;
-      float acc = 0.0f;
+      float acc = 0.0f;  // (bounding r to the rows that touch the cell -- about half -- was slower: the bound search is serial)
 #pragma unroll 9
       for (int r = 0; r < TH; ++r) acc += wy[r] * (float)d[r * TW];
       s_S[idx] = acc;
     }
     __syncthreads();
+    // columns: one wavefront per output, lanes stride over the tile's columns
     float* out = part_out + (int64_t)tr.slab * (2 * kGridCells * kGridCells);
-    for (int idx = threadIdx.x; idx < 2 * ni * nj; idx += kBlock) {
-      const int ch = idx / (ni * nj), rem = idx - ch * (ni * nj);
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int o = threadIdx.x / kWave; o < 2 * ni * nj; o += kBlock / kWave) {
+      const int ch = o / (ni * nj), rem = o - ch * (ni * nj);
       const int i = rem / nj, j = rem - i * nj;
       const float* S = s_S + (ch * ni + i) * TW;
       const float* wx = s_wx + j * TW;
       float acc = 0.0f;
-#pragma unroll 8
-      for (int c = 0; c < TW; ++c) acc += wx[c] * S[c];
-      out[(ch * kGridCells + i) * kGridCells + j] = acc;
+      for (int c = lane; c < TW; c += kWave) acc += wx[c] * S[c];
+      acc = wave_sum(acc);
+      if (lane == 0) out[(ch * kGridCells + i) * kGridCells + j] = acc;
     }
+    EBOS_STAMP_BWD(6);
     return;
   }
   if (part_out != nullptr) {  // partial tile [2][TH * TW] of this part, plain stores
@@ -1495,6 +1541,9 @@ extern "C" {
 #ifdef EBOS_STAMPS
 int ebos_debug_read_stamps(unsigned long long* host, int count) {  // diagnostic builds only
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_stamps), sizeof(unsigned long long) * count);
+}
+int ebos_debug_read_stamps_bwd(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_stamps_bwd), sizeof(unsigned long long) * count);
 }
 #endif
 

@@ -20,7 +20,7 @@ itself and evaluate the grid -> dense map per source tile in LDS, so the iterati
                                       tile's flow, and leaves partial CELL gradients per tile    (1 kernel)
     ebos_patch_grad_combine_adam_f32  -> d loss / d theta, Adam step, loss[it]                  (1 kernel)
 
-(4 launches, 49.8 us at 2 M events against 64.9 us; with image_gradient on, the dense field and the regulariser launch stay.)
+(4 launches, 48.5 us at 2 M events against 64.9 us; with image_gradient on, the dense field and the regulariser launch stay.)
 
 Expressed through autograd the same iteration is ~35 launches (capturable Adam alone is a dozen) and runs at ~235 us
 even as a replayed HIP graph; this pipeline is bounded by its event kernels.  Anything outside this objective family

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the GRID backward kernel (iwe_dense_tiled_bwd_kernel<..., GRID>) and the GRID forward kernel inside the
+solver loop, from in-kernel stamps (diagnostic build: EBOS_EXTRA_FLAGS=-DEBOS_STAMPS python -m event_based_bos_amd.build --force).
+wall_clock64 ticks at 100 MHz."""
+import argparse, ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import event_based_bos_amd as ebos
+from event_based_bos_amd import _hip
+from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+from bench import H, W, synth_window
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--events", type=int, default=2_000_000)
+a = ap.parse_args()
+lib = _hip.require_gpu()
+raw = ctypes.CDLL(_hip.LIB_PATH)
+ev, _ = synth_window(a.events, 0)
+plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto")
+gh, gw = ebos.solver.patch_grid_shape((H, W), (24, 32), (24, 32))
+loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, lr=0.1, capacity=64)
+loop.run(40)
+torch.cuda.synchronize()
+n = 256
+for name, fn, names in (("backward", raw.ebos_debug_read_stamps_bwd,
+                         ["variance partials reduce", "clear + upstream staging + tile flow", "main loop (lane-0 wave)", "wait for other waves",
+                          "addend / flow_norm / weights", "tile adjoint + store"]),
+                        ("forward", raw.ebos_debug_read_stamps,
+                         ["clear + tile flow", "main loop (lane-0 wave)", "wait for other waves", "decode + slab store"])):
+    buf = (ctypes.c_ulonglong * (n * 8))()
+    fn(buf, n * 8)
+    st = np.array(buf[:], dtype=np.float64).reshape(n, 8) * 10.0  # ns
+    k = len(names)
+    t0 = st[:, 0].min()
+    print(f"{name}: kernel span (first start -> last end) {(st[:, k].max() - t0) / 1e3:.2f} us; start skew median {np.median(st[:, 0] - t0) / 1e3:.2f} max {(st[:, 0].max() - t0) / 1e3:.2f} us")
+    for i, nm in enumerate(names):
+        d = st[:, i + 1] - st[:, i]
+        print(f"  {nm:40s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
+    d = st[:, k] - st[:, 0]
+    print(f"  {'workgroup total':40s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
