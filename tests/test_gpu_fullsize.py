@@ -102,3 +102,47 @@ def test_domain_properties_full_size(setup):
     dn = ebos.ops.image_variance(plan.iwe_dense(flow, weight=torch.full((N,), 1.0 - eps, device=dev)))
     fd = (up - dn).item() / (2 * eps)
     assert abs(wz.grad.sum().item() - fd) < 1e-3 * abs(fd)
+
+
+def test_config4_patch_grid_route_full_size(setup):
+    """BASELINE configs[3] shape (2 M events, 30x40 patch grid -> 1280x720 flow, U(-30, 30)): the grid-sampling event kernels
+    against the materialised route (IWE / loss 1e-6, d loss / d theta rel-L2 1e-5) and against the fp64 oracle through
+    upsample_patch_flow + iwe_dense + var + flow_norm (IWE rel-L2 < 1e-4, loss < 1e-5, gradient rel-L2 < 1e-3); then 20 Adam
+    iterations of both routes stay together (losses 1e-4 relative)."""
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    ebos, ev, fl, plan10, flow = setup
+    n = 2_000_000
+    from _kinks import off_the_kinks_patch
+
+    rs = np.random.RandomState(107)
+    theta = rs.uniform(-30, 30, (2, 30, 40))
+    # (events AT a kink of the piecewise-linear vote are dropped, ~0.2 %: there the f32 and fp64 paths may legitimately take
+    # different one-sided gradients, and the gradient w.r.t. the 2400 patch parameters is a small difference of large sums)
+    ev2 = off_the_kinks_patch(O.synth_events(n, H, W, seed=7), theta, (H, W), (24, 32), (24, 32))
+    n = len(ev2)
+    dev = flow.device
+    plan = ebos.EventPlan.build(torch.from_numpy(ev2).to(dev), (H, W), "first", True, tile="auto")
+    out = {}
+    for grid in (True, False):
+        loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.from_numpy(theta).float().to(dev), 1.0, 0.01, 0.0, capacity=20, lr=0.1,
+                              sample_grid=grid)
+        assert loop.sample_grid == grid and loop.fuse_norm == grid
+        loss, grad = loop.value_and_grad(torch.from_numpy(theta).float().to(dev))
+        iwe = loop.iwe.cpu().double().numpy()
+        hist = loop.run(20).cpu().numpy()
+        out[grid] = (iwe, float(loss), grad.cpu().double().numpy(), hist)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    assert rel(out[True][0], out[False][0]) < 1e-6 and abs(out[True][1] - out[False][1]) <= 1e-6 * abs(out[False][1])
+    assert rel(out[True][2], out[False][2]) < 1e-5
+    np.testing.assert_allclose(out[True][3], out[False][3], rtol=1e-4)
+    tt = torch.from_numpy(theta).requires_grad_(True)
+    dense = O.upsample_patch_flow(tt, (H, W), (24, 32), (24, 32))
+    iwe_ref = O.iwe_dense(torch.from_numpy(ev2), dense, (H, W))
+    loss_ref = -torch.var(iwe_ref) + 0.01 * O.flow_norm(dense)
+    loss_ref.backward()
+    assert rel(out[True][0], iwe_ref.detach().numpy()) < 1e-4
+    assert abs(out[True][1] - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    assert rel(out[True][2], tt.grad.numpy()) < 1e-3
+    # mass: every event whose four taps stay inside the image adds exactly one unit
+    assert abs(out[True][0].sum() - iwe_ref.sum().item()) <= 1e-6 * n

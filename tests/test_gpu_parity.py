@@ -15,6 +15,8 @@ import torch
 
 from oracle import ebos_oracle as O
 
+from _kinks import off_the_kinks as _off_the_kinks, off_the_kinks_patch as _off_the_kinks_patch
+
 pytestmark = pytest.mark.gpu
 
 H, W = 24, 32
@@ -806,27 +808,6 @@ def test_hot_pixels_overflow_high_and_low_fields(ebos, splits):
     assert abs(var - expect.var(ddof=1)) < 1e-5 * expect.var(ddof=1)
 
 
-def _off_the_kinks(ev, flow, direction, amp, margin=5e-4):
-    """Drop the events whose f64-warped coordinate lies within ``margin`` px of an integer.  The bilinear vote is
-    piecewise linear in the warped coordinate: AT an integer its value is continuous but its gradient jumps (and the
-    inside-the-image test switches), so there an f32 warp (~1e-5 px of rounding at +-90 px) and the f64 oracle
-    legitimately report the two different one-sided gradients -- one such event in 60000 is 2e-3..1e-2 of the flow
-    gradient of these small images.  Everything else about the case (clustering, borders, out-of-image) is untouched;
-    ~0.2 % of the events go.  Iterated because dropping the first / last event moves the reference time."""
-    if amp == 0.0:
-        return ev   # zero flow: every event sits on a kink, the gradient is not compared
-    for _ in range(16):
-        warped = O.warp_dense_torch(torch.from_numpy(ev), torch.from_numpy(flow), direction, True).numpy().reshape(-1, 4)
-        near = (np.abs(warped[:, :2] - np.rint(warped[:, :2])) < margin).any(1)
-        # t == t_ref leaves the source coordinate untouched (an integer for the compact kinds): those events stay, their
-        # displacement is exactly zero in f32 and in f64 alike
-        near &= warped[:, 2] != 0.0
-        if not near.any() or len(ev) - int(near.sum()) < 2:
-            return ev
-        ev = ev[~near]
-    return ev
-
-
 def test_fuzz_fused_path_against_oracle(ebos):
     """Seeded fuzz over the knobs that interact in the tile-private pipeline: image size (tiles cut by the border), tile
     configuration, halo (taps beyond it spill), event clustering (hot pixels, blobs, borders), flow magnitude (beyond the
@@ -879,7 +860,7 @@ def test_fuzz_fused_path_against_oracle(ebos):
         got = plan.iwe_dense(fg, pad=(pad, pad), halo=halo, splits=splits)
         scale = max(float(expect.detach().norm()), 1e-12)
         assert float((got.detach().cpu().double() - expect.detach()).norm()) / scale < 1e-4, tag
-        if v_ref is not None and float(v_ref) > 0:
+        if v_ref is not None and float(v_ref.detach()) > 0:
             v = plan.contrast_dense(fg, "image_variance", omit, pad=(pad, pad), halo=halo, splits=splits)
             assert abs(v.item() - v_ref.item()) <= 1e-5 * abs(v_ref.item()) + 1e-9, tag
             v.backward()
@@ -1121,12 +1102,6 @@ def test_grid_sampling_kernels_match_upsample_then_dense(ebos, case, terms):
     assert abs(out[True][1] - loss.item()) <= 1e-5 * abs(loss.item()) + 1e-9
     if n > 100:
         assert rel(out[True][2], tt.grad.numpy()) < 1e-3
-
-
-def _off_the_kinks_patch(ev, theta, size, patch, slide, margin=5e-4):
-    """_off_the_kinks for a patch-grid flow (the fp64 dense field of the oracle's upsample)."""
-    dense = O.upsample_patch_flow(torch.from_numpy(theta), size, patch, slide).numpy()
-    return _off_the_kinks(ev, dense, "first", 1.0, margin)
 
 
 def test_grid_sampling_refuses_unsupported_configurations(ebos):
