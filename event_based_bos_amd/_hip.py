@@ -102,7 +102,7 @@ SIGNATURES = {
                                      _P, _P, _P, _P]),
     "ebos_patch_grad_partials_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "ebos_iwe_patch_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P,
-                                          _P, _P, _P, _Z, _P, _F, _P, _P, _L, _L, _P, _P, _P]),
+                                          _P, _P, _P, _Z, _P, _F, _F, _P, _P, _L, _L, _P, _P, _P]),
     "ebos_patch_grad_combine_adam_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _I, _P, _P,
                                               _F, _P, _I, _P, _I, _P, _P]),
     "ebos_flow_regularisers_partials": (_I, []),

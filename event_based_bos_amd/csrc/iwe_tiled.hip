@@ -250,26 +250,28 @@ struct MomentsIn {
   double* moments;         // (mean, M), written by workgroup 0 (nullable)
 };
 
-// s_lerp [TH + TW]: row / column interpolation of the tile; s_cells [2][kGridCells][kGridCells]: the block of grid cells the
-// tile touches.  Two halves with ONE global round trip (the cell block) between them, which the caller fills with its own
-// set-up work (LDS clear, upstream-tile staging) -- sampling the grid straight from global memory cost 3-4 dependent L2
-// round trips per workgroup.  2 * kGridCells^2 <= kBlock: one cell value per thread.
+// AP = apron in pixels around the tile (0 forward; 2 backward: the image_gradient regulariser reads neighbours up to 2 px away).
+// s_lerp [(TH + 2 AP) + (TW + 2 AP)]: row / column interpolation of the tile + apron (clamped to the image);
+// s_cells [2][kGridCells][kGridCells]: the block of grid cells they touch; s_flow [2][TH + 2 AP][TW + 2 AP].
+// Two halves with ONE global round trip (the cell block) between them, which the caller fills with its own set-up work (LDS
+// clear, upstream-tile staging) -- sampling the grid straight from global memory cost 3-4 dependent L2 round trips per
+// workgroup.  2 * kGridCells^2 <= kBlock: one cell value per thread.
 struct TileGrid {
   int gi0, ni, gj0, nj;
   float cell;  // this thread's value of the cell block (threads >= 2 ni nj: unused)
 };
 
-template <int TH, int TW>
+template <int TH, int TW, int AP>
 __device__ __forceinline__ TileGrid tile_grid_begin(const float* __restrict__ grid, const GridSrc& gs, int tr0, int tc0, int H, int W,
                                                     Lerp* s_lerp) {
   static_assert(2 * kGridCells * kGridCells <= kBlock, "one cell value per thread");
-  for (int i = threadIdx.x; i < TH + TW; i += kBlock)
-    s_lerp[i] = i < TH ? lerp_at(gs.ay, min(tr0 + i, H - 1)) : lerp_at(gs.ax, min(tc0 + i - TH, W - 1));
+  constexpr int PH = TH + 2 * AP, PW = TW + 2 * AP;
+  for (int i = threadIdx.x; i < PH + PW; i += kBlock)
+    s_lerp[i] = i < PH ? lerp_at(gs.ay, min(max(tr0 + i - AP, 0), H - 1)) : lerp_at(gs.ax, min(max(tc0 + i - PH - AP, 0), W - 1));
   __syncthreads();
-  const int rows = min(TH, H - tr0), cols = min(TW, W - tc0);
   TileGrid t;
-  t.gi0 = s_lerp[0].i0, t.ni = s_lerp[rows - 1].i1 - t.gi0 + 1;
-  t.gj0 = s_lerp[TH].i0, t.nj = s_lerp[TH + cols - 1].i1 - t.gj0 + 1;
+  t.gi0 = s_lerp[0].i0, t.ni = s_lerp[PH - 1].i1 - t.gi0 + 1;          // (indices are monotone in the clamped coordinate)
+  t.gj0 = s_lerp[PH].i0, t.nj = s_lerp[PH + PW - 1].i1 - t.gj0 + 1;
   const int idx = min((int)threadIdx.x, 2 * t.ni * t.nj - 1);  // clamped: the load is unconditional
   const int ch = idx / (t.ni * t.nj), rem = idx - ch * (t.ni * t.nj);
   const int i = rem / t.nj, j = rem - i * t.nj;
@@ -277,27 +279,30 @@ __device__ __forceinline__ TileGrid tile_grid_begin(const float* __restrict__ gr
   return t;
 }
 
-// second half: cell block -> LDS, then the tile's flow [2][TH * TW].  Ends with a barrier.
-template <int TH, int TW>
+// second half: cell block -> LDS, then the flow of tile + apron.  Ends with a barrier.
+template <int TH, int TW, int AP>
 __device__ __forceinline__ void tile_grid_finish(const TileGrid& t, float* s_flow, const Lerp* s_lerp, float* s_cells) {
+  constexpr int PH = TH + 2 * AP, PW = TW + 2 * AP;
   if ((int)threadIdx.x < 2 * t.ni * t.nj) {
     const int ch = threadIdx.x / (t.ni * t.nj), rem = threadIdx.x - ch * (t.ni * t.nj);
     const int i = rem / t.nj, j = rem - i * t.nj;
     s_cells[(ch * kGridCells + i) * kGridCells + j] = t.cell;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
-    const int rl = i / TW, cl = i - rl * TW;
-    Lerp ly = s_lerp[rl], lx = s_lerp[TH + cl];
+  for (int i = threadIdx.x; i < PH * PW; i += kBlock) {
+    const int rl = i / PW, cl = i - rl * PW;
+    Lerp ly = s_lerp[rl], lx = s_lerp[PH + cl];
     lx.i0 -= t.gj0;  // indices into the cell block
     lx.i1 -= t.gj0;
     const float* u0 = s_cells + (ly.i0 - t.gi0) * kGridCells;
     const float* u1 = s_cells + (ly.i1 - t.gi0) * kGridCells;
     s_flow[i] = grid_bilerp(u0, u1, ly, lx);
-    s_flow[TH * TW + i] = grid_bilerp(u0 + kGridCells * kGridCells, u1 + kGridCells * kGridCells, ly, lx);
+    s_flow[PH * PW + i] = grid_bilerp(u0 + kGridCells * kGridCells, u1 + kGridCells * kGridCells, ly, lx);
   }
   __syncthreads();
 }
+
+constexpr int kBwdApron = 2;  // pixels of flow the GRID backward kernel keeps around its tile
 
 struct CGroup {
   unsigned pr[4], pc[4];  // tile-local source row / column
@@ -569,13 +574,13 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   float* s_flow = reinterpret_cast<float*>(s_acc + kCells);  // GRID: the tile's dense flow, behind the accumulators
   Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * TH * TW);
   TileGrid tg{};
-  if (GRID) tg = tile_grid_begin<TH, TW>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);  // (its cell load flies over the clear)
+  if (GRID) tg = tile_grid_begin<TH, TW, 0>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);  // (its cell load flies over the clear)
   for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
     reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
   if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
   if (GRID) {
-    tile_grid_finish<TH, TW>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
+    tile_grid_finish<TH, TW, 0>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
     flow = s_flow;
   }
   __syncthreads();
@@ -831,11 +836,12 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
                                                   const GradImage& G, double& tot_x, double& tot_y, bool* any_spill,
                                                   const ChunkQueue& queue) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)TH * TW : (int64_t)H * W);  // GRID: tile flow in LDS
+  constexpr int PH = TH + 2 * kBwdApron, PW = TW + 2 * kBwdApron;  // GRID: the tile's flow (+ apron) in LDS
+  const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)PH * PW : (int64_t)H * W);
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
   const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
-  const unsigned base_lin = GRID ? 0u : (unsigned)(tr0 * W + tc0);
-  const unsigned uW = GRID ? (unsigned)TW : (unsigned)W;
+  const unsigned base_lin = GRID ? (unsigned)(kBwdApron * PW + kBwdApron) : (unsigned)(tr0 * W + tc0);
+  const unsigned uW = GRID ? (unsigned)PW : (unsigned)W;
   bool spilled = false;
   const int32_t g_last = tr.g_last;
   // dynamic chunks of 64 groups per wave, as in the forward loop: with a static stride the first wave was done 5.9 us
@@ -950,13 +956,14 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
                            float* __restrict__ d_weight, double* __restrict__ partials,
                            const double* __restrict__ var_moments, const float* __restrict__ upstream,
                            const float* __restrict__ addend, float* __restrict__ part_out, GridSrc gs, int adaptive,
-                           float s_norm, double* __restrict__ reg_partials, MomentsIn mj) {
+                           float s_norm, float s_tv, double* __restrict__ reg_partials, MomentsIn mj) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
   float* s_g = reinterpret_cast<float*>(s_raw + 2 * TH * TW);      // [LH][LW] upstream gradient tile
-  float* s_flow = s_g + LH * LW;                                   // GRID: [2][TH*TW] flow of this tile
-  Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * TH * TW);    // GRID: [TH + TW] row / column interpolation of the tile
+  constexpr int AP = kBwdApron, PH = TH + 2 * AP, PW = TW + 2 * AP;
+  float* s_flow = s_g + LH * LW;                                   // GRID: [2][PH][PW] flow of this tile + apron
+  Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * PH * PW);    // GRID: [PH + PW] row / column interpolation
   // part_out != nullptr (dense): adaptive work items -- this workgroup is one part of a tile and writes its partial d_flow
   // tile to slab tr.slab of part_out; bwd_parts_combine_kernel sums the parts
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, GRID ? (adaptive ? 0 : 1) : (part_out ? 0 : 1));
@@ -994,7 +1001,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const int R = min(max(oy + rl + pad_h, 0), G.h - 1), C = min(max(ox + cl + pad_w, 0), G.w - 1);
       raw[k] = g_image[(int64_t)R * G.w + C];
     }
-    const TileGrid tg = tile_grid_begin<TH, TW>(flow_arg, gs, tr0, tc0, H, W, s_lerp);
+    const TileGrid tg = tile_grid_begin<TH, TW, AP>(flow_arg, gs, tr0, tc0, H, W, s_lerp);
     if (mj.partials != nullptr) {
       double sm = 0.0, sq = 0.0;
       for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
@@ -1036,7 +1043,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
       if (i < LH * LW) s_g[i] = valid ? G.a * raw[k] + G.c : 0.0f;
     }
-    tile_grid_finish<TH, TW>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
+    tile_grid_finish<TH, TW, AP>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + PH + PW));
     flow = s_flow;
   } else {
     if (var_moments != nullptr) {
@@ -1184,19 +1191,21 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     // adjoint of the grid -> dense map on this tile, separable like the stand-alone adjoint: rows first
     //   S[ch][i][c] = sum_r wy(r, gi0 + i) * (d[ch][r][c] + addend),   then   P[ch][i][j] = sum_c wx(c, gj0 + j) * S[ch][i][c]
     const int rows = min(TH, H - tr0), cols = min(TW, W - tc0);
-    const int gi0 = s_lerp[0].i0, ni = s_lerp[rows - 1].i1 - gi0 + 1;
-    const int gj0 = s_lerp[TH].i0, nj = s_lerp[TH + cols - 1].i1 - gj0 + 1;
+    const Lerp* s_ly = s_lerp + AP;        // row r of the tile
+    const Lerp* s_lx = s_lerp + PH + AP;   // column c of the tile
+    const int gi0 = s_ly[0].i0, ni = s_ly[rows - 1].i1 - gi0 + 1;   // the cells the TILE touches (the combine pass's indexing)
+    const int gj0 = s_lx[0].i0, nj = s_lx[cols - 1].i1 - gj0 + 1;
     float* s_S = s_g;                          // the upstream tile is dead by now: [2][ni][TW] row sums,
     float* s_wy = s_g + 2 * kGridCells * TW;   // [ni][TH] row weights (0 beyond the image),
     float* s_wx = s_wy + kGridCells * TH;      // [nj][TW] column weights
     for (int idx = threadIdx.x; idx < ni * TH; idx += kBlock) {
       const int i = idx / TH, r = idx - i * TH;
-      const Lerp l = s_lerp[r];
+      const Lerp l = s_ly[r];
       s_wy[idx] = r < rows ? (l.i0 == gi0 + i ? l.w0 : 0.0f) + (l.i1 == gi0 + i ? l.w1 : 0.0f) : 0.0f;
     }
     for (int idx = threadIdx.x; idx < nj * TW; idx += kBlock) {
       const int j = idx / TW, c = idx - j * TW;
-      const Lerp l = s_lerp[TH + c];
+      const Lerp l = s_lx[c];
       s_wx[idx] = c < cols ? (l.i0 == gj0 + j ? l.w0 : 0.0f) + (l.i1 == gj0 + j ? l.w1 : 0.0f) : 0.0f;
     }
     if (addend != nullptr && tr.part == 0) {  // the regulariser gradient enters once per tile (coalesced row reads)
@@ -1211,21 +1220,42 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
     __shared__ double s_red_norm[kBlock / kWave];
     if (reg_partials != nullptr) {
-      // flow_norm regulariser (src/costs/flow_norm.py:45-56: mean |flow|, s_norm = weight / (H W)) is pointwise in the dense
-      // flow, and this tile's flow is in LDS: value partial + gradient here, no dense field and no regulariser launch
+      // The flow regularisers on this tile's own flow (in LDS, with a 2 px apron): value partial + gradient here -- no dense
+      // field, no regulariser launch.  flow_norm (src/costs/flow_norm.py:45-56: mean |flow|, s_norm = weight / (H W)) is
+      // pointwise; image_gradient (src/costs/image_gradient.py:60-75: mean(|d/d row| + |d/d col|) over both components,
+      // s_tv = weight / (2 H W)) reads the torch.gradient lines through the pixel, up to 2 px away -- the same device
+      // functions as the stand-alone regulariser kernel, on LDS lines instead of global ones.
       double val = 0.0;
       if (tr.part == 0) {
         for (int idx = threadIdx.x; idx < TH * TW; idx += kBlock) {
           const int rl = idx / TW, cl = idx - rl * TW;
           if (rl < rows && cl < cols) {
-            const float u = s_flow[idx], v = s_flow[TH * TW + idx];
-            const float nrm = sqrtf(u * u + v * v);
-            val += (double)(s_norm * nrm);
-            if (nrm > 0.0f) {  // torch: the sub-gradient of the norm at 0 is 0
-              const float inv = s_norm / nrm;
-              s_d[idx] += (double)(inv * u);
-              s_d[TH * TW + idx] += (double)(inv * v);
+            const int o = (rl + AP) * PW + cl + AP;
+            const float u = s_flow[o], v = s_flow[PH * PW + o];
+            float gu = 0.0f, gv = 0.0f;
+            if (s_norm != 0.0f) {
+              const float nrm = sqrtf(u * u + v * v);
+              val += (double)(s_norm * nrm);
+              if (nrm > 0.0f) {  // torch: the sub-gradient of the norm at 0 is 0
+                const float inv = s_norm / nrm;
+                gu += inv * u;
+                gv += inv * v;
+              }
             }
+            if (s_tv != 0.0f) {
+              // line bases such that base[i * stride] is sample i of the image column / row through this pixel
+              const float* col_u = s_flow + (AP - tr0) * PW + cl + AP;
+              const float* row_u = s_flow + (rl + AP) * PW + AP - tc0;
+              const float* col_v = col_u + PH * PW;
+              const float* row_v = row_u + PH * PW;
+              const int r = tr0 + rl, c = tc0 + cl;
+              val += (double)(s_tv * (fabsf(central(col_u, r, H, PW)) + fabsf(central(row_u, c, W, 1)) +
+                                      fabsf(central(col_v, r, H, PW)) + fabsf(central(row_v, c, W, 1))));
+              gu += s_tv * (tv_adjoint(col_u, r, H, PW) + tv_adjoint(row_u, c, W, 1));
+              gv += s_tv * (tv_adjoint(col_v, r, H, PW) + tv_adjoint(row_v, c, W, 1));
+            }
+            s_d[idx] += (double)gu;
+            s_d[TH * TW + idx] += (double)gv;
           }
         }
       }
@@ -1372,15 +1402,16 @@ int reserve_lds(K kern, size_t lds, const char* what) {
 }
 
 // what the GRID kernels add to the LDS of their dense twins: the tile's flow, its row / column interpolation and the cell block
-template <int TH, int TW>
+template <int TH, int TW, int AP>
 constexpr size_t grid_lds_extra() {
-  return (size_t)2 * TH * TW * sizeof(float) + (size_t)(TH + TW) * sizeof(Lerp) + (size_t)2 * kGridCells * kGridCells * sizeof(float);
+  return (size_t)2 * (TH + 2 * AP) * (TW + 2 * AP) * sizeof(float) + (size_t)(TH + TW + 4 * AP) * sizeof(Lerp) +
+         (size_t)2 * kGridCells * kGridCells * sizeof(float);
 }
 
 // LDS of the GRID accumulate kernel: accumulators + the tile's own flow; some tile configurations do not fit
 template <int TH, int TW, int HALO>
 constexpr bool grid_fwd_fits() {
-  return ((size_t)(TH + 2 * HALO) * (TW + 2 * HALO) + (TW + 2 * HALO) / 2 + 2) * sizeof(double) + grid_lds_extra<TH, TW>() + 1024 <= 160 * 1024;
+  return ((size_t)(TH + 2 * HALO) * (TW + 2 * HALO) + (TW + 2 * HALO) / 2 + 2) * sizeof(double) + grid_lds_extra<TH, TW, 0>() + 1024 <= 160 * 1024;
 }
 
 template <int TH, int TW, int HALO>
@@ -1415,7 +1446,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
         return EBOS_ERR_UNSUPPORTED;
       }
       ka = iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true>;
-      lds += grid_lds_extra<TH, TW>();
+      lds += grid_lds_extra<TH, TW, 0>();
       gs = *grid_src;
     } else {
       set_error("ebos_iwe_patch_slab: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
@@ -1455,7 +1486,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
 
 template <int TH, int TW, int HALO>
 constexpr size_t grid_bwd_lds() {
-  return (size_t)2 * TH * TW * sizeof(double) + (size_t)(TH + 2 * HALO) * (TW + 2 * HALO) * sizeof(float) + grid_lds_extra<TH, TW>();
+  return (size_t)2 * TH * TW * sizeof(double) + (size_t)(TH + 2 * HALO) * (TW + 2 * HALO) * sizeof(float) + grid_lds_extra<TH, TW, kBwdApron>();
 }
 template <int TH, int TW, int HALO>
 constexpr bool grid_bwd_fits() {
@@ -1469,7 +1500,7 @@ template <int TH, int TW, int HALO>
 int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int pad_h,
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
                      double* partials, const double* var_moments, const float* upstream, const float* addend, float* part_out,
-                     hipStream_t s, const GridSrc* grid_src = nullptr, int adaptive = 0, float s_norm = 0.0f,
+                     hipStream_t s, const GridSrc* grid_src = nullptr, int adaptive = 0, float s_norm = 0.0f, float s_tv = 0.0f,
                      double* reg_partials = nullptr, MomentsIn mj = MomentsIn{}) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
@@ -1478,7 +1509,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
-             const double*, const float*, const float*, float*, GridSrc, int, float, double*, MomentsIn);
+             const double*, const float*, const float*, float*, GridSrc, int, float, float, double*, MomentsIn);
   if (grid_src != nullptr) {
     if constexpr (grid_bwd_fits<TH, TW, HALO>()) {
       if (!compact || uniform || part_out == nullptr) {
@@ -1490,7 +1521,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
       if (int rc = reserve_lds(kb, lds, "ebos_iwe_patch_tiled_bwd")) return rc;
       const unsigned grid = (unsigned)(tiles_y * tiles_x * (adaptive ? kAdaptiveItemsPerTile : 1));
       kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr,
-                                               nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive, s_norm,
+                                               nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive, s_norm, s_tv,
                                                reg_partials, mj);
       return EBOS_OK;
     } else {
@@ -1510,7 +1541,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   const unsigned grid = (unsigned)(tiles_y * tiles_x * (part_out ? kAdaptiveItemsPerTile : 1));
   kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
                                            partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0, 0.0f,
-                                           nullptr, MomentsIn{});
+                                           0.0f, nullptr, MomentsIn{});
   if (part_out)
     bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
                                                                                                   addend, d_flow);
@@ -1636,7 +1667,10 @@ int ebos_patch_fused_supported(int tile_h, int tile_w, int halo, int slide_h, in
   using namespace ebos;
   int rc = 0;
 #define EBOS_CALL(TH, TW, HL) \
-  ((grid_fwd_fits<TH, TW, HL>() && grid_bwd_fits<TH, TW, HL>() && TH / slide_h + 3 <= kGridCells && TW / slide_w + 3 <= kGridCells) ? 1 : 0)
+  ((grid_fwd_fits<TH, TW, HL>() && grid_bwd_fits<TH, TW, HL>() && (TH + 2 * kBwdApron) / slide_h + 3 <= kGridCells && \
+    (TW + 2 * kBwdApron) / slide_w + 3 <= kGridCells)                                                                   \
+       ? 1                                                                                                              \
+       : 0)
   if (slide_h <= 0 || slide_w <= 0) return 0;
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
@@ -1794,13 +1828,18 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
                                  int H, int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, const double* var_moments, const float* upstream,
                                  const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
-                                 float w_flow_norm, double* reg_partials, const double* var_partials, int64_t n_var_partials,
+                                 float w_flow_norm, float w_image_gradient, double* reg_partials, const double* var_partials,
+                                 int64_t n_var_partials,
                                  int64_t n_var_pixels, float* out_variance, double* out_moments, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(var_partials == nullptr || (var_moments == nullptr && upstream != nullptr && n_var_partials >= 1 && n_var_pixels >= 2),
                "ebos_iwe_patch_tiled_bwd: var_partials needs upstream, no var_moments, and sane counts");
   const MomentsIn mj{var_partials, n_var_partials, n_var_pixels, out_variance, out_moments};
-  EBOS_REQUIRE(w_flow_norm == 0.0f || reg_partials, "ebos_iwe_patch_tiled_bwd: w_flow_norm given but reg_partials is NULL");
+  EBOS_REQUIRE((w_flow_norm == 0.0f && w_image_gradient == 0.0f) || reg_partials,
+               "ebos_iwe_patch_tiled_bwd: regulariser weight given but reg_partials is NULL");
+  EBOS_REQUIRE(w_image_gradient == 0.0f || (H >= 2 && W >= 2),
+               "ebos_iwe_patch_tiled_bwd: image_gradient needs at least 2 samples per axis (torch.gradient)");
+  const bool any_reg = w_flow_norm != 0.0f || w_image_gradient != 0.0f;
   EBOS_REQUIRE(grid && g_image && grad_partials && key_offsets && grp_offsets && cpix && cdt,
                "ebos_iwe_patch_tiled_bwd: NULL grid/g_image/grad_partials/plan buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0 && gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 &&
@@ -1828,7 +1867,8 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
 #define EBOS_CALL(TH, TW, HL)                                                                                              \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, grid, false, H, W, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr, nullptr, \
                                var_moments, upstream, addend, grad_partials, s, &gs, adaptive,                                     \
-                               w_flow_norm / (float)((int64_t)H * W), w_flow_norm != 0.0f ? reg_partials : nullptr, mj)
+                               w_flow_norm / (float)((int64_t)H * W), w_image_gradient / (float)(2 * (int64_t)H * W),              \
+                               any_reg ? reg_partials : nullptr, mj)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

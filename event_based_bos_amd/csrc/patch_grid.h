@@ -73,4 +73,25 @@ __device__ __forceinline__ float weight_on(const Axis& a, int r, int gi) {
   return (l.i0 == gi ? l.w0 : 0.0f) + (l.i1 == gi ? l.w1 : 0.0f);
 }
 
+// ---- image_gradient regulariser (src/costs/image_gradient.py:60-75): torch.gradient lines, shared by the stand-alone regulariser
+// kernel (solver_kernels.hip) and the GRID backward kernel (iwe_tiled.hip), which evaluates it on the tile's own flow
+__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// torch.gradient along one axis (spacing 1, edge_order 1) at index i of a line of n samples with stride st
+__device__ __forceinline__ float central(const float* f, int i, int n, int64_t st) {
+  if (i == 0) return f[st] - f[0];
+  if (i == n - 1) return f[(int64_t)(n - 1) * st] - f[(int64_t)(n - 2) * st];
+  return (f[(int64_t)(i + 1) * st] - f[(int64_t)(i - 1) * st]) * 0.5f;
+}
+
+// d/d f[i] of sum_k |central(f, k)|  (f: a line of n >= 2 samples)
+__device__ __forceinline__ float tv_adjoint(const float* f, int i, int n, int64_t st) {
+  float g = 0.0f;
+  if (i >= 1) g += sgn(central(f, i - 1, n, st)) * (i - 1 == 0 ? 1.0f : 0.5f);          // k = i - 1 reads f[i] with +
+  if (i + 1 <= n - 1) g -= sgn(central(f, i + 1, n, st)) * (i + 1 == n - 1 ? 1.0f : 0.5f);  // k = i + 1 reads f[i] with -
+  if (i == 0) g -= sgn(central(f, 0, n, st));
+  if (i == n - 1) g += sgn(central(f, n - 1, n, st));
+  return g;
+}
+
 }  // namespace ebos

@@ -13,30 +13,12 @@
 //   Adam            torch.optim.Adam (defaults: amsgrad = False, weight_decay = 0), the optimiser of the loop in
 //                   src/solver/generative_max_likelihood.py:306-341
 #include "common.h"
+#include "patch_grid.h"
 
 namespace ebos {
 namespace {
 
 constexpr int kRegGrid = 1024;
-
-__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
-
-// torch.gradient along one axis (spacing 1, edge_order 1) at index i of a line of n samples with stride st
-__device__ __forceinline__ float central(const float* f, int i, int n, int64_t st) {
-  if (i == 0) return f[st] - f[0];
-  if (i == n - 1) return f[(int64_t)(n - 1) * st] - f[(int64_t)(n - 2) * st];
-  return (f[(int64_t)(i + 1) * st] - f[(int64_t)(i - 1) * st]) * 0.5f;
-}
-
-// d/d f[i] of sum_k |central(f, k)|  (f: a line of n >= 2 samples)
-__device__ __forceinline__ float tv_adjoint(const float* f, int i, int n, int64_t st) {
-  float g = 0.0f;
-  if (i >= 1) g += sgn(central(f, i - 1, n, st)) * (i - 1 == 0 ? 1.0f : 0.5f);          // k = i - 1 reads f[i] with +
-  if (i + 1 <= n - 1) g -= sgn(central(f, i + 1, n, st)) * (i + 1 == n - 1 ? 1.0f : 0.5f);  // k = i + 1 reads f[i] with -
-  if (i == 0) g -= sgn(central(f, 0, n, st));
-  if (i == n - 1) g += sgn(central(f, n - 1, n, st));
-  return g;
-}
 
 // Optional side job of the regulariser pass: turn the (sum, sum of squares) partials that the slab combine pass left
 // (ebos_iwe_dense_slab_f32 with want_variance = 2) into the variance and (mean, M) -- what moments_finalize_kernel does
@@ -232,7 +214,6 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
                "ebos_cmax_patch_solve: NULL buffer");
   const bool has_reg_ = q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f;
   if (q->grad_partials != nullptr) {  // the event kernels sample the patch grid: dense only feeds the regulariser pass
-    EBOS_REQUIRE(q->w_image_gradient == 0.0f || q->dense, "ebos_cmax_patch_solve: image_gradient weight given but dense is NULL");
     EBOS_REQUIRE(q->grp_offsets && q->cpix && q->cdt, "ebos_cmax_patch_solve: grad_partials (grid-sampling kernels) needs the compact plan");
     EBOS_REQUIRE(ebos_patch_fused_supported(q->tile_h, q->tile_w, q->halo, q->slide_h, q->slide_w),
                  "ebos_cmax_patch_solve: grad_partials given but tile %dx%d halo %d / sliding window %dx%d is outside "
@@ -240,8 +221,8 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
   } else {
     EBOS_REQUIRE(q->dense && q->d_dense && q->upsample_scratch, "ebos_cmax_patch_solve: NULL dense / d_dense / upsample_scratch");
   }
-  // (grid sampling with flow_norm only: the backward kernel evaluates that term from the tile's flow, no d_reg image)
-  EBOS_REQUIRE(!has_reg_ || q->d_reg || (q->grad_partials != nullptr && q->w_image_gradient == 0.0f),
+  // (grid sampling: the backward kernel evaluates the regularisers from the tile's flow, no d_reg image)
+  EBOS_REQUIRE(!has_reg_ || q->d_reg || q->grad_partials != nullptr,
                "ebos_cmax_patch_solve: regulariser weights given but d_reg is NULL");
   EBOS_REQUIRE((q->w_variance != 0.0f) != (q->w_gradient_magnitude != 0.0f),
                "ebos_cmax_patch_solve: exactly one of w_variance / w_gradient_magnitude must be non-zero");
@@ -253,8 +234,8 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
 static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_stream_t stream) {
   using namespace ebos;
   const bool grid = q->grad_partials != nullptr;  // the event kernels evaluate the grid -> dense map per tile themselves
-  // flow_norm alone is pointwise in the dense flow: with grid sampling the backward kernel evaluates it from the tile's flow
-  const bool fuse_norm = grid && q->w_image_gradient == 0.0f && q->w_flow_norm != 0.0f;
+  // with grid sampling the backward kernel evaluates the flow regularisers from the tile's own flow (2 px apron in LDS)
+  const bool fuse_norm = grid && (q->w_image_gradient != 0.0f || q->w_flow_norm != 0.0f);
   const bool has_reg = (q->w_flow_norm != 0.0f || q->w_image_gradient != 0.0f) && !fuse_norm;  // regulariser LAUNCH needed
   int rc = EBOS_OK;
   if (!grid || has_reg) {  // (the regulariser pass reads the dense field)
@@ -301,7 +282,8 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
                                       use_gm ? q->d_iwe : q->iwe, nullptr, use_gm ? 0 : (q->omit_boundary ? 1 : 0),
                                       (use_gm || !has_reg) ? nullptr : q->moments, use_gm ? nullptr : q->upstream,
                                       has_reg ? q->d_reg : nullptr, q->grad_partials, q->grad_partials_bytes,
-                                      q->splits == 0 ? q->part_table : nullptr, fuse_norm ? q->w_flow_norm : 0.0f, q->reg_partials,
+                                      q->splits == 0 ? q->part_table : nullptr, fuse_norm ? q->w_flow_norm : 0.0f,
+                                      fuse_norm ? q->w_image_gradient : 0.0f, q->reg_partials,
                                       (use_gm || has_reg) ? nullptr : var_partials, n_parts, n_px, q->variance, q->moments, stream);
     if (rc) return rc;
     const int n_items = (int)(ebos_patch_grad_partials_bytes(q->H, q->W, q->tile_h, q->tile_w, q->splits == 0) / 2048);

@@ -89,8 +89,8 @@ class FusedPatchLoop(object):
         if sample_grid is None and os.environ.get("EBOS_SAMPLE_GRID", "1") == "0":  # A/B switch for measurements
             can = False
         self.sample_grid = can if sample_grid is None else bool(sample_grid)
-        # flow_norm alone is pointwise in the dense flow: with grid sampling the backward kernel evaluates it per tile
-        self.fuse_norm = self.sample_grid and self.w_tv == 0.0 and self.w_norm != 0.0
+        # with grid sampling the backward kernel evaluates the flow regularisers per tile, from the flow it holds in LDS
+        self.fuse_norm = self.sample_grid and (self.w_tv != 0.0 or self.w_norm != 0.0)
         self.has_reg = self.has_reg and not self.fuse_norm  # from here on: "the regulariser LAUNCH is needed"
         self.dense = torch.empty((2, H, W), **f32) if (self.has_reg or not self.sample_grid) else None
         self.d_dense = None if self.sample_grid else torch.empty((2, H, W), **f32)
@@ -164,7 +164,8 @@ class FusedPatchLoop(object):
                                                    None if use_gm else ptr(self.upstream),
                                                    ptr(self.d_reg), ptr(self.grad_partials), self.grad_partials.numel() * 4,
                                                    ptr(plan.part_table) if self.splits == 0 else None,
-                                                   self.w_norm if self.fuse_norm else 0.0, ptr(self.reg_partials),
+                                                   self.w_norm if self.fuse_norm else 0.0, self.w_tv if self.fuse_norm else 0.0,
+                                                   ptr(self.reg_partials),
                                                    None if (use_gm or self.has_reg) else self.ws.data_ptr() + off, n_parts, n_px,
                                                    ptr(self.variance), ptr(self.moments), s), "ebos_iwe_patch_tiled_bwd")
             return

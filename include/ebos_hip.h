@@ -338,17 +338,18 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
  * [2, H, W] field, no upsample launch, LDS reads instead of L2 gathers ("fused into the warp's flow
  * fetch").  Same results as ebos_upsample_patch_flow_f32 + ebos_iwe_dense_slab_f32 (one shared expression).
  *
- * ebos_patch_fused_supported   1 when (tile, halo) leaves LDS for the tile's flow and a tile touches at most 16 x 16
- *   grid cells (tile / slide + 3 <= 16 per axis); 0 otherwise (use the upsample + dense entry points).
+ * ebos_patch_fused_supported   1 when (tile, halo) leaves LDS for the tile's flow and a tile + 2 px apron touches at most
+ *   16 x 16 grid cells ((tile + 4) / slide + 3 <= 16 per axis); 0 otherwise (use the upsample + dense entry points).
  * ebos_iwe_patch_slab_f32      forward; arguments as ebos_iwe_dense_slab_f32 with (grid, gh, gw, patch, slide) in place
  *   of flow; compact plans with unit weights only.
  * ebos_iwe_patch_tiled_bwd_f32 backward; instead of d_flow every work item writes the adjoint of the grid -> dense map
  *   restricted to its tile: <= 16 x 16 partial cell gradients per flow component into grad_partials
  *   (ebos_patch_grad_partials_bytes; adaptive = part_table != NULL).  addend [2, H, W] (nullable) enters once per tile.
- *   w_flow_norm != 0: the flow_norm regulariser w * mean |flow| (src/costs/flow_norm.py:45-56) is pointwise in the dense
- *   flow, which the tile holds in LDS: its gradient is added here and its value leaves as one f64 partial per work item in
+ *   w_flow_norm / w_image_gradient != 0: the flow regularisers w * mean |flow| (src/costs/flow_norm.py:45-56, pointwise) and
+ *   w * mean(|d flow / d row| + |d flow / d col|) (src/costs/image_gradient.py:60-75, torch.gradient lines, unit weights) are
+ *   evaluated on the flow the tile holds in LDS (with a 2 px apron): gradient added here, value as one f64 partial per work item in
  *   reg_partials [ebos_patch_grad_partials_bytes / 2048] (slots of unused work items are not written: zero the buffer
- *   once) -- no dense field and no ebos_flow_regularisers_f32 launch for this term.
+ *   once) -- no dense field and no ebos_flow_regularisers_f32 launch.
  *   var_partials (nullable; then var_moments must be NULL and upstream given): the (sum, sum of squares) partials that the
  *   forward call left with want_variance = 2 (ebos_iwe_slab_partials tells where).  Every workgroup reduces them itself
  *   (14 KB of L2 reads) and folds the variance gradient in; workgroup 0 also writes out_variance [1] / out_moments [2]
@@ -373,7 +374,8 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
                                  int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, const double* var_moments, const float* upstream,
                                  const float* addend, float* grad_partials, size_t grad_partials_bytes,
-                                 const int32_t* part_table, float w_flow_norm, double* reg_partials,
+                                 const int32_t* part_table, float w_flow_norm, float w_image_gradient,
+                                 double* reg_partials,
                                  const double* var_partials, int64_t n_var_partials, int64_t n_var_pixels,
                                  float* out_variance, double* out_moments, ebos_stream_t stream);
 int ebos_patch_grad_combine_adam_f32(const float* grad_partials, const int32_t* part_table, int tile_h, int tile_w,

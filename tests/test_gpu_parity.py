@@ -1072,7 +1072,7 @@ def test_grid_sampling_kernels_match_upsample_then_dense(ebos, case, terms):
     gh, gw = len(np.arange(0, H - patch[0] + slide[0], slide[0])), len(np.arange(0, W - patch[1] + slide[1], slide[1]))
     theta = rs.uniform(-12, 12, (2, gh, gw))
     w_var, w_gm = (0.0, 1.5) if terms == "gm" else (2.0, 0.0)
-    # "var+norm": flow_norm alone is evaluated inside the backward kernel from the tile's flow (no regulariser launch)
+    # the regularisers are evaluated inside the backward kernel from the tile's flow (no dense field, no regulariser launch)
     w_norm, w_tv = {"var+reg": (0.02, 0.03), "var+norm": (0.05, 0.0)}.get(terms, (0.0, 0.0))
     ev = _off_the_kinks_patch(ev, theta, (H, W), patch, slide)
     plan = ebos.EventPlan.build(G(ev), (H, W), "first", True, tile=tile)
@@ -1083,7 +1083,7 @@ def test_grid_sampling_kernels_match_upsample_then_dense(ebos, case, terms):
         loop = FusedPatchLoop(plan, patch, slide, G(theta).float(), w_var, w_norm, w_tv, halo=halo, capacity=1, splits=splits,
                               w_gradient_magnitude=w_gm, sample_grid=grid)
         assert loop.sample_grid == grid and (loop.d_dense is None) == grid
-        assert loop.fuse_norm == (grid and terms == "var+norm") and (loop.dense is None) == (grid and terms != "var+reg")
+        assert loop.fuse_norm == (grid and terms in ("var+norm", "var+reg")) and (loop.dense is None) == grid
         loss, grad = loop.value_and_grad(G(theta).float())
         out[grid] = (loop.iwe.cpu().double().numpy(), float(loss), grad.cpu().double().numpy())
     assert rel(out[True][0], out[False][0]) < 1e-6
