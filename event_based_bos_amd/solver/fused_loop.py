@@ -16,11 +16,12 @@ Grid-sampling route (``sample_grid``, the default whenever ``ebos_patch_fused_su
 itself and evaluate the grid -> dense map per source tile in LDS, so the iteration shrinks to
 
     ebos_iwe_patch_slab_f32           theta -> IWE + variance partials                         (2 kernels)
-    ebos_iwe_patch_tiled_bwd_f32      reduces the variance partials, folds the variance gradient in, evaluates flow_norm from the
+    ebos_iwe_patch_tiled_bwd_f32      reduces the variance partials, folds the variance gradient in, evaluates the flow regularisers from the
                                       tile's flow, and leaves partial CELL gradients per tile    (1 kernel)
     ebos_patch_grad_combine_adam_f32  -> d loss / d theta, Adam step, loss[it]                  (1 kernel)
 
-(4 launches, 48.5 us at 2 M events against 64.9 us; with image_gradient on, the dense field and the regulariser launch stay.)
+(4 launches, 48.5 us at 2 M events against 64.9 us; image_gradient too is evaluated there, on a 2 px apron of the tile's flow:
+55 us against 98 us.)
 
 Expressed through autograd the same iteration is ~35 launches (capturable Adam alone is a dozen) and runs at ~235 us
 even as a replayed HIP graph; this pipeline is bounded by its event kernels.  Anything outside this objective family
