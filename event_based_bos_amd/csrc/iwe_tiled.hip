@@ -1363,8 +1363,10 @@ struct SlabConfig {
 };
 // f64 tile + halo must fit 160 KiB (forward); backward needs 16 TH TW + 4 LH LW bytes
 // {45, 80, 32} cuts 720 x 1280 into exactly 16 x 16 = 256 tiles: one workgroup per CU of an MI355X
-constexpr SlabConfig kSlabConfigs[] = {{64, 64, 32}, {45, 80, 32}, {32, 64, 32}, {32, 32, 32},
-                                       {64, 64, 16}, {32, 32, 16}, {32, 32, 8}};
+// smaller halos for windows whose displacements are small (BOS flows are typically a few pixels): slabs, LDS clear / decode and
+// the backward kernel's upstream tile all shrink with (TH + 2 halo)(TW + 2 halo); taps beyond the halo stay correct (spill)
+constexpr SlabConfig kSlabConfigs[] = {{64, 64, 32}, {45, 80, 32}, {32, 64, 32}, {32, 32, 32}, {64, 64, 16},
+                                       {45, 80, 16}, {32, 32, 16}, {32, 32, 8}};
 constexpr int kNumSlabConfigs = sizeof(kSlabConfigs) / sizeof(kSlabConfigs[0]);
 
 struct SlabLayout {
@@ -1564,6 +1566,7 @@ bool slab_config_ok(int th, int tw, int halo) {
   else if (tile_h == 32 && tile_w == 64 && halo == 32) { rc = CALL(32, 64, 32); } \
   else if (tile_h == 32 && tile_w == 32 && halo == 32) { rc = CALL(32, 32, 32); } \
   else if (tile_h == 64 && tile_w == 64 && halo == 16) { rc = CALL(64, 64, 16); } \
+  else if (tile_h == 45 && tile_w == 80 && halo == 16) { rc = CALL(45, 80, 16); } \
   else if (tile_h == 32 && tile_w == 32 && halo == 16) { rc = CALL(32, 32, 16); } \
   else if (tile_h == 32 && tile_w == 32 && halo == 8) { rc = CALL(32, 32, 8); }
 

@@ -22,11 +22,12 @@ ap.add_argument("--patch", type=int, nargs=2, default=[24, 32])
 ap.add_argument("--dense", action="store_true", help="materialised route (upsample -> dense kernels -> adjoint) instead of grid sampling")
 ap.add_argument("--flow-norm", type=float, default=0.001)
 ap.add_argument("--image-gradient", type=float, default=0.0)
+ap.add_argument("--halo", type=int, default=32)
 a = ap.parse_args()
 ev, _ = synth_window(a.events, 0)
-plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto")
+plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=ebos.event_plan.choose_tile((H, W), a.halo))
 gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
-loop = FusedPatchLoop(plan, a.patch, a.patch, torch.zeros((2, gh, gw)), 1.0, a.flow_norm, a.image_gradient, lr=0.1, capacity=a.iters + 3,
+loop = FusedPatchLoop(plan, a.patch, a.patch, torch.zeros((2, gh, gw)), 1.0, a.flow_norm, a.image_gradient, halo=a.halo, lr=0.1, capacity=a.iters + 3,
                       sample_grid=False if a.dense else None)
 loop.run(3)
 torch.cuda.synchronize()
@@ -34,4 +35,4 @@ t0 = time.perf_counter()
 losses = loop.run(a.iters)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f"sample_grid {loop.sample_grid}, flow_norm {a.flow_norm}, image_gradient {a.image_gradient}: {a.events} events, {a.iters} iterations: {dt / a.iters * 1e6:.1f} us/iteration; loss {losses[0].item():.5f} -> {losses[-1].item():.5f}")
+print(f"tile {plan.tile} halo {a.halo}, sample_grid {loop.sample_grid}, flow_norm {a.flow_norm}, image_gradient {a.image_gradient}: {a.events} events, {a.iters} iterations: {dt / a.iters * 1e6:.1f} us/iteration; loss {losses[0].item():.5f} -> {losses[-1].item():.5f}")
