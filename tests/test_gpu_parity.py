@@ -1111,7 +1111,8 @@ def test_grid_sampling_refuses_unsupported_configurations(ebos):
     assert lib.ebos_patch_fused_supported(45, 80, 32, 24, 32) == 1
     assert lib.ebos_patch_fused_supported(45, 80, 32, 2, 2) == 0      # too many cells per tile
     assert lib.ebos_patch_fused_supported(64, 64, 32, 24, 32) == 0    # no LDS left for the tile's flow
-    assert lib.ebos_patch_fused_supported(45, 80, 16, 24, 32) == 0    # not a built configuration
+    assert lib.ebos_patch_fused_supported(45, 80, 16, 24, 32) == 1    # the small-displacement configuration
+    assert lib.ebos_patch_fused_supported(45, 80, 24, 24, 32) == 0    # not a built configuration
     ev = O.synth_events(5000, 128, 128, seed=3)
     plan = ebos.EventPlan.build(G(ev), (128, 128), "first", True, tile=(64, 64))
     with pytest.raises(ValueError):
