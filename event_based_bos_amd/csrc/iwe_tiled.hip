@@ -410,7 +410,7 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       const unsigned q01 = (unsigned)(__float_as_int(t0) - __float_as_int(u0));  // A0 - q00
       const unsigned q10 = (unsigned)(__float_as_int(u1) - kMagicBits);
       const unsigned q11 = (unsigned)(__float_as_int(t1) - __float_as_int(u1));  // A1 - q10
-      const unsigned t = (unsigned)(rl * LW + cl);
+      const unsigned t = __umul24((unsigned)rl, (unsigned)LW) + (unsigned)cl;  // (rl < 2^24 whenever the result is used)
       const unsigned word = inside ? (t >> 1) + (t & 1u) * kPlane : kDummy;
       atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
       atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
