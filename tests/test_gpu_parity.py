@@ -858,7 +858,9 @@ def test_fuzz_fused_path_against_oracle(ebos):
         assert plan.compact == (kind != 4), tag
         fg = G(flow).float().requires_grad_(True)
         got = plan.iwe_dense(fg, pad=(pad, pad), halo=halo, splits=splits)
-        scale = max(float(expect.detach().norm()), 1e-12)
+        # (relative to the image, but not below 5 % of ONE event's unit mass: with a couple of events pushed almost entirely
+        # out of the image, what is left inside is a tap of weight ~1e-3 whose f32 error is that of a full-weight tap)
+        scale = max(float(expect.detach().norm()), 0.05)
         assert float((got.detach().cpu().double() - expect.detach()).norm()) / scale < 1e-4, tag
         if v_ref is not None and float(v_ref.detach()) > 0:
             v = plan.contrast_dense(fg, "image_variance", omit, pad=(pad, pad), halo=halo, splits=splits)
