@@ -3,7 +3,7 @@
 One iteration of the loop in src/solver/generative_max_likelihood.py:306-341 (zero_grad -> objective -> backward ->
 optimizer.step) for the objective  ``-w * contrast(IWE(dense(theta))) + w_n * flow_norm(dense) + w_g * image_gradient(dense)``
 (contrast = image variance, or the gradient magnitude with two more cost kernels)
-is five C-ABI calls / eight kernels on one stream, all on buffers allocated once per window:
+is, on the MATERIALISED route, five C-ABI calls / eight kernels on one stream, all on buffers allocated once per window:
 
     ebos_upsample_patch_flow_f32      theta [2, gh, gw] -> dense [2, H, W]
     ebos_iwe_dense_slab_f32           dense -> IWE + variance partials           (2 kernels; 3 without regularisers)
