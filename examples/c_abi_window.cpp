@@ -5,6 +5,8 @@
 // gradient for a dense flow, and checks two things a caller can check without a reference:
 //   * mass:      sum(IWE) == number of events whose four taps stay inside the image (zero flow: all of them)
 //   * gradient:  a finite difference of the variance along the direction "towards zero flow" matches <d_flow, direction>
+// and then hands the whole Adam loop of a patch-flow solver to the library (ebos_cmax_patch_solve_f32: 4 kernel launches per
+// iteration, the event kernels sample the patch grid themselves) and checks that the loss falls.
 //
 //   hipcc --offload-arch=gfx950 -std=c++17 -Iinclude examples/c_abi_window.cpp \
 //         -Levent_based_bos_amd/lib -lebos_hip -Wl,-rpath,$PWD/event_based_bos_amd/lib -o examples/c_abi_window
@@ -152,6 +154,47 @@ int main(int argc, char** argv) {
   std::printf("smooth flow: variance %.6f, d/d(direction): analytic %.6f, finite difference %.6f\n", v, directional, fd);
   if (std::fabs(fd - directional) > 0.1 * std::fabs(directional) + 1e-4) {  // the objective has kinks: FD is approximate
  std::fprintf(stderr, "gradient check failed\n"); return 6; }
+  // ---- the Adam loop of a patch-flow solver, enqueued by ONE call: patch grid [2, gh, gw] -> flow by the patch -> dense map of
+  // src/solver/patch_eklt.py:173-204, evaluated per source tile inside the event kernels (no dense flow field), loss =
+  // -variance + 0.001 flow_norm.  The events of this window do not move, so from a grid of 1.5 px the loop has to walk the
+  // flow back towards zero: the loss must fall.
+  const int PH = 20, PW = 26, gh = (H + PH - 1) / PH, gw = (W + PW - 1) / PW, n_iter = 40;
+  if (!ebos_patch_fused_supported(TH, TW, HALO, PH, PW)) {
+    std::printf("(tile %dx%d + %d leaves no LDS for grid sampling: solver section skipped)\nOK\n", TH, TW, HALO);
+    return 0;
+  }
+  const size_t n_grid = (size_t)2 * gh * gw;
+  auto *theta = dev_alloc<float>(n_grid), *d_theta = dev_alloc<float>(n_grid), *m1 = dev_alloc<float>(n_grid), *m2 = dev_alloc<float>(n_grid);
+  std::vector<float> h_theta(n_grid, 1.5f);
+  HIP_OK(hipMemcpy(theta, h_theta.data(), n_grid * 4, hipMemcpyHostToDevice));
+  const size_t gp_bytes = ebos_patch_grad_partials_bytes(H, W, TH, TW, 0);
+  const size_t n_items = gp_bytes / 2048;  // one regulariser value partial per work item of the backward kernel
+  const size_t n_reg = n_items > (size_t)ebos_flow_regularisers_partials() ? n_items : (size_t)ebos_flow_regularisers_partials();
+  const float minus_one = -1.0f;
+  HIP_OK(hipMemcpy(upstream, &minus_one, 4, hipMemcpyHostToDevice));  // loss = -w_variance * variance
+  ebos_cmax_patch_problem q{};
+  q.grp_offsets = grp; q.cpix = cpix; q.cdt = cdt; q.key_offsets = key_offsets; q.n = n;
+  q.H = H; q.W = W; q.tile_h = TH; q.tile_w = TW; q.halo = HALO; q.splits = 1;
+  q.gh = gh; q.gw = gw; q.patch_h = PH; q.patch_w = PW; q.slide_h = PH; q.slide_w = PW;
+  q.w_variance = 1.0f; q.w_flow_norm = 0.001f;
+  q.lr = 0.05; q.beta1 = 0.9; q.beta2 = 0.999; q.eps = 1e-8;
+  q.theta = theta; q.d_theta = d_theta; q.exp_avg = m1; q.exp_avg_sq = m2; q.step = dev_alloc<int>(1);
+  q.iwe = iwe; q.variance = var; q.moments = moments; q.upstream = upstream;
+  q.reg_partials = dev_alloc<double>(n_reg);  // zero-filled once
+  q.workspace = ws; q.workspace_bytes = ws_bytes;
+  q.losses = dev_alloc<float>(n_iter); q.losses_cap = n_iter;
+  q.grad_partials = reinterpret_cast<float*>(dev_alloc<char>(gp_bytes)); q.grad_partials_bytes = gp_bytes;
+  if (ebos_cmax_patch_solve_f32(&q, n_iter, nullptr) != 0) { std::fprintf(stderr, "solve failed: %s\n", ebos_last_error()); return 7; }
+  std::vector<float> h_losses(n_iter);
+  HIP_OK(hipMemcpy(h_losses.data(), q.losses, n_iter * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_theta.data(), theta, n_grid * 4, hipMemcpyDeviceToHost));
+  double mean_abs = 0.0;
+  for (float t : h_theta) mean_abs += std::fabs(t) / (double)n_grid;
+  std::printf("solver:      %d Adam iterations on a %dx%d patch grid, loss %.6f -> %.6f, mean |flow| 1.5 -> %.3f px\n", n_iter, gh, gw,
+              h_losses[0], h_losses[n_iter - 1], mean_abs);
+  for (float l : h_losses)
+    if (!std::isfinite(l)) { std::fprintf(stderr, "non-finite loss\n"); return 8; }
+  if (!(h_losses[n_iter - 1] < h_losses[0]) || !(mean_abs < 1.5)) { std::fprintf(stderr, "the solver did not improve the objective\n"); return 8; }
   std::printf("OK\n");
   return 0;
 }

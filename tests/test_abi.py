@@ -103,8 +103,8 @@ def test_product_never_imports_oracle():
 @pytest.mark.gpu
 def test_c_abi_is_usable_without_python(tmp_path, lib):
     """examples/c_abi_window.cpp: a plain host program (hipcc, no torch) drives the library through include/ebos_hip.h --
-    raw sensor columns -> plan -> objective -> gradient -- and checks mass conservation and a finite-difference
-    derivative itself."""
+    raw sensor columns -> plan -> objective -> gradient -> 40 Adam iterations of the native patch-flow solver loop -- and checks
+    mass conservation, a finite-difference derivative and that the loss falls, itself."""
     import shutil
     import subprocess
 
@@ -119,6 +119,8 @@ def test_c_abi_is_usable_without_python(tmp_path, lib):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe, "150000"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.strip().endswith("OK"), (run.stdout[-1000:], run.stderr[-1000:])
+    assert "solver:" in run.stdout, run.stdout[-1000:]
+    print(run.stdout)
 
 
 def test_header_is_plain_c(tmp_path):
