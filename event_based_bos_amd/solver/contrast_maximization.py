@@ -122,7 +122,7 @@ class ContrastMaximization(SolverBase):
     def estimate(self, events, *args, **kwargs) -> np.ndarray:
         """events [n, 4] (x=row, y=col, t, p) -> flow [2, H, W] (numpy), like the reference's solvers."""
         ev = to_gpu(events)
-        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile="auto")
+        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile=self.plan_tile())
         self.history = []
         if self.motion_model == "dense-flow":
             flow = self._estimate_patch_flow(plan)
@@ -133,6 +133,13 @@ class ContrastMaximization(SolverBase):
         else:
             raise NotImplementedError(f"motion_model {self.motion_model!r}")
         return flow.detach().cpu().numpy().astype(np.float64)
+
+    def plan_tile(self):
+        """Source tile of the window plans: the configuration built for this solver's ``halo`` that fills the GPU best
+        (``halo: 16`` -- windows whose displacements stay within ~16 px -- selects the smaller LDS windows)."""
+        from ..event_plan import choose_tile
+
+        return choose_tile(self.orig_image_shape, self.halo)
 
     def pyramid_scales(self):
         """[(patch_size, sliding_window, n_iter)] coarse to fine.  Without ``patch.pyramid`` one scale (``patch.size``);

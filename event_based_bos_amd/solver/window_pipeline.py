@@ -54,7 +54,7 @@ class WindowPipeline(object):
     # ------------------------------------------------------------------ stages
     def _ingest(self, store: RawEventStore, window: Tuple[int, int]) -> EventPlan:
         s = self.solver
-        plan = store.plan(window[0], window[1], s.orig_image_shape, s.warp_direction, True, tile="auto", device=self.device,
+        plan = store.plan(window[0], window[1], s.orig_image_shape, s.warp_direction, True, tile=s.plan_tile(), device=self.device,
                           deferred=True)  # no host read-back: the host never waits for the GPU until the end
         if not fused_loop.supported(s.contrast_terms, s.flow_terms, s.blur_sigma, s.opt_method, plan, s.halo):
             raise NotImplementedError("this solver configuration is outside the fused objective family: "

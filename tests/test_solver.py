@@ -368,3 +368,27 @@ def test_event_thresholding_freezes_sparse_patches():
     pipe.run(store, [(0, len(ev))])
     pf = pipe.patch_flows[0].cpu().numpy() if hasattr(pipe.patch_flows[0], "cpu") else np.asarray(pipe.patch_flows[0])
     assert np.all(pf[:, ~want] == 0.0) and np.all(np.abs(pf[:, want]).max(0) > 0.0)
+
+
+@pytest.mark.gpu
+def test_solver_halo_option_selects_the_small_window_configuration():
+    """solver.halo: 16 plans the windows on the tile configuration built for that halo (720x1280: 45x80 + 16) and changes
+    nothing but the size of the tile-private windows: same losses and flows as halo 32 (displacements beyond a halo are still
+    handled, by the spill path -- here none are)."""
+    import event_based_bos_amd as ebos
+
+    h, w = 720, 1280
+    ev = moving_points(h, w, 3000, 40, np.array([3.0, -2.0]), seed=8)
+    out = {}
+    for halo in (32, 16):
+        cfg = load_cfg()["solver"]
+        cfg.update(patch={"size": [48, 64], "sliding_window": [48, 64]}, cost_with_weight={"image_variance": 1.0, "flow_norm": 0.001},
+                   iwe={"method": "bilinear_vote", "blur_sigma": 0}, halo=halo,
+                   optimizer={"method": "Adam", "n_iter": 25, "parameters": {"lr": 0.2}})
+        s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+        assert s.plan_tile() == (45, 80)
+        flow = s.estimate(ev)
+        assert s.fused
+        out[halo] = (np.array(s.history), flow)
+    np.testing.assert_allclose(out[16][0], out[32][0], rtol=1e-5)
+    assert np.abs(out[16][1] - out[32][1]).max() < 1e-3

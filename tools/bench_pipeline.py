@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--events", type=int, default=2_000_000)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--nc", type=int, nargs="+", default=[1, 2, 3, 4], help="windows in flight to try")
+    ap.add_argument("--halo", type=int, default=32, help="solver halo (16: tile 45x80 + 16 for small displacements)")
     ap.add_argument("--repeat", type=int, default=1, help="timed runs per setting (the minimum is reported)")
     a = ap.parse_args()
     n = a.windows * a.events
@@ -36,10 +37,10 @@ def main():
                                             "p": rs.randint(0, 2, n).astype(bool)})
     windows = [(k * a.events, (k + 1) * a.events) for k in range(a.windows)]
     cfg = {"motion_model": "dense-flow", "warp_direction": "first", "cost_with_weight": {"image_variance": 1.0, "flow_norm": 0.001},
-           "patch": {"size": [24, 32], "sliding_window": [24, 32]},
+           "patch": {"size": [24, 32], "sliding_window": [24, 32]}, "halo": a.halo,
            "optimizer": {"method": "Adam", "n_iter": a.iters, "parameters": {"lr": 0.1}}}
     solver = ebos.solver.collections["contrast_maximization"]((H, W), (H, W), solver_config=cfg)
-    res = {"windows": a.windows, "events_per_window": a.events, "iterations": a.iters}
+    res = {"windows": a.windows, "events_per_window": a.events, "iterations": a.iters, "halo": a.halo}
     host_windows = [store.load_event(*wnd) for wnd in windows[:2]]
     solver.estimate(host_windows[0])  # warm the process
     torch.cuda.synchronize()
