@@ -1,31 +1,46 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mevents/s through the fused warp + IWE (+ variance contrast) pass at 1280x720.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5] [--dry-run]
 
-Workload (BASELINE.json configs[1]): one window of 10 M synthetic events (recipe of
-src/utils/event_utils.py:40-47, seed = rank) at 1280x720, dense per-pixel flow U(-30, 30)
-(src/utils/flow_utils.py:29), normalised time, reference time "first", variance contrast.
-One "step" = one evaluation of the contrast objective on the resident window (ebos_iwe_dense_slab_f32):
-    fused warp + bilinear splat into tile-private LDS images -> slab combine (writes the IWE) -> variance.
-The window is resident in HBM in its plan form (SoA f32, binned by source tile: built once per window
-and reused by every solver iteration; its one-off build time is reported as plan_build_ms and is NOT
-in the timed region).  With N > 1 every rank owns an independent window (weak scaling, no collective
-in the data path); timing is barrier + synchronize bracketed, max over ranks.
+With ``--gpus N > 1`` and no launcher environment (RANK unset) this process starts the N ranks itself
+(``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>``, as a
+CHILD process, before anything here has touched the GPU) and relays rank 0's JSON line; launched BY torchrun (RANK set)
+it is one rank of that job.  One process per GPU, ``torch.distributed`` ("nccl" = RCCL) only for the rendezvous, the
+barrier around the timed region, the MAX over ranks and the final object gather: the path has NO data-path collective.
+
+Workloads (BASELINE.json ``configs``; ``--config``):
+  2 (default)  one window of 10 M synthetic events per rank (recipe of src/utils/event_utils.py:40-47, seed = rank) at
+               1280x720, dense per-pixel flow U(-30, 30) (src/utils/flow_utils.py:29), normalised time, reference time
+               "first", variance contrast.  One step = one evaluation of the contrast objective on the resident window
+               (ebos_iwe_dense_slab_f32: tile accumulate -> slab combine (writes the IWE) -> variance).  WEAK scaling.
+  4            64 time windows x 2 M events, 30x40 patch-flow grid per window (src/solver/patch_eklt.py:173-204), windows
+               dealt round-robin to the ranks (the per-window loop of bos_event.py:144-220).  One step = the objective of
+               every window this rank owns, evaluated once (ebos_iwe_patch_slab_f32).  STRONG scaling (64 windows in all).
+  5            512 2-DoF hypotheses (32 x 16 grid over [-30, 30]^2: the grid sampler of
+               src/solver/generative_max_likelihood.py:238-255) over ONE window of 50 M events replicated on every rank,
+               hypotheses in contiguous blocks of 512 / N.  One step = this rank's block evaluated once.  STRONG scaling.
+
+The window is resident in HBM in its plan form (compact events binned by source tile: built once per window and reused
+by every solver iteration); its one-off build time is reported as ``plan_build_ms`` and, folded into a single
+evaluation, as ``value_incl_plan_build`` -- it is NOT in the timed region of ``value``.
+
+Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize() and
+MAX-reduced over the ranks; blocks repeat until >= ``--min-seconds`` of timed work and the MEDIAN block is reported
+(``repeats``).  The dominant kernels are timed by HIP events stamped with their own dispatch (hipExtLaunchKernelGGL on the
+launch stream) during the first timed blocks.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -35,22 +50,148 @@ H, W = 720, 1280
 N_EVENTS = 10_000_000
 FLOW_MAX = 30.0
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+DOMINANT_SOURCE = os.path.join("event_based_bos_amd", "csrc", "iwe_tiled.hip")
+CONFIG4 = dict(windows=64, events=2_000_000, patch=(24, 32), slide=(24, 32))   # -> patch grid 30 x 40
+CONFIG5 = dict(events=50_000_000, grid=(32, 16), theta_max=30.0)              # -> 512 hypotheses
+DEFAULT_STEPS = {2: 200, 4: 10, 5: 2}
+DEFAULT_WARMUP = {2: 20, 4: 2, 5: 1}
 
 
-def synth_window(n, seed):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5))
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch + rendezvous + shard assignment + gather only (gloo, CPU, no kernels)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much timed work")
+    ap.add_argument("--max-repeats", type=int, default=400)
+    ap.add_argument("--events", type=int, default=None, help="events per window (default: the config's)")
+    ap.add_argument("--windows", type=int, default=None, help="config 4: number of windows (default 64)")
+    ap.add_argument("--tile", type=int, nargs=2, default=[0, 0], help="source tile (0 0 = choose_tile: 45x80 at 1280x720)")
+    ap.add_argument("--halo", type=int, default=32)
+    ap.add_argument("--splits", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informative legs (fwd+bwd, streams, rotating windows, solver)")
+    ap.add_argument("--no-compact", action="store_true", help="read the 12 B/event (x, y, dt) plan instead of 6 B/event")
+    ap.add_argument("--cpu-sample", type=int, default=N_EVENTS, help="events of the window the CPU baseline is timed on")
+    ap.add_argument("--rotating-windows", type=int, default=8, help="distinct 10 M-event plans cycled by the cache-cold leg")
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = DEFAULT_STEPS[args.config]
+    if args.warmup is None:
+        args.warmup = DEFAULT_WARMUP[args.config]
+    return args
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank job.  Runs before this process has imported torch or touched the GPU; the ranks are CHILD
+    processes (never an exec of a GPU-initialised process).  Their output goes straight through: rank 0 prints the line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: needed by RCCL across processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def shard_for(config, rank, world, args):
+    """Units of this rank: config 4 windows round-robin, config 5 hypotheses in contiguous blocks,
+    config 2 one own window per rank."""
+    from event_based_bos_amd.sharding import shard_units
+
+    if config == 4:
+        return shard_units(args.windows or CONFIG4["windows"], world, rank, "round_robin")
+    if config == 5:
+        return shard_units(CONFIG5["grid"][0] * CONFIG5["grid"][1], world, rank, "block")
+    return [rank]
+
+
+def dry_run(args):
+    """The N-rank plumbing without a GPU: rendezvous (gloo), shard assignment, barrier, MAX-reduce, object gather."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_for(args.config, rank, world, args)
+    seen = [{"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", 0)), "units": len(mine), "first_units": mine[:4]}]
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parts = [None] * world
+        dist.all_gather_object(parts, seen[0])
+        seen = parts
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "config": args.config, "n_gpus": world, "ranks_seen": seen,
+                          "units_total": sum(s["units"] for s in seen), "max_over_ranks_check": float(t.item()),
+                          "steps": args.steps, "warmup": args.warmup}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# inputs
+# ---------------------------------------------------------------------------------------------------------------------
+def synth_window(n, seed, flow=True):
+    import numpy as np
+
     rs = np.random.RandomState(seed)
     x = rs.randint(0, H, n)
     y = rs.randint(0, W, n)
     t = np.sort(rs.uniform(0.0, 0.5, n))
     p = rs.randint(0, 2, n)
     ev = np.stack([x, y, t, p], axis=1).astype(np.float64)
-    flow = np.random.RandomState(1000 + seed).uniform(-FLOW_MAX, FLOW_MAX, (2, H, W))
-    return ev, flow
+    fl = np.random.RandomState(1000 + seed).uniform(-FLOW_MAX, FLOW_MAX, (2, H, W)) if flow else None
+    return ev, fl
+
+
+def git_blob_sha(path):
+    """`git hash-object` of a file without git (the GPU box has no .git): sha1("blob <len>\\0" + content)."""
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC collection -- only if that collection was made on the
+    kernel source as it is NOW (blob hash of csrc/iwe_tiled.hip recorded by tools/make_pmc_json.py); else None."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None, {"traffic_note": "profiles/pmc_latest.json missing"}
+    stamp = {"traffic_commit": rec.get("commit"), "traffic_kernel": rec.get("kernel_template"),
+             "traffic_source_blob": rec.get("source_blob_sha")}
+    now = git_blob_sha(os.path.join(ROOT, DOMINANT_SOURCE))
+    if rec.get("source_blob_sha") is None or rec.get("source_blob_sha") != now:
+        stamp["traffic_note"] = f"stale: collected on blob {rec.get('source_blob_sha')}, kernel source is now {now}"
+        return None, stamp
+    return rec.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch"), stamp
 
 
 def cpu_baseline(ev, flow, sample):
     """The oracle's op-for-op torch-CPU restatement of the reference path (kind 'port'), timed on this
     host's cores on a bounded sample of the same window."""
+    import torch
+
     from oracle import ebos_oracle as O
 
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -68,7 +209,7 @@ def cpu_baseline(ev, flow, sample):
         if best is None or dt_ < best:
             best, threads = dt_, cand
     torch.set_num_threads(threads)
-    out = {}
+    out, contrast = {}, None
     for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
         e = torch.from_numpy(ev[:sample]).to(dt)
         f = torch.from_numpy(flow).to(dt)
@@ -76,10 +217,12 @@ def cpu_baseline(ev, flow, sample):
         for rep in range(6):
             t0 = time.perf_counter()
             iwe = O.iwe_dense(e, f, (H, W))
-            O.image_variance(iwe)
+            var = O.image_variance(iwe)
             times.append(time.perf_counter() - t0)
             if sum(times) > 40.0 and rep >= 2:  # a slow host: stay within the bench's few minutes
                 break
+        if name == "f64":
+            contrast = abs(float(var.item()))  # (the oracle's cost is signed for minimisation; the contrast is its magnitude)
         out[name] = sample / statistics.median(times[1:]) / 1e6
         reps = len(times) - 1
     model = "unknown"
@@ -93,60 +236,141 @@ def cpu_baseline(ev, flow, sample):
             "sample": (f"{'the whole window' if sample >= len(ev) else 'first ' + str(sample) + ' events of the window'} "
                        f"({min(sample, len(ev))} events), fwd warp+IWE+variance, torch-CPU fp64 (reference default dtype), "
                        f"median of {reps} after 1 warm-up; fp32 on the same sample: {out['f32']:.2f} Mevents/s"),
-            "value_f32": round(out["f32"], 3)}
+            "value_f32": round(out["f32"], 3), "contrast_f64": contrast}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--events", type=int, default=N_EVENTS)
-    ap.add_argument("--tile", type=int, nargs=2, default=[0, 0], help="source tile (0 0 = choose_tile: 45x80 at 1280x720)")
-    ap.add_argument("--halo", type=int, default=32)
-    ap.add_argument("--splits", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-compact", action="store_true", help="read the 12 B/event (x, y, dt) plan instead of 6 B/event")
-    ap.add_argument("--cpu-sample", type=int, default=N_EVENTS, help="events of the window the CPU baseline is timed on")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
+class Rank(object):
+    def __init__(self, args):
+        import torch
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun also for a world of 1
-    if distributed:
-        import torch.distributed as dist
+        self.args = args
+        self.rank = int(os.environ.get("RANK", 0))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", 0))
+        self.world = int(os.environ.get("WORLD_SIZE", 1))
+        self.distributed = self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun also for a world of 1
+        if self.distributed:
+            import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if distributed else 0)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+        else:
+            torch.cuda.set_device(0)
+        self.dev = torch.device("cuda", self.local_rank if self.distributed else 0)
+
+    def sync_all(self):
+        import torch
+
+        torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        import torch
+
+        if not self.distributed:
+            return seconds
+        tt = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def gather(self, obj):
+        if not self.distributed:
+            return [obj]
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, obj)
+        return parts
+
+    def timed_blocks(self, step, lib, profile_kernel=0, launches_per_step=1, profile_blocks=2):
+        """Warm-up, then blocks of exactly --steps steps (barrier + synchronize on both sides, MAX over ranks) until
+        --min-seconds of timed work; returns (block times [s], per-launch kernel times [ms] of the profiled blocks)."""
+        import ctypes
+
+        a = self.args
+        for _ in range(a.warmup):
+            step()
+        self.sync_all()
+        blocks, kernel_ms = [], []
+        while True:
+            prof = len(blocks) < profile_blocks
+            nrec = max(1, a.steps * launches_per_step)
+            if prof:
+                from event_based_bos_amd import _hip
+                _hip.check(lib.ebos_profile_start_kernel(profile_kernel, nrec), "ebos_profile_start_kernel")
+            self.sync_all()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            self.sync_all()
+            blocks.append(self.max_over_ranks(time.perf_counter() - t0))
+            if prof:
+                buf = (ctypes.c_float * nrec)()
+                got = lib.ebos_profile_stop(buf, nrec)
+                kernel_ms.extend(buf[i] for i in range(got))
+            if sum(blocks) >= a.min_seconds or len(blocks) >= a.max_repeats:
+                return blocks, kernel_ms
+
+
+def roofline_entry(kernel, kernel_ms_list, algo_bytes, extra=None):
+    k_ms = statistics.mean(kernel_ms_list) if kernel_ms_list else float("nan")
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+    traffic, stamp = pmc_traffic(kernel)
+    ent = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel_ms": round(k_ms, 4),
+           "kernel_ms_min": round(min(kernel_ms_list), 4) if kernel_ms_list else None,
+           "kernel_ms_max": round(max(kernel_ms_list), 4) if kernel_ms_list else None,
+           "kernel_launches_timed": len(kernel_ms_list), "algorithmic_bytes": algo_bytes}
+    ent.update(stamp)
+    if extra:
+        ent.update(extra)
+    return ent
+
+
+def base_line(R, value, ms_per_step, blocks, scaling, workload_cfg):
+    a = R.args
+    return {"metric": "Mevents/sec warped+IWE at 1280x720", "value": round(value, 2), "unit": "Mevents/s", "n_gpus": R.world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": workload_cfg,
+            "repeats": len(blocks), "timed_seconds": round(sum(blocks), 4),
+            "block_ms": {"median": round(statistics.median(blocks) * 1e3, 4), "min": round(min(blocks) * 1e3, 4),
+                         "max": round(max(blocks) * 1e3, 4)}}
+
+
+def run_config2(R):
+    import ctypes
+
+    import numpy as np
+    import torch
 
     import event_based_bos_amd as ebos
     from event_based_bos_amd import _hip
 
+    a, dev, rank, world = R.args, R.dev, R.rank, R.world
     lib = _hip.require_gpu()
-    n = args.events
+    n = a.events or N_EVENTS
     ev, flow_np = synth_window(n, seed=rank)
     ev_gpu = torch.from_numpy(ev).to(dev)
     flow = torch.from_numpy(flow_np).float().to(dev)
-    if args.tile[0] <= 0:
-        args.tile = list(ebos.event_plan.choose_tile((H, W), args.halo))
+    if a.tile[0] <= 0:
+        a.tile = list(ebos.event_plan.choose_tile((H, W), a.halo))
     plan_first_ms = plan_build_ms = 0.0
-    for attempt in range(2):  # the first build also pays one-off allocator / code-object costs: report the second
+    for attempt in range(3):  # the first build also pays one-off allocator / code-object costs: report the best later one
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        plan = ebos.EventPlan.build(ev_gpu, (H, W), "first", True, tile=tuple(args.tile))
+        plan = ebos.EventPlan.build(ev_gpu, (H, W), "first", True, tile=tuple(a.tile))
         torch.cuda.synchronize()
-        plan_build_ms = (time.perf_counter() - t0) * 1e3
-        plan_first_ms = plan_first_ms or plan_build_ms
+        ms = (time.perf_counter() - t0) * 1e3
+        plan_first_ms = plan_first_ms or ms
+        plan_build_ms = ms if attempt == 1 else min(plan_build_ms or ms, ms)
     del ev_gpu
 
-    import ctypes
-
-    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, args.tile[0], args.tile[1], args.halo, args.splits, 0, 0))
+    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, a.tile[0], a.tile[1], a.halo, a.splits, 0, 0))
     ws = torch.zeros(nws, dtype=torch.uint8, device=dev)  # zero-filled once (spill section stays zero)
     out = torch.empty(1, dtype=torch.float32, device=dev)
     moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
@@ -154,109 +378,156 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     P = lambda t: t.data_ptr()
 
-    cptrs = plan._compact_ptrs() if (plan.compact and not args.no_compact) else (None, None, None)
+    def compact_ptrs(pl):
+        return pl._compact_ptrs() if (pl.compact and not a.no_compact) else (None, None, None)
+
+    cptrs = compact_ptrs(plan)
     bytes_per_event = 6.0 if cptrs[0] else 12.0
 
-    def step():
-        # one objective evaluation: tile accumulate -> slab combine (writes the IWE) -> variance
-        _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n, P(flow),
-                                               H, W, args.tile[0], args.tile[1], args.halo, args.splits, 0, 0, P(ws), nws,
-                                               P(iwe), 1, 0, P(out), P(moments), P(plan.part_table), stream), "ebos_iwe_dense_slab")
+    def make_step(pl, fl, cp):
+        def step():
+            # one objective evaluation: tile accumulate -> slab combine (writes the IWE) -> variance
+            _hip.check(lib.ebos_iwe_dense_slab_f32(P(pl.x), P(pl.y), P(pl.dt), None, *cp, P(pl.key_offsets), pl.n, P(fl),
+                                                   H, W, a.tile[0], a.tile[1], a.halo, a.splits, 0, 0, P(ws), nws,
+                                                   P(iwe), 1, 0, P(out), P(moments), P(pl.part_table), stream), "ebos_iwe_dense_slab")
+        return step
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    _hip.check(lib.ebos_profile_start(args.steps), "ebos_profile_start")  # HIP events around the dominant kernel
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    buf = (ctypes.c_float * args.steps)()
-    nrec = lib.ebos_profile_stop(buf, args.steps)
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kernel_ms = statistics.mean(buf[i] for i in range(nrec)) if nrec else float("nan")
+    step = make_step(plan, flow, cptrs)
+    blocks, kernel_ms = R.timed_blocks(step, lib, _hip.PROFILE_SLAB_ACCUMULATE)
+    elapsed = statistics.median(blocks)
     contrast = float(out.item())
+    ranks_seen = R.gather({"rank": rank, "local_rank": R.local_rank, "device": torch.cuda.get_device_name(dev),
+                           "events": plan.n, "contrast": contrast})
 
-    # extra (outside the timed region): forward + backward of the objective, direct C-ABI calls
-    #   slab forward + variance -> tile-private backward (variance gradient folded in from the moments)
-    upstream = torch.full((1,), -1.0, dtype=torch.float32, device=dev)  # loss = -variance
-    d_flow = torch.empty((2, H, W), dtype=torch.float32, device=dev)
+    extras = {}
+    if not a.no_extras:
+        # (1) combine pass of the same step, timed the same way (outside `value`'s blocks)
+        _hip.check(lib.ebos_profile_start_kernel(_hip.PROFILE_SLAB_COMBINE, 100), "profile")
+        for _ in range(100):
+            step()
+        torch.cuda.synchronize()
+        buf = (ctypes.c_float * 100)()
+        got = lib.ebos_profile_stop(buf, 100)
+        comb = [buf[i] for i in range(got)]
+        extras["combine_kernel_ms"] = {"mean": round(statistics.mean(comb), 4), "min": round(min(comb), 4), "max": round(max(comb), 4)}
 
-    def step_fwd_bwd():
-        step()
-        _hip.check(lib.ebos_iwe_dense_tiled_bwd_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
-                                                    P(flow), H, W, args.tile[0], args.tile[1], args.halo, 0, 0, P(iwe), None,
-                                                    0, P(d_flow), None, P(moments), P(upstream), None, P(ws), nws,
-                                                    P(plan.part_table) if args.splits == 0 else None, stream), "ebos_iwe_dense_tiled_bwd")
+        # (2) forward + backward of the objective, direct C-ABI calls:
+        #     slab forward + variance -> tile-private backward (variance gradient folded in from the moments)
+        upstream = torch.full((1,), -1.0, dtype=torch.float32, device=dev)  # loss = -variance
+        d_flow = torch.empty((2, H, W), dtype=torch.float32, device=dev)
 
-    for _ in range(3):
-        step_fwd_bwd()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    reps = max(5, args.steps // 2)
-    for _ in range(reps):
-        step_fwd_bwd()
-    torch.cuda.synchronize()
-    fwdbwd_ms = (time.perf_counter() - t1) / reps * 1e3
+        def step_fwd_bwd():
+            step()
+            _hip.check(lib.ebos_iwe_dense_tiled_bwd_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
+                                                        P(flow), H, W, a.tile[0], a.tile[1], a.halo, 0, 0, P(iwe), None,
+                                                        0, P(d_flow), None, P(moments), P(upstream), None, P(ws), nws,
+                                                        P(plan.part_table) if a.splits == 0 else None, stream), "ebos_iwe_dense_tiled_bwd")
 
-    # Informative only (NOT `value`): independent evaluations -- hypotheses of a sweep, windows of a recording -- in flight on
-    # three HIP streams, each with its own workspace and outputs: the small combine / finalize kernels of one evaluation
-    # run in the wave slots the one-workgroup-per-CU accumulate kernel of another leaves free.
-    lanes = []
-    for _ in range(3):
-        lanes.append((torch.cuda.Stream(device=dev), torch.zeros(nws, dtype=torch.uint8, device=dev), torch.empty_like(iwe),
-                      torch.empty_like(out), torch.empty_like(moments)))
+        for _ in range(5):
+            step_fwd_bwd()
+        torch.cuda.synchronize()
+        reps = max(20, a.steps)
+        _hip.check(lib.ebos_profile_start_kernel(_hip.PROFILE_TILED_BWD, reps), "profile")
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            step_fwd_bwd()
+        torch.cuda.synchronize()
+        fwdbwd_ms = (time.perf_counter() - t1) / reps * 1e3
+        buf = (ctypes.c_float * reps)()
+        got = lib.ebos_profile_stop(buf, reps)
+        bwd_ms = [buf[i] for i in range(got)]
+        extras["fwd_bwd_ms"] = round(fwdbwd_ms, 4)
+        extras["fwd_bwd_mevents_per_s"] = round(n / fwdbwd_ms / 1e3, 2)
+        # SURVEY 8(d) backward: 12 B/event (p unused) + read dIWE 4 B/px + write dflow 8 B/px
+        extras["roofline_bwd"] = roofline_entry("iwe_dense_tiled_bwd_kernel", bwd_ms, 12.0 * plan.n + 12.0 * H * W)
 
-    def overlapped(count):
-        for k in range(count):
-            st, ws_k, iwe_k, out_k, mom_k = lanes[k % 3]
-            _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
-                                                   P(flow), H, W, args.tile[0], args.tile[1], args.halo, args.splits, 0, 0,
-                                                   P(ws_k), nws, P(iwe_k), 1, 0, P(out_k), P(mom_k), P(plan.part_table),
-                                                   st.cuda_stream), "ebos_iwe_dense_slab")
+        # (3) Informative only (NOT `value`): independent evaluations -- hypotheses of a sweep, windows of a recording -- in
+        # flight on three HIP streams, each with its own workspace and outputs
+        lanes = []
+        for _ in range(3):
+            lanes.append((torch.cuda.Stream(device=dev), torch.zeros(nws, dtype=torch.uint8, device=dev), torch.empty_like(iwe),
+                          torch.empty_like(out), torch.empty_like(moments)))
 
-    torch.cuda.synchronize()
-    overlapped(6)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    overlapped(3 * max(10, args.steps))
-    torch.cuda.synchronize()
-    overlapped_ms = (time.perf_counter() - t2) / (3 * max(10, args.steps)) * 1e3
+        def overlapped(count):
+            for k in range(count):
+                st, ws_k, iwe_k, out_k, mom_k = lanes[k % 3]
+                _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
+                                                       P(flow), H, W, a.tile[0], a.tile[1], a.halo, a.splits, 0, 0,
+                                                       P(ws_k), nws, P(iwe_k), 1, 0, P(out_k), P(mom_k), P(plan.part_table),
+                                                       st.cuda_stream), "ebos_iwe_dense_slab")
 
-    # Informative only: one Adam iteration of the patch-flow solver on the same window (BASELINE configs[3] shape: 30x40 patch grid
-    # -> 1280x720 flow, image_variance + flow_norm), the whole loop enqueued by one C call (ebos_cmax_patch_solve_f32)
-    solver_extra = None
-    if rank == 0:
-        try:
-            from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+        torch.cuda.synchronize()
+        overlapped(6)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        cnt = 3 * max(10, a.steps)
+        overlapped(cnt)
+        torch.cuda.synchronize()
+        overlapped_ms = (time.perf_counter() - t2) / cnt * 1e3
+        extras["independent_evaluations_on_3_streams"] = {"ms_per_evaluation": round(overlapped_ms, 4),
+                                                          "mevents_per_s": round(n / overlapped_ms / 1e3, 2),
+                                                          "note": "informative, not `value`: 3 evaluations in flight, own workspaces"}
+        del lanes
 
-            gh, gw = ebos.solver.patch_grid_shape((H, W), (24, 32), (24, 32))
-            sl = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, lr=0.1, capacity=260)
-            sl.run(10)
-            torch.cuda.synchronize()
-            t4 = time.perf_counter()
-            sl.run(200)
-            torch.cuda.synchronize()
-            solver_extra = {"us_per_iteration": round((time.perf_counter() - t4) / 200 * 1e6, 1), "events": plan.n,
-                            "patch_grid": [gh, gw], "objective": "image_variance + 0.001 flow_norm, Adam",
-                            "event_kernels_sample_the_patch_grid": bool(sl.sample_grid),
-                            "note": "informative, not `value`: forward + backward + Adam step per iteration"}
-            del sl
-        except Exception as err:  # the headline measurement must not depend on the solver layer
-            solver_extra = {"error": repr(err)}
+        # (4) cache-cold leg: distinct windows cycled so that the event stream of consecutive steps exceeds the 256 MiB
+        # Infinity Cache (FETCH_SIZE counts Infinity-Cache hits as memory traffic: the resident-window number above is
+        # measured in a cache-warm regime, this one streams from HBM)
+        nrot = max(2, a.rotating_windows)
+        rot = []
+        for k in range(nrot):
+            ev_k, fl_k = synth_window(n, seed=100 + k)
+            pk = ebos.EventPlan.build(torch.from_numpy(ev_k).to(dev), (H, W), "first", True, tile=tuple(a.tile))
+            # keep only what the kernel reads
+            rot.append((pk, torch.from_numpy(fl_k).float().to(dev)))
+            del ev_k, fl_k
+        rsteps = [make_step(pk, fk, compact_ptrs(pk)) for pk, fk in rot]
+        for s_ in rsteps:
+            s_()
+        torch.cuda.synchronize()
+        rounds = max(2, min(25, int(200 / nrot)))
+        _hip.check(lib.ebos_profile_start_kernel(_hip.PROFILE_SLAB_ACCUMULATE, rounds * nrot), "profile")
+        t3 = time.perf_counter()
+        for _ in range(rounds):
+            for s_ in rsteps:
+                s_()
+        torch.cuda.synchronize()
+        rot_ms = (time.perf_counter() - t3) / (rounds * nrot) * 1e3
+        buf = (ctypes.c_float * (rounds * nrot))()
+        got = lib.ebos_profile_stop(buf, rounds * nrot)
+        rk = [buf[i] for i in range(got)]
+        stream_bytes = sum((6.0 if pk.compact else 12.0) * pk.n + 8.0 * H * W for pk, _ in rot)
+        algo = 12.0 * n + 12.0 * H * W
+        extras["rotating_windows"] = {"n_windows": nrot, "bytes_streamed_per_cycle": stream_bytes,
+                                      "ms_per_step": round(rot_ms, 4), "mevents_per_s": round(n / rot_ms / 1e3, 2),
+                                      "kernel_ms": round(statistics.mean(rk), 4),
+                                      "achieved": round(algo / (statistics.mean(rk) * 1e-3) / 1e9, 1),
+                                      "frac": round(algo / (statistics.mean(rk) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "note": f"{nrot} distinct windows cycled ({stream_bytes / 2**20:.0f} MiB of plan + flow per cycle "
+                                              "> 256 MiB Infinity Cache): the HBM-streaming regime"}
+        del rot, rsteps
+
+        # (5) one Adam iteration of the patch-flow solver on the same window (BASELINE configs[3] shape)
+        if rank == 0:
+            try:
+                from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+                gh, gw = ebos.solver.patch_grid_shape((H, W), (24, 32), (24, 32))
+                sl = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, lr=0.1, capacity=260)
+                sl.run(10)
+                torch.cuda.synchronize()
+                t4 = time.perf_counter()
+                sl.run(200)
+                torch.cuda.synchronize()
+                extras["solver_iteration"] = {"us_per_iteration": round((time.perf_counter() - t4) / 200 * 1e6, 1), "events": plan.n,
+                                              "patch_grid": [gh, gw], "objective": "image_variance + 0.001 flow_norm, Adam",
+                                              "event_kernels_sample_the_patch_grid": bool(sl.sample_grid),
+                                              "note": "informative, not `value`: forward + backward + Adam step per iteration"}
+                del sl
+            except Exception as err:  # the headline measurement must not depend on the solver layer
+                extras["solver_iteration"] = {"error": repr(err)}
 
     # next to the nominal peak, a bandwidth this box actually delivers -- a device-to-device copy of 1 GiB
-    # (read + write bytes counted), best of 5
+    # (read + write bytes counted), best of 6
     a_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
     b_buf = torch.empty_like(a_buf)
     copy_gbs = 0.0
@@ -269,50 +540,210 @@ def main():
     del a_buf, b_buf
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * n * args.steps / elapsed / 1e6
+        ms_per_step = elapsed / a.steps * 1e3
+        value = world * n * a.steps / elapsed / 1e6
         # 12 B/event (x, y, dt; p unused) + flow read (8 B/px) + IWE write (4 B/px)
         algo_bytes = 12.0 * plan.n + 12.0 * H * W
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         format_bytes = bytes_per_event * plan.n + 12.0 * H * W  # what the plan format actually stores per event
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("iwe_slab_accumulate_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "Mevents/sec warped+IWE at 1280x720", "value": round(value, 2), "unit": "Mevents/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
-                                   "variance cost, fwd objective (tile accumulate + slab combine + variance)",
-                       "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
-                       "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if cptrs[0] else "SoA f32 (x,y,dt), 12 B/event")
-                                 + f", binned by source tile {args.tile[0]}x{args.tile[1]}, halo {args.halo}, splits {args.splits}", "parallelism": f"windows sharded, {world} rank(s), no collective"},
-            "roofline": {"bound": "hbm", "kernel": "iwe_slab_accumulate_kernel", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": algo_bytes,
-                         "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
-                         "plan_format_bytes": format_bytes,
-                         "plan_format_GBps": round(format_bytes / (kernel_ms * 1e-3) / 1e9, 1)},
-            "plan_build_ms": round(plan_build_ms, 2), "plan_build_first_call_ms": round(plan_first_ms, 2), "fwd_bwd_ms": round(fwdbwd_ms, 4),
-            "fwd_bwd_mevents_per_s": round(n / fwdbwd_ms / 1e3, 2), "contrast": contrast,
-            "independent_evaluations_on_3_streams": {"ms_per_evaluation": round(overlapped_ms, 4),
-                                                     "mevents_per_s": round(n / overlapped_ms / 1e3, 2),
-                                                     "note": "informative, not `value`: 3 evaluations in flight, own workspaces"},
-        }
-        if solver_extra is not None:
-            line["solver_iteration"] = solver_extra
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ev, flow_np, min(args.cpu_sample, n))
+        k_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
+        roof = roofline_entry("iwe_slab_accumulate_kernel", kernel_ms, algo_bytes,
+                              {"measured_copy_GBps": round(copy_gbs, 1),
+                               "frac_of_measured_copy": round(algo_bytes / (k_ms * 1e-3) / 1e9 / copy_gbs, 4),
+                               "plan_format_bytes": format_bytes,
+                               "plan_format_GBps": round(format_bytes / (k_ms * 1e-3) / 1e9, 1),
+                               "step_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        if "rotating_windows" in extras:
+            roof["frac_rotating_windows"] = extras["rotating_windows"]["frac"]
+        line = base_line(R, value, ms_per_step, blocks, "weak", {
+            "workload": "BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
+                        "variance cost, fwd objective (tile accumulate + slab combine + variance)",
+            "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
+            "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if cptrs[0] else "SoA f32 (x,y,dt), 12 B/event")
+                      + f", binned by source tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}, splits {a.splits}",
+            "parallelism": f"windows sharded, {world} rank(s), no collective"})
+        line["roofline"] = roof
+        line["ranks_seen"] = ranks_seen
+        line["plan_build_ms"] = round(plan_build_ms, 3)
+        line["plan_build_first_call_ms"] = round(plan_first_ms, 2)
+        # one evaluation of a FRESH window (BASELINE configs[1] read literally): plan build + one step
+        line["value_incl_plan_build"] = round(n / (plan_build_ms + ms_per_step) / 1e3, 2)
+        line["contrast"] = contrast
+        line.update(extras)
+        if world == 1 and not a.no_cpu_baseline:
+            sample = min(a.cpu_sample, n)
+            line["cpu_baseline"] = cpu_baseline(ev, flow_np, sample)
             line["speedup_vs_cpu_port_f64"] = round(value / line["cpu_baseline"]["value"], 1)
+            if sample < n:  # the same sample through the GPU path (outside the timed region)
+                ps = ebos.EventPlan.build(torch.from_numpy(ev[:sample]).to(dev), (H, W), "first", True, tile=tuple(a.tile))
+                make_step(ps, flow, compact_ptrs(ps))()
+                gpu_c = float(out.item())
+            else:
+                gpu_c = contrast
+            cpu_c = line["cpu_baseline"]["contrast_f64"]
+            line["contrast_cpu"] = cpu_c
+            line["contrast_gpu_same_sample"] = gpu_c
+            line["contrast_rel_err"] = abs(gpu_c - cpu_c) / abs(cpu_c)
         print(json.dumps(line))
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def run_config4(R):
+    """64 windows x 2 M events, 30x40 patch-flow grid, windows round-robin over the ranks."""
+    import numpy as np
+    import torch
+
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd import _hip
+    from event_based_bos_amd.event_plan import _workspace
+
+    a, dev, rank, world = R.args, R.dev, R.rank, R.world
+    lib = _hip.require_gpu()
+    n = a.events or CONFIG4["events"]
+    n_windows = a.windows or CONFIG4["windows"]
+    mine = shard_for(4, rank, world, a)
+    ph, pw = CONFIG4["patch"]
+    sh, sw = CONFIG4["slide"]
+    if a.tile[0] <= 0:
+        a.tile = list(ebos.event_plan.choose_tile((H, W), a.halo))
+    if not lib.ebos_patch_fused_supported(a.tile[0], a.tile[1], a.halo, sh, sw):
+        raise SystemExit(f"config 4 needs a tile the grid-sampling kernels support, got {a.tile} halo {a.halo}")
+    gh, gw = ebos.solver.patch_grid_shape((H, W), (ph, pw), (sh, sw))
+    stream = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    t0 = time.perf_counter()
+    plans, grids = [], []
+    for wi in mine:
+        ev, _ = synth_window(n, seed=wi, flow=False)
+        plans.append(ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile)))
+        grids.append(torch.from_numpy(np.random.RandomState(100 + wi).uniform(-FLOW_MAX, FLOW_MAX, (2, gh, gw))).float().to(dev))
+    torch.cuda.synchronize()
+    ingest_s = time.perf_counter() - t0
+    splits = 1
+    ws = _workspace(plans[0], (0, 0), a.halo, splits) if plans else None  # evaluations run back to back: one workspace
+    iwe = torch.empty((H, W), dtype=torch.float32, device=dev)
+    outs = torch.empty(max(len(mine), 1), dtype=torch.float32, device=dev)
+    moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
+
+    def step():
+        for k, (pl, g) in enumerate(zip(plans, grids)):
+            _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), gh, gw, ph, pw, sh, sw, H, W,
+                                                   a.tile[0], a.tile[1], a.halo, splits, 0, 0, P(ws), ws.numel(), P(iwe), 1, 0,
+                                                   outs.data_ptr() + 4 * k, P(moments), P(pl.part_table), stream),
+                       "ebos_iwe_patch_slab")
+
+    blocks, kernel_ms = R.timed_blocks(step, lib, _hip.PROFILE_SLAB_ACCUMULATE, launches_per_step=max(len(mine), 1), profile_blocks=1)
+    elapsed = statistics.median(blocks)
+    res = {int(wi): float(v) for wi, v in zip(mine, outs[:len(mine)].tolist())}
+    seen = R.gather({"rank": rank, "local_rank": R.local_rank, "device": torch.cuda.get_device_name(dev),
+                     "windows": len(mine), "events": int(sum(p.n for p in plans)), "contrasts": res})
+    if rank == 0:
+        total_events = n * n_windows
+        ms_per_step = elapsed / a.steps * 1e3
+        value = total_events * a.steps / elapsed / 1e6
+        algo = 12.0 * n + 4.0 * H * W + 8.0 * gh * gw  # per launch: events + IWE write + the patch grid (no dense flow field)
+        line = base_line(R, value, ms_per_step, blocks, "strong", {
+            "workload": f"BASELINE configs[3]: {n_windows} time windows x {n} events, {gh}x{gw} patch-flow grid "
+                        f"(patch {ph}x{pw}, slide {sh}x{sw}) -> 1280x720, variance cost, fwd objective per window",
+            "windows_total": n_windows, "events_per_window": n, "height": H, "width": W,
+            "layout": f"compact SoA 6 B/event, tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}; flow sampled from the patch grid per tile",
+            "parallelism": f"windows round-robin over {world} rank(s) (bos_event.py:144-220), no collective"})
+        line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<GRID>", kernel_ms, algo)
+        line["ranks_seen"] = [{k: v for k, v in s.items() if k != "contrasts"} for s in seen]
+        merged = {}
+        for s in seen:
+            merged.update(s["contrasts"])
+        line["windows_evaluated"] = len(merged)
+        line["contrast_first_windows"] = [merged[k] for k in sorted(merged)[:4]]
+        line["ingest_s_this_rank"] = round(ingest_s, 2)
+        print(json.dumps(line))
+
+
+def run_config5(R):
+    """512 2-DoF hypotheses over one 50 M-event window replicated on every rank, hypotheses in blocks."""
+    import numpy as np
+    import torch
+
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd import _hip
+
+    a, dev, rank, world = R.args, R.dev, R.rank, R.world
+    lib = _hip.require_gpu()
+    n = a.events or CONFIG5["events"]
+    g0, g1 = CONFIG5["grid"]
+    tm = CONFIG5["theta_max"]
+    # optuna grid sampler over [-30, 30) x [-30, 30) (generative_max_likelihood.py:238-255), 32 x 16 points
+    gx, gy = np.arange(-tm, tm, 2 * tm / g0), np.arange(-tm, tm, 2 * tm / g1)
+    grid = np.stack(np.meshgrid(gx, gy, indexing="ij"), -1).reshape(-1, 2)
+    mine = shard_for(5, rank, world, a)
+    if a.tile[0] <= 0:
+        a.tile = list(ebos.event_plan.choose_tile((H, W), a.halo))
+    ev, _ = synth_window(n, seed=0, flow=False)  # the SAME window on every rank
+    t0 = time.perf_counter()
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile))
+    torch.cuda.synchronize()
+    ingest_s = time.perf_counter() - t0
+    del ev
+    th = torch.from_numpy(grid[mine]).float().to(dev)
+    res = {}
+
+    def step():
+        res["v"] = plan.variance_2dof(th, chunk=8, halo=a.halo)
+
+    blocks, _ = R.timed_blocks(step, lib, _hip.PROFILE_SLAB_ACCUMULATE, launches_per_step=max(len(mine), 1), profile_blocks=0)
+    elapsed = statistics.median(blocks)
+    v = res["v"].cpu().numpy()
+    # roofline leg: the timed sweep keeps three hypotheses in flight on three streams, where a dispatch's begin-to-end time
+    # includes the time it shares the chip with its neighbours; the kernel is therefore timed on ONE stream, back to back
+    import ctypes
+    nrec = min(len(mine), 64)
+    _hip.check(lib.ebos_profile_start_kernel(_hip.PROFILE_SLAB_ACCUMULATE, nrec), "profile")
+    plan.variance_2dof(th[:nrec], chunk=8, halo=a.halo, n_streams=1)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_float * nrec)()
+    got = lib.ebos_profile_stop(buf, nrec)
+    kernel_ms = [buf[i] for i in range(got)]
+    seen = R.gather({"rank": rank, "local_rank": R.local_rank, "device": torch.cuda.get_device_name(dev),
+                     "hypotheses": len(mine), "events": plan.n,
+                     "variances": {int(k): float(x) for k, x in zip(mine, v)}})
+    if rank == 0:
+        K = grid.shape[0]
+        ms_per_step = elapsed / a.steps * 1e3
+        value = float(n) * K * a.steps / elapsed / 1e6  # event-warps per second, whole job
+        algo = 12.0 * plan.n + 4.0 * H * W  # per hypothesis launch: events + IWE write (theta is two floats)
+        line = base_line(R, value, ms_per_step, blocks, "strong", {
+            "workload": f"BASELINE configs[4]: {K}-hypothesis 2-DoF flow sweep ({g0}x{g1} grid over [-{tm:g},{tm:g})^2) over {n} events, "
+                        "1280x720, variance cost per hypothesis",
+            "hypotheses_total": K, "events": n, "height": H, "width": W,
+            "layout": f"compact SoA 6 B/event, tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}; event window replicated per rank",
+            "parallelism": f"hypotheses in contiguous blocks over {world} rank(s) (generative_max_likelihood.py:229-236), no collective"})
+        line["unit_note"] = "Mevents/s counts event-warps: every hypothesis warps and splats every event"
+        line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<UNIFORM>", kernel_ms, algo,
+                                          {"note": "kernel timed on one stream, back to back (the timed sweep overlaps three)",
+                                           "ms_per_hypothesis_in_sweep": round(ms_per_step / max(len(mine), 1), 5)})
+        line["ranks_seen"] = [{k: x for k, x in s.items() if k != "variances"} for s in seen]
+        merged = {}
+        for s in seen:
+            merged.update(s["variances"])
+        best = max(merged, key=merged.get)
+        line["hypotheses_evaluated"] = len(merged)
+        line["best_hypothesis"] = {"index": int(best), "theta": grid[best].tolist(), "variance": merged[best]}
+        line["ingest_s_this_rank"] = round(ingest_s, 2)
+        print(json.dumps(line))
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args, argv)  # before torch / HIP is touched in this process
+    if args.dry_run:
+        return dry_run(args)
+    R = Rank(args)
+    {2: run_config2, 4: run_config4, 5: run_config5}[args.config](R)
+    if R.distributed:
+        R.dist.barrier()
+        R.dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

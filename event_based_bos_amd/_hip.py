@@ -19,6 +19,7 @@ EBOS_OK = 0
 REF_FIRST, REF_LAST, REF_FRACTION, REF_TIMEBASE = 0, 1, 2, 3
 SPLAT_BILINEAR, SPLAT_COUNT, SPLAT_POLARITY = 0, 1, 2
 GAUSS_REFLECT_SCIPY, GAUSS_REFLECT_TORCH = 0, 1
+PROFILE_SLAB_ACCUMULATE, PROFILE_TILED_BWD, PROFILE_SLAB_COMBINE = 0, 1, 2
 ABI_VERSION = 1
 
 
@@ -44,6 +45,7 @@ _GAUSS = [_P, _P, _L, _L, _L, _P, _I, _I, _P]
 SIGNATURES = {
     "ebos_profile_start": (_I, [_I]),
     "ebos_profile_stop": (_I, [C.POINTER(C.c_float), _I]),
+    "ebos_profile_start_kernel": (_I, [_I, _I]),
     "ebos_version": (_I, []),
     "ebos_last_error": (C.c_char_p, []),
     "ebos_build_info": (C.c_char_p, []),

@@ -11,7 +11,8 @@ namespace ebos {
 constexpr int kWave = 64;  // CDNA wavefront width
 
 void set_error(const char* fmt, ...);
-bool profile_next_pair(hipEvent_t* start, hipEvent_t* stop);  // false unless ebos_profile_start() is active
+// false unless ebos_profile_start[_kernel]() is active for this launcher (`which`: ebos_profile_kernel)
+bool profile_next_pair(hipEvent_t* start, hipEvent_t* stop, int which = 0);
 
 #define EBOS_REQUIRE(cond, ...)                 \
   do {                                          \

@@ -22,6 +22,7 @@ void set_error(const char* fmt, ...) {
 // (hipExtLaunchKernelGGL start/stop events on the stream it launches on).  Off by default: zero cost.
 struct ProfileState {
   bool on = false;
+  int which = 0;  // ebos_profile_kernel: which launcher's dispatches are stamped
   std::vector<hipEvent_t> ev;  // pairs
   int used = 0;
 };
@@ -29,8 +30,8 @@ static ProfileState g_prof;
 
 // Next free (start, stop) event pair, or false when profiling is off / the pairs are used up.  The launcher hands the
 // pair to hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end timestamps.
-bool profile_next_pair(hipEvent_t* start, hipEvent_t* stop) {
-  if (!g_prof.on) return false;
+bool profile_next_pair(hipEvent_t* start, hipEvent_t* stop, int which) {
+  if (!g_prof.on || which != g_prof.which) return false;
   const int pairs = (int)g_prof.ev.size() / 2;
   if (g_prof.used >= pairs) return false;
   *start = g_prof.ev[2 * g_prof.used];
@@ -41,12 +42,14 @@ bool profile_next_pair(hipEvent_t* start, hipEvent_t* stop) {
 }  // namespace ebos
 
 extern "C" {
-int ebos_profile_start(int max_records) {
+int ebos_profile_start(int max_records) { return ebos_profile_start_kernel(EBOS_PROFILE_SLAB_ACCUMULATE, max_records); }
+int ebos_profile_start_kernel(int which, int max_records) {
   using namespace ebos;
-  if (max_records <= 0 || g_prof.on) {
-    set_error("ebos_profile_start: bad max_records or profiling already on");
+  if (max_records <= 0 || g_prof.on || which < 0 || which > EBOS_PROFILE_SLAB_COMBINE) {
+    set_error("ebos_profile_start: bad kernel selector / max_records, or profiling already on");
     return EBOS_ERR_INVALID_ARG;
   }
+  g_prof.which = which;
   g_prof.ev.resize(2 * (size_t)max_records);
   for (auto& e : g_prof.ev)
     if (hipEventCreate(&e) != hipSuccess) {

@@ -1457,7 +1457,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   }
   if (int rc = reserve_lds(ka, lds, "ebos_iwe_dense_slab")) return rc;
   hipEvent_t t0, t1;
-  if (profile_next_pair(&t0, &t1))  // bench.py's roofline leg: events stamped with this dispatch's begin / end
+  if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_ACCUMULATE))  // bench.py's roofline leg: events stamped with this dispatch's begin / end
     hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, L.tiles_x,
                           splits, pad_h, pad_w, slabs, spill, gs);
   else
@@ -1466,10 +1466,15 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   if (L.w % 4 == 0 && pad_w % 4 == 0) {
     dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows);
     nparts = (int64_t)gb.x * gb.y;
-    iwe_slab_combine4_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
-                                                                             pad_h, pad_w, iwe, omit ? 1 : 0,
-                                                                             want_var ? partials : nullptr,
-                                                                             splits == 0 ? ev.part_off : nullptr);
+    if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_COMBINE))
+      hipExtLaunchKernelGGL((iwe_slab_combine4_kernel<TH, TW, HALO>), gb, dim3(kCombineBlock), 0, s, t0, t1, 0, slabs, spill, L.tiles_y,
+                            L.tiles_x, splits, H, W, pad_h, pad_w, iwe, omit ? 1 : 0, want_var ? partials : nullptr,
+                            splits == 0 ? ev.part_off : nullptr);
+    else
+      iwe_slab_combine4_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
+                                                                               pad_h, pad_w, iwe, omit ? 1 : 0,
+                                                                               want_var ? partials : nullptr,
+                                                                               splits == 0 ? ev.part_off : nullptr);
   } else {
     dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
     nparts = (int64_t)gb.x * gb.y;
@@ -1522,9 +1527,15 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
       lds = grid_bwd_lds<TH, TW, HALO>();
       if (int rc = reserve_lds(kb, lds, "ebos_iwe_patch_tiled_bwd")) return rc;
       const unsigned grid = (unsigned)(tiles_y * tiles_x * (adaptive ? kAdaptiveItemsPerTile : 1));
-      kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr,
-                                               nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive, s_norm, s_tv,
-                                               reg_partials, mj);
+      hipEvent_t t0, t1;
+      if (profile_next_pair(&t0, &t1, EBOS_PROFILE_TILED_BWD))
+        hipExtLaunchKernelGGL(kb, dim3(grid), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image,
+                              affine, g_lo, (float*)nullptr, (float*)nullptr, (double*)nullptr, var_moments, upstream, addend, part_out,
+                              *grid_src, adaptive, s_norm, s_tv, reg_partials, mj);
+      else
+        kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr,
+                                                 nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive, s_norm, s_tv,
+                                                 reg_partials, mj);
       return EBOS_OK;
     } else {
       set_error("ebos_iwe_patch_tiled_bwd: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
@@ -1541,9 +1552,15 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
 #undef EBOS_PICK
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
   const unsigned grid = (unsigned)(tiles_y * tiles_x * (part_out ? kAdaptiveItemsPerTile : 1));
-  kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
-                                           partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0, 0.0f,
-                                           0.0f, nullptr, MomentsIn{});
+  hipEvent_t t0, t1;
+  if (profile_next_pair(&t0, &t1, EBOS_PROFILE_TILED_BWD))
+    hipExtLaunchKernelGGL(kb, dim3(grid), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine,
+                          g_lo, d_flow, d_weight, partials, var_moments, upstream, part_out ? (const float*)nullptr : addend, part_out,
+                          GridSrc{}, 0, 0.0f, 0.0f, (double*)nullptr, MomentsIn{});
+  else
+    kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
+                                             partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0, 0.0f,
+                                             0.0f, nullptr, MomentsIn{});
   if (part_out)
     bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
                                                                                                   addend, d_flow);

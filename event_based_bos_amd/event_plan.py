@@ -442,6 +442,14 @@ def _slab_ok(plan: EventPlan, halo) -> bool:
     return (plan.tile[0], plan.tile[1], int(halo)) in _SLAB_CONFIGS
 
 
+def _refuse_deferred(plan: EventPlan, what: str) -> None:
+    """A deferred plan keeps ``n`` as an upper bound and zero-fills the tail of its SoA arrays: only the tile-range
+    (slab / tiled) kernels skip that tail, the general kernels would read it as events at (0, 0)."""
+    if plan.__dict__.get("_deferred"):
+        raise NotImplementedError(f"{what}: a plan built with deferred=True only runs on the tile-private kernels "
+                                  "(a built tile / halo configuration); rebuild it with deferred=False for the general path")
+
+
 def _workspace(plan: EventPlan, pad, halo, splits) -> torch.Tensor:
     """Zero-filled once; the kernels keep the spill section zero between calls."""
     lib = _hip.require_gpu()
@@ -476,6 +484,7 @@ def _launch_iwe_dense(plan: EventPlan, flow32: torch.Tensor, weight, pad, halo, 
     H, W = plan.image_size
     if _slab_ok(plan, halo):
         return _launch_iwe_dense_slab(plan, flow32, weight, pad, halo, splits)[0]
+    _refuse_deferred(plan, "iwe_dense")
     iwe = torch.zeros((H + 2 * pad[0], W + 2 * pad[1]), dtype=torch.float32, device=plan.device)
     with torch.cuda.device(plan.device):
         if plan.binned and halo is not None:
@@ -521,6 +530,7 @@ def _launch_dense_bwd(plan, flow32, weight_p, pad, g_image, affine, g_lo, want_d
                                                    ptr(plan.part_table) if adaptive else None, stream_ptr()),
                   "ebos_iwe_dense_tiled_bwd")
         return d_flow, d_w
+    _refuse_deferred(plan, "iwe_dense backward")
     if var_moments is not None:  # general kernels take the affine form
         affine = torch.empty(2, dtype=torch.float32, device=plan.device)
         with torch.cuda.device(plan.device):
@@ -617,6 +627,7 @@ class _FusedIwe2Dof(torch.autograd.Function):
                                                  ptr(iwes), 0, 0, None, None, ptr(plan.part_table), stream_ptr()),
                       "ebos_iwe_2dof_slab")
             else:
+                _refuse_deferred(plan, "iwe_2dof")
                 iwes = torch.zeros((K, h, w), dtype=torch.float32, device=plan.device)
                 check(lib.ebos_iwe_2dof_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), ptr(wp), plan.n, ptr(th32), K, h, w,
                                             pad[0], pad[1], ptr(iwes), stream_ptr()), "ebos_iwe_2dof")

@@ -10,7 +10,12 @@ returned tensor with its provenance (source events, flow, reference-time mode). 
 checked through its version counter -- is handed to ``EventImageConverter`` with unit weight, the image is produced by
 ``EventPlan.iwe_dense`` (one pass over 6-12 B/event, autograd to the flow through the tile-private backward) instead
 of a 4-atomics-per-event splat of the materialised coordinates.  The plan (SoA conversion + counting sort) is cached
-on the identity and version of the caller's ``events`` tensor, so a solver loop pays for it once per window.
+per ``events`` tensor OBJECT (a weak reference, checked on every hit) and its version counter, so a solver loop pays
+for it once per window.  An address is not an identity: a per-window loop frees ``events`` and the caching allocator
+hands the same address (same shape, version 0) to a later window, so the entry dies with its tensor
+(``weakref.finalize``) and a hit requires ``entry.ref() is events``.  The flow's version counter is recorded too: a
+flow updated in place between ``warp_event`` and ``create_iwe`` (``optimizer.step()``, ``clamp_``) no longer matches
+the materialised coordinates, and the image is then splatted from those, like the reference.
 
 Policy (env ``EBOS_FUSE_API``): ``f32`` (default) fuses float32 inputs only -- the fused path computes in f32 and a
 float64 caller is given the float64 kernels it asked for; ``all`` also fuses float64 inputs (result cast back);
@@ -19,6 +24,7 @@ float64 caller is given the float64 kernels it asked for; ``all`` also fuses flo
 from __future__ import annotations
 
 import os
+import weakref
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -29,7 +35,7 @@ from .event_plan import EventPlan
 
 MAX_CACHED_PLANS = 4
 stats = {"plan_builds": 0, "plan_hits": 0, "fused_images": 0}
-_plans: "OrderedDict[tuple, EventPlan]" = OrderedDict()
+_plans: "OrderedDict[tuple, tuple]" = OrderedDict()  # key -> (weakref to the events tensor, plan)
 
 
 def policy() -> str:
@@ -47,6 +53,7 @@ class Provenance:
     normalize_t: bool
     image_size: Tuple[int, int]
     warped_version: int = 0
+    flow_version: int = 0
 
 
 def eligible(events: torch.Tensor, flow: torch.Tensor, image_size) -> bool:
@@ -60,6 +67,7 @@ def eligible(events: torch.Tensor, flow: torch.Tensor, image_size) -> bool:
 
 def tag(warped: torch.Tensor, prov: Provenance) -> torch.Tensor:
     prov.warped_version = warped._version
+    prov.flow_version = prov.flow._version
     warped._ebos_provenance = prov
     return warped
 
@@ -68,21 +76,28 @@ def provenance_of(warped) -> Optional[Provenance]:
     prov = getattr(warped, "_ebos_provenance", None)
     if prov is None or warped._version != prov.warped_version or prov.events._version != prov.events_version:
         return None  # the warped events (or their source) were modified in place since the warp
+    if prov.flow._version != prov.flow_version:
+        return None  # the flow was updated in place since the warp: `warped` holds the OLD flow's coordinates
     return prov
+
+
+def _evict(key) -> None:
+    _plans.pop(key, None)
 
 
 def plan_for(prov: Provenance) -> EventPlan:
     ev = prov.events
-    key = (ev.data_ptr(), tuple(ev.shape), ev.dtype, ev._version, ev.device.index, prov.ref_mode, prov.ref_fraction,
+    key = (id(ev), ev.data_ptr(), tuple(ev.shape), ev.dtype, ev._version, ev.device.index, prov.ref_mode, prov.ref_fraction,
            prov.normalize_t, tuple(prov.image_size))
-    plan = _plans.get(key)
-    if plan is not None:
+    entry = _plans.get(key)
+    if entry is not None and entry[0]() is ev:  # the very tensor object the plan was built from, still alive
         _plans.move_to_end(key)
         stats["plan_hits"] += 1
-        return plan
+        return entry[1]
     direction = {0: "first", 1: "last"}.get(prov.ref_mode, float(prov.ref_fraction))
     plan = EventPlan.build(ev.detach(), prov.image_size, direction, prov.normalize_t, tile="auto")
-    _plans[key] = plan
+    _plans[key] = (weakref.ref(ev), plan)
+    weakref.finalize(ev, _evict, key)  # the entry (and its device memory) goes when the caller drops the window
     stats["plan_builds"] += 1
     while len(_plans) > MAX_CACHED_PLANS:
         _plans.popitem(last=False)

@@ -43,11 +43,24 @@ def patch_grid_shape(image_size, patch_size, sliding_window):
     return gh, gw
 
 
-class ContrastMaximization(SolverBase):
-    def __init__(self, orig_image_shape, crop_image_shape, calibration_parameter=None, solver_config=None,
-                 visualize_module=None):
-        super().__init__(orig_image_shape, crop_image_shape, calibration_parameter, solver_config, visualize_module)
-        cfg = self.slv_config
+class ContrastMaximizationMixin(object):
+    """The CMax logic, independent of WHICH ``SolverBase`` it is composed over (``make_solver_class``): the build's
+    own (``solver/base.py``) or the reference's (``src/solver/base.py:54-378``, whose visualisation / flow-error methods the
+    driver calls, bos_event.py:202-219).  Needs from the base's constructor only ``slv_config`` and ``orig_image_shape``
+    (both bases set them, reference :72-83); everything else it uses is set up by ``_cmax_setup``."""
+
+    def _cmax_setup(self) -> None:
+        cfg = self.slv_config = dict(self.slv_config or {})
+        self.orig_image_shape = tuple(int(v) for v in self.orig_image_shape)
+        # attributes the build's SolverBase provides and the reference's does not (it calls the padding ``padding``, :74-76)
+        if not hasattr(self, "pad"):
+            self.pad = int(cfg.get("outer_padding", 0))
+        if not hasattr(self, "warp_direction"):
+            self.warp_direction = cfg.get("warp_direction", "first")
+        if not hasattr(self, "motion_model"):  # (the reference's visualize_one_batch_warp reads self.motion_model, :183)
+            self.motion_model = cfg.get("motion_model", "dense-flow")
+        if not hasattr(self, "previous_best"):
+            self.previous_best = None
         self.cost_with_weight: Dict[str, float] = dict(cfg.get("cost_with_weight") or {cfg.get("cost", "image_variance"): 1.0})
         self.contrast_terms = {k: w for k, w in self.cost_with_weight.items() if k in CONTRAST_COSTS}
         self.flow_terms = {k: w for k, w in self.cost_with_weight.items() if k not in CONTRAST_COSTS}
@@ -134,6 +147,12 @@ class ContrastMaximization(SolverBase):
             raise NotImplementedError(f"motion_model {self.motion_model!r}")
         return flow.detach().cpu().numpy().astype(np.float64)
 
+    def _warm_start(self):
+        """Warm start handed over by ``set_previous_frame_best_estimation`` -- the build's base stores it as
+        ``previous_best``, the reference's as ``previous_frame_best_estimation`` (src/solver/base.py:355-361)."""
+        prev = getattr(self, "previous_best", None)
+        return prev if prev is not None else getattr(self, "previous_frame_best_estimation", None)
+
     def plan_tile(self):
         """Source tile of the window plans: the configuration built for this solver's ``halo`` that fills the GPU best
         (``halo: 16`` -- windows whose displacements stay within ~16 px -- selects the smaller LDS windows)."""
@@ -173,8 +192,8 @@ class ContrastMaximization(SolverBase):
             gh, gw = patch_grid_shape((H, W), patch_size, sliding_window)
             if theta is not None:  # initialise from the coarser scale: resize(x0, patch_image_size), pyramid2.py:253-255
                 init = torch.nn.functional.interpolate(theta[None], size=(gh, gw), mode="bilinear", align_corners=False)[0]
-            elif self.previous_best is not None:
-                init = to_gpu(self.previous_best, device=plan.device, dtype=torch.float32).reshape(2, gh, gw)
+            elif self._warm_start() is not None:
+                init = to_gpu(self._warm_start(), device=plan.device, dtype=torch.float32).reshape(2, gh, gw)
             else:
                 init = torch.zeros((2, gh, gw), dtype=torch.float32, device=plan.device)
             mask = self.patch_mask(plan, patch_size, sliding_window)
@@ -330,3 +349,32 @@ class ContrastMaximization(SolverBase):
                 self.history.append(float(loss.detach()))
             theta = theta.detach()
         return theta
+
+
+def make_solver_class(base, name: str = "ContrastMaximization"):
+    """``ContrastMaximization`` composed over ``base`` (a ``SolverBase``): constructor signature of the plugin surface
+    (src/solver/base.py:64-71), ``estimate`` and the objective from the mixin, everything else -- ``preprocess``, the
+    imagers / warpers, and with the reference's base its ``visualize_*`` / ``calculate_flow_error`` /
+    ``save_flow_error_as_text`` -- from ``base``."""
+
+    def __init__(self, orig_image_shape, crop_image_shape, calibration_parameter=None, solver_config=None, visualize_module=None):
+        base.__init__(self, orig_image_shape, crop_image_shape, {} if calibration_parameter is None else calibration_parameter,
+                      {} if solver_config is None else solver_config, visualize_module)
+        self._cmax_setup()
+
+    return type(name, (ContrastMaximizationMixin, base), {"__init__": __init__, "__doc__": ContrastMaximizationMixin.__doc__,
+                                                          "__module__": __name__})
+
+
+ContrastMaximization = make_solver_class(SolverBase)
+
+
+def register_into(solver_module, names=("contrast_maximization", "cmax")):
+    """Add the CMax solver to ANOTHER solver registry -- the reference's ``src.solver`` -- built over THAT module's
+    ``SolverBase``, so that ``bos_event.py`` drives it unchanged: ``solver.collections[config["solver"]["method"]](...)``
+    (bos_event.py:330-337), ``solv.preprocess`` / ``solv.estimate`` (:190-194) and the visualisation / error methods
+    (:202-219) all resolve.  Returns the class."""
+    cls = make_solver_class(solver_module.SolverBase)
+    for n in names:
+        solver_module.collections[n] = cls
+    return cls

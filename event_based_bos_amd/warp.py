@@ -70,8 +70,10 @@ class Warp(object):
         calib_param ... stored, unused (as in the reference).
         strict (bool | None) ... raise IndexError when an event's source pixel is outside the flow field
             (torch.gather raises in the reference).  The check reads one counter back from the GPU, so
-            by default it is on for numpy / CPU inputs (which synchronise anyway) and off for GPU
-            tensors; EBOS_STRICT=1 forces it on.
+            by default it is immediate for numpy / CPU inputs (which synchronise anyway) and DEFERRED for GPU
+            tensors: the count stays on the device, comes back asynchronously and a later warp_event call (or
+            ``check_out_of_range()``) raises.  strict=True / EBOS_STRICT=1: immediate everywhere;
+            strict=False / EBOS_STRICT=0: never checked.
     """
 
     def __init__(self, image_size: tuple, calculate_feature: bool = False, normalize_t: bool = False,
@@ -80,6 +82,8 @@ class Warp(object):
         self.feature_2dof = FeatureCalculatorMock()
         self.feature_dense = FeatureCalculatorMock()
         self.strict = strict
+        # deferred out-of-range check of GPU-tensor calls: device counter per device, (page-locked copy, event, device) in flight
+        self._oob_dev, self._oob_pending, self._oob_calls = {}, [], 0
 
     def update_property(self, image_size: Optional[tuple] = None, calculate_feature: Optional[bool] = None,
                         normalize_t: Optional[bool] = None, calib_param: Optional[np.ndarray] = None):
@@ -166,6 +170,40 @@ class Warp(object):
             return self._warp_2dof(events, motion, ref_mode, frac, None, None)
         raise MotionModelKeyError(f"{motion_model = } not supported")
 
+    def _snapshot_oob(self, device) -> None:
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(self._oob_dev[device], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(device))
+        self._oob_pending.append((host, done, device))
+        del self._oob_pending[:-4]
+
+    def _raise_pending_oob(self, wait: bool = False) -> None:
+        keep, bad = [], 0
+        for host, done, device in self._oob_pending:
+            if wait:
+                done.synchronize()
+            if done.query():
+                bad = max(bad, int(host.item()))  # (snapshots of one running counter)
+            else:
+                keep.append((host, done, device))
+        self._oob_pending[:] = keep
+        if bad:
+            for c in self._oob_dev.values():
+                c.zero_()
+            self._oob_pending.clear()
+            raise IndexError(f"{bad} event(s) of earlier warp_event call(s) have a source pixel outside the flow field "
+                             f"(index out of range in gather, src/warp.py:334-336); they were left un-warped.  "
+                             f"Warp(..., strict=True) or EBOS_STRICT=1 raises at the call itself, EBOS_STRICT=0 disables the check")
+
+    def check_out_of_range(self) -> None:
+        """Wait for the out-of-range count of the GPU-tensor calls made so far and raise ``IndexError`` if any event had a
+        source pixel outside the flow field (the reference raises inside ``torch.gather``, src/warp.py:334-336; for GPU
+        tensors the check is deferred so that a solver loop does not synchronise on it)."""
+        for device in list(self._oob_dev):
+            self._snapshot_oob(device)
+        self._raise_pending_oob(wait=True)
+
     def _strict_for(self, kind: str) -> bool:
         if os.environ.get("EBOS_STRICT", "") == "1":
             return True
@@ -183,11 +221,25 @@ class Warp(object):
             ev, fl = ev[None], fl[None]
         assert ev.dim() == fl.dim() - 1 == 3  # same shape contract as :312
         strict = self._strict_for(kind)
+        lazy = (not strict) and self.strict is None and os.environ.get("EBOS_STRICT", "") != "0" \
+            and not torch.cuda.is_current_stream_capturing()
         oob = torch.zeros(1, dtype=torch.int32, device=ev.device) if strict else None
+        if lazy:
+            # GPU tensors: every call adds to one device-resident counter; every 16th call (and the first) sends it through
+            # page-locked memory behind the kernel, and a later call that finds such a read-back complete looks at it -- the
+            # loop never waits for the device.  check_out_of_range() is the blocking form.
+            self._raise_pending_oob()
+            oob = self._oob_dev.get(ev.device)
+            if oob is None:
+                oob = self._oob_dev[ev.device] = torch.zeros(1, dtype=torch.int32, device=ev.device)
         warped = ops.warp_dense(ev, fl, ref_mode, frac, self.normalize_t, int(self.image_size[1]), oob, timebase)
         if strict and int(oob.item()) > 0:
             raise IndexError(f"{int(oob.item())} event(s) have a source pixel outside the flow field "
                              f"(index out of range in gather, src/warp.py:334-336)")
+        if lazy:
+            self._oob_calls += 1
+            if self._oob_calls % 16 == 1:
+                self._snapshot_oob(ev.device)
         feat = self.feature_dense.calculate_feature(skip=not self.calculate_feature)
         return back(warped.squeeze(), kind), feat
 

@@ -68,6 +68,13 @@ typedef enum ebos_splat_mode {
  * off by default. */
 int ebos_profile_start(int max_records);
 int ebos_profile_stop(float* ms, int cap);
+/* The same for another kernel of the path (one selector active at a time): */
+typedef enum ebos_profile_kernel {
+  EBOS_PROFILE_SLAB_ACCUMULATE = 0, /* iwe_slab_accumulate_kernel (what ebos_profile_start selects)                    */
+  EBOS_PROFILE_TILED_BWD = 1,       /* iwe_dense_tiled_bwd_kernel of ebos_iwe_{dense,2dof,patch}_tiled_bwd_f32          */
+  EBOS_PROFILE_SLAB_COMBINE = 2     /* the slab combine pass (IWE assembly + variance) of ebos_iwe_*_slab_f32           */
+} ebos_profile_kernel;
+int ebos_profile_start_kernel(int which, int max_records);
 
 int ebos_version(void);               /* EBOS_ABI_VERSION of the loaded library */
 const char* ebos_last_error(void);    /* host string                            */

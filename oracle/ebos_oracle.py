@@ -9,10 +9,13 @@ never imports it: the product path is HIP-only and fails loudly without its exte
 Parity status: PINNED.  Every function below is checked against golden vectors captured
 from the reference itself (imported from /root/reference in the build container by
 ``tests/golden/make_golden.py``; fixtures committed under ``tests/golden/``) by
-``tests/test_oracle_golden.py``.  Two pieces have no runnable reference here and are
-pinned analytically only ("parity unpinned" for them): the torch 3-tap blur and the
-patch->dense upsample (both need torchvision, absent from the image) -- see the
-docstrings of ``gaussian_blur3_torch`` and ``upsample_patch_flow``.
+``tests/test_oracle_golden.py``.  Two pieces call torchvision, which is absent from the
+image: the torch 3-tap blur and the patch->dense upsample.  For them the REFERENCE'S OWN
+functions were run with only ``torchvision...resize`` / ``gaussian_blur`` shimmed by torch
+primitives (``make_golden.py --upsample`` -> ``golden_upsample.npz``, labelled shimmed):
+the arithmetic around those two calls is pinned, their insides are not ("shimmed" parity,
+short of full) -- see ``gaussian_blur3_torch`` and ``upsample_patch_flow``.  The raw-column
+loader restatement (``events_from_raw_columns``) stays "parity unpinned" (needs h5py).
 
 Conventions (reference src/data_loader/ccs.py:293-296, src/warp.py:334):
   event = (x, y, t, p);  x = ROW (height) coordinate, y = COLUMN (width) coordinate;
@@ -279,8 +282,11 @@ def create_image_numpy(events: np.ndarray, image_size, pad=(0, 0), method="bilin
 
 
 def gaussian_blur3_torch(img: torch.Tensor, sigma: float) -> torch.Tensor:
-    """torchvision ``gaussian_blur(img, kernel_size=3, sigma)`` restated (PARITY UNPINNED:
-    torchvision is absent here).  Published algorithm (torchvision 0.13
+    """torchvision ``gaussian_blur(img, kernel_size=3, sigma)`` restated.  torchvision is absent from the image, so the
+    reference's call site (src/event_image_converter.py:394-405) was run with that one function SHIMMED
+    (tests/golden/make_golden.py --upsample -> golden_upsample.npz, tests/test_oracle_golden.py): the surrounding reshapes,
+    kernel_size = 3 and the squeeze are pinned, the inside of gaussian_blur is this restatement on both sides ("shimmed",
+    not full parity).  Published algorithm (torchvision 0.13
     transforms/functional_tensor.py ``_get_gaussian_kernel1d``/``gaussian_blur``): taps
     ``exp(-0.5 (x/sigma)^2)`` at x = -1,0,1, normalised to sum 1; separable; reflect pad 1.
     Call site: src/event_image_converter.py:399-404.  img [..., H, W]."""
@@ -401,8 +407,11 @@ def patch_grid_shape(image_size, patch_size, sliding_window) -> Tuple[int, int]:
 def upsample_patch_flow(patch_flow: torch.Tensor, image_size, patch_size, sliding_window) -> torch.Tensor:
     """src/solver/patch_eklt.py:173-204 with torchvision ``resize(bilinear)`` restated as
     ``F.interpolate(mode='bilinear', align_corners=False)`` (what torchvision 0.13 calls for
-    tensors; antialias off).  PARITY UNPINNED against the reference (torchvision absent);
-    pinned analytically in tests (constant field, linear ramp interior)."""
+    tensors; antialias only acts when down-sampling).  Pinned against the reference's own function run with ONLY ``resize``
+    shimmed to F.interpolate (torchvision is absent; tests/golden/make_golden.py --upsample -> golden_upsample.npz, six
+    geometries incl. overlapping windows and non-divisible sizes, agreement 1e-13): the pad / target-size / centre-crop
+    arithmetic is the reference's, the inside of ``resize`` is "shimmed".  Also pinned analytically (constant field,
+    linear ramp interior)."""
     gh, gw = patch_flow.shape[-2:]
     pad_h = int(patch_size[0] / 2 // sliding_window[0]) + 1
     pad_w = int(patch_size[1] / 2 // sliding_window[1]) + 1

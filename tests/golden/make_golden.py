@@ -136,9 +136,160 @@ def make_patches():
     print("golden_patches.npz:", len(out), "arrays")
 
 
+def install_torchvision_shim():
+    """torchvision is absent from the image (and there is no network to install it): the two torchvision functions the
+    reference calls on this path are SHIMMED with torch primitives, so that the reference's OWN code around them (pad
+    arithmetic, resize target size, centre crop -- src/solver/patch_eklt.py:173-204; the [None, None] / squeeze handling and
+    kernel_size of src/event_image_converter.py:394-405) runs and is pinned.  What stays un-pinned is the inside of the two
+    shimmed functions themselves; the fixtures carry ``shimmed = 1`` to say so.
+
+      resize(img, size, interpolation=BILINEAR)  ->  F.interpolate(img[None], size, mode="bilinear", align_corners=False)[0]
+          (what torchvision's tensor path calls; its antialias flag only acts when DOWN-sampling, the path up-samples)
+      gaussian_blur(img, kernel_size=3, sigma)   ->  taps exp(-x^2 / (2 sigma^2)) at x = -1, 0, 1, normalised, outer product,
+          reflect padding 1, depth-wise conv2d (torchvision's published _get_gaussian_kernel1d / gaussian_blur)"""
+    import torch.nn.functional as F
+
+    def resize(img, size, interpolation=None, max_size=None, antialias=None):
+        assert img.dim() == 3 and (interpolation is None or str(interpolation).lower().endswith("bilinear"))
+        return F.interpolate(img[None], size=list(size), mode="bilinear", align_corners=False)[0]
+
+    def gaussian_blur(img, kernel_size, sigma=None):
+        ks = [kernel_size, kernel_size] if isinstance(kernel_size, int) else list(kernel_size)
+        sg = [float(sigma), float(sigma)] if not isinstance(sigma, (list, tuple)) else [float(v) for v in sigma]
+        ker = []
+        for k, sd in zip(ks, sg):
+            half = (k - 1) * 0.5
+            x = torch.linspace(-half, half, steps=k, dtype=img.dtype)
+            pdf = torch.exp(-0.5 * (x / sd) ** 2)
+            ker.append(pdf / pdf.sum())
+        k2 = ker[1][:, None] * ker[0][None, :]   # (y taps) x (x taps)
+        lead = img.shape[:-2]
+        x = img.reshape(-1, 1, *img.shape[-2:])
+        x = F.pad(x, (ks[0] // 2, ks[0] // 2, ks[1] // 2, ks[1] // 2), mode="reflect")
+        return F.conv2d(x, k2[None, None]).reshape(*lead, *img.shape[-2:])
+
+    class InterpolationMode(object):
+        BILINEAR = "bilinear"
+
+    tv = types.ModuleType("torchvision")
+    tr = types.ModuleType("torchvision.transforms")
+    fn = types.ModuleType("torchvision.transforms.functional")
+    fn.resize, fn.gaussian_blur, fn.InterpolationMode = resize, gaussian_blur, InterpolationMode
+    tr.functional, tr.InterpolationMode = fn, InterpolationMode
+    tv.transforms = tr
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.transforms.functional": fn})
+    return fn
+
+
+def make_upsample():
+    """golden_upsample.npz (SHIMMED, see install_torchvision_shim): the reference's
+    ``PatchEklt.interpolate_dense_flow_from_patch_tensor`` (src/solver/patch_eklt.py:173-204) on seeded patch grids --
+    BASELINE's (30, 40) -> 720x1280, an overlapping-window case, non-divisible sizes, a 1x1 grid -- and
+    ``EventImageConverter.create_image_from_events_tensor(..., sigma in {1, 3})`` (src/event_image_converter.py:372-405),
+    un-batched and batched."""
+    fn = install_torchvision_shim()
+    import_reference()
+    for n in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"):  # import_reference re-stubs them
+        pass
+    install_torchvision_shim()
+    import src.event_image_converter as ref_eic
+    from src.solver import patch_eklt as ref_pe
+
+    ref_pe.transforms = sys.modules["torchvision.transforms"]          # the names the reference module bound at import
+    ref_eic.gaussian_blur = fn.gaussian_blur                           # (its own import was swallowed: ImportError, :12-17)
+    out = {"shimmed": np.array(1)}
+    cases = [((720, 1280), (24, 32), (24, 32)),    # BASELINE configs[3]: grid (30, 40)
+             ((128, 160), (32, 32), (16, 16)),     # overlapping windows: pad 2
+             ((100, 150), (24, 32), (24, 32)),     # sizes that are no multiple of the sliding window
+             ((90, 121), (30, 40), (15, 27)),      # everything odd
+             ((64, 64), (64, 64), (64, 64)),       # a 1 x 1 grid
+             ((60, 80), (10, 16), (5, 4))]         # patch / 2 // slide > 1: pad 2 x 3
+    for k, (size, patch, slide) in enumerate(cases):
+        _, shape = ref_pe.PatchEklt.prepare_patch(None, size, patch, slide)
+        ns = types.SimpleNamespace(patch_size=patch, sliding_window=slide, patch_image_size=tuple(shape), n_pixel_downsample=1,
+                                   orig_image_shape=size)
+        grid = np.random.RandomState(500 + k).uniform(-30, 30, (2,) + tuple(shape))
+        dense = ref_pe.PatchEklt.interpolate_dense_flow_from_patch_tensor(ns, torch.from_numpy(grid.reshape(-1))).numpy()
+        tag = f"u{k}"
+        out[tag + "_cfg"] = np.array([*size, *patch, *slide])
+        out[tag + "_grid"] = grid
+        out[tag + "_shape"] = np.array(dense.shape)
+        if dense.size <= 100_000:
+            out[tag + "_dense"] = dense
+        else:   # the 1280x720 field is 14.7 MB in fp64: keep strided samples, border lines and sums (a fixture is small data)
+            out[tag + "_dense_stride"] = dense[:, ::7, ::11].copy()
+            out[tag + "_dense_rows"] = dense[:, [0, 1, 23, 24, 359, 695, 696, 718, 719], :].copy()
+            out[tag + "_dense_cols"] = dense[:, :, [0, 1, 31, 32, 640, 1247, 1248, 1278, 1279]].copy()
+            out[tag + "_dense_rowsum"] = dense.sum(2)
+            out[tag + "_dense_colsum"] = dense.sum(1)
+        print(tag, size, patch, slide, "grid", shape, "->", dense.shape)
+    # tensor blur: un-batched and batched, sigma 1 and 3 (kernel_size stays 3: src/event_image_converter.py:404)
+    H, W, N = 24, 32, 2000
+    e2 = synth_events(N, H, W, seed=10)
+    e2[:, 0] += np.random.RandomState(11).uniform(0, 0.999, N) * (np.arange(N) % 3 == 0)
+    eb = np.stack([e2, synth_events(N, H, W, seed=20)])
+    out["b_events"], out["b_events_batched"] = e2, eb
+    for pad in (0, 2):
+        ic = ref_eic.EventImageConverter((H, W), outer_padding=pad)
+        for sigma in (1, 3):
+            out[f"b_p{pad}_s{sigma}"] = ic.create_image_from_events_tensor(torch.from_numpy(e2), "bilinear_vote", sigma=sigma).numpy()
+            out[f"b_p{pad}_s{sigma}_batched"] = ic.create_image_from_events_tensor(torch.from_numpy(eb), "bilinear_vote",
+                                                                                  sigma=sigma).numpy()
+            out[f"b_p{pad}_s{sigma}_f32"] = ic.create_image_from_events_tensor(torch.from_numpy(e2).float(), "bilinear_vote",
+                                                                              sigma=sigma).numpy()
+    out["b_create_iwe_default"] = ref_eic.EventImageConverter((H, W)).create_iwe(torch.from_numpy(e2)).numpy()  # sigma = 1 (:55)
+    np.savez_compressed(os.path.join(HERE, "golden_upsample.npz"), **out)
+    print("golden_upsample.npz:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "golden_upsample.npz")) // 1024, "KiB")
+
+
+def public_surface(cls):
+    """{method name: str(inspect.signature)} of the public callables a class defines or inherits (object's own excluded),
+    plus ``__init__``."""
+    import inspect
+
+    out = {}
+    for name, member in inspect.getmembers(cls):
+        if name != "__init__" and name.startswith("_"):
+            continue
+        if callable(member) and not isinstance(member, type):
+            try:
+                out[name] = str(inspect.signature(member))
+            except (TypeError, ValueError):
+                pass
+    return out
+
+
+def make_signatures():
+    """signatures.json: the plugin surface of the reference as data -- ``inspect.signature`` of every public method of
+    ``Warp``, ``EventImageConverter``, ``CostBase``, ``HybridCost``, every registered cost and ``SolverBase``, plus the
+    registries' keys and class attributes (``name``, ``required_keys``).  tests/test_surface.py compares the build's classes
+    with it (and checks that the solver composed over a base with exactly these methods exposes all of them)."""
+    import json
+
+    Warp, EIC, _, costs = import_reference()
+    import src.solver as rsolver
+
+    sig = {"Warp": public_surface(Warp), "EventImageConverter": public_surface(EIC), "CostBase": public_surface(costs.CostBase),
+           "HybridCost": public_surface(costs.HybridCost), "SolverBase": public_surface(rsolver.SolverBase),
+           "costs.functions": {k: {"methods": public_surface(v), "name": v.name, "required_keys": list(v.required_keys)}
+                               for k, v in sorted(costs.functions.items())},
+           "solver.collections": sorted(rsolver.collections),
+           "driver_calls_on_solver": ["preprocess", "estimate", "visualize_original_sequential", "visualize_flows",
+                                      "visualize_pred_sequential", "visualize_gt_sequential", "calculate_flow_error",
+                                      "save_flow_error_as_text"],   # bos_event.py:190-219
+           "driver_reads_on_solver": ["sequential_video_list", "evaluation_text_list", "visualizer", "orig_imager"]}
+    with open(os.path.join(HERE, "signatures.json"), "w") as f:
+        json.dump(sig, f, indent=1, sort_keys=True)
+    print("signatures.json:", {k: len(v) for k, v in sig.items()})
+
+
 def main():
     if "--patches" in sys.argv:   # the other fixtures stay byte-identical
         return make_patches()
+    if "--signatures" in sys.argv:
+        return make_signatures()
+    if "--upsample" in sys.argv:
+        return make_upsample()
     Warp, EIC, SobelTorch, costs = import_reference()
     out = {}
 

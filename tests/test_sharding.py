@@ -67,3 +67,42 @@ def test_sharded_equals_single_process(tmp_path):
 
 def test_gather_detects_duplicates():
     assert gather_results({0: 1.0, 2: 3.0}) == {0: 1.0, 2: 3.0}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N: the launcher itself (no kernels: --dry-run uses gloo on the CPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench(*flags, env=None):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected from rank 0, got {len(lines)}: {r.stdout[-500:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config,total,per_rank", [(2, 2, [[0], [1]]), (4, 64, [[0, 2, 4, 6], [1, 3, 5, 7]]),
+                                                   (5, 512, [[0, 1, 2, 3], [256, 257, 258, 259]])])
+def test_bench_gpus_flag_launches_the_ranks_itself(config, total, per_rank):
+    """`python bench.py --gpus 2` with no launcher environment must start two ranks by itself (torch.distributed.run as a
+    child process), shard the units as DESIGN section 7 says, and relay ONE line from rank 0."""
+    line = _bench("--gpus", "2", "--config", str(config), "--dry-run")
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["config"] == config
+    seen = sorted(line["ranks_seen"], key=lambda s: s["rank"])
+    assert [s["rank"] for s in seen] == [0, 1] and [s["local_rank"] for s in seen] == [0, 1]
+    assert line["units_total"] == total
+    assert [s["first_units"] for s in seen] == per_rank
+    assert abs(line["max_over_ranks_check"] - 0.002) < 1e-12  # the MAX over ranks took rank 1's value
+
+
+def test_bench_single_rank_needs_no_launcher():
+    line = _bench("--dry-run")
+    assert line["n_gpus"] == 1 and [s["rank"] for s in line["ranks_seen"]] == [0] and line["steps"] == 200 and line["warmup"] == 20
