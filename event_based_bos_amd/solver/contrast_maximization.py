@@ -94,7 +94,7 @@ class ContrastMaximizationMixin(object):
         self.lr = float((ocfg.get("parameters") or {}).get("lr", 0.05))
         self.scipy_options = dict(ocfg.get("options") or {})
         self.refine_iters = int(ocfg.get("refine_iters", 0))  # 2-DoF models: Adam steps after the grid sweep
-        self.param_ranges = cfg.get("parameters") or {}
+        self.param_ranges = cfg.get("parameters") or {}  # {name: {min, max}} or the reference's list of names (_param_range)
         self.halo = int(cfg.get("halo", 32))
         # optimizer.graph: capture one whole iteration (upsample -> fused objective -> backward -> Adam update) into a
         # HIP graph and replay it.  Measured on MI355X / ROCm 7.2 (tools/bench_solver.py, 2 M events at 1280x720):
@@ -326,9 +326,45 @@ class ContrastMaximizationMixin(object):
             self.graphed = False
             return 0
 
+    def _param_range(self, key: str) -> Dict[str, float]:
+        """{min, max} of a motion parameter: ``parameters: {trans_x: {min, max}}`` (this solver's YAMLs) or -- when
+        ``parameters`` is the reference's LIST of parameter names (configs/hot_plate1.yaml:48-50) -- the sampler ranges of
+        ``optimizer.parameters`` (:71-80), default +-30 px."""
+        rng = self.param_ranges.get(key) if isinstance(self.param_ranges, dict) else None
+        if rng is None:
+            rng = ((self.slv_config.get("optimizer") or {}).get("parameters") or {}).get(key)
+        return rng if isinstance(rng, dict) and "min" in rng and "max" in rng else {"min": -30.0, "max": 30.0}
+
+    def _translation_loss(self, plan: EventPlan, theta: torch.Tensor) -> torch.Tensor:
+        """-contrast of the IWE under the translation ``theta`` [2] (autograd through the 2-DoF tile-private kernels)."""
+        iwe = plan.iwe_2dof(theta[None], pad=(self.pad, self.pad), halo=self.halo)[0]
+        if self.blur_sigma > 0:
+            iwe = EventImageConverter._gaussian_blur3(iwe, self.blur_sigma)
+        total = 0.0
+        for name, wgt in self.contrast_terms.items():
+            fn = ops.image_variance if name == "image_variance" else ops.gradient_magnitude
+            total = total + wgt * fn(iwe, self.omit_boundary)
+        return -total
+
     def _estimate_translation(self, plan: EventPlan) -> torch.Tensor:
-        rx = self.param_ranges.get("trans_x") or {"min": -30.0, "max": 30.0}
-        ry = self.param_ranges.get("trans_y") or {"min": -30.0, "max": 30.0}
+        """``optimizer.method: grid`` -- exhaustive sweep over the parameter ranges (the optuna grid sampler of
+        src/solver/generative_max_likelihood.py:238-255), optionally refined by ``refine_iters`` Adam steps;
+        ``Adam`` -- n_iter Adam steps on (trans_x, trans_y) from the warm start (or zero), the loop shape of :306-341."""
+        if self.opt_method == "Adam":
+            start = self._warm_start()
+            theta = (torch.zeros(2, dtype=torch.float32, device=plan.device) if start is None else
+                     to_gpu(start, device=plan.device, dtype=torch.float32).reshape(2)).clone().requires_grad_(True)
+            opt = torch.optim.Adam([theta], lr=self.lr)
+            for _ in range(self.n_iter):
+                opt.zero_grad(set_to_none=True)
+                loss = self._translation_loss(plan, theta)
+                loss.backward()
+                opt.step()
+                self.history.append(float(loss.detach()))
+            return theta.detach()
+        if self.opt_method not in ("grid", "sweep"):
+            raise NotImplementedError(f"optimizer.method {self.opt_method!r} for a 2-DoF motion model: Adam or grid")
+        rx, ry = self._param_range("trans_x"), self._param_range("trans_y")
         n = max(2, int(round(np.sqrt(max(self.n_iter, 4)))))
         gx = torch.arange(n, dtype=torch.float32) * ((rx["max"] - rx["min"]) / n) + rx["min"]  # np.arange(min, max, step), :238-255
         gy = torch.arange(n, dtype=torch.float32) * ((ry["max"] - ry["min"]) / n) + ry["min"]
@@ -342,8 +378,7 @@ class ContrastMaximizationMixin(object):
             opt = torch.optim.Adam([theta], lr=self.lr)
             for _ in range(self.refine_iters):
                 opt.zero_grad(set_to_none=True)
-                iwe = plan.iwe_2dof(theta[None], pad=(self.pad, self.pad), halo=self.halo)[0]
-                loss = -ops.image_variance(iwe, self.omit_boundary)
+                loss = self._translation_loss(plan, theta)
                 loss.backward()
                 opt.step()
                 self.history.append(float(loss.detach()))

@@ -253,9 +253,12 @@ def public_surface(cls):
             continue
         if callable(member) and not isinstance(member, type):
             try:
-                out[name] = str(inspect.signature(member))
+                sig = inspect.signature(member)
             except (TypeError, ValueError):
-                pass
+                continue
+            out[name] = {"signature": str(sig),
+                         "params": [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                                    for p in sig.parameters.values()]}
     return out
 
 
@@ -283,9 +286,36 @@ def make_signatures():
     print("signatures.json:", {k: len(v) for k, v in sig.items()})
 
 
+def make_config():
+    """config_hot_plate1.json: the reference's configs/hot_plate1.yaml as PARSED data (``input``) and what the reference's
+    own ``propagate_config`` (src/utils/config_utils.py:42-88) makes of it (``propagated``) -- BASELINE configs[0] declares this
+    file as its input; pins ``event_based_bos_amd.utils.propagate_config`` and feeds tools/run_cmax.py on the GPU box."""
+    import copy
+    import json
+
+    import yaml
+
+    import_reference()
+    spec = importlib.util.spec_from_file_location("ref_config_utils", f"{REF}/src/utils/config_utils.py")
+    sys.modules.setdefault("src.utils.misc", types.ModuleType("src.utils.misc")).fetch_runtime_information = lambda: {}
+    cu = importlib.util.module_from_spec(spec)
+    cu.__package__ = "src.utils"
+    spec.loader.exec_module(cu)
+    with open(f"{REF}/configs/hot_plate1.yaml") as f:
+        cfg = yaml.safe_load(f)
+    out = {"source": "configs/hot_plate1.yaml of the reference, parsed with yaml.safe_load", "input": copy.deepcopy(cfg)}
+    cu.propagate_config(cfg)
+    out["propagated"] = cfg
+    with open(os.path.join(HERE, "config_hot_plate1.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("config_hot_plate1.json: solver keys", sorted(cfg["solver"]))
+
+
 def main():
     if "--patches" in sys.argv:   # the other fixtures stay byte-identical
         return make_patches()
+    if "--config" in sys.argv:
+        return make_config()
     if "--signatures" in sys.argv:
         return make_signatures()
     if "--upsample" in sys.argv:

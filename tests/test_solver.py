@@ -240,6 +240,63 @@ def test_yaml_driven_run_improves_contrast():
     assert rep["variance_warped"] > 1.3 * rep["variance_unwarped"], rep
 
 
+def test_propagate_config_equals_the_reference_on_its_own_yaml():
+    """tests/golden/config_hot_plate1.json holds the reference's configs/hot_plate1.yaml as parsed data and what the
+    reference's propagate_config (src/utils/config_utils.py:42-88) makes of it: same result, key for key."""
+    import copy
+    import json
+
+    import event_based_bos_amd as ebos
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "config_hot_plate1.json")))
+    cfg = copy.deepcopy(fx["input"])
+    assert ebos.utils.propagate_config(cfg) is cfg and cfg == fx["propagated"]
+    assert (cfg["data"]["height"], cfg["data"]["width"]) == (720, 1280)                          # :5-6
+    assert cfg["solver"]["filter"]["parameters"]["ymin"] == 320 and cfg["data"]["crop_width"] == 640  # :23-26
+    # the solver reads it: ROI from the propagated filter parameters, n_iter / method / blur from :46-70, the LIST form of
+    # `parameters` (:48-50) with the sampler ranges of optimizer.parameters
+    scfg = dict(cfg["solver"], method="contrast_maximization", cost_with_weight={"image_variance": 1.0})
+    s = ebos.solver.collections["contrast_maximization"]((720, 1280), (720, 640), solver_config=scfg)
+    assert s.roi == (0, 720, 320, 960) and s.motion_model == "2d-translation" and s.warp_direction == "first"
+    assert (s.opt_method, s.n_iter, s.blur_sigma, s.pad) == ("Adam", 600, 3.0, 0)
+    assert s._param_range("trans_x") == {"min": -30.0, "max": 30.0} and s._param_range("p_x") == {"min": -0.4, "max": 0.4}
+    # a config without the optional sections propagates too (the reference would raise KeyError on solver.filter)
+    small = {"data": {"height": 260, "width": 346}, "common_params": {"xmin": 0, "xmax": 260, "ymin": 0, "ymax": 346}, "solver": {}}
+    ebos.utils.propagate_config(small)
+    assert small["solver"]["filter"]["parameters"] == {"xmin": 0, "xmax": 260, "ymin": 0, "ymax": 346}
+    assert small["solver"]["crop_height"] == 260 and small["params_openpiv"]["pad_y1"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [None, (260, 346)])
+def test_reference_hot_plate1_config_drives_the_solver(size):
+    """BASELINE configs[0]: the reference's configs/hot_plate1.yaml (fixture: parsed data), consumed key for key by
+    tools/run_cmax.py with the driver protocol of bos_event.py:190-194 -- at 720x1280 with the region of interest as the file
+    declares it, and at the 346x260 override.  2d-translation + Adam x 600 + blur_sigma 3 come from the file; the recovered
+    translation must be the scene's (3, -2) px within 0.75 px and sharpen the IWE."""
+    import json
+    import subprocess
+    import sys
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_cmax.py"), "--config_file",
+           os.path.join(ROOT, "tests", "golden", "config_hot_plate1.json")]
+    if size:
+        cmd += ["--height", str(size[0]), "--width", str(size[1])]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    print(rep)
+    assert rep["overrides"]["solver.method"] == ["patch_eklt_pyramid2", "contrast_maximization"]
+    assert rep["image"] == list(size or (720, 1280)) and rep["crop"] == list(size or (720, 640))
+    assert rep["roi"] == ([0, size[0], 0, size[1]] if size else [0, 720, 320, 960])
+    assert (rep["motion_model"], rep["optimizer"], rep["iterations"], rep["blur_sigma"]) == ("2d-translation", "Adam", 600, 3.0)
+    assert rep["events"] <= rep["events_in"] and (size is not None or rep["events"] < 0.6 * rep["events_in"])  # ROI = half the columns
+    assert rep["loss_last"] < rep["loss_first"] and rep["variance_warped"] > 1.3 * rep["variance_unwarped"], rep
+    # estimate() returns the dense flow -theta (src/warp.py:186-187) = the scene's displacement: (3, -2) px plus a bump of up to
+    # (6, -3) px in the middle of the frame
+    assert 2.5 < rep["flow_mean_in_roi"][0] < 6.5 and -4.0 < rep["flow_mean_in_roi"][1] < -1.5, rep
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_concurrent,pyramid", [(1, False), (2, False), (3, True)])
 def test_window_pipeline_matches_per_window_estimates(n_concurrent, pyramid):
