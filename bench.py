@@ -359,15 +359,23 @@ def run_config2(R):
     flow = torch.from_numpy(flow_np).float().to(dev)
     if a.tile[0] <= 0:
         a.tile = list(ebos.event_plan.choose_tile((H, W), a.halo))
-    plan_first_ms = plan_build_ms = 0.0
-    for attempt in range(3):  # the first build also pays one-off allocator / code-object costs: report the best later one
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        plan = ebos.EventPlan.build(ev_gpu, (H, W), "first", True, tile=tuple(a.tile))
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) * 1e3
-        plan_first_ms = plan_first_ms or ms
-        plan_build_ms = ms if attempt == 1 else min(plan_build_ms or ms, ms)
+    # plan build, timed host + device per window.  emit="compact" (ebos_plan_lean): what the unit-weight objective reads and
+    # nothing else; the full build also leaves SoA x / y / dt / p and the permutation (per-event weights).  The first build of
+    # a process also pays one-off allocator / code-object costs: the best of the later ones is reported.
+    def time_build(emit):
+        first = best = 0.0
+        for attempt in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pl = ebos.EventPlan.build(ev_gpu, (H, W), "first", True, tile=tuple(a.tile), emit=emit)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            first = first or ms
+            best = ms if attempt == 1 else min(best or ms, ms)
+        return pl, first, best
+
+    _, _, plan_build_full_ms = time_build("full")
+    plan, plan_first_ms, plan_build_ms = time_build("full" if a.no_compact else "compact")
     del ev_gpu
 
     nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, a.tile[0], a.tile[1], a.halo, a.splits, 0, 0))
@@ -376,7 +384,7 @@ def run_config2(R):
     moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
     iwe = torch.empty((H, W), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    P = lambda t: t.data_ptr()
+    P = lambda t: None if t is None else t.data_ptr()
 
     def compact_ptrs(pl):
         return pl._compact_ptrs() if (pl.compact and not a.no_compact) else (None, None, None)
@@ -476,8 +484,7 @@ def run_config2(R):
         rot = []
         for k in range(nrot):
             ev_k, fl_k = synth_window(n, seed=100 + k)
-            pk = ebos.EventPlan.build(torch.from_numpy(ev_k).to(dev), (H, W), "first", True, tile=tuple(a.tile))
-            # keep only what the kernel reads
+            pk = ebos.EventPlan.build(torch.from_numpy(ev_k).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact")
             rot.append((pk, torch.from_numpy(fl_k).float().to(dev)))
             del ev_k, fl_k
         rsteps = [make_step(pk, fk, compact_ptrs(pk)) for pk, fk in rot]
@@ -564,6 +571,8 @@ def run_config2(R):
         line["roofline"] = roof
         line["ranks_seen"] = ranks_seen
         line["plan_build_ms"] = round(plan_build_ms, 3)
+        line["plan_build_kind"] = "lean (emit='compact': compact events + offsets only)" if plan.lean else "full (SoA + perm + compact)"
+        line["plan_build_full_ms"] = round(plan_build_full_ms, 3)
         line["plan_build_first_call_ms"] = round(plan_first_ms, 2)
         # one evaluation of a FRESH window (BASELINE configs[1] read literally): plan build + one step
         line["value_incl_plan_build"] = round(n / (plan_build_ms + ms_per_step) / 1e3, 2)
@@ -574,7 +583,7 @@ def run_config2(R):
             line["cpu_baseline"] = cpu_baseline(ev, flow_np, sample)
             line["speedup_vs_cpu_port_f64"] = round(value / line["cpu_baseline"]["value"], 1)
             if sample < n:  # the same sample through the GPU path (outside the timed region)
-                ps = ebos.EventPlan.build(torch.from_numpy(ev[:sample]).to(dev), (H, W), "first", True, tile=tuple(a.tile))
+                ps = ebos.EventPlan.build(torch.from_numpy(ev[:sample]).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact")
                 make_step(ps, flow, compact_ptrs(ps))()
                 gpu_c = float(out.item())
             else:
@@ -613,7 +622,7 @@ def run_config4(R):
     plans, grids = [], []
     for wi in mine:
         ev, _ = synth_window(n, seed=wi, flow=False)
-        plans.append(ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile)))
+        plans.append(ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact"))
         grids.append(torch.from_numpy(np.random.RandomState(100 + wi).uniform(-FLOW_MAX, FLOW_MAX, (2, gh, gw))).float().to(dev))
     torch.cuda.synchronize()
     ingest_s = time.perf_counter() - t0
@@ -678,7 +687,7 @@ def run_config5(R):
         a.tile = list(ebos.event_plan.choose_tile((H, W), a.halo))
     ev, _ = synth_window(n, seed=0, flow=False)  # the SAME window on every rank
     t0 = time.perf_counter()
-    plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile))
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact")
     torch.cuda.synchronize()
     ingest_s = time.perf_counter() - t0
     del ev

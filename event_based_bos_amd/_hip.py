@@ -70,6 +70,8 @@ SIGNATURES = {
     "ebos_bin_scratch_bytes": (_Z, [_L]),
     "ebos_bin_scratch_bytes_events": (_Z, [_L, _I, _I, _I, _I]),
     "ebos_bin_events_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ebos_plan_lean_scratch_bytes": (_Z, [_L, _I, _I, _I, _I]),
+    "ebos_plan_lean": (_I, [_I, _P, _P, _P, _P, _D, _L, _I, _D, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
     "ebos_plan_compact_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _L, _P]),
     "ebos_iwe_dense_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_dense_tiled_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
@@ -82,6 +84,7 @@ SIGNATURES = {
     "ebos_plan_parts": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_2dof_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    "ebos_variance_dense_job_f32": (_I, [_P, _P, _P, _P, _P, _P]),
     "ebos_iwe_2dof_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_2dof_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "ebos_cost_scratch_bytes": (_Z, [_I]),
@@ -137,6 +140,13 @@ class CmaxPatchProblem(C.Structure):
                  ("grad_partials_bytes", _Z)])
 
 
+class DenseJob(C.Structure):
+    """``ebos_dense_job`` of include/ebos_hip.h (same field order)."""
+    _fields_ = ([(k, _P) for k in ("xs", "ys", "dts", "grp_offsets", "cpix", "cdt", "key_offsets")] + [("n", _L)] +
+                [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "splits", "pad_h", "pad_w", "omit_boundary")] +
+                [("workspace", _P), ("workspace_bytes", _Z), ("part_table", _P), ("iwe", _P), ("moments", _P)])
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -187,7 +197,32 @@ def require_gpu() -> C.CDLL:
 
 
 def stream_ptr(device: Optional[torch.device] = None) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """hipStream_t of torch's current stream on ``device`` (default: the current device) as an integer.  The raw getter:
+    ``torch.cuda.current_stream()`` builds a Stream object per call (~5-10 us of the ~20 us an operator launch costs)."""
+    idx = torch._C._cuda_getDevice() if device is None or device.index is None else device.index
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
+class on_device(object):
+    """``with on_device(dev):`` -- like ``torch.cuda.device(dev)`` but free when ``dev`` is already current (the usual
+    case; the torch context manager costs ~10 us per operator launch either way)."""
+    __slots__ = ("idx", "ctx")
+
+    def __init__(self, device):
+        self.idx = device.index if isinstance(device, torch.device) else device
+        self.ctx = None
+
+    def __enter__(self):
+        if self.idx is not None and torch._C._cuda_getDevice() != self.idx:
+            self.ctx = torch.cuda.device(self.idx)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
 
 
 def check(rc: int, what: str) -> None:

@@ -22,7 +22,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libebos_hip.so")
 
-SOURCES = ["errors.cpp", "warp_kernels.hip", "splat_kernels.hip", "event_plan.hip", "iwe_fused.hip", "iwe_tiled.hip",
+SOURCES = ["errors.cpp", "warp_kernels.hip", "splat_kernels.hip", "event_plan.hip", "plan_lean.hip", "iwe_fused.hip", "iwe_tiled.hip",
            "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip", "solver_kernels.hip"]
 
 # -munsafe-fp-atomics: hardware global_atomic_add_f32/f64 and ds_add_f32 instead of CAS loops.

@@ -318,6 +318,10 @@ __device__ __forceinline__ void load_cgroup(CGroup& g, int32_t grp, const TileRa
   g.pr[1] = P.x >> 24;         g.pc[1] = (P.x >> 16) & 255u;
   g.pr[2] = (P.y >> 8) & 255u; g.pc[2] = P.y & 255u;
   g.pr[3] = P.y >> 24;         g.pc[3] = (P.y >> 16) & 255u;
+#ifdef EBOS_ABL_RUN4  // ablation (results wrong on purpose): what a one-pixel-per-group format would save
+  g.pr[1] = g.pr[2] = g.pr[3] = g.pr[0];
+  g.pc[1] = g.pc[2] = g.pc[3] = g.pc[0];
+#endif
 }
 
 // Work distribution inside the workgroup is DYNAMIC: a wave processes one chunk of 64 groups (one group per lane) at a
@@ -411,7 +415,11 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       const unsigned q10 = (unsigned)(__float_as_int(u1) - kMagicBits);
       const unsigned q11 = (unsigned)(__float_as_int(t1) - __float_as_int(u1));  // A1 - q10
       const unsigned t = __umul24((unsigned)rl, (unsigned)LW) + (unsigned)cl;  // (rl < 2^24 whenever the result is used)
+#ifdef EBOS_ABL_INTERLEAVE  // ablation: one pair word per column, no parity logic (decode not adapted: results wrong)
+      const unsigned word = inside ? t : kDummy;
+#else
       const unsigned word = inside ? (t >> 1) + (t & 1u) * kPlane : kDummy;
+#endif
       atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
       atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
       n_inside += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside));  // wave-uniform: s_bcnt1 on the mask
@@ -1834,6 +1842,36 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
   if (rc != EBOS_OK) return rc;
   EBOS_CHECK_LAUNCH("ebos_iwe_dense_tiled_bwd");
   return EBOS_OK;
+}
+
+int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_variance, const float* upstream,
+                                float* d_flow, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(job && flow && out_variance, "ebos_variance_dense_job: NULL job / flow / out_variance");
+  EBOS_REQUIRE(job->iwe && job->moments && job->workspace, "ebos_variance_dense_job: the job needs iwe, moments and a workspace");
+  int rc = ebos_iwe_dense_slab_f32(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n,
+                                   flow, job->H, job->W, job->tile_h, job->tile_w, job->halo, job->splits, job->pad_h, job->pad_w,
+                                   job->workspace, job->workspace_bytes, job->iwe, 1, job->omit_boundary, out_variance, job->moments,
+                                   job->part_table, stream);
+  if (rc != EBOS_OK || d_flow == nullptr) return rc;
+  static float* d_one = nullptr;  // upstream == NULL: a device constant 1.0f (created on first use, never freed)
+  if (upstream == nullptr) {
+    if (d_one == nullptr) {
+      const float one = 1.0f;
+      if (hipMalloc(reinterpret_cast<void**>(&d_one), sizeof(float)) != hipSuccess ||
+          hipMemcpy(d_one, &one, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("ebos_variance_dense_job: cannot create the unit upstream");
+        return EBOS_ERR_LAUNCH;
+      }
+    }
+    upstream = d_one;
+  }
+  const bool adaptive = job->splits == 0 && job->part_table != nullptr;
+  return ebos_iwe_dense_tiled_bwd_f32(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n,
+                                      flow, job->H, job->W, job->tile_h, job->tile_w, job->halo, job->pad_h, job->pad_w, job->iwe, nullptr,
+                                      job->omit_boundary ? 1 : 0, d_flow, nullptr, job->moments, upstream, nullptr,
+                                      adaptive ? job->workspace : nullptr, adaptive ? job->workspace_bytes : 0,
+                                      adaptive ? job->part_table : nullptr, stream);
 }
 
 size_t ebos_patch_grad_partials_bytes(int H, int W, int tile_h, int tile_w, int adaptive) {

@@ -116,10 +116,10 @@ class RawEventStore(object):
         return tuple(c.pin_memory().to(dev, non_blocking=True) for c in cols)
 
     def plan(self, start_index: int, end_index: int, image_size: Tuple[int, int], direction="first",
-             normalize_t: bool = True, tile="auto", device="cuda", deferred: bool = False) -> EventPlan:
+             normalize_t: bool = True, tile="auto", device="cuda", deferred: bool = False, emit: str = "full") -> EventPlan:
         col, row, t, pol = self.load_raw(start_index, end_index, device)
         return EventPlan.build_raw(col, row, t, pol, image_size, direction, normalize_t, tile, self.TICKS_PER_SECOND,
-                                   deferred=deferred)
+                                   deferred=deferred, emit=emit)
 
     # ------------------------------------------------------------------ index <-> time
     def _times(self) -> np.ndarray:

@@ -95,7 +95,8 @@ def plan_for(prov: Provenance) -> EventPlan:
         stats["plan_hits"] += 1
         return entry[1]
     direction = {0: "first", 1: "last"}.get(prov.ref_mode, float(prov.ref_fraction))
-    plan = EventPlan.build(ev.detach(), prov.image_size, direction, prov.normalize_t, tile="auto")
+    # (only unit-weight images are fused: the lean build -- compact events and offsets, nothing else -- is all they read)
+    plan = EventPlan.build(ev.detach(), prov.image_size, direction, prov.normalize_t, tile="auto", emit="compact")
     _plans[key] = (weakref.ref(ev), plan)
     weakref.finalize(ev, _evict, key)  # the entry (and its device memory) goes when the caller drops the window
     stats["plan_builds"] += 1

@@ -38,7 +38,7 @@ def time_range(events: torch.Tensor) -> torch.Tensor:
     events = _cuda_contig(events, "events")
     b, n, _ = events.shape
     out = torch.empty((b, 2), dtype=events.dtype, device=events.device)
-    with torch.cuda.device(events.device):
+    with _hip.on_device(events.device):
         fn = getattr(lib, "ebos_time_range_" + suffix(events.dtype))
         check(fn(ptr(events), b, n, ptr(out), stream_ptr()), "ebos_time_range")
     return out
@@ -49,7 +49,7 @@ def time_range(events: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 class _WarpDense(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, events, flow, ref_mode, ref_fraction, normalize_t, row_stride, oob, timebase):
+    def forward(ctx, events, flow, ref_mode, ref_fraction, normalize_t, row_stride, oob, timebase, tmm):
         lib = _hip.require_gpu()
         events = _cuda_contig(events, "events")
         flow = _cuda_contig(flow, "flow")
@@ -59,10 +59,10 @@ class _WarpDense(torch.autograd.Function):
         if timebase is not None:  # explicit (t_ref, period) per batch row
             tmm = _cuda_contig(timebase.to(events.dtype).reshape(b, 2), "timebase")
             ref_mode = _hip.REF_TIMEBASE
-        else:
+        elif tmm is None:  # (a caller that warps the same window again and again passes the range it already has)
             tmm = time_range(events)
         out = torch.empty_like(events)
-        with torch.cuda.device(events.device):
+        with _hip.on_device(events.device):
             fn = getattr(lib, "ebos_warp_dense_" + suffix(events.dtype))
             check(fn(ptr(events), ptr(flow), ptr(tmm), ref_mode, ref_fraction, int(normalize_t), b, n, H, W,
                      row_stride, ptr(out), ptr(oob), stream_ptr()), "ebos_warp_dense")
@@ -80,24 +80,25 @@ class _WarpDense(torch.autograd.Function):
             g = _cuda_contig(g, "grad")
             b, n, _ = events.shape
             d_flow = torch.zeros(fshape, dtype=events.dtype, device=events.device)
-            with torch.cuda.device(events.device):
+            with _hip.on_device(events.device):
                 fn = getattr(lib, "ebos_warp_dense_bwd_" + suffix(events.dtype))
                 check(fn(ptr(events), ptr(tmm), ref_mode, ref_fraction, normalize_t, ptr(g), b, n, fshape[-2],
                          fshape[-1], row_stride, ptr(d_flow), stream_ptr()), "ebos_warp_dense_bwd")
-        return None, d_flow, None, None, None, None, None, None
+        return None, d_flow, None, None, None, None, None, None, None
 
 
 def warp_dense(events: torch.Tensor, flow: torch.Tensor, ref_mode: int, ref_fraction: float, normalize_t: bool,
                row_stride: Optional[int] = None, oob: Optional[torch.Tensor] = None,
-               timebase: Optional[torch.Tensor] = None) -> torch.Tensor:
+               timebase: Optional[torch.Tensor] = None, tmm: Optional[torch.Tensor] = None) -> torch.Tensor:
     """events [b, n, 4], flow [b, 2, H, W] -> warped [b, n, 4].  src/warp.py:292-342.
-    ``timebase`` [b, 2] = (t_ref, period) overrides the direction-derived reference time."""
+    ``timebase`` [b, 2] = (t_ref, period) overrides the direction-derived reference time; ``tmm`` [b, 2] = the (min t,
+    max t) of ``time_range(events)`` if the caller already has it."""
     if events.dim() != 3 or events.shape[-1] != 4 or flow.dim() != 4 or flow.shape[1] != 2:
         raise ValueError(f"warp_dense expects events [b,n,4] and flow [b,2,H,W], got {tuple(events.shape)}, {tuple(flow.shape)}")
     if events.shape[0] != flow.shape[0]:
         raise ValueError("warp_dense: batch sizes of events and flow differ")
     stride = int(flow.shape[-1] if row_stride is None else row_stride)
-    return _WarpDense.apply(events, flow, int(ref_mode), float(ref_fraction), bool(normalize_t), stride, oob, timebase)
+    return _WarpDense.apply(events, flow, int(ref_mode), float(ref_fraction), bool(normalize_t), stride, oob, timebase, tmm)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -119,7 +120,7 @@ class _Warp2Dof(torch.autograd.Function):
         out = torch.empty_like(events)
         if time_period is not None:
             time_period = _cuda_contig(time_period.to(events.dtype).reshape(1), "time_period")
-        with torch.cuda.device(events.device):
+        with _hip.on_device(events.device):
             fn = getattr(lib, "ebos_warp_2dof_" + suffix(events.dtype))
             check(fn(ptr(events), ptr(theta), ptr(tmm), ref_mode, ref_fraction, int(normalize_t), ptr(time_period), n,
                      ptr(out), stream_ptr()), "ebos_warp_2dof")
@@ -136,7 +137,7 @@ class _Warp2Dof(torch.autograd.Function):
             lib = _hip.require_gpu()
             g = _cuda_contig(g, "grad")
             d_theta = torch.zeros(2, dtype=events.dtype, device=events.device)
-            with torch.cuda.device(events.device):
+            with _hip.on_device(events.device):
                 fn = getattr(lib, "ebos_warp_2dof_bwd_" + suffix(events.dtype))
                 check(fn(ptr(events), ptr(tmm), ref_mode, ref_fraction, normalize_t, ptr(period) if has_period else None,
                          ptr(g), events.shape[0], ptr(d_theta), stream_ptr()), "ebos_warp_2dof_bwd")
@@ -165,7 +166,7 @@ class _Splat(torch.autograd.Function):
             weight = _cuda_contig(weight.to(events.dtype), "weight")
         shape = (b, 2, h, w) if mode == _hip.SPLAT_POLARITY else (b, h, w)
         image = torch.zeros(shape, dtype=events.dtype, device=events.device)
-        with torch.cuda.device(events.device):
+        with _hip.on_device(events.device):
             fn = getattr(lib, "ebos_splat_" + suffix(events.dtype))
             check(fn(ptr(events), ptr(weight), float(weight_scalar), mode, float(eps), b, n, h, w, pad_h, pad_w,
                      ptr(image), stream_ptr()), "ebos_splat")
@@ -189,7 +190,7 @@ class _Splat(torch.autograd.Function):
                 d_events = torch.empty_like(events)
             if need_w:
                 d_weight = torch.empty((b, n), dtype=events.dtype, device=events.device)
-            with torch.cuda.device(events.device):
+            with _hip.on_device(events.device):
                 fn = getattr(lib, "ebos_splat_bwd_" + suffix(events.dtype))
                 check(fn(ptr(events), ptr(weight) if has_w else None, ws, eps, ptr(g), b, n, h, w, pad_h, pad_w,
                          ptr(d_events), ptr(d_weight), stream_ptr()), "ebos_splat_bwd")
@@ -229,7 +230,7 @@ class _ImageVariance(torch.autograd.Function):
         out = torch.empty(K, dtype=images.dtype, device=images.device)
         moments = torch.empty((K, 2), dtype=torch.float64, device=images.device)
         scratch = _cost_scratch(lib, K, images.device)
-        with torch.cuda.device(images.device):
+        with _hip.on_device(images.device):
             fn = getattr(lib, "ebos_image_variance_" + suffix(images.dtype))
             check(fn(ptr(images), K, h, w, int(omit), ptr(out), ptr(moments), ptr(scratch), scratch.numel(),
                      stream_ptr()), "ebos_image_variance")
@@ -244,7 +245,7 @@ class _ImageVariance(torch.autograd.Function):
         K, h, w = images.shape
         g = _cuda_contig(g.to(images.dtype), "grad")
         d = torch.empty_like(images)
-        with torch.cuda.device(images.device):
+        with _hip.on_device(images.device):
             fn = getattr(lib, "ebos_image_variance_grad_" + suffix(images.dtype))
             check(fn(ptr(images), K, h, w, ctx.omit, ptr(moments), ptr(g), ptr(d), stream_ptr()),
                   "ebos_image_variance_grad")
@@ -259,7 +260,7 @@ class _GradientMagnitude(torch.autograd.Function):
         K, h, w = images.shape
         out = torch.empty(K, dtype=images.dtype, device=images.device)
         scratch = _cost_scratch(lib, K, images.device)
-        with torch.cuda.device(images.device):
+        with _hip.on_device(images.device):
             fn = getattr(lib, "ebos_gradient_magnitude_" + suffix(images.dtype))
             check(fn(ptr(images), K, h, w, int(omit), ptr(out), ptr(scratch), scratch.numel(), stream_ptr()),
                   "ebos_gradient_magnitude")
@@ -274,7 +275,7 @@ class _GradientMagnitude(torch.autograd.Function):
         K, h, w = images.shape
         g = _cuda_contig(g.to(images.dtype), "grad")
         d = torch.empty_like(images)
-        with torch.cuda.device(images.device):
+        with _hip.on_device(images.device):
             fn = getattr(lib, "ebos_gradient_magnitude_grad_" + suffix(images.dtype))
             check(fn(ptr(images), K, h, w, ctx.omit, ptr(g), ptr(d), stream_ptr()), "ebos_gradient_magnitude_grad")
         return d, None
@@ -313,7 +314,7 @@ class _UpsamplePatchFlow(torch.autograd.Function):
         _, gh, gw = grid.shape
         H, W = image_size
         dense = torch.empty((2, H, W), dtype=torch.float32, device=grid.device)
-        with torch.cuda.device(grid.device):
+        with _hip.on_device(grid.device):
             check(lib.ebos_upsample_patch_flow_f32(ptr(grid), gh, gw, patch[0], patch[1], slide[0], slide[1], H, W,
                                                    ptr(dense), stream_ptr()), "ebos_upsample_patch_flow")
         ctx.meta = (gh, gw, patch, slide, H, W)
@@ -326,7 +327,7 @@ class _UpsamplePatchFlow(torch.autograd.Function):
         g = _cuda_contig(g.float(), "grad")
         d = torch.empty((2, gh, gw), dtype=torch.float32, device=g.device)
         scratch = torch.empty(int(lib.ebos_upsample_bwd_scratch_bytes(gh, W)) // 4, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _hip.on_device(g.device):
             check(lib.ebos_upsample_patch_flow_bwd_f32(ptr(g), gh, gw, patch[0], patch[1], slide[0], slide[1], H, W,
                                                        ptr(scratch), ptr(d), stream_ptr()), "ebos_upsample_patch_flow_bwd")
         return d, None, None, None
@@ -371,7 +372,7 @@ def _gauss1d_launch(x: torch.Tensor, axis: int, taps: torch.Tensor, boundary: in
     out = torch.empty_like(x)
     if x.numel() == 0:
         return out
-    with torch.cuda.device(x.device):
+    with _hip.on_device(x.device):
         fn = getattr(lib, entry + suffix(x.dtype))
         check(fn(ptr(x), ptr(out), outer, L, inner, ptr(taps), (taps.numel() - 1) // 2, boundary, stream_ptr()),
               entry.rstrip("_"))

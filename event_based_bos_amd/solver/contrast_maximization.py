@@ -135,7 +135,9 @@ class ContrastMaximizationMixin(object):
     def estimate(self, events, *args, **kwargs) -> np.ndarray:
         """events [n, 4] (x=row, y=col, t, p) -> flow [2, H, W] (numpy), like the reference's solvers."""
         ev = to_gpu(events)
-        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile=self.plan_tile())
+        # (the objective uses unit weights: the lean build -- compact events + offsets only -- is all it reads; windows with
+        # fractional, i.e. undistorted, coordinates fall back to the full build inside)
+        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile=self.plan_tile(), emit="compact")
         self.history = []
         if self.motion_model == "dense-flow":
             flow = self._estimate_patch_flow(plan)

@@ -206,7 +206,7 @@ class FusedPatchLoop(object):
         lib, plan, s = self.lib, self.plan, stream_ptr()
         H, W = plan.image_size
         gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
-        with torch.cuda.device(plan.device):
+        with _hip.on_device(plan.device):
             self.theta.copy_(theta.detach().to(self.theta))
             self._forward_backward(lib, plan, s)
             if self.sample_grid:  # plain gradient: theta = NULL, no optimiser step
@@ -259,7 +259,7 @@ class FusedPatchLoop(object):
         if self.t + n_iter > self.losses.numel():
             raise ValueError(f"capacity {self.losses.numel()} < {self.t} steps done + {n_iter}")
         t0 = self.t
-        with torch.cuda.device(self.plan.device):
+        with _hip.on_device(self.plan.device):
             if native:
                 import ctypes
 

@@ -45,7 +45,7 @@ class WindowPipeline(object):
         self.histories: List[List[float]] = []
         # the streams live as long as the pipeline: torch's caching allocator pools blocks per stream, so fresh streams
         # per run would turn every buffer of every window into a new hipMalloc
-        with torch.cuda.device(self.device):
+        with _hip.on_device(self.device):
             # high priority: the few short ingest kernels must not queue behind thousands of solver launches (the plan
             # build ends in a host read-back, and the host is what enqueues the next group)
             self.ingest_stream = torch.cuda.Stream(device=self.device, priority=-1)
@@ -90,7 +90,7 @@ class WindowPipeline(object):
                         theta_mask=mask))
             problems = (_hip.CmaxPatchProblem * len(loops))(*[lp.problem() for lp in loops])
             handles = (ctypes.c_void_p * len(loops))(*[st.cuda_stream for st in streams[:len(loops)]])
-            with torch.cuda.device(self.device):
+            with _hip.on_device(self.device):
                 check(self.lib.ebos_cmax_patch_solve_many_f32(problems, handles, len(loops), int(n_iter)),
                       "ebos_cmax_patch_solve_many")
             for w, lp in enumerate(loops):
@@ -110,7 +110,7 @@ class WindowPipeline(object):
     def run(self, store: RawEventStore, windows: Sequence[Tuple[int, int]]) -> List[np.ndarray]:
         """Dense flow [2, H, W] (float64 numpy, like ``estimate``) of every (start_index, end_index) window."""
         dev = self.device
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             ingest, streams = self.ingest_stream, self.streams
             groups = [list(windows[i:i + self.n_concurrent]) for i in range(0, len(windows), self.n_concurrent)]
             pending: List[dict] = []

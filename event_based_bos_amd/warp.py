@@ -232,7 +232,20 @@ class Warp(object):
             oob = self._oob_dev.get(ev.device)
             if oob is None:
                 oob = self._oob_dev[ev.device] = torch.zeros(1, dtype=torch.int32, device=ev.device)
-        warped = ops.warp_dense(ev, fl, ref_mode, frac, self.normalize_t, int(self.image_size[1]), oob, timebase)
+        tmm = None
+        if kind == GPU and timebase is None:
+            # (min t, max t) of a window does not change between solver iterations: remembered on the caller's tensor object
+            # together with its version counter (a reduction over all events + ~50 us of host work per warp otherwise)
+            memo = getattr(event, "_ebos_time_range", None)
+            if memo is not None and memo[0] == event._version and memo[1].dtype == ev.dtype:
+                tmm = memo[1]
+            else:
+                tmm = ops.time_range(ev)
+                try:
+                    event._ebos_time_range = (event._version, tmm)
+                except AttributeError:
+                    pass
+        warped = ops.warp_dense(ev, fl, ref_mode, frac, self.normalize_t, int(self.image_size[1]), oob, timebase, tmm)
         if strict and int(oob.item()) > 0:
             raise IndexError(f"{int(oob.item())} event(s) have a source pixel outside the flow field "
                              f"(index out of range in gather, src/warp.py:334-336)")

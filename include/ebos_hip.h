@@ -237,6 +237,26 @@ int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const f
 int ebos_plan_parts(const int32_t* key_offsets, int H, int W, int tile_h, int tile_w, int n_cu, int fixed_events,
                     int32_t* part_table, ebos_stream_t stream);
 
+/* Lean plan build: the compact plan (below) straight from the window -- AoS float32 / float64 [n, 4] = (x = row, y = col, t, p)
+ * as the reference's loader hands it over (src/data_loader/ccs.py:289-297), or the raw sensor columns (:57-66) -- without
+ * the SoA arrays and the permutation that only per-event weights and fractional source coordinates need.  Two-level
+ * counting sort (chunk -> (tile, row band) -> source pixel) whose scattered writes complete inside the L2 / LDS; no
+ * global atomics per event.  Outputs exactly what ebos_bin_events_f32 + ebos_plan_compact_f32 produce:
+ *     key_offsets [n_keys + 1], grp_offsets [tiles + 1], cpix / cdt [capacity_slots >= n + 3 tiles + 4]
+ * (the order of the events inside one source pixel is unspecified in both), plus
+ *     counts [2] (device int32): events outside the image (dropped), kept events with a fractional / negative source
+ *                coordinate -- the plan is valid iff counts[1] == 0;
+ *     tminmax [2] (device double, nullable): (min t, max t) of the window in seconds.
+ *   source: 0 = `events` float32 [n, 4], 1 = `events` float64 [n, 4], 2 / 3 = raw columns with int32 / int64 ticks.
+ *   ref_mode: EBOS_REF_FIRST / LAST / FRACTION; dt = (t - t_ref) [/ (tmax - tmin) if normalize_t], evaluated in fp64.
+ *   scratch: >= ebos_plan_lean_scratch_bytes(...) bytes (8 B per event + histograms).  1 <= n < 2^31. */
+size_t ebos_plan_lean_scratch_bytes(int64_t n, int H, int W, int tile_h, int tile_w);
+int ebos_plan_lean(int source, const void* events, const int16_t* col, const int16_t* row, const void* t,
+                   double ticks_per_second, int64_t n, int ref_mode, double ref_fraction, int normalize_t, int H, int W,
+                   int tile_h, int tile_w, int32_t* key_offsets, int32_t* grp_offsets, uint16_t* cpix, float* cdt,
+                   int64_t capacity_slots, int32_t* counts, double* tminmax, void* scratch, size_t scratch_bytes,
+                   ebos_stream_t stream);
+
 /* Compact plan: the 6 B/event layout of the tile-private kernels, valid when every source coordinate is a
  * non-negative integer (frac_count == 0; camera events always are).  Per tile t the events occupy the groups
  * [grp_offsets[t], grp_offsets[t+1]) of 4 slots (16-byte vector loads, tiles start on a group boundary):
@@ -329,6 +349,31 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary,
                             float* out_variance, double* moments, const int32_t* part_table,
                             ebos_stream_t stream);
+/* One call for the objective AND its gradient -- the drop-in autograd path (plan.contrast_dense(flow).backward(), i.e.
+ * warp.py:330-342 + event_image_converter.py:581-620 + torch.var and what autograd derives) costs what its kernels
+ * cost only if the host does not marshal ~60 arguments through two calls per iteration.  ebos_dense_job holds everything
+ * that is constant per (plan, padding, halo, splits): the caller fills it ONCE (plain pointers / sizes, same meaning as the
+ * arguments of ebos_iwe_dense_slab_f32 / ebos_iwe_dense_tiled_bwd_f32) and passes its address afterwards.
+ *   iwe [h, w] and moments [2] are scratch outputs owned by the job (IWE and (mean, M) of the LAST evaluation).
+ * ebos_variance_dense_job_f32: out_variance[0] = var(IWE(flow)) (omit_boundary as in the costs); if d_flow != NULL also
+ *   d_flow [2, H, W] = upstream[0] * d var / d flow (upstream: device f32 [1]; NULL = 1).  Enqueues accumulate, combine,
+ *   finalize (and the tile-private backward) on `stream`; no host synchronisation. */
+typedef struct ebos_dense_job {
+  const float *xs, *ys, *dts;          /* (x, y, dt) plan, nullable when the compact trio is given */
+  const int32_t* grp_offsets;          /* compact plan (ebos_plan_compact_f32), nullable trio      */
+  const uint16_t* cpix;
+  const float* cdt;
+  const int32_t* key_offsets;
+  int64_t n;
+  int H, W, tile_h, tile_w, halo, splits, pad_h, pad_w, omit_boundary;
+  void* workspace;                     /* >= ebos_iwe_slab_workspace_bytes(...), zero-filled once   */
+  size_t workspace_bytes;
+  const int32_t* part_table;           /* adaptive work items (splits == 0), else nullable          */
+  float* iwe;                          /* [H + 2 pad_h, W + 2 pad_w]                                */
+  double* moments;                     /* [2]                                                       */
+} ebos_dense_job;
+int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_variance, const float* upstream,
+                                float* d_flow, ebos_stream_t stream);
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
                                  const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
                                  const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,

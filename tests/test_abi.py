@@ -138,8 +138,9 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
-def test_problem_struct_layout_matches_the_ctypes_mirror(tmp_path):
-    """ebos_cmax_patch_problem as a C compiler lays it out == the ctypes.Structure the host layer fills (size and every
+@pytest.mark.parametrize("c_name,py_name", [("ebos_cmax_patch_problem", "CmaxPatchProblem"), ("ebos_dense_job", "DenseJob")])
+def test_problem_struct_layout_matches_the_ctypes_mirror(tmp_path, c_name, py_name):
+    """The structs of the ABI as a C compiler lays them out == the ctypes.Structure the host layer fills (size and every
     field offset): a field added on one side only, or a changed order, shows here and not as a wild pointer on the GPU."""
     import ctypes
     import shutil
@@ -150,10 +151,11 @@ def test_problem_struct_layout_matches_the_ctypes_mirror(tmp_path):
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("no gcc")
-    fields = [f[0] for f in _hip.CmaxPatchProblem._fields_]
+    mirror = getattr(_hip, py_name)
+    fields = [f[0] for f in mirror._fields_]
     # the header declares exactly these names, in this order
     hdr = open(os.path.join(ROOT, "include", "ebos_hip.h")).read()
-    body = hdr[hdr.index("typedef struct ebos_cmax_patch_problem {"):hdr.index("} ebos_cmax_patch_problem;")]
+    body = hdr[hdr.index("typedef struct %s {" % c_name):hdr.index("} %s;" % c_name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     declared = []
     for stmt in body.split("{", 1)[1].split(";"):
@@ -162,13 +164,13 @@ def test_problem_struct_layout_matches_the_ctypes_mirror(tmp_path):
     assert declared == fields, (declared, fields)
     src = tmp_path / "layout.c"
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ebos_hip.h"', 'int main(void) {',
-             '  printf("%zu\\n", sizeof(ebos_cmax_patch_problem));']
-    lines += [f'  printf("%zu\\n", offsetof(ebos_cmax_patch_problem, {f}));' for f in fields]
+             '  printf("%%zu\\n", sizeof(%s));' % c_name]
+    lines += [f'  printf("%zu\\n", offsetof({c_name}, {f}));' for f in fields]
     lines += ['  return 0;', '}']
     src.write_text("\n".join(lines) + "\n")
     exe = tmp_path / "layout"
     r = subprocess.run([gcc, "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
-    want = [ctypes.sizeof(_hip.CmaxPatchProblem)] + [getattr(_hip.CmaxPatchProblem, f).offset for f in fields]
+    want = [ctypes.sizeof(mirror)] + [getattr(mirror, f).offset for f in fields]
     assert got == want

@@ -117,3 +117,109 @@ def test_deferred_plan_equals_synchronous_plan():
     frac = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=None).bin((32, 32), deferred=True)
     with pytest.raises(ValueError):
         frac.counts()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# lean plan build (emit="compact", ebos_plan_lean): same compact plan as the full build
+# ---------------------------------------------------------------------------------------------------------------------
+def _canon(plan):
+    """(key_offsets, grp_offsets, per-slot pixel, per-pixel sorted dt) of a compact plan -- the order of the events inside
+    one source pixel is unspecified (atomic cursors), so dt is sorted inside every pixel run before comparing."""
+    ko = plan.key_offsets.cpu().numpy().astype(np.int64)
+    go = plan.grp_offsets.cpu().numpy().astype(np.int64)
+    th, tw = plan.tile
+    cpix = plan.cpix.cpu().numpy().view(np.uint16)
+    cdt = plan.cdt.cpu().numpy()
+    pix_all, dt_all = [], []
+    for t in range(len(go) - 1):
+        n_t = ko[(t + 1) * th * tw] - ko[t * th * tw]
+        s0 = 4 * go[t]
+        px, dt = cpix[s0:s0 + n_t].astype(np.int64), cdt[s0:s0 + n_t]
+        pad_dt = cdt[s0 + n_t:4 * go[t + 1]]
+        assert np.isnan(pad_dt).all() and len(pad_dt) < 4, "padding slots of a tile carry dt = NaN"
+        key = (px >> 8) * tw + (px & 255)
+        assert (np.diff(key) >= 0).all(), "events of a tile are sorted by source pixel"
+        order = np.lexsort((dt, key))
+        pix_all.append(px[order])
+        dt_all.append(dt[order])
+    return ko, go, np.concatenate(pix_all), np.concatenate(dt_all)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["f64", "f32", "raw32", "raw64", "oob", "skew", "small_tiles", "middle"])
+def test_lean_plan_is_the_compact_part_of_the_full_plan(case):
+    """emit="compact" (two-level counting sort, no SoA / perm) against the full build: key_offsets and grp_offsets equal,
+    cpix / cdt BIT-IDENTICAL once the events inside each source pixel are put in a canonical order, same counts, same
+    part table -- and bit-identical images (integer accumulation)."""
+    import event_based_bos_amd as ebos
+
+    h, w, n, tile, direction, norm = 180, 240, 150_000, (45, 80), "first", True
+    if case == "small_tiles":
+        h, w, tile = 100, 150, (32, 32)
+    if case == "middle":
+        direction, norm = "middle", False
+    x, y, t, p = O.synth_raw_columns(n, h, w, seed=12)
+    if case == "oob":
+        x[::53] = w + 2
+        y[7::61] = -1
+    if case == "skew":  # most events in one corner: bins beyond the LDS staging take the global-scatter branch
+        n = 400_000
+        x, y, t, p = O.synth_raw_columns(n, h, w, seed=13)
+        x[: n * 3 // 4] = x[: n * 3 // 4] % 70
+        y[: n * 3 // 4] = y[: n * 3 // 4] % 20
+    if case == "raw64":
+        t = t.astype(np.int64) + 2 ** 33
+    store = ebos.data_loader.RawEventStore({"x": x, "y": y, "t": t, "p": p})
+    if case.startswith("raw") or case in ("oob", "skew"):
+        full = store.plan(0, n, (h, w), direction, norm, tile=tile)
+        lean = store.plan(0, n, (h, w), direction, norm, tile=tile, emit="compact")
+    else:
+        ev = torch.from_numpy(store.load_event(0, n)).cuda()
+        if case == "f32":
+            ev = ev.float()
+        full = ebos.EventPlan.build(ev, (h, w), direction, norm, tile=tile)
+        lean = ebos.EventPlan.build(ev, (h, w), direction, norm, tile=tile, emit="compact")
+    assert lean.lean and lean.compact and not full.lean and lean.x is None and lean.perm is None
+    assert (lean.n, lean.n_input, lean.n_dropped, lean.tile) == (full.n, full.n_input, full.n_dropped, full.tile)
+    assert lean.counts() == full.counts()
+    a, b = _canon(full), _canon(lean)
+    for u, v, name in zip(a, b, ("key_offsets", "grp_offsets", "cpix", "cdt")):
+        assert np.array_equal(u, v), name
+    assert torch.equal(lean.part_table, full.part_table)
+    flow = torch.from_numpy(O.synth_dense_flow(h, w, seed=5, max_val=9.0)).float().cuda()
+    halo = 32 if tile == (45, 80) else 16
+    if case == "skew":  # > 4096 events on one cell: the exact f64 redo of the fixed-point path sums floats in event order
+        assert O.rel_l2(lean.iwe_dense(flow, halo=halo).cpu().numpy(), full.iwe_dense(flow, halo=halo).cpu().numpy()) < 1e-6
+    else:
+        assert torch.equal(lean.iwe_dense(flow, halo=halo), full.iwe_dense(flow, halo=halo))
+    f1, f2 = flow.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    lean.contrast_dense(f1, halo=halo).backward()
+    full.contrast_dense(f2, halo=halo).backward()
+    assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 1e-6
+    th = torch.tensor([[2.5, -4.0]], device="cuda")
+    assert O.rel_l2(lean.iwe_2dof(th, halo=halo).cpu().numpy(), full.iwe_2dof(th, halo=halo).cpu().numpy()) < (1e-6 if case == "skew" else 1e-30)
+    assert torch.equal(lean.pixel_event_counts(), full.pixel_event_counts())
+    with pytest.raises(NotImplementedError):   # what a lean plan cannot do says so
+        lean.iwe_dense(flow, weight=torch.ones(n, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        lean.iwe_dense(flow, halo=None)
+
+
+@pytest.mark.gpu
+def test_lean_build_falls_back_for_fractional_sources_and_runs_deferred():
+    import event_based_bos_amd as ebos
+
+    h, w, n = 96, 128, 20_000
+    ev = O.synth_events(n, h, w, seed=3)
+    ev[::4, 0] += 0.5
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile=(32, 32), emit="compact")
+    assert not plan.lean and not plan.compact  # fractional coordinates: the (x, y, dt) format of the full build
+    x, y, t, p = O.synth_raw_columns(n, h, w, seed=4)
+    x[::97] = w + 3
+    store = ebos.data_loader.RawEventStore({"x": x, "y": y, "t": t, "p": p})
+    flow = torch.from_numpy(O.synth_dense_flow(h, w, seed=5, max_val=6.0)).float().cuda()
+    sync = store.plan(0, n, (h, w), "first", True, tile=(32, 32), emit="compact")
+    lazy = store.plan(0, n, (h, w), "first", True, tile=(32, 32), emit="compact", deferred=True)  # no host read-back at all
+    dropped = int((x >= w).sum())
+    assert sync.n == n - dropped and lazy.n == n and lazy.lean and lazy.counts() == (dropped, 0)
+    assert torch.equal(lazy.iwe_dense(flow, halo=16), sync.iwe_dense(flow, halo=16))

@@ -49,6 +49,12 @@ def main():
     res["build_f64_ms"] = timed(lambda: ebos.EventPlan.build(g64, (H, W), "first", True, tile="auto"))
     res["build_f32_ms"] = timed(lambda: ebos.EventPlan.build(g32, (H, W), "first", True, tile="auto"))
     res["build_raw_ms"] = timed(lambda: ebos.EventPlan.build_raw(*raw, (H, W), "first", True, tile="auto"))
+    # lean build (emit="compact": ebos_plan_lean -- compact events + offsets only)
+    res["lean_f64_ms"] = timed(lambda: ebos.EventPlan.build(g64, (H, W), "first", True, tile="auto", emit="compact"))
+    res["lean_f32_ms"] = timed(lambda: ebos.EventPlan.build(g32, (H, W), "first", True, tile="auto", emit="compact"))
+    res["lean_raw_ms"] = timed(lambda: ebos.EventPlan.build_raw(*raw, (H, W), "first", True, tile="auto", emit="compact"))
+    res["lean_raw_deferred_ms"] = timed(lambda: ebos.EventPlan.build_raw(*raw, (H, W), "first", True, tile="auto", emit="compact",
+                                                                         deferred=True))
     res["soa_only_raw_ms"] = timed(lambda: ebos.EventPlan.build_raw(*raw, (H, W), "first", True, tile=None))
     pin = [torch.from_numpy(v).pin_memory() for v in (col, row, t, pol)]
     res["h2d_raw_ms"] = timed(lambda: [v.to("cuda", non_blocking=True) for v in pin])

@@ -38,8 +38,10 @@ def synthetic_window(cfg):
     base = np.array(d.get("base_displacement", [3.0, -2.0]))  # the whole background texture shifts, plus the bump
     flow = np.stack([base[0] + g, base[1] - 0.5 * g], 1)  # true displacement over the window at each point
     t = rs.uniform(0, 1, (len(pts), per_point))
-    x = np.rint(pts[:, None, 0] + t * flow[:, None, 0]).reshape(-1)
-    y = np.rint(pts[:, None, 1] + t * flow[:, None, 1]).reshape(-1)
+    x = (pts[:, None, 0] + t * flow[:, None, 0]).reshape(-1)
+    y = (pts[:, None, 1] + t * flow[:, None, 1]).reshape(-1)
+    if not d.get("warp", False):  # `data.warp: true` (configs/hot_plate1.yaml:7): the loader undistorts the events, their
+        x, y = np.rint(x), np.rint(y)  # coordinates are then fractional; raw sensor events sit on integer pixels
     ev = np.stack([x, y, 10.0 + 0.0083 * t.reshape(-1), rs.randint(0, 2, x.size)], 1)
     ev = ev[(ev[:, 0] >= 0) & (ev[:, 0] < h) & (ev[:, 1] >= 0) & (ev[:, 1] < w)]
     return ev[np.argsort(ev[:, 2], kind="stable")], (h, w)
