@@ -318,10 +318,6 @@ __device__ __forceinline__ void load_cgroup(CGroup& g, int32_t grp, const TileRa
   g.pr[1] = P.x >> 24;         g.pc[1] = (P.x >> 16) & 255u;
   g.pr[2] = (P.y >> 8) & 255u; g.pc[2] = P.y & 255u;
   g.pr[3] = P.y >> 24;         g.pc[3] = (P.y >> 16) & 255u;
-#ifdef EBOS_ABL_RUN4  // ablation (results wrong on purpose): what a one-pixel-per-group format would save
-  g.pr[1] = g.pr[2] = g.pr[3] = g.pr[0];
-  g.pc[1] = g.pc[2] = g.pc[3] = g.pc[0];
-#endif
 }
 
 // Work distribution inside the workgroup is DYNAMIC: a wave processes one chunk of 64 groups (one group per lane) at a
@@ -415,11 +411,7 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       const unsigned q10 = (unsigned)(__float_as_int(u1) - kMagicBits);
       const unsigned q11 = (unsigned)(__float_as_int(t1) - __float_as_int(u1));  // A1 - q10
       const unsigned t = __umul24((unsigned)rl, (unsigned)LW) + (unsigned)cl;  // (rl < 2^24 whenever the result is used)
-#ifdef EBOS_ABL_INTERLEAVE  // ablation: one pair word per column, no parity logic (decode not adapted: results wrong)
-      const unsigned word = inside ? t : kDummy;
-#else
       const unsigned word = inside ? (t >> 1) + (t & 1u) * kPlane : kDummy;
-#endif
       atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
       atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
       n_inside += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside));  // wave-uniform: s_bcnt1 on the mask

@@ -654,14 +654,15 @@ def test_upsample_and_blur_vs_reference_code_with_shimmed_torchvision(ebos):
     """HIP upsample kernel (ebos_upsample_patch_flow_f32), the grid-sampling event kernels' flow (through a zero-displacement
     check) and the GPU 3-tap blur against tests/golden/golden_upsample.npz -- the reference's own
     interpolate_dense_flow_from_patch_tensor / create_image_from_events_tensor run with torchvision's resize / gaussian_blur
-    shimmed (make_golden.py --upsample).  f32 kernels: 1e-5 of the +-30 range; f64 blur: 1e-12."""
+    shimmed (make_golden.py --upsample).  f32 kernels: 1e-4 px absolute on a +-30 px field (f32 lerp of values up to 30: a few
+    1e-5); f64 blur: 1e-12."""
     from test_oracle_golden import _upsample_cases, check_dense_against_fixture
 
     g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_upsample.npz"), allow_pickle=False))
     for tag, size, patch, slide in _upsample_cases(g):
         grid = G(g[tag + "_grid"], torch.float32).requires_grad_(True)
         dense = ebos.ops.upsample_patch_flow(grid, patch, slide, size)
-        check_dense_against_fixture(g, tag, dense.detach().double().cpu().numpy(), rtol=1e-5, atol=3e-5)
+        check_dense_against_fixture(g, tag, dense.detach().double().cpu().numpy(), rtol=1e-5, atol=1e-4)
         # adjoint: <upsample(grid), probe> differentiated = upsample^T probe, against torch autograd of the oracle map
         probe = np.random.RandomState(7).normal(size=tuple(dense.shape))
         (dense * G(probe, torch.float32)).sum().backward()
