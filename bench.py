@@ -72,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--tile", type=int, nargs=2, default=[0, 0], help="source tile (0 0 = choose_tile: 45x80 at 1280x720)")
     ap.add_argument("--halo", type=int, default=32)
     ap.add_argument("--splits", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=3, help="configs 4 / 5: independent windows / hypotheses kept in flight per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative legs (fwd+bwd, streams, rotating windows, solver)")
     ap.add_argument("--no-compact", action="store_true", help="read the 12 B/event (x, y, dt) plan instead of 6 B/event")
@@ -602,7 +603,6 @@ def run_config4(R):
 
     import event_based_bos_amd as ebos
     from event_based_bos_amd import _hip
-    from event_based_bos_amd.event_plan import _workspace
 
     a, dev, rank, world = R.args, R.dev, R.rank, R.world
     lib = _hip.require_gpu()
@@ -617,7 +617,7 @@ def run_config4(R):
         raise SystemExit(f"config 4 needs a tile the grid-sampling kernels support, got {a.tile} halo {a.halo}")
     gh, gw = ebos.solver.patch_grid_shape((H, W), (ph, pw), (sh, sw))
     stream = torch.cuda.current_stream().cuda_stream
-    P = lambda t: t.data_ptr()
+    P = lambda t: None if t is None else t.data_ptr()
     t0 = time.perf_counter()
     plans, grids = [], []
     for wi in mine:
@@ -627,20 +627,48 @@ def run_config4(R):
     torch.cuda.synchronize()
     ingest_s = time.perf_counter() - t0
     splits = 1
-    ws = _workspace(plans[0], (0, 0), a.halo, splits) if plans else None  # evaluations run back to back: one workspace
-    iwe = torch.empty((H, W), dtype=torch.float32, device=dev)
+    # The windows are independent (bos_event.py:144-220): like solver.WindowPipeline, a rank keeps three of them in flight on
+    # three HIP streams, each with its own workspace and image -- the small combine / finalize kernels of one window run in
+    # the wave slots the one-workgroup-per-CU accumulate kernel of another leaves free.  --streams 1: back to back.
+    n_lanes = max(1, min(a.streams, len(plans)))
+    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, a.tile[0], a.tile[1], a.halo, splits, 0, 0))
+    lanes = [(torch.cuda.Stream(device=dev) if n_lanes > 1 else None, torch.zeros(nws, dtype=torch.uint8, device=dev),
+              torch.empty((H, W), dtype=torch.float32, device=dev), torch.empty((1, 2), dtype=torch.float64, device=dev))
+             for _ in range(n_lanes)]
     outs = torch.empty(max(len(mine), 1), dtype=torch.float32, device=dev)
-    moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
+    main = torch.cuda.current_stream(dev)
 
     def step():
+        if n_lanes > 1:
+            for st, _, _, _ in lanes:
+                st.wait_stream(main)
         for k, (pl, g) in enumerate(zip(plans, grids)):
+            st, ws, iwe, moments = lanes[k % n_lanes]
             _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), gh, gw, ph, pw, sh, sw, H, W,
-                                                   a.tile[0], a.tile[1], a.halo, splits, 0, 0, P(ws), ws.numel(), P(iwe), 1, 0,
-                                                   outs.data_ptr() + 4 * k, P(moments), P(pl.part_table), stream),
+                                                   a.tile[0], a.tile[1], a.halo, splits, 0, 0, P(ws), nws, P(iwe), 1, 0,
+                                                   outs.data_ptr() + 4 * k, P(moments), P(pl.part_table),
+                                                   st.cuda_stream if st is not None else stream),
                        "ebos_iwe_patch_slab")
+        if n_lanes > 1:
+            for st, _, _, _ in lanes:
+                main.wait_stream(st)
 
-    blocks, kernel_ms = R.timed_blocks(step, lib, _hip.PROFILE_SLAB_ACCUMULATE, launches_per_step=max(len(mine), 1), profile_blocks=1)
+    blocks, _ = R.timed_blocks(step, lib, _hip.PROFILE_SLAB_ACCUMULATE, launches_per_step=max(len(mine), 1), profile_blocks=0)
     elapsed = statistics.median(blocks)
+    # roofline leg: the kernel timed on ONE stream, back to back (a dispatch that shares the chip with its neighbours' kernels
+    # has no clean begin-to-end time)
+    import ctypes
+    nrec = max(1, min(len(plans), 16))
+    _hip.check(lib.ebos_profile_start_kernel(_hip.PROFILE_SLAB_ACCUMULATE, nrec), "profile")
+    for k, (pl, g) in enumerate(zip(plans[:nrec], grids[:nrec])):
+        _, ws, iwe, moments = lanes[0]
+        _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), gh, gw, ph, pw, sh, sw, H, W,
+                                               a.tile[0], a.tile[1], a.halo, splits, 0, 0, P(ws), nws, P(iwe), 1, 0,
+                                               outs.data_ptr() + 4 * k, P(moments), P(pl.part_table), stream), "ebos_iwe_patch_slab")
+    torch.cuda.synchronize()
+    buf = (ctypes.c_float * nrec)()
+    got = lib.ebos_profile_stop(buf, nrec)
+    kernel_ms = [buf[i] for i in range(got)]
     res = {int(wi): float(v) for wi, v in zip(mine, outs[:len(mine)].tolist())}
     seen = R.gather({"rank": rank, "local_rank": R.local_rank, "device": torch.cuda.get_device_name(dev),
                      "windows": len(mine), "events": int(sum(p.n for p in plans)), "contrasts": res})
@@ -655,7 +683,9 @@ def run_config4(R):
             "windows_total": n_windows, "events_per_window": n, "height": H, "width": W,
             "layout": f"compact SoA 6 B/event, tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}; flow sampled from the patch grid per tile",
             "parallelism": f"windows round-robin over {world} rank(s) (bos_event.py:144-220), no collective"})
-        line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<GRID>", kernel_ms, algo)
+        line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<GRID>", kernel_ms, algo,
+                                          {"note": "kernel timed on one stream, back to back",
+                                           "ms_per_window_in_step": round(ms_per_step / max(len(mine), 1), 5), "streams": n_lanes})
         line["ranks_seen"] = [{k: v for k, v in s.items() if k != "contrasts"} for s in seen]
         merged = {}
         for s in seen:
@@ -695,7 +725,7 @@ def run_config5(R):
     res = {}
 
     def step():
-        res["v"] = plan.variance_2dof(th, chunk=8, halo=a.halo)
+        res["v"] = plan.variance_2dof(th, chunk=8, halo=a.halo, n_streams=a.streams)
 
     blocks, _ = R.timed_blocks(step, lib, _hip.PROFILE_SLAB_ACCUMULATE, launches_per_step=max(len(mine), 1), profile_blocks=0)
     elapsed = statistics.median(blocks)
