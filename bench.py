@@ -28,7 +28,7 @@ evaluation, as ``value_incl_plan_build`` -- it is NOT in the timed region of ``v
 Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize() and
 MAX-reduced over the ranks; blocks repeat until >= ``--min-seconds`` of timed work and the MEDIAN block is reported
 (``repeats``).  The dominant kernels are timed by HIP events stamped with their own dispatch (hipExtLaunchKernelGGL on the
-launch stream) during the first timed blocks.
+launch stream) during the last two timed blocks (steady-state clocks).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -188,6 +188,27 @@ def pmc_traffic(kernel):
     return rec.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch"), stamp
 
 
+def rocprof_stats(kernel_prefix, ends="false>"):
+    """Average duration of a kernel from the committed rocprofv3 --kernel-trace --stats run of the default bench command
+    (profiles/kernel_stats_latest.json, tools/collect_round_profiles.sh) -- only if it was taken on the kernel source as it is
+    now; else None.  Quoted NEXT to the live HIP-event timing: an event pair attached to a dispatch (hipExtLaunchKernelGGL)
+    brackets the dispatch plus the gap to the packet in front of it, rocprofv3 reports the dispatch's own begin / end."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "kernel_stats_latest.json")))
+    except (OSError, ValueError):
+        return None
+    if rec.get("source_blob_sha") != git_blob_sha(os.path.join(ROOT, DOMINANT_SOURCE)):
+        return None
+    best = None
+    for name, k in rec.get("kernels", {}).items():
+        # (`ends`: the last template flag -- GRID -- is false for the dense-flow instantiations the roofline entries are about)
+        if name.startswith(kernel_prefix) and name.endswith(ends) and (best is None or k["calls"] > best["calls"]):
+            best = dict(k, kernel=name)
+    if best is not None:
+        best["commit"] = rec.get("commit")
+    return best
+
+
 def cpu_baseline(ev, flow, sample):
     """The oracle's op-for-op torch-CPU restatement of the reference path (kind 'port'), timed on this
     host's cores on a bounded sample of the same window."""
@@ -298,8 +319,8 @@ class Rank(object):
             step()
         self.sync_all()
         blocks, kernel_ms = [], []
-        while True:
-            prof = len(blocks) < profile_blocks
+
+        def one_block(prof):
             nrec = max(1, a.steps * launches_per_step)
             if prof:
                 from event_based_bos_amd import _hip
@@ -314,8 +335,12 @@ class Rank(object):
                 buf = (ctypes.c_float * nrec)()
                 got = lib.ebos_profile_stop(buf, nrec)
                 kernel_ms.extend(buf[i] for i in range(got))
-            if sum(blocks) >= a.min_seconds or len(blocks) >= a.max_repeats:
-                return blocks, kernel_ms
+
+        while sum(blocks) < a.min_seconds and len(blocks) < a.max_repeats:
+            one_block(False)
+        for _ in range(profile_blocks):  # the profiled blocks come LAST: clocks and caches are in their steady state by then
+            one_block(True)
+        return blocks, kernel_ms
 
 
 def roofline_entry(kernel, kernel_ms_list, algo_bytes, extra=None):
@@ -328,6 +353,11 @@ def roofline_entry(kernel, kernel_ms_list, algo_bytes, extra=None):
            "kernel_ms_max": round(max(kernel_ms_list), 4) if kernel_ms_list else None,
            "kernel_launches_timed": len(kernel_ms_list), "algorithmic_bytes": algo_bytes}
     ent.update(stamp)
+    rp = rocprof_stats(kernel.split("<")[0] + "<") if "<" not in kernel else None
+    if rp is not None:  # the committed rocprofv3 run of this command, same kernel source
+        ent["rocprofv3"] = {"avg_us": rp["avg_us"], "min_us": rp["min_us"], "calls": rp["calls"], "commit": rp["commit"],
+                            "achieved": round(algo_bytes / (rp["avg_us"] * 1e-6) / 1e9, 1),
+                            "frac": round(algo_bytes / (rp["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "kernel": rp["kernel"]}
     if extra:
         ent.update(extra)
     return ent
