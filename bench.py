@@ -72,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--tile", type=int, nargs=2, default=[0, 0], help="source tile (0 0 = choose_tile: 45x80 at 1280x720)")
     ap.add_argument("--halo", type=int, default=32)
     ap.add_argument("--splits", type=int, default=1)
+    ap.add_argument("--flow-max", type=float, default=FLOW_MAX, help="amplitude of the synthetic flow (BASELINE: 30 px)")
     ap.add_argument("--streams", type=int, default=3, help="configs 4 / 5: independent windows / hypotheses kept in flight per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative legs (fwd+bwd, streams, rotating windows, solver)")
@@ -149,7 +150,7 @@ def dry_run(args):
 # ---------------------------------------------------------------------------------------------------------------------
 # inputs
 # ---------------------------------------------------------------------------------------------------------------------
-def synth_window(n, seed, flow=True):
+def synth_window(n, seed, flow=True, flow_max=FLOW_MAX):
     import numpy as np
 
     rs = np.random.RandomState(seed)
@@ -158,7 +159,7 @@ def synth_window(n, seed, flow=True):
     t = np.sort(rs.uniform(0.0, 0.5, n))
     p = rs.randint(0, 2, n)
     ev = np.stack([x, y, t, p], axis=1).astype(np.float64)
-    fl = np.random.RandomState(1000 + seed).uniform(-FLOW_MAX, FLOW_MAX, (2, H, W)) if flow else None
+    fl = np.random.RandomState(1000 + seed).uniform(-flow_max, flow_max, (2, H, W)) if flow else None
     return ev, fl
 
 
@@ -385,7 +386,7 @@ def run_config2(R):
     a, dev, rank, world = R.args, R.dev, R.rank, R.world
     lib = _hip.require_gpu()
     n = a.events or N_EVENTS
-    ev, flow_np = synth_window(n, seed=rank)
+    ev, flow_np = synth_window(n, seed=rank, flow_max=a.flow_max)
     ev_gpu = torch.from_numpy(ev).to(dev)
     flow = torch.from_numpy(flow_np).float().to(dev)
     if a.tile[0] <= 0:
@@ -514,7 +515,7 @@ def run_config2(R):
         nrot = max(2, a.rotating_windows)
         rot = []
         for k in range(nrot):
-            ev_k, fl_k = synth_window(n, seed=100 + k)
+            ev_k, fl_k = synth_window(n, seed=100 + k, flow_max=a.flow_max)
             pk = ebos.EventPlan.build(torch.from_numpy(ev_k).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact")
             rot.append((pk, torch.from_numpy(fl_k).float().to(dev)))
             del ev_k, fl_k
@@ -593,8 +594,9 @@ def run_config2(R):
         if "rotating_windows" in extras:
             roof["frac_rotating_windows"] = extras["rotating_windows"]["frac"]
         line = base_line(R, value, ms_per_step, blocks, "weak", {
-            "workload": "BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
-                        "variance cost, fwd objective (tile accumulate + slab combine + variance)",
+            "workload": ("BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
+                         "variance cost, fwd objective (tile accumulate + slab combine + variance)") if (a.flow_max == FLOW_MAX and n == N_EVENTS)
+                        else f"NOT the BASELINE workload: {n} events, flow U(-{a.flow_max:g},{a.flow_max:g})",
             "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
             "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if cptrs[0] else "SoA f32 (x,y,dt), 12 B/event")
                       + f", binned by source tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}, splits {a.splits}",

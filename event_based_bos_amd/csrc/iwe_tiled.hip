@@ -34,6 +34,7 @@
 #include "patch_grid.h"
 
 namespace ebos {
+__device__ float g_unit_upstream = 1.0f;  // upstream of ebos_variance_dense_job_f32 when the caller passes none
 namespace {
 
 constexpr float kEps = 1e-6f;  // src/event_image_converter.py:586
@@ -1846,15 +1847,11 @@ int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, fl
                                    job->workspace, job->workspace_bytes, job->iwe, 1, job->omit_boundary, out_variance, job->moments,
                                    job->part_table, stream);
   if (rc != EBOS_OK || d_flow == nullptr) return rc;
-  static float* d_one = nullptr;  // upstream == NULL: a device constant 1.0f (created on first use, never freed)
-  if (upstream == nullptr) {
-    if (d_one == nullptr) {
-      const float one = 1.0f;
-      if (hipMalloc(reinterpret_cast<void**>(&d_one), sizeof(float)) != hipSuccess ||
-          hipMemcpy(d_one, &one, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        set_error("ebos_variance_dense_job: cannot create the unit upstream");
-        return EBOS_ERR_LAUNCH;
-      }
+  if (upstream == nullptr) {  // a device-resident 1.0f of the code object: no allocation, no copy (the ABI never allocates)
+    static const float* d_one = nullptr;
+    if (d_one == nullptr && hipGetSymbolAddress((void**)&d_one, HIP_SYMBOL(ebos::g_unit_upstream)) != hipSuccess) {
+      set_error("ebos_variance_dense_job: cannot resolve the unit upstream");
+      return EBOS_ERR_LAUNCH;
     }
     upstream = d_one;
   }
