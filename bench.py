@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5))
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend of an N-rank run: nccl (= RCCL, one GPU per rank) or gloo (host-side barrier / "
+                         "reduce; ranks may then share a GPU -- a functional test of the N-rank path on a one-GPU box)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch + rendezvous + shard assignment + gather only (gloo, CPU, no kernels)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much timed work")
@@ -274,17 +277,24 @@ class Rank(object):
         self.local_rank = int(os.environ.get("LOCAL_RANK", 0))
         self.world = int(os.environ.get("WORLD_SIZE", 1))
         self.distributed = self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun also for a world of 1
+        index = 0
         if self.distributed:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                    device_id=torch.device("cuda", self.local_rank))
+            n_dev = torch.cuda.device_count()
+            if args.backend == "nccl" and self.local_rank >= n_dev:
+                raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but {n_dev} GPU(s) visible (one GPU per rank with nccl)")
+            index = self.local_rank % max(n_dev, 1)
+            torch.cuda.set_device(index)
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", index))
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             self.dist = dist
         else:
             torch.cuda.set_device(0)
-        self.dev = torch.device("cuda", self.local_rank if self.distributed else 0)
+        self.dev = torch.device("cuda", index)
 
     def sync_all(self):
         import torch
@@ -299,7 +309,7 @@ class Rank(object):
 
         if not self.distributed:
             return seconds
-        tt = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        tt = torch.tensor([seconds], dtype=torch.float64, device=self.dev if self.args.backend == "nccl" else "cpu")
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
 

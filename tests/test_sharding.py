@@ -106,3 +106,47 @@ def test_bench_gpus_flag_launches_the_ranks_itself(config, total, per_rank):
 def test_bench_single_rank_needs_no_launcher():
     line = _bench("--dry-run")
     assert line["n_gpus"] == 1 and [s["rank"] for s in line["ranks_seen"]] == [0] and line["steps"] == 200 and line["warmup"] == 20
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py on the GPU box: the JSON contract of the driver, and the N-rank path with real kernels (two ranks on ONE GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_single_gpu():
+    line = _bench("--steps", "20", "--warmup", "5", "--min-seconds", "0.05", "--events", "400000", "--cpu-sample", "400000",
+                  "--rotating-windows", "2")
+    for k in CONTRACT + ("cpu_baseline", "roofline_bwd", "rotating_windows", "contrast_cpu", "contrast_rel_err", "value_incl_plan_build",
+                         "repeats", "ranks_seen", "plan_build_ms"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["unit"] == "Mevents/s" and line["dtype"] == "f32" and line["higher_is_better"] is True
+    assert "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(line["value"] - 400000 * 20 / (line["ms_per_step"] * 20 * 1e-3) / 1e6) < 0.02 * line["value"]
+    assert line["contrast_rel_err"] < 1e-5                      # GPU variance == the CPU baseline leg's own result
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+    assert line["repeats"] >= 1 and line["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,flags,total_key,total", [
+    (2, ["--events", "300000", "--no-extras"], None, None),
+    (4, ["--windows", "6", "--events", "200000"], "windows_evaluated", 6),
+    (5, ["--events", "400000"], "hypotheses_evaluated", 512)])
+def test_bench_two_ranks_with_real_kernels_on_one_gpu(config, flags, total_key, total):
+    """`bench.py --gpus 2` end to end on the GPU box: the parent launches two ranks; with --backend gloo both may use the one
+    GPU of the box (barrier / MAX / gather on the host).  Same code path as the RCCL run except the backend name."""
+    line = _bench("--gpus", "2", "--backend", "gloo", "--config", str(config), "--steps", "2", "--warmup", "1", "--min-seconds", "0.01",
+                  "--no-cpu-baseline", *flags)
+    assert line["n_gpus"] == 2 and sorted(s["rank"] for s in line["ranks_seen"]) == [0, 1]
+    assert line["scaling"] == ("weak" if config == 2 else "strong") and line["value"] > 0
+    if total_key:
+        assert line[total_key] == total
+    if config == 2:  # weak scaling: both ranks' events counted
+        assert abs(line["value"] - 2 * 300000 / (line["ms_per_step"] * 1e-3) / 1e6) < 0.02 * line["value"]
+        assert len({s["contrast"] for s in line["ranks_seen"]}) == 2  # different windows (seed = rank)
