@@ -551,7 +551,6 @@ class _DenseJob(object):
         self.ws = _workspace(plan, pad, halo, splits)
         self.iwe = torch.empty((H + 2 * pad[0], W + 2 * pad[1]), dtype=torch.float32, device=plan.device)
         self.moments = torch.empty((1, 2), dtype=torch.float64, device=plan.device)
-        self.token = 0  # bumped by every evaluation: `iwe` / `moments` hold the LAST one
         g, c, d = plan._compact_ptrs()
         self.struct = _hip.DenseJob(ptr(plan.x), ptr(plan.y), ptr(plan.dt), g, c, d, ptr(plan.key_offsets), plan.n, H, W,
                                     plan.tile[0], plan.tile[1], int(halo), int(splits), pad[0], pad[1], int(omit), ptr(self.ws),
@@ -574,7 +573,6 @@ def _run_dense_job(job: _DenseJob, flow32: torch.Tensor, want_grad: bool):
     lib = _hip.require_gpu()
     out = torch.empty(1, dtype=torch.float32, device=flow32.device)
     d_flow = torch.empty_like(flow32) if want_grad else None
-    job.token += 1
     if torch._C._cuda_getDevice() == job.index:
         rc = lib.ebos_variance_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), None, ptr(d_flow), stream_ptr())
     else:
