@@ -105,7 +105,9 @@ def test_deferred_plan_equals_synchronous_plan():
     dropped = int(((x >= W) | (y < 0)).sum())
     assert sync.n == 30000 - dropped and lazy.n == 30000 and lazy.compact
     assert lazy.counts() == (dropped, 0) and sync.counts() == (dropped, 0)
-    assert torch.equal(lazy.iwe_dense(flow), sync.iwe_dense(flow))  # BIT-EXACT (fixed-point accumulation)
+    # (integer accumulation: bit-identical per work item; two BUILDS may differ by one ulp where a tile is cut into parts)
+    a_img, b_img = lazy.iwe_dense(flow), sync.iwe_dense(flow)
+    assert float((a_img - b_img).abs().max()) <= 4e-7 * float(b_img.abs().max())
     f1, f2 = flow.clone().requires_grad_(True), flow.clone().requires_grad_(True)
     lazy.contrast_dense(f1).backward()
     sync.contrast_dense(f2).backward()
@@ -188,16 +190,26 @@ def test_lean_plan_is_the_compact_part_of_the_full_plan(case):
     assert torch.equal(lean.part_table, full.part_table)
     flow = torch.from_numpy(O.synth_dense_flow(h, w, seed=5, max_val=9.0)).float().cuda()
     halo = 32 if tile == (45, 80) else 16
-    if case == "skew":  # > 4096 events on one cell: the exact f64 redo of the fixed-point path sums floats in event order
-        assert O.rel_l2(lean.iwe_dense(flow, halo=halo).cpu().numpy(), full.iwe_dense(flow, halo=halo).cpu().numpy()) < 1e-6
+    # Images are bit-identical between two plans of the same window when every tile is ONE work item.  When tiles are cut into
+    # parts (adaptive work items: few tiles on many CUs, or skewed windows) the parts are ranges of the tile's groups, so the
+    # unspecified order of the events inside a source pixel decides which part an event lands in; each part's integer field
+    # sums are converted to f32 on their own, and a pixel may then differ by one ulp between two BUILDS (never between two
+    # evaluations of one plan).  "skew" also overflows the fixed-point fields: its exact f64 redo sums floats in event order.
+    one_item_per_tile = lean.resolve_splits(None) == 1 and full.resolve_splits(None) == 1
+    a_img, b_img = lean.iwe_dense(flow, halo=halo), full.iwe_dense(flow, halo=halo)
+    if one_item_per_tile and case != "skew":
+        assert torch.equal(a_img, b_img)
     else:
-        assert torch.equal(lean.iwe_dense(flow, halo=halo), full.iwe_dense(flow, halo=halo))
+        assert float((a_img - b_img).abs().max()) <= 4e-7 * float(b_img.abs().max()) and O.rel_l2(a_img.cpu().numpy(), b_img.cpu().numpy()) < 1e-7
+    if case != "skew":
+        assert torch.equal(a_img, lean.iwe_dense(flow, halo=halo))  # one plan, two evaluations: always bit-identical
     f1, f2 = flow.clone().requires_grad_(True), flow.clone().requires_grad_(True)
     lean.contrast_dense(f1, halo=halo).backward()
     full.contrast_dense(f2, halo=halo).backward()
     assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 1e-6
     th = torch.tensor([[2.5, -4.0]], device="cuda")
-    assert O.rel_l2(lean.iwe_2dof(th, halo=halo).cpu().numpy(), full.iwe_2dof(th, halo=halo).cpu().numpy()) < (1e-6 if case == "skew" else 1e-30)
+    assert O.rel_l2(lean.iwe_2dof(th, halo=halo).cpu().numpy(), full.iwe_2dof(th, halo=halo).cpu().numpy()) < (
+        1e-30 if (one_item_per_tile and case != "skew") else 1e-6)
     assert torch.equal(lean.pixel_event_counts(), full.pixel_event_counts())
     with pytest.raises(NotImplementedError):   # what a lean plan cannot do says so
         lean.iwe_dense(flow, weight=torch.ones(n, device="cuda"))
@@ -222,4 +234,5 @@ def test_lean_build_falls_back_for_fractional_sources_and_runs_deferred():
     lazy = store.plan(0, n, (h, w), "first", True, tile=(32, 32), emit="compact", deferred=True)  # no host read-back at all
     dropped = int((x >= w).sum())
     assert sync.n == n - dropped and lazy.n == n and lazy.lean and lazy.counts() == (dropped, 0)
-    assert torch.equal(lazy.iwe_dense(flow, halo=16), sync.iwe_dense(flow, halo=16))
+    a_img, b_img = lazy.iwe_dense(flow, halo=16), sync.iwe_dense(flow, halo=16)
+    assert float((a_img - b_img).abs().max()) <= 4e-7 * float(b_img.abs().max())
