@@ -351,7 +351,26 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
   const unsigned base_lin = GRID ? 0u : (unsigned)(tr.ty * TH * W + tr.tx * TW);
   const unsigned uW = GRID ? (unsigned)TW : (unsigned)W;
-  unsigned n_inside = 0;  // events of this wave whose taps went into the window (wave-uniform)
+  // Dense field in memory: the two gathers per event go through a buffer descriptor -- a 32-bit byte offset per lane
+  // (one v_mad_u32_u24 + one shift) plus a scalar offset for the tile origin / the second component, instead of
+  // v_mul_lo_u32 + 64-bit address arithmetic per load (the loop is VALU-throughput-bound: DESIGN 4.1 #18)
+  constexpr bool kBuf = !UNIFORM && !GRID;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow), 0, kBuf ? 2 * H * W * (int)sizeof(float) : 0, 0x00020000);
+  const int soff0 = (int)(base_lin * 4u), soff1 = soff0 + H * W * (int)sizeof(float);
+  const unsigned uW4 = uW * 4u;
+  auto fetch = [&](unsigned pr, unsigned pc, float& u, float& v) {
+    if (UNIFORM) {
+      u = uni_u, v = uni_v;
+    } else if (kBuf) {
+      const unsigned off = __umul24(pr, uW4) + (pc << 2);
+      u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff0, 0));
+      v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff1, 0));
+    } else {
+      const unsigned lin = base_lin + pr * uW + pc;
+      u = flow[lin], v = flow1[lin];
+    }
+  };
   bool spilled = false;
   const int32_t g_last = tr.g_last;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -363,20 +382,12 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   load_cgroup<TH, TW>(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev);
   float fu[4], fv[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned lin = base_lin + cur.pr[e] * uW + cur.pc[e];
-    fu[e] = UNIFORM ? uni_u : flow[lin];
-    fv[e] = UNIFORM ? uni_v : flow1[lin];
-  }
+  for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pc[e], fu[e], fv[e]);
   while (tr.g_first + c_cur * kWave <= g_last) {  // wave-uniform
     const int32_t grp = tr.g_first + c_cur * kWave + lane;
     float gu[4], gv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned lin = base_lin + nxt.pr[e] * uW + nxt.pc[e];
-      gu[e] = UNIFORM ? uni_u : flow[lin];
-      gv[e] = UNIFORM ? uni_v : flow1[lin];
-    }
+    for (int e = 0; e < 4; ++e) fetch(nxt.pr[e], nxt.pc[e], gu[e], gv[e]);
     const int c_nn = queue.pull();
     CGroup nn;
     load_cgroup<TH, TW>(nn, tr.g_first + c_nn * kWave + lane, tr, ev);
@@ -415,7 +426,6 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       const unsigned word = inside ? (t >> 1) + (t & 1u) * kPlane : kDummy;
       atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
       atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
-      n_inside += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inside));  // wave-uniform: s_bcnt1 on the mask
     }
     cur = nxt;
     nxt = nn;
@@ -428,8 +438,10 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
     }
   }
   if (any_spill) *any_spill = spilled;
-  // this wave's share of the checksum, reported by its first lane (the kernel sums over lanes)
-  return MODE == ACC_FX && lane == 0 ? (unsigned long long)n_inside << kFxShift : 0ull;
+  // Checksum: nothing is counted per event.  Every finite event whose taps are inside the window adds exactly 2^20 units, so the
+  // kernel expects 2^20 x (events of the slice - events the spill pass took over); a non-finite event (NaN / Inf flow or time)
+  // makes the sums disagree and the slice is redone by the exact f64 loop, which is correct for it as well.
+  return 0ull;
 }
 
 // PASS_MAIN: the lean hot loop -- every tap that lands inside the LDS window is accumulated, branch-free (dead or
@@ -520,6 +532,7 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
           atomic_add(&s_acc[cell + dn + 1], (double)(fs * fcq));
         }
       } else if (!inside && wv != 0.0f && f.ok) {  // beyond the halo: spill image (zero-invariant scratch)
+        if (FMT == FMT_COMPACT && !HAS_W) added += 1ull << kFxShift;  // (lean path: the checksum leaves these events out)
         const float w00 = a * b * wv, w10 = f.fr * b * wv, w01 = a * f.fc * wv, w11 = f.fr * f.fc * wv;
         const int R = f.R + pad_h, C = f.C + pad_w;
         const bool r0 = R >= 0 && R < h, r1 = R + 1 >= 0 && R + 1 < h;
@@ -588,15 +601,18 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   EBOS_STAMP(1);
 
   bool spilled = false;
-  const unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID>(
+  unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID>(
       tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue);
+  constexpr bool kLeanLoop = FMT == FMT_COMPACT && !HAS_W;  // accumulate_compact_fx: counts nothing per event
+  if (kLeanLoop && threadIdx.x == 0 && tr.g_first <= tr.g_last)  // 2^20 units per event of the slice (padding slots excluded)
+    added += (unsigned long long)(min(tr.end, tr.beg + 4 * (tr.g_last - tr.g_first + 1)) - tr.beg) << kFxShift;
   if (spilled) s_flag[1] = 1;  // benign race: every writer stores 1
   EBOS_STAMP(2);
   __syncthreads();
   EBOS_STAMP(3);
-  if (s_flag[1])  // rare: taps beyond the halo go to the spill image with global atomics
-    accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
-                                                                                nullptr, queue);
+  if (s_flag[1])  // rare: taps beyond the halo go to the spill image with global atomics (lean path: minus their units)
+    added -= accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
+                                                                                         nullptr, queue);
 
   float4* out = reinterpret_cast<float4*>(slabs + (int64_t)tr.slab * (LH * LW));
   bool f64_flush = (MODE == ACC_F64);
