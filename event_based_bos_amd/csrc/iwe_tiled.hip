@@ -321,6 +321,24 @@ __device__ __forceinline__ void load_cgroup(CGroup& g, int32_t grp, const TileRa
   g.pr[3] = P.y >> 24;         g.pc[3] = (P.y >> 16) & 255u;
 }
 
+// The forward loop's form of a group: the tile-local column comes as a BYTE offset inside a row of the LDS window,
+// pcq = 4 * (col_in_tile + HALO) -- the unit every address of that loop is computed in (flow gather offset, LDS word)
+struct CGroupQ {
+  unsigned pr[4], pcq[4];
+  float dt[4];
+};
+template <int HALO>
+__device__ __forceinline__ void load_cgroup_q(CGroupQ& g, int32_t grp, const TileRange& tr, const EvPtrs& p) {
+  const int32_t j = max(min(grp, tr.g_last), tr.g_first);
+  const float4 D = reinterpret_cast<const float4*>(p.cdt)[j];
+  const uint2 P = reinterpret_cast<const uint2*>(p.cpix)[j];
+  g.dt[0] = D.x; g.dt[1] = D.y; g.dt[2] = D.z; g.dt[3] = D.w;
+  g.pr[0] = (P.x >> 8) & 255u; g.pcq[0] = ((P.x & 255u) << 2) + 4u * HALO;
+  g.pr[1] = P.x >> 24;         g.pcq[1] = (((P.x >> 16) & 255u) << 2) + 4u * HALO;
+  g.pr[2] = (P.y >> 8) & 255u; g.pcq[2] = ((P.y & 255u) << 2) + 4u * HALO;
+  g.pr[3] = P.y >> 24;         g.pcq[3] = (((P.y >> 16) & 255u) << 2) + 4u * HALO;
+}
+
 // Work distribution inside the workgroup is DYNAMIC: a wave processes one chunk of 64 groups (one group per lane) at a
 // time and draws its next chunk from an LDS counter.  With a static stride the 16 waves finish far apart -- the SIMD
 // arbiter favours older waves, so wave 0 was done after 9 us and then sat 7 us at the barrier (in-kernel stamps) --
@@ -345,7 +363,6 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   constexpr unsigned kDummy = LH * LW;      // first word of the dummy region (LW / 2 + 2 words)
   constexpr float kMagic = 12582912.0f;     // 1.5 * 2^23
   constexpr int kMagicBits = 0x4B400000;
-  unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
   // GRID: `flow` is the tile's own [2][TH * TW] flow in LDS
   const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)TH * TW : (int64_t)H * W);
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
@@ -355,20 +372,26 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   // (one v_mad_u32_u24 + one shift) plus a scalar offset for the tile origin / the second component, instead of
   // v_mul_lo_u32 + 64-bit address arithmetic per load (the loop is VALU-throughput-bound: DESIGN 4.1 #18)
   constexpr bool kBuf = !UNIFORM && !GRID;
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow), 0, kBuf ? 2 * H * W * (int)sizeof(float) : 0, 0x00020000);
+  // (pcq carries 4 * HALO: the descriptor's base is moved back by as much -- a scalar offset must not go negative, the address
+  // unit adds it as an unsigned 32-bit value -- and the range check gets the same allowance)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(const_cast<float*>(flow)) - 4 * HALO, 0, kBuf ? 2 * H * W * (int)sizeof(float) + 4 * HALO : 0, 0x00020000);
   const int soff0 = (int)(base_lin * 4u), soff1 = soff0 + H * W * (int)sizeof(float);
   const unsigned uW4 = uW * 4u;
-  auto fetch = [&](unsigned pr, unsigned pc, float& u, float& v) {
+  const char* __restrict__ flow_b0 = reinterpret_cast<const char*>(flow) - 4 * HALO;   // GRID: byte-addressed LDS reads
+  const char* __restrict__ flow_b1 = reinterpret_cast<const char*>(flow1) - 4 * HALO;
+  auto fetch = [&](unsigned pr, unsigned pcq, float& u, float& v) {
     if (UNIFORM) {
       u = uni_u, v = uni_v;
-    } else if (kBuf) {
-      const unsigned off = __umul24(pr, uW4) + (pc << 2);
-      u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff0, 0));
-      v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff1, 0));
     } else {
-      const unsigned lin = base_lin + pr * uW + pc;
-      u = flow[lin], v = flow1[lin];
+      const unsigned off = __umul24(pr, uW4) + pcq;
+      if (kBuf) {
+        u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff0, 0));
+        v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff1, 0));
+      } else {
+        u = *reinterpret_cast<const float*>(flow_b0 + off);
+        v = *reinterpret_cast<const float*>(flow_b1 + off);
+      }
     }
   };
   bool spilled = false;
@@ -377,32 +400,37 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   constexpr int kWaves = kBlock / kWave;
   // chunk c covers groups [g_first + 64 c, g_first + 64 c + 64); this wave starts with chunks `wave` and `wave + 16`
   int c_cur = wave, c_nxt = wave + kWaves;
-  CGroup cur, nxt;
-  load_cgroup<TH, TW>(cur, tr.g_first + c_cur * kWave + lane, tr, ev);
-  load_cgroup<TH, TW>(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev);
+  CGroupQ cur, nxt;
+  load_cgroup_q<HALO>(cur, tr.g_first + c_cur * kWave + lane, tr, ev);
+  load_cgroup_q<HALO>(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev);
   float fu[4], fv[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pc[e], fu[e], fv[e]);
+  for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pcq[e], fu[e], fv[e]);
+  char* const s_bytes = reinterpret_cast<char*>(s_acc);
   while (tr.g_first + c_cur * kWave <= g_last) {  // wave-uniform
     const int32_t grp = tr.g_first + c_cur * kWave + lane;
     float gu[4], gv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) fetch(nxt.pr[e], nxt.pc[e], gu[e], gv[e]);
+    for (int e = 0; e < 4; ++e) fetch(nxt.pr[e], nxt.pcq[e], gu[e], gv[e]);
     const int c_nn = queue.pull();
-    CGroup nn;
-    load_cgroup<TH, TW>(nn, tr.g_first + c_nn * kWave + lane, tr, ev);
+    CGroupQ nn;
+    load_cgroup_q<HALO>(nn, tr.g_first + c_nn * kWave + lane, tr, ev);
     const bool lane_live = grp <= g_last;  // the last chunk of the slice may be partial
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float lx = -cur.dt[e] * fu[e], ly = -cur.dt[e] * fv[e];  // source coordinates are integers: x' = rs + lx
       const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
       const float fr = fmaxf(lx - r0, 0.0f), fc = fmaxf(ly - c0, 0.0f);
-      const int rl = (int)cur.pr[e] + HALO + (int)r0, cl = (int)cur.pc[e] + HALO + (int)c0;
-      const bool ok = lane_live && (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
-      const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
+      // row of the LDS window, and 4 x its column (= byte offset of the column's f32 / half the offset of its pair word)
+      const int rl = (int)cur.pr[e] + HALO + (int)r0;
+      const int cl4 = (int)cur.pcq[e] + ((int)c0 << 2);
+      // false for NaN (padding slots carry dt = NaN); +-Inf converts to INT_MAX / INT_MIN and fails the window test below
+      const bool ok = lane_live && !__builtin_isunordered(lx, ly);  // one v_cmp_o_f32
+      const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl4 < (unsigned)(4 * (LW - 1));
       spilled |= ok && !inside;
       if (MODE == ACC_F64) {  // one double per cell; out-of-window / padding lanes add +0.0 to cell (0, 0) (select, not
         const float a = 1.0f - fr, b = 1.0f - fc;  // multiply: their weights may be NaN)
+        const int cl = cl4 >> 2;
         double* cell = s_acc + (inside ? rl * LW + cl : 0);
         atomic_add(cell, (double)(inside ? a * b : 0.0f));
         atomic_add(cell + 1, (double)(inside ? a * fc : 0.0f));
@@ -422,10 +450,15 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       const unsigned q01 = (unsigned)(__float_as_int(t0) - __float_as_int(u0));  // A0 - q00
       const unsigned q10 = (unsigned)(__float_as_int(u1) - kMagicBits);
       const unsigned q11 = (unsigned)(__float_as_int(t1) - __float_as_int(u1));  // A1 - q10
-      const unsigned t = __umul24((unsigned)rl, (unsigned)LW) + (unsigned)cl;  // (rl < 2^24 whenever the result is used)
-      const unsigned word = inside ? (t >> 1) + (t & 1u) * kPlane : kDummy;
-      atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
-      atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
+      // Byte address of the pair word: with t = rl LW + cl the word is (t >> 1) + (t & 1) kPlane, i.e. byte
+      //   8 (t >> 1) + 8 kPlane (t & 1) = 4 t + (t & 1) (8 kPlane - 4),   and t & 1 = cl & 1 (LW is even)
+      // -- two multiply-adds and a bit-field extract on values the loop has anyway (4 cl), instead of and / compare / select /
+      // shift / add on t (four VALU instructions per event fewer, one of them a compare: DESIGN 4.1 #18).
+      const unsigned t4 = __umul24((unsigned)rl, 4u * LW) + (unsigned)cl4;  // (rl < 2^24 whenever the result is used)
+      const unsigned byte = __umul24(((unsigned)cl4 >> 2) & 1u, 8u * kPlane - 4u) + t4;
+      unsigned long long* w = reinterpret_cast<unsigned long long*>(s_bytes + (inside ? byte : 8u * kDummy));
+      atomicAdd(w, ((unsigned long long)q01 << 32) | q00);
+      atomicAdd(w + LW / 2, ((unsigned long long)q11 << 32) | q10);
     }
     cur = nxt;
     nxt = nn;
@@ -859,6 +892,24 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
   const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
   const unsigned base_lin = GRID ? (unsigned)(kBwdApron * PW + kBwdApron) : (unsigned)(tr0 * W + tc0);
   const unsigned uW = GRID ? (unsigned)PW : (unsigned)W;
+  // dense field in memory: gathers through a buffer descriptor with 32-bit offsets, as in accumulate_compact_fx
+  constexpr bool kBuf = !UNIFORM && !GRID;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow), 0, kBuf ? 2 * H * W * (int)sizeof(float) : 0, 0x00020000);
+  const int soff0 = (int)(base_lin * 4u), soff1 = soff0 + H * W * (int)sizeof(float);
+  const unsigned uW4 = uW * 4u;
+  auto fetch = [&](unsigned pr, unsigned pc, float& u, float& v) {
+    if (UNIFORM) {
+      u = uni_u, v = uni_v;
+    } else if (kBuf) {
+      const unsigned off = __umul24(pr, uW4) + (pc << 2);
+      u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff0, 0));
+      v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff1, 0));
+    } else {
+      const unsigned lin = base_lin + pr * uW + pc;
+      u = flow[lin], v = flow1[lin];
+    }
+  };
   bool spilled = false;
   const int32_t g_last = tr.g_last;
   // dynamic chunks of 64 groups per wave, as in the forward loop: with a static stride the first wave was done 5.9 us
@@ -871,20 +922,12 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
   load_cgroup<TH, TW>(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev);
   float fu[4], fv[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned lin = base_lin + cur.pr[e] * uW + cur.pc[e];
-    fu[e] = UNIFORM ? uni_u : flow[lin];
-    fv[e] = UNIFORM ? uni_v : flow1[lin];
-  }
+  for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pc[e], fu[e], fv[e]);
   while (tr.g_first + c_cur * kWave <= g_last) {  // wave-uniform
     const bool lane_live = tr.g_first + c_cur * kWave + lane <= g_last;  // the last chunk may be partial
     float gu[4], gv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned lin = base_lin + nxt.pr[e] * uW + nxt.pc[e];
-      gu[e] = UNIFORM ? uni_u : flow[lin];
-      gv[e] = UNIFORM ? uni_v : flow1[lin];
-    }
+    for (int e = 0; e < 4; ++e) fetch(nxt.pr[e], nxt.pc[e], gu[e], gv[e]);
     const int c_nn = queue.pull();
     CGroup nn;
     load_cgroup<TH, TW>(nn, tr.g_first + c_nn * kWave + lane, tr, ev);
@@ -898,7 +941,8 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
       const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
       const float fr = lx - r0, fc = ly - c0;
       const int rl = (int)cur.pr[e] + HALO + (int)r0, cl = (int)cur.pc[e] + HALO + (int)c0;
-      const bool ok = lane_live && (fabsf(lx) + fabsf(ly)) < 1e9f;  // false for NaN (padding slot) and Inf
+      // false for NaN (padding slots carry dt = NaN); +-Inf converts to INT_MAX / INT_MIN and fails the window test below
+      const bool ok = lane_live && !__builtin_isunordered(lx, ly);  // one v_cmp_o_f32
       const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
       float g00, g10, g01, g11;
       bool use;
