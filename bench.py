@@ -354,6 +354,15 @@ class Rank(object):
         return blocks, kernel_ms
 
 
+def format_rate(format_bytes, kernel_ms_list):
+    """The bytes the compact plan format actually streams per launch (6 B/event, not the 12 B/event of SURVEY 8(d) that
+    `achieved` is priced on): `frac` may exceed 1 on a kernel with no flow gathers -- that is the format's 2x, not bandwidth."""
+    k_ms = statistics.fmean(kernel_ms_list) if kernel_ms_list else float("nan")
+    gbs = format_bytes / (k_ms * 1e-3) / 1e9
+    return {"plan_format_bytes": format_bytes, "plan_format_GBps": round(gbs, 1), "plan_format_frac": round(gbs / HBM_PEAK_GBS, 4),
+            "frac_note": "achieved/frac price SURVEY 8(d)'s 12 B/event; the plan stores 6 B/event, plan_format_* is the real stream"}
+
+
 def roofline_entry(kernel, kernel_ms_list, algo_bytes, extra=None):
     k_ms = statistics.mean(kernel_ms_list) if kernel_ms_list else float("nan")
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
@@ -727,7 +736,8 @@ def run_config4(R):
             "parallelism": f"windows round-robin over {world} rank(s) (bos_event.py:144-220), no collective"})
         line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<GRID>", kernel_ms, algo,
                                           {"note": "kernel timed on one stream, back to back",
-                                           "ms_per_window_in_step": round(ms_per_step / max(len(mine), 1), 5), "streams": n_lanes})
+                                           "ms_per_window_in_step": round(ms_per_step / max(len(mine), 1), 5), "streams": n_lanes,
+                                           **format_rate(6.0 * n + 4.0 * H * W + 8.0 * gh * gw, kernel_ms)})
         line["ranks_seen"] = [{k: v for k, v in s.items() if k != "contrasts"} for s in seen]
         merged = {}
         for s in seen:
@@ -799,7 +809,8 @@ def run_config5(R):
         line["unit_note"] = "Mevents/s counts event-warps: every hypothesis warps and splats every event"
         line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<UNIFORM>", kernel_ms, algo,
                                           {"note": "kernel timed on one stream, back to back (the timed sweep overlaps three)",
-                                           "ms_per_hypothesis_in_sweep": round(ms_per_step / max(len(mine), 1), 5)})
+                                           "ms_per_hypothesis_in_sweep": round(ms_per_step / max(len(mine), 1), 5),
+                                           **format_rate(6.0 * plan.n + 4.0 * H * W, kernel_ms)})
         line["ranks_seen"] = [{k: x for k, x in s.items() if k != "variances"} for s in seen]
         merged = {}
         for s in seen:
