@@ -139,14 +139,18 @@ class ContrastMaximizationMixin(object):
         # fractional, i.e. undistorted, coordinates fall back to the full build inside)
         plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile=self.plan_tile(), emit="compact")
         self.history = []
-        if self.motion_model == "dense-flow":
-            flow = self._estimate_patch_flow(plan)
-        elif self.motion_model in ("2d-translation", "rigid-optical-flow"):
-            theta = self._estimate_translation(plan)
-            H, W = self.orig_image_shape
-            flow = (-theta).reshape(2, 1, 1).expand(2, H, W)  # dense flow equivalent of theta (src/warp.py:186-187)
-        else:
-            raise NotImplementedError(f"motion_model {self.motion_model!r}")
+        # The optimisation loops below call loss.backward() thousands of times on graphs of one or two nodes: with the autograd
+        # engine's device thread each call pays two thread hand-offs (~35 us of a ~100 us iteration, tools/bench_autograd.py);
+        # single-threaded, backward runs on the calling thread.  Restored on exit.
+        with torch.autograd.set_multithreading_enabled(False):
+            if self.motion_model == "dense-flow":
+                flow = self._estimate_patch_flow(plan)
+            elif self.motion_model in ("2d-translation", "rigid-optical-flow"):
+                theta = self._estimate_translation(plan)
+                H, W = self.orig_image_shape
+                flow = (-theta).reshape(2, 1, 1).expand(2, H, W)  # dense flow equivalent of theta (src/warp.py:186-187)
+            else:
+                raise NotImplementedError(f"motion_model {self.motion_model!r}")
         return flow.detach().cpu().numpy().astype(np.float64)
 
     def _warm_start(self):
