@@ -1107,6 +1107,19 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     tile_grid_finish<TH, TW, AP>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + PH + PW));
     flow = s_flow;
   } else {
+    // The upstream tile with every global read in flight at once: unconditional clamped loads, fully unrolled, issued before
+    // anything waits (a loop of bounds-checked loads is waited for one by one: 5.6 us of set-up per workgroup, in-kernel stamps)
+    constexpr int kStage = (LH * LW + kBlock - 1) / kBlock;
+    float raw[kStage];
+    // (not gated by "this item has events": that is known one round trip later than the tile's position)
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+      const int i = min((int)threadIdx.x + k * kBlock, LH * LW - 1);
+      const int rl = i / LW, cl = i - rl * LW;
+      const int R = min(max(oy + rl + pad_h, 0), G.h - 1), C = min(max(ox + cl + pad_w, 0), G.w - 1);
+      raw[k] = g_image[(int64_t)R * G.w + C];
+    }
+    const bool live = tr.g_first <= tr.g_last;
     if (var_moments != nullptr) {
       // g_image is the IWE itself and the loss is upstream * var(IWE): d var / d IWE = 2 (IWE - mean) / (M - 1), folded
       // in as an affine map (no d_iwe image, no separate affine kernel)
@@ -1115,10 +1128,14 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       G.c = (float)(-a * var_moments[0]);
     }
     for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
-    if (tr.g_first <= tr.g_last) {
-      for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        const int i = threadIdx.x + k * kBlock;
         const int rl = i / LW, cl = i - rl * LW;
-        s_g[i] = G.at(oy + rl + pad_h, ox + cl + pad_w);
+        const int R = oy + rl + pad_h, C = ox + cl + pad_w;
+        const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
+        if (i < LH * LW) s_g[i] = valid ? G.a * raw[k] + G.c : 0.0f;
       }
     }
   }
@@ -1360,6 +1377,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   if (part_out != nullptr) {  // partial tile [2][TH * TW] of this part, plain stores
     float* out = part_out + (int64_t)tr.slab * (LH * LW);
     for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) out[i] = (float)s_d[i];
+    EBOS_STAMP_BWD(5);
     return;
   }
   // every flow pixel belongs to exactly one tile: plain coalesced stores, zeros where no event lives
@@ -1373,6 +1391,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       d_flow[hw + o] = (float)s_d[TH * TW + i] + (addend ? addend[hw + o] : 0.0f);
     }
   }
+  EBOS_STAMP_BWD(5);
 }
 
 __global__ void __launch_bounds__(256) theta_grad_finalize_kernel(const double* __restrict__ partials, int ntiles, float* d_theta) {

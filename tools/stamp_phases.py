@@ -8,13 +8,33 @@ import event_based_bos_amd as ebos
 from event_based_bos_amd import _hip
 from bench import H, W, synth_window
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--events", type=int, default=10_000_000)
+ap.add_argument("--grid", action="store_true", help="the grid-sampling kernel of BASELINE configs[3] (30x40 patch grid) instead of a dense field")
+args = ap.parse_args()
 lib = _hip.require_gpu()
-raw = ctypes.CDLL(_hip.LIB_PATH)
-ev, fl = synth_window(10_000_000, 0)
-plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto")
+raw = ctypes.CDLL(os.environ.get("EBOS_HIP_LIBRARY", _hip.LIB_PATH))
+ev, fl = synth_window(args.events, 0)
+plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto", emit="compact")
 flow = torch.from_numpy(fl).float().cuda()
-for _ in range(5):
-    iwe = plan.iwe_dense(flow)
+if args.grid:
+    th, tw = plan.tile
+    gh, gw = ebos.solver.patch_grid_shape((H, W), (24, 32), (24, 32))
+    g = torch.from_numpy(np.random.RandomState(1).uniform(-30, 30, (2, gh, gw))).float().cuda()
+    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, th, tw, 32, 1, 0, 0))
+    ws = torch.zeros(nws, dtype=torch.uint8, device="cuda")
+    iwe = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    out = torch.empty(1, dtype=torch.float32, device="cuda")
+    mom = torch.empty((1, 2), dtype=torch.float64, device="cuda")
+    P = lambda t: None if t is None else t.data_ptr()
+    for _ in range(5):
+        _hip.check(lib.ebos_iwe_patch_slab_f32(*plan._compact_ptrs(), P(plan.key_offsets), plan.n, P(g), gh, gw, 24, 32, 24, 32, H, W, th, tw,
+                                               32, 1, 0, 0, P(ws), nws, P(iwe), 1, 0, P(out), P(mom), P(plan.part_table),
+                                               torch.cuda.current_stream().cuda_stream), "ebos_iwe_patch_slab")
+else:
+    for _ in range(5):
+        iwe = plan.iwe_dense(flow)
 torch.cuda.synchronize()
 n = 256
 buf = (ctypes.c_ulonglong * (n * 8))()

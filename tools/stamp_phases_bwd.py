@@ -12,11 +12,27 @@ from bench import H, W, synth_window
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--events", type=int, default=2_000_000)
+ap.add_argument("--dense", action="store_true", help="the dense-field backward kernel (plan.variance_and_grad_dense) instead of the solver loop's")
 a = ap.parse_args()
 lib = _hip.require_gpu()
-raw = ctypes.CDLL(_hip.LIB_PATH)
+raw = ctypes.CDLL(os.environ.get("EBOS_HIP_LIBRARY", _hip.LIB_PATH))
 ev, _ = synth_window(a.events, 0)
 plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto")
+if a.dense:
+    flow = torch.from_numpy(synth_window(16, 0)[1]).float().cuda()
+    for _ in range(5):
+        plan.variance_and_grad_dense(flow)
+    torch.cuda.synchronize()
+    n = 256
+    buf = (ctypes.c_ulonglong * (n * 8))()
+    raw.ebos_debug_read_stamps_bwd(buf, n * 8)
+    st = np.array(buf[:], dtype=np.float64).reshape(n, 8)[:, [0, 2, 3, 4, 5]] * 10.0  # ns (stamp 1 belongs to the grid kernel)
+    t0 = st[:, 0].min()
+    print(f"dense backward, {a.events} events: kernel span {(st[:, 4].max() - t0) / 1e3:.2f} us; start skew max {(st[:, 0].max() - t0) / 1e3:.2f} us")
+    for i, nm in enumerate(["clear + upstream tile staging", "main loop (lane-0 wave)", "wait for other waves", "d_flow tile store"]):
+        d = st[:, i + 1] - st[:, i]
+        print(f"  {nm:40s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
+    sys.exit(0)
 gh, gw = ebos.solver.patch_grid_shape((H, W), (24, 32), (24, 32))
 loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, lr=0.1, capacity=64)
 loop.run(40)
