@@ -82,6 +82,38 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
   return r;
 }
 
+// two block-wide sums at once, in the order block_sum uses for each (bit-identical results): the shuffles of the two values
+// overlap and the pair costs two barriers instead of four.  `red` holds >= 2 * blockDim.x / 64 items.  Results valid in thread 0.
+template <typename T>
+__device__ __forceinline__ void block_sum2(T& a, T& b, T* red) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+  const int nw = (blockDim.x + kWave - 1) / kWave;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const T oa = __shfl_down(a, off, kWave), ob = __shfl_down(b, off, kWave);
+    a += oa;
+    b += ob;
+  }
+  if (lane == 0) {
+    red[wid] = a;
+    red[nw + wid] = b;
+  }
+  __syncthreads();
+  T ra = (threadIdx.x < nw) ? red[threadIdx.x] : T(0), rb = (threadIdx.x < nw) ? red[nw + threadIdx.x] : T(0);
+  if (wid == 0) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      const T oa = __shfl_down(ra, off, kWave), ob = __shfl_down(rb, off, kWave);
+      ra += oa;
+      rb += ob;
+    }
+  }
+  __syncthreads();
+  a = ra;
+  b = rb;
+}
+
 // hardware float atomics (no CAS loop): global_atomic_add_f32 / _f64, ds_add_f32 / _f64
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }

@@ -758,9 +758,8 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
   if (partials != nullptr) {
     const bool in = C < w && R >= g_lo && R < h - g_lo && C >= g_lo && C < w - g_lo;
     double s = in ? (double)v : 0.0, ss = in ? (double)v * (double)v : 0.0;
-    __shared__ double red[kCombineBlock / kWave];
-    s = block_sum(s, red);
-    ss = block_sum(ss, red);
+    __shared__ double red[2 * kCombineBlock / kWave];
+    block_sum2(s, ss, red);
     if (threadIdx.x == 0) {
       const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
       partials[2 * b] = s;
@@ -831,9 +830,8 @@ iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tile
           ss += (double)e[k] * (double)e[k];
         }
     }
-    __shared__ double red[kCombineBlock / kWave];
-    s = block_sum(s, red);
-    ss = block_sum(ss, red);
+    __shared__ double red[2 * kCombineBlock / kWave];
+    block_sum2(s, ss, red);
     if (threadIdx.x == 0) {
       const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
       partials[2 * b] = s;
@@ -850,9 +848,8 @@ moments_finalize_kernel(const double* __restrict__ partials, int64_t nparts, int
     s += partials[2 * i];
     ss += partials[2 * i + 1];
   }
-  __shared__ double red[4];
-  s = block_sum(s, red);
-  ss = block_sum(ss, red);
+  __shared__ double red[8];
+  block_sum2(s, ss, red);
   if (threadIdx.x == 0) {
     const double mean = m > 0 ? s / (double)m : 0.0;
     if (out) out[0] = (float)((ss - s * mean) / (double)(m - 1));
@@ -1069,9 +1066,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
         sm += mj.partials[2 * i];
         sq += mj.partials[2 * i + 1];
       }
-      __shared__ double red_m[kBlock / kWave];
-      sm = block_sum(sm, red_m);
-      sq = block_sum(sq, red_m);
+      __shared__ double red_m[2 * kBlock / kWave];
+      block_sum2(sm, sq, red_m);
       if (threadIdx.x == 0) {
         const double mean = mj.n_pixels > 0 ? sm / (double)mj.n_pixels : 0.0;
         s_mom[0] = mean;
@@ -1256,9 +1252,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   __syncthreads();
 
   if (UNIFORM) {
-    __shared__ double red[kBlock / kWave];
-    tot_x = block_sum(tot_x, red);
-    tot_y = block_sum(tot_y, red);
+    __shared__ double red[2 * kBlock / kWave];
+    block_sum2(tot_x, tot_y, red);
     if (threadIdx.x == 0) {
       partials[2 * blockIdx.x] = tot_x;
       partials[2 * blockIdx.x + 1] = tot_y;
@@ -1400,9 +1395,8 @@ __global__ void __launch_bounds__(256) theta_grad_finalize_kernel(const double* 
     sx += partials[2 * i];
     sy += partials[2 * i + 1];
   }
-  __shared__ double red[4];
-  sx = block_sum(sx, red);
-  sy = block_sum(sy, red);
+  __shared__ double red[8];
+  block_sum2(sx, sy, red);
   if (threadIdx.x == 0) {
     d_theta[0] = (float)sx;
     d_theta[1] = (float)sy;
