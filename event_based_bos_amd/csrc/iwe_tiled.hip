@@ -26,6 +26,7 @@
 // their autograd w.r.t. the flow and the per-event weight (backward).
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include <hip/hip_ext.h>
@@ -603,7 +604,8 @@ __device__ __forceinline__ long long fx_hi(long long v) { return (v - fx_lo(v)) 
 template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false>
 __global__ void __launch_bounds__(kBlock)
 iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
-                           int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill, GridSrc gs) {
+                           int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill, GridSrc gs,
+                           unsigned* __restrict__ spill_epoch, unsigned epoch) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr int kCells = LH * LW + LW / 2 + 2;  // + a dummy region that absorbs the adds of out-of-window lanes
   static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
@@ -643,6 +645,9 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   EBOS_STAMP(2);
   __syncthreads();
   EBOS_STAMP(3);
+  // SpillEpoch: a workgroup that puts anything into the spill image stamps the workspace with this call's number; the combine
+  // pass reads the 3.7 MB spill image only if the stamp is this call's (it is all zero otherwise, and stays so)
+  if (s_flag[1] && threadIdx.x == 0) *spill_epoch = epoch;  // benign race: every writer stores the same value
   if (s_flag[1])  // rare: taps beyond the halo go to the spill image with global atomics (lean path: minus their units)
     added -= accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
                                                                                          nullptr, queue);
@@ -723,7 +728,8 @@ template <int TH, int TW, int HALO>
 __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
-                        const int32_t* __restrict__ part_off) {
+                        const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch) {
+  const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
   const int R = blockIdx.y, C = blockIdx.x * kCombineBlock + threadIdx.x;
@@ -748,7 +754,7 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
       }
     }
     const int64_t gi = (int64_t)R * w + C;
-    const float sp = spill[gi];
+    const float sp = spill_used ? spill[gi] : 0.0f;
     if (sp != 0.0f) {
       v += sp;
       spill[gi] = 0.0f;  // keep the spill image zero between calls
@@ -776,7 +782,8 @@ template <int TH, int TW, int HALO>
 __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
                          int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
-                         const int32_t* __restrict__ part_off) {
+                         const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch) {
+  const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   static_assert(HALO % 4 == 0 && TW % 4 == 0, "vector combine needs 4-aligned windows");
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
@@ -809,7 +816,7 @@ iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tile
       }
     }
     const int64_t gi = (int64_t)R * w + C;
-    const float4 s4 = *reinterpret_cast<const float4*>(spill + gi);
+    const float4 s4 = spill_used ? *reinterpret_cast<const float4*>(spill + gi) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (s4.x != 0.f || s4.y != 0.f || s4.z != 0.f || s4.w != 0.f) {
       v.x += s4.x;
       v.y += s4.y;
@@ -1446,7 +1453,7 @@ constexpr int kNumSlabConfigs = sizeof(kSlabConfigs) / sizeof(kSlabConfigs[0]);
 struct SlabLayout {
   int tiles_y, tiles_x, nblk, h, w, combine_blocks;
   size_t slab_cells;   // per workgroup
-  size_t off_spill, off_partials, total;
+  size_t off_spill, off_partials, off_epoch, total;
 };
 
 constexpr int kAdaptiveItemsPerTile = 2;  // work items of an adaptive plan = 2 x tiles (ebos_plan_parts)
@@ -1463,8 +1470,18 @@ inline SlabLayout slab_layout(int H, int W, int th, int tw, int halo, int splits
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
   L.off_spill = align((size_t)L.nblk * L.slab_cells * sizeof(float));
   L.off_partials = L.off_spill + align((size_t)L.h * L.w * sizeof(float));
-  L.total = L.off_partials + align((size_t)L.combine_blocks * 2 * sizeof(double));
+  L.off_epoch = L.off_partials + align((size_t)L.combine_blocks * 2 * sizeof(double));  // SpillEpoch word
+  L.total = L.off_epoch + 256;
   return L;
+}
+
+// SpillEpoch: every forward call gets a number of its own (never 0: a zero-filled workspace matches no call).  Host-side state
+// only; a replayed HIP graph repeats its number, which can only make a combine pass read an all-zero spill image it could skip.
+inline unsigned next_spill_epoch() {
+  static std::atomic<unsigned> counter{0};
+  unsigned e = counter.fetch_add(1, std::memory_order_relaxed) + 1;
+  if (e == 0) e = counter.fetch_add(1, std::memory_order_relaxed) + 1;
+  return e;
 }
 
 template <typename K>
@@ -1502,8 +1519,10 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   float* slabs = reinterpret_cast<float*>(ws);
   float* spill = reinterpret_cast<float*>(ws + L.off_spill);
   double* partials = reinterpret_cast<double*>(ws + L.off_partials);
+  unsigned* spill_epoch = reinterpret_cast<unsigned*>(ws + L.off_epoch);
+  const unsigned epoch = next_spill_epoch();
   // unit weights -> verified fixed point (2 ds_add_u64 per event); per-event weights -> f64 (any magnitude/sign)
-  void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*, GridSrc);
+  void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*, GridSrc, unsigned*, unsigned);
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   GridSrc gs{};
 #define EBOS_PICK(HW, MD)                                                                                              \
@@ -1533,9 +1552,10 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   hipEvent_t t0, t1;
   if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_ACCUMULATE))  // bench.py's roofline leg: events stamped with this dispatch's begin / end
     hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, L.tiles_x,
-                          splits, pad_h, pad_w, slabs, spill, gs);
+                          splits, pad_h, pad_w, slabs, spill, gs, spill_epoch, epoch);
   else
-    ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill, gs);
+    ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill, gs,
+                                                         spill_epoch, epoch);
   int64_t nparts;
   if (L.w % 4 == 0 && pad_w % 4 == 0) {
     dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows);
@@ -1543,19 +1563,19 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
     if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_COMBINE))
       hipExtLaunchKernelGGL((iwe_slab_combine4_kernel<TH, TW, HALO>), gb, dim3(kCombineBlock), 0, s, t0, t1, 0, slabs, spill, L.tiles_y,
                             L.tiles_x, splits, H, W, pad_h, pad_w, iwe, omit ? 1 : 0, want_var ? partials : nullptr,
-                            splits == 0 ? ev.part_off : nullptr);
+                            splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch);
     else
       iwe_slab_combine4_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
                                                                                pad_h, pad_w, iwe, omit ? 1 : 0,
                                                                                want_var ? partials : nullptr,
-                                                                               splits == 0 ? ev.part_off : nullptr);
+                                                                               splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch);
   } else {
     dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
     nparts = (int64_t)gb.x * gb.y;
     iwe_slab_combine_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
                                                                             pad_h, pad_w, iwe, omit ? 1 : 0,
                                                                             want_var ? partials : nullptr,
-                                                                            splits == 0 ? ev.part_off : nullptr);
+                                                                            splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch);
   }
   if (want_var == 1) {  // want_var == 2: the caller reduces the partials itself (ebos_iwe_slab_partials)
     const int lo = omit ? 1 : 0;

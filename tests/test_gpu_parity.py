@@ -546,6 +546,35 @@ def test_2dof_tile_private_sweep(ebos):
         assert rel(i2[k].cpu().numpy(), ref.numpy()) < 1e-5
 
 
+def test_spill_image_is_consumed_by_the_call_that_wrote_it(ebos):
+    """Taps beyond the halo go to the workspace's spill image and the combine pass reads that image only when THIS call's
+    accumulate pass stamped the workspace (csrc/iwe_tiled.hip, SpillEpoch).  Alternate calls that spill with calls that do not, on
+    one plan (= one workspace): every result must match the oracle, in either order, and the calls that do not spill repeat
+    bit for bit whatever ran before them."""
+    h, w, n = 96, 128, 40_000
+    ev = O.synth_events(n, h, w, seed=77)
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile=(32, 32))
+    thetas = [[3.0, -2.0], [60.0, -55.0], [0.5, 0.25], [-70.0, 48.0], [3.0, -2.0], [-70.0, 48.0], [0.5, 0.25]]  # halo 16: the big ones spill
+    seen = {}
+    for k, th in enumerate(thetas):
+        iwe = plan.iwe_2dof(G(np.array([th]), torch.float32), halo=16)[0].cpu().numpy()
+        ref = O.iwe_2dof(torch.from_numpy(ev), torch.tensor(th, dtype=torch.float64), (h, w)).numpy()
+        assert rel(iwe, ref) < 1e-5, (k, th)
+        key = tuple(th)
+        if key in seen and max(abs(th[0]), abs(th[1])) <= 16:  # (spill taps are global float atomics: order-dependent rounding)
+            assert np.array_equal(seen[key], iwe), (k, th)
+        seen[key] = iwe
+    # dense flow: a field whose left half stays inside the halo and whose right half leaves it, then a small field again
+    rs = np.random.RandomState(5)
+    small = rs.uniform(-8, 8, (2, h, w))
+    big = small.copy()
+    big[:, :, w // 2:] = rs.uniform(40, 70, (2, h, w - w // 2))
+    for k, fl in enumerate([small, big, small, big]):
+        iwe = plan.iwe_dense(G(fl, torch.float32), halo=16).cpu().numpy()
+        ref = O.iwe_dense(torch.from_numpy(ev), torch.from_numpy(fl), (h, w)).numpy()
+        assert rel(iwe, ref) < 1e-5, k
+
+
 def test_non_finite_events_are_contained(ebos):
     """NaN / Inf coordinates and timestamps: the reference poisons pixel 0 (NaN * 0 in the masked scatter); here
     such taps are dropped and every other pixel is unaffected."""
