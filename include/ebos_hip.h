@@ -314,7 +314,9 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  *   want_variance = 2: only the (sum, sum of squares) partials are left in the workspace (ebos_iwe_slab_partials),
  *   no finalize launch; out_variance / moments are not touched.
  *   workspace: >= ebos_iwe_slab_workspace_bytes(...) bytes, ZERO-FILLED ONCE by the caller when it is
- *   allocated; the kernels keep its spill section (taps beyond the halo) zero between calls.
+ *   allocated; the kernels keep its spill section (taps beyond the halo) zero between calls, and a word behind the partials
+ *   holds the number of the last call whose accumulate pass wrote spill taps (the combine pass reads the spill section only
+ *   for that call).  One workspace serves one stream at a time.
  *   Results are deterministic (fixed summation order) except for taps beyond the halo.
  *   splits >= 1: every tile is cut into `splits` equal parts (workgroups); splits = 0: the adaptive work items of
  *   part_table (ebos_plan_parts; NULL otherwise).
