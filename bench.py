@@ -79,6 +79,9 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=3, help="configs 4 / 5: independent windows / hypotheses kept in flight per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative legs (fwd+bwd, streams, rotating windows, solver)")
+    ap.add_argument("--batch", type=int, default=64, help="config 4: windows per ebos_iwe_slab_batch_f32 call (16 per launch inside); 0 = one call per window")
+    ap.add_argument("--no-tail-stream", action="store_true", help="config 4, batched: combine / finalize passes on the same stream as the accumulate passes")
+    ap.add_argument("--no-graph", action="store_true", help="config 4: enqueue every window's calls from Python instead of replaying a captured pass")
     ap.add_argument("--no-compact", action="store_true", help="read the 12 B/event (x, y, dt) plan instead of 6 B/event")
     ap.add_argument("--cpu-sample", type=int, default=N_EVENTS, help="events of the window the CPU baseline is timed on")
     ap.add_argument("--rotating-windows", type=int, default=8, help="distinct 10 M-event plans cycled by the cache-cold leg")
@@ -687,9 +690,9 @@ def run_config4(R):
               torch.empty((H, W), dtype=torch.float32, device=dev), torch.empty((1, 2), dtype=torch.float64, device=dev))
              for _ in range(n_lanes)]
     outs = torch.empty(max(len(mine), 1), dtype=torch.float32, device=dev)
-    main = torch.cuda.current_stream(dev)
 
-    def step():
+    def eager_step():
+        main = torch.cuda.current_stream(dev)
         if n_lanes > 1:
             for st, _, _, _ in lanes:
                 st.wait_stream(main)
@@ -698,14 +701,69 @@ def run_config4(R):
             _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), gh, gw, ph, pw, sh, sw, H, W,
                                                    a.tile[0], a.tile[1], a.halo, splits, 0, 0, P(ws), nws, P(iwe), 1, 0,
                                                    outs.data_ptr() + 4 * k, P(moments), P(pl.part_table),
-                                                   st.cuda_stream if st is not None else stream),
+                                                   st.cuda_stream if st is not None else main.cuda_stream),
                        "ebos_iwe_patch_slab")
         if n_lanes > 1:
             for st, _, _, _ in lanes:
                 main.wait_stream(st)
 
+    # One pass is 3 launches x the rank's windows through a 35-argument C call each: enqueued from Python it is HOST-bound (0.86 ms
+    # of host time for 64 windows against < 0.8 ms of GPU work).  The pass is therefore captured once as a HIP graph (fork / join
+    # over the side streams) and replayed -- the launch-bound inner loop the solver's FusedPatchLoop replays the same way.
+    # --no-graph: enqueue every call from Python.
+    def measure_enqueue(fn):
+        enq = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            enq.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+        return statistics.median(enq) * 1e3
+
+    eager_step()  # (first call: reserves LDS, creates workspaces' state)
+    torch.cuda.synchronize()
+    eager_enqueue_ms = measure_enqueue(eager_step)
+    step, graphed = eager_step, False
+    if not a.no_graph and plans:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=dev)
+            cap.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.graph(graph, stream=cap):
+                eager_step()
+            torch.cuda.synchronize()
+            step, graphed = graph.replay, True
+        except Exception as e:  # capture not possible: the eager pass stays
+            sys.stderr.write(f"[bench] config 4: graph capture failed ({type(e).__name__}: {e}); eager pass\n")
+            torch.cuda.synchronize()
+    first = outs[:len(mine)].clone()
+    # --batch B (default 16): the rank's windows go through ebos_iwe_slab_batch_f32, B windows per accumulate / combine / finalize
+    # launch; the combine / finalize passes of one batch run on a second stream beside the accumulate pass of the next.
+    # Same kernels' bodies, same bits as the per-window calls (checked below).  --batch 0: per-window calls.
+    batches = []
+    if a.batch > 0 and plans:
+        tail = torch.cuda.Stream(device=dev)
+        # (one call per --batch windows; inside a call the library launches 16 windows at a time and joins the tail stream at its end)
+        for b0 in range(0, len(plans), a.batch):
+            batches.append(ebos.SlabBatch(plans[b0:b0 + a.batch], grids[b0:b0 + a.batch], patch=((ph, pw), (sh, sw)), halo=a.halo,
+                                          splits=splits))
+
+        def batch_step():  # accumulate passes back to back on the current stream, combine / finalize passes beside them on `tail`
+            for bt in batches:
+                bt.run(tail_stream=None if a.no_tail_stream else tail.cuda_stream)
+
+        batch_step()
+        torch.cuda.synchronize()
+        got = torch.cat([bt.variances for bt in batches])
+        if not torch.equal(first, got):
+            raise SystemExit(f"config 4: batched contrasts differ from the per-window calls: {first[:4].tolist()} vs {got[:4].tolist()}")
+        step, graphed = batch_step, False
     blocks, _ = R.timed_blocks(step, lib, _hip.PROFILE_SLAB_ACCUMULATE, launches_per_step=max(len(mine), 1), profile_blocks=0)
     elapsed = statistics.median(blocks)
+    if graphed and not torch.equal(first, outs[:len(mine)]):
+        raise SystemExit("config 4: the replayed graph's contrasts differ from the eager pass")
+    host_enqueue_ms = measure_enqueue(step)
     # roofline leg: the kernel timed on ONE stream, back to back (a dispatch that shares the chip with its neighbours' kernels
     # has no clean begin-to-end time)
     import ctypes
@@ -745,6 +803,10 @@ def run_config4(R):
         line["windows_evaluated"] = len(merged)
         line["contrast_first_windows"] = [merged[k] for k in sorted(merged)[:4]]
         line["ingest_s_this_rank"] = round(ingest_s, 2)
+        line["host_enqueue_ms_per_step"] = round(host_enqueue_ms, 4)
+        line["pass_is_a_replayed_hip_graph"] = graphed
+        line["windows_per_launch"] = min(a.batch, 16) if batches else 1
+        line["host_enqueue_ms_per_step_eager"] = round(eager_enqueue_ms, 4)
         print(json.dumps(line))
 
 

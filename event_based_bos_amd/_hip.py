@@ -103,6 +103,7 @@ SIGNATURES = {
     "ebos_upsample_patch_flow_bwd_adam_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _D, _D, _D, _D, _I, _P,
                                                    _P, _F, _P, _I, _P, _I, _P, _P]),
     "ebos_patch_fused_supported": (_I, [_I, _I, _I, _I, _I]),
+    "ebos_iwe_slab_batch_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _Z, _I, _I, _P, _P]),
     "ebos_iwe_patch_slab_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I,
                                      _P, _P, _P, _P]),
     "ebos_patch_grad_partials_bytes": (_Z, [_I, _I, _I, _I, _I]),
@@ -145,6 +146,12 @@ class DenseJob(C.Structure):
     _fields_ = ([(k, _P) for k in ("xs", "ys", "dts", "grp_offsets", "cpix", "cdt", "key_offsets")] + [("n", _L)] +
                 [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "splits", "pad_h", "pad_w", "omit_boundary")] +
                 [("workspace", _P), ("workspace_bytes", _Z), ("part_table", _P), ("iwe", _P), ("moments", _P)])
+
+
+class SlabWindow(C.Structure):
+    """``ebos_slab_window`` of include/ebos_hip.h (same field order): one window of ``ebos_iwe_slab_batch_f32``."""
+    _fields_ = [(k, _P) for k in ("grp_offsets", "cpix", "cdt", "key_offsets", "part_table", "flow", "workspace", "iwe",
+                                  "out_variance", "moments")]
 
 
 _lib: Optional[C.CDLL] = None

@@ -601,11 +601,12 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 __device__ __forceinline__ long long fx_lo(long long v) { return (long long)(int)(unsigned)(v & 0xffffffffll); }
 __device__ __forceinline__ long long fx_hi(long long v) { return (v - fx_lo(v)) >> 32; }
 
+// the accumulate pass of one work item (blockIdx.x) of one window: shared by the single-window and the batched kernel
 template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false>
-__global__ void __launch_bounds__(kBlock)
-iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
-                           int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill, GridSrc gs,
-                           unsigned* __restrict__ spill_epoch, unsigned epoch) {
+__device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t* __restrict__ key_offsets,
+                                                const float* __restrict__ flow_arg, int H, int W, int tiles_x, int splits, int pad_h,
+                                                int pad_w, float* __restrict__ slabs, float* spill, const GridSrc& gs,
+                                                unsigned* __restrict__ spill_epoch, unsigned epoch) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   constexpr int kCells = LH * LW + LW / 2 + 2;  // + a dummy region that absorbs the adds of out-of-window lanes
   static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
@@ -719,6 +720,45 @@ iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   EBOS_STAMP(4);
 }
 
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false>
+__global__ void __launch_bounds__(kBlock)
+iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
+                           int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill, GridSrc gs,
+                           unsigned* __restrict__ spill_epoch, unsigned epoch) {
+  accumulate_tile<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID>(ev, key_offsets, flow_arg, H, W, tiles_x, splits, pad_h, pad_w, slabs,
+                                                                 spill, gs, spill_epoch, epoch);
+}
+
+// ---- several independent windows of one geometry in ONE launch (ebos_iwe_slab_batch_f32) ---------------------------------
+// Thin windows (BASELINE configs[3]: 2 M events) are bound by per-launch and per-workgroup fixed work, and at one workgroup per CU
+// consecutive accumulate launches cannot overlap: batched, a CU starts the next window's workgroup the moment it has finished
+// this one's.  The windows' pointers travel by value in the kernel arguments (blockIdx.y / .z selects the window).
+struct FwdWindow {
+  EvPtrs ev;
+  const int32_t* key_offsets;
+  const float* flow;     // [2, H, W] or the patch grid [2, gh, gw]
+  float* slabs;          // this window's workspace sections
+  float* spill;
+  unsigned* spill_epoch;
+  double* partials;
+  float* iwe;
+  float* out_var;        // nullable
+  double* moments;       // nullable
+};
+constexpr int kMaxBatch = 16;
+struct FwdBatch {
+  FwdWindow w[kMaxBatch];
+};
+static_assert(sizeof(FwdBatch) <= 3072, "the batch travels in the kernel argument segment");
+
+template <int TH, int TW, int HALO, bool GRID>
+__global__ void __launch_bounds__(kBlock)
+iwe_slab_accumulate_batch_kernel(FwdBatch b, int H, int W, int tiles_x, int splits, int pad_h, int pad_w, GridSrc gs, unsigned epoch) {
+  const FwdWindow& w = b.w[blockIdx.y];
+  accumulate_tile<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, GRID>(w.ev, w.key_offsets, w.flow, H, W, tiles_x, splits, pad_h, pad_w,
+                                                                         w.slabs, w.spill, gs, w.spill_epoch, epoch);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward B: combine slabs (+ spill) -> IWE, optional variance moments of the row segment
 // ---------------------------------------------------------------------------------------------------
@@ -779,10 +819,10 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
 constexpr int kCombineRows = 4;
 
 template <int TH, int TW, int HALO>
-__global__ void __launch_bounds__(kCombineBlock)
-iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
-                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
-                         const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch) {
+__device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
+                                               int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo,
+                                               double* __restrict__ partials, const int32_t* __restrict__ part_off,
+                                               const unsigned* __restrict__ spill_epoch, unsigned epoch) {
   const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   static_assert(HALO % 4 == 0 && TW % 4 == 0, "vector combine needs 4-aligned windows");
@@ -847,9 +887,27 @@ iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tile
   }
 }
 
+template <int TH, int TW, int HALO>
+__global__ void __launch_bounds__(kCombineBlock)
+iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
+                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
+                         const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch) {
+  combine4_block<TH, TW, HALO>(slabs, spill, tiles_y, tiles_x, splits, H, W, pad_h, pad_w, iwe, g_lo, partials, part_off, spill_epoch,
+                               epoch);
+}
+
+template <int TH, int TW, int HALO>
+__global__ void __launch_bounds__(kCombineBlock)
+iwe_slab_combine4_batch_kernel(FwdBatch b, int tiles_y, int tiles_x, int splits, int H, int W, int pad_h, int pad_w, int g_lo,
+                               int want_var, unsigned epoch) {
+  const FwdWindow& w = b.w[blockIdx.z];
+  combine4_block<TH, TW, HALO>(w.slabs, w.spill, tiles_y, tiles_x, splits, H, W, pad_h, pad_w, w.iwe, g_lo,
+                               want_var ? w.partials : nullptr, splits == 0 ? w.ev.part_off : nullptr, w.spill_epoch, epoch);
+}
+
 // one workgroup: partials -> out (unbiased variance), moments (mean, M).  Fixed summation order.
-__global__ void __launch_bounds__(256)
-moments_finalize_kernel(const double* __restrict__ partials, int64_t nparts, int64_t m, float* out, double* moments) {
+__device__ __forceinline__ void moments_finalize_block(const double* __restrict__ partials, int64_t nparts, int64_t m, float* out,
+                                                       double* moments) {
   double s = 0.0, ss = 0.0;
   for (int64_t i = threadIdx.x; i < nparts; i += blockDim.x) {
     s += partials[2 * i];
@@ -865,6 +923,14 @@ moments_finalize_kernel(const double* __restrict__ partials, int64_t nparts, int
       moments[1] = (double)m;
     }
   }
+}
+__global__ void __launch_bounds__(256)
+moments_finalize_kernel(const double* __restrict__ partials, int64_t nparts, int64_t m, float* out, double* moments) {
+  moments_finalize_block(partials, nparts, m, out, moments);
+}
+__global__ void __launch_bounds__(256) moments_finalize_batch_kernel(FwdBatch b, int64_t nparts, int64_t m) {
+  const FwdWindow& w = b.w[blockIdx.x];
+  moments_finalize_block(w.partials, nparts, m, w.out_var, w.moments);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1484,6 +1550,36 @@ inline unsigned next_spill_epoch() {
   return e;
 }
 
+// stream-ordering events of the batched entry (fork to / join from its tail stream): a small ring of timing-free events, created
+// on first use.  Re-recording an event does not disturb the waits already enqueued on its previous record.
+// (an event that could not be created is nullptr: order_after then reports the failure)
+inline hipEvent_t next_order_event() {
+  constexpr int kRing = 64;
+  static hipEvent_t ring[kRing];
+  static std::atomic<unsigned> created{0}, cursor{0};
+  static std::atomic_flag lock = ATOMIC_FLAG_INIT;
+  if (created.load(std::memory_order_acquire) == 0) {
+    while (lock.test_and_set(std::memory_order_acquire)) {}
+    if (created.load(std::memory_order_relaxed) == 0) {
+      for (int i = 0; i < kRing; ++i)
+        if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) ring[i] = nullptr;
+      created.store(1, std::memory_order_release);
+    }
+    lock.clear(std::memory_order_release);
+  }
+  return ring[cursor.fetch_add(1, std::memory_order_relaxed) % kRing];
+}
+
+// make `later` wait for everything enqueued on `earlier` so far
+inline int order_after(hipStream_t later, hipStream_t earlier, const char* what) {
+  hipEvent_t ev = next_order_event();
+  if (ev == nullptr || hipEventRecord(ev, earlier) != hipSuccess || hipStreamWaitEvent(later, ev, 0) != hipSuccess) {
+    set_error("%s: cannot order the tail stream (%s)", what, hipGetErrorString(hipGetLastError()));
+    return EBOS_ERR_LAUNCH;
+  }
+  return EBOS_OK;
+}
+
 template <typename K>
 int reserve_lds(K kern, size_t lds, const char* what) {
   if (lds > 64 * 1024 &&
@@ -1581,6 +1677,63 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
     const int lo = omit ? 1 : 0;
     const int64_t m = (int64_t)(L.h - 2 * lo > 0 ? L.h - 2 * lo : 0) * (L.w - 2 * lo > 0 ? L.w - 2 * lo : 0);
     moments_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, nparts, m, out_var, moments);
+  }
+  return EBOS_OK;
+}
+
+// n <= kMaxBatch windows of one geometry: accumulate, combine and finalize each as ONE launch over (work item, window)
+template <int TH, int TW, int HALO>
+int launch_slab_fwd_batch(const FwdBatch& b, int n, int H, int W, int splits, int pad_h, int pad_w, int want_var, int omit,
+                          hipStream_t s, hipStream_t s_tail, const GridSrc* grid_src) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  size_t lds = ((size_t)LH * LW + LW / 2 + 2) * sizeof(double);
+  const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
+  if (!(L.w % 4 == 0 && pad_w % 4 == 0)) {
+    set_error("ebos_iwe_slab_batch: needs image and padding widths that are multiples of 4 (call the single-window entry)");
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  const unsigned epoch = next_spill_epoch();
+  GridSrc gs{};
+  hipEvent_t t0, t1;
+  if (grid_src != nullptr) {
+    if constexpr (grid_fwd_fits<TH, TW, HALO>()) {
+      auto ka = iwe_slab_accumulate_batch_kernel<TH, TW, HALO, true>;
+      lds += grid_lds_extra<TH, TW, 0>();
+      gs = *grid_src;
+      if (int rc = reserve_lds(ka, lds, "ebos_iwe_slab_batch")) return rc;
+      if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_ACCUMULATE))
+        hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk, (unsigned)n), dim3(kBlock), lds, s, t0, t1, 0, b, H, W, L.tiles_x, splits, pad_h,
+                              pad_w, gs, epoch);
+      else
+        ka<<<dim3((unsigned)L.nblk, (unsigned)n), dim3(kBlock), lds, s>>>(b, H, W, L.tiles_x, splits, pad_h, pad_w, gs, epoch);
+    } else {
+      set_error("ebos_iwe_slab_batch: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
+      return EBOS_ERR_UNSUPPORTED;
+    }
+  } else {
+    auto ka = iwe_slab_accumulate_batch_kernel<TH, TW, HALO, false>;
+    if (int rc = reserve_lds(ka, lds, "ebos_iwe_slab_batch")) return rc;
+    if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_ACCUMULATE))
+      hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk, (unsigned)n), dim3(kBlock), lds, s, t0, t1, 0, b, H, W, L.tiles_x, splits, pad_h,
+                            pad_w, gs, epoch);
+    else
+      ka<<<dim3((unsigned)L.nblk, (unsigned)n), dim3(kBlock), lds, s>>>(b, H, W, L.tiles_x, splits, pad_h, pad_w, gs, epoch);
+  }
+  // the combine + finalize passes of this batch go to s_tail (when the caller gave one): they need no LDS and run beside the
+  // accumulate pass of the NEXT batch, which the caller enqueues on s right behind this one
+  if (s_tail != s)
+    if (int rc = order_after(s_tail, s, "ebos_iwe_slab_batch")) return rc;
+  const dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows, (unsigned)n);
+  if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_COMBINE))
+    hipExtLaunchKernelGGL((iwe_slab_combine4_batch_kernel<TH, TW, HALO>), gb, dim3(kCombineBlock), 0, s_tail, t0, t1, 0, b, L.tiles_y,
+                          L.tiles_x, splits, H, W, pad_h, pad_w, omit ? 1 : 0, want_var, epoch);
+  else
+    iwe_slab_combine4_batch_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s_tail>>>(b, L.tiles_y, L.tiles_x, splits, H, W, pad_h,
+                                                                                        pad_w, omit ? 1 : 0, want_var, epoch);
+  if (want_var == 1) {
+    const int lo = omit ? 1 : 0;
+    const int64_t m = (int64_t)(L.h - 2 * lo > 0 ? L.h - 2 * lo : 0) * (L.w - 2 * lo > 0 ? L.w - 2 * lo : 0);
+    moments_finalize_batch_kernel<<<dim3((unsigned)n), dim3(256), 0, s_tail>>>(b, (int64_t)gb.x * gb.y, m);
   }
   return EBOS_OK;
 }
@@ -1809,6 +1962,77 @@ int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, co
   return iwe_slab_entry(&gs, nullptr, nullptr, nullptr, nullptr, grp_offsets, cpix, cdt, key_offsets, n, grid, H, W, tile_h, tile_w, halo,
                         splits, pad_h, pad_w, workspace, workspace_bytes, iwe, want_variance, omit_boundary, out_variance, moments,
                         part_table, stream);
+}
+
+int ebos_iwe_slab_batch_f32(const ebos_slab_window* windows, int n_windows, int gh, int gw, int patch_h, int patch_w, int slide_h,
+                            int slide_w, int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w,
+                            size_t workspace_bytes, int want_variance, int omit_boundary, ebos_stream_t stream,
+                            ebos_stream_t tail_stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(windows && n_windows >= 0, "ebos_iwe_slab_batch: NULL windows");
+  EBOS_REQUIRE(H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64, "ebos_iwe_slab_batch: bad sizes (splits=%d)",
+               splits);
+  const bool patch = gh > 0 || gw > 0;
+  if (patch) {
+    EBOS_REQUIRE(gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 && slide_h > 0 && slide_w > 0,
+                 "ebos_iwe_slab_batch: bad patch grid (%dx%d, patch %dx%d, slide %dx%d)", gh, gw, patch_h, patch_w, slide_h, slide_w);
+    if (!ebos_patch_fused_supported(tile_h, tile_w, halo, slide_h, slide_w)) {
+      set_error("ebos_iwe_slab_batch: tile %dx%d halo %d with sliding window %dx%d is outside ebos_patch_fused_supported", tile_h, tile_w,
+                halo, slide_h, slide_w);
+      return EBOS_ERR_UNSUPPORTED;
+    }
+  }
+  if (!slab_config_ok(tile_h, tile_w, halo)) {
+    set_error("ebos_iwe_slab_batch: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  const size_t need = ebos_iwe_slab_workspace_bytes(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w);
+  if (workspace_bytes < need) {
+    set_error("ebos_iwe_slab_batch: workspaces too small (%zu < %zu)", workspace_bytes, need);
+    return EBOS_ERR_SCRATCH;
+  }
+  const SlabLayout L = slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w);
+  const int n_tiles_ = L.tiles_y * L.tiles_x;
+  GridSrc gs{};
+  if (patch) gs = GridSrc{make_axis(gh, patch_h, slide_h, H), make_axis(gw, patch_w, slide_w, W)};
+  hipStream_t s = as_stream(stream);
+  hipStream_t s_tail = tail_stream ? as_stream(tail_stream) : s;
+  for (int first = 0; first < n_windows; first += kMaxBatch) {
+    const int n = n_windows - first < kMaxBatch ? n_windows - first : kMaxBatch;
+    FwdBatch b{};
+    for (int k = 0; k < n; ++k) {
+      const ebos_slab_window& q = windows[first + k];
+      EBOS_REQUIRE(q.grp_offsets && q.cpix && q.cdt && q.key_offsets && q.flow && q.workspace && q.iwe,
+                   "ebos_iwe_slab_batch: window %d: NULL plan / flow / workspace / iwe (compact plans with unit weights only)", first + k);
+      EBOS_REQUIRE(splits != 0 || q.part_table, "ebos_iwe_slab_batch: window %d: splits = 0 needs the plan's part_table", first + k);
+      EBOS_REQUIRE(want_variance != 1 || q.out_variance || q.moments, "ebos_iwe_slab_batch: window %d: variance without an output",
+                   first + k);
+      char* ws = reinterpret_cast<char*>(q.workspace);
+      const int32_t* pt = q.part_table;
+      FwdWindow& w = b.w[k];
+      w.ev = EvPtrs{nullptr, nullptr, nullptr, nullptr, q.grp_offsets, q.cpix, q.cdt, pt, pt ? pt + n_tiles_ + 1 : nullptr,
+                    pt ? pt + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
+      w.key_offsets = q.key_offsets;
+      w.flow = q.flow;
+      w.slabs = reinterpret_cast<float*>(ws);
+      w.spill = reinterpret_cast<float*>(ws + L.off_spill);
+      w.partials = reinterpret_cast<double*>(ws + L.off_partials);
+      w.spill_epoch = reinterpret_cast<unsigned*>(ws + L.off_epoch);
+      w.iwe = q.iwe;
+      w.out_var = q.out_variance;
+      w.moments = q.moments;
+    }
+    int rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL) \
+  launch_slab_fwd_batch<TH, TW, HL>(b, n, H, W, splits, pad_h, pad_w, want_variance, omit_boundary, s, s_tail, patch ? &gs : nullptr)
+    EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+    if (rc != EBOS_OK) return rc;
+  }
+  if (s_tail != s && n_windows > 0)  // join: work enqueued on `stream` after this call sees every window's results
+    if (int rc = order_after(s, s_tail, "ebos_iwe_slab_batch")) return rc;
+  EBOS_CHECK_LAUNCH("ebos_iwe_slab_batch");
+  return EBOS_OK;
 }
 
 int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,

@@ -540,6 +540,71 @@ def _workspace(plan: EventPlan, pad, halo, splits) -> torch.Tensor:
     return cache[key]
 
 
+class SlabBatch(object):
+    """Independent windows of one geometry evaluated by ``ebos_iwe_slab_batch_f32``: accumulate, combine and finalize each run as
+    one launch over (work item, window), 16 windows at a time -- the time windows of bos_event.py:144-220 when they are thin
+    (BASELINE configs[3]: 2 M events), where per-launch fixed work and the gaps between launches dominate.
+
+        batch = SlabBatch(plans, flows, patch=((24, 32), (24, 32)))   # flows: patch grids [2, gh, gw]; patch=None: dense [2, H, W]
+        batch.run()                      # -> variances [n] (device), batch.iwes [n, h, w]
+    The array of window descriptors is filled once; ``run`` is ONE C call.  Results are bit-identical to per-window calls."""
+
+    def __init__(self, plans, flows, patch=None, pad=(0, 0), halo: int = DEFAULT_HALO, splits: Optional[int] = None,
+                 omit_boundary: bool = False):
+        lib = _hip.require_gpu()
+        if not plans:
+            raise ValueError("SlabBatch: no windows")
+        p0 = plans[0]
+        H, W = p0.image_size
+        self.plans, self.flows = list(plans), [f.contiguous().float() for f in flows]
+        self.pad, self.halo, self.omit = (int(pad[0]), int(pad[1])), int(halo), bool(omit_boundary)
+        self.splits = p0.resolve_splits(splits)
+        for pl, fl in zip(self.plans, self.flows):
+            if pl.image_size != p0.image_size or pl.tile != p0.tile or not pl.compact or pl.device != p0.device:
+                raise ValueError("SlabBatch: windows must share image size, tile and device, and be compact (unit-weight) plans")
+            if pl.resolve_splits(splits) != self.splits:
+                raise ValueError("SlabBatch: windows must share the work-item mode (all adaptive or all with the same split count)")
+        if patch is None:
+            self.grid = (0, 0, 0, 0, 0, 0)
+            want = (2, H, W)
+        else:
+            (ph, pw), (sh, sw) = patch
+            gh, gw = self.flows[0].shape[-2:]
+            self.grid = (int(gh), int(gw), int(ph), int(pw), int(sh), int(sw))
+            want = (2, gh, gw)
+        for fl in self.flows:
+            if tuple(fl.shape) != want:
+                raise ValueError(f"SlabBatch: flow of shape {tuple(fl.shape)}, expected {want}")
+        n = len(self.plans)
+        dev = p0.device
+        self.nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, p0.tile[0], p0.tile[1], self.halo, self.splits, *self.pad))
+        self.workspaces = torch.zeros((n, (self.nws + 255) // 256 * 256), dtype=torch.uint8, device=dev)
+        self.iwes = torch.empty((n, H + 2 * self.pad[0], W + 2 * self.pad[1]), dtype=torch.float32, device=dev)
+        self.variances = torch.empty(n, dtype=torch.float32, device=dev)
+        self.moments = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        self.windows = (_hip.SlabWindow * n)()
+        P = lambda t: None if t is None else t.data_ptr()
+        for k, (pl, fl) in enumerate(zip(self.plans, self.flows)):
+            w = self.windows[k]
+            cp = pl._compact_ptrs()
+            w.grp_offsets, w.cpix, w.cdt = cp[0], cp[1], cp[2]
+            w.key_offsets, w.part_table, w.flow = P(pl.key_offsets), P(pl.part_table) if self.splits == 0 else None, P(fl)
+            w.workspace, w.iwe = self.workspaces[k].data_ptr(), self.iwes[k].data_ptr()
+            w.out_variance, w.moments = self.variances.data_ptr() + 4 * k, self.moments[k].data_ptr()
+        self._lib, self._tile, self._size = lib, p0.tile, (H, W)
+
+    def run(self, want_variance: bool = True, stream: Optional[int] = None, tail_stream: Optional[int] = None) -> torch.Tensor:
+        """``tail_stream`` (a raw HIP stream of the caller's): the combine / finalize passes of each 16 windows run there, beside
+        the accumulate pass of the next 16; the results are ordered on ``stream`` when the call returns either way."""
+        H, W = self._size
+        _hip.check(self._lib.ebos_iwe_slab_batch_f32(self.windows, len(self.plans), *self.grid, H, W, self._tile[0], self._tile[1],
+                                                     self.halo, self.splits, self.pad[0], self.pad[1], self.workspaces.shape[1],
+                                                     1 if want_variance else 0, 1 if self.omit else 0,
+                                                     _hip.stream_ptr() if stream is None else stream, tail_stream),
+                   "ebos_iwe_slab_batch")
+        return self.variances
+
+
 class _DenseJob(object):
     """``ebos_dense_job`` of one (plan, padding, halo, splits, omit_boundary) with the buffers it points at: filled once,
     after which an objective (+ gradient) evaluation is ONE C call with six arguments (``ebos_variance_dense_job_f32``)."""

@@ -415,6 +415,33 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
  * launches become three and the [2, H, W] flow / gradient fields disappear.
  * ---------------------------------------------------------------------------------------- */
 int ebos_patch_fused_supported(int tile_h, int tile_w, int halo, int slide_h, int slide_w);
+/* ebos_iwe_slab_batch_f32  n_windows INDEPENDENT windows of one geometry (the time windows of bos_event.py:144-220, BASELINE
+ *   configs[3]) per call: accumulate, combine and finalize each run as ONE launch over (work item, window) for up to 16 windows
+ *   at a time -- thin windows are bound by per-launch fixed work, and at one workgroup per CU consecutive accumulate launches
+ *   cannot overlap.  Per window: its compact plan (unit weights), its flow -- a dense field [2, H, W] when gh == gw == 0, else
+ *   a patch grid [2, gh, gw] (arguments as ebos_iwe_patch_slab_f32) --, its OWN workspace (each >= workspace_bytes >=
+ *   ebos_iwe_slab_workspace_bytes, zero-filled once), iwe [h, w] and variance outputs.  Needs w and pad_w multiples of 4.
+ *   Results are bit-identical to n_windows calls of ebos_iwe_dense_slab_f32 / ebos_iwe_patch_slab_f32.  `windows` is a HOST
+ *   array, read before the call returns.  tail_stream (nullable): a second stream of the caller's for the combine / finalize
+ *   passes, which need no LDS and then run beside the accumulate pass of the next 16 windows; `stream` is made to wait for it
+ *   before the call returns, so the results are ordered on `stream` either way. */
+typedef struct ebos_slab_window {
+  const int32_t* grp_offsets;  /* the window's compact plan (ebos_plan_lean / ebos_plan_events_*)                 */
+  const uint16_t* cpix;
+  const float* cdt;
+  const int32_t* key_offsets;
+  const int32_t* part_table;   /* adaptive work items (splits == 0), else nullable                               */
+  const float* flow;           /* [2, H, W], or the patch grid [2, gh, gw]                                        */
+  void* workspace;             /* this window's own, zero-filled once                                             */
+  float* iwe;                  /* [H + 2 pad_h, W + 2 pad_w], overwritten                                         */
+  float* out_variance;         /* [1], nullable                                                                   */
+  double* moments;             /* [2] (mean, M), nullable                                                         */
+} ebos_slab_window;
+int ebos_iwe_slab_batch_f32(const ebos_slab_window* windows, int n_windows, int gh, int gw, int patch_h, int patch_w, int slide_h,
+                            int slide_w, int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w,
+                            size_t workspace_bytes, int want_variance, int omit_boundary, ebos_stream_t stream,
+                            ebos_stream_t tail_stream);
+
 int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
                             const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw, int patch_h,
                             int patch_w, int slide_h, int slide_w, int H, int W, int tile_h, int tile_w, int halo,

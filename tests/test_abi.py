@@ -138,7 +138,8 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
-@pytest.mark.parametrize("c_name,py_name", [("ebos_cmax_patch_problem", "CmaxPatchProblem"), ("ebos_dense_job", "DenseJob")])
+@pytest.mark.parametrize("c_name,py_name", [("ebos_cmax_patch_problem", "CmaxPatchProblem"), ("ebos_dense_job", "DenseJob"),
+                                             ("ebos_slab_window", "SlabWindow")])
 def test_problem_struct_layout_matches_the_ctypes_mirror(tmp_path, c_name, py_name):
     """The structs of the ABI as a C compiler lays them out == the ctypes.Structure the host layer fills (size and every
     field offset): a field added on one side only, or a changed order, shows here and not as a wild pointer on the GPU."""

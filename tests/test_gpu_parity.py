@@ -575,6 +575,52 @@ def test_spill_image_is_consumed_by_the_call_that_wrote_it(ebos):
         assert rel(iwe, ref) < 1e-5, k
 
 
+@pytest.mark.parametrize("n_windows", [3, 18])
+def test_batched_windows_equal_per_window_calls(ebos, n_windows):
+    """ebos_iwe_slab_batch_f32 (SlabBatch): several independent windows per launch -- dense fields and patch grids, windows of
+    different event counts (one of them empty-ish), more windows than one launch holds (16): images and variances are
+    bit-identical to one call per window, and the first window also matches the oracle."""
+    h, w = 96, 128
+    rs = np.random.RandomState(3)
+    evs = [O.synth_events(int(n), h, w, seed=100 + k) for k, n in enumerate(rs.randint(50, 30_000, n_windows))]
+    plans = [ebos.EventPlan.build(G(e), (h, w), "first", True, tile=(32, 32), emit="compact") for e in evs]
+    assert all(p.compact for p in plans)
+    # dense fields (one of them leaves the halo: spill path inside a batch)
+    flows = [rs.uniform(-12, 12, (2, h, w)) for _ in range(n_windows)]
+    flows[1][:, :, : w // 2] = 45.0
+    fl_gpu = [G(f, torch.float32) for f in flows]
+    batch = ebos.SlabBatch(plans, fl_gpu, halo=16)
+    var = batch.run().cpu().numpy()
+    for k in range(n_windows):
+        iwe = plans[k].iwe_dense(fl_gpu[k], halo=16)
+        if k != 1:  # (spill taps are global float atomics: not bit-reproducible)
+            assert torch.equal(iwe, batch.iwes[k]), k
+        else:
+            assert rel(batch.iwes[k].cpu().numpy(), iwe.cpu().numpy()) < 1e-6
+        v = torch.var(iwe.double()).item()
+        assert abs(var[k] - v) <= 1e-5 * abs(v) + 1e-12, k
+    ref = O.iwe_dense(torch.from_numpy(evs[0]), torch.from_numpy(flows[0]), (h, w)).numpy()
+    assert rel(batch.iwes[0].cpu().numpy(), ref) < 1e-5
+    again = batch.run().cpu().numpy()  # same workspaces, second call
+    keep = np.arange(n_windows) != 1
+    assert np.array_equal(var[keep], again[keep])
+    # patch grids
+    patch, slide = (8, 8), (8, 8)
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, slide)
+    grids = [G(rs.uniform(-10, 10, (2, gh, gw)), torch.float32) for _ in range(n_windows)]
+    lib = ebos._hip.require_gpu()
+    if not lib.ebos_patch_fused_supported(32, 32, 16, *slide):
+        pytest.skip("grid-sampling kernels not built for this tile")
+    pb = ebos.SlabBatch(plans, grids, patch=(patch, slide), halo=16)
+    pv = pb.run().cpu().numpy()
+    for k in range(n_windows):
+        dense = ebos.ops.upsample_patch_flow(grids[k], patch, slide, (h, w))
+        iwe = plans[k].iwe_dense(dense, halo=16)
+        assert rel(pb.iwes[k].cpu().numpy(), iwe.cpu().numpy()) < 1e-5, k
+        v = torch.var(iwe.double()).item()
+        assert abs(pv[k] - v) <= 2e-5 * abs(v) + 1e-12, k
+
+
 def test_non_finite_events_are_contained(ebos):
     """NaN / Inf coordinates and timestamps: the reference poisons pixel 0 (NaN * 0 in the masked scatter); here
     such taps are dropped and every other pixel is unaffected."""
