@@ -164,3 +164,42 @@ def test_config4_patch_grid_route_full_size(setup):
     print(f"[config 4, un-filtered stream of {len(ev3)} events ({len(ev3) - n} near a kink)] IWE rel-L2 {e_iwe:.2e}, loss rel {e_loss:.2e}, "
           f"d loss / d theta rel-L2 {e_grad:.2e} (filtered stream: {rel(out[True][2], tt.grad.numpy()):.2e})")
     assert e_iwe < 1e-4 and e_loss < 1e-5 and e_grad < 5e-2
+
+
+def test_config4_batched_windows_full_size(setup):
+    """BASELINE configs[3] as ebos_iwe_slab_batch_f32 runs it (bench.py --config 4): five independent windows of different sizes at
+    1280x720 with the shipped 45x80 + 32 tile, 30x40 patch grids, adaptive work items -- images and variances bit-identical to one
+    ebos_iwe_patch_slab_f32 call per window (more than 16 windows: tests/test_gpu_parity.py), the first window also against the
+    fp64 oracle (IWE rel-L2 < 1e-4, variance < 1e-5)."""
+    ebos, ev, fl, plan10, flow = setup
+    from event_based_bos_amd import _hip
+
+    lib = _hip.require_gpu()
+    dev = flow.device
+    rs = np.random.RandomState(41)
+    sizes = [2_000_000, 300_000, 1_000_000, 5_000, 2_000_000]
+    evs = [O.synth_events(n, H, W, seed=300 + k) for k, n in enumerate(sizes)]
+    plans = [ebos.EventPlan.build(torch.from_numpy(e).to(dev), (H, W), "first", True, tile="auto", emit="compact") for e in evs]
+    grids = [torch.from_numpy(rs.uniform(-30, 30, (2, 30, 40))).float().to(dev) for _ in sizes]
+    for splits in (None, 1):  # the plans' own work-item mode (adaptive), then one workgroup per tile
+        batch = ebos.SlabBatch(plans, grids, patch=((24, 32), (24, 32)), splits=splits)
+        var = batch.run(tail_stream=torch.cuda.Stream(device=dev).cuda_stream).cpu().numpy()
+        torch.cuda.synchronize()
+        th, tw = plans[0].tile
+        nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, th, tw, 32, batch.splits, 0, 0))
+        ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
+        iwe = torch.empty((H, W), dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        mom = torch.empty((1, 2), dtype=torch.float64, device=dev)
+        P = lambda t: None if t is None else t.data_ptr()
+        for k, (pl, g) in enumerate(zip(plans, grids)):
+            _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), 30, 40, 24, 32, 24, 32, H, W, th, tw, 32,
+                                                   batch.splits, 0, 0, P(ws), nws, P(iwe), 1, 0, P(out), P(mom),
+                                                   P(pl.part_table) if batch.splits == 0 else None, _hip.stream_ptr()), "ebos_iwe_patch_slab")
+            assert torch.equal(iwe, batch.iwes[k]), (splits, k)
+            assert out.item() == var[k], (splits, k)
+    dense = O.upsample_patch_flow(grids[0].cpu().double(), (H, W), (24, 32), (24, 32))
+    ref = O.iwe_dense(torch.from_numpy(evs[0]), dense, (H, W))
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    assert rel(batch.iwes[0].cpu().double().numpy(), ref.numpy()) < 1e-4
+    assert abs(var[0] - torch.var(ref).item()) <= 1e-5 * torch.var(ref).item()
