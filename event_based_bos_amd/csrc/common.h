@@ -48,6 +48,41 @@ __device__ __forceinline__ T wave_sum(T v) {
   for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
   return v;  // valid in lane 0
 }
+// float / double sums through the DPP cross-lane path of the VALU (row_shr 1, 2, 4, 8, then row_bcast 15 and 31: the total ends up in
+// lane 63 and is read back with v_readlane -> valid in EVERY lane) instead of six ds_bpermute round trips through the LDS pipe:
+// a wave sum costs ~10 VALU instructions' worth of latency, not ~6 x 100 cycles.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v) {
+  v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row of 16 holds the row's sum
+  v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return v;
+}
+template <>
+__device__ __forceinline__ float wave_sum<float>(float v) {
+  v = wave_sum_dpp(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <>
+__device__ __forceinline__ double wave_sum<double>(double v) {
+  const long long b = __builtin_bit_cast(long long, wave_sum_dpp(v));
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
 template <typename T>
 __device__ __forceinline__ T wave_min(T v) {
 #pragma unroll
@@ -82,19 +117,15 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
   return r;
 }
 
-// two block-wide sums at once, in the order block_sum uses for each (bit-identical results): the shuffles of the two values
-// overlap and the pair costs two barriers instead of four.  `red` holds >= 2 * blockDim.x / 64 items.  Results valid in thread 0.
+// two block-wide sums at once, in the order block_sum uses for each (bit-identical results): the two reductions interleave
+// and the pair costs two barriers instead of four.  `red` holds >= 2 * blockDim.x / 64 items.  Results valid in thread 0.
 template <typename T>
 __device__ __forceinline__ void block_sum2(T& a, T& b, T* red) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = threadIdx.x / kWave;
   const int nw = (blockDim.x + kWave - 1) / kWave;
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    const T oa = __shfl_down(a, off, kWave), ob = __shfl_down(b, off, kWave);
-    a += oa;
-    b += ob;
-  }
+  a = wave_sum(a);
+  b = wave_sum(b);
   if (lane == 0) {
     red[wid] = a;
     red[nw + wid] = b;
@@ -102,12 +133,8 @@ __device__ __forceinline__ void block_sum2(T& a, T& b, T* red) {
   __syncthreads();
   T ra = (threadIdx.x < nw) ? red[threadIdx.x] : T(0), rb = (threadIdx.x < nw) ? red[nw + threadIdx.x] : T(0);
   if (wid == 0) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-      const T oa = __shfl_down(ra, off, kWave), ob = __shfl_down(rb, off, kWave);
-      ra += oa;
-      rb += ob;
-    }
+    ra = wave_sum(ra);
+    rb = wave_sum(rb);
   }
   __syncthreads();
   a = ra;

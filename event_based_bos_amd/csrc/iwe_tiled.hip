@@ -1132,13 +1132,16 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const int R = min(max(oy + rl + pad_h, 0), G.h - 1), C = min(max(ox + cl + pad_w, 0), G.w - 1);
       raw[k] = g_image[(int64_t)R * G.w + C];
     }
-    const TileGrid tg = tile_grid_begin<TH, TW, AP>(flow_arg, gs, tr0, tc0, H, W, s_lerp);
+    // (3) before (2): the partials' loads are in flight while tile_grid_begin computes its tables and waits at its barrier
+    double sm = 0.0, sq = 0.0;
     if (mj.partials != nullptr) {
-      double sm = 0.0, sq = 0.0;
       for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
         sm += mj.partials[2 * i];
         sq += mj.partials[2 * i + 1];
       }
+    }
+    const TileGrid tg = tile_grid_begin<TH, TW, AP>(flow_arg, gs, tr0, tc0, H, W, s_lerp);
+    if (mj.partials != nullptr) {
       __shared__ double red_m[2 * kBlock / kWave];
       block_sum2(sm, sq, red_m);
       if (threadIdx.x == 0) {
