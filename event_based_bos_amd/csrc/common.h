@@ -62,6 +62,12 @@ __device__ __forceinline__ double dpp_or_zero(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_or_zero(unsigned long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(v & 0xffffffffull), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum_dpp(T v) {
   v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
@@ -71,6 +77,13 @@ __device__ __forceinline__ T wave_sum_dpp(T v) {
   v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
   v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
   return v;
+}
+template <>
+__device__ __forceinline__ unsigned long long wave_sum<unsigned long long>(unsigned long long v) {  // modulo 2^64
+  v = wave_sum_dpp(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 template <>
 __device__ __forceinline__ float wave_sum<float>(float v) {

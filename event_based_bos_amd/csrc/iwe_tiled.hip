@@ -611,7 +611,7 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   constexpr int kCells = LH * LW + LW / 2 + 2;  // + a dummy region that absorbs the adds of out-of-window lanes
   static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
   extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words; + dummy
-  __shared__ unsigned long long s_chk[2 * kBlock / kWave];
+  __shared__ unsigned long long s_chk[1];  // sum over the workgroup of (units added - units decoded), modulo 2^64
   __shared__ int s_flag[2];  // [0] fixed-point overflow, [1] some event left the LDS window
   __shared__ unsigned s_next;  // chunk queue of the lean loop
   const ChunkQueue queue{&s_next};
@@ -628,7 +628,10 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
     reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
-  if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
+  if (threadIdx.x == 0) {
+    s_next = 2 * (kBlock / kWave);
+    s_chk[0] = 0ull;
+  }
   if (GRID) {
     tile_grid_finish<TH, TW, 0>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
     flow = s_flow;
@@ -679,28 +682,12 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
       out[i] = make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv,
                            ((float)a1.x + (float)b0.y) * kInv, ((float)a1.y + (float)b1.x) * kInv);
     }
-    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    unsigned long long a = added, d = decoded;
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-      a += __shfl_down(a, off, kWave);
-      d += __shfl_down(d, off, kWave);
-    }
-    if (lane == 0) {
-      s_chk[2 * wid] = a;
-      s_chk[2 * wid + 1] = d;
-    }
+    // sum(added) == sum(decoded) over the workgroup  <=>  sum(added - decoded) == 0 modulo 2^64: one value per lane, one DPP wave
+    // sum, one LDS atomic per wave, one barrier (two values, shuffles, a serial 32-term loop and two barriers before)
+    const unsigned long long diff = wave_sum(added - decoded);
+    if ((threadIdx.x & (kWave - 1)) == 0 && diff != 0ull) atomicAdd(&s_chk[0], diff);
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long ta = 0, td = 0;
-      for (int k = 0; k < kBlock / kWave; ++k) {
-        ta += s_chk[2 * k];
-        td += s_chk[2 * k + 1];
-      }
-      s_flag[0] = (ta != td);
-    }
-    __syncthreads();
-    if (s_flag[0]) {  // a field wrapped: redo this slice exactly in f64 and overwrite the slab (spill taps already issued)
+    if (s_chk[0] != 0ull) {  // a field wrapped: redo this slice exactly in f64 and overwrite the slab (spill taps already issued)
       for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
       if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);  // the redo draws its chunks afresh
       __syncthreads();
