@@ -616,17 +616,22 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   __shared__ unsigned s_next;  // chunk queue of the lean loop
   const ChunkQueue queue{&s_next};
   EBOS_STAMP(0);
+  static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
+  // (dense field: the clear comes first -- it needs nothing, and the dependent loads of tile_range fly over it)
+  if (!GRID)
+    for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
+      reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, splits);
   if (tr.ty < 0) return;  // unused work item of an adaptive plan: its slab is never read
 
-  static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
   const float* flow = flow_arg;
   float* s_flow = reinterpret_cast<float*>(s_acc + kCells);  // GRID: the tile's dense flow, behind the accumulators
   Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * TH * TW);
   TileGrid tg{};
-  if (GRID) tg = tile_grid_begin<TH, TW, 0>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);  // (its cell load flies over the clear)
-  for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
-    reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+  if (GRID) {
+    tg = tile_grid_begin<TH, TW, 0>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);  // (its cell load flies over the clear)
+    for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+  }
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     s_next = 2 * (kBlock / kWave);
