@@ -340,6 +340,29 @@ __device__ __forceinline__ void load_cgroup_q(CGroupQ& g, int32_t grp, const Til
   g.pr[3] = P.y >> 24;         g.pcq[3] = (((P.y >> 16) & 255u) << 2) + 4u * HALO;
 }
 
+// Slabs travel from the accumulate pass to the combine pass WRITE-THROUGH (sc1 buffer stores): the 16 MB a launch stores do not sit
+// dirty in the L2s until the end-of-kernel release writes them back in one burst (1.7 us of the accumulate pass).  Every load of
+// them is an sc1 load, the reader's half of that hand-off form in the cdna guide (it costs nothing measurable).  Builtins, not
+// inline asm: the compiler then owns the wait states around the stores' data registers.
+#ifndef EBOS_PLAIN_SLABS
+typedef unsigned slab_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void slab_store4(__amdgpu_buffer_rsrc_t r, unsigned byte, float4 v) {
+  const slab_u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte, 0, kAuxSc1);
+}
+__device__ __forceinline__ float4 slab_load4(__amdgpu_buffer_rsrc_t r, unsigned byte) {
+  const slab_u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte, 0, kAuxSc1);
+  return make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
+}
+__device__ __forceinline__ float slab_load1(__amdgpu_buffer_rsrc_t r, unsigned byte) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte, 0, kAuxSc1));
+}
+#endif
+
 // Work distribution inside the workgroup is DYNAMIC: a wave processes one chunk of 64 groups (one group per lane) at a
 // time and draws its next chunk from an LDS counter.  With a static stride the 16 waves finish far apart -- the SIMD
 // arbiter favours older waves, so wave 0 was done after 9 us and then sat 7 us at the barrier (in-kernel stamps) --
@@ -662,6 +685,12 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
                                                                                          nullptr, queue);
 
   float4* out = reinterpret_cast<float4*>(slabs + (int64_t)tr.slab * (LH * LW));
+#ifndef EBOS_PLAIN_SLABS
+  const __amdgpu_buffer_rsrc_t out_rsrc = slab_rsrc(reinterpret_cast<const float*>(out), (unsigned)(LH * LW * sizeof(float)));
+#define EBOS_SLAB_STORE(i, v) slab_store4(out_rsrc, (unsigned)(i) * 16u, (v))
+#else
+#define EBOS_SLAB_STORE(i, v) out[i] = (v)
+#endif
   bool f64_flush = (MODE == ACC_F64);
   if (MODE == ACC_FX) {
     // One pass: decode 4 consecutive cells (c0 % 4 == 0) of a row from planes A and B, write them to the slab
@@ -684,8 +713,8 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
       const unsigned bmh = j > 0 ? pb[wrow + 2 * j - 1].y : 0u;  // pair (4j-1, 4j); its lo field belongs to the previous group
       decoded += ((unsigned long long)a0.x + a0.y) + ((unsigned long long)a1.x + a1.y) + ((unsigned long long)b0.x + b0.y) +
                  ((unsigned long long)b1.x + b1.y);
-      out[i] = make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv,
-                           ((float)a1.x + (float)b0.y) * kInv, ((float)a1.y + (float)b1.x) * kInv);
+      EBOS_SLAB_STORE(i, make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv,
+                                     ((float)a1.x + (float)b0.y) * kInv, ((float)a1.y + (float)b1.x) * kInv));
     }
     // sum(added) == sum(decoded) over the workgroup  <=>  sum(added - decoded) == 0 modulo 2^64: one value per lane, one DPP wave
     // sum, one LDS atomic per wave, one barrier (two values, shuffles, a serial 32-term loop and two barriers before)
@@ -706,7 +735,7 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
     // slab = the LDS image as f32, 16 B per lane, fully coalesced plain stores
     for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
       const double* p = &s_acc[4 * i];
-      out[i] = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+      EBOS_SLAB_STORE(i, make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]));
     }
   }
   EBOS_STAMP(4);
@@ -762,6 +791,9 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
                         const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch) {
   const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
+#ifndef EBOS_PLAIN_SLABS
+  const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(slabs, 0xffffffffu);  // (offsets stay below the workspace size: < 4 GiB)
+#endif
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
   const int R = blockIdx.y, C = blockIdx.x * kCombineBlock + threadIdx.x;
@@ -781,8 +813,13 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
         const int cl = c - (tx * TW - HALO);
         const int tile = ty * tiles_x + tx;
         const int s0 = part_off ? part_off[tile] : tile * splits, np = part_off ? part_off[tile + 1] - s0 : splits;
+#ifndef EBOS_PLAIN_SLABS
+        const unsigned s_byte = ((unsigned)s0 * (unsigned)(LH * LW) + (unsigned)(rl * LW + cl)) * 4u;
+        for (int p = 0; p < np; ++p) v += slab_load1(all_slabs, s_byte + (unsigned)p * (unsigned)(LH * LW * 4));
+#else
         const float* s = slabs + (int64_t)s0 * (LH * LW) + rl * LW + cl;
         for (int p = 0; p < np; ++p) v += s[(int64_t)p * (LH * LW)];
+#endif
       }
     }
     const int64_t gi = (int64_t)R * w + C;
@@ -816,6 +853,9 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
                                                double* __restrict__ partials, const int32_t* __restrict__ part_off,
                                                const unsigned* __restrict__ spill_epoch, unsigned epoch) {
   const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
+#ifndef EBOS_PLAIN_SLABS
+  const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(slabs, 0xffffffffu);  // (offsets stay below the workspace size: < 4 GiB)
+#endif
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   static_assert(HALO % 4 == 0 && TW % 4 == 0, "vector combine needs 4-aligned windows");
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
@@ -837,9 +877,17 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
         const int cl = c - (tx * TW - HALO);
         const int tile = ty * tiles_x + tx;
         const int s0 = part_off ? part_off[tile] : tile * splits, np = part_off ? part_off[tile + 1] - s0 : splits;
+#ifndef EBOS_PLAIN_SLABS
+        const unsigned sp_byte = ((unsigned)s0 * (unsigned)(LH * LW) + (unsigned)(rl * LW + cl)) * 4u;
+#else
         const float* sp = slabs + (int64_t)s0 * (LH * LW) + rl * LW + cl;
+#endif
         for (int p = 0; p < np; ++p) {
+#ifndef EBOS_PLAIN_SLABS
+          const float4 t = slab_load4(all_slabs, sp_byte + (unsigned)p * (unsigned)(LH * LW * 4));
+#else
           const float4 t = *reinterpret_cast<const float4*>(sp + (int64_t)p * (LH * LW));
+#endif
           v.x += t.x;
           v.y += t.y;
           v.z += t.z;

@@ -621,6 +621,49 @@ def test_batched_windows_equal_per_window_calls(ebos, n_windows):
         assert abs(pv[k] - v) <= 2e-5 * abs(v) + 1e-12, k
 
 
+@pytest.mark.parametrize("size,tile,n", [((96, 128), (32, 32), 20_000), ((720, 1280), (45, 80), 400_000)])
+def test_slab_handoff_never_reads_a_previous_calls_slabs(ebos, size, tile, n):
+    """The accumulate pass stores its slabs write-through (sc1) and the combine pass reads them with sc1 loads (csrc/iwe_tiled.hip):
+    nothing of an earlier call's slabs -- same addresses, possibly still cached somewhere -- may reach a later image.  Two different
+    windows (and two flows each) share ONE workspace and alternate 150 times, at a size where every slab line of the previous call
+    still fits the L2s and at the full image size: every image and variance must equal, bit for bit, the one computed with a
+    workspace of its own."""
+    from event_based_bos_amd import _hip
+
+    lib = _hip.require_gpu()
+    h, w = size
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(11)
+    plans = [ebos.EventPlan.build(G(O.synth_events(n + 977 * k, h, w, seed=50 + k)), (h, w), "first", True, tile=tile, emit="compact")
+             for k in range(2)]
+    flows = [G(rs.uniform(-20, 20, (2, h, w)), torch.float32) for _ in range(2)]
+    halo, splits = 32, 1
+    nws = int(lib.ebos_iwe_slab_workspace_bytes(h, w, tile[0], tile[1], halo, splits, 0, 0))
+    P = lambda t: None if t is None else t.data_ptr()
+
+    def run(pl, fl, ws, iwe, out):
+        _hip.check(lib.ebos_iwe_dense_slab_f32(None, None, None, None, *pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(fl), h, w, tile[0], tile[1],
+                                               halo, splits, 0, 0, P(ws), nws, P(iwe), 1, 0, P(out), None, None, _hip.stream_ptr()),
+                   "ebos_iwe_dense_slab")
+
+    want = {}
+    for a in range(2):
+        for b in range(2):
+            ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
+            iwe, out = torch.empty((h, w), dtype=torch.float32, device=dev), torch.empty(1, dtype=torch.float32, device=dev)
+            run(plans[a], flows[b], ws, iwe, out)
+            want[a, b] = (iwe.clone(), out.clone())
+    assert not torch.equal(want[0, 0][0], want[1, 0][0]) and not torch.equal(want[0, 0][0], want[0, 1][0])
+    ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
+    iwe, out = torch.empty((h, w), dtype=torch.float32, device=dev), torch.empty(1, dtype=torch.float32, device=dev)
+    bad = 0
+    for it in range(150):
+        a, b = it % 2, (it // 2) % 2
+        run(plans[a], flows[b], ws, iwe, out)
+        bad += int(not torch.equal(iwe, want[a, b][0])) + int(not torch.equal(out, want[a, b][1]))
+    assert bad == 0, f"{bad} of 300 results differ from the fresh-workspace ones"
+
+
 def test_non_finite_events_are_contained(ebos):
     """NaN / Inf coordinates and timestamps: the reference poisons pixel 0 (NaN * 0 in the masked scatter); here
     such taps are dropped and every other pixel is unaffected."""
