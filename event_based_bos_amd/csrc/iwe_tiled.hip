@@ -1491,7 +1491,33 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     EBOS_STAMP_BWD(5);
     return;
   }
-  // every flow pixel belongs to exactly one tile: plain coalesced stores, zeros where no event lives
+  // every flow pixel belongs to exactly one tile: coalesced stores, zeros where no event lives
+#ifndef EBOS_PLAIN_SLABS
+  if ((W & 3) == 0 && TW % 4 == 0) {
+    // 16 bytes per lane, write-through: the 7.4 MB of a 1280x720 gradient do not wait for the end-of-kernel write-back
+    const __amdgpu_buffer_rsrc_t dr = slab_rsrc(d_flow, 0xffffffffu);
+    for (int i = threadIdx.x; i < TH * (TW / 4); i += kBlock) {
+      const int rl = i / (TW / 4), cl = (i - rl * (TW / 4)) * 4;
+      const int r = tr0 + rl, c = tc0 + cl;
+      if (r < H && c < W) {
+        const int64_t o = (int64_t)r * W + c;
+        const double* dx = s_d + rl * TW + cl;
+        const double* dy = dx + TH * TW;
+        float4 gx = make_float4((float)dx[0], (float)dx[1], (float)dx[2], (float)dx[3]);
+        float4 gy = make_float4((float)dy[0], (float)dy[1], (float)dy[2], (float)dy[3]);
+        if (addend) {
+          const float4 ax = *reinterpret_cast<const float4*>(addend + o), ay = *reinterpret_cast<const float4*>(addend + hw + o);
+          gx.x += ax.x, gx.y += ax.y, gx.z += ax.z, gx.w += ax.w;
+          gy.x += ay.x, gy.y += ay.y, gy.z += ay.z, gy.w += ay.w;
+        }
+        slab_store4(dr, (unsigned)(o * 4), gx);
+        slab_store4(dr, (unsigned)((hw + o) * 4), gy);
+      }
+    }
+    EBOS_STAMP_BWD(5);
+    return;
+  }
+#endif
   for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
     const int rl = i / TW, cl = i - rl * TW;
     const int r = tr0 + rl, c = tc0 + cl;
