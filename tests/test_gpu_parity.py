@@ -664,6 +664,32 @@ def test_slab_handoff_never_reads_a_previous_calls_slabs(ebos, size, tile, n):
     assert bad == 0, f"{bad} of 300 results differ from the fresh-workspace ones"
 
 
+@pytest.mark.parametrize("emit", ["full", "compact"])
+def test_empty_and_three_event_windows_through_the_plan_paths(ebos, emit):
+    """A window without events, and one with three: plan build (both builds), tile-private forward, value + gradient in one call, and
+    the batched entry.  No event -> zero image, zero variance, zero gradient; three events -> mass 3 and the oracle's variance."""
+    h, w = 96, 128
+    dev = torch.device("cuda:0")
+    for n in (0, 3):
+        ev = np.zeros((n, 4))
+        if n:
+            ev[:, 0], ev[:, 1], ev[:, 2] = np.arange(n) + 5, 7, np.linspace(0, 1, n)
+        plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (h, w), "first", True, tile=(32, 32), emit=emit)
+        assert plan.n == n
+        fl = torch.full((2, h, w), 1.5, device=dev)
+        iwe = plan.iwe_dense(fl, halo=16)
+        v, g = plan.variance_and_grad_dense(fl)
+        assert abs(float(iwe.sum()) - n) < 1e-5 and torch.isfinite(g).all()
+        if n == 0:
+            assert float(v) == 0.0 and float(g.abs().sum()) == 0.0
+        else:
+            ref = O.iwe_dense(torch.from_numpy(ev), fl.cpu().double(), (h, w))
+            assert rel(iwe.cpu().numpy(), ref.numpy()) < 1e-5 and abs(float(v) - torch.var(ref).item()) < 1e-5 * torch.var(ref).item()
+        if plan.compact:
+            batch = ebos.SlabBatch([plan, plan], [fl, fl], halo=16)
+            assert batch.run().tolist() == [float(v), float(v)] and torch.equal(batch.iwes[0], iwe) and torch.equal(batch.iwes[1], iwe)
+
+
 def test_non_finite_events_are_contained(ebos):
     """NaN / Inf coordinates and timestamps: the reference poisons pixel 0 (NaN * 0 in the masked scatter); here
     such taps are dropped and every other pixel is unaffected."""
