@@ -1,26 +1,30 @@
 // iwe_tiled.hip -- tile-private fused warp + IWE pipeline for gfx950 (the fast path of the hot loop).
 //
-// Events are binned by source tile (event_plan.hip).  One 1024-thread workgroup owns one (tile, split):
+// Events are binned by source tile (event_plan.hip / plan_lean.hip).  One 1024-thread workgroup owns one work item (a tile, or a
+// part of a heavy tile):
 //
-//   forward   iwe_slab_accumulate_kernel   events (SoA, coalesced, software-pipelined: the loads of batch
-//                                          k+1 are in flight while batch k's taps are accumulated) ->
-//                                          warp in registers -> ds_add_f64 into an LDS image of the tile +
-//                                          HALO px per side -> the LDS image is written ONCE as a plain,
-//                                          fully coalesced f32 "slab" (no global atomics, no memset)
-//             iwe_slab_combine_kernel      per pixel: sum the <= 9 slabs that cover it (+ the spill image of
-//                                          beyond-halo taps), write the IWE, and reduce the variance moments
-//                                          (sum, sum of squares; f64) of the row segment -> partials
+//   forward   iwe_slab_accumulate_kernel   compact events (u16 tile-local pixel + f32 dt, 16-byte loads, software-pipelined: group k+2
+//                                          is loading and the flow of group k+1 is being gathered while group k's taps are
+//                                          accumulated) -> warp in registers -> paired fixed point, two ds_add_u64 per event, into an
+//                                          LDS image of the tile + HALO px per side (verified by a checksum; an exact f64 redo if a
+//                                          field overflowed; per-event weights: ds_add_f64) -> the LDS image is written ONCE as a
+//                                          coalesced f32 "slab", write-through (no global atomics, no memset)
+//             iwe_slab_combine4_kernel     per pixel: sum the <= 9 slabs that cover it (+ the spill image of beyond-halo taps when
+//                                          this call wrote any), write the IWE, and reduce the variance moments (sum, sum of
+//                                          squares; f64) of its 4 x 256 pixels -> partials
 //             moments_finalize_kernel      one workgroup: partials -> (mean, M, variance); deterministic
-//   backward  iwe_dense_tiled_bwd_kernel   upstream image tile (+halo) staged in LDS, four LDS gathers per event,
-//                                          wave-level segmented sum over the events of one source pixel
-//                                          (__shfl), ds_add_f64 into a [2][TH][TW] LDS tile, then d_flow of
-//                                          the tile is written with plain stores -- every flow pixel belongs
-//                                          to exactly one tile, so no global atomics and no zero-fill.
+//             *_batch_kernel               the same three over (work item, window) for up to 16 independent windows
+//   backward  iwe_dense_tiled_bwd_kernel   upstream image tile (+halo) staged in LDS with all its loads in flight, four LDS gathers per
+//                                          event, the events of one source pixel summed in registers per lane, ds_add_f64 into a
+//                                          [2][TH][TW] LDS tile, then d_flow of the tile is written once, 16 bytes per lane,
+//                                          write-through -- every flow pixel belongs to exactly one tile, so no global atomics and
+//                                          no zero-fill.
+//   GRID variants of both: the flow argument is a patch grid [2, gh, gw], evaluated per tile into LDS (patch_grid.h).
 //
-// Why f64 in LDS: measured on MI355X (tools/ubench_lds_atomics.hip) ds_add_f32 sustains ~0.33 lanes/clk/CU
-// (200 Gop/s chip-wide, any bank pattern) but ds_add_f64 ~2.8 and ds_add_u64 ~4.6 lanes/clk/CU.
-// Why slabs: a global float atomic costs ~50 ns per 256-B wave instruction per CU at the memory side and
-// same-address atomics serialise (~88/us), whereas plain stores stream at HBM rate.
+// Why 64-bit LDS atomics: ds_add_f32 is ~8-15x slower than ds_add_u64 / ds_add_f64 on gfx950 (tools/ubench_lds.hip,
+// profiles/r02_lds_cost_and_phases.txt).  Why slabs: a global float atomic costs ~50 ns per 256-B wave instruction per CU at the
+// memory side and same-address atomics serialise (~88/us), whereas stores stream at HBM rate.  What bounds the loops, what was
+// tried and what it was worth: DESIGN.md 4.1.
 //
 // reference semantics: src/warp.py:330-342 + src/event_image_converter.py:581-620 (forward);
 // their autograd w.r.t. the flow and the per-event weight (backward).
@@ -1681,6 +1685,11 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   static_assert(((size_t)LH * LW + LW / 2 + 2) * sizeof(double) + 1024 <= 160 * 1024,
                 "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
   const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
+  if (L.off_spill >= ((size_t)1 << 32)) {  // the combine pass addresses the slab section with 32-bit byte offsets (sc1 buffer loads)
+    set_error("ebos_iwe_*_slab: %zu bytes of slabs (image %dx%d, %d work items): the slab section must stay below 4 GiB", L.off_spill, H,
+              W, L.nblk);
+    return EBOS_ERR_UNSUPPORTED;
+  }
   float* slabs = reinterpret_cast<float*>(ws);
   float* spill = reinterpret_cast<float*>(ws + L.off_spill);
   double* partials = reinterpret_cast<double*>(ws + L.off_partials);
@@ -1757,6 +1766,11 @@ int launch_slab_fwd_batch(const FwdBatch& b, int n, int H, int W, int splits, in
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   size_t lds = ((size_t)LH * LW + LW / 2 + 2) * sizeof(double);
   const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
+  if (L.off_spill >= ((size_t)1 << 32)) {  // the combine pass addresses the slab section with 32-bit byte offsets (sc1 buffer loads)
+    set_error("ebos_iwe_*_slab: %zu bytes of slabs (image %dx%d, %d work items): the slab section must stay below 4 GiB", L.off_spill, H,
+              W, L.nblk);
+    return EBOS_ERR_UNSUPPORTED;
+  }
   if (!(L.w % 4 == 0 && pad_w % 4 == 0)) {
     set_error("ebos_iwe_slab_batch: needs image and padding widths that are multiples of 4 (call the single-window entry)");
     return EBOS_ERR_UNSUPPORTED;
@@ -1830,6 +1844,10 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   static_assert((size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float) <= 160 * 1024,
                 "backward tile must fit the 160 KiB LDS of a CDNA4 CU");
   const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
+  if ((size_t)2 * H * W * sizeof(float) >= ((size_t)1 << 32)) {  // d_flow is written through a buffer descriptor, 32-bit byte offsets
+    set_error("ebos_iwe_*_tiled_bwd: a %dx%d flow gradient does not fit 32-bit byte offsets", H, W);
+    return EBOS_ERR_UNSUPPORTED;
+  }
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
              const double*, const float*, const float*, float*, GridSrc, int, float, float, double*, MomentsIn);
