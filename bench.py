@@ -725,7 +725,7 @@ def run_config4(R):
     torch.cuda.synchronize()
     eager_enqueue_ms = measure_enqueue(eager_step)
     step, graphed = eager_step, False
-    if not a.no_graph and plans:
+    if not a.no_graph and plans and a.batch <= 0:  # (the batched entry below needs no graph: one C call per pass)
         try:
             graph = torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream(device=dev)
