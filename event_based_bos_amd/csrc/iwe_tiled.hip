@@ -1147,7 +1147,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   __shared__ unsigned s_next;  // chunk queue of the lean loop
   const ChunkQueue queue{&s_next};
   EBOS_STAMP_BWD(0);
-  if (tr.ty < 0 && !(GRID && mj.partials != nullptr && blockIdx.x == 0)) return;  // unused work item
+  if (tr.ty < 0 && !(mj.partials != nullptr && blockIdx.x == 0)) return;  // unused work item (workgroup 0 still reports the variance)
   const float* flow = flow_arg;
   const int64_t hw = (int64_t)H * W;
   GradImage G;
@@ -1236,7 +1236,33 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       raw[k] = g_image[(int64_t)R * G.w + C];
     }
     const bool live = tr.g_first <= tr.g_last;
-    if (var_moments != nullptr) {
+    if (mj.partials != nullptr) {
+      // the (sum, sum of squares) partials the forward call left (want_variance = 2): every workgroup reduces them itself while its
+      // staging loads fly -- the finalize launch between forward and backward disappears; workgroup 0 reports the variance
+      double sm = 0.0, sq = 0.0;
+      for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
+        sm += mj.partials[2 * i];
+        sq += mj.partials[2 * i + 1];
+      }
+      __shared__ double red_d[2 * kBlock / kWave];
+      block_sum2(sm, sq, red_d);
+      if (threadIdx.x == 0) {
+        const double mean = mj.n_pixels > 0 ? sm / (double)mj.n_pixels : 0.0;
+        s_mom[0] = mean;
+        if (blockIdx.x == 0) {
+          if (mj.out_var) mj.out_var[0] = (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
+          if (mj.moments) {
+            mj.moments[0] = mean;
+            mj.moments[1] = (double)mj.n_pixels;
+          }
+        }
+      }
+      __syncthreads();
+      if (tr.ty < 0) return;  // (workgroup 0 of an adaptive plan may be an unused item: it only reports the variance)
+      const double a = 2.0 * (double)upstream[0] / ((double)mj.n_pixels - 1.0);
+      G.a = (float)a;
+      G.c = (float)(-a * s_mom[0]);
+    } else if (var_moments != nullptr) {
       // g_image is the IWE itself and the loss is upstream * var(IWE): d var / d IWE = 2 (IWE - mean) / (M - 1), folded
       // in as an affine map (no d_iwe image, no separate affine kernel)
       const double a = 2.0 * (double)upstream[0] / (var_moments[1] - 1.0);
@@ -1890,11 +1916,11 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   if (profile_next_pair(&t0, &t1, EBOS_PROFILE_TILED_BWD))
     hipExtLaunchKernelGGL(kb, dim3(grid), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine,
                           g_lo, d_flow, d_weight, partials, var_moments, upstream, part_out ? (const float*)nullptr : addend, part_out,
-                          GridSrc{}, 0, 0.0f, 0.0f, (double*)nullptr, MomentsIn{});
+                          GridSrc{}, 0, 0.0f, 0.0f, (double*)nullptr, mj);
   else
     kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
                                              partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0, 0.0f,
-                                             0.0f, nullptr, MomentsIn{});
+                                             0.0f, nullptr, mj);
   if (part_out)
     bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
                                                                                                   addend, d_flow);
@@ -2199,19 +2225,20 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
   return EBOS_OK;
 }
 
-int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
-                                 const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
-                                 const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
-                                 int tile_h,
-                                 int tile_w, int halo, int pad_h, int pad_w, const float* g_image, const float* affine,
-                                 int g_lo, float* d_flow, float* d_weight, const double* var_moments,
-                                 const float* upstream, const float* addend, void* workspace, size_t workspace_bytes,
-                                 const int32_t* part_table, ebos_stream_t stream) {
+// mj.partials != nullptr: the variance partials of the forward call (want_variance = 2) are reduced inside the kernel
+static int dense_tiled_bwd_impl(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
+                                const uint16_t* cpix, const float* cdt, const int32_t* key_offsets, int64_t n, const float* flow, int H,
+                                int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
+                                const float* affine, int g_lo, float* d_flow, float* d_weight, const double* var_moments,
+                                const float* upstream, const float* addend, void* workspace, size_t workspace_bytes,
+                                const int32_t* part_table, ebos_stream_t stream, const ebos::MomentsIn& mj) {
   using namespace ebos;
   EBOS_REQUIRE(flow && g_image && d_flow && key_offsets, "ebos_iwe_dense_tiled_bwd: NULL flow/g_image/d_flow/key_offsets");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_dense_tiled_bwd: bad sizes");
-  EBOS_REQUIRE((var_moments == nullptr) == (upstream == nullptr), "ebos_iwe_dense_tiled_bwd: var_moments and upstream go together");
+  EBOS_REQUIRE(mj.partials != nullptr ? (var_moments == nullptr && upstream != nullptr)
+                                      : ((var_moments == nullptr) == (upstream == nullptr)),
+               "ebos_iwe_dense_tiled_bwd: var_moments and upstream go together");
   float* part_out = nullptr;
   if (part_table != nullptr) {  // adaptive work items: partial tiles go through the slab section of the forward workspace
     const size_t need = ebos_iwe_slab_workspace_bytes(H, W, tile_h, tile_w, halo, 0, pad_h, pad_w);
@@ -2233,7 +2260,7 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, \
-                               nullptr, var_moments, upstream, addend, part_out, s)
+                               nullptr, var_moments, upstream, addend, part_out, s, nullptr, 0, 0.0f, 0.0f, nullptr, mj)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;
@@ -2241,16 +2268,39 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
   return EBOS_OK;
 }
 
+int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
+                                 const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                                 const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
+                                 int tile_h,
+                                 int tile_w, int halo, int pad_h, int pad_w, const float* g_image, const float* affine,
+                                 int g_lo, float* d_flow, float* d_weight, const double* var_moments,
+                                 const float* upstream, const float* addend, void* workspace, size_t workspace_bytes,
+                                 const int32_t* part_table, ebos_stream_t stream) {
+  return dense_tiled_bwd_impl(xs, ys, dts, weight, grp_offsets, cpix, cdt, key_offsets, n, flow, H, W, tile_h, tile_w, halo, pad_h, pad_w,
+                              g_image, affine, g_lo, d_flow, d_weight, var_moments, upstream, addend, workspace, workspace_bytes,
+                              part_table, stream, ebos::MomentsIn{});
+}
+
 int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_variance, const float* upstream,
                                 float* d_flow, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(job && flow && out_variance, "ebos_variance_dense_job: NULL job / flow / out_variance");
   EBOS_REQUIRE(job->iwe && job->moments && job->workspace, "ebos_variance_dense_job: the job needs iwe, moments and a workspace");
+  // value + gradient: the forward call leaves the (sum, sum of squares) partials (want_variance = 2) and the backward kernel reduces
+  // them itself -- no finalize launch in between; value only: the forward call finalizes
   int rc = ebos_iwe_dense_slab_f32(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n,
                                    flow, job->H, job->W, job->tile_h, job->tile_w, job->halo, job->splits, job->pad_h, job->pad_w,
-                                   job->workspace, job->workspace_bytes, job->iwe, 1, job->omit_boundary, out_variance, job->moments,
-                                   job->part_table, stream);
+                                   job->workspace, job->workspace_bytes, job->iwe, d_flow ? 2 : 1, job->omit_boundary, out_variance,
+                                   job->moments, job->part_table, stream);
   if (rc != EBOS_OK || d_flow == nullptr) return rc;
+  size_t poff = 0;
+  int64_t nparts = 0, npix = 0;
+  rc = ebos_iwe_slab_partials(job->H, job->W, job->tile_h, job->tile_w, job->halo, job->splits, job->pad_h, job->pad_w, job->omit_boundary,
+                              &poff, &nparts, &npix);
+  if (rc != EBOS_OK) return rc;
+  EBOS_REQUIRE(npix >= 2, "ebos_variance_dense_job: the variance needs at least two pixels");
+  const MomentsIn mj{reinterpret_cast<const double*>(reinterpret_cast<const char*>(job->workspace) + poff), nparts, npix, out_variance,
+                     job->moments};
   if (upstream == nullptr) {  // a device-resident 1.0f of the code object: no allocation, no copy (the ABI never allocates)
     static const float* d_one = nullptr;
     if (d_one == nullptr && hipGetSymbolAddress((void**)&d_one, HIP_SYMBOL(ebos::g_unit_upstream)) != hipSuccess) {
@@ -2260,11 +2310,10 @@ int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, fl
     upstream = d_one;
   }
   const bool adaptive = job->splits == 0 && job->part_table != nullptr;
-  return ebos_iwe_dense_tiled_bwd_f32(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n,
-                                      flow, job->H, job->W, job->tile_h, job->tile_w, job->halo, job->pad_h, job->pad_w, job->iwe, nullptr,
-                                      job->omit_boundary ? 1 : 0, d_flow, nullptr, job->moments, upstream, nullptr,
-                                      adaptive ? job->workspace : nullptr, adaptive ? job->workspace_bytes : 0,
-                                      adaptive ? job->part_table : nullptr, stream);
+  return dense_tiled_bwd_impl(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n, flow,
+                              job->H, job->W, job->tile_h, job->tile_w, job->halo, job->pad_h, job->pad_w, job->iwe, nullptr,
+                              job->omit_boundary ? 1 : 0, d_flow, nullptr, nullptr, upstream, nullptr, adaptive ? job->workspace : nullptr,
+                              adaptive ? job->workspace_bytes : 0, adaptive ? job->part_table : nullptr, stream, mj);
 }
 
 size_t ebos_patch_grad_partials_bytes(int H, int W, int tile_h, int tile_w, int adaptive) {

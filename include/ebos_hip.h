@@ -358,8 +358,10 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
  * arguments of ebos_iwe_dense_slab_f32 / ebos_iwe_dense_tiled_bwd_f32) and passes its address afterwards.
  *   iwe [h, w] and moments [2] are scratch outputs owned by the job (IWE and (mean, M) of the LAST evaluation).
  * ebos_variance_dense_job_f32: out_variance[0] = var(IWE(flow)) (omit_boundary as in the costs); if d_flow != NULL also
- *   d_flow [2, H, W] = upstream[0] * d var / d flow (upstream: device f32 [1]; NULL = 1).  Enqueues accumulate, combine,
- *   finalize (and the tile-private backward) on `stream`; no host synchronisation. */
+ *   d_flow [2, H, W] = upstream[0] * d var / d flow (upstream: device f32 [1]; NULL = 1).  Enqueues accumulate, combine and
+ *   finalize on `stream` -- or, with d_flow, accumulate, combine and the tile-private backward, which reduces the variance
+ *   partials of the combine pass itself and writes out_variance / moments (three launches, no finalize); no host
+ *   synchronisation. */
 typedef struct ebos_dense_job {
   const float *xs, *ys, *dts;          /* (x, y, dt) plan, nullable when the compact trio is given */
   const int32_t* grp_offsets;          /* compact plan (ebos_plan_compact_f32), nullable trio      */
