@@ -500,6 +500,20 @@ def run_config2(R):
         bwd_ms = [buf[i] for i in range(got)]
         extras["fwd_bwd_ms"] = round(fwdbwd_ms, 4)
         extras["fwd_bwd_mevents_per_s"] = round(n / fwdbwd_ms / 1e3, 2)
+        # the same as ONE native call (ebos_variance_dense_job_f32: accumulate, combine, backward -- the backward kernel reduces the
+        # variance partials itself, no finalize launch): what plan.variance_and_grad_dense / contrast_dense(...).backward() enqueue
+        job = ebos.event_plan._dense_job(plan, (0, 0), a.halo, a.splits, False)
+        out_j = torch.empty(1, dtype=torch.float32, device=dev)
+        for _ in range(5):
+            _hip.check(lib.ebos_variance_dense_job_f32(job.ref, P(flow), P(out_j), P(upstream), P(d_flow), stream), "ebos_variance_dense_job")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            _hip.check(lib.ebos_variance_dense_job_f32(job.ref, P(flow), P(out_j), P(upstream), P(d_flow), stream), "ebos_variance_dense_job")
+        torch.cuda.synchronize()
+        job_ms = (time.perf_counter() - t1) / reps * 1e3
+        extras["fwd_bwd_one_call_ms"] = round(job_ms, 4)
+        extras["fwd_bwd_one_call_mevents_per_s"] = round(n / job_ms / 1e3, 2)
         # SURVEY 8(d) backward: 12 B/event (p unused) + read dIWE 4 B/px + write dflow 8 B/px
         extras["roofline_bwd"] = roofline_entry("iwe_dense_tiled_bwd_kernel", bwd_ms, 12.0 * plan.n + 12.0 * H * W)
 
