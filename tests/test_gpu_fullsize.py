@@ -41,7 +41,10 @@ def test_config2_variance_full_size_vs_oracle(setup):
     iwe = plan.iwe_dense(flow)
     assert O.rel_l2(iwe.cpu().numpy(), iwe_ref.detach().numpy()) < 1e-5          # north_star bar: 1e-4
     assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
-    assert O.rel_l2(fg.grad.cpu().numpy(), f.grad.numpy()) < 1e-3                  # SURVEY 8d bar
+    e_grad = O.rel_l2(fg.grad.cpu().numpy(), f.grad.numpy())
+    print(f"[config 2, un-filtered stream of {N} events] IWE rel-L2 {O.rel_l2(iwe.cpu().numpy(), iwe_ref.detach().numpy()):.2e}, "
+          f"loss rel {abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()):.2e}, d loss / d flow rel-L2 {e_grad:.2e}")
+    assert e_grad < 1e-3                                                           # SURVEY 8d bar
     # ~1.6 % of the mass leaves the image (IWE sum 9 838 422.9 of 10 M)
     assert abs(iwe.sum().item() - 9_838_422.9) < 50.0
 
@@ -54,8 +57,11 @@ def test_config3_gradient_magnitude_full_size_vs_cpu_autograd(setup):
     fg = flow.clone().requires_grad_(True)
     loss = -plan.contrast_dense(fg, "gradient_magnitude")
     loss.backward()
+    e_grad = O.rel_l2(fg.grad.cpu().numpy(), f.grad.numpy())
+    print(f"[config 3, un-filtered stream of {N} events] loss rel {abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()):.2e}, "
+          f"d loss / d flow rel-L2 {e_grad:.2e}")
     assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())       # cost rel err < 1e-5
-    assert O.rel_l2(fg.grad.cpu().numpy(), f.grad.numpy()) < 1e-3                  # gradient rel-L2 < 1e-3
+    assert e_grad < 1e-3                                                           # gradient rel-L2 < 1e-3 (no event filtered)
 
 
 def test_kernel_organisations_agree_and_are_reproducible(setup):
@@ -147,8 +153,8 @@ def test_config4_patch_grid_route_full_size(setup):
     # mass: every event whose four taps stay inside the image adds exactly one unit
     assert abs(out[True][0].sum() - iwe_ref.sum().item()) <= 1e-6 * n
     # The same comparison on the UN-filtered stream (the ~0.2 % of events within 5e-4 px of a kink kept): value bars unchanged;
-    # the gradient w.r.t. the 2400 patch parameters is reported, with a bar that only catches a broken kernel -- at a kink
-    # the f32 path and the fp64 oracle may take different one-sided derivatives of the piecewise-linear vote
+    # the gradient w.r.t. the 2400 patch parameters is reported and held to 3e-3 (measured 1.4e-3: a regression of 2x is seen) -- at a
+    # kink the f32 path and the fp64 oracle may take different one-sided derivatives of the piecewise-linear vote
     ev3 = O.synth_events(2_000_000, H, W, seed=7)
     plan3 = ebos.EventPlan.build(torch.from_numpy(ev3).to(dev), (H, W), "first", True, tile="auto")
     loop3 = FusedPatchLoop(plan3, (24, 32), (24, 32), torch.from_numpy(theta).float().to(dev), 1.0, 0.01, 0.0, capacity=4, lr=0.1,
@@ -163,7 +169,7 @@ def test_config4_patch_grid_route_full_size(setup):
     e_grad = rel(grad3.cpu().double().numpy(), t3.grad.numpy())
     print(f"[config 4, un-filtered stream of {len(ev3)} events ({len(ev3) - n} near a kink)] IWE rel-L2 {e_iwe:.2e}, loss rel {e_loss:.2e}, "
           f"d loss / d theta rel-L2 {e_grad:.2e} (filtered stream: {rel(out[True][2], tt.grad.numpy()):.2e})")
-    assert e_iwe < 1e-4 and e_loss < 1e-5 and e_grad < 5e-2
+    assert e_iwe < 1e-4 and e_loss < 1e-5 and e_grad < 3e-3
 
 
 def test_config4_batched_windows_full_size(setup):
