@@ -73,7 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--events", type=int, default=None, help="events per window (default: the config's)")
     ap.add_argument("--windows", type=int, default=None, help="config 4: number of windows (default 64)")
     ap.add_argument("--tile", type=int, nargs=2, default=[0, 0], help="source tile (0 0 = choose_tile: 45x80 at 1280x720)")
-    ap.add_argument("--halo", type=int, default=32)
+    ap.add_argument("--halo", type=lambda v: v if v == "auto" else int(v), default=32,
+                    help="a built halo of the tile-private kernels, or 'auto': run-time LDS windows per tile (EBOS_HALO_AUTO)")
     ap.add_argument("--splits", type=int, default=1)
     ap.add_argument("--flow-max", type=float, default=FLOW_MAX, help="amplitude of the synthetic flow (BASELINE: 30 px)")
     ap.add_argument("--streams", type=int, default=3, help="configs 4 / 5: independent windows / hypotheses kept in flight per rank")
@@ -412,7 +413,7 @@ def run_config2(R):
     ev_gpu = torch.from_numpy(ev).to(dev)
     flow = torch.from_numpy(flow_np).float().to(dev)
     if a.tile[0] <= 0:
-        a.tile = list(ebos.event_plan.choose_tile((H, W), a.halo))
+        a.tile = list(ebos.event_plan.choose_tile((H, W), 32 if a.halo == 'auto' else a.halo))
     # plan build, timed host + device per window.  emit="compact" (ebos_plan_lean): what the unit-weight objective reads and
     # nothing else; the full build also leaves SoA x / y / dt / p and the permutation (per-event weights).  The first build of
     # a process also pays one-off allocator / code-object costs: the best of the later ones is reported.
@@ -431,8 +432,9 @@ def run_config2(R):
     _, _, plan_build_full_ms = time_build("full")
     plan, plan_first_ms, plan_build_ms = time_build("full" if a.no_compact else "compact")
     del ev_gpu
+    a.halo_code = ebos.event_plan.resolve_halo(plan, a.halo)  # an int for the C ABI ('auto' -> EBOS_HALO_AUTO(32, 64 max|dt|))
 
-    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, a.tile[0], a.tile[1], a.halo, a.splits, 0, 0))
+    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, a.tile[0], a.tile[1], a.halo_code, a.splits, 0, 0))
     ws = torch.zeros(nws, dtype=torch.uint8, device=dev)  # zero-filled once (spill section stays zero)
     out = torch.empty(1, dtype=torch.float32, device=dev)
     moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
@@ -450,7 +452,7 @@ def run_config2(R):
         def step():
             # one objective evaluation: tile accumulate -> slab combine (writes the IWE) -> variance
             _hip.check(lib.ebos_iwe_dense_slab_f32(P(pl.x), P(pl.y), P(pl.dt), None, *cp, P(pl.key_offsets), pl.n, P(fl),
-                                                   H, W, a.tile[0], a.tile[1], a.halo, a.splits, 0, 0, P(ws), nws,
+                                                   H, W, a.tile[0], a.tile[1], a.halo_code, a.splits, 0, 0, P(ws), nws,
                                                    P(iwe), 1, 0, P(out), P(moments), P(pl.part_table), stream), "ebos_iwe_dense_slab")
         return step
 
@@ -481,7 +483,7 @@ def run_config2(R):
         def step_fwd_bwd():
             step()
             _hip.check(lib.ebos_iwe_dense_tiled_bwd_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
-                                                        P(flow), H, W, a.tile[0], a.tile[1], a.halo, 0, 0, P(iwe), None,
+                                                        P(flow), H, W, a.tile[0], a.tile[1], a.halo_code, 0, 0, P(iwe), None,
                                                         0, P(d_flow), None, P(moments), P(upstream), None, P(ws), nws,
                                                         P(plan.part_table) if a.splits == 0 else None, stream), "ebos_iwe_dense_tiled_bwd")
 
@@ -502,7 +504,7 @@ def run_config2(R):
         extras["fwd_bwd_mevents_per_s"] = round(n / fwdbwd_ms / 1e3, 2)
         # the same as ONE native call (ebos_variance_dense_job_f32: accumulate, combine, backward -- the backward kernel reduces the
         # variance partials itself, no finalize launch): what plan.variance_and_grad_dense / contrast_dense(...).backward() enqueue
-        job = ebos.event_plan._dense_job(plan, (0, 0), a.halo, a.splits, False)
+        job = ebos.event_plan._dense_job(plan, (0, 0), a.halo_code, a.splits, False)
         out_j = torch.empty(1, dtype=torch.float32, device=dev)
         for _ in range(5):
             _hip.check(lib.ebos_variance_dense_job_f32(job.ref, P(flow), P(out_j), P(upstream), P(d_flow), stream), "ebos_variance_dense_job")
@@ -528,7 +530,7 @@ def run_config2(R):
             for k in range(count):
                 st, ws_k, iwe_k, out_k, mom_k = lanes[k % 3]
                 _hip.check(lib.ebos_iwe_dense_slab_f32(P(plan.x), P(plan.y), P(plan.dt), None, *cptrs, P(plan.key_offsets), plan.n,
-                                                       P(flow), H, W, a.tile[0], a.tile[1], a.halo, a.splits, 0, 0,
+                                                       P(flow), H, W, a.tile[0], a.tile[1], a.halo_code, a.splits, 0, 0,
                                                        P(ws_k), nws, P(iwe_k), 1, 0, P(out_k), P(mom_k), P(plan.part_table),
                                                        st.cuda_stream), "ebos_iwe_dense_slab")
 
@@ -680,8 +682,8 @@ def run_config4(R):
     ph, pw = CONFIG4["patch"]
     sh, sw = CONFIG4["slide"]
     if a.tile[0] <= 0:
-        a.tile = list(ebos.event_plan.choose_tile((H, W), a.halo))
-    if not lib.ebos_patch_fused_supported(a.tile[0], a.tile[1], a.halo, sh, sw):
+        a.tile = list(ebos.event_plan.choose_tile((H, W), 32 if a.halo == 'auto' else a.halo))
+    if not lib.ebos_patch_fused_supported(a.tile[0], a.tile[1], 32 if a.halo == 'auto' else a.halo, sh, sw):
         raise SystemExit(f"config 4 needs a tile the grid-sampling kernels support, got {a.tile} halo {a.halo}")
     gh, gw = ebos.solver.patch_grid_shape((H, W), (ph, pw), (sh, sw))
     stream = torch.cuda.current_stream().cuda_stream
@@ -694,12 +696,13 @@ def run_config4(R):
         grids.append(torch.from_numpy(np.random.RandomState(100 + wi).uniform(-FLOW_MAX, FLOW_MAX, (2, gh, gw))).float().to(dev))
     torch.cuda.synchronize()
     ingest_s = time.perf_counter() - t0
+    a.halo_code = ebos.event_plan.resolve_halo(plans[0], a.halo) if plans else 32
     splits = 1
     # The windows are independent (bos_event.py:144-220): like solver.WindowPipeline, a rank keeps three of them in flight on
     # three HIP streams, each with its own workspace and image -- the small combine / finalize kernels of one window run in
     # the wave slots the one-workgroup-per-CU accumulate kernel of another leaves free.  --streams 1: back to back.
     n_lanes = max(1, min(a.streams, len(plans)))
-    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, a.tile[0], a.tile[1], a.halo, splits, 0, 0))
+    nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, a.tile[0], a.tile[1], a.halo_code, splits, 0, 0))
     lanes = [(torch.cuda.Stream(device=dev) if n_lanes > 1 else None, torch.zeros(nws, dtype=torch.uint8, device=dev),
               torch.empty((H, W), dtype=torch.float32, device=dev), torch.empty((1, 2), dtype=torch.float64, device=dev))
              for _ in range(n_lanes)]
@@ -713,7 +716,7 @@ def run_config4(R):
         for k, (pl, g) in enumerate(zip(plans, grids)):
             st, ws, iwe, moments = lanes[k % n_lanes]
             _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), gh, gw, ph, pw, sh, sw, H, W,
-                                                   a.tile[0], a.tile[1], a.halo, splits, 0, 0, P(ws), nws, P(iwe), 1, 0,
+                                                   a.tile[0], a.tile[1], a.halo_code, splits, 0, 0, P(ws), nws, P(iwe), 1, 0,
                                                    outs.data_ptr() + 4 * k, P(moments), P(pl.part_table),
                                                    st.cuda_stream if st is not None else main.cuda_stream),
                        "ebos_iwe_patch_slab")
@@ -786,7 +789,7 @@ def run_config4(R):
     for k, (pl, g) in enumerate(zip(plans[:nrec], grids[:nrec])):
         _, ws, iwe, moments = lanes[0]
         _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), gh, gw, ph, pw, sh, sw, H, W,
-                                               a.tile[0], a.tile[1], a.halo, splits, 0, 0, P(ws), nws, P(iwe), 1, 0,
+                                               a.tile[0], a.tile[1], a.halo_code, splits, 0, 0, P(ws), nws, P(iwe), 1, 0,
                                                outs.data_ptr() + 4 * k, P(moments), P(pl.part_table), stream), "ebos_iwe_patch_slab")
     torch.cuda.synchronize()
     buf = (ctypes.c_float * nrec)()
@@ -842,7 +845,7 @@ def run_config5(R):
     grid = np.stack(np.meshgrid(gx, gy, indexing="ij"), -1).reshape(-1, 2)
     mine = shard_for(5, rank, world, a)
     if a.tile[0] <= 0:
-        a.tile = list(ebos.event_plan.choose_tile((H, W), a.halo))
+        a.tile = list(ebos.event_plan.choose_tile((H, W), 32 if a.halo == 'auto' else a.halo))
     ev, _ = synth_window(n, seed=0, flow=False)  # the SAME window on every rank
     t0 = time.perf_counter()
     plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact")

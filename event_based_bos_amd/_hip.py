@@ -78,6 +78,7 @@ SIGNATURES = {
     "ebos_tiled_config": (_I, [C.POINTER(C.c_int), _I]),
     "ebos_iwe_dense_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "ebos_slab_config": (_I, [C.POINTER(C.c_int), _I]),
+    "ebos_halo_auto": (_I, [_I, _D]),
     "ebos_iwe_slab_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "ebos_iwe_dense_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P, _P]),
     "ebos_iwe_2dof_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P, _P]),
@@ -203,11 +204,21 @@ def require_gpu() -> C.CDLL:
     return lib
 
 
+# The raw getters are unversioned torch internals: resolved ONCE, with the public API as the fall-back of a torch build
+# that renames them -- the fall-back builds a Stream object per call (~5-10 us), it is never wrong.
+_raw_device = getattr(torch._C, "_cuda_getDevice", None) or (lambda: torch.cuda.current_device())
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
+def current_device_index() -> int:
+    return _raw_device()
+
+
 def stream_ptr(device: Optional[torch.device] = None) -> int:
     """hipStream_t of torch's current stream on ``device`` (default: the current device) as an integer.  The raw getter:
     ``torch.cuda.current_stream()`` builds a Stream object per call (~5-10 us of the ~20 us an operator launch costs)."""
-    idx = torch._C._cuda_getDevice() if device is None or device.index is None else device.index
-    return torch._C._cuda_getCurrentRawStream(idx)
+    idx = _raw_device() if device is None or device.index is None else device.index
+    return _raw_stream(idx)
 
 
 class on_device(object):
@@ -220,7 +231,7 @@ class on_device(object):
         self.ctx = None
 
     def __enter__(self):
-        if self.idx is not None and torch._C._cuda_getDevice() != self.idx:
+        if self.idx is not None and _raw_device() != self.idx:
             self.ctx = torch.cuda.device(self.idx)
             self.ctx.__enter__()
         return self

@@ -108,18 +108,33 @@ __device__ __forceinline__ void adam_record_loss(const AdamJob& job, int lane) {
   }
 }
 
+// The optimiser state of gradient element i, loaded BEFORE the gradient is known: the loads of (mask, exp_avg, exp_avg_sq, theta)
+// then fly beside those of the gradient's terms instead of queueing behind the d_grid store (which may alias them as far as
+// the compiler knows) -- one memory round trip per element instead of two in a kernel that is nothing but latency.
+struct AdamState {
+  float mask, m, v, th;
+};
+__device__ __forceinline__ AdamState adam_load(const AdamJob& job, int64_t i, int64_t cell) {
+  AdamState a{1.0f, 0.0f, 0.0f, 0.0f};
+  if (job.grad_mask != nullptr) a.mask = job.grad_mask[cell];
+  if (job.theta != nullptr) a.m = job.exp_avg[i], a.v = job.exp_avg_sq[i], a.th = job.theta[i];
+  return a;
+}
 // gradient element i (grid cell `cell` of one flow component): mask, store, Adam step
-__device__ __forceinline__ void adam_apply(const AdamJob& job, int64_t i, int64_t cell, float g, float* __restrict__ d_grid) {
-  if (job.grad_mask != nullptr) g *= job.grad_mask[cell];
+__device__ __forceinline__ void adam_apply(const AdamJob& job, int64_t i, const AdamState& a, float g, float* __restrict__ d_grid) {
+  if (job.grad_mask != nullptr) g *= a.mask;
   d_grid[i] = g;
   if (job.theta != nullptr) {
-    const float mi = job.exp_avg[i] + job.w1 * (g - job.exp_avg[i]);      // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = job.exp_avg_sq[i] * job.beta2 + job.w2 * (g * g);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float mi = a.m + job.w1 * (g - a.m);                            // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = a.v * job.beta2 + job.w2 * (g * g);                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     job.exp_avg[i] = mi;
     job.exp_avg_sq[i] = vi;
     const float denom = sqrtf(vi) / job.bc2_sqrt + job.eps;               // (exp_avg_sq.sqrt() / sqrt(bias_correction2)) + eps
-    job.theta[i] = job.theta[i] - job.step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value = -step_size)
+    job.theta[i] = a.th - job.step_size * (mi / denom);                   // param.addcdiv_(exp_avg, denom, value = -step_size)
   }
+}
+__device__ __forceinline__ void adam_apply(const AdamJob& job, int64_t i, int64_t cell, float g, float* __restrict__ d_grid) {
+  adam_apply(job, i, adam_load(job, i, cell), g, d_grid);
 }
 
 // Partial cell gradients of the GRID backward kernel (iwe_tiled.hip) -> d_grid (+ Adam): one thread per grid element sums
@@ -135,6 +150,7 @@ patch_grad_combine_kernel(const float* __restrict__ partials, const int32_t* __r
   if (idx >= 2 * ay.g * ax.g) return;
   const int ch = idx / (ay.g * ax.g), cell = idx - ch * (ay.g * ax.g);
   const int gi = cell / ax.g, gj = cell - gi * ax.g;
+  const AdamState st = adam_load(job, idx, cell);  // (in flight beside the partials)
   // candidate tiles per axis (<= kSpan, the conservative pixel support of the cell) and the first cell of each one's block
   constexpr int kSpan = 4;
   int r_lo, r_hi, c_lo, c_hi;
@@ -184,7 +200,7 @@ patch_grad_combine_kernel(const float* __restrict__ partials, const int32_t* __r
       }
     }
   }
-  adam_apply(job, idx, cell, acc, d_grid);
+  adam_apply(job, idx, st, acc, d_grid);
 }
 
 // pass 2: one wavefront per grid cell, lanes stride over the cell's column support

@@ -39,7 +39,6 @@
 #include "patch_grid.h"
 
 namespace ebos {
-__device__ float g_unit_upstream = 1.0f;  // upstream of ebos_variance_dense_job_f32 when the caller passes none
 namespace {
 
 constexpr float kEps = 1e-6f;  // src/event_image_converter.py:586
@@ -326,22 +325,58 @@ __device__ __forceinline__ void load_cgroup(CGroup& g, int32_t grp, const TileRa
   g.pr[3] = P.y >> 24;         g.pc[3] = (P.y >> 16) & 255u;
 }
 
+// The LDS window of one work item: its source tile plus hr rows / hc columns of halo on each side.
+//   static kernels (DYN = false): hr = hc = HALO, every expression below folds to the compile-time constant;
+//   DYN kernels: HALO is the LARGEST window (it sizes the LDS and the slab stride) and (hr, hc) are chosen per tile AT RUN TIME
+//   from a bound on the tile's own displacements, |flow| over the tile x max |dt| of the window (BOS displacements are a few
+//   pixels; the +-30 px of the sampler range is the search bound, not the operating point).  Clear, decode, slab store,
+//   combine reads and the backward kernel's upstream tile all scale with (TH + 2 hr)(TW + 2 hc); taps beyond the window
+//   still go to the spill image, so the choice moves time, never results.  hc is a multiple of 4 (slab rows are written
+//   and combined 4 cells at a time).
+template <int TH, int TW, int HALO, bool DYN>
+struct Win {
+  int hr, hc;
+  __device__ __forceinline__ int HR() const { return DYN ? hr : HALO; }
+  __device__ __forceinline__ int HC() const { return DYN ? hc : HALO; }
+  __device__ __forceinline__ int LH() const { return TH + 2 * HR(); }
+  __device__ __forceinline__ int LW() const { return TW + 2 * HC(); }
+  // Row pitch of the window IN LDS, in cells (= dwords of a paired-word plane row).  A run-time width that is a multiple of 32
+  // dwords (80 + 2 x 8 = 96, 80 + 2 x 24 = 128) puts the two rows an event adds to -- and every vertically adjacent pair of
+  // events -- on the same banks: the forward loop ran 26 us instead of 21 at 6 px flows (hc = 8).  The pitch is therefore the
+  // width rounded up to 16 modulo 32, what the built windows happen to have (112, 144); slabs stay dense (LW floats per row).
+  __device__ __forceinline__ int P() const { return DYN ? ((LW() - 16 + 31) / 32) * 32 + 16 : LW(); }
+};
+// cells of the LDS image of a kernel (accumulators + the dummy region that absorbs the adds of out-of-window lanes): the largest
+// window, at ITS pitch when the kernel chooses windows at run time
+template <int TH, int TW, int HALO, bool DYN>
+constexpr int acc_cells() {
+  constexpr int lw = TW + 2 * HALO, pt = DYN ? ((lw - 16 + 31) / 32) * 32 + 16 : lw;
+  return (TH + 2 * HALO) * pt + pt / 2 + 2;
+}
+// halo that keeps every tap of a displacement of at most `disp` pixels inside the window: floor(x + eps) moves by <= ceil(disp)
+// and the second tap sits one further
+__device__ __forceinline__ int halo_for(float disp, int align, int cap) {
+  const int need = (int)ceilf(fminf(disp, 4096.0f)) + 1;  // (NaN -> fminf gives 4096 -> the cap)
+  return min(cap, (max(need, 1) + align - 1) / align * align);
+}
+// (hr, hc) as one table word: the accumulate pass tells the combine pass what it stored for a tile
+__device__ __forceinline__ unsigned win_pack(int hr, int hc) { return (unsigned)hr | ((unsigned)hc << 8); }
+
 // The forward loop's form of a group: the tile-local column comes as a BYTE offset inside a row of the LDS window,
-// pcq = 4 * (col_in_tile + HALO) -- the unit every address of that loop is computed in (flow gather offset, LDS word)
+// pcq = 4 * (col_in_tile + hc) -- the unit every address of that loop is computed in (flow gather offset, LDS word)
 struct CGroupQ {
   unsigned pr[4], pcq[4];
   float dt[4];
 };
-template <int HALO>
-__device__ __forceinline__ void load_cgroup_q(CGroupQ& g, int32_t grp, const TileRange& tr, const EvPtrs& p) {
+__device__ __forceinline__ void load_cgroup_q(CGroupQ& g, int32_t grp, const TileRange& tr, const EvPtrs& p, unsigned hc4) {
   const int32_t j = max(min(grp, tr.g_last), tr.g_first);
   const float4 D = reinterpret_cast<const float4*>(p.cdt)[j];
   const uint2 P = reinterpret_cast<const uint2*>(p.cpix)[j];
   g.dt[0] = D.x; g.dt[1] = D.y; g.dt[2] = D.z; g.dt[3] = D.w;
-  g.pr[0] = (P.x >> 8) & 255u; g.pcq[0] = ((P.x & 255u) << 2) + 4u * HALO;
-  g.pr[1] = P.x >> 24;         g.pcq[1] = (((P.x >> 16) & 255u) << 2) + 4u * HALO;
-  g.pr[2] = (P.y >> 8) & 255u; g.pcq[2] = ((P.y & 255u) << 2) + 4u * HALO;
-  g.pr[3] = P.y >> 24;         g.pcq[3] = (((P.y >> 16) & 255u) << 2) + 4u * HALO;
+  g.pr[0] = (P.x >> 8) & 255u; g.pcq[0] = ((P.x & 255u) << 2) + hc4;
+  g.pr[1] = P.x >> 24;         g.pcq[1] = (((P.x >> 16) & 255u) << 2) + hc4;
+  g.pr[2] = (P.y >> 8) & 255u; g.pcq[2] = ((P.y & 255u) << 2) + hc4;
+  g.pr[3] = P.y >> 24;         g.pcq[3] = (((P.y >> 16) & 255u) << 2) + hc4;
 }
 
 // Slabs travel from the accumulate pass to the combine pass WRITE-THROUGH (sc1 buffer stores): the 16 MB a launch stores do not sit
@@ -382,13 +417,13 @@ struct ChunkQueue {
 
 // MODE == ACC_F64: the same loop with four ds_add_f64 per event -- the exact redo of a slice whose fixed-point fields
 // overflowed (hot pixels, or a flow that piles thousands of events onto one cell).
-template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false>
+template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false, bool DYN = false>
 __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                           const float* __restrict__ flow, int H, int W, bool* any_spill,
-                                                          const ChunkQueue& queue) {
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  constexpr unsigned kPlane = LH * LW / 2;  // words per plane
-  constexpr unsigned kDummy = LH * LW;      // first word of the dummy region (LW / 2 + 2 words)
+                                                          const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win) {
+  const int LH = win.LH(), LW = win.LW(), HR = win.HR(), HC = win.HC(), PT = win.P();  // (compile-time constants unless DYN)
+  const unsigned kPlane = LH * PT / 2;  // words per plane
+  const unsigned kDummy = LH * PT;      // first word of the dummy region (PT / 2 + 2 words)
   constexpr float kMagic = 12582912.0f;     // 1.5 * 2^23
   constexpr int kMagicBits = 0x4B400000;
   // GRID: `flow` is the tile's own [2][TH * TW] flow in LDS
@@ -400,14 +435,15 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   // (one v_mad_u32_u24 + one shift) plus a scalar offset for the tile origin / the second component, instead of
   // v_mul_lo_u32 + 64-bit address arithmetic per load (the loop is VALU-throughput-bound: DESIGN 4.1 #18)
   constexpr bool kBuf = !UNIFORM && !GRID;
-  // (pcq carries 4 * HALO: the descriptor's base is moved back by as much -- a scalar offset must not go negative, the address
+  // (pcq carries 4 * HC: the descriptor's base is moved back by as much -- a scalar offset must not go negative, the address
   // unit adds it as an unsigned 32-bit value -- and the range check gets the same allowance)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<char*>(const_cast<float*>(flow)) - 4 * HALO, 0, kBuf ? 2 * H * W * (int)sizeof(float) + 4 * HALO : 0, 0x00020000);
+      reinterpret_cast<char*>(const_cast<float*>(flow)) - 4 * HC, 0, kBuf ? 2 * H * W * (int)sizeof(float) + 4 * HC : 0, 0x00020000);
   const int soff0 = (int)(base_lin * 4u), soff1 = soff0 + H * W * (int)sizeof(float);
   const unsigned uW4 = uW * 4u;
-  const char* __restrict__ flow_b0 = reinterpret_cast<const char*>(flow) - 4 * HALO;   // GRID: byte-addressed LDS reads
-  const char* __restrict__ flow_b1 = reinterpret_cast<const char*>(flow1) - 4 * HALO;
+  const char* __restrict__ flow_b0 = reinterpret_cast<const char*>(flow) - 4 * HC;   // GRID: byte-addressed LDS reads
+  const char* __restrict__ flow_b1 = reinterpret_cast<const char*>(flow1) - 4 * HC;
+  const unsigned hc4 = 4u * (unsigned)HC, lw4 = 4u * (unsigned)PT;
   auto fetch = [&](unsigned pr, unsigned pcq, float& u, float& v) {
     if (UNIFORM) {
       u = uni_u, v = uni_v;
@@ -429,8 +465,8 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   // chunk c covers groups [g_first + 64 c, g_first + 64 c + 64); this wave starts with chunks `wave` and `wave + 16`
   int c_cur = wave, c_nxt = wave + kWaves;
   CGroupQ cur, nxt;
-  load_cgroup_q<HALO>(cur, tr.g_first + c_cur * kWave + lane, tr, ev);
-  load_cgroup_q<HALO>(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev);
+  load_cgroup_q(cur, tr.g_first + c_cur * kWave + lane, tr, ev, hc4);
+  load_cgroup_q(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev, hc4);
   float fu[4], fv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pcq[e], fu[e], fv[e]);
@@ -442,7 +478,7 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
     for (int e = 0; e < 4; ++e) fetch(nxt.pr[e], nxt.pcq[e], gu[e], gv[e]);
     const int c_nn = queue.pull();
     CGroupQ nn;
-    load_cgroup_q<HALO>(nn, tr.g_first + c_nn * kWave + lane, tr, ev);
+    load_cgroup_q(nn, tr.g_first + c_nn * kWave + lane, tr, ev, hc4);
     const bool lane_live = grp <= g_last;  // the last chunk of the slice may be partial
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -450,20 +486,22 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
       const float fr = fmaxf(lx - r0, 0.0f), fc = fmaxf(ly - c0, 0.0f);
       // row of the LDS window, and 4 x its column (= byte offset of the column's f32 / half the offset of its pair word)
-      const int rl = (int)cur.pr[e] + HALO + (int)r0;
+      const int rl = (int)cur.pr[e] + HR + (int)r0;
       const int cl4 = (int)cur.pcq[e] + ((int)c0 << 2);
-      // false for NaN (padding slots carry dt = NaN); +-Inf converts to INT_MAX / INT_MIN and fails the window test below
-      const bool ok = lane_live && !__builtin_isunordered(lx, ly);  // one v_cmp_o_f32
+      // false for NaN (padding slots carry dt = NaN), +-Inf and anything beyond 2^29: the column is tested in units of 4 (cl4), and
+      // (int)c0 << 2 WRAPS for |c0| >= 2^29 (INT_MAX << 2 = -4, INT_MIN << 2 = 0): such an event would pass the window test and be
+      // deposited at column pc - 1 or pc with full weight -- the reference masks it out
+      const bool ok = lane_live && (fabsf(lx) + fabsf(ly) < 5.0e8f);
       const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl4 < (unsigned)(4 * (LW - 1));
       spilled |= ok && !inside;
       if (MODE == ACC_F64) {  // one double per cell; out-of-window / padding lanes add +0.0 to cell (0, 0) (select, not
         const float a = 1.0f - fr, b = 1.0f - fc;  // multiply: their weights may be NaN)
         const int cl = cl4 >> 2;
-        double* cell = s_acc + (inside ? rl * LW + cl : 0);
+        double* cell = s_acc + (inside ? rl * PT + cl : 0);
         atomic_add(cell, (double)(inside ? a * b : 0.0f));
         atomic_add(cell + 1, (double)(inside ? a * fc : 0.0f));
-        atomic_add(cell + LW, (double)(inside ? fr * b : 0.0f));
-        atomic_add(cell + LW + 1, (double)(inside ? fr * fc : 0.0f));
+        atomic_add(cell + PT, (double)(inside ? fr * b : 0.0f));
+        atomic_add(cell + PT + 1, (double)(inside ? fr * fc : 0.0f));
         continue;
       }
       // The event's unit of weight (2^20) is split exactly: first between the two rows, then each row between its two
@@ -482,11 +520,11 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       //   8 (t >> 1) + 8 kPlane (t & 1) = 4 t + (t & 1) (8 kPlane - 4),   and t & 1 = cl & 1 (LW is even)
       // -- two multiply-adds and a bit-field extract on values the loop has anyway (4 cl), instead of and / compare / select /
       // shift / add on t (four VALU instructions per event fewer, one of them a compare: DESIGN 4.1 #18).
-      const unsigned t4 = __umul24((unsigned)rl, 4u * LW) + (unsigned)cl4;  // (rl < 2^24 whenever the result is used)
+      const unsigned t4 = __umul24((unsigned)rl, lw4) + (unsigned)cl4;  // (rl < 2^24 whenever the result is used)
       const unsigned byte = __umul24(((unsigned)cl4 >> 2) & 1u, 8u * kPlane - 4u) + t4;
       unsigned long long* w = reinterpret_cast<unsigned long long*>(s_bytes + (inside ? byte : 8u * kDummy));
       atomicAdd(w, ((unsigned long long)q01 << 32) | q00);
-      atomicAdd(w + LW / 2, ((unsigned long long)q11 << 32) | q10);
+      atomicAdd(w + PT / 2, ((unsigned long long)q11 << 32) | q10);  // (next row of the same plane: + 4 PT bytes)
     }
     cur = nxt;
     nxt = nn;
@@ -514,15 +552,16 @@ enum Pass { PASS_MAIN = 0, PASS_SPILL = 1 };
 
 // UNIFORM: one translation theta for all events (2-DoF model, src/warp.py:364-383: x' = x + dt * theta, i.e. a
 // dense flow of -theta everywhere) -- the two flow gathers disappear.
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM, bool GRID = false>
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
 __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                      const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
-                                                     float* spill, bool* any_spill, const ChunkQueue& queue) {
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+                                                     float* spill, bool* any_spill, const ChunkQueue& queue,
+                                                     const Win<TH, TW, HALO, DYN>& win) {
+  const int LH = win.LH(), LW = win.LW(), PT = win.P();
   unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
   const int tr0 = tr.ty * TH, tc0 = tr.tx * TW;
-  const int oy = tr0 - HALO, ox = tc0 - HALO;  // LDS cell (0,0) = un-padded pixel (oy, ox)
+  const int oy = tr0 - win.HR(), ox = tc0 - win.HC();  // LDS cell (0,0) = un-padded pixel (oy, ox)
   const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)TH * TW : (int64_t)H * W);
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;  // flow == theta pair
   const int fl_r0 = GRID ? tr0 : 0, fl_c0 = GRID ? tc0 : 0, fl_w = GRID ? TW : W;  // GRID: tile-local flow in LDS
@@ -530,7 +569,7 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
   bool spilled = false;
   if (tr.g_first > tr.g_last) return 0;
   if (FMT == FMT_COMPACT && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop (fixed point, or its exact f64 redo)
-    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID>(tr, s_acc, ev, flow, H, W, any_spill, queue);
+    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID, DYN>(tr, s_acc, ev, flow, H, W, any_spill, queue, win);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
   const int32_t g_last = tr.g_last;
@@ -578,15 +617,15 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
           const unsigned q10 = (unsigned)(__float_as_int(__fmaf_rn(fs, b, kMagic)) - kMagicBits);
           const unsigned q01 = (unsigned)(__float_as_int(__fmaf_rn(as, fcq, kMagic)) - kMagicBits);
           const unsigned q11 = (unsigned)(__float_as_int(__fmaf_rn(fs, fcq, kMagic)) - kMagicBits);
-          const unsigned t = (unsigned)(rl * LW + cl);
-          const int word = inside ? (int)((t >> 1) + (t & 1u) * (LH * LW / 2)) : LH * LW;  // LH*LW.. = dummy region
+          const unsigned t = (unsigned)(rl * PT + cl);
+          const int word = inside ? (int)((t >> 1) + (t & 1u) * (LH * PT / 2)) : LH * PT;  // LH*PT.. = dummy region
           atomicAdd(s_fx + word, ((unsigned long long)q01 << 32) | q00);
-          atomicAdd(s_fx + word + LW / 2, ((unsigned long long)q11 << 32) | q10);
+          atomicAdd(s_fx + word + PT / 2, ((unsigned long long)q11 << 32) | q10);
           added += q00 + q10 + q01 + q11;
         } else {
           const float as = a * ws, fs = frq * ws;
-          const int cell = inside ? rl * LW + cl : LH * LW;
-          const int dn = inside ? LW : 0;
+          const int cell = inside ? rl * PT + cl : LH * PT;
+          const int dn = inside ? PT : 0;
           atomic_add(&s_acc[cell], (double)(as * b));
           atomic_add(&s_acc[cell + dn], (double)(fs * b));
           atomic_add(&s_acc[cell + 1], (double)(as * fcq));
@@ -628,28 +667,91 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 __device__ __forceinline__ long long fx_lo(long long v) { return (long long)(int)(unsigned)(v & 0xffffffffll); }
 __device__ __forceinline__ long long fx_hi(long long v) { return (v - fx_lo(v)) >> 32; }
 
-// the accumulate pass of one work item (blockIdx.x) of one window: shared by the single-window and the batched kernel
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false>
+// ---- run-time LDS windows (DYN kernels): a bound on the tile's displacements --------------------------------------------------
+// max |u|, max |v| over the tile's own pixels of a dense flow [2, H, W]: unconditional clamped loads, all in flight at once (the
+// same lines the loop's gathers are about to fetch: they warm the L2 for them).  NaN entries are ignored (their events are
+// dropped by the loop), Inf gives Inf (-> the largest window).  Valid per thread; reduce with tile_bound_reduce.
+template <int TH, int TW>
+__device__ __forceinline__ void tile_flow_absmax(const float* __restrict__ flow, int H, int W, int tr0, int tc0, float& mu, float& mv) {
+  constexpr int kIt = (TH * TW + kBlock - 1) / kBlock;
+  float u[kIt], v[kIt];
+#pragma unroll
+  for (int k = 0; k < kIt; ++k) {
+    const int i = min((int)threadIdx.x + k * kBlock, TH * TW - 1);
+    const int rl = i / TW, cl = i - rl * TW;
+    const int64_t o = (int64_t)min(tr0 + rl, H - 1) * W + min(tc0 + cl, W - 1);
+    u[k] = flow[o];
+    v[k] = flow[(int64_t)H * W + o];
+  }
+  mu = mv = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kIt; ++k) {
+    mu = fmaxf(mu, fabsf(u[k]));
+    mv = fmaxf(mv, fabsf(v[k]));
+  }
+}
+// per-wave maxima -> s_red [2 * waves]; the caller's next barrier publishes them and tile_bound_read folds them (every thread,
+// broadcast reads: no barrier of its own)
+__device__ __forceinline__ void tile_bound_post(float mu, float mv, float* s_red) {
+  mu = wave_max(mu);
+  mv = wave_max(mv);
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    s_red[threadIdx.x / kWave] = mu;
+    s_red[kBlock / kWave + threadIdx.x / kWave] = mv;
+  }
+}
+template <int TH, int TW, int HALO, bool DYN>
+__device__ __forceinline__ Win<TH, TW, HALO, DYN> tile_bound_read(const float* s_red, float dt_bound) {
+  Win<TH, TW, HALO, DYN> w{HALO, HALO};
+  if (DYN) {
+    float mu = 0.0f, mv = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; ++k) {
+      mu = fmaxf(mu, s_red[k]);
+      mv = fmaxf(mv, s_red[kBlock / kWave + k]);
+    }
+    w.hr = halo_for(mu * dt_bound, 1, HALO);
+    w.hc = halo_for(mv * dt_bound, 4, HALO);
+  }
+  return w;
+}
+
+// the accumulate pass of one work item (blockIdx.x) of one window: shared by the single-window and the batched kernels.
+//   DYN      the LDS window is chosen per tile at run time (Win above); halo_tab [tiles] tells the combine pass
+//   ZERO     the decode pass zeroes every LDS word it reads, so that the NEXT window of a persistent workgroup starts on a clean
+//            image without a clear of its own (do_clear = false after the first)
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false, bool ZERO = false>
 __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t* __restrict__ key_offsets,
                                                 const float* __restrict__ flow_arg, int H, int W, int tiles_x, int splits, int pad_h,
                                                 int pad_w, float* __restrict__ slabs, float* spill, const GridSrc& gs,
-                                                unsigned* __restrict__ spill_epoch, unsigned epoch) {
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  constexpr int kCells = LH * LW + LW / 2 + 2;  // + a dummy region that absorbs the adds of out-of-window lanes
-  static_assert(LW % 4 == 0, "slab rows are written 4 cells at a time");
+                                                unsigned* __restrict__ spill_epoch, unsigned epoch, float dt_bound = 0.0f,
+                                                unsigned* __restrict__ halo_tab = nullptr, bool do_clear = true) {
+  constexpr int kLHmax = TH + 2 * HALO, kLWmax = TW + 2 * HALO;
+  constexpr int kCells = acc_cells<TH, TW, HALO, DYN>();
+  static_assert(kLWmax % 4 == 0, "slab rows are written 4 cells at a time");
+  static_assert(!DYN || (FMT == FMT_COMPACT && !HAS_W), "run-time windows: the lean loop only");
   extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words; + dummy
   __shared__ unsigned long long s_chk[1];  // sum over the workgroup of (units added - units decoded), modulo 2^64
   __shared__ int s_flag[2];  // [0] fixed-point overflow, [1] some event left the LDS window
   __shared__ unsigned s_next;  // chunk queue of the lean loop
+  __shared__ float s_bound[2 * kBlock / kWave];  // DYN: per-wave maxima of |u|, |v| over the tile
   const ChunkQueue queue{&s_next};
   EBOS_STAMP(0);
   static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
-  // (dense field: the clear comes first -- it needs nothing, and the dependent loads of tile_range fly over it)
-  if (!GRID)
+  // (dense field: the clear comes first -- it needs nothing, and the dependent loads of tile_range fly over it; run-time
+  // windows: the tile's flow values, which bound its displacements, are requested before the clear and awaited after it)
+  constexpr bool kBoundFromFlow = DYN && !GRID && !UNIFORM;
+  if (!GRID && !kBoundFromFlow && do_clear)
     for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
       reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, splits);
   if (tr.ty < 0) return;  // unused work item of an adaptive plan: its slab is never read
+  float mu = 0.0f, mv = 0.0f;
+  if (kBoundFromFlow) {
+    tile_flow_absmax<TH, TW>(flow_arg, H, W, tr.ty * TH, tr.tx * TW, mu, mv);
+    if (do_clear)
+      for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+  }
 
   const float* flow = flow_arg;
   float* s_flow = reinterpret_cast<float*>(s_acc + kCells);  // GRID: the tile's dense flow, behind the accumulators
@@ -657,23 +759,37 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   TileGrid tg{};
   if (GRID) {
     tg = tile_grid_begin<TH, TW, 0>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);  // (its cell load flies over the clear)
-    for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+    if (do_clear)
+      for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   }
   if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     s_next = 2 * (kBlock / kWave);
     s_chk[0] = 0ull;
   }
+  if (DYN) {  // a bound on this tile's displacements: |flow| over the tile (dense), the cells its pixels interpolate (GRID), theta
+    if (UNIFORM) {
+      mu = fabsf(flow_arg[0]), mv = fabsf(flow_arg[1]);
+    } else if (GRID) {  // (bilinear interpolation never leaves the range of its cells; every thread holds a cell of the block)
+      const int idx = min((int)threadIdx.x, 2 * tg.ni * tg.nj - 1);
+      const bool second = idx >= tg.ni * tg.nj;
+      mu = second ? 0.0f : fabsf(tg.cell), mv = second ? fabsf(tg.cell) : 0.0f;
+    }
+    tile_bound_post(mu, mv, s_bound);
+  }
   if (GRID) {
     tile_grid_finish<TH, TW, 0>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
     flow = s_flow;
   }
   __syncthreads();
+  const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(s_bound, dt_bound);
+  const int LH = win.LH(), LW = win.LW(), PT = win.P();  // (PT: row pitch in LDS; slabs are dense, LW floats per row)
+  if (DYN && threadIdx.x == 0) halo_tab[tr.ty * tiles_x + tr.tx] = win_pack(win.hr, win.hc);  // (every part of a tile: same word)
   EBOS_STAMP(1);
 
   bool spilled = false;
-  unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID>(
-      tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue);
+  unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN>(
+      tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win);
   constexpr bool kLeanLoop = FMT == FMT_COMPACT && !HAS_W;  // accumulate_compact_fx: counts nothing per event
   if (kLeanLoop && threadIdx.x == 0 && tr.g_first <= tr.g_last)  // 2^20 units per event of the slice (padding slots excluded)
     added += (unsigned long long)(min(tr.end, tr.beg + 4 * (tr.g_last - tr.g_first + 1)) - tr.beg) << kFxShift;
@@ -685,12 +801,13 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   // pass reads the 3.7 MB spill image only if the stamp is this call's (it is all zero otherwise, and stays so)
   if (s_flag[1] && threadIdx.x == 0) *spill_epoch = epoch;  // benign race: every writer stores the same value
   if (s_flag[1])  // rare: taps beyond the halo go to the spill image with global atomics (lean path: minus their units)
-    added -= accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
-                                                                                         nullptr, queue);
+    added -= accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID, DYN>(tr, s_acc, ev, flow, H, W, pad_h, pad_w,
+                                                                                              spill, nullptr, queue, win);
 
-  float4* out = reinterpret_cast<float4*>(slabs + (int64_t)tr.slab * (LH * LW));
+  // (the slab stride is the LARGEST window's: a run-time window fills the first LH * LW floats of its slab)
+  float4* out = reinterpret_cast<float4*>(slabs + (int64_t)tr.slab * (kLHmax * kLWmax));
 #ifndef EBOS_PLAIN_SLABS
-  const __amdgpu_buffer_rsrc_t out_rsrc = slab_rsrc(reinterpret_cast<const float*>(out), (unsigned)(LH * LW * sizeof(float)));
+  const __amdgpu_buffer_rsrc_t out_rsrc = slab_rsrc(reinterpret_cast<const float*>(out), (unsigned)(kLHmax * kLWmax * sizeof(float)));
 #define EBOS_SLAB_STORE(i, v) slab_store4(out_rsrc, (unsigned)(i) * 16u, (v))
 #else
 #define EBOS_SLAB_STORE(i, v) out[i] = (v)
@@ -705,20 +822,48 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
     //   (it was, until a 40 000-event hot pixel showed it).  Both changes are negative: they cannot cancel.
     // Fields are unsigned 32-bit: lo = low dword (column c), hi = high dword (column c + 1).  The two fields that make
     // up one pixel (plane A + plane B) are added as floats: their integer sum could pass 2^32 although neither did.
-    const uint2* pa = reinterpret_cast<const uint2*>(s_acc);
-    const uint2* pb = pa + LH * LW / 2;
+    uint2* pa = reinterpret_cast<uint2*>(s_acc);
+    uint2* pb = pa + LH * PT / 2;
     unsigned long long decoded = 0;
     constexpr float kInv = (float)kFxInv;
-    for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
-      const int r = i / (LW / 4), j = i - r * (LW / 4);  // cells 4j..4j+3 <- A words 2j, 2j+1 and B words 2j-1, 2j, 2j+1
-      const int wrow = r * (LW / 2);
+    // cells 4j..4j+3 of row r <- A words 2j, 2j+1 and B words 2j-1, 2j, 2j+1 (pair (4j-1, 4j): its lo field belongs to the previous quad)
+    auto decode_quad = [&](int r, int j, int slab_quad) {
+      const int wrow = r * (PT / 2);
       const uint2 a0 = pa[wrow + 2 * j], a1 = pa[wrow + 2 * j + 1];
       const uint2 b0 = pb[wrow + 2 * j], b1 = pb[wrow + 2 * j + 1];
-      const unsigned bmh = j > 0 ? pb[wrow + 2 * j - 1].y : 0u;  // pair (4j-1, 4j); its lo field belongs to the previous group
+      const unsigned bmh = j > 0 ? pb[wrow + 2 * j - 1].y : 0u;
+      if (ZERO) {
+        const uint2 z = make_uint2(0u, 0u);
+        pa[wrow + 2 * j] = z, pa[wrow + 2 * j + 1] = z;
+        pb[wrow + 2 * j] = z, pb[wrow + 2 * j + 1] = z;
+      }
       decoded += ((unsigned long long)a0.x + a0.y) + ((unsigned long long)a1.x + a1.y) + ((unsigned long long)b0.x + b0.y) +
                  ((unsigned long long)b1.x + b1.y);
-      EBOS_SLAB_STORE(i, make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv,
-                                     ((float)a1.x + (float)b0.y) * kInv, ((float)a1.y + (float)b1.x) * kInv));
+      EBOS_SLAB_STORE(slab_quad, make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv,
+                                             ((float)a1.x + (float)b0.y) * kInv, ((float)a1.y + (float)b1.x) * kInv));
+    };
+    if (ZERO) {
+      // Rows are dealt to WAVES (64 / q rows per wave and step, q = LW / 4 quads per row): a word that two neighbouring quads read
+      // (the pair that straddles them) is read by two lanes of ONE wave -- in program order before either lane's zeroing store --
+      // so the decode pass can zero what it reads without a second pass over the image.
+      const int q = LW / 4, rpi = kWave / q;  // (q <= 64: LW <= 256)
+      const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+      int sub = 0, j = lane;
+      while (j >= q) j -= q, ++sub;  // (<= 3 steps: q >= 16 for the built tiles)
+      const bool act = sub < rpi;
+      for (int r0 = wave * rpi; r0 < LH; r0 += (kBlock / kWave) * rpi) {
+        const int r = r0 + sub;
+        if (act && r < LH) decode_quad(r, j, r * q + j);
+      }
+      // the dummy region took the (garbage) adds of out-of-window lanes; a later window may lay real cells over it
+      for (int i = threadIdx.x; i < PT / 2 + 2; i += kBlock) reinterpret_cast<unsigned long long*>(s_acc)[LH * PT + i] = 0ull;
+    } else {
+      const int q = LW / 4;
+      const float inv_q = 1.0f / (float)q;  // (run-time width: row = floor((i + 0.5) / q) exactly for i < 2^16)
+      for (int i = threadIdx.x; i < LH * q; i += kBlock) {
+        const int r = DYN ? (int)(((float)i + 0.5f) * inv_q) : i / q;
+        decode_quad(r, i - r * q, i);
+      }
     }
     // sum(added) == sum(decoded) over the workgroup  <=>  sum(added - decoded) == 0 modulo 2^64: one value per lane, one DPP wave
     // sum, one LDS atomic per wave, one barrier (two values, shuffles, a serial 32-term loop and two barriers before)
@@ -729,35 +874,45 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
       for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
       if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);  // the redo draws its chunks afresh
       __syncthreads();
-      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM, GRID>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
-                                                                                    nullptr, queue);
+      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM, GRID, DYN>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
+                                                                                         nullptr, queue, win);
       __syncthreads();
       f64_flush = true;
     }
   }
   if (f64_flush) {
     // slab = the LDS image as f32, 16 B per lane, fully coalesced plain stores
-    for (int i = threadIdx.x; i < LH * LW / 4; i += kBlock) {
-      const double* p = &s_acc[4 * i];
+    const int q = LW / 4;
+    const float inv_q = 1.0f / (float)q;
+    for (int i = threadIdx.x; i < LH * q; i += kBlock) {
+      const int r = DYN ? (int)(((float)i + 0.5f) * inv_q) : i / q;
+      double* p = &s_acc[r * PT + 4 * (i - r * q)];
       EBOS_SLAB_STORE(i, make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]));
+      if (ZERO) p[0] = p[1] = p[2] = p[3] = 0.0;
     }
+    if (ZERO)
+      for (int i = threadIdx.x; i < PT / 2 + 2; i += kBlock) s_acc[LH * PT + i] = 0.0;
   }
   EBOS_STAMP(4);
 }
 
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false>
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
 __global__ void __launch_bounds__(kBlock)
 iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
                            int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill, GridSrc gs,
-                           unsigned* __restrict__ spill_epoch, unsigned epoch) {
-  accumulate_tile<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID>(ev, key_offsets, flow_arg, H, W, tiles_x, splits, pad_h, pad_w, slabs,
-                                                                 spill, gs, spill_epoch, epoch);
+                           unsigned* __restrict__ spill_epoch, unsigned epoch, float dt_bound, unsigned* __restrict__ halo_tab) {
+  accumulate_tile<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN>(ev, key_offsets, flow_arg, H, W, tiles_x, splits, pad_h, pad_w,
+                                                                      slabs, spill, gs, spill_epoch, epoch, dt_bound, halo_tab);
 }
 
 // ---- several independent windows of one geometry in ONE launch (ebos_iwe_slab_batch_f32) ---------------------------------
-// Thin windows (BASELINE configs[3]: 2 M events) are bound by per-launch and per-workgroup fixed work, and at one workgroup per CU
-// consecutive accumulate launches cannot overlap: batched, a CU starts the next window's workgroup the moment it has finished
-// this one's.  The windows' pointers travel by value in the kernel arguments (blockIdx.y / .z selects the window).
+// Thin windows (BASELINE configs[3]: 2 M events) are bound by per-workgroup fixed work, not by their events: of 10.7 us a
+// (tile, window) workgroup spent 1.6 clearing its LDS image, 2.2 evaluating the tile's flow, 2.4 in the event loop, 1.5 at the
+// barrier and 3.0 decoding and storing its slab (in-kernel stamps).  The batched accumulate pass is therefore
+// PERSISTENT: workgroup b takes work item b of EVERY window of the batch in turn.  The LDS image is cleared once; afterwards the
+// decode pass zeroes each word as it reads it (ZERO), and the write-through slab stores of window k drain while the workgroup is
+// already setting up and looping over window k + 1 (nothing waits for them until the kernel ends).
+// The windows' pointers travel by value in the kernel arguments.
 struct FwdWindow {
   EvPtrs ev;
   const int32_t* key_offsets;
@@ -765,6 +920,7 @@ struct FwdWindow {
   float* slabs;          // this window's workspace sections
   float* spill;
   unsigned* spill_epoch;
+  unsigned* halo_tab;
   double* partials;
   float* iwe;
   float* out_var;        // nullable
@@ -776,12 +932,25 @@ struct FwdBatch {
 };
 static_assert(sizeof(FwdBatch) <= 3072, "the batch travels in the kernel argument segment");
 
-template <int TH, int TW, int HALO, bool GRID>
+template <int TH, int TW, int HALO, bool GRID, bool DYN>
 __global__ void __launch_bounds__(kBlock)
-iwe_slab_accumulate_batch_kernel(FwdBatch b, int H, int W, int tiles_x, int splits, int pad_h, int pad_w, GridSrc gs, unsigned epoch) {
-  const FwdWindow& w = b.w[blockIdx.y];
-  accumulate_tile<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, GRID>(w.ev, w.key_offsets, w.flow, H, W, tiles_x, splits, pad_h, pad_w,
-                                                                         w.slabs, w.spill, gs, w.spill_epoch, epoch);
+iwe_slab_accumulate_batch_kernel(FwdBatch b, int n, int H, int W, int tiles_x, int splits, int pad_h, int pad_w, GridSrc gs,
+                                 unsigned epoch, float dt_bound) {
+  EBOS_STAMP(5);
+  {  // the one clear of the LDS image (here, not in the first window's pass: that one may be an unused work item and return early)
+    extern __shared__ double s_acc[];
+    constexpr int kCells = acc_cells<TH, TW, HALO, DYN>();
+    for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+    __syncthreads();
+  }
+  for (int k = 0; k < n; ++k) {
+    const FwdWindow& w = b.w[k];
+    accumulate_tile<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, GRID, DYN, true>(w.ev, w.key_offsets, w.flow, H, W, tiles_x, splits,
+                                                                                      pad_h, pad_w, w.slabs, w.spill, gs, w.spill_epoch,
+                                                                                      epoch, dt_bound, w.halo_tab, false);
+    __syncthreads();  // the flags / counters of this window are re-initialised by the next one
+  }
+  EBOS_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -789,11 +958,14 @@ iwe_slab_accumulate_batch_kernel(FwdBatch b, int H, int W, int tiles_x, int spli
 // ---------------------------------------------------------------------------------------------------
 constexpr int kCombineBlock = 256;
 
+// halo_tab (DYN accumulate pass; nullptr otherwise): the window (hr, hc) each tile's slabs were stored with -- candidates are found
+// with the largest window HALO, a candidate whose own window does not reach the pixel is skipped
 template <int TH, int TW, int HALO>
 __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
-                        const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch) {
+                        const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch,
+                        const unsigned* __restrict__ halo_tab) {
   const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
 #ifndef EBOS_PLAIN_SLABS
   const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(slabs, 0xffffffffu);  // (offsets stay below the workspace size: < 4 GiB)
@@ -812,16 +984,21 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
     int tx1 = (c + HALO >= 0) ? (c + HALO) / TW : -1;
     if (tx1 > tiles_x - 1) tx1 = tiles_x - 1;
     for (int ty = ty0; ty <= ty1; ++ty) {
-      const int rl = r - (ty * TH - HALO);
       for (int tx = tx0; tx <= tx1; ++tx) {
-        const int cl = c - (tx * TW - HALO);
         const int tile = ty * tiles_x + tx;
+        int hr = HALO, hc = HALO;
+        if (halo_tab != nullptr) {
+          const unsigned t = halo_tab[tile];
+          hr = (int)(t & 255u), hc = (int)(t >> 8);
+        }
+        const int rl = r - (ty * TH - hr), cl = c - (tx * TW - hc), lw = TW + 2 * hc;
+        if ((unsigned)rl >= (unsigned)(TH + 2 * hr) || (unsigned)cl >= (unsigned)lw) continue;
         const int s0 = part_off ? part_off[tile] : tile * splits, np = part_off ? part_off[tile + 1] - s0 : splits;
 #ifndef EBOS_PLAIN_SLABS
-        const unsigned s_byte = ((unsigned)s0 * (unsigned)(LH * LW) + (unsigned)(rl * LW + cl)) * 4u;
+        const unsigned s_byte = ((unsigned)s0 * (unsigned)(LH * LW) + (unsigned)(rl * lw + cl)) * 4u;
         for (int p = 0; p < np; ++p) v += slab_load1(all_slabs, s_byte + (unsigned)p * (unsigned)(LH * LW * 4));
 #else
-        const float* s = slabs + (int64_t)s0 * (LH * LW) + rl * LW + cl;
+        const float* s = slabs + (int64_t)s0 * (LH * LW) + rl * lw + cl;
         for (int p = 0; p < np; ++p) v += s[(int64_t)p * (LH * LW)];
 #endif
       }
@@ -851,11 +1028,12 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
 // many moment partials at 1280x720.  Needs w, pad_w, HALO, TW multiples of 4 (the scalar kernel covers the rest).
 constexpr int kCombineRows = 4;
 
-template <int TH, int TW, int HALO>
+template <int TH, int TW, int HALO, bool DYN>
 __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
                                                int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo,
                                                double* __restrict__ partials, const int32_t* __restrict__ part_off,
-                                               const unsigned* __restrict__ spill_epoch, unsigned epoch) {
+                                               const unsigned* __restrict__ spill_epoch, unsigned epoch,
+                                               const unsigned* __restrict__ halo_tab) {
   const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
 #ifndef EBOS_PLAIN_SLABS
   const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(slabs, 0xffffffffu);  // (offsets stay below the workspace size: < 4 GiB)
@@ -868,6 +1046,21 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
   const int r = R - pad_h, c = C - pad_w;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool live = R < h && C < w;
+  // DYN: the windows of the tiles this workgroup's 4 x 256 pixels can see, fetched ONCE into LDS (a per-candidate global load would
+  // put a dependent L2 round trip in front of every slab load: +1.3 us on a 7.8 us pass)
+  constexpr int kTabY = (kCombineRows + 2 * HALO + TH - 1) / TH + 2, kTabX = (256 + 2 * HALO + TW - 1) / TW + 2;  // (floor differences + 1)
+  __shared__ unsigned s_tab[DYN ? kTabY * kTabX : 1];
+  int tab_y0 = 0, tab_x0 = 0;
+  if (DYN) {
+    const int r_first = (int)blockIdx.y * kCombineRows - pad_h, c_first = (int)blockIdx.x * 256 - pad_w;
+    tab_y0 = max((r_first - HALO - TH + 1 >= 0) ? (r_first - HALO) / TH : 0, 0);   // (a lower bound of every pixel's ty0 / tx0)
+    tab_x0 = max((c_first - HALO - TW + 1 >= 0) ? (c_first - HALO) / TW : 0, 0);
+    for (int i = threadIdx.x; i < kTabY * kTabX; i += kCombineBlock) {
+      const int ty = min(tab_y0 + i / kTabX, tiles_y - 1), tx = min(tab_x0 + i % kTabX, tiles_x - 1);
+      s_tab[i] = halo_tab[ty * tiles_x + tx];
+    }
+    __syncthreads();
+  }
   if (live) {
     int ty0 = (r - HALO - TH + 1 >= 0) ? (r - HALO - TH + 1 + TH - 1) / TH : 0;
     int ty1 = (r + HALO >= 0) ? (r + HALO) / TH : -1;
@@ -876,15 +1069,20 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
     int tx1 = (c + HALO >= 0) ? (c + HALO) / TW : -1;
     if (tx1 > tiles_x - 1) tx1 = tiles_x - 1;
     for (int ty = ty0; ty <= ty1; ++ty) {
-      const int rl = r - (ty * TH - HALO);
       for (int tx = tx0; tx <= tx1; ++tx) {
-        const int cl = c - (tx * TW - HALO);
         const int tile = ty * tiles_x + tx;
+        int hr = HALO, hc = HALO;
+        if (DYN) {  // (hc is a multiple of 4 and so is c: a quad lies inside a window or outside it, never across its edge)
+          const unsigned t = s_tab[(ty - tab_y0) * kTabX + (tx - tab_x0)];
+          hr = (int)(t & 255u), hc = (int)(t >> 8);
+        }
+        const int rl = r - (ty * TH - hr), cl = c - (tx * TW - hc), lw = TW + 2 * hc;
+        if (DYN && ((unsigned)rl >= (unsigned)(TH + 2 * hr) || (unsigned)cl >= (unsigned)lw)) continue;
         const int s0 = part_off ? part_off[tile] : tile * splits, np = part_off ? part_off[tile + 1] - s0 : splits;
 #ifndef EBOS_PLAIN_SLABS
-        const unsigned sp_byte = ((unsigned)s0 * (unsigned)(LH * LW) + (unsigned)(rl * LW + cl)) * 4u;
+        const unsigned sp_byte = ((unsigned)s0 * (unsigned)(LH * LW) + (unsigned)(rl * lw + cl)) * 4u;
 #else
-        const float* sp = slabs + (int64_t)s0 * (LH * LW) + rl * LW + cl;
+        const float* sp = slabs + (int64_t)s0 * (LH * LW) + rl * lw + cl;
 #endif
         for (int p = 0; p < np; ++p) {
 #ifndef EBOS_PLAIN_SLABS
@@ -931,22 +1129,24 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
   }
 }
 
-template <int TH, int TW, int HALO>
+template <int TH, int TW, int HALO, bool DYN = false>
 __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
                          int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
-                         const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch) {
-  combine4_block<TH, TW, HALO>(slabs, spill, tiles_y, tiles_x, splits, H, W, pad_h, pad_w, iwe, g_lo, partials, part_off, spill_epoch,
-                               epoch);
+                         const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch,
+                         const unsigned* __restrict__ halo_tab) {
+  combine4_block<TH, TW, HALO, DYN>(slabs, spill, tiles_y, tiles_x, splits, H, W, pad_h, pad_w, iwe, g_lo, partials, part_off,
+                                    spill_epoch, epoch, halo_tab);
 }
 
-template <int TH, int TW, int HALO>
+template <int TH, int TW, int HALO, bool DYN = false>
 __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine4_batch_kernel(FwdBatch b, int tiles_y, int tiles_x, int splits, int H, int W, int pad_h, int pad_w, int g_lo,
                                int want_var, unsigned epoch) {
   const FwdWindow& w = b.w[blockIdx.z];
-  combine4_block<TH, TW, HALO>(w.slabs, w.spill, tiles_y, tiles_x, splits, H, W, pad_h, pad_w, w.iwe, g_lo,
-                               want_var ? w.partials : nullptr, splits == 0 ? w.ev.part_off : nullptr, w.spill_epoch, epoch);
+  combine4_block<TH, TW, HALO, DYN>(w.slabs, w.spill, tiles_y, tiles_x, splits, H, W, pad_h, pad_w, w.iwe, g_lo,
+                                    want_var ? w.partials : nullptr, splits == 0 ? w.ev.part_off : nullptr, w.spill_epoch, epoch,
+                                    w.halo_tab);
 }
 
 // one workgroup: partials -> out (unbiased variance), moments (mean, M).  Fixed summation order.
@@ -994,12 +1194,12 @@ struct GradImage {
 // Same budget discipline as accumulate_compact_fx.  PASS_MAIN: events whose four taps lie inside the LDS window of the
 // upstream image (others read a dummy cell and contribute 0, but raise the flag); PASS_SPILL: the rare second sweep
 // for exactly those events, reading the upstream image from global memory.
-template <int TH, int TW, int HALO, bool UNIFORM, int PASS, bool GRID = false>
+template <int TH, int TW, int HALO, bool UNIFORM, int PASS, bool GRID = false, bool DYN = false>
 __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s_d, const float* s_g, const EvPtrs& ev,
                                                   const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                   const GradImage& G, double& tot_x, double& tot_y, bool* any_spill,
-                                                  const ChunkQueue& queue) {
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+                                                  const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win) {
+  const int LH = win.LH(), LW = win.LW(), HR = win.HR(), HC = win.HC();  // (compile-time constants unless DYN)
   constexpr int PH = TH + 2 * kBwdApron, PW = TW + 2 * kBwdApron;  // GRID: the tile's flow (+ apron) in LDS
   const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)PH * PW : (int64_t)H * W);
   const float uni_u = UNIFORM ? -flow[0] : 0.0f, uni_v = UNIFORM ? -flow[1] : 0.0f;
@@ -1054,9 +1254,10 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
       const float lx = -edt * fu[e], ly = -edt * fv[e];
       const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
       const float fr = lx - r0, fc = ly - c0;
-      const int rl = (int)cur.pr[e] + HALO + (int)r0, cl = (int)cur.pc[e] + HALO + (int)c0;
-      // false for NaN (padding slots carry dt = NaN); +-Inf converts to INT_MAX / INT_MIN and fails the window test below
-      const bool ok = lane_live && !__builtin_isunordered(lx, ly);  // one v_cmp_o_f32
+      const int rl = (int)cur.pr[e] + HR + (int)r0, cl = (int)cur.pc[e] + HC + (int)c0;
+      // false for NaN (padding slots carry dt = NaN), +-Inf and anything beyond 2^29 -- the forward loop's test, so that value and
+      // gradient agree on which events exist (an Inf displacement has NaN fractions: the spill sweep must not take it either)
+      const bool ok = lane_live && (fabsf(lx) + fabsf(ly) < 5.0e8f);
       const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
       float g00, g10, g01, g11;
       bool use;
@@ -1070,7 +1271,7 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
         g11 = p[LW + 1];
       } else {
         use = ok && !inside;
-        const int R = tr0 - HALO + rl + pad_h, C = tc0 - HALO + cl + pad_w;
+        const int R = tr0 - HR + rl + pad_h, C = tc0 - HC + cl + pad_w;
         g00 = use ? G.at(R, C) : 0.0f;
         g10 = use ? G.at(R + 1, C) : 0.0f;
         g01 = use ? G.at(R, C + 1) : 0.0f;
@@ -1123,7 +1324,9 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
 // the workgroup writes the adjoint of the grid -> dense map restricted to its tile: a block of <= kGridCells x kGridCells
 // partial cell gradients per flow component (part_out [items][2][kGridCells][kGridCells]); patch_grad_combine_kernel
 // (flow_upsample.hip) sums the tiles that touch a cell.  `adaptive`: work items of the plan's part table.
-template <int TH, int TW, int HALO, bool HAS_W, int FMT, bool UNIFORM, bool GRID = false>
+// DYN: the LDS window of the upstream image is chosen per tile at run time (Win), from the same bound as the forward pass's --
+// the 63 KB per workgroup that a 32 px halo stages shrink to what the tile's displacements can reach.
+template <int TH, int TW, int HALO, bool HAS_W, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
 __global__ void __launch_bounds__(kBlock)
 iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
                            int tiles_x, int pad_h, int pad_w, const float* __restrict__ g_image,
@@ -1131,13 +1334,14 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
                            float* __restrict__ d_weight, double* __restrict__ partials,
                            const double* __restrict__ var_moments, const float* __restrict__ upstream,
                            const float* __restrict__ addend, float* __restrict__ part_out, GridSrc gs, int adaptive,
-                           float s_norm, float s_tv, double* __restrict__ reg_partials, MomentsIn mj) {
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+                           float s_norm, float s_tv, double* __restrict__ reg_partials, MomentsIn mj, float dt_bound) {
+  constexpr int kLHmax = TH + 2 * HALO, kLWmax = TW + 2 * HALO;
+  static_assert(!DYN || (FMT == FMT_COMPACT && !HAS_W), "run-time windows: the lean loop only");
   extern __shared__ double s_raw[];
   double* s_d = s_raw;                                             // [2][TH*TW] d_flow accumulators
   float* s_g = reinterpret_cast<float*>(s_raw + 2 * TH * TW);      // [LH][LW] upstream gradient tile
   constexpr int AP = kBwdApron, PH = TH + 2 * AP, PW = TW + 2 * AP;
-  float* s_flow = s_g + LH * LW;                                   // GRID: [2][PH][PW] flow of this tile + apron
+  float* s_flow = s_g + kLHmax * kLWmax;                           // GRID: [2][PH][PW] flow of this tile + apron
   Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * PH * PW);    // GRID: [PH + PW] row / column interpolation
   // part_out != nullptr (dense): adaptive work items -- this workgroup is one part of a tile and writes its partial d_flow
   // tile to slab tr.slab of part_out; bwd_parts_combine_kernel sums the parts
@@ -1145,6 +1349,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   __shared__ double s_mom[2];
   __shared__ int s_spill;  // some event's taps left the LDS window of the upstream image
   __shared__ unsigned s_next;  // chunk queue of the lean loop
+  __shared__ float s_bound[2 * kBlock / kWave];  // DYN: per-wave maxima of |u|, |v| over the tile
   const ChunkQueue queue{&s_next};
   EBOS_STAMP_BWD(0);
   if (tr.ty < 0 && !(mj.partials != nullptr && blockIdx.x == 0)) return;  // unused work item (workgroup 0 still reports the variance)
@@ -1158,139 +1363,128 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   G.w = W + 2 * pad_w;
   G.lo = g_lo;
   const int tr0 = max(tr.ty, 0) * TH, tc0 = max(tr.tx, 0) * TW;
-  const int oy = tr0 - HALO, ox = tc0 - HALO;
   if (threadIdx.x == 0) {
     s_spill = 0;
     s_next = 2 * (kBlock / kWave);
   }
-  if (GRID) {
-    // Set-up with every global read in flight at once: (1) the raw upstream tile into registers -- unconditional, clamped
-    // loads, fully unrolled (predicated loads are waited for one by one) -- (2) the tile's block of grid cells, (3) the
-    // variance partials; then the LDS work: accumulator clear, affine map + store of the upstream tile, the tile's flow.
-    constexpr int kStage = (LH * LW + kBlock - 1) / kBlock;
-    float raw[kStage];
+  // ---- set-up.  Every global read in flight at once: (1) the raw upstream tile into registers -- unconditional, clamped loads,
+  // fully unrolled (a loop of bounds-checked loads is waited for one by one: 5.6 us of set-up per workgroup, in-kernel stamps; not
+  // gated by "this item has events": that is known one round trip later than the tile's position) -- (2) GRID: the tile's block of
+  // grid cells, (3) the variance partials the forward call left (want_variance = 2: every workgroup reduces them itself while its
+  // staging loads fly, no finalize launch between forward and backward; workgroup 0 reports the variance).  Then the LDS work:
+  // accumulator clear, affine map + store of the upstream tile, GRID: the tile's flow.
+  // DYN: the window decides WHERE the upstream tile is, and its bound -- (2) / the tile's flow values / theta -- is one round trip
+  // away.  The SMALLEST window (4 px: what a converged BOS flow needs) is therefore staged speculatively with everything else;
+  // only a tile whose bound asks for more stages again, one round trip later.
+  constexpr int kStage = (kLHmax * kLWmax + kBlock - 1) / kBlock;
+  float raw[kStage];
+  Win<TH, TW, HALO, DYN> win{HALO, HALO};
+  auto stage_loads = [&]() {
+    const int LW = win.LW(), n_px = win.LH() * LW, oy = tr0 - win.HR(), ox = tc0 - win.HC();
+    const float inv_lw = 1.0f / (float)LW;
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
-      const int i = min((int)threadIdx.x + k * kBlock, LH * LW - 1);
-      const int rl = i / LW, cl = i - rl * LW;
+      if (DYN && k * kBlock >= n_px) break;  // (uniform)
+      const int i = min((int)threadIdx.x + k * kBlock, n_px - 1);
+      const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
       const int R = min(max(oy + rl + pad_h, 0), G.h - 1), C = min(max(ox + cl + pad_w, 0), G.w - 1);
       raw[k] = g_image[(int64_t)R * G.w + C];
     }
-    // (3) before (2): the partials' loads are in flight while tile_grid_begin computes its tables and waits at its barrier
-    double sm = 0.0, sq = 0.0;
-    if (mj.partials != nullptr) {
-      for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
-        sm += mj.partials[2 * i];
-        sq += mj.partials[2 * i + 1];
-      }
-    }
-    const TileGrid tg = tile_grid_begin<TH, TW, AP>(flow_arg, gs, tr0, tc0, H, W, s_lerp);
-    if (mj.partials != nullptr) {
-      __shared__ double red_m[2 * kBlock / kWave];
-      block_sum2(sm, sq, red_m);
-      if (threadIdx.x == 0) {
-        const double mean = mj.n_pixels > 0 ? sm / (double)mj.n_pixels : 0.0;
-        s_mom[0] = mean;
-        if (blockIdx.x == 0) {
-          if (mj.out_var) mj.out_var[0] = (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
-          if (mj.moments) {
-            mj.moments[0] = mean;
-            mj.moments[1] = (double)mj.n_pixels;
-          }
-        }
-      }
-      __syncthreads();
-      if (tr.ty < 0) return;  // (workgroup 0 of an adaptive plan may be an unused item: it only reports the variance)
-      // d var / d IWE = 2 (IWE - mean) / (M - 1) as an affine map of the IWE, from the partials reduced above
-      const double a = 2.0 * (double)upstream[0] / ((double)mj.n_pixels - 1.0);
-      G.a = (float)a;
-      G.c = (float)(-a * s_mom[0]);
-    } else if (var_moments != nullptr) {
-      const double a = 2.0 * (double)upstream[0] / (var_moments[1] - 1.0);
-      G.a = (float)a;
-      G.c = (float)(-a * var_moments[0]);
-    }
-    EBOS_STAMP_BWD(1);
-    for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
+  };
+  auto stage_store = [&]() {  // affine map of the upstream image (the variance gradient), zero outside the valid region
+    const int LW = win.LW(), n_px = win.LH() * LW, oy = tr0 - win.HR(), ox = tc0 - win.HC();
+    const float inv_lw = 1.0f / (float)LW;
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
+      if (DYN && k * kBlock >= n_px) break;
       const int i = threadIdx.x + k * kBlock;
-      const int rl = i / LW, cl = i - rl * LW;
+      const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
       const int R = oy + rl + pad_h, C = ox + cl + pad_w;
       const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-      if (i < LH * LW) s_g[i] = valid ? G.a * raw[k] + G.c : 0.0f;
+      if (i < n_px) s_g[i] = valid ? G.a * raw[k] + G.c : 0.0f;
     }
-    tile_grid_finish<TH, TW, AP>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + PH + PW));
-    flow = s_flow;
-  } else {
-    // The upstream tile with every global read in flight at once: unconditional clamped loads, fully unrolled, issued before
-    // anything waits (a loop of bounds-checked loads is waited for one by one: 5.6 us of set-up per workgroup, in-kernel stamps)
-    constexpr int kStage = (LH * LW + kBlock - 1) / kBlock;
-    float raw[kStage];
-    // (not gated by "this item has events": that is known one round trip later than the tile's position)
-#pragma unroll
-    for (int k = 0; k < kStage; ++k) {
-      const int i = min((int)threadIdx.x + k * kBlock, LH * LW - 1);
-      const int rl = i / LW, cl = i - rl * LW;
-      const int R = min(max(oy + rl + pad_h, 0), G.h - 1), C = min(max(ox + cl + pad_w, 0), G.w - 1);
-      raw[k] = g_image[(int64_t)R * G.w + C];
+  };
+  constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
+  if (DYN) win = Win<TH, TW, HALO, DYN>{kSpecHalo, kSpecHalo};
+  stage_loads();
+  double sm = 0.0, sq = 0.0;
+  if (mj.partials != nullptr) {
+    for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
+      sm += mj.partials[2 * i];
+      sq += mj.partials[2 * i + 1];
     }
-    const bool live = tr.g_first <= tr.g_last;
-    if (mj.partials != nullptr) {
-      // the (sum, sum of squares) partials the forward call left (want_variance = 2): every workgroup reduces them itself while its
-      // staging loads fly -- the finalize launch between forward and backward disappears; workgroup 0 reports the variance
-      double sm = 0.0, sq = 0.0;
-      for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
-        sm += mj.partials[2 * i];
-        sq += mj.partials[2 * i + 1];
-      }
-      __shared__ double red_d[2 * kBlock / kWave];
-      block_sum2(sm, sq, red_d);
-      if (threadIdx.x == 0) {
-        const double mean = mj.n_pixels > 0 ? sm / (double)mj.n_pixels : 0.0;
-        s_mom[0] = mean;
-        if (blockIdx.x == 0) {
-          if (mj.out_var) mj.out_var[0] = (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
-          if (mj.moments) {
-            mj.moments[0] = mean;
-            mj.moments[1] = (double)mj.n_pixels;
-          }
+  }
+  TileGrid tg{};
+  if (GRID) tg = tile_grid_begin<TH, TW, AP>(flow_arg, gs, tr0, tc0, H, W, s_lerp);  // (the partials' loads fly over its barrier)
+  if (DYN) {
+    float mu, mv;
+    if (UNIFORM) {
+      mu = fabsf(flow_arg[0]), mv = fabsf(flow_arg[1]);
+    } else if (GRID) {  // (the cell block covers tile + apron: a superset of what the tile's own pixels interpolate)
+      const int idx = min((int)threadIdx.x, 2 * tg.ni * tg.nj - 1);
+      const bool second = idx >= tg.ni * tg.nj;
+      mu = second ? 0.0f : fabsf(tg.cell), mv = second ? fabsf(tg.cell) : 0.0f;
+    } else {
+      tile_flow_absmax<TH, TW>(flow_arg, H, W, tr0, tc0, mu, mv);
+    }
+    tile_bound_post(mu, mv, s_bound);
+  }
+  if (mj.partials != nullptr) {
+    __shared__ double red_m[2 * kBlock / kWave];
+    block_sum2(sm, sq, red_m);
+    if (threadIdx.x == 0) {
+      const double mean = mj.n_pixels > 0 ? sm / (double)mj.n_pixels : 0.0;
+      s_mom[0] = mean;
+      if (blockIdx.x == 0) {
+        if (mj.out_var) mj.out_var[0] = (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
+        if (mj.moments) {
+          mj.moments[0] = mean;
+          mj.moments[1] = (double)mj.n_pixels;
         }
       }
-      __syncthreads();
-      if (tr.ty < 0) return;  // (workgroup 0 of an adaptive plan may be an unused item: it only reports the variance)
-      const double a = 2.0 * (double)upstream[0] / ((double)mj.n_pixels - 1.0);
-      G.a = (float)a;
-      G.c = (float)(-a * s_mom[0]);
-    } else if (var_moments != nullptr) {
+    }
+    __syncthreads();
+    if (tr.ty < 0) return;  // (workgroup 0 of an adaptive plan may be an unused item: it only reports the variance)
+    // d var / d IWE = 2 (IWE - mean) / (M - 1) as an affine map of the IWE, from the partials reduced above
+    const double a = 2.0 * (upstream ? (double)upstream[0] : 1.0) / ((double)mj.n_pixels - 1.0);  // (null upstream: 1)
+    G.a = (float)a;
+    G.c = (float)(-a * s_mom[0]);
+  } else {
+    if (DYN) __syncthreads();  // publishes s_bound (the reduction above has barriers of its own)
+    if (var_moments != nullptr) {
       // g_image is the IWE itself and the loss is upstream * var(IWE): d var / d IWE = 2 (IWE - mean) / (M - 1), folded
       // in as an affine map (no d_iwe image, no separate affine kernel)
       const double a = 2.0 * (double)upstream[0] / (var_moments[1] - 1.0);
       G.a = (float)a;
       G.c = (float)(-a * var_moments[0]);
     }
-    for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
-    if (live) {
-#pragma unroll
-      for (int k = 0; k < kStage; ++k) {
-        const int i = threadIdx.x + k * kBlock;
-        const int rl = i / LW, cl = i - rl * LW;
-        const int R = oy + rl + pad_h, C = ox + cl + pad_w;
-        const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-        if (i < LH * LW) s_g[i] = valid ? G.a * raw[k] + G.c : 0.0f;
-      }
+  }
+  if (DYN) {
+    const Win<TH, TW, HALO, DYN> need = tile_bound_read<TH, TW, HALO, DYN>(s_bound, dt_bound);
+    if (need.hr > win.hr || need.hc > win.hc) {  // (uniform) the speculative window is too small: stage the real one
+      win = need;
+      stage_loads();
     }
+  }
+  EBOS_STAMP_BWD(1);
+  for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
+  if (GRID || tr.g_first <= tr.g_last) stage_store();
+  if (GRID) {
+    tile_grid_finish<TH, TW, AP>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + PH + PW));
+    flow = s_flow;
   }
   __syncthreads();
   EBOS_STAMP_BWD(2);
+  const int LH = win.LH(), LW = win.LW();
+  const int oy = tr0 - win.HR(), ox = tc0 - win.HC();
 
   double tot_x = 0.0, tot_y = 0.0;  // UNIFORM: this lane's sum of dt * dL/d(x', y')
   constexpr bool kLean = (FMT == FMT_COMPACT) && !HAS_W;
   if (kLean) {
     bool spilled = false;
     if (tr.g_first <= tr.g_last)
-      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN, GRID>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y, &spilled,
-                                                                queue);
+      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN, GRID, DYN>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
+                                                                     &spilled, queue, win);
     if (spilled) s_spill = 1;
     EBOS_STAMP_BWD(3);
     __syncthreads();
@@ -1299,8 +1493,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
       __syncthreads();
       if (tr.g_first <= tr.g_last)
-        bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL, GRID>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
-                                                                   nullptr, queue);
+        bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL, GRID, DYN>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
+                                                                        nullptr, queue, win);
     }
   } else if (tr.g_first <= tr.g_last) {
     const float* __restrict__ flow1 = UNIFORM ? flow : flow + hw;
@@ -1516,7 +1710,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     return;
   }
   if (part_out != nullptr) {  // partial tile [2][TH * TW] of this part, plain stores
-    float* out = part_out + (int64_t)tr.slab * (LH * LW);
+    float* out = part_out + (int64_t)tr.slab * (kLHmax * kLWmax);
     for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) out[i] = (float)s_d[i];
     EBOS_STAMP_BWD(5);
     return;
@@ -1618,8 +1812,21 @@ constexpr int kNumSlabConfigs = sizeof(kSlabConfigs) / sizeof(kSlabConfigs[0]);
 struct SlabLayout {
   int tiles_y, tiles_x, nblk, h, w, combine_blocks;
   size_t slab_cells;   // per workgroup
-  size_t off_spill, off_partials, off_epoch, total;
+  size_t off_spill, off_partials, off_epoch, off_halo, total;
 };
+
+// `halo` arguments of the C ABI: h >= 0 is a built halo; EBOS_HALO_AUTO(max_halo, q) = -(max_halo + 256 q) asks for run-time
+// windows per tile, at most max_halo (a built halo), with |dt| <= q / 64 for every event of the plan (ebos_hip.h)
+struct HaloArg {
+  int halo;        // the built configuration (the largest window)
+  bool dyn;
+  float dt_bound;
+};
+inline HaloArg decode_halo(int halo) {
+  if (halo >= 0) return HaloArg{halo, false, 0.0f};
+  const int a = -halo;
+  return HaloArg{a & 255, true, (float)(a >> 8) / 64.0f};
+}
 
 constexpr int kAdaptiveItemsPerTile = 2;  // work items of an adaptive plan = 2 x tiles (ebos_plan_parts)
 
@@ -1636,7 +1843,8 @@ inline SlabLayout slab_layout(int H, int W, int th, int tw, int halo, int splits
   L.off_spill = align((size_t)L.nblk * L.slab_cells * sizeof(float));
   L.off_partials = L.off_spill + align((size_t)L.h * L.w * sizeof(float));
   L.off_epoch = L.off_partials + align((size_t)L.combine_blocks * 2 * sizeof(double));  // SpillEpoch word
-  L.total = L.off_epoch + 256;
+  L.off_halo = L.off_epoch + 256;  // [tiles] window (hr, hc) of each tile's slabs (run-time windows)
+  L.total = L.off_halo + align((size_t)L.tiles_y * L.tiles_x * sizeof(unsigned));
   return L;
 }
 
@@ -1653,20 +1861,26 @@ inline unsigned next_spill_epoch() {
 // on first use.  Re-recording an event does not disturb the waits already enqueued on its previous record.
 // (an event that could not be created is nullptr: order_after then reports the failure)
 inline hipEvent_t next_order_event() {
-  constexpr int kRing = 64;
-  static hipEvent_t ring[kRing];
-  static std::atomic<unsigned> created{0}, cursor{0};
-  static std::atomic_flag lock = ATOMIC_FLAG_INIT;
-  if (created.load(std::memory_order_acquire) == 0) {
-    while (lock.test_and_set(std::memory_order_acquire)) {}
-    if (created.load(std::memory_order_relaxed) == 0) {
+  constexpr int kRing = 64, kMaxDevices = 64;
+  struct Ring {
+    hipEvent_t ev[kRing];
+    std::atomic<unsigned> created{0}, cursor{0};
+    std::atomic_flag lock = ATOMIC_FLAG_INIT;
+  };
+  static Ring rings[kMaxDevices];  // an event belongs to the device it was created on: one ring per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  Ring& r = rings[dev];
+  if (r.created.load(std::memory_order_acquire) == 0) {
+    while (r.lock.test_and_set(std::memory_order_acquire)) {}
+    if (r.created.load(std::memory_order_relaxed) == 0) {
       for (int i = 0; i < kRing; ++i)
-        if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) ring[i] = nullptr;
-      created.store(1, std::memory_order_release);
+        if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) r.ev[i] = nullptr;
+      r.created.store(1, std::memory_order_release);
     }
-    lock.clear(std::memory_order_release);
+    r.lock.clear(std::memory_order_release);
   }
-  return ring[cursor.fetch_add(1, std::memory_order_relaxed) % kRing];
+  return r.ev[r.cursor.fetch_add(1, std::memory_order_relaxed) % kRing];
 }
 
 // make `later` wait for everything enqueued on `earlier` so far
@@ -1699,17 +1913,16 @@ constexpr size_t grid_lds_extra() {
 // LDS of the GRID accumulate kernel: accumulators + the tile's own flow; some tile configurations do not fit
 template <int TH, int TW, int HALO>
 constexpr bool grid_fwd_fits() {
-  return ((size_t)(TH + 2 * HALO) * (TW + 2 * HALO) + (TW + 2 * HALO) / 2 + 2) * sizeof(double) + grid_lds_extra<TH, TW, 0>() + 1024 <= 160 * 1024;
+  return (size_t)acc_cells<TH, TW, HALO, true>() * sizeof(double) + grid_lds_extra<TH, TW, 0>() + 1024 <= 160 * 1024;
 }
 
 template <int TH, int TW, int HALO>
 int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* flow, bool uniform, int H, int W, int splits,
                     int pad_h, int pad_w, char* ws, float* iwe, int want_var, int omit, float* out_var, double* moments,
-                    int acc_mode, hipStream_t s, const GridSrc* grid_src = nullptr) {
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  size_t lds = ((size_t)LH * LW + LW / 2 + 2) * sizeof(double);  // + dummy region
-  static_assert(((size_t)LH * LW + LW / 2 + 2) * sizeof(double) + 1024 <= 160 * 1024,
-                "f64 tile + halo must fit the 160 KiB LDS of a CDNA4 CU");
+                    int acc_mode, hipStream_t s, const GridSrc* grid_src = nullptr, const HaloArg& ha = HaloArg{HALO, false, 0.0f}) {
+  size_t lds = (size_t)acc_cells<TH, TW, HALO, false>() * sizeof(double);  // + dummy region
+  static_assert((size_t)acc_cells<TH, TW, HALO, true>() * sizeof(double) + 1024 <= 160 * 1024,
+                "f64 tile + halo (at the run-time windows' pitch) must fit the 160 KiB LDS of a CDNA4 CU");
   const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
   if (L.off_spill >= ((size_t)1 << 32)) {  // the combine pass addresses the slab section with 32-bit byte offsets (sc1 buffer loads)
     set_error("ebos_iwe_*_slab: %zu bytes of slabs (image %dx%d, %d work items): the slab section must stay below 4 GiB", L.off_spill, H,
@@ -1720,10 +1933,15 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   float* spill = reinterpret_cast<float*>(ws + L.off_spill);
   double* partials = reinterpret_cast<double*>(ws + L.off_partials);
   unsigned* spill_epoch = reinterpret_cast<unsigned*>(ws + L.off_epoch);
+  unsigned* halo_tab = reinterpret_cast<unsigned*>(ws + L.off_halo);
   const unsigned epoch = next_spill_epoch();
   // unit weights -> verified fixed point (2 ds_add_u64 per event); per-event weights -> f64 (any magnitude/sign)
-  void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*, GridSrc, unsigned*, unsigned);
+  void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*, GridSrc, unsigned*, unsigned, float,
+             unsigned*);
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
+  // run-time windows: the lean loop only (compact plan, unit weights, fixed point); anything else runs the largest window
+  const bool dyn = ha.dyn && compact && acc_mode == ACC_FX;
+  if (dyn) lds = (size_t)acc_cells<TH, TW, HALO, true>() * sizeof(double);
   GridSrc gs{};
 #define EBOS_PICK(HW, MD)                                                                                              \
   (uniform ? (compact ? iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_COMPACT, true>                            \
@@ -1734,13 +1952,17 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   else if (acc_mode == ACC_F64) ka = EBOS_PICK(false, ACC_F64);
   else ka = EBOS_PICK(false, ACC_FX);
 #undef EBOS_PICK
+  if (dyn)
+    ka = uniform ? iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, true, false, true>
+                 : iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, false, true>;
   if (grid_src != nullptr) {  // `flow` is a patch grid, sampled per tile inside the kernel (compact unit-weight plans)
     if constexpr (grid_fwd_fits<TH, TW, HALO>()) {
       if (!compact || uniform) {
         set_error("ebos_iwe_patch_slab: needs the compact plan format and unit weights");
         return EBOS_ERR_UNSUPPORTED;
       }
-      ka = iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true>;
+      ka = dyn ? iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, true>
+               : iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, false>;
       lds += grid_lds_extra<TH, TW, 0>();
       gs = *grid_src;
     } else {
@@ -1752,30 +1974,31 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   hipEvent_t t0, t1;
   if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_ACCUMULATE))  // bench.py's roofline leg: events stamped with this dispatch's begin / end
     hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, L.tiles_x,
-                          splits, pad_h, pad_w, slabs, spill, gs, spill_epoch, epoch);
+                          splits, pad_h, pad_w, slabs, spill, gs, spill_epoch, epoch, ha.dt_bound, halo_tab);
   else
     ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill, gs,
-                                                         spill_epoch, epoch);
+                                                         spill_epoch, epoch, ha.dt_bound, halo_tab);
   int64_t nparts;
   if (L.w % 4 == 0 && pad_w % 4 == 0) {
     dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows);
     nparts = (int64_t)gb.x * gb.y;
+    auto kc = dyn ? iwe_slab_combine4_kernel<TH, TW, HALO, true> : iwe_slab_combine4_kernel<TH, TW, HALO, false>;
     if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_COMBINE))
-      hipExtLaunchKernelGGL((iwe_slab_combine4_kernel<TH, TW, HALO>), gb, dim3(kCombineBlock), 0, s, t0, t1, 0, slabs, spill, L.tiles_y,
+      hipExtLaunchKernelGGL(kc, gb, dim3(kCombineBlock), 0, s, t0, t1, 0, slabs, spill, L.tiles_y,
                             L.tiles_x, splits, H, W, pad_h, pad_w, iwe, omit ? 1 : 0, want_var ? partials : nullptr,
-                            splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch);
+                            splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch, halo_tab);
     else
-      iwe_slab_combine4_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
-                                                                               pad_h, pad_w, iwe, omit ? 1 : 0,
-                                                                               want_var ? partials : nullptr,
-                                                                               splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch);
+      kc<<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W, pad_h, pad_w, iwe, omit ? 1 : 0,
+                                            want_var ? partials : nullptr, splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch,
+                                            halo_tab);
   } else {
     dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
     nparts = (int64_t)gb.x * gb.y;
     iwe_slab_combine_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
                                                                             pad_h, pad_w, iwe, omit ? 1 : 0,
                                                                             want_var ? partials : nullptr,
-                                                                            splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch);
+                                                                            splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch,
+                                                                            dyn ? halo_tab : nullptr);
   }
   if (want_var == 1) {  // want_var == 2: the caller reduces the partials itself (ebos_iwe_slab_partials)
     const int lo = omit ? 1 : 0;
@@ -1785,12 +2008,12 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   return EBOS_OK;
 }
 
-// n <= kMaxBatch windows of one geometry: accumulate, combine and finalize each as ONE launch over (work item, window)
+// n <= kMaxBatch windows of one geometry: the accumulate pass as ONE persistent launch (workgroup b = work item b of every window
+// in turn), combine and finalize each as one launch over (pixel block | 1, window)
 template <int TH, int TW, int HALO>
 int launch_slab_fwd_batch(const FwdBatch& b, int n, int H, int W, int splits, int pad_h, int pad_w, int want_var, int omit,
-                          hipStream_t s, hipStream_t s_tail, const GridSrc* grid_src) {
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  size_t lds = ((size_t)LH * LW + LW / 2 + 2) * sizeof(double);
+                          hipStream_t s, hipStream_t s_tail, const GridSrc* grid_src, const HaloArg& ha) {
+  size_t lds = (size_t)(ha.dyn ? acc_cells<TH, TW, HALO, true>() : acc_cells<TH, TW, HALO, false>()) * sizeof(double);
   const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
   if (L.off_spill >= ((size_t)1 << 32)) {  // the combine pass addresses the slab section with 32-bit byte offsets (sc1 buffer loads)
     set_error("ebos_iwe_*_slab: %zu bytes of slabs (image %dx%d, %d work items): the slab section must stay below 4 GiB", L.off_spill, H,
@@ -1804,41 +2027,36 @@ int launch_slab_fwd_batch(const FwdBatch& b, int n, int H, int W, int splits, in
   const unsigned epoch = next_spill_epoch();
   GridSrc gs{};
   hipEvent_t t0, t1;
+  void (*ka)(FwdBatch, int, int, int, int, int, int, int, GridSrc, unsigned, float);
   if (grid_src != nullptr) {
     if constexpr (grid_fwd_fits<TH, TW, HALO>()) {
-      auto ka = iwe_slab_accumulate_batch_kernel<TH, TW, HALO, true>;
+      ka = ha.dyn ? iwe_slab_accumulate_batch_kernel<TH, TW, HALO, true, true> : iwe_slab_accumulate_batch_kernel<TH, TW, HALO, true, false>;
       lds += grid_lds_extra<TH, TW, 0>();
       gs = *grid_src;
-      if (int rc = reserve_lds(ka, lds, "ebos_iwe_slab_batch")) return rc;
-      if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_ACCUMULATE))
-        hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk, (unsigned)n), dim3(kBlock), lds, s, t0, t1, 0, b, H, W, L.tiles_x, splits, pad_h,
-                              pad_w, gs, epoch);
-      else
-        ka<<<dim3((unsigned)L.nblk, (unsigned)n), dim3(kBlock), lds, s>>>(b, H, W, L.tiles_x, splits, pad_h, pad_w, gs, epoch);
     } else {
       set_error("ebos_iwe_slab_batch: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
       return EBOS_ERR_UNSUPPORTED;
     }
   } else {
-    auto ka = iwe_slab_accumulate_batch_kernel<TH, TW, HALO, false>;
-    if (int rc = reserve_lds(ka, lds, "ebos_iwe_slab_batch")) return rc;
-    if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_ACCUMULATE))
-      hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk, (unsigned)n), dim3(kBlock), lds, s, t0, t1, 0, b, H, W, L.tiles_x, splits, pad_h,
-                            pad_w, gs, epoch);
-    else
-      ka<<<dim3((unsigned)L.nblk, (unsigned)n), dim3(kBlock), lds, s>>>(b, H, W, L.tiles_x, splits, pad_h, pad_w, gs, epoch);
+    ka = ha.dyn ? iwe_slab_accumulate_batch_kernel<TH, TW, HALO, false, true> : iwe_slab_accumulate_batch_kernel<TH, TW, HALO, false, false>;
   }
+  if (int rc = reserve_lds(ka, lds, "ebos_iwe_slab_batch")) return rc;
+  if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_ACCUMULATE))
+    hipExtLaunchKernelGGL(ka, dim3((unsigned)L.nblk), dim3(kBlock), lds, s, t0, t1, 0, b, n, H, W, L.tiles_x, splits, pad_h, pad_w, gs,
+                          epoch, ha.dt_bound);
+  else
+    ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(b, n, H, W, L.tiles_x, splits, pad_h, pad_w, gs, epoch, ha.dt_bound);
   // the combine + finalize passes of this batch go to s_tail (when the caller gave one): they need no LDS and run beside the
   // accumulate pass of the NEXT batch, which the caller enqueues on s right behind this one
   if (s_tail != s)
     if (int rc = order_after(s_tail, s, "ebos_iwe_slab_batch")) return rc;
   const dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows, (unsigned)n);
+  auto kc = ha.dyn ? iwe_slab_combine4_batch_kernel<TH, TW, HALO, true> : iwe_slab_combine4_batch_kernel<TH, TW, HALO, false>;
   if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_COMBINE))
-    hipExtLaunchKernelGGL((iwe_slab_combine4_batch_kernel<TH, TW, HALO>), gb, dim3(kCombineBlock), 0, s_tail, t0, t1, 0, b, L.tiles_y,
-                          L.tiles_x, splits, H, W, pad_h, pad_w, omit ? 1 : 0, want_var, epoch);
+    hipExtLaunchKernelGGL(kc, gb, dim3(kCombineBlock), 0, s_tail, t0, t1, 0, b, L.tiles_y, L.tiles_x, splits, H, W, pad_h, pad_w,
+                          omit ? 1 : 0, want_var, epoch);
   else
-    iwe_slab_combine4_batch_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s_tail>>>(b, L.tiles_y, L.tiles_x, splits, H, W, pad_h,
-                                                                                        pad_w, omit ? 1 : 0, want_var, epoch);
+    kc<<<gb, dim3(kCombineBlock), 0, s_tail>>>(b, L.tiles_y, L.tiles_x, splits, H, W, pad_h, pad_w, omit ? 1 : 0, want_var, epoch);
   if (want_var == 1) {
     const int lo = omit ? 1 : 0;
     const int64_t m = (int64_t)(L.h - 2 * lo > 0 ? L.h - 2 * lo : 0) * (L.w - 2 * lo > 0 ? L.w - 2 * lo : 0);
@@ -1864,7 +2082,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
                      double* partials, const double* var_moments, const float* upstream, const float* addend, float* part_out,
                      hipStream_t s, const GridSrc* grid_src = nullptr, int adaptive = 0, float s_norm = 0.0f, float s_tv = 0.0f,
-                     double* reg_partials = nullptr, MomentsIn mj = MomentsIn{}) {
+                     double* reg_partials = nullptr, MomentsIn mj = MomentsIn{}, const HaloArg& ha = HaloArg{HALO, false, 0.0f}) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert((size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float) <= 160 * 1024,
@@ -1875,15 +2093,17 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
     return EBOS_ERR_UNSUPPORTED;
   }
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
+  const bool dyn = ha.dyn && compact;  // run-time windows: the lean loop only
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
-             const double*, const float*, const float*, float*, GridSrc, int, float, float, double*, MomentsIn);
+             const double*, const float*, const float*, float*, GridSrc, int, float, float, double*, MomentsIn, float);
   if (grid_src != nullptr) {
     if constexpr (grid_bwd_fits<TH, TW, HALO>()) {
       if (!compact || uniform || part_out == nullptr) {
         set_error("ebos_iwe_patch_tiled_bwd: needs the compact plan format, unit weights and a partials buffer");
         return EBOS_ERR_UNSUPPORTED;
       }
-      kb = iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, true>;
+      kb = dyn ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, true, true>
+               : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, true, false>;
       lds = grid_bwd_lds<TH, TW, HALO>();
       if (int rc = reserve_lds(kb, lds, "ebos_iwe_patch_tiled_bwd")) return rc;
       const unsigned grid = (unsigned)(tiles_y * tiles_x * (adaptive ? kAdaptiveItemsPerTile : 1));
@@ -1891,11 +2111,11 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
       if (profile_next_pair(&t0, &t1, EBOS_PROFILE_TILED_BWD))
         hipExtLaunchKernelGGL(kb, dim3(grid), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image,
                               affine, g_lo, (float*)nullptr, (float*)nullptr, (double*)nullptr, var_moments, upstream, addend, part_out,
-                              *grid_src, adaptive, s_norm, s_tv, reg_partials, mj);
+                              *grid_src, adaptive, s_norm, s_tv, reg_partials, mj, ha.dt_bound);
       else
         kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr,
                                                  nullptr, var_moments, upstream, addend, part_out, *grid_src, adaptive, s_norm, s_tv,
-                                                 reg_partials, mj);
+                                                 reg_partials, mj, ha.dt_bound);
       return EBOS_OK;
     } else {
       set_error("ebos_iwe_patch_tiled_bwd: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
@@ -1910,17 +2130,20 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   if (ev.w) kb = EBOS_PICK(true);
   else kb = EBOS_PICK(false);
 #undef EBOS_PICK
+  if (dyn)
+    kb = uniform ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, true, false, true>
+                 : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, false, true>;
   if (int rc = reserve_lds(kb, lds, "ebos_iwe_dense_tiled_bwd")) return rc;
   const unsigned grid = (unsigned)(tiles_y * tiles_x * (part_out ? kAdaptiveItemsPerTile : 1));
   hipEvent_t t0, t1;
   if (profile_next_pair(&t0, &t1, EBOS_PROFILE_TILED_BWD))
     hipExtLaunchKernelGGL(kb, dim3(grid), dim3(kBlock), lds, s, t0, t1, 0, ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine,
                           g_lo, d_flow, d_weight, partials, var_moments, upstream, part_out ? (const float*)nullptr : addend, part_out,
-                          GridSrc{}, 0, 0.0f, 0.0f, (double*)nullptr, mj);
+                          GridSrc{}, 0, 0.0f, 0.0f, (double*)nullptr, mj, ha.dt_bound);
   else
     kb<<<dim3(grid), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, tiles_x, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight,
                                              partials, var_moments, upstream, part_out ? nullptr : addend, part_out, GridSrc{}, 0, 0.0f,
-                                             0.0f, nullptr, mj);
+                                             0.0f, nullptr, mj, ha.dt_bound);
   if (part_out)
     bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
                                                                                                   addend, d_flow);
@@ -1968,9 +2191,17 @@ int ebos_slab_config(int* out, int cap) {
   return kNumSlabConfigs;
 }
 
-int ebos_iwe_slab_partials(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w, int omit_boundary,
+int ebos_halo_auto(int max_halo, double dt_bound) {
+  if (max_halo <= 0 || max_halo > 255 || !(dt_bound >= 0.0) || dt_bound > 4096.0) return max_halo;  // (no auto: the built halo itself)
+  int q = (int)(dt_bound * 64.0);
+  if ((double)q < dt_bound * 64.0) ++q;  // rounded UP: the bound stays a bound
+  return EBOS_HALO_AUTO(max_halo, q < 1 ? 1 : q);
+}
+
+int ebos_iwe_slab_partials(int H, int W, int tile_h, int tile_w, int halo_arg, int splits, int pad_h, int pad_w, int omit_boundary,
                            size_t* offset_bytes, int64_t* n_partials, int64_t* n_pixels) {
   using namespace ebos;
+  const int halo = decode_halo(halo_arg).halo;
   EBOS_REQUIRE(offset_bytes && n_partials && n_pixels, "ebos_iwe_slab_partials: NULL output");
   EBOS_REQUIRE(H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && halo >= 0 && splits >= 0 && pad_h >= 0 && pad_w >= 0,
                "ebos_iwe_slab_partials: bad sizes");
@@ -1984,8 +2215,9 @@ int ebos_iwe_slab_partials(int H, int W, int tile_h, int tile_w, int halo, int s
   return EBOS_OK;
 }
 
-size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w) {
+size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo_arg, int splits, int pad_h, int pad_w) {
   using namespace ebos;
+  const int halo = decode_halo(halo_arg).halo;
   if (H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0 || halo < 0 || splits < 0 || pad_h < 0 || pad_w < 0) return 0;
   return slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w).total;
 }
@@ -1993,10 +2225,12 @@ size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int h
 static int iwe_slab_entry(const ebos::GridSrc* grid_src, const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
                             const uint16_t* cpix, const float* cdt,
                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
-                            int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
+                            int tile_w, int halo_arg, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
                             double* moments, const int32_t* part_table, ebos_stream_t stream) {
   using namespace ebos;
+  const HaloArg ha = decode_halo(halo_arg);
+  const int halo = ha.halo;
   EBOS_REQUIRE(flow && iwe && key_offsets && workspace, "ebos_iwe_dense_slab: NULL flow/iwe/key_offsets/workspace");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_slab: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64,
@@ -2024,7 +2258,7 @@ static int iwe_slab_entry(const ebos::GridSrc* grid_src, const float* xs, const 
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                          \
   launch_slab_fwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, splits, pad_h, pad_w, ws, iwe, want_variance, omit_boundary, \
-                              out_variance, moments, acc_mode, s, grid_src)
+                              out_variance, moments, acc_mode, s, grid_src, ha)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;
@@ -2043,8 +2277,9 @@ int ebos_iwe_dense_slab_f32(const float* xs, const float* ys, const float* dts, 
                         stream);
 }
 
-int ebos_patch_fused_supported(int tile_h, int tile_w, int halo, int slide_h, int slide_w) {
+int ebos_patch_fused_supported(int tile_h, int tile_w, int halo_arg, int slide_h, int slide_w) {
   using namespace ebos;
+  const int halo = decode_halo(halo_arg).halo;
   int rc = 0;
 #define EBOS_CALL(TH, TW, HL) \
   ((grid_fwd_fits<TH, TW, HL>() && grid_bwd_fits<TH, TW, HL>() && (TH + 2 * kBwdApron) / slide_h + 3 <= kGridCells && \
@@ -2078,10 +2313,12 @@ int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, co
 }
 
 int ebos_iwe_slab_batch_f32(const ebos_slab_window* windows, int n_windows, int gh, int gw, int patch_h, int patch_w, int slide_h,
-                            int slide_w, int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w,
+                            int slide_w, int H, int W, int tile_h, int tile_w, int halo_arg, int splits, int pad_h, int pad_w,
                             size_t workspace_bytes, int want_variance, int omit_boundary, ebos_stream_t stream,
                             ebos_stream_t tail_stream) {
   using namespace ebos;
+  const HaloArg ha = decode_halo(halo_arg);
+  const int halo = ha.halo;
   EBOS_REQUIRE(windows && n_windows >= 0, "ebos_iwe_slab_batch: NULL windows");
   EBOS_REQUIRE(H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64, "ebos_iwe_slab_batch: bad sizes (splits=%d)",
                splits);
@@ -2131,13 +2368,14 @@ int ebos_iwe_slab_batch_f32(const ebos_slab_window* windows, int n_windows, int 
       w.spill = reinterpret_cast<float*>(ws + L.off_spill);
       w.partials = reinterpret_cast<double*>(ws + L.off_partials);
       w.spill_epoch = reinterpret_cast<unsigned*>(ws + L.off_epoch);
+      w.halo_tab = reinterpret_cast<unsigned*>(ws + L.off_halo);
       w.iwe = q.iwe;
       w.out_var = q.out_variance;
       w.moments = q.moments;
     }
     int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL) \
-  launch_slab_fwd_batch<TH, TW, HL>(b, n, H, W, splits, pad_h, pad_w, want_variance, omit_boundary, s, s_tail, patch ? &gs : nullptr)
+  launch_slab_fwd_batch<TH, TW, HL>(b, n, H, W, splits, pad_h, pad_w, want_variance, omit_boundary, s, s_tail, patch ? &gs : nullptr, ha)
     EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
     if (rc != EBOS_OK) return rc;
@@ -2151,10 +2389,12 @@ int ebos_iwe_slab_batch_f32(const ebos_slab_window* windows, int n_windows, int 
 int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
                             const uint16_t* cpix, const float* cdt,
                            const int32_t* key_offsets, int64_t n, const float* thetas, int K, int H, int W, int tile_h,
-                           int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace, size_t workspace_bytes,
+                           int tile_w, int halo_arg, int splits, int pad_h, int pad_w, void* workspace, size_t workspace_bytes,
                            float* iwes, int want_variance, int omit_boundary, float* out_variance, double* moments,
                            const int32_t* part_table, ebos_stream_t stream) {
   using namespace ebos;
+  const HaloArg ha = decode_halo(halo_arg);
+  const int halo = ha.halo;
   EBOS_REQUIRE(thetas && iwes && key_offsets && workspace, "ebos_iwe_2dof_slab: NULL thetas/iwes/key_offsets/workspace");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_2dof_slab: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64,
@@ -2180,7 +2420,7 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
 #define EBOS_CALL(TH, TW, HL)                                                                                            \
   launch_slab_fwd<TH, TW, HL>(evp, key_offsets, thetas + 2 * k, true, H, W, splits, pad_h, pad_w, ws, iwes + k * hw,     \
                               want_variance, omit_boundary, out_variance ? out_variance + k : nullptr,                   \
-                              moments ? moments + 2 * k : nullptr, (int)ACC_FX, s)
+                              moments ? moments + 2 * k : nullptr, (int)ACC_FX, s, nullptr, ha)
     EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
     if (rc != EBOS_OK) return rc;
@@ -2192,9 +2432,11 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
 int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
                             const uint16_t* cpix, const float* cdt,
                                 const int32_t* key_offsets, int64_t n, const float* thetas, int K, int H, int W, int tile_h,
-                                int tile_w, int halo, int pad_h, int pad_w, const float* g_images, const float* affine,
+                                int tile_w, int halo_arg, int pad_h, int pad_w, const float* g_images, const float* affine,
                                 int g_lo, float* d_thetas, void* workspace, size_t workspace_bytes, ebos_stream_t stream) {
   using namespace ebos;
+  const HaloArg ha = decode_halo(halo_arg);
+  const int halo = ha.halo;
   EBOS_REQUIRE(thetas && g_images && d_thetas && key_offsets && workspace, "ebos_iwe_2dof_tiled_bwd: NULL argument");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_2dof_tiled_bwd: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_2dof_tiled_bwd: bad sizes");
@@ -2216,7 +2458,8 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
     int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                              \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, thetas + 2 * k, true, H, W, pad_h, pad_w, g_images + k * hw,              \
-                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, nullptr, nullptr, nullptr, nullptr, s)
+                               affine ? affine + 2 * k : nullptr, g_lo, d_thetas + 2 * k, nullptr, partials, nullptr, nullptr, nullptr, nullptr, s, \
+                               nullptr, 0, 0.0f, 0.0f, nullptr, MomentsIn{}, ha)
     EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
     if (rc != EBOS_OK) return rc;
@@ -2228,16 +2471,17 @@ int ebos_iwe_2dof_tiled_bwd_f32(const float* xs, const float* ys, const float* d
 // mj.partials != nullptr: the variance partials of the forward call (want_variance = 2) are reduced inside the kernel
 static int dense_tiled_bwd_impl(const float* xs, const float* ys, const float* dts, const float* weight, const int32_t* grp_offsets,
                                 const uint16_t* cpix, const float* cdt, const int32_t* key_offsets, int64_t n, const float* flow, int H,
-                                int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
+                                int W, int tile_h, int tile_w, int halo_arg, int pad_h, int pad_w, const float* g_image,
                                 const float* affine, int g_lo, float* d_flow, float* d_weight, const double* var_moments,
                                 const float* upstream, const float* addend, void* workspace, size_t workspace_bytes,
                                 const int32_t* part_table, ebos_stream_t stream, const ebos::MomentsIn& mj) {
   using namespace ebos;
+  const HaloArg ha = decode_halo(halo_arg);
+  const int halo = ha.halo;
   EBOS_REQUIRE(flow && g_image && d_flow && key_offsets, "ebos_iwe_dense_tiled_bwd: NULL flow/g_image/d_flow/key_offsets");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_tiled_bwd: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && g_lo >= 0, "ebos_iwe_dense_tiled_bwd: bad sizes");
-  EBOS_REQUIRE(mj.partials != nullptr ? (var_moments == nullptr && upstream != nullptr)
-                                      : ((var_moments == nullptr) == (upstream == nullptr)),
+  EBOS_REQUIRE(mj.partials != nullptr ? var_moments == nullptr : ((var_moments == nullptr) == (upstream == nullptr)),
                "ebos_iwe_dense_tiled_bwd: var_moments and upstream go together");
   float* part_out = nullptr;
   if (part_table != nullptr) {  // adaptive work items: partial tiles go through the slab section of the forward workspace
@@ -2260,7 +2504,7 @@ static int dense_tiled_bwd_impl(const float* xs, const float* ys, const float* d
   int rc = EBOS_ERR_UNSUPPORTED;
 #define EBOS_CALL(TH, TW, HL)                                                                                       \
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, flow, false, H, W, pad_h, pad_w, g_image, affine, g_lo, d_flow, d_weight, \
-                               nullptr, var_moments, upstream, addend, part_out, s, nullptr, 0, 0.0f, 0.0f, nullptr, mj)
+                               nullptr, var_moments, upstream, addend, part_out, s, nullptr, 0, 0.0f, 0.0f, nullptr, mj, ha)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;
@@ -2301,14 +2545,7 @@ int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, fl
   EBOS_REQUIRE(npix >= 2, "ebos_variance_dense_job: the variance needs at least two pixels");
   const MomentsIn mj{reinterpret_cast<const double*>(reinterpret_cast<const char*>(job->workspace) + poff), nparts, npix, out_variance,
                      job->moments};
-  if (upstream == nullptr) {  // a device-resident 1.0f of the code object: no allocation, no copy (the ABI never allocates)
-    static const float* d_one = nullptr;
-    if (d_one == nullptr && hipGetSymbolAddress((void**)&d_one, HIP_SYMBOL(ebos::g_unit_upstream)) != hipSuccess) {
-      set_error("ebos_variance_dense_job: cannot resolve the unit upstream");
-      return EBOS_ERR_LAUNCH;
-    }
-    upstream = d_one;
-  }
+  // (upstream == nullptr: the backward kernel takes 1.0f -- no device-resident constant, nothing per-device to cache)
   const bool adaptive = job->splits == 0 && job->part_table != nullptr;
   return dense_tiled_bwd_impl(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n, flow,
                               job->H, job->W, job->tile_h, job->tile_w, job->halo, job->pad_h, job->pad_w, job->iwe, nullptr,
@@ -2325,13 +2562,15 @@ size_t ebos_patch_grad_partials_bytes(int H, int W, int tile_h, int tile_w, int 
 
 int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const int32_t* key_offsets,
                                  int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w,
-                                 int H, int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w, const float* g_image,
+                                 int H, int W, int tile_h, int tile_w, int halo_arg, int pad_h, int pad_w, const float* g_image,
                                  const float* affine, int g_lo, const double* var_moments, const float* upstream,
                                  const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
                                  float w_flow_norm, float w_image_gradient, double* reg_partials, const double* var_partials,
                                  int64_t n_var_partials,
                                  int64_t n_var_pixels, float* out_variance, double* out_moments, ebos_stream_t stream) {
   using namespace ebos;
+  const HaloArg ha = decode_halo(halo_arg);
+  const int halo = ha.halo;
   EBOS_REQUIRE(var_partials == nullptr || (var_moments == nullptr && upstream != nullptr && n_var_partials >= 1 && n_var_pixels >= 2),
                "ebos_iwe_patch_tiled_bwd: var_partials needs upstream, no var_moments, and sane counts");
   const MomentsIn mj{var_partials, n_var_partials, n_var_pixels, out_variance, out_moments};
@@ -2368,7 +2607,7 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
   launch_tiled_bwd<TH, TW, HL>(evp, key_offsets, grid, false, H, W, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr, nullptr, \
                                var_moments, upstream, addend, grad_partials, s, &gs, adaptive,                                     \
                                w_flow_norm / (float)((int64_t)H * W), w_image_gradient / (float)(2 * (int64_t)H * W),              \
-                               any_reg ? reg_partials : nullptr, mj)
+                               any_reg ? reg_partials : nullptr, mj, ha)
   EBOS_SLAB_DISPATCH(EBOS_CALL)
 #undef EBOS_CALL
   if (rc != EBOS_OK) return rc;

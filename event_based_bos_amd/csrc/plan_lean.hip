@@ -441,14 +441,11 @@ int ebos_plan_lean(int source, const void* events, const int16_t* col, const int
   const LeanIn in{events, col, row, t, ticks_per_second};
   const size_t lds_bins = (size_t)L.n_bins * 4;
   const size_t lds_sort = (size_t)(2 * L.pix_cap) * 4 + (size_t)L.sort_cap * 6;
-  static bool reserved = false;
-  if (!reserved) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lean_bin_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kSortLds) != hipSuccess) {
-      set_error("ebos_plan_lean: cannot reserve LDS for the bin sort");
-      return EBOS_ERR_LAUNCH;
-    }
-    reserved = true;
+  // (every call, like reserve_lds() of the event kernels: the attribute is per device, and a process may drive several)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lean_bin_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kSortLds) != hipSuccess) {
+    set_error("ebos_plan_lean: cannot reserve LDS for the bin sort");
+    return EBOS_ERR_LAUNCH;
   }
   lean_init_kernel<<<dim3(1), dim3(1), 0, s>>>(sc, counts);
 #define EBOS_LEAN(SRC)                                                                                                      \

@@ -64,6 +64,43 @@ def parse_direction(direction: Union[str, float]) -> Tuple[int, float]:
     raise ValueError(f"direction argument should be first, middle, last. Or float. {direction}")
 
 
+def dt_bound_for(direction: Union[str, float], normalize_t: bool) -> Optional[float]:
+    """max |dt| over the events of a window as the HOST knows it without looking at the events: with normalised time
+    dt = (t - t_ref) / (t_max - t_min) lies in [-f, 1 - f] for a reference time at fraction f of the window
+    (src/warp.py:245-253, 283-287).  None when the time stays in seconds (the bound is then the window's length: unknown here)."""
+    if not normalize_t:
+        return None
+    _, frac = parse_direction(direction)
+    return max(abs(frac), abs(1.0 - frac))
+
+
+def resolve_halo(plan: "EventPlan", halo) -> int:
+    """The ``halo`` argument of the tile-private operators -> the integer the C ABI takes.  An int is a built halo;
+    ``"auto"`` asks for run-time windows per tile (``EBOS_HALO_AUTO``: each work item sizes its LDS window from a bound on ITS
+    OWN displacements, |flow| over the tile x max |dt|), bounded by the largest halo built for the plan's tile; it needs a plan
+    that knows its |dt| bound (normalised time) and falls back to that largest halo otherwise."""
+    if halo != "auto":
+        return int(halo)
+    biggest = max((hl for th, tw, hl in _hip.slab_configs() if (th, tw) == tuple(plan.tile)), default=None)
+    if biggest is None:
+        raise ValueError(f"no tile-private kernels are built for tile {plan.tile}")
+    if plan.dt_bound is None:
+        return biggest
+    return int(_hip.load_library().ebos_halo_auto(biggest, float(plan.dt_bound)))
+
+
+def _norm_halo(plan: "EventPlan", halo):
+    """None stays None (general kernels); "auto" becomes the ABI's EBOS_HALO_AUTO code on a binned plan."""
+    if halo is None or halo != "auto":
+        return halo
+    return resolve_halo(plan, halo) if plan.binned else None
+
+
+def _max_halo(halo: int) -> int:
+    """the built halo behind a (possibly EBOS_HALO_AUTO-encoded) halo argument"""
+    return halo if halo >= 0 else (-halo) & 255
+
+
 _N_CU = {}
 
 
@@ -97,6 +134,7 @@ class EventPlan:
     cpix: Optional[torch.Tensor] = None          # compact plan: int16 storage of u16 (row << 8 | col), padded groups
     cdt: Optional[torch.Tensor] = None           # compact plan: f32 dt, NaN in padding slots
     part_table: Optional[torch.Tensor] = None    # adaptive work items (ebos_plan_parts): int32 [5 tiles + 1]
+    dt_bound: Optional[float] = None             # max |dt| over the events as known on the host (dt_bound_for), else None
 
     @property
     def binned(self) -> bool:
@@ -157,6 +195,11 @@ class EventPlan:
         if not events.is_cuda:
             raise _hip.HipUnavailableError("EventPlan.build: events must be on the GPU")
         events = events.contiguous()
+        if emit == "compact" and deferred:
+            # a lean plan is valid iff no source coordinate is fractional, and a deferred build never reads that count back: only
+            # the raw int16 columns (build_raw) are integers by construction
+            raise ValueError("EventPlan.build: emit='compact' with deferred=True needs integer source coordinates by construction: "
+                             "use build_raw (sensor columns), or deferred=False")
         if emit == "compact" and tile is not None and events.shape[0] > 0:
             lean = _build_lean(0 if events.dtype == torch.float32 else 1, events, None, image_size, direction, normalize_t, tile,
                                1.0, deferred)
@@ -172,7 +215,7 @@ class EventPlan:
             fn = getattr(lib, "ebos_events_to_soa_" + _hip.suffix(events.dtype))
             check(fn(ptr(events), ptr(tmm), ref_mode, frac, int(normalize_t), n, ptr(x), ptr(y), ptr(dt), ptr(p),
                      stream_ptr()), "ebos_events_to_soa")
-        plan = EventPlan(x, y, dt, p, (H, W), n, n)
+        plan = EventPlan(x, y, dt, p, (H, W), n, n, dt_bound=dt_bound_for(direction, normalize_t))
         if tile is not None:
             plan = plan.bin(tile)
         return plan
@@ -222,7 +265,7 @@ class EventPlan:
             check(lib.ebos_raw_events_to_soa(ptr(col), ptr(row), ptr(t), t.element_size(), ptr(pol), float(ticks_per_second),
                                              ptr(tmm), ref_mode, frac, int(normalize_t), n, ptr(x), ptr(y), ptr(dt), ptr(p),
                                              stream_ptr()), "ebos_raw_events_to_soa")
-        plan = EventPlan(x, y, dt, p, (H, W), n, n)
+        plan = EventPlan(x, y, dt, p, (H, W), n, n, dt_bound=dt_bound_for(direction, normalize_t))
         if tile is not None:
             plan = plan.bin(tile, deferred=deferred)  # int16 columns: integer coordinates by construction
         return plan
@@ -276,7 +319,7 @@ class EventPlan:
             check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), PART_FIXED_EVENTS, ptr(part_table), stream_ptr()),
                   "ebos_plan_parts")
         out = EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
-                        (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt, part_table)
+                        (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt, part_table, self.dt_bound)
         out.__dict__["_counts"], out.__dict__["_deferred"] = counts, bool(deferred)
         out.__dict__["_parts_used"] = None if deferred else int(part_table[tiles_y * tiles_x].item())
         return out
@@ -327,14 +370,15 @@ class EventPlan:
     def iwe_dense(self, flow: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
                   halo: Optional[int] = DEFAULT_HALO, splits: Optional[int] = None) -> torch.Tensor:
         """Fused dense-flow warp + bilinear IWE: flow [2, H, W] -> iwe [H + 2 pad_h, W + 2 pad_w].
-        ``halo=None`` (or an un-binned plan) selects the general global-atomic kernel."""
-        return _FusedIweDense.apply(flow, weight, self, (int(pad[0]), int(pad[1])), halo, self.resolve_splits(splits))
+        ``halo=None`` (or an un-binned plan) selects the general global-atomic kernel; ``halo="auto"``: run-time windows per
+        tile (``resolve_halo``)."""
+        return _FusedIweDense.apply(flow, weight, self, (int(pad[0]), int(pad[1])), _norm_halo(self, halo), self.resolve_splits(splits))
 
     def iwe_2dof(self, thetas: torch.Tensor, pad: Tuple[int, int] = (0, 0), weight: Optional[torch.Tensor] = None,
                  halo: Optional[int] = DEFAULT_HALO, splits: Optional[int] = None) -> torch.Tensor:
         """Fused 2-DoF warp + bilinear IWE for K hypotheses: thetas [K, 2] -> iwes [K, h, w].
         Binned plans use the tile-private pipeline (|dt * theta| beyond ``halo`` spills, still correct)."""
-        return _FusedIwe2Dof.apply(thetas, weight, self, (int(pad[0]), int(pad[1])), halo, self.resolve_splits(splits))
+        return _FusedIwe2Dof.apply(thetas, weight, self, (int(pad[0]), int(pad[1])), _norm_halo(self, halo), self.resolve_splits(splits))
 
     def variance_2dof(self, thetas: torch.Tensor, omit_boundary: bool = False, pad: Tuple[int, int] = (0, 0),
                       halo: int = DEFAULT_HALO, splits: Optional[int] = None, chunk: int = 8,
@@ -345,6 +389,7 @@ class EventPlan:
         the one-workgroup-per-CU accumulate kernel of another leaves free (bench.py measures 23.6 us per evaluation
         with three in flight against 39.4 us back to back, 10 M events)."""
         lib = _hip.require_gpu()
+        halo = _norm_halo(self, halo)
         if not _slab_ok(self, halo):
             return ops.image_variance(self.iwe_2dof(thetas, pad, None, None), omit_boundary)
         th = thetas.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -387,6 +432,7 @@ class EventPlan:
         flow32 = _check_flow(self, flow.detach())
         splits = self.resolve_splits(splits)
         pad = (int(pad[0]), int(pad[1]))
+        halo = _norm_halo(self, halo)
         if not _slab_ok(self, halo):
             f = flow32.clone().requires_grad_(True)
             v = self.contrast_dense(f, "image_variance", omit_boundary, pad, halo)
@@ -402,6 +448,7 @@ class EventPlan:
         lib = _hip.require_gpu()
         if flows.dim() != 4 or tuple(flows.shape[1:]) != (2,) + tuple(self.image_size):
             raise ValueError(f"flows must be [K, 2, {self.image_size[0]}, {self.image_size[1]}], got {tuple(flows.shape)}")
+        halo = _norm_halo(self, halo)
         if not _slab_ok(self, halo):
             return torch.stack([self.contrast_dense(f, "image_variance", omit_boundary, pad, halo).detach() for f in flows])
         fl = flows.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -439,7 +486,13 @@ class EventPlan:
                        splits: Optional[int] = None) -> torch.Tensor:
         """Contrast of the IWE under ``flow`` (0-d tensor, raw contrast: callers apply the sign).
         Same value and gradient as ``cost(iwe_dense(flow))``, but the variance gradient is folded
-        into the backward event kernel (no d_iwe image)."""
+        into the backward event kernel (no d_iwe image).
+
+        One stream at a time per plan: the evaluation runs on a job cached on the plan (image, moments and workspace are shared
+        between calls), so calls on the same plan from two streams must be ordered by the caller -- independent evaluations
+        go through ``variance_dense_many`` / ``variance_2dof``, which give every stream its own buffers.  First order only:
+        the gradient is produced with the value, ``backward`` is once-differentiable (``create_graph=True`` raises)."""
+        halo = _norm_halo(self, halo)
         if cost == "image_variance":
             return _FusedVarianceDense.apply(flow, self, (int(pad[0]), int(pad[1])), bool(omit_boundary), halo,
                                              self.resolve_splits(splits))
@@ -491,7 +544,7 @@ def _build_lean(source: int, events, raw, image_size, direction, normalize_t, ti
         if fractional:
             return None  # fractional (undistorted) source coordinates: the (x, y, dt) format of the full build
     plan = EventPlan(None, None, None, None, (H, W), n - dropped, n, (th, tw), key_offsets, None, dropped, grp_offsets, cpix, cdt,
-                     part_table)
+                     part_table, dt_bound_for(direction, normalize_t))
     plan.__dict__["_counts"], plan.__dict__["_deferred"], plan.__dict__["_parts_used"] = counts, bool(deferred), used
     return plan
 
@@ -514,7 +567,9 @@ def _slab_ok(plan: EventPlan, halo) -> bool:
         return False
     if _SLAB_CONFIGS is None:
         _SLAB_CONFIGS = set(_hip.slab_configs())
-    return (plan.tile[0], plan.tile[1], int(halo)) in _SLAB_CONFIGS
+    if halo == "auto":
+        return any((th, tw) == tuple(plan.tile) for th, tw, _ in _SLAB_CONFIGS)
+    return (plan.tile[0], plan.tile[1], _max_halo(int(halo))) in _SLAB_CONFIGS
 
 
 def _refuse_deferred(plan: EventPlan, what: str) -> None:
@@ -557,7 +612,7 @@ class SlabBatch(object):
         p0 = plans[0]
         H, W = p0.image_size
         self.plans, self.flows = list(plans), [f.contiguous().float() for f in flows]
-        self.pad, self.halo, self.omit = (int(pad[0]), int(pad[1])), int(halo), bool(omit_boundary)
+        self.pad, self.halo, self.omit = (int(pad[0]), int(pad[1])), int(_norm_halo(p0, halo)), bool(omit_boundary)
         self.splits = p0.resolve_splits(splits)
         for pl, fl in zip(self.plans, self.flows):
             if pl.image_size != p0.image_size or pl.tile != p0.tile or not pl.compact or pl.device != p0.device:
@@ -638,7 +693,7 @@ def _run_dense_job(job: _DenseJob, flow32: torch.Tensor, want_grad: bool):
     lib = _hip.require_gpu()
     out = torch.empty(1, dtype=torch.float32, device=flow32.device)
     d_flow = torch.empty_like(flow32) if want_grad else None
-    if torch._C._cuda_getDevice() == job.index:
+    if _hip.current_device_index() == job.index:
         rc = lib.ebos_variance_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), None, ptr(d_flow), stream_ptr())
     else:
         with _hip.on_device(flow32.device):
@@ -797,6 +852,7 @@ class _FusedVarianceDense(torch.autograd.Function):
         return out[0].to(flow.dtype)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable  # the saved gradient is a constant: create_graph must raise, not drop terms
     def backward(ctx, g):
         if ctx.eager:
             (d_flow,) = ctx.saved_tensors

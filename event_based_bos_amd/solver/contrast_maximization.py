@@ -95,7 +95,8 @@ class ContrastMaximizationMixin(object):
         self.scipy_options = dict(ocfg.get("options") or {})
         self.refine_iters = int(ocfg.get("refine_iters", 0))  # 2-DoF models: Adam steps after the grid sweep
         self.param_ranges = cfg.get("parameters") or {}  # {name: {min, max}} or the reference's list of names (_param_range)
-        self.halo = int(cfg.get("halo", 32))
+        # "auto": run-time LDS windows per tile (event_plan.resolve_halo), bounded by the largest built halo
+        self.halo = "auto" if cfg.get("halo", 32) == "auto" else int(cfg.get("halo", 32))
         # optimizer.graph: capture one whole iteration (upsample -> fused objective -> backward -> Adam update) into a
         # HIP graph and replay it.  Measured on MI355X / ROCm 7.2 (tools/bench_solver.py, 2 M events at 1280x720):
         # 0.195 ms per replayed iteration against 0.68 ms for the eager loop (interpreter + autograd overhead around
@@ -164,7 +165,7 @@ class ContrastMaximizationMixin(object):
         (``halo: 16`` -- windows whose displacements stay within ~16 px -- selects the smaller LDS windows)."""
         from ..event_plan import choose_tile
 
-        return choose_tile(self.orig_image_shape, self.halo)
+        return choose_tile(self.orig_image_shape, 32 if self.halo == "auto" else self.halo)
 
     def pyramid_scales(self):
         """[(patch_size, sliding_window, n_iter)] coarse to fine.  Without ``patch.pyramid`` one scale (``patch.size``);

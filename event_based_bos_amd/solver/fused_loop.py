@@ -65,7 +65,9 @@ class FusedPatchLoop(object):
         self.w_gm = float(w_gradient_magnitude)
         if (self.w_var != 0.0) == (self.w_gm != 0.0):
             raise ValueError("exactly one contrast weight (variance or gradient magnitude) must be non-zero")
-        self.omit, self.pad, self.halo = bool(omit_boundary), (int(pad), int(pad)), int(halo)
+        from ..event_plan import _norm_halo
+
+        self.omit, self.pad, self.halo = bool(omit_boundary), (int(pad), int(pad)), int(_norm_halo(plan, halo))  # ("auto": run-time windows)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         dev = plan.device
         H, W = plan.image_size

@@ -334,8 +334,22 @@ int ebos_iwe_dense_bwd_f32(const float* x, const float* y, const float* dt, cons
  * grp_offsets / cpix / cdt (nullable trio): the compact plan of ebos_plan_compact_f32; when given and weight is
  *   NULL, xs/ys/dts are not read (6 B/event instead of 12).  All SoA arrays are read 4 events (16 bytes) per
  *   lane: 16-byte aligned, padded to a multiple of 4 elements.
- * (tile_h, tile_w, halo) must be one of ebos_slab_config().
+ * (tile_h, tile_w, halo) must be one of ebos_slab_config() -- or halo = EBOS_HALO_AUTO(max_halo, q):
+ *
+ * RUN-TIME WINDOWS.  Every `halo` argument / field of this section also takes EBOS_HALO_AUTO(max_halo, q) (a negative number):
+ *   (tile_h, tile_w, max_halo) is a built configuration -- it sizes the LDS, the slabs and the workspace -- and every work item
+ *   chooses ITS OWN window (hr rows, hc columns of halo per side, hc a multiple of 4, both <= max_halo) inside the kernel, from a
+ *   bound on its displacements: max |flow| over the tile's own pixels (dense flow), over the grid cells its pixels interpolate
+ *   (patch grid), or |theta| (2-DoF), times q / 64 >= max |dt| over the plan's events (1.0 -> q = 64 with normalised time and
+ *   reference time inside the window; ebos_halo_auto rounds a bound up for you).  LDS clear / decode, slab traffic, the combine
+ *   pass's reads and the backward kernel's upstream tile shrink with the window; BOS displacements are a few pixels, the +-30 px
+ *   of the sampler range (configs/hot_plate1.yaml:46-80) is the search bound, not the operating point.  Taps beyond a window go to
+ *   the spill image exactly as with a built halo, so the choice moves time, never results: images are bit-identical to those of
+ *   the built max_halo as long as nothing spills.  Compact plans with unit weights (the lean loops); other calls run max_halo.
+ *   The forward pass records each tile's window behind the SpillEpoch word of its workspace for its combine pass.
  * ---------------------------------------------------------------------------------------- */
+#define EBOS_HALO_AUTO(max_halo, dt_bound_q64) (-((int)(max_halo) + 256 * (int)(dt_bound_q64)))
+int ebos_halo_auto(int max_halo, double dt_bound); /* EBOS_HALO_AUTO(max_halo, ceil(64 dt_bound)); max_halo itself if out of range */
 int ebos_slab_config(int* out, int cap);
 size_t ebos_iwe_slab_workspace_bytes(int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h,
                                      int pad_w);

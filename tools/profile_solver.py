@@ -22,11 +22,11 @@ ap.add_argument("--patch", type=int, nargs=2, default=[24, 32])
 ap.add_argument("--dense", action="store_true", help="materialised route (upsample -> dense kernels -> adjoint) instead of grid sampling")
 ap.add_argument("--flow-norm", type=float, default=0.001)
 ap.add_argument("--image-gradient", type=float, default=0.0)
-ap.add_argument("--halo", type=int, default=32)
+ap.add_argument("--halo", type=lambda v: v if v == "auto" else int(v), default=32, help="a built halo, or auto (run-time windows per tile)")
 ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile (default: choose_tile for the halo)")
 a = ap.parse_args()
 ev, _ = synth_window(a.events, 0)
-plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=tuple(a.tile) if a.tile else ebos.event_plan.choose_tile((H, W), a.halo))
+plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=tuple(a.tile) if a.tile else ebos.event_plan.choose_tile((H, W), 32 if a.halo == "auto" else a.halo))
 gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
 loop = FusedPatchLoop(plan, a.patch, a.patch, torch.zeros((2, gh, gw)), 1.0, a.flow_norm, a.image_gradient, halo=a.halo, lr=0.1, capacity=a.iters + 3,
                       sample_grid=False if a.dense else None)
