@@ -693,7 +693,7 @@ def run_config4(R):
     for wi in mine:
         ev, _ = synth_window(n, seed=wi, flow=False)
         plans.append(ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact"))
-        grids.append(torch.from_numpy(np.random.RandomState(100 + wi).uniform(-FLOW_MAX, FLOW_MAX, (2, gh, gw))).float().to(dev))
+        grids.append(torch.from_numpy(np.random.RandomState(100 + wi).uniform(-a.flow_max, a.flow_max, (2, gh, gw))).float().to(dev))
     torch.cuda.synchronize()
     ingest_s = time.perf_counter() - t0
     a.halo_code = ebos.event_plan.resolve_halo(plans[0], a.halo) if plans else 32
@@ -804,8 +804,9 @@ def run_config4(R):
         value = total_events * a.steps / elapsed / 1e6
         algo = 12.0 * n + 4.0 * H * W + 8.0 * gh * gw  # per launch: events + IWE write + the patch grid (no dense flow field)
         line = base_line(R, value, ms_per_step, blocks, "strong", {
-            "workload": f"BASELINE configs[3]: {n_windows} time windows x {n} events, {gh}x{gw} patch-flow grid "
-                        f"(patch {ph}x{pw}, slide {sh}x{sw}) -> 1280x720, variance cost, fwd objective per window",
+            "workload": (f"BASELINE configs[3]: {n_windows} time windows x {n} events, {gh}x{gw} patch-flow grid "
+                         f"(patch {ph}x{pw}, slide {sh}x{sw}) -> 1280x720, variance cost, fwd objective per window"
+                         + ("" if a.flow_max == FLOW_MAX else f"; NOT the BASELINE flow: cells U(-{a.flow_max:g},{a.flow_max:g})")),
             "windows_total": n_windows, "events_per_window": n, "height": H, "width": W,
             "layout": f"compact SoA 6 B/event, tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}; flow sampled from the patch grid per tile",
             "parallelism": f"windows round-robin over {world} rank(s) (bos_event.py:144-220), no collective"})

@@ -368,10 +368,22 @@ struct CGroupQ {
   unsigned pr[4], pcq[4];
   float dt[4];
 };
-__device__ __forceinline__ void load_cgroup_q(CGroupQ& g, int32_t grp, const TileRange& tr, const EvPtrs& p, unsigned hc4) {
+// a group as it comes from memory (24 bytes): what the persistent batched kernel holds while it prefetches a window's first chunks
+struct CRaw {
+  float4 D;
+  uint2 P;
+};
+__device__ __forceinline__ CRaw load_craw(int32_t grp, const TileRange& tr, const EvPtrs& p) {
   const int32_t j = max(min(grp, tr.g_last), tr.g_first);
-  const float4 D = reinterpret_cast<const float4*>(p.cdt)[j];
-  const uint2 P = reinterpret_cast<const uint2*>(p.cpix)[j];
+  return CRaw{reinterpret_cast<const float4*>(p.cdt)[j], reinterpret_cast<const uint2*>(p.cpix)[j]};
+}
+__device__ __forceinline__ void decode_craw(CGroupQ& g, const CRaw& r, unsigned hc4);
+__device__ __forceinline__ void load_cgroup_q(CGroupQ& g, int32_t grp, const TileRange& tr, const EvPtrs& p, unsigned hc4) {
+  decode_craw(g, load_craw(grp, tr, p), hc4);
+}
+__device__ __forceinline__ void decode_craw(CGroupQ& g, const CRaw& r, unsigned hc4) {
+  const float4 D = r.D;
+  const uint2 P = r.P;
   g.dt[0] = D.x; g.dt[1] = D.y; g.dt[2] = D.z; g.dt[3] = D.w;
   g.pr[0] = (P.x >> 8) & 255u; g.pcq[0] = ((P.x & 255u) << 2) + hc4;
   g.pr[1] = P.x >> 24;         g.pcq[1] = (((P.x >> 16) & 255u) << 2) + hc4;
@@ -420,7 +432,8 @@ struct ChunkQueue {
 template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false, bool DYN = false>
 __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                           const float* __restrict__ flow, int H, int W, bool* any_spill,
-                                                          const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win) {
+                                                          const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win,
+                                                          const CRaw* pre = nullptr) {
   const int LH = win.LH(), LW = win.LW(), HR = win.HR(), HC = win.HC(), PT = win.P();  // (compile-time constants unless DYN)
   const unsigned kPlane = LH * PT / 2;  // words per plane
   const unsigned kDummy = LH * PT;      // first word of the dummy region (PT / 2 + 2 words)
@@ -465,8 +478,13 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   // chunk c covers groups [g_first + 64 c, g_first + 64 c + 64); this wave starts with chunks `wave` and `wave + 16`
   int c_cur = wave, c_nxt = wave + kWaves;
   CGroupQ cur, nxt;
-  load_cgroup_q(cur, tr.g_first + c_cur * kWave + lane, tr, ev, hc4);
-  load_cgroup_q(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev, hc4);
+  if (pre != nullptr) {  // (persistent batched kernel: this window's first two chunks were requested during the previous window)
+    decode_craw(cur, pre[0], hc4);
+    decode_craw(nxt, pre[1], hc4);
+  } else {
+    load_cgroup_q(cur, tr.g_first + c_cur * kWave + lane, tr, ev, hc4);
+    load_cgroup_q(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev, hc4);
+  }
   float fu[4], fv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pcq[e], fu[e], fv[e]);
@@ -556,7 +574,7 @@ template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, boo
 __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                      const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                      float* spill, bool* any_spill, const ChunkQueue& queue,
-                                                     const Win<TH, TW, HALO, DYN>& win) {
+                                                     const Win<TH, TW, HALO, DYN>& win, const CRaw* pre = nullptr) {
   const int LH = win.LH(), LW = win.LW(), PT = win.P();
   unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
@@ -569,7 +587,7 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
   bool spilled = false;
   if (tr.g_first > tr.g_last) return 0;
   if (FMT == FMT_COMPACT && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop (fixed point, or its exact f64 redo)
-    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID, DYN>(tr, s_acc, ev, flow, H, W, any_spill, queue, win);
+    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID, DYN>(tr, s_acc, ev, flow, H, W, any_spill, queue, win, pre);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
   const int32_t g_last = tr.g_last;
@@ -716,91 +734,51 @@ __device__ __forceinline__ Win<TH, TW, HALO, DYN> tile_bound_read(const float* s
   return w;
 }
 
-// the accumulate pass of one work item (blockIdx.x) of one window: shared by the single-window and the batched kernels.
-//   DYN      the LDS window is chosen per tile at run time (Win above); halo_tab [tiles] tells the combine pass
-//   ZERO     the decode pass zeroes every LDS word it reads, so that the NEXT window of a persistent workgroup starts on a clean
-//            image without a clear of its own (do_clear = false after the first)
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false, bool ZERO = false>
-__device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t* __restrict__ key_offsets,
-                                                const float* __restrict__ flow_arg, int H, int W, int tiles_x, int splits, int pad_h,
-                                                int pad_w, float* __restrict__ slabs, float* spill, const GridSrc& gs,
-                                                unsigned* __restrict__ spill_epoch, unsigned epoch, float dt_bound = 0.0f,
-                                                unsigned* __restrict__ halo_tab = nullptr, bool do_clear = true) {
+// workgroup state of the accumulate pass
+struct TileShared {
+  unsigned long long chk;  // sum over the workgroup of (units added - units decoded), modulo 2^64
+  int flag[2];             // [0] fixed-point overflow, [1] some event left the LDS window
+  unsigned next;           // chunk queue of the lean loop
+  float bound[2 * kBlock / kWave];  // DYN: per-wave maxima of |u|, |v| over the tile
+};
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// Everything of one work item after its set-up barrier: the event loop, the rare spill sweep, the decode pass that writes the slab
+// and checks the fixed-point sums (f64 redo if a field wrapped).
+//   DYN         the LDS window `win` was chosen at run time; halo_tab [tiles] tells the combine pass
+//   ZERO        the decode pass zeroes every LDS word it reads: the NEXT window of a persistent workgroup starts on a clean image
+//   pre         the slice's first two chunks, already loaded (persistent kernel), or nullptr
+//   after_loop  called by every wave as it leaves the event loop, before the barrier: the persistent kernel requests the next
+//               window's first chunks there, so that they arrive while this window's image is decoded and stored
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID, bool DYN, bool ZERO, typename Hook>
+__device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW, HALO, DYN>& win, const float* flow, double* s_acc,
+                                          TileShared& sh, const EvPtrs& ev, int H, int W, int tiles_x, int pad_h, int pad_w,
+                                          float* __restrict__ slabs, float* spill, unsigned* __restrict__ spill_epoch, unsigned epoch,
+                                          unsigned* __restrict__ halo_tab, const CRaw* pre, Hook&& after_loop) {
   constexpr int kLHmax = TH + 2 * HALO, kLWmax = TW + 2 * HALO;
   constexpr int kCells = acc_cells<TH, TW, HALO, DYN>();
-  static_assert(kLWmax % 4 == 0, "slab rows are written 4 cells at a time");
-  static_assert(!DYN || (FMT == FMT_COMPACT && !HAS_W), "run-time windows: the lean loop only");
-  extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words; + dummy
-  __shared__ unsigned long long s_chk[1];  // sum over the workgroup of (units added - units decoded), modulo 2^64
-  __shared__ int s_flag[2];  // [0] fixed-point overflow, [1] some event left the LDS window
-  __shared__ unsigned s_next;  // chunk queue of the lean loop
-  __shared__ float s_bound[2 * kBlock / kWave];  // DYN: per-wave maxima of |u|, |v| over the tile
-  const ChunkQueue queue{&s_next};
-  EBOS_STAMP(0);
-  static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
-  // (dense field: the clear comes first -- it needs nothing, and the dependent loads of tile_range fly over it; run-time
-  // windows: the tile's flow values, which bound its displacements, are requested before the clear and awaited after it)
-  constexpr bool kBoundFromFlow = DYN && !GRID && !UNIFORM;
-  if (!GRID && !kBoundFromFlow && do_clear)
-    for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
-      reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
-  const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, splits);
-  if (tr.ty < 0) return;  // unused work item of an adaptive plan: its slab is never read
-  float mu = 0.0f, mv = 0.0f;
-  if (kBoundFromFlow) {
-    tile_flow_absmax<TH, TW>(flow_arg, H, W, tr.ty * TH, tr.tx * TW, mu, mv);
-    if (do_clear)
-      for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
-  }
-
-  const float* flow = flow_arg;
-  float* s_flow = reinterpret_cast<float*>(s_acc + kCells);  // GRID: the tile's dense flow, behind the accumulators
-  Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * TH * TW);
-  TileGrid tg{};
-  if (GRID) {
-    tg = tile_grid_begin<TH, TW, 0>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);  // (its cell load flies over the clear)
-    if (do_clear)
-      for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
-  }
-  if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
-  if (threadIdx.x == 0) {
-    s_next = 2 * (kBlock / kWave);
-    s_chk[0] = 0ull;
-  }
-  if (DYN) {  // a bound on this tile's displacements: |flow| over the tile (dense), the cells its pixels interpolate (GRID), theta
-    if (UNIFORM) {
-      mu = fabsf(flow_arg[0]), mv = fabsf(flow_arg[1]);
-    } else if (GRID) {  // (bilinear interpolation never leaves the range of its cells; every thread holds a cell of the block)
-      const int idx = min((int)threadIdx.x, 2 * tg.ni * tg.nj - 1);
-      const bool second = idx >= tg.ni * tg.nj;
-      mu = second ? 0.0f : fabsf(tg.cell), mv = second ? fabsf(tg.cell) : 0.0f;
-    }
-    tile_bound_post(mu, mv, s_bound);
-  }
-  if (GRID) {
-    tile_grid_finish<TH, TW, 0>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
-    flow = s_flow;
-  }
-  __syncthreads();
-  const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(s_bound, dt_bound);
+  const ChunkQueue queue{&sh.next};
   const int LH = win.LH(), LW = win.LW(), PT = win.P();  // (PT: row pitch in LDS; slabs are dense, LW floats per row)
   if (DYN && threadIdx.x == 0) halo_tab[tr.ty * tiles_x + tr.tx] = win_pack(win.hr, win.hc);  // (every part of a tile: same word)
   EBOS_STAMP(1);
 
   bool spilled = false;
   unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN>(
-      tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win);
+      tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, pre);
+  after_loop();
   constexpr bool kLeanLoop = FMT == FMT_COMPACT && !HAS_W;  // accumulate_compact_fx: counts nothing per event
   if (kLeanLoop && threadIdx.x == 0 && tr.g_first <= tr.g_last)  // 2^20 units per event of the slice (padding slots excluded)
     added += (unsigned long long)(min(tr.end, tr.beg + 4 * (tr.g_last - tr.g_first + 1)) - tr.beg) << kFxShift;
-  if (spilled) s_flag[1] = 1;  // benign race: every writer stores 1
+  if (spilled) sh.flag[1] = 1;  // benign race: every writer stores 1
   EBOS_STAMP(2);
   __syncthreads();
   EBOS_STAMP(3);
   // SpillEpoch: a workgroup that puts anything into the spill image stamps the workspace with this call's number; the combine
   // pass reads the 3.7 MB spill image only if the stamp is this call's (it is all zero otherwise, and stays so)
-  if (s_flag[1] && threadIdx.x == 0) *spill_epoch = epoch;  // benign race: every writer stores the same value
-  if (s_flag[1])  // rare: taps beyond the halo go to the spill image with global atomics (lean path: minus their units)
+  if (sh.flag[1] && threadIdx.x == 0) *spill_epoch = epoch;  // benign race: every writer stores the same value
+  if (sh.flag[1])  // rare: taps beyond the halo go to the spill image with global atomics (lean path: minus their units)
     added -= accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID, DYN>(tr, s_acc, ev, flow, H, W, pad_h, pad_w,
                                                                                               spill, nullptr, queue, win);
 
@@ -868,11 +846,11 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
     // sum(added) == sum(decoded) over the workgroup  <=>  sum(added - decoded) == 0 modulo 2^64: one value per lane, one DPP wave
     // sum, one LDS atomic per wave, one barrier (two values, shuffles, a serial 32-term loop and two barriers before)
     const unsigned long long diff = wave_sum(added - decoded);
-    if ((threadIdx.x & (kWave - 1)) == 0 && diff != 0ull) atomicAdd(&s_chk[0], diff);
+    if ((threadIdx.x & (kWave - 1)) == 0 && diff != 0ull) atomicAdd(&sh.chk, diff);
     __syncthreads();
-    if (s_chk[0] != 0ull) {  // a field wrapped: redo this slice exactly in f64 and overwrite the slab (spill taps already issued)
+    if (sh.chk != 0ull) {  // a field wrapped: redo this slice exactly in f64 and overwrite the slab (spill taps already issued)
       for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
-      if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);  // the redo draws its chunks afresh
+      if (threadIdx.x == 0) sh.next = 2 * (kBlock / kWave);  // the redo draws its chunks afresh
       __syncthreads();
       accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM, GRID, DYN>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
                                                                                          nullptr, queue, win);
@@ -894,6 +872,70 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
       for (int i = threadIdx.x; i < PT / 2 + 2; i += kBlock) s_acc[LH * PT + i] = 0.0;
   }
   EBOS_STAMP(4);
+}
+
+
+// set-up of one work item: LDS clear (first window of a workgroup), tile range, GRID: the tile's flow into LDS, DYN: the window
+// from a bound on the tile's displacements.  Returns false for an unused work item of an adaptive plan (nothing to do).
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false, bool ZERO = false>
+__device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t* __restrict__ key_offsets,
+                                                const float* __restrict__ flow_arg, int H, int W, int tiles_x, int splits, int pad_h,
+                                                int pad_w, float* __restrict__ slabs, float* spill, const GridSrc& gs,
+                                                unsigned* __restrict__ spill_epoch, unsigned epoch, float dt_bound = 0.0f,
+                                                unsigned* __restrict__ halo_tab = nullptr) {
+  constexpr int kLWmax = TW + 2 * HALO;
+  constexpr int kCells = acc_cells<TH, TW, HALO, DYN>();
+  static_assert(kLWmax % 4 == 0, "slab rows are written 4 cells at a time");
+  static_assert(!DYN || (FMT == FMT_COMPACT && !HAS_W), "run-time windows: the lean loop only");
+  extern __shared__ double s_acc[];  // [LH][LW] doubles, or 2 planes of [LH][LW/2] paired words; + dummy
+  __shared__ TileShared sh;
+  EBOS_STAMP(0);
+  static_assert(kCells % 2 == 0, "LDS image is cleared 16 bytes per lane");
+  // (dense field: the clear comes first -- it needs nothing, and the dependent loads of tile_range fly over it; run-time
+  // windows: the tile's flow values, which bound its displacements, are requested before the clear and awaited after it)
+  constexpr bool kBoundFromFlow = DYN && !GRID && !UNIFORM;
+  if (!GRID && !kBoundFromFlow)
+    for (int i = threadIdx.x; i < kCells / 2; i += kBlock)  // all-zero bits = 0 in both modes
+      reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+  const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, splits);
+  if (tr.ty < 0) return;  // unused work item of an adaptive plan: its slab is never read
+  float mu = 0.0f, mv = 0.0f;
+  if (kBoundFromFlow) {
+    tile_flow_absmax<TH, TW>(flow_arg, H, W, tr.ty * TH, tr.tx * TW, mu, mv);
+    for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+  }
+
+  const float* flow = flow_arg;
+  float* s_flow = reinterpret_cast<float*>(s_acc + kCells);  // GRID: the tile's dense flow, behind the accumulators
+  Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * TH * TW);
+  TileGrid tg{};
+  if (GRID) {
+    tg = tile_grid_begin<TH, TW, 0>(flow_arg, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);  // (its cell load flies over the clear)
+    for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+  }
+  if (threadIdx.x < 2) sh.flag[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    sh.next = 2 * (kBlock / kWave);
+    sh.chk = 0ull;
+  }
+  if (DYN) {  // a bound on this tile's displacements: |flow| over the tile (dense), the cells its pixels interpolate (GRID), theta
+    if (UNIFORM) {
+      mu = fabsf(flow_arg[0]), mv = fabsf(flow_arg[1]);
+    } else if (GRID) {  // (bilinear interpolation never leaves the range of its cells; every thread holds a cell of the block)
+      const int idx = min((int)threadIdx.x, 2 * tg.ni * tg.nj - 1);
+      const bool second = idx >= tg.ni * tg.nj;
+      mu = second ? 0.0f : fabsf(tg.cell), mv = second ? fabsf(tg.cell) : 0.0f;
+    }
+    tile_bound_post(mu, mv, sh.bound);
+  }
+  if (GRID) {
+    tile_grid_finish<TH, TW, 0>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
+    flow = s_flow;
+  }
+  __syncthreads();
+  const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(sh.bound, dt_bound);
+  tile_body<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN, ZERO>(tr, win, flow, s_acc, sh, ev, H, W, tiles_x, pad_h, pad_w, slabs,
+                                                                     spill, spill_epoch, epoch, halo_tab, nullptr, NoHook{});
 }
 
 template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
@@ -936,19 +978,86 @@ template <int TH, int TW, int HALO, bool GRID, bool DYN>
 __global__ void __launch_bounds__(kBlock)
 iwe_slab_accumulate_batch_kernel(FwdBatch b, int n, int H, int W, int tiles_x, int splits, int pad_h, int pad_w, GridSrc gs,
                                  unsigned epoch, float dt_bound) {
+  // A software pipeline over the batch's windows.  What a window's work item needs before its event loop can start -- its
+  // tile range (dependent scalar loads), GRID: its block of grid cells, its first two chunks of events -- used to be three exposed
+  // memory round trips per window (3.2 us of set-up and ~1 us at the head of the loop, of 11.9 us: in-kernel stamps).  They are
+  // now requested one window ahead: the tile range before the current window's loop, chunks and cells by every wave as it
+  // leaves that loop, so that they arrive while the current image is decoded, zeroed and stored.
+  constexpr int kCells = acc_cells<TH, TW, HALO, DYN>();
+  extern __shared__ double s_acc[];
+  __shared__ TileShared sh;
+  float* s_flow = reinterpret_cast<float*>(s_acc + kCells);  // GRID: the tile's dense flow, behind the accumulators
+  Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * TH * TW);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   EBOS_STAMP(5);
-  {  // the one clear of the LDS image (here, not in the first window's pass: that one may be an unused work item and return early)
-    extern __shared__ double s_acc[];
-    constexpr int kCells = acc_cells<TH, TW, HALO, DYN>();
-    for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
-    __syncthreads();
+  // the one clear of the LDS image: afterwards the decode pass zeroes what it reads
+  for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+  TileRange tr = tile_range<FMT_COMPACT>(b.w[0].key_offsets, b.w[0].ev, TH * TW, tiles_x, splits);
+  CRaw pre[2];
+  TileGrid tg{};
+  int lerp_tile = -1;  // GRID: the tile whose row / column interpolation s_lerp holds
+  auto request = [&](const FwdWindow& w, const TileRange& t) {  // a window's first two chunks (+ GRID, same tile: its cell block)
+    pre[0] = load_craw(t.g_first + wave * kWave + lane, t, w.ev);
+    pre[1] = load_craw(t.g_first + (wave + kBlock / kWave) * kWave + lane, t, w.ev);
+    if (GRID && t.ty * tiles_x + t.tx == lerp_tile) {
+      const int idx = min((int)threadIdx.x, 2 * tg.ni * tg.nj - 1);
+      const int ch = idx / (tg.ni * tg.nj), rem = idx - ch * (tg.ni * tg.nj);
+      const int i = rem / tg.nj, j = rem - i * tg.nj;
+      tg.cell = w.flow[((int64_t)ch * gs.ay.g + tg.gi0 + i) * gs.ax.g + tg.gj0 + j];
+    }
+  };
+  if (tr.ty >= 0) {
+    if (GRID) {
+      tg = tile_grid_begin<TH, TW, 0>(b.w[0].flow, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);
+      lerp_tile = tr.ty * tiles_x + tr.tx;
+    }
+    request(b.w[0], tr);
   }
+  __syncthreads();
   for (int k = 0; k < n; ++k) {
     const FwdWindow& w = b.w[k];
-    accumulate_tile<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, GRID, DYN, true>(w.ev, w.key_offsets, w.flow, H, W, tiles_x, splits,
-                                                                                      pad_h, pad_w, w.slabs, w.spill, gs, w.spill_epoch,
-                                                                                      epoch, dt_bound, w.halo_tab, false);
+    const bool more = k + 1 < n;
+    TileRange trn = tr;
+    if (more) trn = tile_range<FMT_COMPACT>(b.w[k + 1].key_offsets, b.w[k + 1].ev, TH * TW, tiles_x, splits);  // (scalar loads: in flight)
+    const bool next_live = more && trn.ty >= 0;
+    const FwdWindow& wn = b.w[more ? k + 1 : k];
+    EBOS_STAMP(0);
+    if (tr.ty >= 0) {
+      if (threadIdx.x < 2) sh.flag[threadIdx.x] = 0;
+      if (threadIdx.x == 0) {
+        sh.next = 2 * (kBlock / kWave);
+        sh.chk = 0ull;
+      }
+      const float* flow = w.flow;
+      if (GRID && tr.ty * tiles_x + tr.tx != lerp_tile) {  // (adaptive plans: this window's item is another tile) no prefetch
+        tg = tile_grid_begin<TH, TW, 0>(w.flow, gs, tr.ty * TH, tr.tx * TW, H, W, s_lerp);
+        lerp_tile = tr.ty * tiles_x + tr.tx;
+      }
+      if (DYN) {
+        float mu = 0.0f, mv = 0.0f;
+        if (GRID) {
+          const int idx = min((int)threadIdx.x, 2 * tg.ni * tg.nj - 1);
+          const bool second = idx >= tg.ni * tg.nj;
+          mu = second ? 0.0f : fabsf(tg.cell), mv = second ? fabsf(tg.cell) : 0.0f;
+        } else {
+          tile_flow_absmax<TH, TW>(w.flow, H, W, tr.ty * TH, tr.tx * TW, mu, mv);
+        }
+        tile_bound_post(mu, mv, sh.bound);
+      }
+      if (GRID) {
+        tile_grid_finish<TH, TW, 0>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + TH + TW));
+        flow = s_flow;
+      }
+      __syncthreads();
+      const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(sh.bound, dt_bound);
+      tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, GRID, DYN, true>(
+          tr, win, flow, s_acc, sh, w.ev, H, W, tiles_x, pad_h, pad_w, w.slabs, w.spill, w.spill_epoch, epoch, w.halo_tab, pre,
+          [&]() { if (next_live) request(wn, trn); });
+    } else if (next_live) {
+      request(wn, trn);
+    }
     __syncthreads();  // the flags / counters of this window are re-initialised by the next one
+    tr = trn;
   }
   EBOS_STAMP(6);
 }
@@ -1377,36 +1486,42 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   // away.  The SMALLEST window (4 px: what a converged BOS flow needs) is therefore staged speculatively with everything else;
   // only a tile whose bound asks for more stages again, one round trip later.
   constexpr int kStage = (kLHmax * kLWmax + kBlock - 1) / kBlock;
-  float raw[kStage];
+  constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
+  constexpr int kSpecStage = DYN ? ((TH + 2 * kSpecHalo) * (TW + 2 * kSpecHalo) + kBlock - 1) / kBlock : 1;
+  float raw[kStage], raw_spec[kSpecStage];  // (two register sets: the real window's loads must not wait for the speculative ones)
   Win<TH, TW, HALO, DYN> win{HALO, HALO};
-  auto stage_loads = [&]() {
+  bool spec_hit = false;
+  auto stage_loads = [&](float* dst, int n_stage) {
     const int LW = win.LW(), n_px = win.LH() * LW, oy = tr0 - win.HR(), ox = tc0 - win.HC();
     const float inv_lw = 1.0f / (float)LW;
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
-      if (DYN && k * kBlock >= n_px) break;  // (uniform)
+      if (k >= n_stage || (DYN && k * kBlock >= n_px)) break;  // (uniform)
       const int i = min((int)threadIdx.x + k * kBlock, n_px - 1);
       const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
       const int R = min(max(oy + rl + pad_h, 0), G.h - 1), C = min(max(ox + cl + pad_w, 0), G.w - 1);
-      raw[k] = g_image[(int64_t)R * G.w + C];
+      dst[k] = g_image[(int64_t)R * G.w + C];
     }
   };
-  auto stage_store = [&]() {  // affine map of the upstream image (the variance gradient), zero outside the valid region
+  auto stage_store = [&](const float* src, int n_stage) {  // affine map of the upstream image (the variance gradient), zero outside the valid region
     const int LW = win.LW(), n_px = win.LH() * LW, oy = tr0 - win.HR(), ox = tc0 - win.HC();
     const float inv_lw = 1.0f / (float)LW;
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
-      if (DYN && k * kBlock >= n_px) break;
+      if (k >= n_stage || (DYN && k * kBlock >= n_px)) break;
       const int i = threadIdx.x + k * kBlock;
       const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
       const int R = oy + rl + pad_h, C = ox + cl + pad_w;
       const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-      if (i < n_px) s_g[i] = valid ? G.a * raw[k] + G.c : 0.0f;
+      if (i < n_px) s_g[i] = valid ? G.a * src[k] + G.c : 0.0f;
     }
   };
-  constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
-  if (DYN) win = Win<TH, TW, HALO, DYN>{kSpecHalo, kSpecHalo};
-  stage_loads();
+  if (DYN) {
+    win = Win<TH, TW, HALO, DYN>{kSpecHalo, kSpecHalo};
+    stage_loads(raw_spec, kSpecStage);
+  } else {
+    stage_loads(raw, kStage);
+  }
   double sm = 0.0, sq = 0.0;
   if (mj.partials != nullptr) {
     for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
@@ -1461,14 +1576,18 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   }
   if (DYN) {
     const Win<TH, TW, HALO, DYN> need = tile_bound_read<TH, TW, HALO, DYN>(s_bound, dt_bound);
-    if (need.hr > win.hr || need.hc > win.hc) {  // (uniform) the speculative window is too small: stage the real one
+    spec_hit = need.hr <= win.hr && need.hc <= win.hc;
+    if (!spec_hit) {  // (uniform) the speculative window is too small: stage the real one
       win = need;
-      stage_loads();
+      stage_loads(raw, kStage);
     }
   }
   EBOS_STAMP_BWD(1);
   for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
-  if (GRID || tr.g_first <= tr.g_last) stage_store();
+  if (GRID || tr.g_first <= tr.g_last) {
+    if (DYN && spec_hit) stage_store(raw_spec, kSpecStage);
+    else stage_store(raw, kStage);
+  }
   if (GRID) {
     tile_grid_finish<TH, TW, AP>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + PH + PW));
     flow = s_flow;
