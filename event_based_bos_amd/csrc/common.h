@@ -96,6 +96,16 @@ __device__ __forceinline__ double wave_sum<double>(double v) {
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
+// maximum of NON-NEGATIVE floats over the wave through the DPP path (lanes shifted in from outside a row read 0); valid in every lane
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  v = fmaxf(v, dpp_or_zero<0x111, 0xf>(v));  // row_shr:1
+  v = fmaxf(v, dpp_or_zero<0x112, 0xf>(v));  // row_shr:2
+  v = fmaxf(v, dpp_or_zero<0x114, 0xf>(v));  // row_shr:4
+  v = fmaxf(v, dpp_or_zero<0x118, 0xf>(v));  // row_shr:8   -> lane 15 of every row of 16 holds the row's maximum
+  v = fmaxf(v, dpp_or_zero<0x142, 0xa>(v));  // row_bcast:15 into rows 1 and 3
+  v = fmaxf(v, dpp_or_zero<0x143, 0xc>(v));  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 template <typename T>
 __device__ __forceinline__ T wave_min(T v) {
 #pragma unroll

@@ -711,8 +711,8 @@ __device__ __forceinline__ void tile_flow_absmax(const float* __restrict__ flow,
 // per-wave maxima -> s_red [2 * waves]; the caller's next barrier publishes them and tile_bound_read folds them (every thread,
 // broadcast reads: no barrier of its own)
 __device__ __forceinline__ void tile_bound_post(float mu, float mv, float* s_red) {
-  mu = wave_max(mu);
-  mv = wave_max(mv);
+  mu = wave_max_nonneg(mu);  // (|.| values; Inf stays Inf, NaN entries were skipped by fmaxf)
+  mv = wave_max_nonneg(mv);
   if ((threadIdx.x & (kWave - 1)) == 0) {
     s_red[threadIdx.x / kWave] = mu;
     s_red[kBlock / kWave + threadIdx.x / kWave] = mv;
@@ -1303,11 +1303,41 @@ struct GradImage {
 // Same budget discipline as accumulate_compact_fx.  PASS_MAIN: events whose four taps lie inside the LDS window of the
 // upstream image (others read a dummy cell and contribute 0, but raise the flag); PASS_SPILL: the rare second sweep
 // for exactly those events, reading the upstream image from global memory.
-template <int TH, int TW, int HALO, bool UNIFORM, int PASS, bool GRID = false, bool DYN = false>
+// The scatter side.  A lane's four events are consecutive in the sorted plan and mostly share a source pixel:
+// they are summed in registers per run, and a run adds to its pixel
+//   MODE == ACC_F64   a pair of ds_add_f64 into s_d [2][TH * TW]  (16.6 - 24.3 issue units each: the kernel was LDS-bound,
+//                     SQ_WAIT_INST_LDS 9.6 M of 57 M wave cycles, profiles/r02z_pmc_util.txt)
+//   MODE == ACC_FX    ONE ds_add_u64 into s_w [TH * TW]: (d/du, d/dv) as two SIGNED 32-bit fixed-point fields of one word,
+//                     word += (qv << 32) + qu in two's complement (a negative low field borrows from the high one and the
+//                     decode gives it back).  The unit is chosen PER TILE: with n the largest event count of one of its source
+//                     pixels (key_offsets) and C >= max |dt| x 2 max |upstream tile| the largest contribution of an event, an
+//                     event gets p = 28 - ceil(log2 n) bits (23 at the ~30 events of a 10 M-event window's fullest pixel: f32's
+//                     own resolution relative to C), fx_scale = 2^p / C rounded down to a power of two.  EXACT by construction,
+//                     not by checksum (signed sums could cancel a wrap): every run sum is checked against fx_limit = 2^(p + 2)
+//                     units (*bad otherwise -- a |dt| beyond the caller's bound, a spill-sweep tap outside the staged tile),
+//                     and |pixel sum| <= runs x 2^(p + 2) <= n 2^(p + 2) <= 2^30: no field can leave its 32 bits.  A workgroup
+//                     that fails the run test redoes its slice in ACC_F64; a tile with a hot pixel (n >= 1024: p < 18) takes
+//                     ACC_F64 from the start.  Integer adds commute: the gradient is
+//                     bit-reproducible, which the f64 atomics (order-dependent rounding) were not.
+template <int TH, int TW, int HALO, bool UNIFORM, int PASS, bool GRID = false, bool DYN = false, int MODE = ACC_F64>
 __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s_d, const float* s_g, const EvPtrs& ev,
                                                   const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                   const GradImage& G, double& tot_x, double& tot_y, bool* any_spill,
-                                                  const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win) {
+                                                  const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win,
+                                                  float fx_scale = 1.0f, float fx_limit = 0.0f, bool* bad = nullptr) {
+  unsigned long long* s_w = reinterpret_cast<unsigned long long*>(s_d);
+  bool out_of_range = false;
+  auto add_run = [&](unsigned pix, float ax, float ay) {
+    if (MODE == ACC_FX) {
+      const float sx = ax * fx_scale, sy = ay * fx_scale;
+      out_of_range |= !(fmaxf(fabsf(sx), fabsf(sy)) < fx_limit);  // (also true for NaN)
+      const int qx = (int)rintf(sx), qy = (int)rintf(sy);           // (v_rndne + v_cvt; a value past the limit converts to garbage: redone)
+      atomicAdd(&s_w[pix], (unsigned long long)(((long long)qy << 32) + (long long)qx));
+    } else {
+      atomic_add(&s_d[pix], (double)ax);
+      atomic_add(&s_d[TH * TW + pix], (double)ay);
+    }
+  };
   const int LH = win.LH(), LW = win.LW(), HR = win.HR(), HC = win.HC();  // (compile-time constants unless DYN)
   constexpr int PH = TH + 2 * kBwdApron, PW = TW + 2 * kBwdApron;  // GRID: the tile's flow (+ apron) in LDS
   const float* __restrict__ flow1 = UNIFORM ? flow : flow + (GRID ? (int64_t)PH * PW : (int64_t)H * W);
@@ -1395,10 +1425,7 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
       } else {
         const unsigned pix = cur.pr[e] * TW + cur.pc[e];
         if (pix != run_pix) {
-          if (run_pix != 0xffffffffu) {
-            atomic_add(&s_d[run_pix], (double)ax);
-            atomic_add(&s_d[TH * TW + run_pix], (double)ay);
-          }
+          if (run_pix != 0xffffffffu) add_run(run_pix, ax, ay);
           run_pix = pix;
           ax = 0.0f;
           ay = 0.0f;
@@ -1411,8 +1438,7 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
       tot_x += (double)ax;
       tot_y += (double)ay;
     } else if (run_pix != 0xffffffffu) {
-      atomic_add(&s_d[run_pix], (double)ax);
-      atomic_add(&s_d[TH * TW + run_pix], (double)ay);
+      add_run(run_pix, ax, ay);
     }
     cur = nxt;
     nxt = nn;
@@ -1425,6 +1451,7 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
     }
   }
   if (any_spill) *any_spill = spilled;
+  if (MODE == ACC_FX && bad) *bad = out_of_range;
 }
 
 // UNIFORM: 2-DoF model (flow == theta pair, x' = x + dt * theta): no flow gathers, and instead of a per-pixel
@@ -1457,8 +1484,10 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, GRID ? (adaptive ? 0 : 1) : (part_out ? 0 : 1));
   __shared__ double s_mom[2];
   __shared__ int s_spill;  // some event's taps left the LDS window of the upstream image
+  __shared__ int s_bad;    // fixed-point scatter: a run sum left its range -> the slice is redone with f64 accumulators
   __shared__ unsigned s_next;  // chunk queue of the lean loop
   __shared__ float s_bound[2 * kBlock / kWave];  // DYN: per-wave maxima of |u|, |v| over the tile
+  __shared__ float s_gmax[2 * kBlock / kWave];   // per-wave maxima of |upstream tile| and of events per source pixel (fixed-point unit)
   const ChunkQueue queue{&s_next};
   EBOS_STAMP_BWD(0);
   if (tr.ty < 0 && !(mj.partials != nullptr && blockIdx.x == 0)) return;  // unused work item (workgroup 0 still reports the variance)
@@ -1474,8 +1503,23 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   const int tr0 = max(tr.ty, 0) * TH, tc0 = max(tr.tx, 0) * TW;
   if (threadIdx.x == 0) {
     s_spill = 0;
+    s_bad = 0;
     s_next = 2 * (kBlock / kWave);
   }
+  // Fixed-point scatter (bwd_compact_slice, ACC_FX): its unit depends on the largest event count of a source pixel of the tile --
+  // the per-pixel counts of the WHOLE tile (an upper bound for a part of it), read off the plan's key offsets while everything
+  // else loads
+  constexpr bool kFxScatter = (FMT == FMT_COMPACT) && !HAS_W && !UNIFORM;
+  int nmax_t = 1;
+  if (kFxScatter && tr.ty >= 0) {
+    const int32_t* ko = key_offsets + (int64_t)(tr.ty * tiles_x + tr.tx) * (TH * TW);
+#pragma unroll
+    for (int k = 0; k < (TH * TW + kBlock - 1) / kBlock; ++k) {
+      const int i = min((int)threadIdx.x + k * kBlock, TH * TW - 1);
+      nmax_t = max(nmax_t, ko[i + 1] - ko[i]);
+    }
+  }
+  float gmax_t = 0.0f;  // this thread's max |staged upstream value|
   // ---- set-up.  Every global read in flight at once: (1) the raw upstream tile into registers -- unconditional, clamped loads,
   // fully unrolled (a loop of bounds-checked loads is waited for one by one: 5.6 us of set-up per workgroup, in-kernel stamps; not
   // gated by "this item has events": that is known one round trip later than the tile's position) -- (2) GRID: the tile's block of
@@ -1513,7 +1557,11 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
       const int R = oy + rl + pad_h, C = ox + cl + pad_w;
       const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-      if (i < n_px) s_g[i] = valid ? G.a * src[k] + G.c : 0.0f;
+      const float gv = valid ? G.a * src[k] + G.c : 0.0f;
+      if (i < n_px) {
+        s_g[i] = gv;
+        gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);  // (a NaN counts as Inf: such a tile takes the f64 path)
+      }
     }
   };
   if (DYN) {
@@ -1592,28 +1640,79 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     tile_grid_finish<TH, TW, AP>(tg, s_flow, s_lerp, reinterpret_cast<float*>(s_lerp + PH + PW));
     flow = s_flow;
   }
+  if (kFxScatter) {
+    gmax_t = wave_max_nonneg(gmax_t);
+    const float nm = wave_max_nonneg((float)nmax_t);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+      s_gmax[threadIdx.x / kWave] = gmax_t;
+      s_gmax[kBlock / kWave + threadIdx.x / kWave] = nm;
+    }
+  }
   __syncthreads();
   EBOS_STAMP_BWD(2);
   const int LH = win.LH(), LW = win.LW();
   const int oy = tr0 - win.HR(), ox = tc0 - win.HC();
+  bool fx = kFxScatter;
+  float fx_scale = 1.0f, fx_limit = 0.0f;
+  if (fx) {
+    float gmax = 0.0f, nmax = 1.0f;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; ++k) {
+      gmax = fmaxf(gmax, s_gmax[k]);
+      nmax = fmaxf(nmax, s_gmax[kBlock / kWave + k]);
+    }
+    int en;
+    frexpf(nmax, &en);                    // nmax < 2^en
+    const int pbits = min(28 - en, 24);   // bits of one event's contribution (24: f32 has no more)
+    // an event contributes dt * (a convex combination of differences of neighbouring upstream values): |.| <= max |dt| x 2 gmax
+    const float cmax = (dt_bound > 0.0f ? dt_bound : 1.0f) * 2.0f * gmax;
+    if (!(cmax < 3.0e38f) || pbits < 18) {
+      fx = false;  // NaN / Inf upstream, or a source pixel with >= 1024 events (a hot pixel: f64 keeps its tile's precision)
+    } else {
+      int e = 0;
+      if (cmax > 0.0f) frexpf(cmax, &e);  // cmax = m 2^e, 0.5 <= m < 1
+      fx_scale = ldexpf(1.0f, max(min(pbits - e, 120), -120));  // cmax x scale <= 2^pbits
+      fx_limit = ldexpf(1.0f, pbits + 2);                       // a run of <= 4 events
+    }
+  }
 
   double tot_x = 0.0, tot_y = 0.0;  // UNIFORM: this lane's sum of dt * dL/d(x', y')
   constexpr bool kLean = (FMT == FMT_COMPACT) && !HAS_W;
   if (kLean) {
-    bool spilled = false;
-    if (tr.g_first <= tr.g_last)
-      bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN, GRID, DYN>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
-                                                                     &spilled, queue, win);
-    if (spilled) s_spill = 1;
-    EBOS_STAMP_BWD(3);
-    __syncthreads();
-    EBOS_STAMP_BWD(4);
-    if (s_spill) {  // rare second sweep; it draws its chunks afresh
-      if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
-      __syncthreads();
+    // main sweep + (rare) spill sweep in one accumulation mode; returns with every wave past its last add
+    auto sweeps = [&](auto mode_tag) {
+      constexpr int M = decltype(mode_tag)::value;
+      bool spilled = false, bad = false;
       if (tr.g_first <= tr.g_last)
-        bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL, GRID, DYN>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
-                                                                        nullptr, queue, win);
+        bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN, GRID, DYN, M>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
+                                                                          &spilled, queue, win, fx_scale, fx_limit, &bad);
+      if (spilled) s_spill = 1;
+      if (bad) s_bad = 1;
+      EBOS_STAMP_BWD(3);
+      __syncthreads();
+      EBOS_STAMP_BWD(4);
+      if (s_spill) {  // rare second sweep; it draws its chunks afresh
+        if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
+        __syncthreads();
+        bad = false;
+        if (tr.g_first <= tr.g_last)
+          bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_SPILL, GRID, DYN, M>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
+                                                                             nullptr, queue, win, fx_scale, fx_limit, &bad);
+        if (bad) s_bad = 1;
+        __syncthreads();
+      }
+    };
+    if (fx) {
+      sweeps(std::integral_constant<int, ACC_FX>{});
+      if (s_bad) {  // (uniform: read after the sweeps' last barrier) a run left the fixed-point range: exact redo in f64
+        fx = false;
+        for (int i = threadIdx.x; i < TH * TW; i += kBlock) s_d[i] = 0.0;  // (the words; the upper half was never touched)
+        if (threadIdx.x == 0) s_next = 2 * (kBlock / kWave);
+        __syncthreads();
+        sweeps(std::integral_constant<int, ACC_F64>{});
+      }
+    } else {
+      sweeps(std::integral_constant<int, ACC_F64>{});
     }
   } else if (tr.g_first <= tr.g_last) {
     const float* __restrict__ flow1 = UNIFORM ? flow : flow + hw;
@@ -1719,6 +1818,17 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
     return;
   }
+  // the tile's gradient, pixel i, component ch: decoded from the fixed-point words or read from the f64 accumulators
+  const float fx_inv = 1.0f / fx_scale;  // (a power of two: exact)
+  const unsigned long long* s_w = reinterpret_cast<const unsigned long long*>(s_d);
+  auto grad_at = [&](int i, int ch) -> float {
+    if (fx) {
+      const long long w = (long long)s_w[i];
+      const long long lo = fx_lo(w);
+      return (float)(ch ? fx_hi(w) : lo) * fx_inv;
+    }
+    return (float)s_d[ch * TH * TW + i];
+  };
   if (GRID) {
     // adjoint of the grid -> dense map on this tile, separable like the stand-alone adjoint: rows first
     //   S[ch][i][c] = sum_r wy(r, gi0 + i) * (d[ch][r][c] + addend),   then   P[ch][i][j] = sum_c wx(c, gj0 + j) * S[ch][i][c]
@@ -1740,13 +1850,26 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const Lerp l = s_lx[c];
       s_wx[idx] = c < cols ? (l.i0 == gj0 + j ? l.w0 : 0.0f) + (l.i1 == gj0 + j ? l.w1 : 0.0f) : 0.0f;
     }
+    // This thread's pixels of the tile gradient, in registers: decoded from the accumulators (fixed-point words or doubles), plus
+    // what enters per pixel (regulariser gradients).  They go back as PLANAR FLOATS s_f [2][TH * TW] in place of the accumulators
+    // -- after a barrier: a pixel's float slots lie inside other pixels' words.
+    constexpr int kPx = (TH * TW + kBlock - 1) / kBlock;
+    float px_u[kPx], px_v[kPx];
+#pragma unroll
+    for (int k = 0; k < kPx; ++k) {
+      const int idx = min((int)threadIdx.x + k * kBlock, TH * TW - 1);
+      px_u[k] = grad_at(idx, 0);
+      px_v[k] = grad_at(idx, 1);
+    }
     if (addend != nullptr && tr.part == 0) {  // the regulariser gradient enters once per tile (coalesced row reads)
-      for (int idx = threadIdx.x; idx < TH * TW; idx += kBlock) {
+#pragma unroll
+      for (int k = 0; k < kPx; ++k) {
+        const int idx = threadIdx.x + k * kBlock;
         const int rl = idx / TW, cl = idx - rl * TW;
-        if (rl < rows && cl < cols) {
+        if (idx < TH * TW && rl < rows && cl < cols) {
           const int64_t o = (int64_t)(tr0 + rl) * W + tc0 + cl;
-          s_d[idx] += (double)addend[o];
-          s_d[TH * TW + idx] += (double)addend[hw + o];
+          px_u[k] += addend[o];
+          px_v[k] += addend[hw + o];
         }
       }
     }
@@ -1759,9 +1882,11 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       // functions as the stand-alone regulariser kernel, on LDS lines instead of global ones.
       double val = 0.0;
       if (tr.part == 0) {
-        for (int idx = threadIdx.x; idx < TH * TW; idx += kBlock) {
+#pragma unroll
+        for (int k = 0; k < kPx; ++k) {
+          const int idx = threadIdx.x + k * kBlock;
           const int rl = idx / TW, cl = idx - rl * TW;
-          if (rl < rows && cl < cols) {
+          if (idx < TH * TW && rl < rows && cl < cols) {
             const int o = (rl + AP) * PW + cl + AP;
             const float u = s_flow[o], v = s_flow[PH * PW + o];
             float gu = 0.0f, gv = 0.0f;
@@ -1786,13 +1911,23 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
               gu += s_tv * (tv_adjoint(col_u, r, H, PW) + tv_adjoint(row_u, c, W, 1));
               gv += s_tv * (tv_adjoint(col_v, r, H, PW) + tv_adjoint(row_v, c, W, 1));
             }
-            s_d[idx] += (double)gu;
-            s_d[TH * TW + idx] += (double)gv;
+            px_u[k] += gu;
+            px_v[k] += gv;
           }
         }
       }
       val = wave_sum(val);  // per-wave partials, summed in wave order by one thread after the barrier below (deterministic)
       if ((threadIdx.x & (kWave - 1)) == 0) s_red_norm[threadIdx.x / kWave] = val;
+    }
+    __syncthreads();  // every accumulator has been read
+    float* s_f = reinterpret_cast<float*>(s_d);
+#pragma unroll
+    for (int k = 0; k < kPx; ++k) {
+      const int idx = threadIdx.x + k * kBlock;
+      if (idx < TH * TW) {
+        s_f[idx] = px_u[k];
+        s_f[TH * TW + idx] = px_v[k];
+      }
     }
     __syncthreads();
     EBOS_STAMP_BWD(5);
@@ -1804,11 +1939,11 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     for (int idx = threadIdx.x; idx < 2 * ni * TW; idx += kBlock) {
       const int ch = idx / (ni * TW), rem = idx - ch * (ni * TW);
       const int i = rem / TW, c = rem - i * TW;
-      const double* d = s_d + ch * TH * TW + c;
+      const float* d = s_f + ch * TH * TW + c;
       const float* wy = s_wy + i * TH;
       float acc = 0.0f;  // (bounding r to the rows that touch the cell -- about half -- was slower: the bound search is serial)
 #pragma unroll 9
-      for (int r = 0; r < TH; ++r) acc += wy[r] * (float)d[r * TW];
+      for (int r = 0; r < TH; ++r) acc += wy[r] * d[r * TW];
       s_S[idx] = acc;
     }
     __syncthreads();
@@ -1830,7 +1965,10 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   }
   if (part_out != nullptr) {  // partial tile [2][TH * TW] of this part, plain stores
     float* out = part_out + (int64_t)tr.slab * (kLHmax * kLWmax);
-    for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) out[i] = (float)s_d[i];
+    for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
+      out[i] = grad_at(i, 0);
+      out[TH * TW + i] = grad_at(i, 1);
+    }
     EBOS_STAMP_BWD(5);
     return;
   }
@@ -1844,10 +1982,9 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const int r = tr0 + rl, c = tc0 + cl;
       if (r < H && c < W) {
         const int64_t o = (int64_t)r * W + c;
-        const double* dx = s_d + rl * TW + cl;
-        const double* dy = dx + TH * TW;
-        float4 gx = make_float4((float)dx[0], (float)dx[1], (float)dx[2], (float)dx[3]);
-        float4 gy = make_float4((float)dy[0], (float)dy[1], (float)dy[2], (float)dy[3]);
+        const int p0 = rl * TW + cl;
+        float4 gx = make_float4(grad_at(p0, 0), grad_at(p0 + 1, 0), grad_at(p0 + 2, 0), grad_at(p0 + 3, 0));
+        float4 gy = make_float4(grad_at(p0, 1), grad_at(p0 + 1, 1), grad_at(p0 + 2, 1), grad_at(p0 + 3, 1));
         if (addend) {
           const float4 ax = *reinterpret_cast<const float4*>(addend + o), ay = *reinterpret_cast<const float4*>(addend + hw + o);
           gx.x += ax.x, gx.y += ax.y, gx.z += ax.z, gx.w += ax.w;
@@ -1867,8 +2004,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     if (r < H && c < W) {
       const int64_t o = (int64_t)r * W + c;
       // addend: gradient of the flow regularisers, summed here instead of in a separate pass over [2, H, W]
-      d_flow[o] = (float)s_d[i] + (addend ? addend[o] : 0.0f);
-      d_flow[hw + o] = (float)s_d[TH * TW + i] + (addend ? addend[hw + o] : 0.0f);
+      d_flow[o] = grad_at(i, 0) + (addend ? addend[o] : 0.0f);
+      d_flow[hw + o] = grad_at(i, 1) + (addend ? addend[hw + o] : 0.0f);
     }
   }
   EBOS_STAMP_BWD(5);

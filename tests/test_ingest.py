@@ -111,7 +111,9 @@ def test_deferred_plan_equals_synchronous_plan():
     f1, f2 = flow.clone().requires_grad_(True), flow.clone().requires_grad_(True)
     lazy.contrast_dense(f1).backward()
     sync.contrast_dense(f2).backward()
-    assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 1e-6
+    # (two builds order the events inside a source pixel differently: the backward kernel's runs, each rounded to the fixed-point
+    # unit of its tile, group differently)
+    assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 2e-5
     with pytest.raises(NotImplementedError):  # per-event weights need the exact event count of a synchronous build
         lazy.iwe_dense(flow, weight=torch.ones(30000, device="cuda"))
     # a float plan with fractional coordinates cannot be deferred
@@ -206,7 +208,13 @@ def test_lean_plan_is_the_compact_part_of_the_full_plan(case):
     f1, f2 = flow.clone().requires_grad_(True), flow.clone().requires_grad_(True)
     lean.contrast_dense(f1, halo=halo).backward()
     full.contrast_dense(f2, halo=halo).backward()
-    assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 1e-6
+    # (two builds order the events inside a source pixel differently, so the backward kernel's runs -- each rounded to the
+    # fixed-point unit of its tile -- group differently; ONE plan evaluated twice gives the same bits: integer scatter)
+    assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 2e-5
+    if case != "skew":
+        f3 = flow.clone().requires_grad_(True)
+        lean.contrast_dense(f3, halo=halo).backward()
+        assert torch.equal(f1.grad, f3.grad)
     th = torch.tensor([[2.5, -4.0]], device="cuda")
     assert O.rel_l2(lean.iwe_2dof(th, halo=halo).cpu().numpy(), full.iwe_2dof(th, halo=halo).cpu().numpy()) < (
         1e-30 if (one_item_per_tile and case != "skew") else 1e-6)
