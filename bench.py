@@ -69,7 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="launch + rendezvous + shard assignment + gather only (gloo, CPU, no kernels)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much timed work")
-    ap.add_argument("--max-repeats", type=int, default=400)
+    ap.add_argument("--max-repeats", type=int, default=100000,
+                    help="cap on timed blocks (the default never binds: --min-seconds decides, also under the driver's --steps 20)")
     ap.add_argument("--events", type=int, default=None, help="events per window (default: the config's)")
     ap.add_argument("--windows", type=int, default=None, help="config 4: number of windows (default 64)")
     ap.add_argument("--tile", type=int, nargs=2, default=[0, 0], help="source tile (0 0 = choose_tile: 45x80 at 1280x720)")
@@ -126,15 +127,33 @@ def shard_for(config, rank, world, args):
     return [rank]
 
 
+RENDEZVOUS_TIMEOUT_S = 120  # a rank that cannot reach the others says so within two minutes instead of hanging the driver's run
+
+
+def init_group(backend, rank, world, device=None):
+    """torch.distributed rendezvous with a bounded wait and a one-line diagnosis."""
+    import datetime
+
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S), **kw)
+    except Exception as e:  # (DistStoreError / DistNetworkError / RuntimeError: all mean "the ranks did not meet")
+        raise SystemExit(f"rank {rank}/{world}: {backend} rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} "
+                         f"failed within {RENDEZVOUS_TIMEOUT_S} s: {type(e).__name__}: {e}")
+    return dist
+
+
 def dry_run(args):
     """The N-rank plumbing without a GPU: rendezvous (gloo), shard assignment, barrier, MAX-reduce, object gather."""
     import torch
-    import torch.distributed as dist
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist = init_group("gloo", rank, world)
     mine = shard_for(args.config, rank, world, args)
     seen = [{"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", 0)), "units": len(mine), "first_units": mine[:4]}]
     t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
@@ -217,6 +236,59 @@ def rocprof_stats(kernel_prefix, ends="false>"):
     return best
 
 
+# The roofline that BINDS the event kernels is instruction issue, not HBM: VALU issue per SIMD and the LDS
+# pipe per CU.  Instruction counts per launch come from the committed PMC collection of the same kernel source
+# (profiles/pmc_latest.json: SQ_INSTS_VALU / SQ_INSTS_LDS, wave-instructions summed over the chip, collected at THIS workload's
+# size); what an instruction costs from the micro-benchmarks (tools/ubench_valu_issue.hip, tools/ubench_lds.hip ->
+# profiles/r02_valu_issue_cost.txt, r02_lds_cost_and_phases.txt): with the kernels' 4 waves per SIMD a VALU wave-instruction of
+# their mix occupies its SIMD for ~3.2 cycles (2.1 v_sub_u32 ... 3.4 v_cndmask, 4.9 v_cmp -> SGPR pair), an LDS wave-instruction
+# the CU's LDS pipe for ~8.6 (ds_add_u64, random cells) ... 15.5 (neighbouring lanes on adjacent cells); reads 6.5 - 13.8.
+ISSUE = {"n_cu": 256, "simd_per_cu": 4, "valu_cycles_per_wave_inst": 3.2, "lds_cycles_per_wave_inst": 10.0,
+         "source": "tools/ubench_valu_issue.hip, tools/ubench_lds.hip (profiles/r02_valu_issue_cost.txt, r02_lds_cost_and_phases.txt)"}
+
+
+def roofline_issue(kernel_key, kernel_ms_list, clock_hz, events=None):
+    """`roofline_issue`: the time the kernel's VALU and LDS instruction streams need at the measured issue costs, against the
+    measured kernel time.  frac = max(valu, lds) bound / measured <= 1; null counts when the PMC collection is stale or absent."""
+    k_ms = statistics.mean(kernel_ms_list) if kernel_ms_list else float("nan")
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    ent = {"kernel": kernel_key, "kernel_ms": round(k_ms, 4), "clock_GHz": round(clock_hz / 1e9, 3), **ISSUE}
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        ent["note"] = "profiles/pmc_latest.json missing"
+        return ent
+    if rec.get("source_blob_sha") != git_blob_sha(os.path.join(ROOT, DOMINANT_SOURCE)):
+        ent["note"] = f"stale: counters collected on blob {rec.get('source_blob_sha')}"
+        return ent
+    k = rec.get("kernels", {}).get(kernel_key, {})
+    valu, lds = k.get("SQ_INSTS_VALU"), k.get("SQ_INSTS_LDS")
+    if valu is None or lds is None:
+        ent["note"] = f"no instruction counters for {kernel_key} in profiles/pmc_latest.json"
+        return ent
+    t_valu = valu / (ISSUE["n_cu"] * ISSUE["simd_per_cu"]) * ISSUE["valu_cycles_per_wave_inst"] / clock_hz * 1e3  # ms
+    t_lds = lds / ISSUE["n_cu"] * ISSUE["lds_cycles_per_wave_inst"] / clock_hz * 1e3
+    bound = "valu_issue" if t_valu >= t_lds else "lds_pipe"
+    ent.update({"bound": bound, "valu_wave_insts": valu, "lds_wave_insts": lds, "valu_bound_ms": round(t_valu, 4),
+                "lds_bound_ms": round(t_lds, 4), "frac": round(max(t_valu, t_lds) / k_ms, 4),
+                "counters_collected_at_events": k.get("events"), "traffic_commit": rec.get("commit")})
+    if events:
+        ent["valu_wave_insts_per_event"] = round(valu / events, 5)  # (x 64 lanes / 64 events per wave: also VALU instructions per event)
+        ent["lds_wave_insts_per_event"] = round(lds / events, 5)
+    return ent
+
+
+def device_clock_hz(dev):
+    """shader clock the issue bound is priced at: the device's maximum engine clock (a LOWER bound of the time: the chip rarely
+    holds it under load, which can only make `roofline_issue.frac` smaller than the truth)"""
+    import torch
+
+    try:
+        return float(torch.cuda.get_device_properties(dev).clock_rate) * 1e3  # kHz -> Hz
+    except Exception:
+        return 2.4e9
+
+
 def cpu_baseline(ev, flow, sample):
     """The oracle's op-for-op torch-CPU restatement of the reference path (kind 'port'), timed on this
     host's cores on a bounded sample of the same window."""
@@ -283,19 +355,12 @@ class Rank(object):
         self.distributed = self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun also for a world of 1
         index = 0
         if self.distributed:
-            import torch.distributed as dist
-
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             n_dev = torch.cuda.device_count()
             if args.backend == "nccl" and self.local_rank >= n_dev:
                 raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but {n_dev} GPU(s) visible (one GPU per rank with nccl)")
             index = self.local_rank % max(n_dev, 1)
             torch.cuda.set_device(index)
-            if args.backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", index))
-            else:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            self.dist = dist
+            self.dist = init_group(args.backend, self.rank, self.world, torch.device("cuda", index))
         else:
             torch.cuda.set_device(0)
         self.dev = torch.device("cuda", index)
@@ -409,6 +474,7 @@ def run_config2(R):
     a, dev, rank, world = R.args, R.dev, R.rank, R.world
     lib = _hip.require_gpu()
     n = a.events or N_EVENTS
+    t_ingest = time.perf_counter()
     ev, flow_np = synth_window(n, seed=rank, flow_max=a.flow_max)
     ev_gpu = torch.from_numpy(ev).to(dev)
     flow = torch.from_numpy(flow_np).float().to(dev)
@@ -431,6 +497,7 @@ def run_config2(R):
 
     _, _, plan_build_full_ms = time_build("full")
     plan, plan_first_ms, plan_build_ms = time_build("full" if a.no_compact else "compact")
+    ingest_s = time.perf_counter() - t_ingest  # host synthesis + upload + the timed plan builds: what a rank spends before its first step
     del ev_gpu
     a.halo_code = ebos.event_plan.resolve_halo(plan, a.halo)  # an int for the C ABI ('auto' -> EBOS_HALO_AUTO(32, 64 max|dt|))
 
@@ -461,10 +528,13 @@ def run_config2(R):
     elapsed = statistics.median(blocks)
     contrast = float(out.item())
     ranks_seen = R.gather({"rank": rank, "local_rank": R.local_rank, "device": torch.cuda.get_device_name(dev),
-                           "events": plan.n, "contrast": contrast})
+                           "events": plan.n, "contrast": contrast, "ingest_s": round(ingest_s, 2)})
 
     extras = {}
-    if not a.no_extras:
+    # The informative legs (fwd + bwd, streams, rotating windows, solver iteration) run on rank 0 ONLY in an N-rank job: eight ranks
+    # each synthesising eight more 10 M-event windows on the host, inside the driver's timeout, buy nothing -- `value` is measured
+    # above, by every rank, and the other ranks wait at the final barrier.
+    if not a.no_extras and (world == 1 or rank == 0):
         # (1) combine pass of the same step, timed the same way (outside `value`'s blocks)
         _hip.check(lib.ebos_profile_start_kernel(_hip.PROFILE_SLAB_COMBINE, 100), "profile")
         for _ in range(100):
@@ -640,6 +710,23 @@ def run_config2(R):
                       + f", binned by source tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}, splits {a.splits}",
             "parallelism": f"windows sharded, {world} rank(s), no collective"})
         line["roofline"] = roof
+        clock = device_clock_hz(dev)
+        dyn = a.halo == "auto"
+        line["roofline_issue"] = roofline_issue("iwe_slab_accumulate_kernel<DENSE,DYN>" if dyn else "iwe_slab_accumulate_kernel",
+                                                kernel_ms, clock, plan.n)
+        if "roofline_bwd" in extras:
+            extras["roofline_bwd_issue"] = roofline_issue("iwe_dense_tiled_bwd_kernel<DENSE,DYN>" if dyn else "iwe_dense_tiled_bwd_kernel",
+                                                          [extras["roofline_bwd"]["kernel_ms"]], clock, plan.n)
+        # the fractions side by side: what each one prices and what it says
+        line["roofline_summary"] = {
+            "hbm_algorithmic_frac": roof["frac"],                       # SURVEY 8(d) bytes (12 B/event + 12 H W) / kernel time / 8 TB/s
+            "hbm_plan_format_frac": round(roof["plan_format_GBps"] / HBM_PEAK_GBS, 4),   # the 6 B/event the compact plan really streams
+            "hbm_counter_traffic_frac": (round(roof["traffic"] / (roof["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                         if roof.get("traffic") else None),              # FETCH / WRITE counters of the same source
+            "hbm_step_frac": roof["step_frac"],                         # the WHOLE step (accumulate + combine + finalize) on the same bytes
+            "hbm_rotating_windows_frac": roof.get("frac_rotating_windows"),              # plans cycled beyond the Infinity Cache
+            "issue_frac": line["roofline_issue"].get("frac"),           # what binds: VALU issue / LDS pipe (roofline_issue)
+            "binding": line["roofline_issue"].get("bound", "unknown (no counters for this kernel source)")}
         line["ranks_seen"] = ranks_seen
         line["plan_build_ms"] = round(plan_build_ms, 3)
         line["plan_build_kind"] = "lean (emit='compact': compact events + offsets only)" if plan.lean else "full (SoA + perm + compact)"
@@ -797,7 +884,7 @@ def run_config4(R):
     kernel_ms = [buf[i] for i in range(got)]
     res = {int(wi): float(v) for wi, v in zip(mine, outs[:len(mine)].tolist())}
     seen = R.gather({"rank": rank, "local_rank": R.local_rank, "device": torch.cuda.get_device_name(dev),
-                     "windows": len(mine), "events": int(sum(p.n for p in plans)), "contrasts": res})
+                     "windows": len(mine), "events": int(sum(p.n for p in plans)), "contrasts": res, "ingest_s": round(ingest_s, 2)})
     if rank == 0:
         total_events = n * n_windows
         ms_per_step = elapsed / a.steps * 1e3
@@ -810,7 +897,10 @@ def run_config4(R):
             "windows_total": n_windows, "events_per_window": n, "height": H, "width": W,
             "layout": f"compact SoA 6 B/event, tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}; flow sampled from the patch grid per tile",
             "parallelism": f"windows round-robin over {world} rank(s) (bos_event.py:144-220), no collective"})
-        line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<GRID>", kernel_ms, algo,
+        dyn = a.halo == "auto"
+        line["roofline_issue"] = roofline_issue("iwe_slab_accumulate_kernel<GRID,DYN>" if dyn else "iwe_slab_accumulate_kernel<GRID>",
+                                                kernel_ms, device_clock_hz(dev), n)
+        line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<GRID,DYN>" if dyn else "iwe_slab_accumulate_kernel<GRID>", kernel_ms, algo,
                                           {"note": "kernel timed on one stream, back to back",
                                            "ms_per_window_in_step": round(ms_per_step / max(len(mine), 1), 5), "streams": n_lanes,
                                            **format_rate(6.0 * n + 4.0 * H * W + 8.0 * gh * gw, kernel_ms)})
@@ -847,8 +937,8 @@ def run_config5(R):
     mine = shard_for(5, rank, world, a)
     if a.tile[0] <= 0:
         a.tile = list(ebos.event_plan.choose_tile((H, W), 32 if a.halo == 'auto' else a.halo))
+    t0 = time.perf_counter()  # (ingest = host synthesis of the window + upload + plan build: what a rank spends before its first step)
     ev, _ = synth_window(n, seed=0, flow=False)  # the SAME window on every rank
-    t0 = time.perf_counter()
     plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact")
     torch.cuda.synchronize()
     ingest_s = time.perf_counter() - t0
@@ -873,7 +963,7 @@ def run_config5(R):
     got = lib.ebos_profile_stop(buf, nrec)
     kernel_ms = [buf[i] for i in range(got)]
     seen = R.gather({"rank": rank, "local_rank": R.local_rank, "device": torch.cuda.get_device_name(dev),
-                     "hypotheses": len(mine), "events": plan.n,
+                     "hypotheses": len(mine), "events": plan.n, "ingest_s": round(ingest_s, 2),
                      "variances": {int(k): float(x) for k, x in zip(mine, v)}})
     if rank == 0:
         K = grid.shape[0]
@@ -887,10 +977,24 @@ def run_config5(R):
             "layout": f"compact SoA 6 B/event, tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}; event window replicated per rank",
             "parallelism": f"hypotheses in contiguous blocks over {world} rank(s) (generative_max_likelihood.py:229-236), no collective"})
         line["unit_note"] = "Mevents/s counts event-warps: every hypothesis warps and splats every event"
-        line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<UNIFORM>", kernel_ms, algo,
+        dyn = a.halo == "auto"
+        key5 = "iwe_slab_accumulate_kernel<UNIFORM,DYN>" if dyn else "iwe_slab_accumulate_kernel<UNIFORM>"
+        line["roofline"] = roofline_entry(key5, kernel_ms, algo,
                                           {"note": "kernel timed on one stream, back to back (the timed sweep overlaps three)",
                                            "ms_per_hypothesis_in_sweep": round(ms_per_step / max(len(mine), 1), 5),
                                            **format_rate(6.0 * plan.n + 4.0 * H * W, kernel_ms)})
+        # SURVEY 8(d) prices config 5 per pass of K hypotheses: 16 B/event ONCE per K + 4 H W K B of images.  The tile-private path
+        # re-streams the plan once per hypothesis; on that accounting (K = 64, one rank's block of the 8-GPU job) it moves
+        k_pass = 64
+        per_pass = 16.0 * plan.n + 4.0 * H * W * k_pass
+        k_ms_mean = statistics.mean(kernel_ms) if kernel_ms else float("nan")
+        line["roofline"]["per_pass_of_K"] = {"K": k_pass, "algorithmic_bytes_per_pass": per_pass,
+                                             "achieved": round(per_pass / (k_pass * k_ms_mean * 1e-3) / 1e9, 1),
+                                             "frac": round(per_pass / (k_pass * k_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "note": "SURVEY 8(d): 16 B/event per pass of K hypotheses + 4 H W K; the kernel is instruction-bound "
+                                                     "(roofline_issue), K hypotheses per event read would save the shared decode only: "
+                                                     "profiles/r03_multi_hypothesis_ablation.txt"}
+        line["roofline_issue"] = roofline_issue(key5, kernel_ms, device_clock_hz(dev), plan.n)
         line["ranks_seen"] = [{k: x for k, x in s.items() if k != "variances"} for s in seen]
         merged = {}
         for s in seen:

@@ -103,6 +103,42 @@ def test_bench_gpus_flag_launches_the_ranks_itself(config, total, per_rank):
     assert abs(line["max_over_ranks_check"] - 0.002) < 1e-12  # the MAX over ranks took rank 1's value
 
 
+@pytest.mark.parametrize("config,total", [(2, 8), (4, 64), (5, 512)])
+def test_bench_eight_ranks_dry_run(config, total):
+    """The job the driver runs for SCALE_rNN.json -- `bench.py --gpus 8` -- through the launcher, the bounded rendezvous, the shard
+    assignment of SURVEY 8(e), the barrier, the MAX over ranks and the gather, on gloo: eight ranks seen, every unit owned by
+    exactly one of them (config 4: windows i -> rank i mod 8; config 5: contiguous blocks of 64 hypotheses)."""
+    from event_based_bos_amd.sharding import shard_units
+
+    line = _bench("--gpus", "8", "--config", str(config), "--dry-run")
+    seen = sorted(line["ranks_seen"], key=lambda s: s["rank"])
+    assert line["n_gpus"] == 8 and [s["rank"] for s in seen] == list(range(8)) and [s["local_rank"] for s in seen] == list(range(8))
+    assert line["units_total"] == total and abs(line["max_over_ranks_check"] - 0.008) < 1e-12
+    owned = []
+    for r in range(8):
+        units = [r] if config == 2 else shard_units(total, 8, r, "round_robin" if config == 4 else "block")
+        assert seen[r]["units"] == len(units) and seen[r]["first_units"] == list(units[:4])
+        owned += list(units)
+    assert sorted(owned) == list(range(total))  # a partition: nothing dropped, nothing done twice
+
+
+def test_bench_rendezvous_failure_is_a_one_line_exit(monkeypatch):
+    """A rank that cannot meet the others must say so (rank, backend, address, reason) and exit -- not hang the driver's run."""
+    import importlib.util
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "RENDEZVOUS_TIMEOUT_S", 2)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))  # nobody listens there and rank 1 does not host the store
+    with pytest.raises(SystemExit) as e:
+        bench.init_group("gloo", 1, 2)
+    assert "rendezvous" in str(e.value) and "rank 1/2" in str(e.value)
+
+
 def test_bench_single_rank_needs_no_launcher():
     line = _bench("--dry-run")
     assert line["n_gpus"] == 1 and [s["rank"] for s in line["ranks_seen"]] == [0] and line["steps"] == 200 and line["warmup"] == 20

@@ -13,6 +13,7 @@ from bench import H, W, synth_window
 ap = argparse.ArgumentParser()
 ap.add_argument("--events", type=int, default=2_000_000)
 ap.add_argument("--dense", action="store_true", help="the dense-field backward kernel (plan.variance_and_grad_dense) instead of the solver loop's")
+ap.add_argument("--halo", type=lambda v: v if v == "auto" else int(v), default=32)
 a = ap.parse_args()
 lib = _hip.require_gpu()
 raw = ctypes.CDLL(os.environ.get("EBOS_HIP_LIBRARY", _hip.LIB_PATH))
@@ -21,7 +22,7 @@ plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, 
 if a.dense:
     flow = torch.from_numpy(synth_window(16, 0)[1]).float().cuda()
     for _ in range(5):
-        plan.variance_and_grad_dense(flow)
+        plan.variance_and_grad_dense(flow, halo=a.halo)
     torch.cuda.synchronize()
     n = 256
     buf = (ctypes.c_ulonglong * (n * 8))()
@@ -34,7 +35,7 @@ if a.dense:
         print(f"  {nm:40s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
     sys.exit(0)
 gh, gw = ebos.solver.patch_grid_shape((H, W), (24, 32), (24, 32))
-loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, lr=0.1, capacity=64)
+loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, lr=0.1, capacity=64, halo=a.halo)
 loop.run(40)
 torch.cuda.synchronize()
 n = 256
