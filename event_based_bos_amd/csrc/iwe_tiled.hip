@@ -427,6 +427,17 @@ struct ChunkQueue {
   }
 };
 
+// Ablation build (-DEBOS_ABL_MULTIK=K, results wrong on purpose): every event is warped and accumulated K times with K different
+// translations into the SAME image -- what K hypotheses per event read would cost per hypothesis if the K images were free
+// (tools/ab_multik.sh, profiles/r03_multi_hypothesis_ablation.txt).
+#ifdef EBOS_ABL_MULTIK
+#define EBOS_KLOOP for (int kk = 0; kk < EBOS_ABL_MULTIK; ++kk)
+#define EBOS_KOFF(v, s) ((v) + (s) * (float)kk)
+#else
+#define EBOS_KLOOP
+#define EBOS_KOFF(v, s) (v)
+#endif
+
 // MODE == ACC_F64: the same loop with four ds_add_f64 per event -- the exact redo of a slice whose fixed-point fields
 // overflowed (hot pixels, or a flow that piles thousands of events onto one cell).
 template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false, bool DYN = false>
@@ -499,8 +510,8 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
     load_cgroup_q(nn, tr.g_first + c_nn * kWave + lane, tr, ev, hc4);
     const bool lane_live = grp <= g_last;  // the last chunk of the slice may be partial
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float lx = -cur.dt[e] * fu[e], ly = -cur.dt[e] * fv[e];  // source coordinates are integers: x' = rs + lx
+    for (int e = 0; e < 4; ++e) EBOS_KLOOP {
+      const float lx = -cur.dt[e] * EBOS_KOFF(fu[e], 0.37f), ly = -cur.dt[e] * EBOS_KOFF(fv[e], -0.21f);  // source coordinates are integers: x' = rs + lx
       const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
       const float fr = fmaxf(lx - r0, 0.0f), fc = fmaxf(ly - c0, 0.0f);
       // row of the LDS window, and 4 x its column (= byte offset of the column's f32 / half the offset of its pair word)
@@ -845,7 +856,11 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
     }
     // sum(added) == sum(decoded) over the workgroup  <=>  sum(added - decoded) == 0 modulo 2^64: one value per lane, one DPP wave
     // sum, one LDS atomic per wave, one barrier (two values, shuffles, a serial 32-term loop and two barriers before)
+#ifdef EBOS_ABL_MULTIK
+    const unsigned long long diff = 0ull * wave_sum(added - decoded);  // (ablation: K x the units, no redo)
+#else
     const unsigned long long diff = wave_sum(added - decoded);
+#endif
     if ((threadIdx.x & (kWave - 1)) == 0 && diff != 0ull) atomicAdd(&sh.chk, diff);
     __syncthreads();
     if (sh.chk != 0ull) {  // a field wrapped: redo this slice exactly in f64 and overwrite the slab (spill taps already issued)
