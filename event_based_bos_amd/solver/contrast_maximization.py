@@ -95,8 +95,10 @@ class ContrastMaximizationMixin(object):
         self.scipy_options = dict(ocfg.get("options") or {})
         self.refine_iters = int(ocfg.get("refine_iters", 0))  # 2-DoF models: Adam steps after the grid sweep
         self.param_ranges = cfg.get("parameters") or {}  # {name: {min, max}} or the reference's list of names (_param_range)
-        # "auto": run-time LDS windows per tile (event_plan.resolve_halo), bounded by the largest built halo
-        self.halo = "auto" if cfg.get("halo", 32) == "auto" else int(cfg.get("halo", 32))
+        # solver.halo: "auto" (default) = run-time LDS windows per tile (event_plan.resolve_halo: each work item sizes its window
+        # from a bound on its own displacements; BOS flows are a few pixels), bounded by the largest built halo; an integer
+        # = that built halo for every tile.  Either way displacements beyond a window are handled exactly (spill path).
+        self.halo = "auto" if cfg.get("halo", "auto") == "auto" else int(cfg.get("halo"))
         # optimizer.graph: capture one whole iteration (upsample -> fused objective -> backward -> Adam update) into a
         # HIP graph and replay it.  Measured on MI355X / ROCm 7.2 (tools/bench_solver.py, 2 M events at 1280x720):
         # 0.195 ms per replayed iteration against 0.68 ms for the eager loop (interpreter + autograd overhead around

@@ -187,23 +187,24 @@ def test_config4_batched_windows_full_size(setup):
     evs = [O.synth_events(n, H, W, seed=300 + k) for k, n in enumerate(sizes)]
     plans = [ebos.EventPlan.build(torch.from_numpy(e).to(dev), (H, W), "first", True, tile="auto", emit="compact") for e in evs]
     grids = [torch.from_numpy(rs.uniform(-30, 30, (2, 30, 40))).float().to(dev) for _ in sizes]
-    for splits in (None, 1):  # the plans' own work-item mode (adaptive), then one workgroup per tile
-        batch = ebos.SlabBatch(plans, grids, patch=((24, 32), (24, 32)), splits=splits)
+    for splits, halo in ((None, 32), (1, 32), (None, "auto"), (1, "auto")):  # adaptive work items / one workgroup per tile; built halo / run-time windows
+        batch = ebos.SlabBatch(plans, grids, patch=((24, 32), (24, 32)), splits=splits, halo=halo)
         var = batch.run(tail_stream=torch.cuda.Stream(device=dev).cuda_stream).cpu().numpy()
         torch.cuda.synchronize()
         th, tw = plans[0].tile
-        nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, th, tw, 32, batch.splits, 0, 0))
+        hcode = batch.halo
+        nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, th, tw, hcode, batch.splits, 0, 0))
         ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
         iwe = torch.empty((H, W), dtype=torch.float32, device=dev)
         out = torch.empty(1, dtype=torch.float32, device=dev)
         mom = torch.empty((1, 2), dtype=torch.float64, device=dev)
         P = lambda t: None if t is None else t.data_ptr()
         for k, (pl, g) in enumerate(zip(plans, grids)):
-            _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), 30, 40, 24, 32, 24, 32, H, W, th, tw, 32,
+            _hip.check(lib.ebos_iwe_patch_slab_f32(*pl._compact_ptrs(), P(pl.key_offsets), pl.n, P(g), 30, 40, 24, 32, 24, 32, H, W, th, tw, hcode,
                                                    batch.splits, 0, 0, P(ws), nws, P(iwe), 1, 0, P(out), P(mom),
                                                    P(pl.part_table) if batch.splits == 0 else None, _hip.stream_ptr()), "ebos_iwe_patch_slab")
-            assert torch.equal(iwe, batch.iwes[k]), (splits, k)
-            assert out.item() == var[k], (splits, k)
+            assert torch.equal(iwe, batch.iwes[k]), (splits, halo, k)
+            assert out.item() == var[k], (splits, halo, k)
     dense = O.upsample_patch_flow(grids[0].cpu().double(), (H, W), (24, 32), (24, 32))
     ref = O.iwe_dense(torch.from_numpy(evs[0]), dense, (H, W))
     rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
