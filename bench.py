@@ -423,13 +423,14 @@ class Rank(object):
         return blocks, kernel_ms
 
 
-def format_rate(format_bytes, kernel_ms_list):
-    """The bytes the compact plan format actually streams per launch (6 B/event, not the 12 B/event of SURVEY 8(d) that
-    `achieved` is priced on): `frac` may exceed 1 on a kernel with no flow gathers -- that is the format's 2x, not bandwidth."""
+def survey_priced(survey_bytes, kernel_ms_list):
+    """Configs 4 / 5 price `roofline.achieved` on the bytes the launch's inputs and outputs OCCUPY (the compact plan: 6 B/event,
+    DESIGN 3) -- SURVEY 8(d)'s 12 B/event (x, y, dt as three floats) would put a kernel with no flow gathers above the HBM peak (1.14
+    in round 2): that is the format's 2x, not bandwidth.  The SURVEY-priced figure is kept here, labelled."""
     k_ms = statistics.fmean(kernel_ms_list) if kernel_ms_list else float("nan")
-    gbs = format_bytes / (k_ms * 1e-3) / 1e9
-    return {"plan_format_bytes": format_bytes, "plan_format_GBps": round(gbs, 1), "plan_format_frac": round(gbs / HBM_PEAK_GBS, 4),
-            "frac_note": "achieved/frac price SURVEY 8(d)'s 12 B/event; the plan stores 6 B/event, plan_format_* is the real stream"}
+    gbs = survey_bytes / (k_ms * 1e-3) / 1e9
+    return {"survey_priced": {"bytes": survey_bytes, "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                              "note": "SURVEY 8(d): 12 B/event (p unused); exceeds what the kernel moves, may exceed 1"}}
 
 
 def roofline_entry(kernel, kernel_ms_list, algo_bytes, extra=None):
@@ -889,7 +890,7 @@ def run_config4(R):
         total_events = n * n_windows
         ms_per_step = elapsed / a.steps * 1e3
         value = total_events * a.steps / elapsed / 1e6
-        algo = 12.0 * n + 4.0 * H * W + 8.0 * gh * gw  # per launch: events + IWE write + the patch grid (no dense flow field)
+        algo = 6.0 * n + 4.0 * H * W + 8.0 * gh * gw  # per launch: compact events (6 B) + IWE write + the patch grid (no dense flow field)
         line = base_line(R, value, ms_per_step, blocks, "strong", {
             "workload": (f"BASELINE configs[3]: {n_windows} time windows x {n} events, {gh}x{gw} patch-flow grid "
                          f"(patch {ph}x{pw}, slide {sh}x{sw}) -> 1280x720, variance cost, fwd objective per window"
@@ -903,7 +904,7 @@ def run_config4(R):
         line["roofline"] = roofline_entry("iwe_slab_accumulate_kernel<GRID,DYN>" if dyn else "iwe_slab_accumulate_kernel<GRID>", kernel_ms, algo,
                                           {"note": "kernel timed on one stream, back to back",
                                            "ms_per_window_in_step": round(ms_per_step / max(len(mine), 1), 5), "streams": n_lanes,
-                                           **format_rate(6.0 * n + 4.0 * H * W + 8.0 * gh * gw, kernel_ms)})
+                                           **survey_priced(12.0 * n + 4.0 * H * W + 8.0 * gh * gw, kernel_ms)})
         line["ranks_seen"] = [{k: v for k, v in s.items() if k != "contrasts"} for s in seen]
         merged = {}
         for s in seen:
@@ -969,7 +970,7 @@ def run_config5(R):
         K = grid.shape[0]
         ms_per_step = elapsed / a.steps * 1e3
         value = float(n) * K * a.steps / elapsed / 1e6  # event-warps per second, whole job
-        algo = 12.0 * plan.n + 4.0 * H * W  # per hypothesis launch: events + IWE write (theta is two floats)
+        algo = 6.0 * plan.n + 4.0 * H * W  # per hypothesis launch: compact events (6 B) + IWE write (theta is two floats)
         line = base_line(R, value, ms_per_step, blocks, "strong", {
             "workload": f"BASELINE configs[4]: {K}-hypothesis 2-DoF flow sweep ({g0}x{g1} grid over [-{tm:g},{tm:g})^2) over {n} events, "
                         "1280x720, variance cost per hypothesis",
@@ -982,7 +983,7 @@ def run_config5(R):
         line["roofline"] = roofline_entry(key5, kernel_ms, algo,
                                           {"note": "kernel timed on one stream, back to back (the timed sweep overlaps three)",
                                            "ms_per_hypothesis_in_sweep": round(ms_per_step / max(len(mine), 1), 5),
-                                           **format_rate(6.0 * plan.n + 4.0 * H * W, kernel_ms)})
+                                           **survey_priced(12.0 * plan.n + 4.0 * H * W, kernel_ms)})
         # SURVEY 8(d) prices config 5 per pass of K hypotheses: 16 B/event ONCE per K + 4 H W K B of images.  The tile-private path
         # re-streams the plan once per hypothesis; on that accounting (K = 64, one rank's block of the 8-GPU job) it moves
         k_pass = 64
