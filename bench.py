@@ -228,8 +228,9 @@ def rocprof_stats(kernel_prefix, ends="false>"):
         return None
     best = None
     for name, k in rec.get("kernels", {}).items():
-        # (`ends`: the last template flag -- GRID -- is false for the dense-flow instantiations the roofline entries are about)
-        if name.startswith(kernel_prefix) and name.endswith(ends) and (best is None or k["calls"] > best["calls"]):
+        # the dense-flow instantiation with a built halo: its trailing template flags (UNIFORM, GRID, DYN -- or GRID, DYN for the
+        # backward kernel's tail) are all false
+        if name.startswith(kernel_prefix) and name.endswith("false, false, false>") and (best is None or k["calls"] > best["calls"]):
             best = dict(k, kernel=name)
     if best is not None:
         best["commit"] = rec.get("commit")
