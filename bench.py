@@ -274,8 +274,8 @@ def roofline_issue(kernel_key, kernel_ms_list, clock_hz, events=None):
                 "lds_bound_ms": round(t_lds, 4), "frac": round(max(t_valu, t_lds) / k_ms, 4),
                 "counters_collected_at_events": k.get("events"), "traffic_commit": rec.get("commit")})
     if events:
-        ent["valu_wave_insts_per_event"] = round(valu / events, 5)  # (x 64 lanes / 64 events per wave: also VALU instructions per event)
-        ent["lds_wave_insts_per_event"] = round(lds / events, 5)
+        ent["valu_insts_per_event"] = round(valu * 64.0 / events, 2)  # a wave-instruction serves 64 lanes, a lane its own events
+        ent["lds_insts_per_event"] = round(lds * 64.0 / events, 2)
     return ent
 
 
