@@ -64,6 +64,26 @@ def test_host_only_entry_points(lib):
     assert rc == -1
 
 
+def test_run_time_window_halo_code(lib):
+    """EBOS_HALO_AUTO (include/ebos_hip.h): the `halo` arguments take -(max_halo + 256 q) with q = ceil(64 max |dt|), the bound
+    ROUNDED UP; host-only entry points decode it to the built halo that sizes the workspace -- usable without a GPU."""
+    from event_based_bos_amd import event_plan
+
+    assert lib.ebos_halo_auto(32, 1.0) == -(32 + 256 * 64)
+    assert lib.ebos_halo_auto(32, 0.5) == -(32 + 256 * 32) and lib.ebos_halo_auto(16, 2.0) == -(16 + 256 * 128)
+    assert lib.ebos_halo_auto(32, 0.501) == -(32 + 256 * 33)            # never below the bound
+    assert lib.ebos_halo_auto(32, 1e-9) == -(32 + 256 * 1)              # at least one unit
+    assert lib.ebos_halo_auto(32, -1.0) == 32 and lib.ebos_halo_auto(0, 1.0) == 0 and lib.ebos_halo_auto(300, 1.0) == 300  # no auto
+    built = lib.ebos_iwe_slab_workspace_bytes(720, 1280, 45, 80, 32, 1, 0, 0)
+    assert built > 0 and lib.ebos_iwe_slab_workspace_bytes(720, 1280, 45, 80, lib.ebos_halo_auto(32, 1.0), 1, 0, 0) == built
+    assert lib.ebos_patch_fused_supported(45, 80, lib.ebos_halo_auto(32, 1.0), 24, 32) == lib.ebos_patch_fused_supported(45, 80, 32, 24, 32)
+    # max |dt| as the host knows it: dt = (t - t_ref) / (t_max - t_min) in [-f, 1 - f] for a reference time at fraction f (src/warp.py:245-253, 283-287)
+    for direction, want in (("first", 1.0), ("last", 1.0), ("middle", 0.5), (0.25, 0.75), ("before", 2.0), ("after", 2.0)):
+        assert event_plan.dt_bound_for(direction, True) == want
+    assert event_plan.dt_bound_for("first", False) is None               # seconds: the window's length is not known on the host
+    assert event_plan._max_halo(-(32 + 256 * 64)) == 32 and event_plan._max_halo(16) == 16
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
 def test_no_cpu_fallback():
     import event_based_bos_amd as ebos
