@@ -438,9 +438,17 @@ struct ChunkQueue {
 #define EBOS_KOFF(v, s) (v)
 #endif
 
+// lane l of chunk c takes group 64 c + l (plain mapping: one group of 4 events per lane, chunks of 64 groups)
+__device__ __forceinline__ int32_t chunk_group(int32_t g_first, int c, int lane) { return g_first + c * kWave + lane; }
+
 // MODE == ACC_F64: the same loop with four ds_add_f64 per event -- the exact redo of a slice whose fixed-point fields
 // overflowed (hot pixels, or a flow that piles thousands of events onto one cell).
-template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false, bool DYN = false>
+// PAIRS: lane l of a chunk of 128 groups takes groups 2 l and 2 l + 1, one per loop step, instead of group l of a chunk of 64.  With
+// pixel-sorted events and ~11 events per source pixel the lanes of ONE wave instruction then hold events of different pixels, and
+// their ds_add_u64 no longer meet on the same words: SQ_LDS_ADDR_CONFLICT per launch is 0.33 M at 30 px flows but 2.3 M at 6 px,
+// 4.8 M at 2 px and 5.8 M at 0.5 px with the plain mapping -- the loop ran 18.5 / 22.0 / 27.7 / 30.4 us; BOS flows are the small
+// ones (profiles/r03_small_flow_conflicts.txt).  A lane's two groups are adjacent in memory: its loads stay coalesced.
+template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false, bool DYN = false, bool PAIRS = false>
 __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                           const float* __restrict__ flow, int H, int W, bool* any_spill,
                                                           const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win,
@@ -486,29 +494,9 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   const int32_t g_last = tr.g_last;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   constexpr int kWaves = kBlock / kWave;
-  // chunk c covers groups [g_first + 64 c, g_first + 64 c + 64); this wave starts with chunks `wave` and `wave + 16`
-  int c_cur = wave, c_nxt = wave + kWaves;
-  CGroupQ cur, nxt;
-  if (pre != nullptr) {  // (persistent batched kernel: this window's first two chunks were requested during the previous window)
-    decode_craw(cur, pre[0], hc4);
-    decode_craw(nxt, pre[1], hc4);
-  } else {
-    load_cgroup_q(cur, tr.g_first + c_cur * kWave + lane, tr, ev, hc4);
-    load_cgroup_q(nxt, tr.g_first + c_nxt * kWave + lane, tr, ev, hc4);
-  }
-  float fu[4], fv[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pcq[e], fu[e], fv[e]);
   char* const s_bytes = reinterpret_cast<char*>(s_acc);
-  while (tr.g_first + c_cur * kWave <= g_last) {  // wave-uniform
-    const int32_t grp = tr.g_first + c_cur * kWave + lane;
-    float gu[4], gv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) fetch(nxt.pr[e], nxt.pcq[e], gu[e], gv[e]);
-    const int c_nn = queue.pull();
-    CGroupQ nn;
-    load_cgroup_q(nn, tr.g_first + c_nn * kWave + lane, tr, ev, hc4);
-    const bool lane_live = grp <= g_last;  // the last chunk of the slice may be partial
+  // the four events of one group into the LDS image (fu / fv: their flow, gathered one step earlier)
+  auto deposit = [&](const CGroupQ& cur, const float* fu, const float* fv, bool lane_live) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) EBOS_KLOOP {
       const float lx = -cur.dt[e] * EBOS_KOFF(fu[e], 0.37f), ly = -cur.dt[e] * EBOS_KOFF(fv[e], -0.21f);  // source coordinates are integers: x' = rs + lx
@@ -555,6 +543,67 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       atomicAdd(w, ((unsigned long long)q01 << 32) | q00);
       atomicAdd(w + PT / 2, ((unsigned long long)q11 << 32) | q10);  // (next row of the same plane: + 4 PT bytes)
     }
+  };
+  if (PAIRS) {
+    // One loop iteration = the two groups of a lane's pair of macro chunk m, written out (no parity branch; the pipeline buffers
+    // rotate once per TWO groups, which also halves the register moves per event): the pair of the next macro chunk was requested an
+    // iteration ago; its first group is decoded after the first deposit, its second after the second group's gathers are on their way,
+    // and then its registers take the loads of the macro chunk after it.  Same three stages as the plain loop: event loads two
+    // groups ahead or more, flow gathers one group ahead.
+    auto pair_group = [&](int m, int j) { return tr.g_first + m * (2 * kWave) + 2 * lane + j; };
+    int m_cur = wave, m_next = wave + kWaves;  // (the plain loop's two pre-assigned chunks: macro chunks wave and wave + 16)
+    CRaw raw0 = load_craw(pair_group(m_cur, 0), tr, ev), raw1 = load_craw(pair_group(m_cur, 1), tr, ev);
+    CGroupQ ga, gb;  // groups 2 l and 2 l + 1 of the current macro chunk
+    decode_craw(ga, raw0, hc4);
+    decode_craw(gb, raw1, hc4);
+    raw0 = load_craw(pair_group(m_next, 0), tr, ev);
+    raw1 = load_craw(pair_group(m_next, 1), tr, ev);
+    float fu[4], fv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fetch(ga.pr[e], ga.pcq[e], fu[e], fv[e]);
+    while (tr.g_first + m_cur * (2 * kWave) <= g_last) {  // wave-uniform
+      const int32_t g0 = pair_group(m_cur, 0);
+      float gu[4], gv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fetch(gb.pr[e], gb.pcq[e], gu[e], gv[e]);
+      deposit(ga, fu, fv, g0 <= g_last);
+      decode_craw(ga, raw0, hc4);  // group 2 l of the next macro chunk
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fetch(ga.pr[e], ga.pcq[e], fu[e], fv[e]);
+      CGroupQ gn;
+      decode_craw(gn, raw1, hc4);  // group 2 l + 1 of the next macro chunk: its registers are free now
+      const int m_new = queue.pull();
+      raw0 = load_craw(pair_group(m_new, 0), tr, ev);
+      raw1 = load_craw(pair_group(m_new, 1), tr, ev);
+      deposit(gb, gu, gv, g0 + 1 <= g_last);
+      gb = gn;
+      m_cur = m_next;
+      m_next = m_new;
+    }
+  } else {
+  // chunk c covers groups [g_first + 64 c, g_first + 64 c + 64); this wave starts with chunks `wave` and `wave + 16`
+  int c_cur = wave, c_nxt = wave + kWaves;
+  CGroupQ cur, nxt;
+  if (pre != nullptr) {  // (persistent batched kernel: this window's first two chunks were requested during the previous window)
+    decode_craw(cur, pre[0], hc4);
+    decode_craw(nxt, pre[1], hc4);
+  } else {
+    load_cgroup_q(cur, chunk_group(tr.g_first, c_cur, lane), tr, ev, hc4);
+    load_cgroup_q(nxt, chunk_group(tr.g_first, c_nxt, lane), tr, ev, hc4);
+  }
+  float fu[4], fv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pcq[e], fu[e], fv[e]);
+  while (chunk_group(tr.g_first, c_cur, 0) <= g_last) {  // wave-uniform
+    const int32_t grp = chunk_group(tr.g_first, c_cur, lane);
+    float gu[4], gv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fetch(nxt.pr[e], nxt.pcq[e], gu[e], gv[e]);
+    const int c_nn = queue.pull();
+    CGroupQ nn;
+    load_cgroup_q(nn, chunk_group(tr.g_first, c_nn, lane), tr, ev, hc4);
+    const bool lane_live = grp <= g_last;  // the last chunk of the slice may be partial
+    deposit(cur, fu, fv, lane_live);
     cur = nxt;
     nxt = nn;
     c_cur = c_nxt;
@@ -564,6 +613,7 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       fu[e] = gu[e];
       fv[e] = gv[e];
     }
+  }
   }
   if (any_spill) *any_spill = spilled;
   // Checksum: nothing is counted per event.  Every finite event whose taps are inside the window adds exactly 2^20 units, so the
@@ -581,7 +631,8 @@ enum Pass { PASS_MAIN = 0, PASS_SPILL = 1 };
 
 // UNIFORM: one translation theta for all events (2-DoF model, src/warp.py:364-383: x' = x + dt * theta, i.e. a
 // dense flow of -theta everywhere) -- the two flow gathers disappear.
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false,
+          bool PAIRS = false>
 __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                      const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                      float* spill, bool* any_spill, const ChunkQueue& queue,
@@ -598,7 +649,7 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
   bool spilled = false;
   if (tr.g_first > tr.g_last) return 0;
   if (FMT == FMT_COMPACT && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop (fixed point, or its exact f64 redo)
-    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID, DYN>(tr, s_acc, ev, flow, H, W, any_spill, queue, win, pre);
+    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID, DYN, PAIRS>(tr, s_acc, ev, flow, H, W, any_spill, queue, win, pre);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
   const int32_t g_last = tr.g_last;
@@ -776,8 +827,17 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
   EBOS_STAMP(1);
 
   bool spilled = false;
-  unsigned long long added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN>(
-      tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, pre);
+  unsigned long long added;
+  // run-time-window kernels: where a source pixel holds several events (>= 4 on average over the tile), neighbouring lanes are
+  // given groups two apart (PAIRS), so that the lanes of one wave instruction hold other pixels' events (accumulate_compact_fx)
+  constexpr bool kCanPair = DYN && FMT == FMT_COMPACT && !HAS_W && MODE == ACC_FX;
+  // (... and where the window is small: at 30 px flows the plain mapping has few address conflicts to begin with and is 1 us faster)
+  if (kCanPair && (tr.end - tr.beg) >= 4 * TH * TW && win.HR() <= 16 && win.HC() <= 16)
+    added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN, kCanPair>(
+        tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, nullptr);
+  else
+    added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN>(
+        tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, pre);
   after_loop();
   constexpr bool kLeanLoop = FMT == FMT_COMPACT && !HAS_W;  // accumulate_compact_fx: counts nothing per event
   if (kLeanLoop && threadIdx.x == 0 && tr.g_first <= tr.g_last)  // 2^20 units per event of the slice (padding slots excluded)
