@@ -74,8 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--events", type=int, default=None, help="events per window (default: the config's)")
     ap.add_argument("--windows", type=int, default=None, help="config 4: number of windows (default 64)")
     ap.add_argument("--tile", type=int, nargs=2, default=[0, 0], help="source tile (0 0 = choose_tile: 45x80 at 1280x720)")
-    ap.add_argument("--halo", type=lambda v: v if v == "auto" else int(v), default=32,
-                    help="a built halo of the tile-private kernels, or 'auto': run-time LDS windows per tile (EBOS_HALO_AUTO)")
+    ap.add_argument("--halo", type=lambda v: v if v == "auto" else int(v), default=None,
+                    help="a built halo of the tile-private kernels, or 'auto': run-time LDS windows per tile (EBOS_HALO_AUTO).  Default: "
+                         "32 for configs 2 and 4 (their flows ARE 30 px: every window would be the full one and the bound costs 2 us), "
+                         "auto for config 5 (most of the sweep's thetas are far below 30 px: 36.7 -> 34.0 ms, the same variances bit for bit)")
     ap.add_argument("--splits", type=int, default=1)
     ap.add_argument("--flow-max", type=float, default=FLOW_MAX, help="amplitude of the synthetic flow (BASELINE: 30 px)")
     ap.add_argument("--streams", type=int, default=3, help="configs 4 / 5: independent windows / hypotheses kept in flight per rank")
@@ -92,6 +94,8 @@ def parse_args(argv=None):
         args.steps = DEFAULT_STEPS[args.config]
     if args.warmup is None:
         args.warmup = DEFAULT_WARMUP[args.config]
+    if args.halo is None:
+        args.halo = "auto" if args.config == 5 else 32
     return args
 
 
