@@ -1265,6 +1265,8 @@ def test_fuzz_fused_path_against_oracle(ebos):
         omit = bool(rs.randint(2))
         splits = int(rs.choice([0, 1, 2, 5]))
         direction = ["first", "middle", "last", 0.3][rs.randint(4)]
+        if case % 3 == 2:  # every third case: run-time windows per tile (EBOS_HALO_AUTO), bounded by the tile's largest built halo
+            halo = "auto"
         tag = f"case {case}: {h}x{w} tile {th}x{tw} halo {halo} n {n} kind {kind} amp {amp} pad {pad} splits {splits} {direction}"
         ev_raw = ev
         ev = _off_the_kinks(ev, flow, direction, amp)
@@ -1609,6 +1611,8 @@ def test_fuzz_grid_sampling_route(ebos):
         pad = int(rs.choice([0, 0, 3]))
         splits = int(rs.choice([0, 1])) if kind == 1 and n >= 20000 else 1
         mask = (rs.uniform(size=(gh, gw)) > 0.3).astype(np.float32) if rs.randint(3) == 0 else None
+        if case % 3 == 2 and lib.ebos_patch_fused_supported(th, tw, 32, slide[0], slide[1]):
+            halo = "auto"  # run-time windows per tile (the grid-sampling kernels take the bound from the cells a tile interpolates)
         tag = f"case {case}: {H}x{W} tile {th}x{tw} halo {halo} patch {patch} slide {slide} grid {gh}x{gw} n {n} kind {kind} amp {amp} {terms} omit {omit} pad {pad} splits {splits} mask {mask is not None}"
         ev = _off_the_kinks_patch(ev, theta, (H, W), patch, slide)
         plan = ebos.EventPlan.build(G(ev), (H, W), "first", True, tile=(th, tw))
