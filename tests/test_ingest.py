@@ -116,6 +116,11 @@ def test_deferred_plan_equals_synchronous_plan():
     assert O.rel_l2(f1.grad.cpu().numpy(), f2.grad.cpu().numpy()) < 2e-5
     with pytest.raises(NotImplementedError):  # per-event weights need the exact event count of a synchronous build
         lazy.iwe_dense(flow, weight=torch.ones(30000, device="cuda"))
+    # a lean plan is valid iff no source coordinate is fractional; a deferred build never looks: float [n, 4] sources are refused
+    # (ADVICE r02), the raw int16 columns above are integers by construction
+    ev_f = torch.from_numpy(np.stack([y, x, t / 1e6, p], 1).astype(np.float64)).cuda()
+    with pytest.raises(ValueError, match="deferred=True needs integer source coordinates"):
+        ebos.EventPlan.build(ev_f, (H, W), "first", True, tile="auto", emit="compact", deferred=True)
     # a float plan with fractional coordinates cannot be deferred
     ev = np.stack([y + 0.25, x, t / 1e6, p], 1).astype(np.float64)
     frac = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=None).bin((32, 32), deferred=True)
