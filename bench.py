@@ -703,7 +703,7 @@ def run_config2(R):
         algo_bytes = 12.0 * plan.n + 12.0 * H * W
         format_bytes = bytes_per_event * plan.n + 12.0 * H * W  # what the plan format actually stores per event
         k_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
-        roof = roofline_entry("iwe_slab_accumulate_kernel", kernel_ms, algo_bytes,
+        roof = roofline_entry("iwe_slab_accumulate_kernel<DENSE,DYN>" if a.halo == "auto" else "iwe_slab_accumulate_kernel", kernel_ms, algo_bytes,
                               {"measured_copy_GBps": round(copy_gbs, 1),
                                "frac_of_measured_copy": round(algo_bytes / (k_ms * 1e-3) / 1e9 / copy_gbs, 4),
                                "plan_format_bytes": format_bytes,
