@@ -832,7 +832,10 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
   // given groups two apart (PAIRS), so that the lanes of one wave instruction hold other pixels' events (accumulate_compact_fx)
   constexpr bool kCanPair = DYN && FMT == FMT_COMPACT && !HAS_W && MODE == ACC_FX;
   // (... and where the window is small: at 30 px flows the plain mapping has few address conflicts to begin with and is 1 us faster)
-  if (kCanPair && (tr.end - tr.beg) >= 4 * TH * TW && win.HR() <= 16 && win.HC() <= 16)
+  // (... or where the pixels are so full -- >= 24 events each: the 50 M-event window of the 2-DoF sweep holds 54 -- that even a 30 px
+  // displacement leaves several events of a pixel on one word: 33.9 -> 33.1 ms per 512-hypothesis sweep)
+  const int32_t n_ev = tr.end - tr.beg;
+  if (kCanPair && n_ev >= 4 * TH * TW && ((win.HR() <= 16 && win.HC() <= 16) || n_ev >= 24 * TH * TW))
     added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN, kCanPair>(
         tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, nullptr);
   else
