@@ -612,7 +612,13 @@ class SlabBatch(object):
         p0 = plans[0]
         H, W = p0.image_size
         self.plans, self.flows = list(plans), [f.contiguous().float() for f in flows]
-        self.pad, self.halo, self.omit = (int(pad[0]), int(pad[1])), int(_norm_halo(p0, halo)), bool(omit_boundary)
+        if halo == "auto":  # one |dt| bound for the whole batch: the largest of the plans' (a plan without one: the built halo)
+            bounds = [pl.dt_bound for pl in plans]
+            if any(b is None for b in bounds):
+                halo = max(hl for th, tw, hl in _hip.slab_configs() if (th, tw) == tuple(p0.tile))
+            else:
+                halo = int(lib.ebos_halo_auto(max(hl for th, tw, hl in _hip.slab_configs() if (th, tw) == tuple(p0.tile)), float(max(bounds))))
+        self.pad, self.halo, self.omit = (int(pad[0]), int(pad[1])), int(halo), bool(omit_boundary)
         self.splits = p0.resolve_splits(splits)
         for pl, fl in zip(self.plans, self.flows):
             if pl.image_size != p0.image_size or pl.tile != p0.tile or not pl.compact or pl.device != p0.device:
