@@ -217,7 +217,11 @@ def pmc_traffic(kernel):
     if rec.get("source_blob_sha") is None or rec.get("source_blob_sha") != now:
         stamp["traffic_note"] = f"stale: collected on blob {rec.get('source_blob_sha')}, kernel source is now {now}"
         return None, stamp
-    return rec.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch"), stamp
+    k = rec.get("kernels", {}).get(kernel, {})
+    t = k.get("hbm_bytes_per_launch")
+    if t is not None and k.get("windows"):  # a batched (persistent) pass: per window / hypothesis of the launch
+        t = t / k["windows"]
+    return t, stamp
 
 
 def rocprof_stats(kernel_prefix, ends="false>"):
@@ -272,6 +276,8 @@ def roofline_issue(kernel_key, kernel_ms_list, clock_hz, events=None):
     if valu is None or lds is None:
         ent["note"] = f"no instruction counters for {kernel_key} in profiles/pmc_latest.json"
         return ent
+    if k.get("windows"):  # a batched (persistent) pass: per window / hypothesis of the launch, like kernel_ms
+        valu, lds = valu / k["windows"], lds / k["windows"]
     t_valu = valu / (ISSUE["n_cu"] * ISSUE["simd_per_cu"]) * ISSUE["valu_cycles_per_wave_inst"] / clock_hz * 1e3  # ms
     t_lds = lds / ISSUE["n_cu"] * ISSUE["lds_cycles_per_wave_inst"] / clock_hz * 1e3
     bound = "valu_issue" if t_valu >= t_lds else "lds_pipe"
@@ -957,7 +963,7 @@ def run_config5(R):
     res = {}
 
     def step():
-        res["v"] = plan.variance_2dof(th, chunk=8, halo=a.halo, n_streams=a.streams)
+        res["v"] = plan.variance_2dof(th, chunk=16, halo=a.halo, n_streams=a.streams)
 
     blocks, _ = R.timed_blocks(step, lib, _hip.PROFILE_SLAB_ACCUMULATE, launches_per_step=max(len(mine), 1), profile_blocks=0)
     elapsed = statistics.median(blocks)
@@ -965,13 +971,15 @@ def run_config5(R):
     # roofline leg: the timed sweep keeps three hypotheses in flight on three streams, where a dispatch's begin-to-end time
     # includes the time it shares the chip with its neighbours; the kernel is therefore timed on ONE stream, back to back
     import ctypes
+    # (the accumulate pass is one PERSISTENT launch per chunk of 16 hypotheses: its time is quoted per hypothesis)
     nrec = min(len(mine), 64)
     _hip.check(lib.ebos_profile_start_kernel(_hip.PROFILE_SLAB_ACCUMULATE, nrec), "profile")
-    plan.variance_2dof(th[:nrec], chunk=8, halo=a.halo, n_streams=1)
+    plan.variance_2dof(th[:nrec], chunk=16, halo=a.halo, n_streams=1)
     torch.cuda.synchronize()
     buf = (ctypes.c_float * nrec)()
     got = lib.ebos_profile_stop(buf, nrec)
-    kernel_ms = [buf[i] for i in range(got)]
+    sizes = [min(16, nrec - k0) for k0 in range(0, nrec, 16)]
+    kernel_ms = [buf[i] / sizes[i] for i in range(min(got, len(sizes)))]
     seen = R.gather({"rank": rank, "local_rank": R.local_rank, "device": torch.cuda.get_device_name(dev),
                      "hypotheses": len(mine), "events": plan.n, "ingest_s": round(ingest_s, 2),
                      "variances": {int(k): float(x) for k, x in zip(mine, v)}})
@@ -988,9 +996,10 @@ def run_config5(R):
             "parallelism": f"hypotheses in contiguous blocks over {world} rank(s) (generative_max_likelihood.py:229-236), no collective"})
         line["unit_note"] = "Mevents/s counts event-warps: every hypothesis warps and splats every event"
         dyn = a.halo == "auto"
-        key5 = "iwe_slab_accumulate_kernel<UNIFORM,DYN>" if dyn else "iwe_slab_accumulate_kernel<UNIFORM>"
+        key5 = "iwe_slab_accumulate_batch_kernel<UNIFORM,DYN>" if dyn else "iwe_slab_accumulate_batch_kernel<UNIFORM>"
         line["roofline"] = roofline_entry(key5, kernel_ms, algo,
-                                          {"note": "kernel timed on one stream, back to back (the timed sweep overlaps three)",
+                                          {"note": "the persistent accumulate pass (one launch per 16 hypotheses) timed on one stream, per hypothesis "
+                                                   "(the timed sweep overlaps three streams)",
                                            "ms_per_hypothesis_in_sweep": round(ms_per_step / max(len(mine), 1), 5),
                                            **survey_priced(12.0 * plan.n + 4.0 * H * W, kernel_ms)})
         # SURVEY 8(d) prices config 5 per pass of K hypotheses: 16 B/event ONCE per K + 4 H W K B of images.  The tile-private path

@@ -1052,10 +1052,14 @@ struct FwdBatch {
 };
 static_assert(sizeof(FwdBatch) <= 3072, "the batch travels in the kernel argument segment");
 
-template <int TH, int TW, int HALO, bool GRID, bool DYN>
+// UNIFORM: the "windows" are HYPOTHESES of one plan -- w.flow is a translation (theta0, theta1) of the 2-DoF model
+// (src/warp.py:364-383) -- as in the sweep of src/solver/generative_max_likelihood.py:229-255: the workgroup keeps its tile and walks
+// the hypotheses (ebos_iwe_2dof_slab_batch_f32).
+template <int TH, int TW, int HALO, bool GRID, bool DYN, bool UNIFORM = false>
 __global__ void __launch_bounds__(kBlock)
 iwe_slab_accumulate_batch_kernel(FwdBatch b, int n, int H, int W, int tiles_x, int splits, int pad_h, int pad_w, GridSrc gs,
                                  unsigned epoch, float dt_bound) {
+  static_assert(!(UNIFORM && GRID), "a translation is not a patch grid");
   // A software pipeline over the batch's windows.  What a window's work item needs before its event loop can start -- its
   // tile range (dependent scalar loads), GRID: its block of grid cells, its first two chunks of events -- used to be three exposed
   // memory round trips per window (3.2 us of set-up and ~1 us at the head of the loop, of 11.9 us: in-kernel stamps).  They are
@@ -1113,7 +1117,9 @@ iwe_slab_accumulate_batch_kernel(FwdBatch b, int n, int H, int W, int tiles_x, i
       }
       if (DYN) {
         float mu = 0.0f, mv = 0.0f;
-        if (GRID) {
+        if (UNIFORM) {
+          mu = fabsf(w.flow[0]), mv = fabsf(w.flow[1]);
+        } else if (GRID) {
           const int idx = min((int)threadIdx.x, 2 * tg.ni * tg.nj - 1);
           const bool second = idx >= tg.ni * tg.nj;
           mu = second ? 0.0f : fabsf(tg.cell), mv = second ? fabsf(tg.cell) : 0.0f;
@@ -1128,7 +1134,7 @@ iwe_slab_accumulate_batch_kernel(FwdBatch b, int n, int H, int W, int tiles_x, i
       }
       __syncthreads();
       const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(sh.bound, dt_bound);
-      tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, GRID, DYN, true>(
+      tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, UNIFORM, GRID, DYN, true>(
           tr, win, flow, s_acc, sh, w.ev, H, W, tiles_x, pad_h, pad_w, w.slabs, w.spill, w.spill_epoch, epoch, w.halo_tab, pre,
           [&]() { if (next_live) request(wn, trn); });
     } else if (next_live) {
@@ -2346,7 +2352,7 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
 // in turn), combine and finalize each as one launch over (pixel block | 1, window)
 template <int TH, int TW, int HALO>
 int launch_slab_fwd_batch(const FwdBatch& b, int n, int H, int W, int splits, int pad_h, int pad_w, int want_var, int omit,
-                          hipStream_t s, hipStream_t s_tail, const GridSrc* grid_src, const HaloArg& ha) {
+                          hipStream_t s, hipStream_t s_tail, const GridSrc* grid_src, const HaloArg& ha, bool uniform = false) {
   size_t lds = (size_t)(ha.dyn ? acc_cells<TH, TW, HALO, true>() : acc_cells<TH, TW, HALO, false>()) * sizeof(double);
   const SlabLayout L = slab_layout(H, W, TH, TW, HALO, splits, pad_h, pad_w);
   if (L.off_spill >= ((size_t)1 << 32)) {  // the combine pass addresses the slab section with 32-bit byte offsets (sc1 buffer loads)
@@ -2371,6 +2377,8 @@ int launch_slab_fwd_batch(const FwdBatch& b, int n, int H, int W, int splits, in
       set_error("ebos_iwe_slab_batch: tile %dx%d halo %d leaves no LDS for the tile's flow (ebos_patch_fused_supported)", TH, TW, HALO);
       return EBOS_ERR_UNSUPPORTED;
     }
+  } else if (uniform) {
+    ka = ha.dyn ? iwe_slab_accumulate_batch_kernel<TH, TW, HALO, false, true, true> : iwe_slab_accumulate_batch_kernel<TH, TW, HALO, false, false, true>;
   } else {
     ka = ha.dyn ? iwe_slab_accumulate_batch_kernel<TH, TW, HALO, false, true> : iwe_slab_accumulate_batch_kernel<TH, TW, HALO, false, false>;
   }
@@ -2760,6 +2768,68 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
     if (rc != EBOS_OK) return rc;
   }
   EBOS_CHECK_LAUNCH("ebos_iwe_2dof_slab");
+  return EBOS_OK;
+}
+
+int ebos_iwe_2dof_slab_batch_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const int32_t* key_offsets,
+                                 int64_t n, const float* thetas, int K, int H, int W, int tile_h, int tile_w, int halo_arg, int splits,
+                                 int pad_h, int pad_w, void* workspaces, size_t workspace_bytes, float* iwes, int want_variance,
+                                 int omit_boundary, float* out_variance, double* moments, const int32_t* part_table,
+                                 ebos_stream_t stream, ebos_stream_t tail_stream) {
+  using namespace ebos;
+  const HaloArg ha = decode_halo(halo_arg);
+  const int halo = ha.halo;
+  EBOS_REQUIRE(thetas && iwes && key_offsets && workspaces && grp_offsets && cpix && cdt,
+               "ebos_iwe_2dof_slab_batch: NULL thetas / iwes / workspaces / compact plan");
+  EBOS_REQUIRE(n >= 0 && K >= 1 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64,
+               "ebos_iwe_2dof_slab_batch: bad sizes (K=%d splits=%d)", K, splits);
+  EBOS_REQUIRE(splits != 0 || part_table, "ebos_iwe_2dof_slab_batch: splits = 0 (adaptive work items) needs the plan's part_table");
+  EBOS_REQUIRE(want_variance != 1 || out_variance || moments, "ebos_iwe_2dof_slab_batch: variance requested without an output");
+  if (!slab_config_ok(tile_h, tile_w, halo)) {
+    set_error("ebos_iwe_2dof_slab_batch: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  const size_t need = ebos_iwe_slab_workspace_bytes(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w);
+  if (workspace_bytes < need || workspace_bytes % 256 != 0) {
+    set_error("ebos_iwe_2dof_slab_batch: every hypothesis needs its own workspace of %zu bytes (a multiple of 256), got %zu", need,
+              workspace_bytes);
+    return EBOS_ERR_SCRATCH;
+  }
+  const SlabLayout L = slab_layout(H, W, tile_h, tile_w, halo, splits, pad_h, pad_w);
+  const int n_tiles_ = L.tiles_y * L.tiles_x;
+  const int64_t hw = (int64_t)L.h * L.w;
+  hipStream_t s = as_stream(stream);
+  hipStream_t s_tail = tail_stream ? as_stream(tail_stream) : s;
+  const EvPtrs evp{nullptr, nullptr, nullptr, nullptr, grp_offsets, cpix, cdt, part_table, part_table ? part_table + n_tiles_ + 1 : nullptr,
+                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
+  for (int first = 0; first < K; first += kMaxBatch) {
+    const int nb = K - first < kMaxBatch ? K - first : kMaxBatch;
+    FwdBatch b{};
+    for (int k = 0; k < nb; ++k) {
+      char* ws = reinterpret_cast<char*>(workspaces) + (size_t)(first + k) * workspace_bytes;
+      FwdWindow& w = b.w[k];
+      w.ev = evp;
+      w.key_offsets = key_offsets;
+      w.flow = thetas + 2 * (first + k);
+      w.slabs = reinterpret_cast<float*>(ws);
+      w.spill = reinterpret_cast<float*>(ws + L.off_spill);
+      w.partials = reinterpret_cast<double*>(ws + L.off_partials);
+      w.spill_epoch = reinterpret_cast<unsigned*>(ws + L.off_epoch);
+      w.halo_tab = reinterpret_cast<unsigned*>(ws + L.off_halo);
+      w.iwe = iwes + (first + k) * hw;
+      w.out_var = out_variance ? out_variance + (first + k) : nullptr;
+      w.moments = moments ? moments + 2 * (first + k) : nullptr;
+    }
+    int rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL) \
+  launch_slab_fwd_batch<TH, TW, HL>(b, nb, H, W, splits, pad_h, pad_w, want_variance, omit_boundary, s, s_tail, nullptr, ha, true)
+    EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+    if (rc != EBOS_OK) return rc;
+  }
+  if (s_tail != s)  // join: work enqueued on `stream` after this call sees every hypothesis' results
+    if (int rc = order_after(s, s_tail, "ebos_iwe_2dof_slab_batch")) return rc;
+  EBOS_CHECK_LAUNCH("ebos_iwe_2dof_slab_batch");
   return EBOS_OK;
 }
 

@@ -381,13 +381,14 @@ class EventPlan:
         return _FusedIwe2Dof.apply(thetas, weight, self, (int(pad[0]), int(pad[1])), _norm_halo(self, halo), self.resolve_splits(splits))
 
     def variance_2dof(self, thetas: torch.Tensor, omit_boundary: bool = False, pad: Tuple[int, int] = (0, 0),
-                      halo: int = DEFAULT_HALO, splits: Optional[int] = None, chunk: int = 8,
+                      halo: int = DEFAULT_HALO, splits: Optional[int] = None, chunk: int = 16,
                       n_streams: int = 3) -> torch.Tensor:
         """Variance contrast of K translation hypotheses (the solver's outer sweep): [K, 2] -> [K].
-        No gradient; images go into reused buffers.  The hypotheses are independent, so they are dealt to ``n_streams``
-        HIP streams with a workspace each: the combine / finalize kernels of one hypothesis run in the wave slots that
-        the one-workgroup-per-CU accumulate kernel of another leaves free (bench.py measures 23.6 us per evaluation
-        with three in flight against 39.4 us back to back, 10 M events)."""
+        No gradient; images go into reused buffers.  The hypotheses are independent: they are dealt in chunks to ``n_streams``
+        HIP streams -- the combine / finalize kernels of one chunk run in the wave slots that the one-workgroup-per-CU accumulate
+        kernel of another leaves free -- and on a compact plan a chunk's accumulate pass is ONE persistent launch in which every
+        workgroup keeps its tile and walks the chunk's hypotheses (``ebos_iwe_2dof_slab_batch_f32``: one LDS clear per launch, the
+        next hypothesis' first events requested while the current image is stored).  ``halo="auto"``: run-time windows per tile."""
         lib = _hip.require_gpu()
         halo = _norm_halo(self, halo)
         if not _slab_ok(self, halo):
@@ -398,14 +399,18 @@ class EventPlan:
         h, w = H + 2 * pad[0], W + 2 * pad[1]
         splits = self.resolve_splits(splits)
         out = torch.empty(K, dtype=torch.float32, device=self.device)
+        chunk = max(1, min(int(chunk), K))
         n_streams = max(1, min(int(n_streams), (K + chunk - 1) // chunk))
-        key = ("sweep", int(halo), int(splits), int(pad[0]), int(pad[1]), h, w, min(chunk, K))
+        persistent = self.compact
+        key = ("sweep", int(halo), int(splits), int(pad[0]), int(pad[1]), h, w, chunk, persistent)
         lanes = self.__dict__.setdefault("_sweep_lanes", {}).get(key)
+        nws = _workspace(self, pad, halo, splits).numel()
+        nws_al = (nws + 255) // 256 * 256
         with _hip.on_device(self.device):
             if lanes is None or len(lanes) < n_streams:  # streams, workspaces and image buffers live with the plan
                 lanes = [(torch.cuda.Stream(device=self.device),
-                          torch.zeros(_workspace(self, pad, halo, splits).numel(), dtype=torch.uint8, device=self.device),
-                          torch.empty((min(chunk, K), h, w), dtype=torch.float32, device=self.device)) for _ in range(n_streams)]
+                          torch.zeros((chunk if persistent else 1) * nws_al, dtype=torch.uint8, device=self.device),  # (one workspace per hypothesis of a chunk)
+                          torch.empty((chunk, h, w), dtype=torch.float32, device=self.device)) for _ in range(n_streams)]
                 self.__dict__["_sweep_lanes"][key] = lanes
             cur = torch.cuda.current_stream(self.device)
             for st, _, _ in lanes[:n_streams]:
@@ -413,12 +418,18 @@ class EventPlan:
             for j, k0 in enumerate(range(0, K, chunk)):
                 kc = min(chunk, K - k0)
                 st, ws, buf = lanes[j % n_streams]
-                check(lib.ebos_iwe_2dof_slab_f32(ptr(self.x), ptr(self.y), ptr(self.dt), None, *self._compact_ptrs(),
-                                                 ptr(self.key_offsets), self.n, th.data_ptr() + 8 * k0, kc, H, W,
-                                                 self.tile[0], self.tile[1], int(halo), int(splits), pad[0], pad[1],
-                                                 ptr(ws), ws.numel(), ptr(buf), 1, int(omit_boundary),
-                                                 out.data_ptr() + 4 * k0, None, ptr(self.part_table), st.cuda_stream),
-                      "ebos_iwe_2dof_slab")
+                if persistent:
+                    check(lib.ebos_iwe_2dof_slab_batch_f32(*self._compact_ptrs(), ptr(self.key_offsets), self.n, th.data_ptr() + 8 * k0, kc,
+                                                           H, W, self.tile[0], self.tile[1], int(halo), int(splits), pad[0], pad[1],
+                                                           ptr(ws), nws_al, ptr(buf), 1, int(omit_boundary), out.data_ptr() + 4 * k0,
+                                                           None, ptr(self.part_table), st.cuda_stream, None), "ebos_iwe_2dof_slab_batch")
+                else:
+                    check(lib.ebos_iwe_2dof_slab_f32(ptr(self.x), ptr(self.y), ptr(self.dt), None, *self._compact_ptrs(),
+                                                     ptr(self.key_offsets), self.n, th.data_ptr() + 8 * k0, kc, H, W,
+                                                     self.tile[0], self.tile[1], int(halo), int(splits), pad[0], pad[1],
+                                                     ptr(ws), ws.numel(), ptr(buf), 1, int(omit_boundary),
+                                                     out.data_ptr() + 4 * k0, None, ptr(self.part_table), st.cuda_stream),
+                          "ebos_iwe_2dof_slab")
             for st, _, _ in lanes[:n_streams]:
                 cur.wait_stream(st)
             th.record_stream(cur)

@@ -493,6 +493,19 @@ int ebos_iwe_2dof_slab_f32(const float* xs, const float* ys, const float* dts, c
                            int omit_boundary, float* out_variance, double* moments, const int32_t* part_table,
                            ebos_stream_t stream);
 
+/* The same K hypotheses with the accumulate pass PERSISTENT over them (the sweep of src/solver/generative_max_likelihood.py:229-255,
+ * BASELINE config 5): one launch per 16 hypotheses in which every workgroup keeps its tile and walks the hypotheses -- one LDS
+ * clear per launch, the decode pass zeroes what it reads, the next hypothesis' first chunks are requested while the current image
+ * is decoded and stored -- followed by one combine and one finalize launch over (pixel block | 1, hypothesis).  Compact plans with
+ * unit weights.  workspaces: K consecutive workspaces of workspace_bytes (>= ebos_iwe_slab_workspace_bytes, a multiple of 256) each,
+ * zero-filled once; tail_stream (nullable) as in ebos_iwe_slab_batch_f32.  Results are bit-identical to ebos_iwe_2dof_slab_f32. */
+int ebos_iwe_2dof_slab_batch_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                                 const int32_t* key_offsets, int64_t n, const float* thetas, int K, int H, int W,
+                                 int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspaces,
+                                 size_t workspace_bytes, float* iwes, int want_variance, int omit_boundary,
+                                 float* out_variance, double* moments, const int32_t* part_table, ebos_stream_t stream,
+                                 ebos_stream_t tail_stream);
+
 /* backward of ebos_iwe_2dof_slab_f32: d_thetas[k] = sum_n dt * dL/d(x', y') for upstream images g_images [K, h, w]
  * (affine [K, 2] / g_lo as in ebos_iwe_dense_bwd_f32); d_thetas [K, 2] is OVERWRITTEN.  workspace: the plan's forward
  * workspace (its slab section is reused for the per-tile partial sums). */

@@ -523,6 +523,15 @@ def test_2dof_tile_private_sweep(ebos):
     assert plan.compact
     var = plan.variance_2dof(G(grid, torch.float32), halo=32, chunk=5)
     iwes = plan.iwe_2dof(G(grid, torch.float32), halo=32)
+    # variance_2dof runs the PERSISTENT accumulate pass over hypotheses (ebos_iwe_2dof_slab_batch_f32: one launch per chunk, every
+    # workgroup keeps its tile and walks the chunk), iwe_2dof one launch per hypothesis: the same variances, bit for bit, in any
+    # chunking, with built halos and run-time windows (the spilling hypothesis aside: global float atomics)
+    per_hyp = torch.stack([ebos.ops.image_variance(iwes[k]) for k in range(len(grid))])
+    for chunk, halo in ((5, 32), (16, 32), (1, 32), (3, "auto"), (16, "auto")):
+        vv = plan.variance_2dof(G(grid, torch.float32), halo=halo, chunk=chunk, n_streams=2)
+        assert torch.equal(vv[:-1], var[:-1]), (chunk, halo)
+        assert abs(vv[-1].item() - var[-1].item()) <= 1e-6 * var[-1].item()
+    assert float((per_hyp[:-1] - var[:-1]).abs().max()) <= 2e-6 * float(var[:-1].abs().max())  # (ops.image_variance: another reduction order)
     for k, th in enumerate(grid):
         ref = O.iwe_2dof(torch.from_numpy(ev), torch.from_numpy(th), (h, w))
         assert rel(iwes[k].cpu().numpy(), ref.numpy()) < 1e-5, k

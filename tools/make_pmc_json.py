@@ -32,8 +32,8 @@ def key_of(name):
     flag = lambda i: len(args) > i and args[i] == "true"
     if base == "iwe_slab_accumulate_kernel":      # <TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN>
         uni, grid, dyn = flag(6), flag(7), flag(8)
-    elif base == "iwe_slab_accumulate_batch_kernel":  # <TH, TW, HALO, GRID, DYN>
-        uni, grid, dyn = False, flag(3), flag(4)
+    elif base == "iwe_slab_accumulate_batch_kernel":  # <TH, TW, HALO, GRID, DYN, UNIFORM>
+        uni, grid, dyn = flag(5), flag(3), flag(4)
     elif base == "iwe_dense_tiled_bwd_kernel":    # <TH, TW, HALO, HAS_W, FMT, UNIFORM, GRID, DYN>
         uni, grid, dyn = flag(5), flag(6), flag(7)
     elif base in ("iwe_slab_combine4_kernel", "iwe_slab_combine4_batch_kernel"):  # <TH, TW, HALO, DYN>

@@ -79,7 +79,7 @@ def main():
                 v = plan.variance_2dof(th, halo=halo, n_streams=1)
         torch.cuda.synchronize()
         print("uniform variances", v[:2].tolist())
-        sizes["uniform"] = {"events": plan.n}
+        sizes["uniform"] = {"events": plan.n, "windows_per_launch": int(th.shape[0])}  # (the persistent pass: one launch per chunk of hypotheses)
     if args.out_dir:
         os.makedirs(args.out_dir, exist_ok=True)
         json.dump(sizes, open(os.path.join(args.out_dir, "workloads.json"), "w"))
