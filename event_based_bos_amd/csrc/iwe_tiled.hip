@@ -377,6 +377,50 @@ __device__ __forceinline__ CRaw load_craw(int32_t grp, const TileRange& tr, cons
   const int32_t j = max(min(grp, tr.g_last), tr.g_first);
   return CRaw{reinterpret_cast<const float4*>(p.cdt)[j], reinterpret_cast<const uint2*>(p.cpix)[j]};
 }
+// ... and as the backward kernel's fixed-point sweep wants it: the tile-local pixel index and the offset of the pixel's flow value are
+// formed HERE, in the block that extracts the bit fields -- the 24-bit multiplier (full rate; v_mul_lo_u32 / v_mad_u64_u32 are
+// quarter rate) is only selected where the compiler can prove the operand ranges, and what it knows about a value decoded in an
+// earlier loop iteration does not reach the block that uses it.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct BGroup {
+  unsigned pr[4], pc[4], pix[4], goff[4];
+  float dt[4];
+};
+__device__ __forceinline__ void decode_bgroup(BGroup& g, const CRaw& raw, unsigned row_pitch, unsigned shift, unsigned base) {
+  const float dd[4] = {raw.D.x, raw.D.y, raw.D.z, raw.D.w};
+  const unsigned pp[4] = {raw.P.x & 0xffffu, raw.P.x >> 16, raw.P.y & 0xffffu, raw.P.y >> 16};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    g.dt[e] = dd[e];
+    g.pr[e] = pp[e] >> 8;
+    g.pc[e] = pp[e] & 255u;
+    g.goff[e] = base + __umul24(g.pr[e], row_pitch) + (g.pc[e] << shift);  // (byte offset | element index of the pixel's flow value)
+  }
+}
+template <int TW>
+__device__ __forceinline__ void finish_bgroup(BGroup& g) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) g.pix[e] = g.pr[e] * (unsigned)TW + g.pc[e];
+}
+template <int TH, int TW>
+__device__ __forceinline__ void load_bgroup(BGroup& g, int32_t grp, const TileRange& tr, const EvPtrs& p, unsigned row_pitch,
+                                            unsigned shift, unsigned base) {
+  decode_bgroup(g, load_craw(grp, tr, p), row_pitch, shift, base);
+  finish_bgroup<TW>(g);
+}
+
+// What the fixed-point sweep of the backward kernel needs before its first step, requested while the kernel still sets up: the
+// first two chunks of every wave (event loads: a round trip) and, dense field, the flow values of the first (gathers: a second,
+// dependent round trip).  Issued with the upstream tile's staging loads they arrive under its LDS stores and the barrier; left to
+// the sweep they were 2 - 3 us in front of its first multiply (in-kernel stamps).
+struct BwdPre {
+  BGroup A, B;
+  float au[4], av[4];
+};
+struct BwdPreRaw {
+  CRaw A, B;
+};
+
 __device__ __forceinline__ void decode_craw(CGroupQ& g, const CRaw& r, unsigned hc4);
 __device__ __forceinline__ void load_cgroup_q(CGroupQ& g, int32_t grp, const TileRange& tr, const EvPtrs& p, unsigned hc4) {
   decode_craw(g, load_craw(grp, tr, p), hc4);
@@ -1408,7 +1452,8 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
                                                   const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                   const GradImage& G, double& tot_x, double& tot_y, bool* any_spill,
                                                   const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win,
-                                                  float fx_scale = 1.0f, float fx_limit = 0.0f, bool* bad = nullptr) {
+                                                  float fx_scale = 1.0f, float fx_limit = 0.0f, bool* bad = nullptr,
+                                                  float dt_limit = 0.0f, const BwdPre* pre = nullptr) {
   unsigned long long* s_w = reinterpret_cast<unsigned long long*>(s_d);
   bool out_of_range = false;
   auto add_run = [&](unsigned pix, float ax, float ay) {
@@ -1453,6 +1498,119 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
   // before the last one (in-kernel stamps)
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   constexpr int kWaves = kBlock / kWave;
+  if constexpr (MODE == ACC_FX && PASS == PASS_MAIN && !UNIFORM) {
+    // The fixed-point main sweep: EVERY EVENT is quantised, by the multiply-add that forms its contribution -- fma(dt x scale,
+    // dL/d(x', y'), 1.5 x 2^23) leaves round-to-nearest-even(dt x scale x d) in the low mantissa bits (|.| <= 2^21 units by the choice
+    // of the unit: no range to test per value) -- and a lane's run of one source pixel is two int32 sums, packed into the (dv, du)
+    // word only where the run ends.  Against converting run sums (two multiplies, two round + convert pairs, the range test and the
+    // 64-bit pack at each of the 5 places a run can end, under divergence mostly executed): 239 -> 192 VALU instructions per
+    // group of 4 events, none of them quarter rate (the LDS index is a 16-bit multiply, the pixel index comes with the group).  The three pipeline stages (group being processed / its successor, whose flow gathers fly / the one
+    // whose event loads fly) are three named register sets used in rotation by a loop written out three times: no copies.
+    // What the choice of the unit cannot promise -- |dt| within the caller's bound -- is checked on the events themselves
+    // (*bad: the workgroup redoes its slice in f64); taps of the spill sweep (PASS_SPILL below) keep the per-run test.
+    constexpr float kMagic = 12582912.0f;  // 1.5 x 2^23: bits 0x4B400000 + q for an integer |q| < 2^22
+    const float nscale = -fx_scale;        // dL/dflow[src] += -dt * dL/d(x', y')
+    float dt_max = 0.0f;
+    auto flush = [&](unsigned pix, int qx, int qy) {
+      atomicAdd(&s_w[pix], (unsigned long long)(((long long)qy << 32) + (long long)qx));
+    };
+    auto fetch_at = [&](unsigned off, float& u, float& v) {
+      if (kBuf) {
+        u = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff0, 0));
+        v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, soff1, 0));
+      } else {
+        u = flow[off], v = flow1[off];
+      }
+    };
+    // (the upstream tile's LDS offset as an opaque scalar: folded as a constant it cost an add per tap pair -- ds_read2_b32 has 8-bit offsets)
+    unsigned sg_off = (unsigned)(reinterpret_cast<const char*>(s_g) - reinterpret_cast<const char*>(s_w));
+    asm volatile("" : "+s"(sg_off));
+    const char* g_bytes = reinterpret_cast<const char*>(s_w) + sg_off;
+    const unsigned g_pitch = kBuf ? uW4 : uW, g_shift = kBuf ? 2u : 0u, g_base = kBuf ? 0u : base_lin;
+    auto step = [&](const BGroup& cur, const v2f (&f)[4], const BGroup& nxt, v2f (&fn)[4], BGroup& nn, int c_cur, int c_nn) {
+      const bool lane_live = tr.g_first + c_cur * kWave + lane <= g_last;  // the last chunk may be partial
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u, v;
+        fetch_at(nxt.goff[e], u, v);
+        fn[e].x = u;
+        fn[e].y = v;
+      }
+      load_bgroup<TH, TW>(nn, tr.g_first + c_nn * kWave + lane, tr, ev, g_pitch, g_shift, g_base);
+      dt_max = fmaxf(fmaxf(dt_max, fabsf(cur.dt[0])), fabsf(cur.dt[1]));  // (a padding slot's NaN drops out of the max)
+      dt_max = fmaxf(fmaxf(dt_max, fabsf(cur.dt[2])), fabsf(cur.dt[3]));
+      unsigned run_pix = cur.pix[0];
+      int qx = 0, qy = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float edt = cur.dt[e];
+        const v2f l = f[e] * (-edt);  // (u, v) as a register pair: one packed multiply, no copies to form its operand
+        const float lx = l.x, ly = l.y;
+        const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
+        // (clamped: a free output modifier, and a NaN -- padding slots carry dt = NaN, an Inf flow gives Inf - Inf -- becomes 0, so
+        // that the masked event's zero factor below meets a finite gradient; the forward loop clamps its fractions at 0 as well)
+        const float fr = fminf(fmaxf(lx - r0, 0.0f), 1.0f), fc = fminf(fmaxf(ly - c0, 0.0f), 1.0f);
+        const int rl = (int)cur.pr[e] + HR + (int)r0, cl = (int)cur.pc[e] + HC + (int)c0;
+        const bool ok = lane_live && (fabsf(lx) + fabsf(ly) < 5.0e8f);  // (the forward loop's test; false for NaN)
+        const bool inside = ok && (unsigned)rl < (unsigned)(LH - 1) && (unsigned)cl < (unsigned)(LW - 1);
+        spilled |= ok && !inside;
+        // (16-bit multiply: full rate -- a plain 32-bit multiply-add is a quarter-rate instruction; an `inside` row fits by far)
+        const float* p = reinterpret_cast<const float*>(
+            g_bytes + 4u * (inside ? ((unsigned)rl & 0xffffu) * ((unsigned)LW & 0xffffu) + (unsigned)cl : 0u));  // cell 0..LW+1: always valid, finite
+        const float g00 = p[0], g10 = p[LW], g01 = p[1], g11 = p[LW + 1];
+        const float d0 = g10 - g00, d1 = g11 - g01, e0 = g01 - g00, e1 = g11 - g10;
+        const float dx = d0 + fc * (d1 - d0);  // dL/dx' = (1 - fc) (g10 - g00) + fc (g11 - g01)
+        const float dy = e0 + fr * (e1 - e0);  // dL/dy' = (1 - fr) (g01 - g00) + fr (g11 - g10)
+        const float es = inside ? edt * nscale : 0.0f;
+        const float tx = __builtin_fmaf(es, dx, kMagic), ty = __builtin_fmaf(es, dy, kMagic);
+        if (e > 0 && cur.pix[e] != run_pix) {
+          flush(run_pix, qx, qy);
+          run_pix = cur.pix[e];
+          qx = 0;
+          qy = 0;
+        }
+        qx += (int)(__float_as_uint(tx) - 0x4B400000u);
+        qy += (int)(__float_as_uint(ty) - 0x4B400000u);
+      }
+      flush(run_pix, qx, qy);
+    };
+    BGroup A, B, C;
+    v2f fa[4], fb[4], fc3[4];
+    int k0 = wave, k1 = wave + kWaves;
+    if (pre) {  // (compile-time: the kernel passes its own object or nothing)
+      A = pre->A;
+      B = pre->B;
+    } else {
+      load_bgroup<TH, TW>(A, tr.g_first + k0 * kWave + lane, tr, ev, g_pitch, g_shift, g_base);
+      load_bgroup<TH, TW>(B, tr.g_first + k1 * kWave + lane, tr, ev, g_pitch, g_shift, g_base);
+    }
+    if (pre && kBuf) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fa[e].x = pre->au[e], fa[e].y = pre->av[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u, v;
+        fetch_at(A.goff[e], u, v);
+        fa[e].x = u;
+        fa[e].y = v;
+      }
+    }
+    while (true) {  // (every exit test is wave-uniform)
+      if (tr.g_first + k0 * kWave > g_last) break;
+      const int k2 = queue.pull();
+      step(A, fa, B, fb, C, k0, k2);
+      if (tr.g_first + k1 * kWave > g_last) break;
+      k0 = queue.pull();
+      step(B, fb, C, fc3, A, k1, k0);
+      if (tr.g_first + k2 * kWave > g_last) break;
+      k1 = queue.pull();
+      step(C, fc3, A, fa, B, k2, k1);
+    }
+    if (any_spill) *any_spill = spilled;
+    if (bad) *bad = dt_max > dt_limit;
+    return;
+  }
   int c_cur = wave, c_nxt = wave + kWaves;
   CGroup cur, nxt;
   load_cgroup<TH, TW>(cur, tr.g_first + c_cur * kWave + lane, tr, ev);
@@ -1654,6 +1812,16 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   } else {
     stage_loads(raw, kStage);
   }
+  // (4) the fixed-point sweep's first two chunks of events per wave (BwdPre): decoded, and the first one's flow gathered, further down
+  constexpr bool kPre = kFxScatter;
+  const bool has_events = tr.ty >= 0 && tr.g_first <= tr.g_last;
+  BwdPreRaw pre_raw;
+  BwdPre pre;
+  if (kPre && has_events) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    pre_raw.A = load_craw(tr.g_first + wave * kWave + lane, tr, ev);
+    pre_raw.B = load_craw(tr.g_first + (wave + kBlock / kWave) * kWave + lane, tr, ev);
+  }
   double sm = 0.0, sq = 0.0;
   if (mj.partials != nullptr) {
     for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
@@ -1714,6 +1882,23 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       stage_loads(raw, kStage);
     }
   }
+  if (kPre && has_events) {
+    const unsigned pitch = GRID ? (unsigned)PW : 4u * (unsigned)W, shift = GRID ? 0u : 2u, base = GRID ? (unsigned)(AP * PW + AP) : 0u;
+    decode_bgroup(pre.A, pre_raw.A, pitch, shift, base);
+    decode_bgroup(pre.B, pre_raw.B, pitch, shift, base);
+    finish_bgroup<TW>(pre.A);
+    finish_bgroup<TW>(pre.B);
+    if (!GRID) {  // (GRID: the tile's flow is in LDS after the barrier below -- the sweep fetches it there)
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_arg), 0, 2 * H * W * (int)sizeof(float), 0x00020000);
+      const int soff0 = (tr0 * W + tc0) * (int)sizeof(float), soff1 = soff0 + H * W * (int)sizeof(float);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pre.au[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)pre.A.goff[e], soff0, 0));
+        pre.av[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)pre.A.goff[e], soff1, 0));
+      }
+    }
+  }
   EBOS_STAMP_BWD(1);
   for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
   if (GRID || tr.g_first <= tr.g_last) {
@@ -1747,10 +1932,11 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
     int en;
     frexpf(nmax, &en);                    // nmax < 2^en
-    const int pbits = min(28 - en, 24);   // bits of one event's contribution (24: f32 has no more)
+    const int pbits = min(28 - en, 21);   // bits of one event's contribution (21: the main sweep quantises per event through a
+                                          // 2^23-based rounding constant, bwd_compact_slice)
     // an event contributes dt * (a convex combination of differences of neighbouring upstream values): |.| <= max |dt| x 2 gmax
     const float cmax = (dt_bound > 0.0f ? dt_bound : 1.0f) * 2.0f * gmax;
-    if (!(cmax < 3.0e38f) || pbits < 18) {
+    if (!(cmax < 1.0e37f) || pbits < 18) {
       fx = false;  // NaN / Inf upstream, or a source pixel with >= 1024 events (a hot pixel: f64 keeps its tile's precision)
     } else {
       int e = 0;
@@ -1769,7 +1955,9 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       bool spilled = false, bad = false;
       if (tr.g_first <= tr.g_last)
         bwd_compact_slice<TH, TW, HALO, UNIFORM, PASS_MAIN, GRID, DYN, M>(tr, s_d, s_g, ev, flow, H, W, pad_h, pad_w, G, tot_x, tot_y,
-                                                                          &spilled, queue, win, fx_scale, fx_limit, &bad);
+                                                                          &spilled, queue, win, fx_scale, fx_limit, &bad,
+                                                                          dt_bound > 0.0f ? dt_bound : 1.0f,
+                                                                          (kPre && M == ACC_FX) ? &pre : nullptr);
       if (spilled) s_spill = 1;
       if (bad) s_bad = 1;
       EBOS_STAMP_BWD(3);

@@ -27,10 +27,11 @@ if a.dense:
     n = 256
     buf = (ctypes.c_ulonglong * (n * 8))()
     raw.ebos_debug_read_stamps_bwd(buf, n * 8)
-    st = np.array(buf[:], dtype=np.float64).reshape(n, 8)[:, [0, 2, 3, 4, 5]] * 10.0  # ns (stamp 1 belongs to the grid kernel)
+    st = np.array(buf[:], dtype=np.float64).reshape(n, 8)[:, [0, 1, 2, 3, 4, 5]] * 10.0  # ns
     t0 = st[:, 0].min()
-    print(f"dense backward, {a.events} events: kernel span {(st[:, 4].max() - t0) / 1e3:.2f} us; start skew max {(st[:, 0].max() - t0) / 1e3:.2f} us")
-    for i, nm in enumerate(["clear + upstream tile staging", "main loop (lane-0 wave)", "wait for other waves", "d_flow tile store"]):
+    print(f"dense backward, {a.events} events: kernel span {(st[:, 5].max() - t0) / 1e3:.2f} us; start skew max {(st[:, 0].max() - t0) / 1e3:.2f} us")
+    for i, nm in enumerate(["loads issued, moments reduced, window known", "clear + upstream tile -> LDS + barrier", "main loop (lane-0 wave)",
+                            "wait for other waves", "d_flow tile store"]):
         d = st[:, i + 1] - st[:, i]
         print(f"  {nm:40s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
     sys.exit(0)
