@@ -401,7 +401,7 @@ class EventPlan:
         out = torch.empty(K, dtype=torch.float32, device=self.device)
         chunk = max(1, min(int(chunk), K))
         n_streams = max(1, min(int(n_streams), (K + chunk - 1) // chunk))
-        persistent = self.compact
+        persistent = self.compact and w % 4 == 0 and pad[1] % 4 == 0  # (what the batched pass asks of its images; else one launch per hypothesis)
         key = ("sweep", int(halo), int(splits), int(pad[0]), int(pad[1]), h, w, chunk, persistent)
         lanes = self.__dict__.setdefault("_sweep_lanes", {}).get(key)
         nws = _workspace(self, pad, halo, splits).numel()
