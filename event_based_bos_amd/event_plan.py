@@ -17,6 +17,7 @@ from dataclasses import dataclass
 from typing import Optional, Tuple, Union
 
 import torch
+from torch.utils import _pytree
 
 from . import _hip, ops
 from ._hip import check, ptr, stream_ptr
@@ -505,8 +506,15 @@ class EventPlan:
         the gradient is produced with the value, ``backward`` is once-differentiable (``create_graph=True`` raises)."""
         halo = _norm_halo(self, halo)
         if cost == "image_variance":
-            return _FusedVarianceDense.apply(flow, self, (int(pad[0]), int(pad[1])), bool(omit_boundary), halo,
-                                             self.resolve_splits(splits))
+            pad2, splits = (int(pad[0]), int(pad[1])), self.resolve_splits(splits)
+            if _eager_ok(self, flow, halo):
+                # value and gradient by the one native call, handed back as a tensor whose ``.backward()`` -- when it is called on
+                # the result itself, the objective idiom -- stores the gradient without entering the autograd engine (the engine's
+                # thread hand-off around a Python backward costs more than both event kernels); any other use of the result
+                # attaches the ordinary autograd node first (_EagerLoss)
+                out, d_flow = _run_dense_job(_dense_job(self, pad2, halo, splits, bool(omit_boundary)), flow, True)
+                return _EagerLoss.wrap(out[0], flow, d_flow)
+            return _FusedVarianceDense.apply(flow, self, pad2, bool(omit_boundary), halo, splits)
         iwe = self.iwe_dense(flow, pad=pad, halo=halo, splits=splits)
         if cost == "gradient_magnitude":
             return ops.gradient_magnitude(iwe, omit_boundary)
@@ -832,6 +840,113 @@ class _FusedIweDense(torch.autograd.Function):
                                         splits=splits)
         d_weight = _unpermute(plan, d_w).to(wdt) if need_w else None
         return (d_flow.to(fdt) if ctx.needs_input_grad[0] else None), d_weight, None, None, None, None
+
+
+def _eager_ok(plan: EventPlan, flow: torch.Tensor, halo) -> bool:
+    """The objective idiom's short cut applies to a float32 leaf of the plan's own shape and device that wants its gradient, has no
+    tensor hooks (they fire inside the engine), with grad mode on, on a tile-private configuration."""
+    return (type(flow) is torch.Tensor or type(flow) is torch.nn.Parameter) and flow.requires_grad and flow.is_leaf and \
+        torch.is_grad_enabled() and flow.dtype == torch.float32 and flow.is_contiguous() and flow.device == plan.device and \
+        tuple(flow.shape) == (2,) + tuple(plan.image_size) and not flow._backward_hooks and \
+        not getattr(flow, "_post_accumulate_grad_hooks", None) and _slab_ok(plan, halo)
+
+
+class _AttachGrad(torch.autograd.Function):
+    """The autograd node of an already computed (value, gradient) pair: what _EagerLoss turns into when it is used as anything
+    but the direct target of ``backward()``.  ``scale``: the Python factor the value has been multiplied with since."""
+
+    @staticmethod
+    def forward(ctx, flow, value, d_flow, scale):
+        ctx.save_for_backward(d_flow)
+        ctx.scale = scale
+        return value.detach()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (d_flow,) = ctx.saved_tensors
+        return d_flow * (g.to(torch.float32) * ctx.scale), None, None, None
+
+
+class _EagerLoss(torch.Tensor):
+    """0-d result of ``contrast_dense`` whose gradient w.r.t. the (leaf) flow exists already.
+
+    ``loss.backward()`` on the object itself -- or on ``-loss`` / ``k * loss`` / ``loss / k`` with a Python number, the sign and
+    weight a caller applies to a contrast -- accumulates that gradient into ``flow.grad`` exactly as the engine would (set when
+    ``None``, added otherwise; scaled by ``gradient`` when one is given) without running the engine.  Every other use -- arithmetic
+    with tensors, ``torch.*`` functions, ``grad_fn`` / ``requires_grad`` queries, ``backward`` with ``inputs`` / ``create_graph``
+    -- first attaches the ordinary autograd node (_AttachGrad) and proceeds on that tensor, so results and graphs are those of
+    ``_FusedVarianceDense``.  ``item()`` / ``detach()`` / printing read the value."""
+
+    _VALUE_ONLY = {"item", "detach", "__float__", "__repr__", "__str__", "__format__", "tolist", "cpu", "numpy", "__bool__",
+                   "__int__", "dim", "size", "numel", "__len__"}
+
+    @staticmethod
+    def wrap(value: torch.Tensor, flow: torch.Tensor, d_flow: torch.Tensor, scale: float = 1.0) -> "_EagerLoss":
+        t = torch.Tensor._make_subclass(_EagerLoss, value)
+        t._ebos = [flow, d_flow, None, scale]  # flow, gradient of the UNSCALED value (None once handed over), attached tensor, factor
+        return t
+
+    def _plain(self) -> torch.Tensor:
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor)
+
+    def _attached(self) -> torch.Tensor:
+        st = self._ebos
+        if st[2] is None:
+            if st[1] is None:
+                raise RuntimeError("contrast_dense: backward() has already consumed this result's gradient; evaluate again "
+                                   "(the objective is one native call) or combine the result into a graph before backward()")
+            st[2] = _AttachGrad.apply(st[0], self._plain(), st[1], st[3])
+        return st[2]
+
+    def _scaled(self, k) -> "_EagerLoss":
+        st = self._ebos
+        if st[2] is not None or st[1] is None:  # already a graph node (or consumed): the ordinary path
+            return self._attached() * k
+        return _EagerLoss.wrap(self._plain() * k, st[0], st[1], st[3] * float(k))
+
+    def __neg__(self):
+        return self._scaled(-1.0)
+
+    def __mul__(self, other):
+        return self._scaled(other) if isinstance(other, (int, float)) and not isinstance(other, bool) else self._attached() * other
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return self._scaled(1.0 / other) if isinstance(other, (int, float)) and not isinstance(other, bool) and other != 0 \
+            else self._attached() / other
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        st = self._ebos
+        flow = st[0]
+        if st[2] is not None or create_graph or inputs is not None or st[1] is None or flow._backward_hooks or \
+                getattr(flow, "_post_accumulate_grad_hooks", None):
+            return self._attached().backward(gradient, retain_graph, create_graph, inputs)
+        g, k = st[1], st[3]
+        if retain_graph:
+            g = g.clone()
+        else:
+            st[1] = None  # the buffer now belongs to flow.grad (or is consumed by the add)
+        with torch.no_grad():
+            if gradient is not None:
+                g.mul_(gradient.to(device=g.device, dtype=torch.float32) * k)
+            elif k != 1.0:
+                g.mul_(k)
+            if flow.grad is None:
+                flow.grad = g
+            else:
+                flow.grad.add_(g)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        value_only = getattr(func, "__name__", "") in cls._VALUE_ONLY
+        conv = (lambda a: a._plain()) if value_only else (lambda a: a._attached())
+        args, kwargs = _pytree.tree_map_only(_EagerLoss, conv, (tuple(args), kwargs))  # (also inside lists: torch.stack([loss, ...]))
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
 
 
 class _FusedVarianceDense(torch.autograd.Function):

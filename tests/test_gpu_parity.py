@@ -377,6 +377,68 @@ def test_fused_dense_costs_padding_weights(ebos, cost, omit):
     assert rel(wt.grad.cpu().numpy(), dw_ref) < 1e-3
 
 
+def test_objective_backward_without_the_engine_keeps_autograd_semantics(ebos):
+    """``plan.contrast_dense(flow).backward()`` on a plain float32 leaf stores the gradient that came with the value without
+    entering the autograd engine (event_plan._EagerLoss).  Everything observable must be what the engine would have done: the same
+    gradient bit for bit, accumulation into an existing ``.grad``, scaling by ``gradient=``, graphs built on top of the result,
+    tensor hooks (which only the engine can fire), value reads, and an error on a second backward."""
+    h, w, n = 96, 128, 30_000
+    ev = O.synth_events(n, h, w, seed=5)
+    fl = G(O.synth_dense_flow(h, w, seed=6, max_val=6.0), torch.float32)
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile="auto")
+    from event_based_bos_amd.event_plan import _EagerLoss, _FusedVarianceDense
+
+    def engine(scale=1.0):  # the ordinary autograd node, as any non-leaf / hooked / double flow gets it
+        f = fl.clone().requires_grad_(True)
+        v = _FusedVarianceDense.apply(f, plan, (0, 0), False, 32, plan.resolve_splits(None))
+        (v * scale).backward()
+        return v.detach(), f.grad
+
+    v_ref, g_ref = engine()
+    f = fl.clone().requires_grad_(True)
+    loss = plan.contrast_dense(f)
+    assert type(loss) is _EagerLoss and loss._ebos[2] is None
+    assert loss.item() == v_ref.item() and loss._ebos[2] is None and f"{loss:.3e}" == f"{v_ref.item():.3e}"
+    loss.backward()
+    assert loss._ebos[2] is None                                          # no autograd node was ever made
+    assert torch.equal(f.grad, g_ref)
+    with pytest.raises(RuntimeError):
+        loss.backward()                                                   # consumed, as a freed graph would be
+    plan.contrast_dense(f).backward()                                     # a second evaluation accumulates
+    assert torch.equal(f.grad, g_ref + g_ref)
+    f.grad = None
+    plan.contrast_dense(f).backward(gradient=torch.tensor(-0.5, device=f.device))
+    assert torch.equal(f.grad, g_ref * -0.5)
+    f.grad = None
+    neg = -plan.contrast_dense(f)                                         # the sign / weight a caller applies: still no engine
+    assert type(neg) is _EagerLoss and neg.item() == -v_ref.item()
+    neg.backward()
+    assert neg._ebos[2] is None and torch.equal(f.grad, -g_ref)
+    f.grad = None
+    (0.25 * plan.contrast_dense(f) / 2.0).backward(retain_graph=True)
+    assert torch.equal(f.grad, g_ref * 0.125)
+    # used in a graph: the node is attached on first use, gradients flow through the composite
+    f2 = fl.clone().requires_grad_(True)
+    total = -plan.contrast_dense(f2) * 2.0 + (f2 * f2).sum() * 1e-3
+    assert type(total) is torch.Tensor and total.grad_fn is not None
+    total.backward()
+    assert rel(f2.grad.cpu().numpy(), (g_ref * -2.0 + 2e-3 * fl).cpu().numpy()) < 1e-6
+    l3 = plan.contrast_dense(fl.clone().requires_grad_(True))
+    assert l3.requires_grad and l3.grad_fn is not None and l3.shape == torch.Size([])
+    stacked = torch.stack([plan.contrast_dense(f2), plan.contrast_dense(f2)])
+    assert stacked.grad_fn is not None
+    # a tensor hook on the flow: only the engine fires it -- the short cut must step aside
+    f3 = fl.clone().requires_grad_(True)
+    seen = []
+    f3.register_hook(lambda g: seen.append(1))
+    l = plan.contrast_dense(f3)
+    assert type(l) is torch.Tensor
+    l.backward()
+    assert seen == [1] and torch.equal(f3.grad, g_ref)
+    with torch.no_grad():
+        assert not plan.contrast_dense(f).requires_grad
+
+
 def test_reference_idiom_is_fused_lazily(ebos, monkeypatch):
     """warp_event + create_iwe, written exactly as against the reference, run on the fused kernels for float32
     GPU tensors: same image and flow gradient as the unfused path, plan built once per event window."""
