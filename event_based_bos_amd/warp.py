@@ -158,6 +158,14 @@ class Warp(object):
         """Warp events [(b,) n, 4] with ``motion`` under ``motion_model``; returns (warped, feature dict)."""
         ref_mode, frac = parse_direction(direction)  # ValueError first, like calculate_reftime (:218)
         if motion_model == "dense-flow":
+            if is_torch(events) and is_torch(motion) and fusion.lazy_eligible(events, motion, self.image_size) and \
+                    not self._strict_for(GPU):
+                # opt-in: the coordinates are computed when (if) something reads them; EventImageConverter does not (fusion.py)
+                prov = fusion.Provenance(events, events._version, motion, ref_mode, frac, direction, bool(self.normalize_t),
+                                         (int(self.image_size[0]), int(self.image_size[1])))
+                lazy = fusion.LazyWarped.make(events, motion, prov,
+                                              lambda: self.warp_event_now(events, motion, ref_mode, frac, direction))
+                return lazy, self.feature_dense.calculate_feature(skip=not self.calculate_feature)
             warped, feat = self._warp_dense(events, motion, ref_mode, frac, None)
             if is_torch(events) and is_torch(motion) and fusion.eligible(events, motion, self.image_size):
                 # remember where these coordinates came from: EventImageConverter can then build the image with the
@@ -169,6 +177,14 @@ class Warp(object):
             assert motion.shape[-1] == 2
             return self._warp_2dof(events, motion, ref_mode, frac, None, None)
         raise MotionModelKeyError(f"{motion_model = } not supported")
+
+    def warp_event_now(self, events, motion, ref_mode, frac, direction) -> torch.Tensor:
+        """The dense-flow warp of GPU tensors, computed and provenance-tagged (what ``warp_event`` returns unless it is lazy)."""
+        warped, _ = self._warp_dense(events, motion, ref_mode, frac, None)
+        if fusion.eligible(events, motion, self.image_size):
+            fusion.tag(warped, fusion.Provenance(events, events._version, motion, ref_mode, frac, direction,
+                                                 bool(self.normalize_t), (int(self.image_size[0]), int(self.image_size[1]))))
+        return warped
 
     def _snapshot_oob(self, device) -> None:
         host = torch.empty(1, dtype=torch.int32, pin_memory=True)

@@ -72,6 +72,11 @@ def main():
         for name, fn in (("contrast_dense_backward", a), ("reference_idiom_fused", c)):
             total, host = timed(fn, args.iters)
             out[name + "_single_threaded_engine"] = {"us_per_iteration": round(total, 1), "host_enqueue_us": round(host, 1)}
+    # opt-in EBOS_FUSE_API=lazy: the idiom's warped events are only computed if something reads them (fusion.LazyWarped)
+    os.environ["EBOS_FUSE_API"] = "lazy"
+    total, host = timed(c, args.iters)
+    out["reference_idiom_lazy_warp"] = {"us_per_iteration": round(total, 1), "host_enqueue_us": round(host, 1)}
+    os.environ.pop("EBOS_FUSE_API")
     print(json.dumps(out))
     if args.profile:
         for name, fn in (("contrast_dense_backward", a), ("reference_idiom_fused", c)):
