@@ -15,8 +15,9 @@
 //             moments_finalize_kernel      one workgroup: partials -> (mean, M, variance); deterministic
 //             *_batch_kernel               the same three over (work item, window) for up to 16 independent windows
 //   backward  iwe_dense_tiled_bwd_kernel   upstream image tile (+halo) staged in LDS with all its loads in flight, four LDS gathers per
-//                                          event, the events of one source pixel summed in registers per lane, ds_add_f64 into a
-//                                          [2][TH][TW] LDS tile, then d_flow of the tile is written once, 16 bytes per lane,
+//                                          event, the events of one source pixel summed in registers per lane (fixed point: one
+//                                          ds_add_u64 per run; ds_add_f64 pairs with per-event weights) into a [2][TH][TW] LDS
+//                                          tile, then d_flow of the tile is written once, 16 bytes per lane,
 //                                          write-through -- every flow pixel belongs to exactly one tile, so no global atomics and
 //                                          no zero-fill.
 //   GRID variants of both: the flow argument is a patch grid [2, gh, gw], evaluated per tile into LDS (patch_grid.h).
@@ -1439,14 +1440,15 @@ struct GradImage {
 //                     word += (qv << 32) + qu in two's complement (a negative low field borrows from the high one and the
 //                     decode gives it back).  The unit is chosen PER TILE: with n the largest event count of one of its source
 //                     pixels (key_offsets) and C >= max |dt| x 2 max |upstream tile| the largest contribution of an event, an
-//                     event gets p = 28 - ceil(log2 n) bits (23 at the ~30 events of a 10 M-event window's fullest pixel: f32's
-//                     own resolution relative to C), fx_scale = 2^p / C rounded down to a power of two.  EXACT by construction,
-//                     not by checksum (signed sums could cancel a wrap): every run sum is checked against fx_limit = 2^(p + 2)
-//                     units (*bad otherwise -- a |dt| beyond the caller's bound, a spill-sweep tap outside the staged tile),
-//                     and |pixel sum| <= runs x 2^(p + 2) <= n 2^(p + 2) <= 2^30: no field can leave its 32 bits.  A workgroup
-//                     that fails the run test redoes its slice in ACC_F64; a tile with a hot pixel (n >= 1024: p < 18) takes
-//                     ACC_F64 from the start.  Integer adds commute: the gradient is
-//                     bit-reproducible, which the f64 atomics (order-dependent rounding) were not.
+//                     event gets p = min(28 - ceil(log2 n), 21) bits, fx_scale = 2^p / C rounded down to a power of two.  EXACT
+//                     by construction, not by checksum (signed sums could cancel a wrap).  Main sweep: every EVENT is quantised
+//                     by the multiply-add that forms its contribution (see the sweep below); |.| <= 2^p follows from the two
+//                     bounds behind C, of which the upstream one holds by construction (C is taken from the staged tile) and the
+//                     |dt| one is checked on the events (*bad otherwise).  Spill sweep (taps read from global memory, beyond the
+//                     staged tile): run sums are converted and checked against fx_limit = 2^(p + 2) units (*bad otherwise).
+//                     |pixel sum| <= n 2^(p + 2) <= 2^30: no field can leave its 32 bits.  A workgroup that raises *bad redoes
+//                     its slice in ACC_F64; a tile with a hot pixel (n >= 1024: p < 18) takes ACC_F64 from the start.  Integer
+//                     adds commute: the gradient is bit-reproducible, which the f64 atomics (order-dependent rounding) were not.
 template <int TH, int TW, int HALO, bool UNIFORM, int PASS, bool GRID = false, bool DYN = false, int MODE = ACC_F64>
 __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s_d, const float* s_g, const EvPtrs& ev,
                                                   const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,

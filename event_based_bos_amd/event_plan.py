@@ -876,10 +876,9 @@ class _EagerLoss(torch.Tensor):
     ``None``, added otherwise; scaled by ``gradient`` when one is given) without running the engine.  Every other use -- arithmetic
     with tensors, ``torch.*`` functions, ``grad_fn`` / ``requires_grad`` queries, ``backward`` with ``inputs`` / ``create_graph``
     -- first attaches the ordinary autograd node (_AttachGrad) and proceeds on that tensor, so results and graphs are those of
-    ``_FusedVarianceDense``.  ``item()`` / ``detach()`` / printing read the value."""
+    ``_FusedVarianceDense``.  ``item()`` / ``detach()`` / ``float()`` / f-strings read the value."""
 
-    _VALUE_ONLY = {"item", "detach", "__float__", "__repr__", "__str__", "__format__", "tolist", "cpu", "numpy", "__bool__",
-                   "__int__", "dim", "size", "numel", "__len__"}
+    _VALUE_ONLY = {"item", "detach", "__float__", "__format__", "tolist", "__bool__", "__int__", "dim", "size", "numel", "__len__"}
 
     @staticmethod
     def wrap(value: torch.Tensor, flow: torch.Tensor, d_flow: torch.Tensor, scale: float = 1.0) -> "_EagerLoss":

@@ -15,6 +15,7 @@ ROOT=$PWD
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --config 4 > "$OUT/bench_config4.json" 2> "$OUT/bench_config4.err"
 python bench.py --config 5 > "$OUT/bench_config5.json" 2> "$OUT/bench_config5.err"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"   # the driver's form
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/prof_bench.err"
 PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU")
