@@ -1022,6 +1022,15 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
       reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, splits);
   if (tr.ty < 0) return;  // unused work item of an adaptive plan: its slab is never read
+  // the lean loop's first two chunks per wave, requested here: they arrive under the rest of the set-up and its barrier instead of
+  // a round trip after it (the persistent batched kernel requests them a whole window ahead)
+  constexpr bool kLeanPre = FMT == FMT_COMPACT && !HAS_W && MODE == ACC_FX;
+  CRaw pre[2];
+  if (kLeanPre) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    pre[0] = load_craw(tr.g_first + wave * kWave + lane, tr, ev);
+    pre[1] = load_craw(tr.g_first + (wave + kBlock / kWave) * kWave + lane, tr, ev);
+  }
   float mu = 0.0f, mv = 0.0f;
   if (kBoundFromFlow) {
     tile_flow_absmax<TH, TW>(flow_arg, H, W, tr.ty * TH, tr.tx * TW, mu, mv);
@@ -1058,7 +1067,8 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   __syncthreads();
   const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(sh.bound, dt_bound);
   tile_body<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN, ZERO>(tr, win, flow, s_acc, sh, ev, H, W, tiles_x, pad_h, pad_w, slabs,
-                                                                     spill, spill_epoch, epoch, halo_tab, nullptr, NoHook{});
+                                                                     spill, spill_epoch, epoch, halo_tab, kLeanPre ? pre : nullptr,
+                                                                     NoHook{});
 }
 
 template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
@@ -1306,33 +1316,75 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
     int tx0 = (c - HALO - TW + 1 >= 0) ? (c - HALO - TW + 1 + TW - 1) / TW : 0;
     int tx1 = (c + HALO >= 0) ? (c + HALO) / TW : -1;
     if (tx1 > tiles_x - 1) tx1 = tiles_x - 1;
-    for (int ty = ty0; ty <= ty1; ++ty) {
-      for (int tx = tx0; tx <= tx1; ++tx) {
-        const int tile = ty * tiles_x + tx;
-        int hr = HALO, hc = HALO;
-        if (DYN) {  // (hc is a multiple of 4 and so is c: a quad lies inside a window or outside it, never across its edge)
-          const unsigned t = s_tab[(ty - tab_y0) * kTabX + (tx - tab_x0)];
-          hr = (int)(t & 255u), hc = (int)(t >> 8);
+    // The candidates: at most kNy x kNx tiles have a window that can reach this quad (the pixel's row lies in at most
+    // floor((2 HALO + TH - 1) / TH) + 1 windows).  Written out as that many SLOTS whose first slab loads are all issued before the
+    // first one is added: as nested loops over (ty, tx, part) the pass waited for each 16-byte load in turn -- up to four dependent
+    // round trips per thread, most of its 6.4 us (the loads sat behind `s_waitcnt vmcnt(0)` one by one).  The additions keep the
+    // loops' order (ty, tx, part), so the image has the same bits; parts beyond a tile's first (adaptive plans, splits > 1)
+    // follow their slot's first in a rolled loop.
+    constexpr int kNy = (2 * HALO + TH - 1) / TH + 1, kNx = (2 * HALO + TW - 1) / TW + 1;
+    bool ok[kNy * kNx];
+    unsigned byte0[kNy * kNx];
+    int parts[kNy * kNx];
+    float4 first[kNy * kNx];
+    auto gather = [&](auto adaptive_tag) {  // (two copies: an adaptive plan's part offsets are loads of their own, issued first)
+      constexpr bool kAdaptive = decltype(adaptive_tag)::value;
+      int tile_of[kNy * kNx], cell[kNy * kNx], s0[kNy * kNx], s1[kNy * kNx];
+#pragma unroll
+      for (int a = 0; a < kNy; ++a) {
+#pragma unroll
+        for (int b = 0; b < kNx; ++b) {
+          const int k = a * kNx + b, ty = ty0 + a, tx = tx0 + b;
+          bool valid = ty <= ty1 && tx <= tx1;
+          const int tyc = min(ty, tiles_y - 1), txc = min(tx, tiles_x - 1);  // (an unused slot still forms an address)
+          tile_of[k] = tyc * tiles_x + txc;
+          int hr = HALO, hc = HALO;
+          if (DYN) {  // (hc is a multiple of 4 and so is c: a quad lies inside a window or outside it, never across its edge)
+            const unsigned t = s_tab[min(tyc - tab_y0, kTabY - 1) * kTabX + min(txc - tab_x0, kTabX - 1)];
+            hr = (int)(t & 255u), hc = (int)(t >> 8);
+          }
+          const int rl = r - (tyc * TH - hr), cl = c - (txc * TW - hc), lw = TW + 2 * hc;
+          if (DYN) valid = valid && (unsigned)rl < (unsigned)(TH + 2 * hr) && (unsigned)cl < (unsigned)lw;
+          ok[k] = valid;
+          cell[k] = valid ? rl * lw + cl : 0;
+          if (kAdaptive) {
+            s0[k] = part_off[tile_of[k]];
+            s1[k] = part_off[tile_of[k] + 1];
+          }
         }
-        const int rl = r - (ty * TH - hr), cl = c - (tx * TW - hc), lw = TW + 2 * hc;
-        if (DYN && ((unsigned)rl >= (unsigned)(TH + 2 * hr) || (unsigned)cl >= (unsigned)lw)) continue;
-        const int s0 = part_off ? part_off[tile] : tile * splits, np = part_off ? part_off[tile + 1] - s0 : splits;
+      }
+#pragma unroll
+      for (int k = 0; k < kNy * kNx; ++k) {
+        const int first_slab = kAdaptive ? s0[k] : tile_of[k] * splits;
+        parts[k] = kAdaptive ? s1[k] - s0[k] : splits;
+        ok[k] = ok[k] && parts[k] > 0;
+        byte0[k] = ok[k] ? ((unsigned)first_slab * (unsigned)(LH * LW) + (unsigned)cell[k]) * 4u : 0u;
 #ifndef EBOS_PLAIN_SLABS
-        const unsigned sp_byte = ((unsigned)s0 * (unsigned)(LH * LW) + (unsigned)(rl * lw + cl)) * 4u;
+        first[k] = slab_load4(all_slabs, byte0[k]);
 #else
-        const float* sp = slabs + (int64_t)s0 * (LH * LW) + rl * lw + cl;
+        first[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slabs) + byte0[k]);
 #endif
-        for (int p = 0; p < np; ++p) {
+      }
+    };
+    if (part_off != nullptr) gather(std::true_type{});
+    else gather(std::false_type{});
+#pragma unroll
+    for (int k = 0; k < kNy * kNx; ++k) {
+      if (!ok[k]) continue;
+      v.x += first[k].x;
+      v.y += first[k].y;
+      v.z += first[k].z;
+      v.w += first[k].w;
+      for (int p = 1; p < parts[k]; ++p) {
 #ifndef EBOS_PLAIN_SLABS
-          const float4 t = slab_load4(all_slabs, sp_byte + (unsigned)p * (unsigned)(LH * LW * 4));
+        const float4 t = slab_load4(all_slabs, byte0[k] + (unsigned)p * (unsigned)(LH * LW * 4));
 #else
-          const float4 t = *reinterpret_cast<const float4*>(sp + (int64_t)p * (LH * LW));
+        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slabs) + byte0[k] + (size_t)p * (LH * LW * 4));
 #endif
-          v.x += t.x;
-          v.y += t.y;
-          v.z += t.z;
-          v.w += t.w;
-        }
+        v.x += t.x;
+        v.y += t.y;
+        v.z += t.z;
+        v.w += t.w;
       }
     }
     const int64_t gi = (int64_t)R * w + C;
@@ -1390,10 +1442,21 @@ iwe_slab_combine4_batch_kernel(FwdBatch b, int tiles_y, int tiles_x, int splits,
 // one workgroup: partials -> out (unbiased variance), moments (mean, M).  Fixed summation order.
 __device__ __forceinline__ void moments_finalize_block(const double* __restrict__ partials, int64_t nparts, int64_t m, float* out,
                                                        double* moments) {
+  // four (sum, sum of squares) pairs per thread in flight at once: rolled, the loop waited for each 16-byte load in turn -- at the
+  // ~900 partials of a 1280x720 image four round trips, most of what this one-workgroup kernel takes (4.6 us on average against
+  // 2.4 at best in the rocprofv3 trace).  The order of the additions is the rolled loop's: same bits.
   double s = 0.0, ss = 0.0;
-  for (int64_t i = threadIdx.x; i < nparts; i += blockDim.x) {
-    s += partials[2 * i];
-    ss += partials[2 * i + 1];
+  const double2* __restrict__ pairs = reinterpret_cast<const double2*>(partials);
+  for (int64_t base = threadIdx.x; base < nparts; base += 4 * (int64_t)blockDim.x) {
+    double2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = pairs[min(base + k * (int64_t)blockDim.x, nparts - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (base + k * (int64_t)blockDim.x < nparts) {
+        s += v[k].x;
+        ss += v[k].y;
+      }
   }
   __shared__ double red[8];
   block_sum2(s, ss, red);
