@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's profiles/ entries come from, on the GPU box (run through gpurun from the repo root):
 #   tools/collect_round_profiles.sh <tag>        e.g. r03
-# 1. bench.py (default command, then --config 4 and --config 5)      -> gpurun_out/<tag>/bench*.json
+# 1. (last, on the counters of step 3) bench.py: default command, --config 4, --config 5, --steps 20 -> gpurun_out/<tag>/bench*.json
 # 2. rocprofv3 --kernel-trace --stats of the SAME default command     -> gpurun_out/<tag>/kernel_stats_bench.csv
 # 3. rocprofv3 --pmc, four separate passes (FETCH_SIZE | WRITE_SIZE | instruction counts | LDS / wait counters) of
 #    tools/profile_step.py --mode all (dense fwd + bwd, the batched patch-grid pass, the 2-DoF sweep; built halo and run-time
@@ -12,10 +12,6 @@ TAG=${1:-r03}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 ROOT=$PWD
-python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-python bench.py --config 4 > "$OUT/bench_config4.json" 2> "$OUT/bench_config4.err"
-python bench.py --config 5 > "$OUT/bench_config5.json" 2> "$OUT/bench_config5.err"
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"   # the driver's form
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/prof_bench.err"
 PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU")
@@ -27,6 +23,13 @@ done
 cd "$ROOT"
 python tools/make_pmc_json.py "$OUT/pmc" "$OUT/pmc.json" "${COMMIT:-unknown}" > "$OUT/pmc_summary.txt" 2>&1
 find "$OUT/prof_bench" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_bench.csv"
+# the bench lines read profiles/pmc_latest.json / kernel_stats_latest.json: install this collection's (on the box) before they run
+cp "$OUT/pmc.json" profiles/pmc_latest.json
+python tools/make_kernel_stats_json.py "$OUT/kernel_stats_bench.csv" profiles/kernel_stats_latest.json "${COMMIT:-unknown}" > /dev/null
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python bench.py --config 4 > "$OUT/bench_config4.json" 2> "$OUT/bench_config4.err"
+python bench.py --config 5 > "$OUT/bench_config5.json" 2> "$OUT/bench_config5.err"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"   # the driver's form
 # keep the merge small: drop the per-dispatch traces
 find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*agent_info.csv" -delete
 head -12 "$OUT/kernel_stats_bench.csv" | cut -c1-200
