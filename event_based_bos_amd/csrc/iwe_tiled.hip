@@ -1788,6 +1788,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   Lerp* s_lerp = reinterpret_cast<Lerp*>(s_flow + 2 * PH * PW);    // GRID: [PH + PW] row / column interpolation
   // part_out != nullptr (dense): adaptive work items -- this workgroup is one part of a tile and writes its partial d_flow
   // tile to slab tr.slab of part_out; bwd_parts_combine_kernel sums the parts
+  // (the accumulator clear needs nothing: first, under the tile range's loads)
+  for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
   const TileRange tr = tile_range<FMT>(key_offsets, ev, TH * TW, tiles_x, GRID ? (adaptive ? 0 : 1) : (part_out ? 0 : 1));
   __shared__ double s_mom[2];
   __shared__ int s_spill;  // some event's taps left the LDS window of the upstream image
@@ -1965,7 +1967,6 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
   }
   EBOS_STAMP_BWD(1);
-  for (int i = threadIdx.x; i < 2 * TH * TW; i += kBlock) s_d[i] = 0.0;
   if (GRID || tr.g_first <= tr.g_last) {
     if (DYN && spec_hit) stage_store(raw_spec, kSpecStage);
     else stage_store(raw, kStage);
