@@ -876,7 +876,9 @@ class _EagerLoss(torch.Tensor):
     ``None``, added otherwise; scaled by ``gradient`` when one is given) without running the engine.  Every other use -- arithmetic
     with tensors, ``torch.*`` functions, ``grad_fn`` / ``requires_grad`` queries, ``backward`` with ``inputs`` / ``create_graph``
     -- first attaches the ordinary autograd node (_AttachGrad) and proceeds on that tensor, so results and graphs are those of
-    ``_FusedVarianceDense``.  ``item()`` / ``detach()`` / ``float()`` / f-strings read the value."""
+    ``_FusedVarianceDense``.  ``item()`` / ``detach()`` / ``float()`` / f-strings read the value.  ``torch.autograd.grad(loss, flow)``
+    dispatches the same way.  One entry point does not consult ``__torch_function__``: the FUNCTION ``torch.autograd.backward([loss])``
+    on the bare result raises ("does not require grad") instead of running -- use the method, or any expression of the result beyond a sign / Python weight (``loss + 0.0``)."""
 
     _VALUE_ONLY = {"item", "detach", "__float__", "__format__", "tolist", "__bool__", "__int__", "dim", "size", "numel", "__len__"}
 

@@ -437,6 +437,15 @@ def test_objective_backward_without_the_engine_keeps_autograd_semantics(ebos):
     assert seen == [1] and torch.equal(f3.grad, g_ref)
     with torch.no_grad():
         assert not plan.contrast_dense(f).requires_grad
+    # the functional entry points: autograd.grad dispatches through __torch_function__; autograd.backward (the function) does not
+    # consult it and must fail loudly on the bare result, never run silently past the flow
+    f4 = fl.clone().requires_grad_(True)
+    (g4,) = torch.autograd.grad(plan.contrast_dense(f4), f4)
+    assert torch.equal(g4, g_ref) and f4.grad is None
+    with pytest.raises(RuntimeError):
+        torch.autograd.backward([plan.contrast_dense(f4)])
+    torch.autograd.backward([plan.contrast_dense(f4) + 0.0])             # (any expression that is not a bare sign / weight attaches the node)
+    assert torch.equal(f4.grad, g_ref)
 
 
 def test_reference_idiom_is_fused_lazily(ebos, monkeypatch):
