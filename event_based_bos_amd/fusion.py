@@ -38,6 +38,7 @@ from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import torch
+from torch.utils import _pytree
 
 from .event_plan import EventPlan
 
@@ -113,7 +114,6 @@ class LazyWarped(torch.Tensor):
         if func in _LAZY_META:
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
-        from torch.utils import _pytree
         args, kwargs = _pytree.tree_map_only(LazyWarped, lambda a: a._real(), (tuple(args), kwargs))
         return func(*args, **kwargs)
 
