@@ -156,6 +156,12 @@ class EventPlan:
         """True when the tile-private kernels read the 6 B/event format (u16 pixel + f32 dt)."""
         return self.cpix is not None
 
+    def clear_cache(self) -> None:
+        """Free what the operators cached on the plan: workspaces, dense jobs and the sweep lanes of ``variance_2dof`` /
+        ``variance_dense_many`` (streams, one workspace per hypothesis of a chunk, image buffers -- up to 1.7 GB at 1280x720)."""
+        for k in ("_workspaces", "_jobs", "_sweep_lanes"):
+            self.__dict__.pop(k, None)
+
     def resolve_splits(self, splits: Optional[int]) -> int:
         """``splits`` of the tile-private forward kernels: k >= 1 cuts every tile into k equal parts, 0 uses the plan's
         adaptive work items (heavy tiles cut into parts, ``ebos_plan_parts``).  ``None`` picks 0 when the plan has a
@@ -400,17 +406,21 @@ class EventPlan:
         h, w = H + 2 * pad[0], W + 2 * pad[1]
         splits = self.resolve_splits(splits)
         out = torch.empty(K, dtype=torch.float32, device=self.device)
-        chunk = max(1, min(int(chunk), K))
-        n_streams = max(1, min(int(n_streams), (K + chunk - 1) // chunk))
+        n_streams = max(1, int(n_streams))
+        chunk = max(1, min(int(chunk), (K + n_streams - 1) // n_streams))  # (a short sweep does not allocate 16 workspaces per lane)
+        n_streams = max(1, min(n_streams, (K + chunk - 1) // chunk))
         persistent = self.compact and w % 4 == 0 and pad[1] % 4 == 0  # (what the batched pass asks of its images; else one launch per hypothesis)
         key = ("sweep", int(halo), int(splits), int(pad[0]), int(pad[1]), h, w, chunk, persistent)
         lanes = self.__dict__.setdefault("_sweep_lanes", {}).get(key)
-        nws = _workspace(self, pad, halo, splits).numel()
+        # (the size is asked of the library: _workspace() would allocate and cache a zero-filled workspace just to be measured)
+        nws = int(lib.ebos_iwe_slab_workspace_bytes(H, W, self.tile[0], self.tile[1], int(halo), int(splits), pad[0], pad[1]))
         nws_al = (nws + 255) // 256 * 256
         with _hip.on_device(self.device):
             if lanes is None or len(lanes) < n_streams:  # streams, workspaces and image buffers live with the plan
+                # one workspace per hypothesis of a chunk (36 MB each at 1280x720, tile 45x80, halo 32: 1.7 GB for 3 lanes of 16);
+                # EventPlan.clear_cache() frees them
                 lanes = [(torch.cuda.Stream(device=self.device),
-                          torch.zeros((chunk if persistent else 1) * nws_al, dtype=torch.uint8, device=self.device),  # (one workspace per hypothesis of a chunk)
+                          torch.zeros((chunk if persistent else 1) * nws_al, dtype=torch.uint8, device=self.device),
                           torch.empty((chunk, h, w), dtype=torch.float32, device=self.device)) for _ in range(n_streams)]
                 self.__dict__["_sweep_lanes"][key] = lanes
             cur = torch.cuda.current_stream(self.device)
@@ -868,6 +878,22 @@ class _AttachGrad(torch.autograd.Function):
         return d_flow * (g.to(torch.float32) * ctx.scale), None, None, None
 
 
+class _ConsumedGrad(torch.autograd.Function):
+    """What an _EagerLoss turns into once ``backward()`` has handed its gradient over: an ordinary tensor that still prints,
+    copies, compares and enters arithmetic like any result whose graph has been freed -- only a SECOND differentiation raises,
+    with the engine's own wording."""
+
+    @staticmethod
+    def forward(ctx, flow, value):
+        return value.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        raise RuntimeError("Trying to backward through the graph a second time: contrast_dense produced its gradient with the "
+                           "value and backward() has already handed it to flow.grad. Evaluate the objective again (it is one "
+                           "native call), or pass retain_graph=True to the first backward().")
+
+
 class _EagerLoss(torch.Tensor):
     """0-d result of ``contrast_dense`` whose gradient w.r.t. the (leaf) flow exists already.
 
@@ -876,16 +902,25 @@ class _EagerLoss(torch.Tensor):
     ``None``, added otherwise; scaled by ``gradient`` when one is given) without running the engine.  Every other use -- arithmetic
     with tensors, ``torch.*`` functions, ``grad_fn`` / ``requires_grad`` queries, ``backward`` with ``inputs`` / ``create_graph``
     -- first attaches the ordinary autograd node (_AttachGrad) and proceeds on that tensor, so results and graphs are those of
-    ``_FusedVarianceDense``.  ``item()`` / ``detach()`` / ``float()`` / f-strings read the value.  ``torch.autograd.grad(loss, flow)``
-    dispatches the same way.  One entry point does not consult ``__torch_function__``: the FUNCTION ``torch.autograd.backward([loss])``
-    on the bare result raises ("does not require grad") instead of running -- use the method, or any expression of the result beyond a sign / Python weight (``loss + 0.0``)."""
+    ``_FusedVarianceDense``.  ``item()`` / ``detach()`` / ``float()`` / f-strings / ``print`` / comparisons read the value.
+    ``torch.autograd.grad(loss, flow)`` dispatches the same way.  One entry point does not consult ``__torch_function__``: the
+    FUNCTION ``torch.autograd.backward([loss])`` on the bare result raises ("does not require grad") instead of running -- use the
+    method, or any expression of the result beyond a sign / Python weight (``loss + 0.0``).
 
-    _VALUE_ONLY = {"item", "detach", "__float__", "__format__", "tolist", "__bool__", "__int__", "dim", "size", "numel", "__len__"}
+    A result and its scaled descendants (``-loss``, ``k * loss``) share ONE gradient cell: the first ``backward()`` among them
+    consumes it for all (as the engine frees the graph they would share), after which each of them is an ordinary tensor whose
+    second differentiation raises (_ConsumedGrad) and whose every other use -- ``print``, ``cpu``, ``clone``, arithmetic for
+    logging -- works."""
+
+    _VALUE_ONLY = {"item", "detach", "__float__", "__format__", "tolist", "__bool__", "__int__", "dim", "size", "numel", "__len__",
+                   "__repr__", "__str__", "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__", "lt", "le", "gt", "ge", "eq",
+                   "ne", "isnan", "isfinite", "isinf"}
 
     @staticmethod
-    def wrap(value: torch.Tensor, flow: torch.Tensor, d_flow: torch.Tensor, scale: float = 1.0) -> "_EagerLoss":
+    def wrap(value: torch.Tensor, flow: torch.Tensor, d_flow: torch.Tensor, scale: float = 1.0, cell=None) -> "_EagerLoss":
         t = torch.Tensor._make_subclass(_EagerLoss, value)
-        t._ebos = [flow, d_flow, None, scale]  # flow, gradient of the UNSCALED value (None once handed over), attached tensor, factor
+        # flow, shared cell [gradient of the UNSCALED value | None once handed over], attached tensor, factor
+        t._ebos = [flow, cell if cell is not None else [d_flow], None, scale]
         return t
 
     def _plain(self) -> torch.Tensor:
@@ -895,17 +930,17 @@ class _EagerLoss(torch.Tensor):
     def _attached(self) -> torch.Tensor:
         st = self._ebos
         if st[2] is None:
-            if st[1] is None:
-                raise RuntimeError("contrast_dense: backward() has already consumed this result's gradient; evaluate again "
-                                   "(the objective is one native call) or combine the result into a graph before backward()")
-            st[2] = _AttachGrad.apply(st[0], self._plain(), st[1], st[3])
+            if st[1][0] is None:  # consumed (by this object or a scaled relative): an ordinary tensor with a freed graph
+                st[2] = _ConsumedGrad.apply(st[0], self._plain())
+            else:
+                st[2] = _AttachGrad.apply(st[0], self._plain(), st[1][0], st[3])
         return st[2]
 
     def _scaled(self, k) -> "_EagerLoss":
         st = self._ebos
-        if st[2] is not None or st[1] is None:  # already a graph node (or consumed): the ordinary path
+        if st[2] is not None or st[1][0] is None:  # already a graph node (or consumed): the ordinary path
             return self._attached() * k
-        return _EagerLoss.wrap(self._plain() * k, st[0], st[1], st[3] * float(k))
+        return _EagerLoss.wrap(self._plain() * k, st[0], None, st[3] * float(k), cell=st[1])
 
     def __neg__(self):
         return self._scaled(-1.0)
@@ -921,20 +956,22 @@ class _EagerLoss(torch.Tensor):
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         st = self._ebos
-        flow = st[0]
-        if st[2] is not None or create_graph or inputs is not None or st[1] is None or flow._backward_hooks or \
+        flow, cell = st[0], st[1]
+        if st[2] is not None or create_graph or inputs is not None or cell[0] is None or flow._backward_hooks or \
                 getattr(flow, "_post_accumulate_grad_hooks", None):
             return self._attached().backward(gradient, retain_graph, create_graph, inputs)
-        g, k = st[1], st[3]
-        if retain_graph:
-            g = g.clone()
-        else:
-            st[1] = None  # the buffer now belongs to flow.grad (or is consumed by the add)
+        g, k = cell[0], st[3]
         with torch.no_grad():
             if gradient is not None:
-                g.mul_(gradient.to(device=g.device, dtype=torch.float32) * k)
-            elif k != 1.0:
-                g.mul_(k)
+                f = gradient.to(device=g.device, dtype=torch.float32) * k
+            else:
+                f = None if k == 1.0 else k
+            if retain_graph:
+                g = g * f if f is not None else g.clone()  # the cell keeps the unscaled gradient for the next backward()
+            else:
+                cell[0] = None  # consumed for this object AND its scaled relatives; the buffer now belongs to flow.grad
+                if f is not None:
+                    g.mul_(f)
             if flow.grad is None:
                 flow.grad = g
             else:

@@ -22,10 +22,34 @@ for P in "${PASSES[@]}"; do
 done
 cd "$ROOT"
 python tools/make_pmc_json.py "$OUT/pmc" "$OUT/pmc.json" "${COMMIT:-unknown}" > "$OUT/pmc_summary.txt" 2>&1
+PMC_RC=$?
 find "$OUT/prof_bench" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_bench.csv"
 # the bench lines read profiles/pmc_latest.json / kernel_stats_latest.json: install this collection's (on the box) before they run
+# -- but only a collection that holds what they read.  A failed or empty rocprofv3 pass still yields a JSON stamped with the current
+# blob hash and an empty kernel table; installed, it would replace the committed evidence by "no counters" (ADVICE r03).
+python tools/make_kernel_stats_json.py "$OUT/kernel_stats_bench.csv" "$OUT/kernel_stats.json" "${COMMIT:-unknown}" > /dev/null
+KS_RC=$?
+python - "$OUT/pmc.json" "$OUT/kernel_stats.json" "$PMC_RC" "$KS_RC" <<'PY'
+import json, sys
+pmc_path, ks_path, pmc_rc, ks_rc = sys.argv[1:5]
+ok = pmc_rc == "0" and ks_rc == "0"
+try:
+    k = json.load(open(pmc_path))["kernels"]
+    acc = next((v for n, v in k.items() if "iwe_slab_accumulate_kernel" in n), None)
+    ok = ok and acc is not None and acc.get("hbm_bytes_per_launch") and acc.get("SQ_INSTS_VALU")
+    ks = json.load(open(ks_path))["kernels"]
+    ok = ok and any("iwe_slab_accumulate_kernel" in n for n in ks)
+except Exception as e:  # missing / malformed file
+    print("collect_round_profiles: unreadable collection:", e, file=sys.stderr)
+    ok = False
+sys.exit(0 if ok else 1)
+PY
+if [ $? -ne 0 ]; then
+  echo "collect_round_profiles: the counter / kernel-stats collection is incomplete; profiles/*_latest.json left as they were" >&2
+  exit 1
+fi
 cp "$OUT/pmc.json" profiles/pmc_latest.json
-python tools/make_kernel_stats_json.py "$OUT/kernel_stats_bench.csv" profiles/kernel_stats_latest.json "${COMMIT:-unknown}" > /dev/null
+cp "$OUT/kernel_stats.json" profiles/kernel_stats_latest.json
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --config 4 > "$OUT/bench_config4.json" 2> "$OUT/bench_config4.err"
 python bench.py --config 5 > "$OUT/bench_config5.json" 2> "$OUT/bench_config5.err"
