@@ -119,6 +119,10 @@ SIGNATURES = {
     "ebos_cmax_adam_step_f32": (_I, [_P, _P, _P, _P, _I, _D, _D, _D, _D, _P, _P, _F, _P, _I, _P, _I, _P]),
     "ebos_cmax_patch_solve_f32": (_I, [_P, _I, _P]),
     "ebos_cmax_patch_solve_many_f32": (_I, [_P, _P, _I, _I]),
+    "ebos_cmax_resident_mailbox_bytes": (_Z, [_I, _I, _I, _I]),
+    "ebos_cmax_resident_supported": (_I, [_P]),
+    "ebos_cmax_patch_solve_resident_f32": (_I, [_P, _I, _P, _Z, _D, _P]),
+    "ebos_cmax_resident_status": (_I, [_P, _P]),
     "ebos_gauss1d_f32": (_I, _GAUSS),
     "ebos_gauss1d_f64": (_I, _GAUSS),
     "ebos_gauss1d_bwd_f32": (_I, _GAUSS),

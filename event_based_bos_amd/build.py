@@ -23,7 +23,7 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libebos_hip.so")
 
 SOURCES = ["errors.cpp", "warp_kernels.hip", "splat_kernels.hip", "event_plan.hip", "plan_lean.hip", "iwe_fused.hip", "iwe_tiled.hip",
-           "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip", "solver_kernels.hip"]
+           "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip", "solver_kernels.hip", "cmax_resident.hip"]
 
 # -munsafe-fp-atomics: hardware global_atomic_add_f32/f64 and ds_add_f32 instead of CAS loops.
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC",
@@ -47,7 +47,7 @@ def _needs_rebuild(target: str, deps: List[str]) -> bool:
 def _compile(src: str, extra: List[str]) -> str:
     obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "ebos_hip.h"), __file__]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(INCLUDE, "ebos_hip.h"), __file__]
     if _needs_rebuild(obj, [path] + headers):
         cmd = [hipcc()] + HIPCC_FLAGS + extra + ["-x", "hip", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -65,7 +65,7 @@ def build_library(force: bool = False, keep_temps: bool = False, verbose: bool =
             os.remove(os.path.join(OBJ_DIR, f))
     extra = ["-save-temps=obj"] if keep_temps else []
     extra += os.environ.get("EBOS_EXTRA_FLAGS", "").split()  # e.g. -DEBOS_STAMPS for the diagnostic build
-    with cf.ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, extra), SOURCES))
     if force or _needs_rebuild(LIB_PATH, objs):
         cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs

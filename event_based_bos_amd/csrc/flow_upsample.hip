@@ -125,12 +125,11 @@ __device__ __forceinline__ void adam_apply(const AdamJob& job, int64_t i, const 
   if (job.grad_mask != nullptr) g *= a.mask;
   d_grid[i] = g;
   if (job.theta != nullptr) {
-    const float mi = a.m + job.w1 * (g - a.m);                            // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = a.v * job.beta2 + job.w2 * (g * g);                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    job.exp_avg[i] = mi;
-    job.exp_avg_sq[i] = vi;
-    const float denom = sqrtf(vi) / job.bc2_sqrt + job.eps;               // (exp_avg_sq.sqrt() / sqrt(bias_correction2)) + eps
-    job.theta[i] = a.th - job.step_size * (mi / denom);                   // param.addcdiv_(exp_avg, denom, value = -step_size)
+    float m = a.m, v = a.v, th = a.th;
+    adam_update(g, m, v, th, job.step_size, job.bc2_sqrt, job.beta2, job.w1, job.w2, job.eps);  // (patch_grid.h: one arithmetic for every kernel)
+    job.exp_avg[i] = m;
+    job.exp_avg_sq[i] = v;
+    job.theta[i] = th;
   }
 }
 __device__ __forceinline__ void adam_apply(const AdamJob& job, int64_t i, int64_t cell, float g, float* __restrict__ d_grid) {
@@ -276,13 +275,13 @@ static int make_adam_job(ebos::AdamJob* out, float* theta, float* exp_avg, float
   EBOS_REQUIRE(t >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
                "%s: bad hyper-parameters (t = %d)", who, t);
   EBOS_REQUIRE(n_reg >= 0 && (n_reg == 0 || reg_partials) && losses_cap >= 0, "%s: bad loss bookkeeping", who);
-  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  const AdamCoef coef = adam_coef(lr, beta1, beta2, t);  // (bias corrections of step t, in double, as torch computes them)
   AdamJob job{};
   job.theta = theta;
   job.exp_avg = exp_avg;
   job.exp_avg_sq = exp_avg_sq;
-  job.step_size = (float)(lr / bc1);
-  job.bc2_sqrt = (float)sqrt(bc2);
+  job.step_size = coef.step_size;
+  job.bc2_sqrt = coef.bc2_sqrt;
   job.beta2 = (float)beta2;
   job.w1 = (float)(1.0 - beta1);
   job.w2 = (float)(1.0 - beta2);

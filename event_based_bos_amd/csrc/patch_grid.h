@@ -34,7 +34,7 @@ struct Lerp {
   float w0, w1;
 };
 
-__device__ __forceinline__ Lerp lerp_at(const Axis& a, int r) {
+__host__ __device__ __forceinline__ Lerp lerp_at(const Axis& a, int r) {
   const int R = r + a.off;
   float src = ((float)R + 0.5f) / (float)a.slide - 0.5f;  // align_corners = False
   if (src < 0.0f) src = 0.0f;
@@ -60,7 +60,7 @@ __device__ __forceinline__ float grid_bilerp(const float* __restrict__ g0, const
 }
 
 // conservative range [lo, hi) of output rows / columns whose interpolation can touch grid cell gi
-__device__ __forceinline__ void support(const Axis& a, int gi, int n_out, int* lo, int* hi) {
+__host__ __device__ __forceinline__ void support(const Axis& a, int gi, int n_out, int* lo, int* hi) {
   // padded indices that clamp onto this cell, +-1 cell of bilinear support, in output pixels
   const int p_lo = gi == 0 ? 0 : gi + a.pad, p_hi = gi == a.g - 1 ? a.n_in - 1 : gi + a.pad;
   int l = (p_lo - 1) * a.slide - a.off - 1, h = (p_hi + 2) * a.slide - a.off + 1;
@@ -92,6 +92,43 @@ __device__ __forceinline__ float tv_adjoint(const float* f, int i, int n, int64_
   if (i == 0) g -= sgn(central(f, 0, n, st));
   if (i == n - 1) g += sgn(central(f, n - 1, n, st));
   return g;
+}
+
+// ---- Adam (torch.optim.Adam, amsgrad off, no weight decay), shared by every kernel that steps the patch grid so that they
+// round alike: the four-launch pipeline's cell combine pass (flow_upsample.hip) and the resident solver kernel
+// (cmax_resident.hip) must follow the SAME trajectory bit for bit -- a last-bit difference in one step is amplified by the
+// kinks of the piecewise-linear objective over a few hundred iterations.
+struct AdamCoef {
+  float step_size;  // lr / (1 - beta1^t)
+  float bc2_sqrt;   // sqrt(1 - beta2^t)
+};
+// beta^t by repeated squaring: IEEE products only, so the host (make_adam_job) and the device (resident kernel) get the same bits
+__host__ __device__ inline double pow_int(double b, int t) {
+  double r = 1.0, p = b;
+  while (t > 0) {
+    if (t & 1) r *= p;
+    p *= p;
+    t >>= 1;
+  }
+  return r;
+}
+__host__ __device__ inline AdamCoef adam_coef(double lr, double beta1, double beta2, int t) {
+  const double bc1 = 1.0 - pow_int(beta1, t), bc2 = 1.0 - pow_int(beta2, t);
+  AdamCoef c;
+  c.step_size = (float)(lr / bc1);
+  c.bc2_sqrt = (float)sqrt(bc2);
+  return c;
+}
+// one element's step; contraction off: every kernel executes exactly these multiplies and adds
+__device__ __forceinline__ void adam_update(float g, float& m, float& v, float& th, float step_size, float bc2_sqrt, float beta2,
+                                            float w1, float w2, float eps) {
+#pragma clang fp contract(off)
+  const float mi = m + w1 * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = v * beta2 + w2 * (g * g);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;    // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+  m = mi;
+  v = vi;
+  th = th - step_size * (mi / denom);                // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
 }  // namespace ebos

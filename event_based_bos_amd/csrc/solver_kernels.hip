@@ -138,17 +138,14 @@ cmax_adam_step_kernel(float* __restrict__ theta, const float* __restrict__ grad,
                       const float* __restrict__ contrast, float contrast_scale, const double* __restrict__ reg_partials,
                       int n_reg, float* __restrict__ losses, int losses_cap) {
   const int t = step[0] + 1;
-  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
-  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const AdamCoef coef = adam_coef(lr, beta1, beta2, t);
   const float b2 = (float)beta2, w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2), e = (float)eps;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float g = grad[i];
-    const float mi = m[i] + w1 * (g - m[i]);        // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * b2 + w2 * (g * g);      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    float mi = m[i], vi = v[i], th = theta[i];
+    adam_update(grad[i], mi, vi, th, coef.step_size, coef.bc2_sqrt, b2, w1, w2, e);  // (patch_grid.h: one arithmetic for every kernel)
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + e;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
-    theta[i] = theta[i] - step_size * (mi / denom); // param.addcdiv_(exp_avg, denom, value = -step_size)
+    theta[i] = th;
   }
   double reg = 0.0;
   for (int i = threadIdx.x; i < n_reg; i += blockDim.x) reg += reg_partials[i];

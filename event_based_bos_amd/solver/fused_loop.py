@@ -118,6 +118,9 @@ class FusedPatchLoop(object):
         self.reg_partials = torch.zeros(max(self.n_reg, 1), dtype=torch.float64, device=dev)
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.graphed = False  # kept for callers that report it: this loop is never graph-replayed
+        self._mailbox = None          # flags / records / status word of the resident launch (allocated on first use)
+        self.resident_status = 0      # status of the last resident launch (0 = completed)
+        self.last_run_mode = "pipeline"
         import ctypes as C
         off, n_parts, n_px = C.c_size_t(), C.c_int64(), C.c_int64()
         check(self.lib.ebos_iwe_slab_partials(H, W, plan.tile[0], plan.tile[1], self.halo, self.splits, self.pad[0], self.pad[1],
@@ -252,8 +255,36 @@ class FusedPatchLoop(object):
         q.grad_partials_bytes = self.grad_partials.numel() * 4 if self.grad_partials is not None else 0
         return q
 
-    def run(self, n_iter: int, native: bool = True) -> torch.Tensor:
+    def resident_supported(self) -> bool:
+        """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_patch_solve_resident_f32)?  Grid-sampling route, variance
+        contrast, one work item per tile, no padding, a tile / halo with a resident kernel, few enough tiles to be co-resident."""
+        if not self.sample_grid or self.w_gm or self.splits != 1 or self.pad != (0, 0):
+            return False
+        import ctypes
+
+        return bool(self.lib.ebos_cmax_resident_supported(ctypes.byref(self.problem())))
+
+    def run_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> int:
+        """``n_iter`` iterations as one resident launch; returns its status after synchronising: 0, or a negative code when the
+        launch ended early (-101 a wait passed the cap, -102 a tap left the largest LDS window, -103 geometry) -- theta and the
+        optimiser state are then UNCHANGED and the caller runs the four-launch pipeline (``run`` does)."""
+        import ctypes
+
+        if self._mailbox is None:
+            H, W = self.plan.image_size
+            nb = int(self.lib.ebos_cmax_resident_mailbox_bytes(H, W, self.plan.tile[0], self.plan.tile[1]))
+            self._mailbox = torch.zeros(nb, dtype=torch.uint8, device=self.plan.device)
+        s = stream_ptr()
+        check(self.lib.ebos_cmax_patch_solve_resident_f32(ctypes.byref(self.problem()), int(n_iter), ptr(self._mailbox),
+                                                          self._mailbox.numel(), float(spin_timeout_s), s),
+              "ebos_cmax_patch_solve_resident")
+        return int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), s))
+
+    def run(self, n_iter: int, native: bool = True, resident: Optional[bool] = None) -> torch.Tensor:
         """``n_iter`` more iterations; returns their losses [n_iter] (device).
+        ``resident`` (default: whenever ``resident_supported()``; ``EBOS_RESIDENT=0`` turns the default off): the whole loop as
+        ONE resident launch; a launch that ends early (status < 0: see ``run_resident``) leaves the state untouched and the
+        four-launch pipeline below runs instead.  The resident call synchronises the stream once, to read its status.
         ``native`` (default): one C call enqueues the whole loop (ebos_cmax_patch_solve_f32); otherwise one Python call
         per kernel group.  (A HIP-graph replay of the iteration was measured slower than plain launches on ROCm 7.2 --
         172 vs 111 us at 2 M events -- and cannot carry the step number, which is a kernel argument.)"""
@@ -261,7 +292,18 @@ class FusedPatchLoop(object):
         if self.t + n_iter > self.losses.numel():
             raise ValueError(f"capacity {self.losses.numel()} < {self.t} steps done + {n_iter}")
         t0 = self.t
+        if resident is None:
+            resident = native and os.environ.get("EBOS_RESIDENT", "1") != "0" and self.resident_supported()
+        elif resident and not self.resident_supported():
+            raise ValueError("resident=True: " + (self.lib.ebos_last_error() or b"").decode())
+        self.last_run_mode = "pipeline"
         with _hip.on_device(self.plan.device):
+            if resident and n_iter > 0:
+                self.resident_status = self.run_resident(n_iter)
+                if self.resident_status == 0:
+                    self.t += n_iter
+                    self.last_run_mode = "resident"
+                    return self.losses[t0:t0 + n_iter]
             if native:
                 import ctypes
 

@@ -700,6 +700,32 @@ int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* problem, int n_iter
 int ebos_cmax_patch_solve_many_f32(const ebos_cmax_patch_problem* problems, const ebos_stream_t* streams,
                                    int n_problems, int n_iter);
 
+
+/* ---- the same loop as ONE resident launch (csrc/cmax_resident.hip) -------------------------------------------------------------
+ * Replaces, for one window, the n_iter x 4 launches that ebos_cmax_patch_solve_f32 enqueues for the loop of
+ * src/solver/generative_max_likelihood.py:306-341 (600 iterations over the SAME events, configs/hot_plate1.yaml:70): one
+ * 1024-thread workgroup per source tile stays resident for all iterations, keeps its tile's geometry, grid cells and Adam state
+ * in registers / LDS, and exchanges only slabs, (sum, sum of squares) records and partial cell gradients with its neighbours
+ * through `workspace`, `grad_partials` and `mailbox`.  Same `problem` struct, same results (IWE bit-identical; losses to ~1e-7).
+ *
+ *   ebos_cmax_resident_supported   1 when `problem` can run resident: grid-sampling route on a compact plan, variance contrast,
+ *                                  splits == 1, no padding, tile / halo with a resident kernel ((45, 80, 32), (32, 32, 32)),
+ *                                  cells whose supports span <= 4 tiles per axis; 0 otherwise (reason: ebos_last_error)
+ *   mailbox                        device memory of ebos_cmax_resident_mailbox_bytes(...): flags, records, the status word;
+ *                                  cleared by every call
+ *   spin_timeout_s                 cap of every in-kernel wait (seconds; e.g. 2.0).  The grid must be co-resident -- the call
+ *                                  checks tiles <= CUs x occupancy and orders resident launches of one device behind each other --
+ *                                  but if a wait still passes the cap (another process's resident grid interleaved with this
+ *                                  one), or a tap leaves the largest LDS window (the spill path of the four-launch pipeline),
+ *                                  the launch ENDS instead of hanging and leaves theta / exp_avg / exp_avg_sq / step untouched.
+ *   ebos_cmax_resident_status      synchronises `stream`, returns EBOS_OK or a negative code (-101 spin cap, -102 spill,
+ *                                  -103 geometry); on a negative code run ebos_cmax_patch_solve_f32 with the same problem.  */
+size_t ebos_cmax_resident_mailbox_bytes(int H, int W, int tile_h, int tile_w);
+int ebos_cmax_resident_supported(const ebos_cmax_patch_problem* problem);
+int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* problem, int n_iter, void* mailbox, size_t mailbox_bytes,
+                                       double spin_timeout_s, ebos_stream_t stream);
+int ebos_cmax_resident_status(const void* mailbox, ebos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

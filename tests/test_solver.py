@@ -451,3 +451,74 @@ def test_solver_halo_option_selects_the_small_window_configuration():
     # WINDOW, so two window sizes round differently at the 1e-5 level and 25 Adam steps carry that along)
     np.testing.assert_allclose(out[16][0], out[32][0], rtol=2e-4)
     assert np.abs(out[16][1] - out[32][1]).max() < 5e-3, np.abs(out[16][1] - out[32][1]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,n_ev,patch,terms", [
+    ((96, 128), 20_000, (24, 32), (1.0, 0.01, 0.02)),      # 12 tiles of 32 x 32: the small end (image_gradient on: the apron's cells)
+    ((260, 346), 100_000, (20, 20), (1.0, 0.001, 0.0)),    # BASELINE configs[0]'s size: 99 tiles, W % 4 != 0 (scalar image stores)
+    ((720, 1280), 400_000, (24, 32), (1.0, 0.001, 0.0)),   # 256 tiles of 45 x 80: one workgroup per CU
+])
+def test_resident_loop_matches_the_four_launch_pipeline(size, n_ev, patch, terms):
+    """The loop of src/solver/generative_max_likelihood.py:306-341 as ONE resident launch (ebos_cmax_patch_solve_resident_f32)
+    against the four-launch pipeline (ebos_cmax_patch_solve_f32): the first IWE bit for bit (same order of additions), losses to
+    1e-6 relative over 300 iterations, patch flows and optimiser state to 1e-5; a resident run can be continued by the pipeline."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w = size
+    rs = np.random.RandomState(11)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+    theta0 = torch.from_numpy(rs.uniform(-3, 3, (2, gh, gw))).float()
+    n_iter = 300
+
+    def make():
+        return FusedPatchLoop(plan, patch, patch, theta0, *terms, halo="auto", lr=0.05, capacity=n_iter + 20)
+
+    ref, res = make(), make()
+    assert res.resident_supported(), ebos.load_library().ebos_last_error()
+    ref.run(1, resident=False)
+    res.run(1, resident=True)
+    assert res.last_run_mode == "resident" and res.resident_status == 0
+    assert torch.equal(ref.iwe, res.iwe)                                  # the image of the first iteration: same bits
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=1e-6)
+    l_ref = ref.run(n_iter - 1, resident=False).cpu().numpy()
+    l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
+    print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
+    np.testing.assert_allclose(l_res, l_ref, rtol=1e-6)
+    np.testing.assert_allclose(ref.losses[:n_iter].cpu().numpy(), res.losses[:n_iter].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(res.exp_avg.cpu().numpy(), ref.exp_avg.cpu().numpy(), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(res.d_theta.cpu().numpy(), ref.d_theta.cpu().numpy(), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=1e-6)
+    # continued by the other mode
+    a = ref.run(10, resident=True).cpu().numpy()
+    b = res.run(10, resident=False).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
+    """A flow whose displacements leave the largest LDS window: the resident launch must END (status -102), leave theta and the
+    optimiser state untouched, and ``run`` must produce the four-launch pipeline's result."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w, n_ev, patch = 96, 128, 20_000, (24, 32)
+    rs = np.random.RandomState(12)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    theta0 = torch.full((2, 4, 4), 45.0)   # 45 px > the 32 px window
+    ref = FusedPatchLoop(plan, patch, patch, theta0, 1.0, 0.01, 0.0, halo="auto", lr=0.05, capacity=16)
+    res = FusedPatchLoop(plan, patch, patch, theta0, 1.0, 0.01, 0.0, halo="auto", lr=0.05, capacity=16)
+    status = res.run_resident(5)
+    assert status == -102, status
+    assert torch.equal(res.theta, theta0.cuda()) and int(res.step.item()) == 0 and float(res.exp_avg.abs().max()) == 0.0
+    l_ref = ref.run(5, resident=False).cpu().numpy()
+    l_res = res.run(5).cpu().numpy()                      # default mode: tries resident, falls back
+    assert res.last_run_mode == "pipeline" and res.resident_status == -102
+    np.testing.assert_array_equal(l_ref, l_res)
+    assert torch.equal(ref.theta, res.theta)
