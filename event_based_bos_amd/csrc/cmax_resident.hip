@@ -54,6 +54,20 @@ __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store((
 // every storing wave, before the barrier behind which the flag is stored (inline asm: invisible to the pass that drops waits)
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// In-kernel phase stamps (diagnostic builds: EBOS_EXTRA_FLAGS=-DEBOS_STAMPS): workgroup b, phase k of the LAST iteration ->
+// g_rstamps[b * 16 + k] (100 MHz clock); read with ebos_debug_read_stamps_resident, tools/stamp_resident.py
+#ifdef EBOS_STAMPS
+__device__ unsigned long long g_rstamps[1024 * 16];
+#define EBOS_RSTAMP(k)                                                                                   \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && it == n_iter - 1) g_rstamps[blockIdx.x * 16 + (k)] = wall_clock64();         \
+  } while (0)
+#else
+#define EBOS_RSTAMP(k) \
+  do {                 \
+  } while (0)
+#endif
+
 enum ResidentStatus : unsigned {
   RES_OK = 0,
   RES_TIMEOUT = 1,   // a wait passed the caller's cap (a workgroup not resident, another resident launch interleaved, ...)
@@ -152,8 +166,29 @@ __device__ __forceinline__ void tile_flow_from_cells(const Lerp* s_rows, const L
   }
 }
 
+// Register pressure decides this kernel's speed between its phases: kept live across the event loops (each of which wants ~100
+// VGPRs and ~100 SGPRs for itself), the 80 dwords of arguments and the tile's geometry were spilled -- 1200 lane moves and 380
+// scratch accesses per iteration, every phase 1.5 - 2 x the time of its stand-alone kernel (first version: 53.6 us per iteration
+// at 2 M events against 42.7 us for the four launches).  So nothing uniform is carried: every phase reads the arguments it needs
+// afresh from the kernel-argument segment (scalar loads behind an opaque asm: the compiler can neither hoist them out of the
+// iteration loop nor merge them across phases) and the geometry from a small LDS block.
+typedef const __attribute__((address_space(4))) ResidentArgs KArgs;
+__device__ __forceinline__ KArgs& fresh_args() {
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(KArgs*)p;
+}
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct Persist {  // one workgroup's iteration-invariant geometry
+  int g_first, g_last, beg, end;                   // its slice of the plan (TileRange)
+  int gi0, ni, gj0, nj;                            // the block of grid cells tile + apron touch
+  int rect_ty0, rect_tx0, rect_ny, rect_nx;        // the tiles whose partial cell gradients that block's cells sum
+};
+
 template <int TH, int TW, int HALO>
-__global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a) {
+__global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_unused) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the stub: the body copies structs out of the constant address space)
   constexpr int kLHmax = TH + 2 * HALO, kLWmax = TW + 2 * HALO;
   constexpr int kCells = acc_cells<TH, TW, HALO, true>();
   constexpr int AP = kBwdApron, PH = TH + 2 * AP, PW = TW + 2 * AP;
@@ -167,354 +202,454 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a) {
   float* s_g = reinterpret_cast<float*>(s_raw + 2 * TH * TW);           //           [LH][LW] upstream window
   float* s_flow_b = s_g + kLHmax * kLWmax;                              //           [2][PH][PW] flow of tile + apron
   Lerp* s_lerp = reinterpret_cast<Lerp*>(reinterpret_cast<char*>(s_raw) + resident_union_bytes<TH, TW, HALO>());  // [PH + PW]
-  float* s_cells = reinterpret_cast<float*>(s_lerp + PH + PW);         // [2][kGridCells][kGridCells]
+  float* s_cells = reinterpret_cast<float*>(s_lerp + PH + PW);         // [2][kGridCells][kGridCells]: theta of the block
   __shared__ TileShared sh;
+  __shared__ Persist P;
   __shared__ int s_spill, s_bad, s_ok;
   __shared__ unsigned s_next;
   __shared__ float s_gmax[2 * kWaves];
   __shared__ unsigned s_win[9];
   __shared__ double s_mom[4];    // mean, variance, sum of the regulariser partials of the previous iteration
-  __shared__ double s_reg;       // this tile's regulariser value partial
-  __shared__ float s_adam[2];    // step size and sqrt(bias correction 2) of the iteration's Adam step
+  __shared__ double s_reg[2];    // this tile's regulariser value partial: of this iteration, of the previous one
+  __shared__ float s_adam[3];    // step size and sqrt(bias correction 2) of the iteration's Adam step; variance of the previous iteration
   __shared__ double s_red[3 * kWaves];
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int n_tiles = a.tiles_y * a.tiles_x;
-  const int tile = blockIdx.x, ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-  const int tr0 = ty * TH, tc0 = tx * TW, H = a.H, W = a.W;
-  const TileRange tr = tile_range<FMT_COMPACT>(a.key_offsets, a.ev, TH * TW, a.tiles_x, 1);
-  const Axis ay = a.gs.ay, ax = a.gs.ax;
+  const int tile = blockIdx.x;
 
   // ---- once: interpolation tables of tile + apron, the block of cells they touch, this thread's element of it -------------------
-  for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
-  for (int i = threadIdx.x; i < PH + PW; i += kBlock)
-    s_lerp[i] = i < PH ? lerp_at(ay, min(max(tr0 + i - AP, 0), H - 1)) : lerp_at(ax, min(max(tc0 + i - PH - AP, 0), W - 1));
-  // events per source pixel (the backward scatter's fixed-point unit): of the plan, not of the iteration
+  float m_e = 0.0f, v_e = 0.0f, g_e = 0.0f;
+  unsigned cand_a = 0, cand_b = 0;  // which tiles' partials this thread's cell sums (below)
+  bool has, owner = false;
+  int n_iter;
   {
-    int nmax_t = 1;
-    const int32_t* ko = a.key_offsets + (int64_t)tile * (TH * TW);
+    KArgs& a = fresh_args();
+    n_iter = a.n_iter;
+    const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
+    const Axis ay = a.gs.ay, ax = a.gs.ax;
+    const EvPtrs ev = a.ev;
+    const int32_t* key_offsets = a.key_offsets;
+    for (int i = threadIdx.x; i < kCells / 2; i += kBlock) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+    for (int i = threadIdx.x; i < PH + PW; i += kBlock)
+      s_lerp[i] = i < PH ? lerp_at(ay, min(max(tr0 + i - AP, 0), H - 1)) : lerp_at(ax, min(max(tc0 + i - PH - AP, 0), W - 1));
+    {  // events per source pixel (the backward scatter's fixed-point unit): of the plan, not of the iteration
+      int nmax_t = 1;
+      const int32_t* ko = key_offsets + (int64_t)tile * (TH * TW);
 #pragma unroll
-    for (int k = 0; k < (TH * TW + kBlock - 1) / kBlock; ++k) {
-      const int i = min((int)threadIdx.x + k * kBlock, TH * TW - 1);
-      nmax_t = max(nmax_t, ko[i + 1] - ko[i]);
+      for (int k = 0; k < (TH * TW + kBlock - 1) / kBlock; ++k) {
+        const int i = min((int)threadIdx.x + k * kBlock, TH * TW - 1);
+        nmax_t = max(nmax_t, ko[i + 1] - ko[i]);
+      }
+      const float nm = wave_max_nonneg((float)nmax_t);
+      if (lane == 0) s_gmax[kWaves + wave] = nm;
     }
-    const float nm = wave_max_nonneg((float)nmax_t);
-    if (lane == 0) s_gmax[kWaves + wave] = nm;
-  }
-  if (threadIdx.x == 0) s_ok = 1;
-  __syncthreads();
-  const int gi0 = s_lerp[0].i0, ni = s_lerp[PH - 1].i1 - gi0 + 1;
-  const int gj0 = s_lerp[PH].i0, nj = s_lerp[PH + PW - 1].i1 - gj0 + 1;
-  const bool has = (int)threadIdx.x < 2 * ni * nj;  // this thread holds element (ch, gi0 + ci, gj0 + cj) of the cell block
-  const int e_ = has ? (int)threadIdx.x : 0;
-  const int ch = e_ / (ni * nj), ci = (e_ - ch * (ni * nj)) / nj, cj = e_ - ch * (ni * nj) - ci * nj;
-  const int gi = gi0 + ci, gj = gj0 + cj;
-  const int64_t gidx = ((int64_t)ch * ay.g + gi) * ax.g + gj;
-  float th_e = 0.0f, m_e = 0.0f, v_e = 0.0f, g_e = 0.0f, mask_e = 1.0f;
-  if (has) {
-    th_e = a.theta[gidx], m_e = a.exp_avg[gidx], v_e = a.exp_avg_sq[gidx];
-    if (a.theta_mask != nullptr) mask_e = a.theta_mask[(int64_t)gi * ax.g + gj];
-  }
-  // which tiles' partial cell gradients this cell sums (the arithmetic of patch_grad_combine_kernel, flow_upsample.hip): <= kSpan
-  // candidate tiles per axis from the cell's conservative pixel support; a candidate counts if its own cell block holds the cell
-  int cand_ty0 = 0, cand_tx0 = 0;
-  unsigned cand_y = 0, cand_x = 0;  // per candidate k: bit 4 k + 3 = valid, bits 4 k .. 4 k + 2 ... (index of the cell in that tile's block: 4 bits)
-  unsigned cand_yv = 0, cand_xv = 0;
-  bool owner = false;
-  {
-    int r_lo, r_hi, c_lo, c_hi;
-    support(ay, gi, H, &r_lo, &r_hi);
-    support(ax, gj, W, &c_lo, &c_hi);
-    cand_ty0 = r_lo / TH, cand_tx0 = c_lo / TW;
-    const int ty_n = r_lo < r_hi ? (r_hi - 1) / TH - cand_ty0 + 1 : 0, tx_n = c_lo < c_hi ? (c_hi - 1) / TW - cand_tx0 + 1 : 0;
-    if (has && (ty_n > kSpan || tx_n > kSpan) && lane == 0) st_sc1(a.status, (unsigned)RES_GEOMETRY);
-    int first_ty = -1, first_tx = -1;
+    __syncthreads();
+    const int gi0 = s_lerp[0].i0, ni = s_lerp[PH - 1].i1 - gi0 + 1;
+    const int gj0 = s_lerp[PH].i0, nj = s_lerp[PH + PW - 1].i1 - gj0 + 1;
+    has = (int)threadIdx.x < 2 * ni * nj;  // this thread holds element (ch, gi0 + ci, gj0 + cj) of the cell block
+    const int e_ = has ? (int)threadIdx.x : 0;
+    const int ch = e_ / (ni * nj), ci = (e_ - ch * (ni * nj)) / nj, cj = e_ - ch * (ni * nj) - ci * nj;
+    const int gi = gi0 + ci, gj = gj0 + cj;
+    const int64_t gidx = ((int64_t)ch * ay.g + gi) * ax.g + gj;
+    if (has) {
+      s_cells[(ch * kGridCells + ci) * kGridCells + cj] = a.theta[gidx];
+      m_e = a.exp_avg[gidx], v_e = a.exp_avg_sq[gidx];
+    }
+    // which tiles' partial cell gradients this cell sums (the arithmetic of patch_grad_combine_kernel, flow_upsample.hip): <= kSpan
+    // candidate tiles per axis from the cell's conservative pixel support; a candidate counts if its own cell block holds the cell.
+    // cand_a = first candidate tile per axis (2 x 8 bits) | validity masks (2 x 4 bits); cand_b = the cell's index in each
+    // candidate's block, 4 bits each (rows: bits 0..15, columns: 16..31)
+    {
+      int r_lo, r_hi, c_lo, c_hi;
+      support(ay, gi, H, &r_lo, &r_hi);
+      support(ax, gj, W, &c_lo, &c_hi);
+      const int cty0 = r_lo / TH, ctx0 = c_lo / TW;
+      const int ty_n = r_lo < r_hi ? (r_hi - 1) / TH - cty0 + 1 : 0, tx_n = c_lo < c_hi ? (c_hi - 1) / TW - ctx0 + 1 : 0;
+      if (has && (ty_n > kSpan || tx_n > kSpan || cty0 > 255 || ctx0 > 255)) st_sc1(a.status, (unsigned)RES_GEOMETRY);
+      int first_ty = -1, first_tx = -1;
+      unsigned yv = 0, xv = 0;
 #pragma unroll
-    for (int k = 0; k < kSpan; ++k) {
-      const int cty = min(cand_ty0 + k, a.tiles_y - 1), ctx = min(cand_tx0 + k, a.tiles_x - 1);
-      const int bi0 = lerp_at(ay, cty * TH).i0, bi1 = lerp_at(ay, min(cty * TH + TH, H) - 1).i1;
-      const int bj0 = lerp_at(ax, ctx * TW).i0, bj1 = lerp_at(ax, min(ctx * TW + TW, W) - 1).i1;
-      const bool oky = k < ty_n && gi >= bi0 && gi <= bi1, okx = k < tx_n && gj >= bj0 && gj <= bj1;
-      cand_y |= (unsigned)(oky ? gi - bi0 : 0) << (4 * k);
-      cand_x |= (unsigned)(okx ? gj - bj0 : 0) << (4 * k);
-      cand_yv |= (unsigned)oky << k;
-      cand_xv |= (unsigned)okx << k;
-      if (oky && first_ty < 0) first_ty = cty;
-      if (okx && first_tx < 0) first_tx = ctx;
+      for (int k = 0; k < kSpan; ++k) {
+        const int cty = min(cty0 + k, tiles_y - 1), ctx = min(ctx0 + k, tiles_x - 1);
+        const int bi0 = lerp_at(ay, cty * TH).i0, bi1 = lerp_at(ay, min(cty * TH + TH, H) - 1).i1;
+        const int bj0 = lerp_at(ax, ctx * TW).i0, bj1 = lerp_at(ax, min(ctx * TW + TW, W) - 1).i1;
+        const bool oky = k < ty_n && gi >= bi0 && gi <= bi1, okx = k < tx_n && gj >= bj0 && gj <= bj1;
+        cand_b |= (unsigned)(oky ? gi - bi0 : 0) << (4 * k);
+        cand_b |= (unsigned)(okx ? gj - bj0 : 0) << (16 + 4 * k);
+        yv |= (unsigned)oky << k;
+        xv |= (unsigned)okx << k;
+        if (oky && first_ty < 0) first_ty = cty;
+        if (okx && first_tx < 0) first_tx = ctx;
+      }
+      cand_a = (unsigned)(cty0 & 255) | ((unsigned)(ctx0 & 255) << 8) | (yv << 16) | (xv << 20);
+      owner = has && first_ty == ty && first_tx == tx;  // the first tile that holds a cell writes it back at the end
     }
-    owner = has && first_ty == ty && first_tx == tx;  // the first tile that holds a cell writes it back at the end
+    if (threadIdx.x == 0) {
+      const TileRange tr = tile_range<FMT_COMPACT>(key_offsets, ev, TH * TW, tiles_x, 1);
+      P.g_first = tr.g_first, P.g_last = tr.g_last, P.beg = tr.beg, P.end = tr.end;
+      P.gi0 = gi0, P.ni = ni, P.gj0 = gj0, P.nj = nj;
+      // the tiles whose partials any cell of this block sums: a rectangle of tiles (<= 64, host-checked), waited for at S3
+      int lo, hi, dummy;
+      support(ay, gi0, H, &lo, &dummy);
+      support(ay, gi0 + ni - 1, H, &dummy, &hi);
+      P.rect_ty0 = lo / TH;
+      P.rect_ny = lo < hi ? min((hi - 1) / TH, tiles_y - 1) - P.rect_ty0 + 1 : 0;
+      support(ax, gj0, W, &lo, &dummy);
+      support(ax, gj0 + nj - 1, W, &dummy, &hi);
+      P.rect_tx0 = lo / TW;
+      P.rect_nx = lo < hi ? min((hi - 1) / TW, tiles_x - 1) - P.rect_tx0 + 1 : 0;
+      if (P.rect_ny * P.rect_nx > kWave) st_sc1(a.status, (unsigned)RES_GEOMETRY);
+      s_ok = 1;
+      s_reg[0] = s_reg[1] = 0.0;
+      s_adam[2] = 0.0f;
+    }
+    __syncthreads();
   }
-  // the tiles whose partials any cell of this block sums: a rectangle of tiles (<= 64, host-checked), waited for at S3
-  int rect_ty0, rect_tx0, rect_ny, rect_nx;
-  {
-    int lo, hi, dummy;
-    support(ay, gi0, H, &lo, &dummy);
-    support(ay, gi0 + ni - 1, H, &dummy, &hi);
-    rect_ty0 = lo / TH;
-    rect_ny = lo < hi ? min((hi - 1) / TH, a.tiles_y - 1) - rect_ty0 + 1 : 0;
-    support(ax, gj0, W, &lo, &dummy);
-    support(ax, gj0 + nj - 1, W, &dummy, &hi);
-    rect_tx0 = lo / TW;
-    rect_nx = lo < hi ? min((hi - 1) / TW, a.tiles_x - 1) - rect_tx0 + 1 : 0;
-    if (rect_ny * rect_nx > kWave && threadIdx.x == 0) st_sc1(a.status, (unsigned)RES_GEOMETRY);
-  }
-  const int lo_px = a.omit ? 1 : 0;
-  const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
-  const bool vec_store = (W & 3) == 0;
-  const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(a.slabs, 0xffffffffu);
-  const __amdgpu_buffer_rsrc_t iwe_rsrc = slab_rsrc(a.iwe, 0xffffffffu);
-  double reg_prev = 0.0;   // thread 0: this tile's regulariser partial of the previous iteration
-  float var_prev = 0.0f;   // workgroup 0, thread 0: the variance of the previous iteration (its loss is recorded one iteration late)
   bool done_ok = true;
 
-  for (int it = 0; it < a.n_iter; ++it) {
+  for (int it = 0; it < n_iter; ++it) {
     const unsigned ep = (unsigned)it + 1u;
-    // ---- F0: cells -> LDS, the tile's window from a bound on its displacements, the tile's flow ------------------------------
-    if (has) s_cells[(ch * kGridCells + ci) * kGridCells + cj] = th_e;
-    tile_bound_post(has && ch == 0 ? fabsf(th_e) : 0.0f, has && ch == 1 ? fabsf(th_e) : 0.0f, sh.bound);
-    if (threadIdx.x < 2) sh.flag[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-      sh.next = 2 * kWaves;
-      sh.chk = 0ull;
-      s_spill = 0;
-      s_bad = 0;
-      s_next = 2 * kWaves;
-      // Adam's bias corrections of step t, as torch computes them (host double in the four-launch pipeline: make_adam_job)
-      const AdamCoef coef = adam_coef(a.lr, a.beta1, a.beta2, a.t0 + it + 1);
-      s_adam[0] = coef.step_size;
-      s_adam[1] = coef.bc2_sqrt;
+    EBOS_RSTAMP(0);
+    Win<TH, TW, HALO, true> win{HALO, HALO};
+    // ---- F0 + F1: the tile's window from a bound on its displacements, the tile's flow; events -> LDS image -> slab ----------------
+    {
+      KArgs& a = fresh_args();
+      const int gi0 = rfl(P.gi0), gj0 = rfl(P.gj0), ninj = rfl(P.ni) * rfl(P.nj);
+      {
+        const bool h2 = (int)threadIdx.x < 2 * ninj;
+        const int e_ = h2 ? (int)threadIdx.x : 0, ch = e_ / ninj, rem = e_ - ch * ninj, nj = rfl(P.nj), ci = rem / nj, cj = rem - ci * nj;
+        const float th = h2 ? s_cells[(ch * kGridCells + ci) * kGridCells + cj] : 0.0f;
+        tile_bound_post(h2 && ch == 0 ? fabsf(th) : 0.0f, h2 && ch == 1 ? fabsf(th) : 0.0f, sh.bound);
+      }
+      if (threadIdx.x < 2) sh.flag[threadIdx.x] = 0;
+      if (threadIdx.x == 0) {
+        sh.next = 2 * kWaves;
+        sh.chk = 0ull;
+        s_spill = 0;
+        s_bad = 0;
+        s_next = 2 * kWaves;
+      }
+      tile_flow_from_cells<TH, TW, 0>(s_lerp + AP, s_lerp + PH + AP, s_cells, gi0, gj0, s_flow_f);
+      __syncthreads();
+      win = tile_bound_read<TH, TW, HALO, true>(sh.bound, a.dt_bound);
+      EBOS_RSTAMP(1);
+      const int tiles_x = a.tiles_x;
+      TileRange tr;
+      tr.ty = tile / tiles_x, tr.tx = tile - tr.ty * tiles_x, tr.slab = tile, tr.part = 0;
+      tr.g_first = rfl(P.g_first), tr.g_last = rfl(P.g_last), tr.beg = rfl(P.beg), tr.end = rfl(P.end);
+      const EvPtrs ev = a.ev;
+      tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, true, false>(tr, win, s_flow_f, s_acc, sh, ev, a.H, a.W, tiles_x, 0, 0,
+                                                                                    a.slabs, nullptr, nullptr, 0u, nullptr, nullptr, NoHook{});
+      EBOS_RSTAMP(2);
+      drain_stores();
+      __syncthreads();
     }
-    __syncthreads();
-    const Win<TH, TW, HALO, true> win = tile_bound_read<TH, TW, HALO, true>(sh.bound, a.dt_bound);
-    tile_flow_from_cells<TH, TW, 0>(s_lerp + AP, s_lerp + PH + AP, s_cells, gi0, gj0, s_flow_f);
-    __syncthreads();
-    // ---- F1: events -> LDS image -> slab (write-through) ------------------------------------------------------------------------
-    tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, true, false>(tr, win, s_flow_f, s_acc, sh, a.ev, H, W, a.tiles_x, 0, 0,
-                                                                                  a.slabs, nullptr, nullptr, 0u, nullptr, nullptr, NoHook{});
-    drain_stores();
-    __syncthreads();
     if (sh.flag[1]) {  // (uniform) a tap left the largest window: the four-launch pipeline's spill path handles that flow
-      if (threadIdx.x == 0) st_sc1(a.status, (unsigned)RES_SPILL);
+      if (threadIdx.x == 0) st_sc1(fresh_args().status, (unsigned)RES_SPILL);
       done_ok = false;
       break;
     }
-    if (threadIdx.x == 0) st_sc1(a.flag1 + tile, ((unsigned long long)ep << 32) | win_pack(win.hr, win.hc));
     // ---- S1: the eight neighbours' slabs (and their windows) --------------------------------------------------------------------
-    if (wave == 0) {
-      const int nty = ty + lane / 3 - 1, ntx = tx + lane % 3 - 1;
-      const bool nb = lane < 9 && nty >= 0 && nty < a.tiles_y && ntx >= 0 && ntx < a.tiles_x;
-      unsigned wv = 0xffffffffu;
-      const bool ok = wave_wait([&]() {
-        if (!nb) return true;
-        const unsigned long long f = ld_sc1(a.flag1 + nty * a.tiles_x + ntx);
-        wv = (unsigned)f;
-        return (unsigned)(f >> 32) >= ep;
-      }, a.status, a.cap_ticks);
-      if (lane < 9) s_win[lane] = nb ? wv : 0xffffffffu;
-      if (lane == 0 && !ok) s_ok = 0;
+    {
+      KArgs& a = fresh_args();
+      const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+      if (threadIdx.x == 0) st_sc1(a.flag1 + tile, ((unsigned long long)ep << 32) | win_pack(win.hr, win.hc));
+      EBOS_RSTAMP(3);
+      if (wave == 0) {
+        const int nty = ty + lane / 3 - 1, ntx = tx + lane % 3 - 1;
+        const bool nb = lane < 9 && nty >= 0 && nty < tiles_y && ntx >= 0 && ntx < tiles_x;
+        unsigned long long* f1 = a.flag1 + (nb ? nty * tiles_x + ntx : tile);
+        unsigned wv = 0xffffffffu;
+        const bool ok = wave_wait([&]() {
+          const unsigned long long f = ld_sc1(f1);
+          wv = (unsigned)f;
+          return !nb || (unsigned)(f >> 32) >= ep;
+        }, a.status, a.cap_ticks);
+        if (lane < 9) s_win[lane] = nb ? wv : 0xffffffffu;
+        if (lane == 0 && !ok) s_ok = 0;
+      } else if (threadIdx.x == kWave) {
+        // (an idle wave: Adam's bias corrections of this iteration's step, as torch computes them -- adam_coef, patch_grid.h)
+        const AdamCoef coef = adam_coef(a.lr, a.beta1, a.beta2, a.t0 + it + 1);
+        s_adam[0] = coef.step_size;
+        s_adam[1] = coef.bc2_sqrt;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     if (!s_ok) { done_ok = false; break; }
+    EBOS_RSTAMP(4);
     // ---- G: this tile's pixels of the IWE = sum of the slabs whose windows reach them, in the combine pass's order ---------------
-    double sm = 0.0, sq = 0.0;
-    for (int q = threadIdx.x; q < TH * (TW / 4); q += kBlock) {
-      const int rl = q / (TW / 4), cl = (q - rl * (TW / 4)) * 4;
-      const int r = tr0 + rl, c = tc0 + cl;
-      if (r >= H || c >= W) continue;
-      float4 part[9];
-      bool okk[9];
+    {
+      KArgs& a = fresh_args();
+      const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
+      const int lo_px = a.omit ? 1 : 0;
+      const bool vec_store = (W & 3) == 0;
+      const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(a.slabs, 0xffffffffu);
+      const __amdgpu_buffer_rsrc_t iwe_rsrc = slab_rsrc(a.iwe, 0xffffffffu);
+      float* iwe = a.iwe;
+      double sm = 0.0, sq = 0.0;
+      for (int q0 = 0; q0 < TH * (TW / 4); q0 += kBlock) {
+        const int q = q0 + (int)threadIdx.x;
+        const int rl = q / (TW / 4), cl = (q - rl * (TW / 4)) * 4;
+        const int r = tr0 + rl, c = tc0 + cl;
+        const bool live = q < TH * (TW / 4) && r < H && c < W;
+        float4 part[9];
+        bool okk[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const unsigned w = s_win[k];
-        const int nty = ty + k / 3 - 1, ntx = tx + k % 3 - 1;
-        const int hr = (int)(w & 255u), hc = (int)((w >> 8) & 255u);
-        const int rr = r - (nty * TH - hr), cc = c - (ntx * TW - hc), lw = TW + 2 * hc;
-        okk[k] = w != 0xffffffffu && (unsigned)rr < (unsigned)(TH + 2 * hr) && (unsigned)cc < (unsigned)lw;
-        const unsigned byte = okk[k] ? ((unsigned)(nty * a.tiles_x + ntx) * (unsigned)(kLHmax * kLWmax) + (unsigned)(rr * lw + cc)) * 4u : 0u;
-        part[k] = slab_load4(all_slabs, byte);
-      }
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-        if (okk[k]) v.x += part[k].x, v.y += part[k].y, v.z += part[k].z, v.w += part[k].w;
-      const float e4[4] = {v.x, v.y, v.z, v.w};
-      const int64_t gi_px = (int64_t)r * W + c;
-      if (vec_store) {
-        slab_store4(iwe_rsrc, (unsigned)(gi_px * 4), v);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (c + k < W) st_sc1(a.iwe + gi_px + k, e4[k]);
-      }
-      if (r >= lo_px && r < H - lo_px) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (c + k >= lo_px && c + k < W - lo_px) {
-            sm += (double)e4[k];
-            sq += (double)e4[k] * (double)e4[k];
+        for (int k = 0; k < 9; ++k) {
+          const unsigned w = s_win[k];
+          const int nty = ty + k / 3 - 1, ntx = tx + k % 3 - 1;
+          const int hr = (int)(w & 255u), hc = (int)((w >> 8) & 255u);
+          const int rr = r - (nty * TH - hr), cc = c - (ntx * TW - hc), lw = TW + 2 * hc;
+          okk[k] = live && w != 0xffffffffu && (unsigned)rr < (unsigned)(TH + 2 * hr) && (unsigned)cc < (unsigned)lw;
+          part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          // (a neighbour's window reaches only the rim of this tile: most waves hold no quad of it and skip its load)
+          if (__builtin_amdgcn_ballot_w64(okk[k]) != 0ull) {
+            const unsigned byte = okk[k] ? ((unsigned)(nty * tiles_x + ntx) * (unsigned)(kLHmax * kLWmax) + (unsigned)(rr * lw + cc)) * 4u : 0u;
+            part[k] = slab_load4(all_slabs, byte);
           }
-      }
-    }
-    drain_stores();
-    block_sum2(sm, sq, s_red);  // (its barriers stand behind every wave's drain)
-    if (threadIdx.x == 0) {
-      unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * n_tiles + tile) * kRecGranules;
-      put_granules(rec, ep, sm);
-      put_granules(rec + 2, ep, sq);
-      put_granules(rec + 4, ep, reg_prev);
-    }
-    // ---- S2: the one all-to-all: every tile's (sum, sum of squares, regulariser partial of the previous iteration) ---------------
-    double as = 0.0, aq = 0.0, ar = 0.0;
-    if (wave * kWave < n_tiles) {
-      const int k = wave * kWave + lane;
-      const unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * n_tiles + min(k, n_tiles - 1)) * kRecGranules;
-      unsigned long long g[6];
-      const bool ok = wave_wait([&]() {
-        bool all = true;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          g[j] = ld_sc1(rec + j);
-          all = all && (unsigned)(g[j] >> 32) == ep;
         }
-        return all;
-      }, a.status, a.cap_ticks);
-      if (ok && k < n_tiles) {
-        as = __builtin_bit_cast(double, (g[0] & 0xffffffffull) | (g[1] << 32));
-        aq = __builtin_bit_cast(double, (g[2] & 0xffffffffull) | (g[3] << 32));
-        ar = __builtin_bit_cast(double, (g[4] & 0xffffffffull) | (g[5] << 32));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          if (okk[k]) v.x += part[k].x, v.y += part[k].y, v.z += part[k].z, v.w += part[k].w;
+        if (live) {
+          const float e4[4] = {v.x, v.y, v.z, v.w};
+          const int64_t gi_px = (int64_t)r * W + c;
+          if (vec_store) {
+            slab_store4(iwe_rsrc, (unsigned)(gi_px * 4), v);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c + k < W) st_sc1(iwe + gi_px + k, e4[k]);
+          }
+          if (r >= lo_px && r < H - lo_px) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c + k >= lo_px && c + k < W - lo_px) {
+                sm += (double)e4[k];
+                sq += (double)e4[k] * (double)e4[k];
+              }
+          }
+        }
       }
-      if (lane == 0 && !ok) s_ok = 0;
+      EBOS_RSTAMP(5);
+      drain_stores();
+      block_sum2(sm, sq, s_red);  // (its barriers stand behind every wave's drain)
+      if (threadIdx.x == 0) {
+        unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * (a.tiles_y * tiles_x) + tile) * kRecGranules;
+        put_granules(rec, ep, sm);
+        put_granules(rec + 2, ep, sq);
+        put_granules(rec + 4, ep, s_reg[1]);
+      }
     }
-    {  // (three sums at once; block_sum2's order per sum)
+    EBOS_RSTAMP(6);
+    // ---- S2: the one all-to-all: every tile's (sum, sum of squares, regulariser partial of the previous iteration) ---------------
+    double mean;
+    {
+      KArgs& a = fresh_args();
+      const int n_tiles = a.tiles_y * a.tiles_x;
+      const int lo_px = a.omit ? 1 : 0;
+      const double n_px = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
+      double as = 0.0, aq = 0.0, ar = 0.0;
+      if (wave * kWave < n_tiles) {
+        const int k = wave * kWave + lane;
+        const unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * n_tiles + min(k, n_tiles - 1)) * kRecGranules;
+        unsigned long long g[6];
+        const bool ok = wave_wait([&]() {
+          bool all = true;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            g[j] = ld_sc1(rec + j);
+            all = all && (unsigned)(g[j] >> 32) == ep;
+          }
+          return all;
+        }, a.status, a.cap_ticks);
+        if (ok && k < n_tiles) {
+          as = __builtin_bit_cast(double, (g[0] & 0xffffffffull) | (g[1] << 32));
+          aq = __builtin_bit_cast(double, (g[2] & 0xffffffffull) | (g[3] << 32));
+          ar = __builtin_bit_cast(double, (g[4] & 0xffffffffull) | (g[5] << 32));
+        }
+        if (lane == 0 && !ok) s_ok = 0;
+      }
+      EBOS_RSTAMP(7);
       as = wave_sum(as), aq = wave_sum(aq), ar = wave_sum(ar);
       if (lane == 0) s_red[wave] = as, s_red[kWaves + wave] = aq, s_red[2 * kWaves + wave] = ar;
       __syncthreads();
       if (threadIdx.x == 0) {
         double S = 0.0, Q = 0.0, R = 0.0;
         for (int k = 0; k < kWaves; ++k) S += s_red[k], Q += s_red[kWaves + k], R += s_red[2 * kWaves + k];
-        const double mean = n_px > 0.0 ? S / n_px : 0.0;
-        s_mom[0] = mean;
-        s_mom[1] = (Q - S * mean) / (n_px - 1.0);
+        const double mn = n_px > 0.0 ? S / n_px : 0.0;
+        s_mom[0] = mn;
+        s_mom[1] = (Q - S * mn) / (n_px - 1.0);
         s_mom[2] = R;
+      }
+      __syncthreads();
+      mean = s_mom[0];
+      if (blockIdx.x == 0 && threadIdx.x == 0) {  // bookkeeping: the loss of the PREVIOUS iteration is complete now
+        const float var_f = (float)s_mom[1];
+        const int t_prev = a.t0 + it - 1;
+        if (it > 0 && a.losses != nullptr && t_prev < a.losses_cap)
+          a.losses[t_prev] = (float)(-(double)a.w_contrast * (double)s_adam[2] + s_mom[2]);
+        s_adam[2] = var_f;
+        a.variance[0] = var_f;
+        a.moments[0] = mean;
+        a.moments[1] = n_px;
+      }
+    }
+    if (!s_ok) { done_ok = false; break; }
+    EBOS_RSTAMP(8);
+    // ---- B0 + B1: upstream window (tile + halo) of d loss / d IWE = 2 (-w) (IWE - mean) / (M - 1), from the tiles' images; the sweep ---
+    FxUnit unit;
+    bool fx;
+    {
+      KArgs& a = fresh_args();
+      const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
+      const int lo_px = a.omit ? 1 : 0;
+      const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
+      // (the window of the UPSTREAM image: the four-launch backward kernel stages at least its speculative 4 px window, and the
+      // fixed-point unit of the scatter follows max |staged value| -- same window, same unit, same bits)
+      constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
+      const Win<TH, TW, HALO, true> wb = (win.hr <= kSpecHalo && win.hc <= kSpecHalo) ? Win<TH, TW, HALO, true>{kSpecHalo, kSpecHalo} : win;
+      const int LW = wb.LW(), n_win = wb.LH() * LW, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
+      GradImage G;
+      G.g = a.iwe;
+      const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
+      G.a = (float)ga;
+      G.c = (float)(-ga * mean);
+      G.h = H, G.w = W, G.lo = lo_px;
+      constexpr int kStage = (kLHmax * kLWmax + kBlock - 1) / kBlock;
+      float raw[kStage];
+      const float inv_lw = 1.0f / (float)LW;
+      const float* iwe = a.iwe;
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        if (k * kBlock >= n_win) break;  // (uniform)
+        const int i = min((int)threadIdx.x + k * kBlock, n_win - 1);
+        const int rl = (int)(((float)i + 0.5f) * inv_lw), cl = i - rl * LW;
+        const int R = min(max(oy + rl, 0), H - 1), C = min(max(ox + cl, 0), W - 1);
+        raw[k] = ld_sc1(iwe + (int64_t)R * W + C);
+      }
+      for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
+      tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
+      float gmax_t = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        if (k * kBlock >= n_win) break;
+        const int i = threadIdx.x + k * kBlock;
+        const int rl = (int)(((float)i + 0.5f) * inv_lw), cl = i - rl * LW;
+        const int R = oy + rl, C = ox + cl;
+        const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
+        const float gv = valid ? G.a * raw[k] + G.c : 0.0f;
+        if (i < n_win) {
+          s_g[i] = gv;
+          gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
+        }
+      }
+      gmax_t = wave_max_nonneg(gmax_t);
+      if (lane == 0) s_gmax[wave] = gmax_t;
+      __syncthreads();
+      EBOS_RSTAMP(9);
+      unit = bwd_fx_unit(s_gmax, a.dt_bound);
+      double tot_x = 0.0, tot_y = 0.0;
+      const BwdShared bsh{&s_spill, &s_bad, &s_next};
+      TileRange tr;
+      tr.ty = ty, tr.tx = tx, tr.slab = tile, tr.part = 0;
+      tr.g_first = rfl(P.g_first), tr.g_last = rfl(P.g_last), tr.beg = rfl(P.beg), tr.end = rfl(P.end);
+      const EvPtrs ev = a.ev;
+      fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, ev, s_flow_b, H, W, 0, 0, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
+                                                           unit, a.dt_bound, BwdPre{}, false, bsh, NoHook{});
+      __syncthreads();
+    }
+    EBOS_RSTAMP(10);
+    // ---- B2: regularisers on the tile's flow, adjoint of grid -> dense on the tile -> partial cell gradients (write-through) ------
+    {
+      KArgs& a = fresh_args();
+      const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+      TileRange tr;
+      tr.ty = ty, tr.tx = tx, tr.slab = tile, tr.part = 0;
+      tr.g_first = tr.g_last = tr.beg = tr.end = 0;
+      const TileGrad<TH, TW> grad{fx, 1.0f / unit.scale, s_d};
+      const float s_norm = a.s_norm, s_tv = a.s_tv;
+      const bool any_reg = s_norm != 0.0f || s_tv != 0.0f;
+      grid_tile_epilogue<TH, TW, HALO, true>(tr, ty * TH, tx * TW, H, W, s_d, s_g, s_flow_b, s_lerp, grad, nullptr, s_norm, s_tv,
+                                             any_reg ? &s_reg[0] : nullptr, a.cell_partials + (int64_t)tile * (2 * kGridCells * kGridCells));
+      EBOS_RSTAMP(11);
+      drain_stores();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        st_sc1(a.flag3 + tile, (unsigned long long)ep);
+        s_reg[1] = any_reg ? s_reg[0] : 0.0;
+      }
+    }
+    EBOS_RSTAMP(12);
+    // ---- S3: the partials of the tiles this block's cells sum; meanwhile the other waves clear the LDS image for the next pass ---
+    {
+      KArgs& a = fresh_args();
+      if (wave == 0) {
+        const int rect_nx = max(rfl(P.rect_nx), 1), n_rect = rfl(P.rect_ny) * rfl(P.rect_nx);
+        const int ry = lane / rect_nx, rx = lane - ry * rect_nx;
+        const bool act = lane < n_rect;
+        const unsigned long long* f = a.flag3 + (rfl(P.rect_ty0) + (act ? ry : 0)) * a.tiles_x + rfl(P.rect_tx0) + (act ? rx : 0);
+        const bool ok = wave_wait([&]() { return !act || ld_sc1(f) >= (unsigned long long)ep; }, a.status, a.cap_ticks);
+        if (lane == 0 && !ok) s_ok = 0;
+      } else {
+        for (int i = threadIdx.x - kWave; i < kCells / 2; i += kBlock - kWave) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
       }
       __syncthreads();
     }
     if (!s_ok) { done_ok = false; break; }
-    const double mean = s_mom[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // bookkeeping: the loss of the PREVIOUS iteration is complete now
-      const float var_f = (float)s_mom[1];
-      if (it > 0 && a.losses != nullptr && a.t0 + it - 1 < a.losses_cap)
-        a.losses[a.t0 + it - 1] = (float)(-(double)a.w_contrast * (double)var_prev + s_mom[2]);
-      var_prev = var_f;
-      a.variance[0] = var_f;
-      a.moments[0] = mean;
-      a.moments[1] = n_px;
-    }
-    // ---- B0: upstream window (tile + halo) of d loss / d IWE = 2 (-w) (IWE - mean) / (M - 1), from the tiles' images ------------
-    // (the window of the UPSTREAM image: the four-launch backward kernel stages at least its speculative 4 px window, and the
-    // fixed-point unit of the scatter follows max |staged value| -- same window, same unit, same bits)
-    constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
-    const Win<TH, TW, HALO, true> wb = (win.hr <= kSpecHalo && win.hc <= kSpecHalo) ? Win<TH, TW, HALO, true>{kSpecHalo, kSpecHalo} : win;
-    const int LW = wb.LW(), n_win = wb.LH() * LW, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
-    GradImage G;
-    G.g = a.iwe;
-    const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
-    G.a = (float)ga;
-    G.c = (float)(-ga * mean);
-    G.h = H, G.w = W, G.lo = lo_px;
-    constexpr int kStage = (kLHmax * kLWmax + kBlock - 1) / kBlock;
-    float raw[kStage];
-    const float inv_lw = 1.0f / (float)LW;
-#pragma unroll
-    for (int k = 0; k < kStage; ++k) {
-      if (k * kBlock >= n_win) break;  // (uniform)
-      const int i = min((int)threadIdx.x + k * kBlock, n_win - 1);
-      const int rl = (int)(((float)i + 0.5f) * inv_lw), cl = i - rl * LW;
-      const int R = min(max(oy + rl, 0), H - 1), C = min(max(ox + cl, 0), W - 1);
-      raw[k] = ld_sc1(a.iwe + (int64_t)R * W + C);
-    }
-    for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
-    tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, gi0, gj0, s_flow_b);
-    float gmax_t = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kStage; ++k) {
-      if (k * kBlock >= n_win) break;
-      const int i = threadIdx.x + k * kBlock;
-      const int rl = (int)(((float)i + 0.5f) * inv_lw), cl = i - rl * LW;
-      const int R = oy + rl, C = ox + cl;
-      const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-      const float gv = valid ? G.a * raw[k] + G.c : 0.0f;
-      if (i < n_win) {
-        s_g[i] = gv;
-        gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
-      }
-    }
-    gmax_t = wave_max_nonneg(gmax_t);
-    if (lane == 0) s_gmax[wave] = gmax_t;
-    __syncthreads();
-    // ---- B1: the sweep: d loss / d flow of the tile's pixels, in LDS -----------------------------------------------------------------
-    const FxUnit unit = bwd_fx_unit(s_gmax, a.dt_bound);
-    double tot_x = 0.0, tot_y = 0.0;
-    const BwdShared bsh{&s_spill, &s_bad, &s_next};
-    const bool fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, a.ev, s_flow_b, H, W, 0, 0, G, tot_x, tot_y,
-                                                                    ChunkQueue{&s_next}, wb, unit, a.dt_bound, BwdPre{}, false, bsh, NoHook{});
-    __syncthreads();
-    // ---- B2: regularisers on the tile's flow, adjoint of grid -> dense on the tile -> partial cell gradients (write-through) ------
-    const TileGrad<TH, TW> grad{fx, 1.0f / unit.scale, s_d};
-    const bool any_reg = a.s_norm != 0.0f || a.s_tv != 0.0f;
-    grid_tile_epilogue<TH, TW, HALO, true>(tr, tr0, tc0, H, W, s_d, s_g, s_flow_b, s_lerp, grad, nullptr, a.s_norm, a.s_tv,
-                                           any_reg ? &s_reg : nullptr, a.cell_partials + (int64_t)tile * (2 * kGridCells * kGridCells));
-    drain_stores();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      st_sc1(a.flag3 + tile, (unsigned long long)ep);
-      reg_prev = any_reg ? s_reg : 0.0;
-    }
-    // ---- S3: the partials of the tiles this block's cells sum; meanwhile the other waves clear the LDS image for the next pass ---
-    if (wave == 0) {
-      const int k = lane, ry = k / max(rect_nx, 1), rx = k - ry * max(rect_nx, 1);
-      const bool act = k < rect_ny * rect_nx;
-      const unsigned long long* f = a.flag3 + (rect_ty0 + (act ? ry : 0)) * a.tiles_x + rect_tx0 + (act ? rx : 0);
-      const bool ok = wave_wait([&]() { return !act || ld_sc1(f) >= (unsigned long long)ep; }, a.status, a.cap_ticks);
-      if (lane == 0 && !ok) s_ok = 0;
-    } else {
-      for (int i = threadIdx.x - kWave; i < kCells / 2; i += kBlock - kWave) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-    if (!s_ok) { done_ok = false; break; }
+    EBOS_RSTAMP(13);
     // ---- A: d loss / d theta of this thread's cell element = sum of the partials of the tiles that hold it; Adam ------------------
     if (has) {
+      KArgs& a = fresh_args();
+      const int tiles_x = a.tiles_x, tiles_y = a.tiles_y;
+      const int ninj = rfl(P.ni) * rfl(P.nj), nj = rfl(P.nj);
+      const int ch = (int)threadIdx.x / ninj, rem = (int)threadIdx.x - ch * ninj, ci = rem / nj, cj = rem - ci * nj;
+      const float* cp = a.cell_partials;
+      const int cty0 = (int)(cand_a & 255u), ctx0 = (int)((cand_a >> 8) & 255u);
+      float mask = 1.0f;
+      if (a.theta_mask != nullptr) mask = a.theta_mask[(int64_t)(rfl(P.gi0) + ci) * a.gs.ax.g + rfl(P.gj0) + cj];
       float pv[kSpan][kSpan];
 #pragma unroll
       for (int p = 0; p < kSpan; ++p)
 #pragma unroll
         for (int q = 0; q < kSpan; ++q) {
-          const int cty = min(cand_ty0 + p, a.tiles_y - 1), ctx = min(cand_tx0 + q, a.tiles_x - 1);
-          const int li = (int)((cand_y >> (4 * p)) & 15u), lj = (int)((cand_x >> (4 * q)) & 15u);
-          pv[p][q] = ld_sc1(a.cell_partials + (((int64_t)(cty * a.tiles_x + ctx) * 2 + ch) * kGridCells + li) * kGridCells + lj);
+          const int cty = min(cty0 + p, tiles_y - 1), ctx = min(ctx0 + q, tiles_x - 1);
+          const int li = (int)((cand_b >> (4 * p)) & 15u), lj = (int)((cand_b >> (16 + 4 * q)) & 15u);
+          pv[p][q] = ld_sc1(cp + (((int64_t)(cty * tiles_x + ctx) * 2 + ch) * kGridCells + li) * kGridCells + lj);
         }
       float g = 0.0f;
 #pragma unroll
       for (int p = 0; p < kSpan; ++p)
 #pragma unroll
-        for (int q = 0; q < kSpan; ++q) g += (((cand_yv >> p) & 1u) && ((cand_xv >> q) & 1u)) ? pv[p][q] : 0.0f;
-      if (a.theta_mask != nullptr) g *= mask_e;
+        for (int q = 0; q < kSpan; ++q) g += (((cand_a >> (16 + p)) & 1u) && ((cand_a >> (20 + q)) & 1u)) ? pv[p][q] : 0.0f;
+      if (a.theta_mask != nullptr) g *= mask;
       g_e = g;
-      adam_update(g, m_e, v_e, th_e, s_adam[0], s_adam[1], (float)a.beta2, (float)(1.0 - a.beta1), (float)(1.0 - a.beta2), (float)a.eps);
+      float th = s_cells[(ch * kGridCells + ci) * kGridCells + cj];
+      adam_update(g, m_e, v_e, th, s_adam[0], s_adam[1], (float)a.beta2, (float)(1.0 - a.beta1), (float)(1.0 - a.beta2), (float)a.eps);
+      s_cells[(ch * kGridCells + ci) * kGridCells + cj] = th;
     }
+    EBOS_RSTAMP(14);
+    __syncthreads();  // the new theta block is in LDS
   }
   if (!done_ok) return;  // (uniform) nothing of the optimiser state was written: the host falls back from unchanged state
 
   // ---- the state goes back: every cell element by the first tile that holds it ------------------------------------------------------
+  KArgs& a = fresh_args();
   if (owner) {
-    a.theta[gidx] = th_e;
+    const int ninj = rfl(P.ni) * rfl(P.nj), nj = rfl(P.nj);
+    const int ch = (int)threadIdx.x / ninj, rem = (int)threadIdx.x - ch * ninj, ci = rem / nj, cj = rem - ci * nj;
+    const int64_t gidx = ((int64_t)ch * a.gs.ay.g + rfl(P.gi0) + ci) * a.gs.ax.g + rfl(P.gj0) + cj;
+    a.theta[gidx] = s_cells[(ch * kGridCells + ci) * kGridCells + cj];
     a.exp_avg[gidx] = m_e;
     a.exp_avg_sq[gidx] = v_e;
     a.d_theta[gidx] = g_e;
   }
-  if (a.n_iter <= 0) return;
+  if (n_iter <= 0) return;
   // the last iteration's loss: its regulariser partials travel through the `done` granules; workgroup 0 gathers them
-  if (threadIdx.x == 0) put_granules(a.done + (size_t)tile * 2, (unsigned)a.n_iter, reg_prev);
+  const int n_tiles = a.tiles_y * a.tiles_x;
+  if (threadIdx.x == 0) put_granules(a.done + (size_t)tile * 2, (unsigned)n_iter, s_reg[1]);
   if (blockIdx.x != 0) return;
   double ar = 0.0;
   if (wave * kWave < n_tiles) {
@@ -523,16 +658,17 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a) {
     unsigned long long g0 = 0, g1 = 0;
     const bool ok = wave_wait([&]() {
       g0 = ld_sc1(rec), g1 = ld_sc1(rec + 1);
-      return (unsigned)(g0 >> 32) == (unsigned)a.n_iter && (unsigned)(g1 >> 32) == (unsigned)a.n_iter;
+      return (unsigned)(g0 >> 32) == (unsigned)n_iter && (unsigned)(g1 >> 32) == (unsigned)n_iter;
     }, a.status, a.cap_ticks);
     if (ok && k < n_tiles) ar = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));
   }
   ar = block_sum(ar, s_red);
   if (threadIdx.x == 0) {
-    const int t_last = a.t0 + a.n_iter - 1;
-    if (a.losses != nullptr && t_last < a.losses_cap) a.losses[t_last] = (float)(-(double)a.w_contrast * (double)var_prev + ar);
-    a.step[0] = a.t0 + a.n_iter;
+    const int t_last = a.t0 + n_iter - 1;
+    if (a.losses != nullptr && t_last < a.losses_cap) a.losses[t_last] = (float)(-(double)a.w_contrast * (double)s_adam[2] + ar);
+    a.step[0] = a.t0 + n_iter;
   }
+#endif
 }
 
 struct MailboxLayout {
@@ -676,6 +812,12 @@ bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
 }  // namespace ebos
 
 extern "C" {
+
+#ifdef EBOS_STAMPS
+int ebos_debug_read_stamps_resident(unsigned long long* host, int count) {  // diagnostic builds only
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_rstamps), sizeof(unsigned long long) * count);
+}
+#endif
 
 size_t ebos_cmax_resident_mailbox_bytes(int H, int W, int tile_h, int tile_w) {
   if (H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0) return 0;

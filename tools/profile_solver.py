@@ -24,16 +24,27 @@ ap.add_argument("--flow-norm", type=float, default=0.001)
 ap.add_argument("--image-gradient", type=float, default=0.0)
 ap.add_argument("--halo", type=lambda v: v if v == "auto" else int(v), default=32, help="a built halo, or auto (run-time windows per tile)")
 ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile (default: choose_tile for the halo)")
+ap.add_argument("--mode", choices=["auto", "resident", "pipeline"], default="auto", help="one resident launch / four launches per iteration")
+ap.add_argument("--size", type=int, nargs=2, default=None, help="image size (default 720 1280)")
+ap.add_argument("--flow-max", type=float, default=0.0, help="initial patch flows U(-m, m) (0: zeros)")
 a = ap.parse_args()
-ev, _ = synth_window(a.events, 0)
+if a.size:
+    import numpy as np
+    H, W = a.size
+    rs = np.random.RandomState(3)
+    ev = np.stack([rs.randint(0, H, a.events), rs.randint(0, W, a.events), np.sort(rs.uniform(0, 0.5, a.events)), rs.randint(0, 2, a.events)], 1).astype(np.float64)
+else:
+    ev, _ = synth_window(a.events, 0)
 plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=tuple(a.tile) if a.tile else ebos.event_plan.choose_tile((H, W), 32 if a.halo == "auto" else a.halo))
 gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
-loop = FusedPatchLoop(plan, a.patch, a.patch, torch.zeros((2, gh, gw)), 1.0, a.flow_norm, a.image_gradient, halo=a.halo, lr=0.1, capacity=a.iters + 3,
+theta0 = torch.zeros((2, gh, gw)) if a.flow_max == 0 else (torch.rand((2, gh, gw), generator=torch.Generator().manual_seed(1)) * 2 - 1) * a.flow_max
+res = {"auto": None, "resident": True, "pipeline": False}[a.mode]
+loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 1.0, a.flow_norm, a.image_gradient, halo=a.halo, lr=0.1, capacity=a.iters + 3,
                       sample_grid=False if a.dense else None)
-loop.run(3)
+loop.run(3, resident=res)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-losses = loop.run(a.iters)
+losses = loop.run(a.iters, resident=res)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f"tile {plan.tile} halo {a.halo}, sample_grid {loop.sample_grid}, flow_norm {a.flow_norm}, image_gradient {a.image_gradient}: {a.events} events, {a.iters} iterations: {dt / a.iters * 1e6:.1f} us/iteration; loss {losses[0].item():.5f} -> {losses[-1].item():.5f}")
+print(f"{H}x{W} mode {loop.last_run_mode} (status {loop.resident_status}), tile {plan.tile} halo {a.halo}, sample_grid {loop.sample_grid}, flow_norm {a.flow_norm}, image_gradient {a.image_gradient}: {a.events} events, {a.iters} iterations: {dt / a.iters * 1e6:.1f} us/iteration; loss {losses[0].item():.5f} -> {losses[-1].item():.5f}")

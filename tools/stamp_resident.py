@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Phase breakdown of ONE iteration of the resident solver kernel (cmax_resident.hip) from in-kernel stamps.
+Diagnostic build of that one file, linked beside the product library:
+    tools/build_stamps_lib.sh        ->  event_based_bos_amd/lib/libebos_stamps.so
+    EBOS_HIP_LIBRARY=$PWD/event_based_bos_amd/lib/libebos_stamps.so python tools/stamp_resident.py [--events N] [--size H W]
+wall_clock64 ticks at 100 MHz (10 ns)."""
+import argparse, ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import event_based_bos_amd as ebos
+from event_based_bos_amd import _hip
+from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--events", type=int, default=2_000_000)
+ap.add_argument("--size", type=int, nargs=2, default=[720, 1280])
+ap.add_argument("--patch", type=int, nargs=2, default=[24, 32])
+ap.add_argument("--iters", type=int, default=60)
+ap.add_argument("--flow-max", type=float, default=0.0)
+a = ap.parse_args()
+lib = _hip.require_gpu()
+raw = ctypes.CDLL(os.environ.get("EBOS_HIP_LIBRARY", _hip.LIB_PATH))
+H, W = a.size
+rs = np.random.RandomState(3)
+ev = np.stack([rs.randint(0, H, a.events), rs.randint(0, W, a.events), np.sort(rs.uniform(0, 0.5, a.events)), rs.randint(0, 2, a.events)], 1).astype(np.float64)
+plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto", emit="compact")
+gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
+theta0 = torch.zeros((2, gh, gw)) if a.flow_max == 0 else (torch.rand((2, gh, gw), generator=torch.Generator().manual_seed(1)) * 2 - 1) * a.flow_max
+loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 1.0, 0.001, 0.0, lr=0.1, capacity=a.iters + 8, halo="auto")
+loop.run(a.iters, resident=True)
+torch.cuda.synchronize()
+assert loop.last_run_mode == "resident", loop.resident_status
+th, tw = plan.tile
+n = -(-H // th) * -(-W // tw)
+buf = (ctypes.c_ulonglong * (n * 16))()
+raw.ebos_debug_read_stamps_resident(buf, n * 16)
+st = np.array(buf[:], dtype=np.float64).reshape(n, 16) * 10.0  # ns
+names = ["F0 cells -> LDS, window, tile flow", "F1 event loop + decode + slab stores issued", "   drain slab stores + barrier + flag1",
+         "S1 wait for the 8 neighbours", "G  gather own tile from slabs (loads + image stores issued)", "   drain + block sum + record",
+         "S2 poll all records", "   reduce (mean / variance)", "B0 stage upstream window, clear, tile flow (apron)", "B1 sweep",
+         "B2 regulariser + tile adjoint (stores issued)", "   drain + barrier + flag3", "S3 wait for the partials' tiles (+ LDS clear)", "A  cell gradients + Adam"]
+print(f"{H}x{W}, {a.events} events, tile {plan.tile}, {n} workgroups; last of {a.iters} iterations")
+tot = st[:, 14] - st[:, 0]
+for i, nm in enumerate(names):
+    d = st[:, i + 1] - st[:, i]
+    print(f"  {nm:62s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
+print(f"  {'iteration (F0 -> A)':62s} median {np.median(tot) / 1e3:6.2f} us   min {tot.min() / 1e3:6.2f}   max {tot.max() / 1e3:6.2f}")
+print(f"  start skew of the iteration across workgroups: {(st[:, 0].max() - st[:, 0].min()) / 1e3:.2f} us")
