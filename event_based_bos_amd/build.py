@@ -44,12 +44,19 @@ def _needs_rebuild(target: str, deps: List[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# per-file flags.  cmax_resident.hip: one kernel with a dozen phases inside an iteration loop -- LICM hoists every phase's
+# thread-index arithmetic out of that loop, where it stays live across all phases, is spilled, and comes back through scratch
+# loads each followed by a full vmcnt(0) wait (5.5 us for four pixels per thread in the epilogue).  MachineSink's
+# sink-insts-to-avoid-spills puts those computations back next to their uses: 41 -> 7 spilled VGPRs.
+PER_FILE_FLAGS = {"cmax_resident.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"]}
+
+
 def _compile(src: str, extra: List[str]) -> str:
     obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(INCLUDE, "ebos_hip.h"), __file__]
     if _needs_rebuild(obj, [path] + headers):
-        cmd = [hipcc()] + HIPCC_FLAGS + extra + ["-x", "hip", "-c", path, "-o", obj]
+        cmd = [hipcc()] + HIPCC_FLAGS + PER_FILE_FLAGS.get(src, []) + extra + ["-x", "hip", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

@@ -55,12 +55,12 @@ __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store((
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // In-kernel phase stamps (diagnostic builds: EBOS_EXTRA_FLAGS=-DEBOS_STAMPS): workgroup b, phase k of the LAST iteration ->
-// g_rstamps[b * 16 + k] (100 MHz clock); read with ebos_debug_read_stamps_resident, tools/stamp_resident.py
+// g_rstamps[b * 32 + k] (100 MHz clock); read with ebos_debug_read_stamps_resident, tools/stamp_resident.py
 #ifdef EBOS_STAMPS
-__device__ unsigned long long g_rstamps[1024 * 16];
+__device__ unsigned long long g_rstamps[1024 * 32];
 #define EBOS_RSTAMP(k)                                                                                   \
   do {                                                                                                   \
-    if (threadIdx.x == 0 && it == n_iter - 1) g_rstamps[blockIdx.x * 16 + (k)] = wall_clock64();         \
+    if (threadIdx.x == 0 && it == n_iter - 1) g_rstamps[blockIdx.x * 32 + (k)] = wall_clock64();         \
   } while (0)
 #else
 #define EBOS_RSTAMP(k) \
@@ -106,6 +106,7 @@ __device__ __forceinline__ void put_granules(unsigned long long* g, unsigned tag
 
 constexpr int kRecGranules = 8;  // a record: (sum, sum of squares, regulariser partial of the previous iteration) = 6 granules, 64-byte stride
 constexpr int kSpan = 4;         // candidate tiles per axis whose partial cell gradients a cell sums (patch_grad_combine_kernel's)
+constexpr int kResElems = 128;   // elements (2 components x cells) of a tile's cell block the resident kernel holds state for
 
 struct ResidentArgs {
   EvPtrs ev;
@@ -117,7 +118,7 @@ struct ResidentArgs {
   int* step;
   float *iwe, *slabs, *cell_partials;
   unsigned* status;
-  unsigned long long *flag1, *flag3, *rec2, *done;   // mailbox sections (zeroed before every launch)
+  unsigned long long *flag1, *flag3, *flagi, *rec2, *done;   // mailbox sections (zeroed before every launch)
   float* losses;
   int losses_cap, t0, n_iter;
   double lr, beta1, beta2, eps;
@@ -209,6 +210,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
   __shared__ unsigned s_next;
   __shared__ float s_gmax[2 * kWaves];
   __shared__ unsigned s_win[9];
+  __shared__ int s_wmax[2];     // largest window (rows, columns) of the grid in this iteration
   __shared__ double s_mom[4];    // mean, variance, sum of the regulariser partials of the previous iteration
   __shared__ double s_reg[2];    // this tile's regulariser value partial: of this iteration, of the previous one
   __shared__ float s_adam[3];    // step size and sqrt(bias correction 2) of the iteration's Adam step; variance of the previous iteration
@@ -218,9 +220,9 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
   const int tile = blockIdx.x;
 
   // ---- once: interpolation tables of tile + apron, the block of cells they touch, this thread's element of it -------------------
-  float m_e = 0.0f, v_e = 0.0f, g_e = 0.0f;
-  unsigned cand_a = 0, cand_b = 0;  // which tiles' partials this thread's cell sums (below)
-  bool has, owner = false;
+  // per element of the cell block (thread e < 2 ni nj), in LDS rather than in registers that would be live across every phase:
+  __shared__ float s_m[kResElems], s_v[kResElems], s_gl[kResElems];  // Adam's exp_avg / exp_avg_sq, the last gradient
+  __shared__ unsigned s_cand_a[kResElems], s_cand_b[kResElems];      // which tiles' partials the element's cell sums (below)
   int n_iter;
   {
     KArgs& a = fresh_args();
@@ -247,20 +249,22 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     __syncthreads();
     const int gi0 = s_lerp[0].i0, ni = s_lerp[PH - 1].i1 - gi0 + 1;
     const int gj0 = s_lerp[PH].i0, nj = s_lerp[PH + PW - 1].i1 - gj0 + 1;
-    has = (int)threadIdx.x < 2 * ni * nj;  // this thread holds element (ch, gi0 + ci, gj0 + cj) of the cell block
+    const bool has = (int)threadIdx.x < 2 * ni * nj;  // this thread steps element (ch, gi0 + ci, gj0 + cj) of the cell block
+    if (2 * ni * nj > kResElems && threadIdx.x == 0) st_sc1(a.status, (unsigned)RES_GEOMETRY);
     const int e_ = has ? (int)threadIdx.x : 0;
     const int ch = e_ / (ni * nj), ci = (e_ - ch * (ni * nj)) / nj, cj = e_ - ch * (ni * nj) - ci * nj;
     const int gi = gi0 + ci, gj = gj0 + cj;
     const int64_t gidx = ((int64_t)ch * ay.g + gi) * ax.g + gj;
     if (has) {
       s_cells[(ch * kGridCells + ci) * kGridCells + cj] = a.theta[gidx];
-      m_e = a.exp_avg[gidx], v_e = a.exp_avg_sq[gidx];
+      s_m[e_ % kResElems] = a.exp_avg[gidx], s_v[e_ % kResElems] = a.exp_avg_sq[gidx], s_gl[e_ % kResElems] = 0.0f;
     }
     // which tiles' partial cell gradients this cell sums (the arithmetic of patch_grad_combine_kernel, flow_upsample.hip): <= kSpan
     // candidate tiles per axis from the cell's conservative pixel support; a candidate counts if its own cell block holds the cell.
     // cand_a = first candidate tile per axis (2 x 8 bits) | validity masks (2 x 4 bits); cand_b = the cell's index in each
     // candidate's block, 4 bits each (rows: bits 0..15, columns: 16..31)
     {
+      unsigned cand_a = 0, cand_b = 0;
       int r_lo, r_hi, c_lo, c_hi;
       support(ay, gi, H, &r_lo, &r_hi);
       support(ax, gj, W, &c_lo, &c_hi);
@@ -282,8 +286,10 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         if (oky && first_ty < 0) first_ty = cty;
         if (okx && first_tx < 0) first_tx = ctx;
       }
-      cand_a = (unsigned)(cty0 & 255) | ((unsigned)(ctx0 & 255) << 8) | (yv << 16) | (xv << 20);
-      owner = has && first_ty == ty && first_tx == tx;  // the first tile that holds a cell writes it back at the end
+      // (bit 24: this tile is the first that holds the cell and writes it back at the end)
+      cand_a = (unsigned)(cty0 & 255) | ((unsigned)(ctx0 & 255) << 8) | (yv << 16) | (xv << 20) |
+               ((unsigned)(first_ty == ty && first_tx == tx) << 24);
+      if (has) s_cand_a[e_ % kResElems] = cand_a, s_cand_b[e_ % kResElems] = cand_b;
     }
     if (threadIdx.x == 0) {
       const TileRange tr = tile_range<FMT_COMPACT>(key_offsets, ev, TH * TW, tiles_x, 1);
@@ -329,6 +335,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         s_spill = 0;
         s_bad = 0;
         s_next = 2 * kWaves;
+        s_wmax[0] = s_wmax[1] = 0;
       }
       tile_flow_from_cells<TH, TW, 0>(s_lerp + AP, s_lerp + PH + AP, s_cells, gi0, gj0, s_flow_f);
       __syncthreads();
@@ -378,21 +385,37 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     }
     if (!s_ok) { done_ok = false; break; }
     EBOS_RSTAMP(4);
-    // ---- G: this tile's pixels of the IWE = sum of the slabs whose windows reach them, in the combine pass's order ---------------
+    // ---- G: the UPSTREAM WINDOW of the IWE (this tile + the halo the backward sweep reads) = per pixel the sum of the slabs whose
+    // windows reach it, in the combine pass's order (same bits as the four-launch image).  This workgroup's own contribution is
+    // decoded from its LDS image (what it stored to its slab, without the round trip); the neighbours' come from their slabs.  A halo
+    // pixel is complete with the 3 x 3 tiles around THIS tile as long as no tile two away reaches it: hr + hr' < TH, hc + hc' < TW
+    // for any two windows -- checked for the whole grid after the all-to-all (every record carries its window); BOS-sized flows
+    // pass, and nothing of the image then travels through memory.  Otherwise (checked below) the tiles publish their images and the
+    // halo is staged from those, as the four-launch backward kernel does.
+    constexpr int kQuads = (kLHmax * kLWmax / 4 + kBlock - 1) / kBlock;
+    constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
+    // (the window of the UPSTREAM image: the four-launch backward kernel stages at least its speculative 4 px window, and the
+    // fixed-point unit of the scatter follows max |staged value| -- same window, same unit, same bits)
+    const Win<TH, TW, HALO, true> wb = (win.hr <= kSpecHalo && win.hc <= kSpecHalo) ? Win<TH, TW, HALO, true>{kSpecHalo, kSpecHalo} : win;
     {
+      float4 wq[kQuads];
       KArgs& a = fresh_args();
       const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
       const int lo_px = a.omit ? 1 : 0;
-      const bool vec_store = (W & 3) == 0;
       const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(a.slabs, 0xffffffffu);
-      const __amdgpu_buffer_rsrc_t iwe_rsrc = slab_rsrc(a.iwe, 0xffffffffu);
-      float* iwe = a.iwe;
+      const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
+      const float inv_qw = 1.0f / (float)qw;
+      const bool lds_f64 = sh.chk != 0ull;               // (tile_body redid its slice exactly: the LDS image holds doubles)
+      const int own_lh = win.LH(), own_pt = win.P();
       double sm = 0.0, sq = 0.0;
-      for (int q0 = 0; q0 < TH * (TW / 4); q0 += kBlock) {
-        const int q = q0 + (int)threadIdx.x;
-        const int rl = q / (TW / 4), cl = (q - rl * (TW / 4)) * 4;
-        const int r = tr0 + rl, c = tc0 + cl;
-        const bool live = q < TH * (TW / 4) && r < H && c < W;
+#pragma unroll
+      for (int kq = 0; kq < kQuads; ++kq) {
+        wq[kq] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kq * kBlock >= n_q) continue;  // (uniform: a small window has fewer quads than the largest one's kQuads per thread)
+        const int i = threadIdx.x + kq * kBlock;
+        const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+        const int r = oy + rl, c = ox + 4 * cq;
+        const bool live = i < n_q && r >= 0 && r < H && c >= 0 && c < W;
         float4 part[9];
         bool okk[9];
 #pragma unroll
@@ -403,8 +426,10 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           const int rr = r - (nty * TH - hr), cc = c - (ntx * TW - hc), lw = TW + 2 * hc;
           okk[k] = live && w != 0xffffffffu && (unsigned)rr < (unsigned)(TH + 2 * hr) && (unsigned)cc < (unsigned)lw;
           part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-          // (a neighbour's window reaches only the rim of this tile: most waves hold no quad of it and skip its load)
-          if (__builtin_amdgcn_ballot_w64(okk[k]) != 0ull) {
+          if (k == 4) {  // this workgroup's own image: LDS
+            part[k] = lds_image_cells4(s_acc, own_lh, own_pt, okk[k] ? rr : 0, okk[k] ? cc >> 2 : 0, lds_f64);
+          } else if (__builtin_amdgcn_ballot_w64(okk[k]) != 0ull) {
+            // (a neighbour's window reaches only the rim of this window: most waves hold no quad of it and skip its load)
             const unsigned byte = okk[k] ? ((unsigned)(nty * tiles_x + ntx) * (unsigned)(kLHmax * kLWmax) + (unsigned)(rr * lw + cc)) * 4u : 0u;
             part[k] = slab_load4(all_slabs, byte);
           }
@@ -413,39 +438,41 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
 #pragma unroll
         for (int k = 0; k < 9; ++k)
           if (okk[k]) v.x += part[k].x, v.y += part[k].y, v.z += part[k].z, v.w += part[k].w;
-        if (live) {
+        wq[kq] = v;
+        // the variance moments: this tile's own pixels (quads lie inside a tile as a whole or outside it)
+        if (live && r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW && r >= lo_px && r < H - lo_px) {
           const float e4[4] = {v.x, v.y, v.z, v.w};
-          const int64_t gi_px = (int64_t)r * W + c;
-          if (vec_store) {
-            slab_store4(iwe_rsrc, (unsigned)(gi_px * 4), v);
-          } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (c + k < W) st_sc1(iwe + gi_px + k, e4[k]);
-          }
-          if (r >= lo_px && r < H - lo_px) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (c + k >= lo_px && c + k < W - lo_px) {
-                sm += (double)e4[k];
-                sq += (double)e4[k] * (double)e4[k];
-              }
-          }
+          for (int k = 0; k < 4; ++k)
+            if (c + k >= lo_px && c + k < W - lo_px) {
+              sm += (double)e4[k];
+              sq += (double)e4[k] * (double)e4[k];
+            }
         }
       }
       EBOS_RSTAMP(5);
-      drain_stores();
-      block_sum2(sm, sq, s_red);  // (its barriers stand behind every wave's drain)
+      block_sum2(sm, sq, s_red);  // (behind its barriers every thread has read what it needs of the LDS image: the backward view may overwrite it)
       if (threadIdx.x == 0) {
         unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * (a.tiles_y * tiles_x) + tile) * kRecGranules;
         put_granules(rec, ep, sm);
         put_granules(rec + 2, ep, sq);
         put_granules(rec + 4, ep, s_reg[1]);
+        st_sc1(rec + 6, ((unsigned long long)ep << 32) | win_pack(wb.hr, wb.hc));
       }
+      // While the records travel: the raw window goes to its place in LDS (held in registers across the all-to-all it was spilled:
+      // +4 us), the d_flow accumulators are cleared and the tile's flow with its apron is evaluated -- none of it needs the mean.
+#pragma unroll
+      for (int kq = 0; kq < kQuads; ++kq) {
+        const int i = threadIdx.x + kq * kBlock;
+        if (i < n_q) reinterpret_cast<float4*>(s_g)[i] = wq[kq];
+      }
+      for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
+      tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
     }
     EBOS_RSTAMP(6);
-    // ---- S2: the one all-to-all: every tile's (sum, sum of squares, regulariser partial of the previous iteration) ---------------
+    // ---- S2: the one all-to-all: every tile's (sum, sum of squares, regulariser partial of the previous iteration, window) ---------
     double mean;
+    bool halo_complete;
     {
       KArgs& a = fresh_args();
       const int n_tiles = a.tiles_y * a.tiles_x;
@@ -455,11 +482,11 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       if (wave * kWave < n_tiles) {
         const int k = wave * kWave + lane;
         const unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * n_tiles + min(k, n_tiles - 1)) * kRecGranules;
-        unsigned long long g[6];
+        unsigned long long g[7];
         const bool ok = wave_wait([&]() {
           bool all = true;
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
+          for (int j = 0; j < 7; ++j) {
             g[j] = ld_sc1(rec + j);
             all = all && (unsigned)(g[j] >> 32) == ep;
           }
@@ -470,7 +497,13 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           aq = __builtin_bit_cast(double, (g[2] & 0xffffffffull) | (g[3] << 32));
           ar = __builtin_bit_cast(double, (g[4] & 0xffffffffull) | (g[5] << 32));
         }
-        if (lane == 0 && !ok) s_ok = 0;
+        const float mh = wave_max_nonneg(ok ? (float)((unsigned)g[6] & 255u) : 255.0f);
+        const float mw = wave_max_nonneg(ok ? (float)(((unsigned)g[6] >> 8) & 255u) : 255.0f);
+        if (lane == 0) {
+          atomicMax(&s_wmax[0], (int)mh);
+          atomicMax(&s_wmax[1], (int)mw);
+          if (!ok) s_ok = 0;
+        }
       }
       EBOS_RSTAMP(7);
       as = wave_sum(as), aq = wave_sum(aq), ar = wave_sum(ar);
@@ -486,6 +519,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       }
       __syncthreads();
       mean = s_mom[0];
+      halo_complete = 2 * s_wmax[0] < TH && 2 * s_wmax[1] < TW;  // (uniform over the GRID: every workgroup saw every window)
       if (blockIdx.x == 0 && threadIdx.x == 0) {  // bookkeeping: the loss of the PREVIOUS iteration is complete now
         const float var_f = (float)s_mom[1];
         const int t_prev = a.t0 + it - 1;
@@ -499,7 +533,60 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     }
     if (!s_ok) { done_ok = false; break; }
     EBOS_RSTAMP(8);
-    // ---- B0 + B1: upstream window (tile + halo) of d loss / d IWE = 2 (-w) (IWE - mean) / (M - 1), from the tiles' images; the sweep ---
+    // ---- the image leaves the kernel in its last iteration -- or now, when tiles two apart reach into each other's halos: every
+    // tile publishes its pixels and the halo is read back from the neighbours' (the four-launch pipeline's staging)
+    if (!halo_complete || it == n_iter - 1) {
+      KArgs& a = fresh_args();
+      const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
+      const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
+      const float inv_qw = 1.0f / (float)qw;
+      float* iwe = a.iwe;
+#pragma unroll
+      for (int kq = 0; kq < kQuads; ++kq) {
+        const int i = threadIdx.x + kq * kBlock;
+        const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+        const int r = oy + rl, c = ox + 4 * cq;
+        if (i < n_q && r >= tr0 && r < min(tr0 + TH, H) && c >= tc0 && c < tc0 + TW) {
+          const float4 v = reinterpret_cast<const float4*>(s_g)[i];
+          const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (c + k < W) st_sc1(iwe + (int64_t)r * W + c + k, e4[k]);
+        }
+      }
+      if (!halo_complete) {
+        drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) st_sc1(a.flagi + tile, (unsigned long long)ep);
+        if (wave == 0) {
+          const int nty = ty + lane / 3 - 1, ntx = tx + lane % 3 - 1;
+          const bool nb = lane < 9 && nty >= 0 && nty < tiles_y && ntx >= 0 && ntx < tiles_x;
+          const unsigned long long* f = a.flagi + (nb ? nty * tiles_x + ntx : tile);
+          const bool ok = wave_wait([&]() { return !nb || ld_sc1(f) >= (unsigned long long)ep; }, a.status, a.cap_ticks);
+          if (lane == 0 && !ok) s_ok = 0;
+        }
+        __syncthreads();
+        if (s_ok) {
+          float4 wq[kQuads];
+#pragma unroll
+          for (int kq = 0; kq < kQuads; ++kq) {
+            const int i = min((int)threadIdx.x + kq * kBlock, n_q - 1);
+            const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+            const int R = min(max(oy + rl, 0), H - 1), c = ox + 4 * cq;
+            const float* row = iwe + (int64_t)R * W;
+            wq[kq] = make_float4(ld_sc1(row + min(max(c, 0), W - 1)), ld_sc1(row + min(max(c + 1, 0), W - 1)),
+                                 ld_sc1(row + min(max(c + 2, 0), W - 1)), ld_sc1(row + min(max(c + 3, 0), W - 1)));
+          }
+#pragma unroll
+          for (int kq = 0; kq < kQuads; ++kq) {
+            const int i = threadIdx.x + kq * kBlock;
+            if (i < n_q) reinterpret_cast<float4*>(s_g)[i] = wq[kq];  // (every thread rewrites the quads it read above: no barrier needed)
+          }
+        }
+      }
+    }
+    if (!s_ok) { done_ok = false; break; }
+    // ---- B0 + B1: upstream window of d loss / d IWE = 2 (-w) (IWE - mean) / (M - 1) -> LDS; the sweep ------------------------------------
     FxUnit unit;
     bool fx;
     {
@@ -507,45 +594,35 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
       const int lo_px = a.omit ? 1 : 0;
       const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
-      // (the window of the UPSTREAM image: the four-launch backward kernel stages at least its speculative 4 px window, and the
-      // fixed-point unit of the scatter follows max |staged value| -- same window, same unit, same bits)
-      constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
-      const Win<TH, TW, HALO, true> wb = (win.hr <= kSpecHalo && win.hc <= kSpecHalo) ? Win<TH, TW, HALO, true>{kSpecHalo, kSpecHalo} : win;
-      const int LW = wb.LW(), n_win = wb.LH() * LW, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
+      const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
+      const float inv_qw = 1.0f / (float)qw;
       GradImage G;
       G.g = a.iwe;
       const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
       G.a = (float)ga;
       G.c = (float)(-ga * mean);
       G.h = H, G.w = W, G.lo = lo_px;
-      constexpr int kStage = (kLHmax * kLWmax + kBlock - 1) / kBlock;
-      float raw[kStage];
-      const float inv_lw = 1.0f / (float)LW;
-      const float* iwe = a.iwe;
-#pragma unroll
-      for (int k = 0; k < kStage; ++k) {
-        if (k * kBlock >= n_win) break;  // (uniform)
-        const int i = min((int)threadIdx.x + k * kBlock, n_win - 1);
-        const int rl = (int)(((float)i + 0.5f) * inv_lw), cl = i - rl * LW;
-        const int R = min(max(oy + rl, 0), H - 1), C = min(max(ox + cl, 0), W - 1);
-        raw[k] = ld_sc1(iwe + (int64_t)R * W + C);
-      }
-      for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
-      tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
       float gmax_t = 0.0f;
-#pragma unroll
-      for (int k = 0; k < kStage; ++k) {
-        if (k * kBlock >= n_win) break;
-        const int i = threadIdx.x + k * kBlock;
-        const int rl = (int)(((float)i + 0.5f) * inv_lw), cl = i - rl * LW;
-        const int R = oy + rl, C = ox + cl;
+      auto affine = [&](int R, int C, float v, bool in_window) {
         const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-        const float gv = valid ? G.a * raw[k] + G.c : 0.0f;
-        if (i < n_win) {
-          s_g[i] = gv;
-          gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
-        }
+        const float gv = valid ? G.a * v + G.c : 0.0f;
+        if (in_window) gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);  // (max |staged value|: the scatter's fixed-point unit)
+        return gv;
+      };
+      EBOS_RSTAMP(18);
+      // the affine map of the image (the variance gradient), in place: every thread maps the quads it parked
+#pragma unroll
+      for (int kq = 0; kq < kQuads; ++kq) {
+        const int i = threadIdx.x + kq * kBlock;
+        const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+        const int R = oy + rl, C = ox + 4 * cq;
+        const bool in = i < n_q;
+        if (kq * kBlock >= n_q) continue;  // (uniform)
+        const float4 v = reinterpret_cast<const float4*>(s_g)[in ? i : 0];
+        const float4 gq = make_float4(affine(R, C, v.x, in), affine(R, C + 1, v.y, in), affine(R, C + 2, v.z, in), affine(R, C + 3, v.w, in));
+        if (in) reinterpret_cast<float4*>(s_g)[i] = gq;
       }
+      EBOS_RSTAMP(19);
       gmax_t = wave_max_nonneg(gmax_t);
       if (lane == 0) s_gmax[wave] = gmax_t;
       __syncthreads();
@@ -601,10 +678,12 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     if (!s_ok) { done_ok = false; break; }
     EBOS_RSTAMP(13);
     // ---- A: d loss / d theta of this thread's cell element = sum of the partials of the tiles that hold it; Adam ------------------
-    if (has) {
+    if ((int)threadIdx.x < 2 * rfl(P.ni) * rfl(P.nj)) {
       KArgs& a = fresh_args();
       const int tiles_x = a.tiles_x, tiles_y = a.tiles_y;
       const int ninj = rfl(P.ni) * rfl(P.nj), nj = rfl(P.nj);
+      const unsigned cand_a = s_cand_a[threadIdx.x % kResElems], cand_b = s_cand_b[threadIdx.x % kResElems];
+      float m_e = s_m[threadIdx.x % kResElems], v_e = s_v[threadIdx.x % kResElems];
       const int ch = (int)threadIdx.x / ninj, rem = (int)threadIdx.x - ch * ninj, ci = rem / nj, cj = rem - ci * nj;
       const float* cp = a.cell_partials;
       const int cty0 = (int)(cand_a & 255u), ctx0 = (int)((cand_a >> 8) & 255u);
@@ -625,10 +704,10 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
 #pragma unroll
         for (int q = 0; q < kSpan; ++q) g += (((cand_a >> (16 + p)) & 1u) && ((cand_a >> (20 + q)) & 1u)) ? pv[p][q] : 0.0f;
       if (a.theta_mask != nullptr) g *= mask;
-      g_e = g;
       float th = s_cells[(ch * kGridCells + ci) * kGridCells + cj];
       adam_update(g, m_e, v_e, th, s_adam[0], s_adam[1], (float)a.beta2, (float)(1.0 - a.beta1), (float)(1.0 - a.beta2), (float)a.eps);
       s_cells[(ch * kGridCells + ci) * kGridCells + cj] = th;
+      s_m[threadIdx.x % kResElems] = m_e, s_v[threadIdx.x % kResElems] = v_e, s_gl[threadIdx.x % kResElems] = g;
     }
     EBOS_RSTAMP(14);
     __syncthreads();  // the new theta block is in LDS
@@ -637,14 +716,14 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
 
   // ---- the state goes back: every cell element by the first tile that holds it ------------------------------------------------------
   KArgs& a = fresh_args();
-  if (owner) {
+  if ((int)threadIdx.x < 2 * rfl(P.ni) * rfl(P.nj) && ((s_cand_a[threadIdx.x % kResElems] >> 24) & 1u)) {
     const int ninj = rfl(P.ni) * rfl(P.nj), nj = rfl(P.nj);
     const int ch = (int)threadIdx.x / ninj, rem = (int)threadIdx.x - ch * ninj, ci = rem / nj, cj = rem - ci * nj;
     const int64_t gidx = ((int64_t)ch * a.gs.ay.g + rfl(P.gi0) + ci) * a.gs.ax.g + rfl(P.gj0) + cj;
     a.theta[gidx] = s_cells[(ch * kGridCells + ci) * kGridCells + cj];
-    a.exp_avg[gidx] = m_e;
-    a.exp_avg_sq[gidx] = v_e;
-    a.d_theta[gidx] = g_e;
+    a.exp_avg[gidx] = s_m[threadIdx.x % kResElems];
+    a.exp_avg_sq[gidx] = s_v[threadIdx.x % kResElems];
+    a.d_theta[gidx] = s_gl[threadIdx.x % kResElems];
   }
   if (n_iter <= 0) return;
   // the last iteration's loss: its regulariser partials travel through the `done` granules; workgroup 0 gathers them
@@ -672,14 +751,15 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
 }
 
 struct MailboxLayout {
-  size_t off_status, off_flag1, off_flag3, off_rec2, off_done, total;
+  size_t off_status, off_flag1, off_flag3, off_flagi, off_rec2, off_done, total;
 };
 inline MailboxLayout mailbox_layout(int n_tiles) {
   MailboxLayout m;
   m.off_status = 0;
   m.off_flag1 = 256;
   m.off_flag3 = m.off_flag1 + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
-  m.off_rec2 = m.off_flag3 + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
+  m.off_flagi = m.off_flag3 + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
+  m.off_rec2 = m.off_flagi + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
   m.off_done = m.off_rec2 + (size_t)2 * n_tiles * kRecGranules * 8;
   m.total = m.off_done + (((size_t)n_tiles * 16 + 255) & ~(size_t)255);
   return m;
@@ -767,6 +847,10 @@ bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
     set_error("resident solve: %d tiles (one record per thread: <= %d)", tiles_y * tiles_x, kBlock);
     return false;
   }
+  if (((q->tile_h + 2 * kBwdApron) / q->slide_h + 3) * ((q->tile_w + 2 * kBwdApron) / q->slide_w + 3) * 2 > kResElems) {
+    set_error("resident solve: sliding window %dx%d: a tile's block of grid cells has more than %d elements", q->slide_h, q->slide_w, kResElems);
+    return false;
+  }
   // every cell sums at most kSpan x kSpan tiles, every tile's block waits for at most 64 tiles
   const Axis ay = make_axis(q->gh, q->patch_h, q->slide_h, q->H), ax = make_axis(q->gw, q->patch_w, q->slide_w, q->W);
   if (ay.off < 0 || ax.off < 0) {
@@ -816,6 +900,9 @@ extern "C" {
 #ifdef EBOS_STAMPS
 int ebos_debug_read_stamps_resident(unsigned long long* host, int count) {  // diagnostic builds only
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_rstamps), sizeof(unsigned long long) * count);
+}
+int ebos_debug_read_stamps_resident_bwd(unsigned long long* host, int count) {  // (this file's copy of the shared backward stamps)
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_stamps_bwd), sizeof(unsigned long long) * count);
 }
 #endif
 
@@ -870,6 +957,7 @@ int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* q, int n_i
   a.status = reinterpret_cast<unsigned*>(mb + m.off_status);
   a.flag1 = reinterpret_cast<unsigned long long*>(mb + m.off_flag1);
   a.flag3 = reinterpret_cast<unsigned long long*>(mb + m.off_flag3);
+  a.flagi = reinterpret_cast<unsigned long long*>(mb + m.off_flagi);
   a.rec2 = reinterpret_cast<unsigned long long*>(mb + m.off_rec2);
   a.done = reinterpret_cast<unsigned long long*>(mb + m.off_done);
   a.losses = q->losses, a.losses_cap = q->losses_cap, a.t0 = q->steps_done, a.n_iter = n_iter;

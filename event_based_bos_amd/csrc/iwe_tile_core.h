@@ -813,6 +813,24 @@ __device__ __forceinline__ Win<TH, TW, HALO, DYN> tile_bound_read(const float* s
   return w;
 }
 
+// cells 4 j .. 4 j + 3 of row r of a workgroup's LDS image as the decode pass of tile_body stores them to its slab: fixed-point planes
+// A / B (row pitch PT cells, LH rows) or, after an exact redo (f64 = true), doubles -- the same conversions, the same bits
+__device__ __forceinline__ float4 lds_image_cells4(const double* s_acc, int LH, int PT, int r, int j, bool f64) {
+  if (f64) {
+    const double* p = s_acc + r * PT + 4 * j;
+    return make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+  }
+  constexpr float kInv = (float)kFxInv;
+  const uint2* pa = reinterpret_cast<const uint2*>(s_acc);
+  const uint2* pb = pa + LH * PT / 2;
+  const int wrow = r * (PT / 2);
+  const uint2 a0 = pa[wrow + 2 * j], a1 = pa[wrow + 2 * j + 1];
+  const uint2 b0 = pb[wrow + 2 * j], b1 = pb[wrow + 2 * j + 1];
+  const unsigned bmh = j > 0 ? pb[wrow + 2 * j - 1].y : 0u;
+  return make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv, ((float)a1.x + (float)b0.y) * kInv,
+                     ((float)a1.y + (float)b1.x) * kInv);
+}
+
 // workgroup state of the accumulate pass
 struct TileShared {
   unsigned long long chk;  // sum over the workgroup of (units added - units decoded), modulo 2^64
@@ -1890,10 +1908,87 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
     const Lerp l = s_lx[c];
     s_wx[idx] = c < cols ? (l.i0 == gj0 + j ? l.w0 : 0.0f) + (l.i1 == gj0 + j ? l.w1 : 0.0f) : 0.0f;
   }
-  // This thread's pixels of the tile gradient, in registers: decoded from the accumulators (fixed-point words or doubles), plus
-  // what enters per pixel (regulariser gradients).  They go back as PLANAR FLOATS s_f [2][TH * TW] in place of the accumulators
-  // -- after a barrier: a pixel's float slots lie inside other pixels' words.
+  // This thread's pixels of the tile gradient: decoded from the accumulators (fixed-point words or doubles), plus what enters per
+  // pixel (regulariser gradients), as PLANAR FLOATS s_f [2][TH * TW] for the row sums.
+  //   kSeparate (where the dead upstream window has the room): s_f lies behind the sums' own buffers, every pixel is decoded,
+  //     completed and stored in one go -- no values held in registers across a barrier, one barrier less (the resident solver kernel
+  //     spilled them: 6.7 us for this half of the epilogue against 3.4 in the stand-alone backward kernel);
+  //   otherwise in place of the accumulators, after a barrier: a pixel's float slots lie inside other pixels' words.
   constexpr int kPx = (TH * TW + kBlock - 1) / kBlock;
+  constexpr bool kSeparate = (size_t)kGridCells * (3 * TW + TH) + (size_t)2 * TH * TW <= (size_t)(TH + 2 * HALO) * (TW + 2 * HALO);
+  float* s_f = kSeparate ? s_wx + kGridCells * TW : reinterpret_cast<float*>(s_d);
+  __shared__ double s_red_norm[kBlock / kWave];
+  // one pixel's regulariser terms on the tile's own flow (in LDS, with a 2 px apron): value -> val, gradient -> (gu, gv).
+  // flow_norm (src/costs/flow_norm.py:45-56: mean |flow|, s_norm = weight / (H W)) is pointwise; image_gradient
+  // (src/costs/image_gradient.py:60-75: mean(|d/d row| + |d/d col|) over both components, s_tv = weight / (2 H W)) reads the
+  // torch.gradient lines through the pixel, up to 2 px away -- the same device functions as the stand-alone regulariser kernel,
+  // on LDS lines instead of global ones.
+  auto regularise = [&](int rl, int cl, float& gu, float& gv, double& val) {
+    const int o = (rl + AP) * PW + cl + AP;
+    const float u = s_flow[o], v = s_flow[PH * PW + o];
+    if (s_norm != 0.0f) {
+      const float nrm = sqrtf(u * u + v * v);
+      val += (double)(s_norm * nrm);
+      if (nrm > 0.0f) {  // torch: the sub-gradient of the norm at 0 is 0
+        const float inv = s_norm / nrm;
+        gu += inv * u;
+        gv += inv * v;
+      }
+    }
+    if (s_tv != 0.0f) {
+      // line bases such that base[i * stride] is sample i of the image column / row through this pixel
+      const float* col_u = s_flow + (AP - tr0) * PW + cl + AP;
+      const float* row_u = s_flow + (rl + AP) * PW + AP - tc0;
+      const float* col_v = col_u + PH * PW;
+      const float* row_v = row_u + PH * PW;
+      const int r = tr0 + rl, c = tc0 + cl;
+      val += (double)(s_tv * (fabsf(central(col_u, r, H, PW)) + fabsf(central(row_u, c, W, 1)) +
+                              fabsf(central(col_v, r, H, PW)) + fabsf(central(row_v, c, W, 1))));
+      gu += s_tv * (tv_adjoint(col_u, r, H, PW) + tv_adjoint(row_u, c, W, 1));
+      gv += s_tv * (tv_adjoint(col_v, r, H, PW) + tv_adjoint(row_v, c, W, 1));
+    }
+  };
+#ifdef EBOS_STAMPS_EPI
+  EBOS_STAMP_BWD(1);
+#endif
+  if constexpr (kSeparate) {
+    double val = 0.0;
+    const bool first = tr.part == 0;  // the per-tile terms enter once per tile
+#pragma unroll
+    for (int k = 0; k < kPx; ++k) {
+      const int idx = threadIdx.x + k * kBlock;
+      if (idx < TH * TW) {
+        const int rl = idx / TW, cl = idx - rl * TW;
+        float pu = grad.at(idx, 0), pv = grad.at(idx, 1);
+        if (first && rl < rows && cl < cols) {
+          if (addend != nullptr) {
+            const int64_t o = (int64_t)(tr0 + rl) * W + tc0 + cl;
+            pu += addend[o];
+            pv += addend[hw + o];
+          }
+          if (reg_out != nullptr) {
+            float gu = 0.0f, gv = 0.0f;
+            regularise(rl, cl, gu, gv, val);
+            pu += gu;
+            pv += gv;
+          }
+        }
+        s_f[idx] = pu;
+        s_f[TH * TW + idx] = pv;
+      }
+    }
+#ifdef EBOS_STAMPS_EPI
+    EBOS_STAMP_BWD(2);
+#endif
+    if (reg_out != nullptr) {
+      val = wave_sum(val);  // per-wave partials, summed in wave order by one thread after the barrier below (deterministic)
+      if ((threadIdx.x & (kWave - 1)) == 0) s_red_norm[threadIdx.x / kWave] = val;
+    }
+#ifdef EBOS_STAMPS_EPI
+    EBOS_STAMP_BWD(7);
+#endif
+    __syncthreads();
+  } else {
   float px_u[kPx], px_v[kPx];
 #pragma unroll
   for (int k = 0; k < kPx; ++k) {
@@ -1913,13 +2008,7 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
       }
     }
   }
-  __shared__ double s_red_norm[kBlock / kWave];
   if (reg_out != nullptr) {
-    // The flow regularisers on this tile's own flow (in LDS, with a 2 px apron): value partial + gradient here -- no dense
-    // field, no regulariser launch.  flow_norm (src/costs/flow_norm.py:45-56: mean |flow|, s_norm = weight / (H W)) is
-    // pointwise; image_gradient (src/costs/image_gradient.py:60-75: mean(|d/d row| + |d/d col|) over both components,
-    // s_tv = weight / (2 H W)) reads the torch.gradient lines through the pixel, up to 2 px away -- the same device
-    // functions as the stand-alone regulariser kernel, on LDS lines instead of global ones.
     double val = 0.0;
     if (tr.part == 0) {
 #pragma unroll
@@ -1927,30 +2016,8 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
         const int idx = threadIdx.x + k * kBlock;
         const int rl = idx / TW, cl = idx - rl * TW;
         if (idx < TH * TW && rl < rows && cl < cols) {
-          const int o = (rl + AP) * PW + cl + AP;
-          const float u = s_flow[o], v = s_flow[PH * PW + o];
           float gu = 0.0f, gv = 0.0f;
-          if (s_norm != 0.0f) {
-            const float nrm = sqrtf(u * u + v * v);
-            val += (double)(s_norm * nrm);
-            if (nrm > 0.0f) {  // torch: the sub-gradient of the norm at 0 is 0
-              const float inv = s_norm / nrm;
-              gu += inv * u;
-              gv += inv * v;
-            }
-          }
-          if (s_tv != 0.0f) {
-            // line bases such that base[i * stride] is sample i of the image column / row through this pixel
-            const float* col_u = s_flow + (AP - tr0) * PW + cl + AP;
-            const float* row_u = s_flow + (rl + AP) * PW + AP - tc0;
-            const float* col_v = col_u + PH * PW;
-            const float* row_v = row_u + PH * PW;
-            const int r = tr0 + rl, c = tc0 + cl;
-            val += (double)(s_tv * (fabsf(central(col_u, r, H, PW)) + fabsf(central(row_u, c, W, 1)) +
-                                    fabsf(central(col_v, r, H, PW)) + fabsf(central(row_v, c, W, 1))));
-            gu += s_tv * (tv_adjoint(col_u, r, H, PW) + tv_adjoint(row_u, c, W, 1));
-            gv += s_tv * (tv_adjoint(col_v, r, H, PW) + tv_adjoint(row_v, c, W, 1));
-          }
+          regularise(rl, cl, gu, gv, val);
           px_u[k] += gu;
           px_v[k] += gv;
         }
@@ -1960,7 +2027,6 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
     if ((threadIdx.x & (kWave - 1)) == 0) s_red_norm[threadIdx.x / kWave] = val;
   }
   __syncthreads();  // every accumulator has been read
-  float* s_f = reinterpret_cast<float*>(s_d);
 #pragma unroll
   for (int k = 0; k < kPx; ++k) {
     const int idx = threadIdx.x + k * kBlock;
@@ -1970,6 +2036,7 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
     }
   }
   __syncthreads();
+  }
   EBOS_STAMP_BWD(5);
   if (reg_out != nullptr && threadIdx.x == 0) {
     double val = 0.0;

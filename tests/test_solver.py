@@ -522,3 +522,27 @@ def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
     assert res.last_run_mode == "pipeline" and res.resident_status == -102
     np.testing.assert_array_equal(l_ref, l_res)
     assert torch.equal(ref.theta, res.theta)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,n_ev,patch,amp", [((96, 128), 20_000, (24, 32), 20.0), ((720, 1280), 400_000, (24, 32), 24.0)])
+def test_resident_loop_with_windows_that_reach_two_tiles_far(size, n_ev, patch, amp):
+    """Flows whose LDS windows are larger than half a tile: a halo pixel may then receive events of a tile TWO away, which the
+    3 x 3 slabs around a workgroup do not hold -- the resident kernel must notice (every record of the all-to-all carries its
+    window), publish the image tiles and stage the halo from them; same losses and flows as the four-launch pipeline, bit for bit."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w = size
+    rs = np.random.RandomState(13)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+    theta0 = torch.from_numpy(rs.uniform(-amp, amp, (2, gh, gw))).float()
+    ref = FusedPatchLoop(plan, patch, patch, theta0, 1.0, 0.001, 0.0, halo="auto", lr=0.01, capacity=64)
+    res = FusedPatchLoop(plan, patch, patch, theta0, 1.0, 0.001, 0.0, halo="auto", lr=0.01, capacity=64)
+    l_ref = ref.run(40, resident=False).cpu().numpy()
+    l_res = res.run(40, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.resident_status == 0
+    np.testing.assert_array_equal(l_res, l_ref)
+    assert torch.equal(ref.theta, res.theta) and torch.equal(ref.iwe, res.iwe)

@@ -32,12 +32,12 @@ torch.cuda.synchronize()
 assert loop.last_run_mode == "resident", loop.resident_status
 th, tw = plan.tile
 n = -(-H // th) * -(-W // tw)
-buf = (ctypes.c_ulonglong * (n * 16))()
-raw.ebos_debug_read_stamps_resident(buf, n * 16)
-st = np.array(buf[:], dtype=np.float64).reshape(n, 16) * 10.0  # ns
+buf = (ctypes.c_ulonglong * (n * 32))()
+raw.ebos_debug_read_stamps_resident(buf, n * 32)
+st = np.array(buf[:], dtype=np.float64).reshape(n, 32) * 10.0  # ns
 names = ["F0 cells -> LDS, window, tile flow", "F1 event loop + decode + slab stores issued", "   drain slab stores + barrier + flag1",
-         "S1 wait for the 8 neighbours", "G  gather own tile from slabs (loads + image stores issued)", "   drain + block sum + record",
-         "S2 poll all records", "   reduce (mean / variance)", "B0 stage upstream window, clear, tile flow (apron)", "B1 sweep",
+         "S1 wait for the 8 neighbours", "G  gather the upstream window (own LDS image + neighbours' slabs)", "   block sum + record; window -> LDS, clear, tile flow (apron)",
+         "S2 poll all records", "   reduce (mean / variance)", "B0 affine map of the window, barrier", "B1 sweep",
          "B2 regulariser + tile adjoint (stores issued)", "   drain + barrier + flag3", "S3 wait for the partials' tiles (+ LDS clear)", "A  cell gradients + Adam"]
 print(f"{H}x{W}, {a.events} events, tile {plan.tile}, {n} workgroups; last of {a.iters} iterations")
 tot = st[:, 14] - st[:, 0]
@@ -46,3 +46,14 @@ for i, nm in enumerate(names):
     print(f"  {nm:62s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
 print(f"  {'iteration (F0 -> A)':62s} median {np.median(tot) / 1e3:6.2f} us   min {tot.min() / 1e3:6.2f}   max {tot.max() / 1e3:6.2f}")
 print(f"  start skew of the iteration across workgroups: {(st[:, 0].max() - st[:, 0].min()) / 1e3:.2f} us")
+if st[:, 18].max() > 0:  # sub-stamps of B0 (vector staging path)
+    for nm, i0, i1 in (("B0: (image publish, if any)", 8, 18), ("B0: affine map of the window in place", 18, 19), ("B0: wave max + barrier", 19, 9)):
+        d = st[:, i1] - st[:, i0]
+        print(f"  {nm:62s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
+bb = (ctypes.c_ulonglong * (n * 8))()
+raw.ebos_debug_read_stamps_resident_bwd(bb, n * 8)
+sb = np.array(bb[:], dtype=np.float64).reshape(n, 8) * 10.0
+for nm, d in (("B1: main sweep (lane-0 wave)", sb[:, 3] - st[:, 9]), ("B1: wait for the other waves", st[:, 10] - sb[:, 3]),
+              ("B2: row / column weights", sb[:, 1] - st[:, 10]), ("B2: pixels: decode + regulariser + planar store", sb[:, 2] - sb[:, 1]),
+              ("B2: wave sum of the regulariser value", sb[:, 7] - sb[:, 2]), ("B2: barrier", sb[:, 5] - sb[:, 7]), ("B2: row sums, column sums, stores", sb[:, 6] - sb[:, 5])):
+    print(f"  {nm:62s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
