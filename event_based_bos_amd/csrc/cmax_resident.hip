@@ -321,6 +321,16 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     // ---- F0 + F1: the tile's window from a bound on its displacements, the tile's flow; events -> LDS image -> slab ----------------
     {
       KArgs& a = fresh_args();
+      const int tiles_x = a.tiles_x;
+      TileRange tr;
+      tr.ty = tile / tiles_x, tr.tx = tile - tr.ty * tiles_x, tr.slab = tile, tr.part = 0;
+      tr.g_first = rfl(P.g_first), tr.g_last = rfl(P.g_last), tr.beg = rfl(P.beg), tr.end = rfl(P.end);
+      const EvPtrs ev = a.ev;
+      // the event loop's first two chunks per wave, requested now: they arrive under the window bound and the tile's flow instead of
+      // a round trip in front of the loop's first deposit (up to 2 M events per window these ARE the tile's events)
+      CRaw pre[2];
+      pre[0] = load_craw(tr.g_first + wave * kWave + lane, tr, ev);
+      pre[1] = load_craw(tr.g_first + (wave + kWaves) * kWave + lane, tr, ev);
       const int gi0 = rfl(P.gi0), gj0 = rfl(P.gj0), ninj = rfl(P.ni) * rfl(P.nj);
       {
         const bool h2 = (int)threadIdx.x < 2 * ninj;
@@ -341,13 +351,8 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       __syncthreads();
       win = tile_bound_read<TH, TW, HALO, true>(sh.bound, a.dt_bound);
       EBOS_RSTAMP(1);
-      const int tiles_x = a.tiles_x;
-      TileRange tr;
-      tr.ty = tile / tiles_x, tr.tx = tile - tr.ty * tiles_x, tr.slab = tile, tr.part = 0;
-      tr.g_first = rfl(P.g_first), tr.g_last = rfl(P.g_last), tr.beg = rfl(P.beg), tr.end = rfl(P.end);
-      const EvPtrs ev = a.ev;
       tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, true, false>(tr, win, s_flow_f, s_acc, sh, ev, a.H, a.W, tiles_x, 0, 0,
-                                                                                    a.slabs, nullptr, nullptr, 0u, nullptr, nullptr, NoHook{});
+                                                                                    a.slabs, nullptr, nullptr, 0u, nullptr, pre, NoHook{});
       EBOS_RSTAMP(2);
       drain_stores();
       __syncthreads();
@@ -468,6 +473,17 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       }
       for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
       tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
+    }
+    // the backward sweep's first two chunks per wave, requested before the all-to-all and decoded behind it
+    BwdPreRaw pre_raw;
+    {
+      KArgs& a = fresh_args();
+      TileRange tr;
+      tr.ty = tr.tx = 0, tr.slab = tile, tr.part = 0;
+      tr.g_first = rfl(P.g_first), tr.g_last = rfl(P.g_last), tr.beg = rfl(P.beg), tr.end = rfl(P.end);
+      const EvPtrs ev = a.ev;
+      pre_raw.A = load_craw(tr.g_first + wave * kWave + lane, tr, ev);
+      pre_raw.B = load_craw(tr.g_first + (wave + kWaves) * kWave + lane, tr, ev);
     }
     EBOS_RSTAMP(6);
     // ---- S2: the one all-to-all: every tile's (sum, sum of squares, regulariser partial of the previous iteration, window) ---------
@@ -634,8 +650,13 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       tr.ty = ty, tr.tx = tx, tr.slab = tile, tr.part = 0;
       tr.g_first = rfl(P.g_first), tr.g_last = rfl(P.g_last), tr.beg = rfl(P.beg), tr.end = rfl(P.end);
       const EvPtrs ev = a.ev;
+      BwdPre pre;
+      decode_bgroup(pre.A, pre_raw.A, (unsigned)PW, 0u, (unsigned)(AP * PW + AP));  // (the tile's flow in LDS: element indices, pitch PW)
+      decode_bgroup(pre.B, pre_raw.B, (unsigned)PW, 0u, (unsigned)(AP * PW + AP));
+      finish_bgroup<TW>(pre.A);
+      finish_bgroup<TW>(pre.B);
       fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, ev, s_flow_b, H, W, 0, 0, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
-                                                           unit, a.dt_bound, BwdPre{}, false, bsh, NoHook{});
+                                                           unit, a.dt_bound, pre, true, bsh, NoHook{});
       __syncthreads();
     }
     EBOS_RSTAMP(10);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/kernel_stats_latest.json from a rocprofv3 --kernel-trace --stats CSV of the default bench command
 (tools/collect_round_profiles.sh): average / min / max duration and call count of the path's kernels, stamped with the blob
-hash of csrc/iwe_tiled.hip the run was made on -- bench.py quotes it next to its live HIP-event timing and drops it when the
+hash of csrc/iwe_tile_core.h the run was made on -- bench.py quotes it next to its live HIP-event timing and drops it when the
 kernel source has changed since.
 
     python tools/make_kernel_stats_json.py <kernel_stats.csv> <out.json> [commit]"""
@@ -12,7 +12,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "event_based_bos_amd", "csrc", "iwe_tiled.hip")
+SRC = os.path.join(ROOT, "event_based_bos_amd", "csrc", "iwe_tile_core.h")
 data = open(SRC, "rb").read()
 out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (tools/collect_round_profiles.sh)",
        "source_blob_sha": hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest(),

@@ -9,13 +9,13 @@ Per kernel (keyed by what it does, not by its full template name):
   SQ_INSTS_VALU / SQ_INSTS_LDS / ...   wave-instructions per launch, summed over the chip (bench.py's roofline_issue)
 Keys: "<kernel>" for the dense-flow instantiation with a built halo (what BENCH lines have always quoted),
 "<kernel><GRID>", "<kernel><UNIFORM>", and "...,DYN>" for the run-time-window variants; the batched accumulate pass is per
-LAUNCH of 16 windows ("windows" says so).  Everything is stamped with the blob hash of csrc/iwe_tiled.hip: bench.py drops a
+LAUNCH of 16 windows ("windows" says so).  Everything is stamped with the blob hash of csrc/iwe_tile_core.h: bench.py drops a
 stale collection to null."""
 import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "event_based_bos_amd", "csrc", "iwe_tiled.hip")
+SRC = os.path.join(ROOT, "event_based_bos_amd", "csrc", "iwe_tile_core.h")
 
 
 def blob_sha(path):  # = git hash-object (bench.py recomputes it and drops a stale `traffic` to null)
