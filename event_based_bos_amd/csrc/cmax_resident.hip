@@ -363,11 +363,35 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       break;
     }
     // ---- S1: the eight neighbours' slabs (and their windows) --------------------------------------------------------------------
+    constexpr int kQuads = (kLHmax * kLWmax / 4 + kBlock - 1) / kBlock;
+    constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
+    // (the window of the UPSTREAM image: the four-launch backward kernel stages at least its speculative 4 px window, and the
+    // fixed-point unit of the scatter follows max |staged value| -- same window, same unit, same bits)
+    const Win<TH, TW, HALO, true> wb = (win.hr <= kSpecHalo && win.hc <= kSpecHalo) ? Win<TH, TW, HALO, true>{kSpecHalo, kSpecHalo} : win;
+    float4 own[kQuads];  // this workgroup's own contribution to the quads of its upstream window, decoded from its LDS image
     {
       KArgs& a = fresh_args();
       const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, ty = tile / tiles_x, tx = tile - ty * tiles_x;
       if (threadIdx.x == 0) st_sc1(a.flag1 + tile, ((unsigned long long)ep << 32) | win_pack(win.hr, win.hc));
       EBOS_RSTAMP(3);
+      {  // while the neighbours' flags travel: the own part of the gather below (needs nothing of theirs)
+        const int H = a.H, W = a.W, tr0 = ty * TH, tc0 = tx * TW;
+        const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
+        const float inv_qw = 1.0f / (float)qw;
+        const bool lds_f64 = sh.chk != 0ull;             // (tile_body redid its slice exactly: the LDS image holds doubles)
+        const int own_lh = win.LH(), own_pt = win.P(), row0 = tr0 - win.HR(), col0 = tc0 - win.HC(), own_lw = win.LW();
+#pragma unroll
+        for (int kq = 0; kq < kQuads; ++kq) {
+          own[kq] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kq * kBlock >= n_q) continue;  // (uniform)
+          const int i = threadIdx.x + kq * kBlock;
+          const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+          const int r = oy + rl, c = ox + 4 * cq, rr = r - row0, cc = c - col0;
+          const bool ok = i < n_q && r >= 0 && r < H && c >= 0 && c < W && (unsigned)rr < (unsigned)own_lh && (unsigned)cc < (unsigned)own_lw;
+          const float4 v = lds_image_cells4(s_acc, own_lh, own_pt, ok ? rr : 0, ok ? cc >> 2 : 0, lds_f64);
+          if (ok) own[kq] = v;
+        }
+      }
       if (wave == 0) {
         const int nty = ty + lane / 3 - 1, ntx = tx + lane % 3 - 1;
         const bool nb = lane < 9 && nty >= 0 && nty < tiles_y && ntx >= 0 && ntx < tiles_x;
@@ -397,11 +421,6 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     // for any two windows -- checked for the whole grid after the all-to-all (every record carries its window); BOS-sized flows
     // pass, and nothing of the image then travels through memory.  Otherwise (checked below) the tiles publish their images and the
     // halo is staged from those, as the four-launch backward kernel does.
-    constexpr int kQuads = (kLHmax * kLWmax / 4 + kBlock - 1) / kBlock;
-    constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
-    // (the window of the UPSTREAM image: the four-launch backward kernel stages at least its speculative 4 px window, and the
-    // fixed-point unit of the scatter follows max |staged value| -- same window, same unit, same bits)
-    const Win<TH, TW, HALO, true> wb = (win.hr <= kSpecHalo && win.hc <= kSpecHalo) ? Win<TH, TW, HALO, true>{kSpecHalo, kSpecHalo} : win;
     {
       float4 wq[kQuads];
       KArgs& a = fresh_args();
@@ -410,8 +429,6 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(a.slabs, 0xffffffffu);
       const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
       const float inv_qw = 1.0f / (float)qw;
-      const bool lds_f64 = sh.chk != 0ull;               // (tile_body redid its slice exactly: the LDS image holds doubles)
-      const int own_lh = win.LH(), own_pt = win.P();
       double sm = 0.0, sq = 0.0;
 #pragma unroll
       for (int kq = 0; kq < kQuads; ++kq) {
@@ -425,17 +442,21 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         bool okk[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          const unsigned w = s_win[k];
+          // (what depends on the candidate only is uniform: scalar registers and the scalar unit -- these phases are bound by vector
+          // instruction issue at four waves per SIMD, not by memory)
+          const unsigned w = (unsigned)rfl((int)s_win[k]);
           const int nty = ty + k / 3 - 1, ntx = tx + k % 3 - 1;
           const int hr = (int)(w & 255u), hc = (int)((w >> 8) & 255u);
-          const int rr = r - (nty * TH - hr), cc = c - (ntx * TW - hc), lw = TW + 2 * hc;
-          okk[k] = live && w != 0xffffffffu && (unsigned)rr < (unsigned)(TH + 2 * hr) && (unsigned)cc < (unsigned)lw;
+          const int row0 = nty * TH - hr, col0 = ntx * TW - hc, lw = TW + 2 * hc, lh = TH + 2 * hr;
+          const unsigned slab0 = (unsigned)(nty * tiles_x + ntx) * (unsigned)(kLHmax * kLWmax);
+          const int rr = r - row0, cc = c - col0;
+          okk[k] = live && w != 0xffffffffu && (unsigned)rr < (unsigned)lh && (unsigned)cc < (unsigned)lw;
           part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (k == 4) {  // this workgroup's own image: LDS
-            part[k] = lds_image_cells4(s_acc, own_lh, own_pt, okk[k] ? rr : 0, okk[k] ? cc >> 2 : 0, lds_f64);
-          } else if (__builtin_amdgcn_ballot_w64(okk[k]) != 0ull) {
+          if (k == 4) {  // this workgroup's own image: decoded from LDS above
+            part[k] = own[kq];
+          } else if (w != 0xffffffffu && __builtin_amdgcn_ballot_w64(okk[k]) != 0ull) {
             // (a neighbour's window reaches only the rim of this window: most waves hold no quad of it and skip its load)
-            const unsigned byte = okk[k] ? ((unsigned)(nty * tiles_x + ntx) * (unsigned)(kLHmax * kLWmax) + (unsigned)(rr * lw + cc)) * 4u : 0u;
+            const unsigned byte = okk[k] ? (slab0 + (unsigned)(rr * lw + cc)) * 4u : 0u;
             part[k] = slab_load4(all_slabs, byte);
           }
         }
@@ -627,15 +648,27 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       };
       EBOS_RSTAMP(18);
       // the affine map of the image (the variance gradient), in place: every thread maps the quads it parked
+      // (an interior tile's window lies inside the valid region as a whole: no per-pixel tests -- vector instruction issue, not
+      // memory, bounds these passes)
+      const bool all_valid = oy >= G.lo && oy + wb.LH() <= G.h - G.lo && ox >= G.lo && ox + wb.LW() <= G.w - G.lo;
 #pragma unroll
       for (int kq = 0; kq < kQuads; ++kq) {
         const int i = threadIdx.x + kq * kBlock;
-        const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
-        const int R = oy + rl, C = ox + 4 * cq;
         const bool in = i < n_q;
         if (kq * kBlock >= n_q) continue;  // (uniform)
         const float4 v = reinterpret_cast<const float4*>(s_g)[in ? i : 0];
-        const float4 gq = make_float4(affine(R, C, v.x, in), affine(R, C + 1, v.y, in), affine(R, C + 2, v.z, in), affine(R, C + 3, v.w, in));
+        float4 gq;
+        if (all_valid) {
+          gq = make_float4(G.a * v.x + G.c, G.a * v.y + G.c, G.a * v.z + G.c, G.a * v.w + G.c);
+          if (in) {
+            const float m4 = fmaxf(fmaxf(fabsf(gq.x), fabsf(gq.y)), fmaxf(fabsf(gq.z), fabsf(gq.w)));
+            gmax_t = fmaxf(gmax_t, (gq.x + gq.y + gq.z + gq.w) == (gq.x + gq.y + gq.z + gq.w) ? m4 : INFINITY);  // (a NaN anywhere: Inf)
+          }
+        } else {
+          const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+          const int R = oy + rl, C = ox + 4 * cq;
+          gq = make_float4(affine(R, C, v.x, in), affine(R, C + 1, v.y, in), affine(R, C + 2, v.z, in), affine(R, C + 3, v.w, in));
+        }
         if (in) reinterpret_cast<float4*>(s_g)[i] = gq;
       }
       EBOS_RSTAMP(19);
