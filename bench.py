@@ -53,8 +53,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 DOMINANT_SOURCE = os.path.join("event_based_bos_amd", "csrc", "iwe_tile_core.h")
 CONFIG4 = dict(windows=64, events=2_000_000, patch=(24, 32), slide=(24, 32))   # -> patch grid 30 x 40
 CONFIG5 = dict(events=50_000_000, grid=(32, 16), theta_max=30.0)              # -> 512 hypotheses
-DEFAULT_STEPS = {2: 200, 4: 10, 5: 2}
-DEFAULT_WARMUP = {2: 20, 4: 2, 5: 1}
+DEFAULT_STEPS = {2: 200, 3: 200, 4: 10, 5: 2}
+DEFAULT_WARMUP = {2: 20, 3: 20, 4: 2, 5: 1}
 
 
 def parse_args(argv=None):
@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend of an N-rank run: nccl (= RCCL, one GPU per rank) or gloo (host-side barrier / "
                          "reduce; ranks may then share a GPU -- a functional test of the N-rank path on a one-GPU box)")
@@ -799,6 +799,135 @@ def run_config2(R):
         print(json.dumps(line))
 
 
+def cpu_baseline_gradmag(ev, flow, sample):
+    """BASELINE configs[2] on the host: the oracle's torch-CPU restatement of warp + IWE + gradient-magnitude contrast (Sobel 3x3 / 8,
+    replicate padding: src/utils/stat_utils.py:69-92, 117-139), forward and forward + backward (autograd), fp64, on a bounded sample."""
+    import torch
+
+    from oracle import ebos_oracle as O
+
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(avail, 8)
+    torch.set_num_threads(threads)
+    e = torch.from_numpy(ev[:sample])
+    times_f, times_fb, contrast = [], [], None
+    for rep in range(4):
+        f = torch.from_numpy(flow).clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        c = O.gradient_magnitude(O.iwe_dense(e, f, (H, W)))
+        t1 = time.perf_counter()
+        c.backward()
+        t2 = time.perf_counter()
+        times_f.append(t1 - t0)
+        times_fb.append(t2 - t0)
+        contrast = abs(float(c.item()))
+        if sum(times_fb) > 40.0 and rep >= 1:
+            break
+    reps = len(times_f) - 1
+    return {"value": round(sample / statistics.median(times_f[1:]) / 1e6, 3), "unit": "Mevents/s", "cores": threads, "host_cpus": avail,
+            "kind": "port", "value_fwd_bwd": round(sample / statistics.median(times_fb[1:]) / 1e6, 3),
+            "sample": (f"first {sample} events of the window, fwd warp + IWE + gradient magnitude (value_fwd_bwd: + autograd backward), "
+                       f"torch-CPU fp64, median of {reps} after 1 warm-up"), "contrast_f64": contrast}
+
+
+def run_config3(R):
+    """BASELINE configs[2]: the config-2 window with the gradient-magnitude contrast (Sobel on the IWE).  A step = one evaluation of
+    the objective on the resident plan (accumulate + combine + ONE Sobel pass that yields the value partials and the gradient image +
+    finalize); informative: value + flow gradient as the one native call (ebos_gradient_magnitude_dense_job_f32)."""
+    import ctypes
+
+    import torch
+
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd import _hip
+
+    a, dev, rank, world = R.args, R.dev, R.rank, R.world
+    lib = _hip.require_gpu()
+    n = a.events or N_EVENTS
+    t_ingest = time.perf_counter()
+    ev, flow_np = synth_window(n, seed=rank, flow_max=a.flow_max)
+    flow = torch.from_numpy(flow_np).float().to(dev)
+    if a.tile[0] <= 0:
+        a.tile = list(ebos.event_plan.choose_tile((H, W), 32 if a.halo == "auto" else a.halo))
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact")
+    halo_code = ebos.event_plan.resolve_halo(plan, a.halo)
+    job = ebos.event_plan._dense_job(plan, (0, 0), halo_code, a.splits, False)
+    d_iwe, partials, n_part = job.gm_buffers()
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    d_flow = torch.empty((2, H, W), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ingest_s = time.perf_counter() - t_ingest
+    stream = _hip.stream_ptr()
+    P = lambda t: t.data_ptr()
+
+    def step():
+        _hip.check(lib.ebos_gradient_magnitude_dense_job_f32(job.ref, P(flow), P(out), None, None, P(d_iwe), P(partials), n_part, stream),
+                   "ebos_gradient_magnitude_dense_job")
+
+    def step_fwd_bwd():
+        _hip.check(lib.ebos_gradient_magnitude_dense_job_f32(job.ref, P(flow), P(out), None, P(d_flow), P(d_iwe), P(partials), n_part, stream),
+                   "ebos_gradient_magnitude_dense_job")
+
+    blocks, sobel_ms = R.timed_blocks(step, lib, profile_kernel=_hip.PROFILE_GRADMAG_FUSED)
+    elapsed = statistics.median(blocks)
+    contrast = float(out.item())
+    ranks_seen = R.gather({"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", rank)), "device": str(dev), "units": 1,
+                           "ingest_s": round(ingest_s, 2)})
+    extras = {}
+    if not a.no_extras and rank == 0:
+        for _ in range(5):
+            step_fwd_bwd()
+        torch.cuda.synchronize()
+        reps = max(50, a.steps)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            step_fwd_bwd()
+        torch.cuda.synchronize()
+        fb_ms = (time.perf_counter() - t1) / reps * 1e3
+        extras["fwd_bwd_one_call_ms"] = round(fb_ms, 4)
+        extras["fwd_bwd_one_call_mevents_per_s"] = round(n / fb_ms / 1e3, 2)
+        # the same through the Python API: (-plan.contrast_dense(flow, "gradient_magnitude")).backward()
+        fl = flow.clone().requires_grad_(True)
+        for _ in range(5):
+            (-plan.contrast_dense(fl, "gradient_magnitude", halo=a.halo)).backward()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fl.grad = None
+            (-plan.contrast_dense(fl, "gradient_magnitude", halo=a.halo)).backward()
+        torch.cuda.synchronize()
+        extras["python_contrast_dense_backward_us"] = round((time.perf_counter() - t1) / reps * 1e6, 1)
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = world * n * a.steps / elapsed / 1e6
+        # SURVEY 8(d), cost kernels: 4 H W bytes read (+ 4 H W written for the gradient image)
+        roof = roofline_entry("gradmag_fused_kernel", sobel_ms, 8.0 * H * W,
+                              {"note": "the Sobel pass of the step: reads the IWE once, writes the gradient image once (SURVEY 8(d): 4 H W + 4 H W "
+                                       "bytes); the step's event kernels are config 2's (bench.py --config 2 carries their rooflines)",
+                               "step_frac_on_event_bytes": round((12.0 * plan.n + 12.0 * H * W) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        line = base_line(R, value, ms_per_step, blocks, "weak", {
+            "workload": ("BASELINE configs[2]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), gradient-magnitude cost "
+                         "(Sobel 3x3 / 8 on the IWE), fwd objective (tile accumulate + slab combine + one Sobel pass)")
+                        if (a.flow_max == FLOW_MAX and n == N_EVENTS) else f"NOT the BASELINE workload: {n} events, flow U(-{a.flow_max:g},{a.flow_max:g})",
+            "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
+            "layout": f"compact SoA (6 B/event), binned by source tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}, splits {a.splits}",
+            "parallelism": f"windows sharded, {world} rank(s), no collective"})
+        line["roofline"] = roof
+        line["ranks_seen"] = ranks_seen
+        line["contrast"] = contrast
+        line.update(extras)
+        if world == 1 and not a.no_cpu_baseline:
+            sample = min(a.cpu_sample, n, 2_000_000)
+            line["cpu_baseline"] = cpu_baseline_gradmag(ev, flow_np, sample)
+            line["speedup_vs_cpu_port_f64"] = round(value / line["cpu_baseline"]["value"], 1)
+            ps = ebos.EventPlan.build(torch.from_numpy(ev[:sample]).to(dev), (H, W), "first", True, tile=tuple(a.tile), emit="compact")
+            gpu_c = float(ps.contrast_dense(flow, "gradient_magnitude", halo=a.halo).item())
+            cpu_c = line["cpu_baseline"]["contrast_f64"]
+            line["contrast_cpu"], line["contrast_gpu_same_sample"] = cpu_c, gpu_c
+            line["contrast_rel_err"] = abs(gpu_c - cpu_c) / abs(cpu_c)
+        print(json.dumps(line))
+
+
 def run_config4(R):
     """64 windows x 2 M events, 30x40 patch-flow grid, windows round-robin over the ranks."""
     import numpy as np
@@ -1063,7 +1192,7 @@ def main(argv=None):
     if args.dry_run:
         return dry_run(args)
     R = Rank(args)
-    {2: run_config2, 4: run_config4, 5: run_config5}[args.config](R)
+    {2: run_config2, 3: run_config3, 4: run_config4, 5: run_config5}[args.config](R)
     if R.distributed:
         R.dist.barrier()
         R.dist.destroy_process_group()

@@ -19,7 +19,7 @@ EBOS_OK = 0
 REF_FIRST, REF_LAST, REF_FRACTION, REF_TIMEBASE = 0, 1, 2, 3
 SPLAT_BILINEAR, SPLAT_COUNT, SPLAT_POLARITY = 0, 1, 2
 GAUSS_REFLECT_SCIPY, GAUSS_REFLECT_TORCH = 0, 1
-PROFILE_SLAB_ACCUMULATE, PROFILE_TILED_BWD, PROFILE_SLAB_COMBINE = 0, 1, 2
+PROFILE_SLAB_ACCUMULATE, PROFILE_TILED_BWD, PROFILE_SLAB_COMBINE, PROFILE_GRADMAG_FUSED = 0, 1, 2, 3
 ABI_VERSION = 1
 
 
@@ -87,6 +87,9 @@ SIGNATURES = {
     "ebos_iwe_2dof_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "ebos_variance_dense_job_f32": (_I, [_P, _P, _P, _P, _P, _P]),
+    "ebos_gradient_magnitude_dense_job_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "ebos_gradient_magnitude_fused_partials": (_L, [_I, _I]),
+    "ebos_gradient_magnitude_fused_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
     "ebos_iwe_2dof_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_2dof_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "ebos_cost_scratch_bytes": (_Z, [_I]),

@@ -9,6 +9,8 @@
 // Sign handling (minimize / maximize) stays in the Python cost classes; these kernels return the
 // raw contrast.  One pass over a 3.7 MB image: HBM/L2-bound streaming reductions, partial sums in
 // fp64, one f64 atomic per workgroup.
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace ebos {
@@ -195,6 +197,120 @@ gradmag_grad_kernel(const T* __restrict__ images, int h, int w, Region rg, const
   }
 }
 
+// ---- gradient magnitude, value partials AND d contrast / d image in ONE pass over an LDS-tiled image ----------------------------
+// gradmag_kernel + gradmag_grad_kernel read the image twice, the second one 81 times per pixel (nine Sobel stencils, each
+// re-evaluated for every pixel that a tap of theirs folds onto), all in fp64.  Here a 256-thread workgroup holds a 16 x 64 tile with
+// a 2 px apron in LDS (replicate padding = clamped loads: the apron of a border tile holds the border's own pixels), evaluates the
+// Sobel pair once per pixel of tile + 1 px (f32: sums of eight image values; zero where the stencil's centre lies outside the
+// cost's region, so that it contributes to nothing), and every thread then sums the value partial of its four pixels (fp64) and
+// gathers their adjoint: nine multiply-adds of neighbouring stencils for a pixel inside the image, the folded form of
+// gradmag_grad_kernel (taps clamped onto the border) for the image's outermost ring only.  4 H W bytes read + 4 H W written:
+// SURVEY 8(d)'s cost-kernel bytes, once.
+constexpr int kGmTH = 16, kGmTW = 64;
+
+__global__ void __launch_bounds__(kCostBlock)
+gradmag_fused_kernel(const float* __restrict__ img, int h, int w, Region rg, const float* __restrict__ upstream, float* __restrict__ d_img,
+                     double* __restrict__ partials) {
+  constexpr int IH = kGmTH + 4, IW = kGmTW + 4, SH = kGmTH + 2, SW = kGmTW + 2;
+  __shared__ float s_img[IH * IW];
+  __shared__ float s_gx[SH * SW], s_gy[SH * SW];
+  const int tr0 = blockIdx.y * kGmTH, tc0 = blockIdx.x * kGmTW;
+  // (every load of the tile in flight before the first LDS store: rolled, the loop waited for each load in turn -- six serial
+  // round trips, 9.5 of the pass's 11 us)
+  constexpr int kLoads = (IH * IW + kCostBlock - 1) / kCostBlock;
+  float stage[kLoads];
+#pragma unroll
+  for (int k = 0; k < kLoads; ++k) {
+    const int i = min((int)threadIdx.x + k * kCostBlock, IH * IW - 1);
+    const int rl = i / IW, cl = i - rl * IW;
+    const int r = min(max(tr0 - 2 + rl, 0), h - 1), c = min(max(tc0 - 2 + cl, 0), w - 1);
+    stage[k] = img[(int64_t)r * w + c];
+  }
+#pragma unroll
+  for (int k = 0; k < kLoads; ++k) {
+    const int i = threadIdx.x + k * kCostBlock;
+    if (i < IH * IW) s_img[i] = stage[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SH * SW; i += kCostBlock) {
+    const int rl = i / SW, cl = i - rl * SW;
+    const int qr = tr0 - 1 + rl, qc = tc0 - 1 + cl;  // the stencil's centre
+    const float* p = s_img + (rl + 1) * IW + cl + 1;
+    const float a00 = p[-IW - 1], a01 = p[-IW], a02 = p[-IW + 1], a10 = p[-1], a12 = p[1], a20 = p[IW - 1], a21 = p[IW], a22 = p[IW + 1];
+    const bool in = qr >= rg.r0 && qr < rg.r1 && qc >= rg.c0 && qc < rg.c1;
+    // Gx = [[-1,-2,-1],[0,0,0],[1,2,1]] (row derivative); Gy = [[-1,0,1],[-2,0,2],[-1,0,1]] (column derivative)
+    s_gx[i] = in ? ((a20 + 2.0f * a21 + a22) - (a00 + 2.0f * a01 + a02)) * 0.125f : 0.0f;
+    s_gy[i] = in ? ((a02 + 2.0f * a12 + a22) - (a00 + 2.0f * a10 + a20)) * 0.125f : 0.0f;
+  }
+  __syncthreads();
+  const float scale = (float)(2.0 * (upstream ? (double)upstream[0] : 1.0) / (double)rg.count() * 0.125);
+  double val = 0.0;
+#pragma unroll
+  for (int k = 0; k < kGmTH * kGmTW / kCostBlock; ++k) {
+    const int i = threadIdx.x + k * kCostBlock;
+    const int rl = i / kGmTW, cl = i - rl * kGmTW;
+    const int pr = tr0 + rl, pc = tc0 + cl;
+    if (pr >= h || pc >= w) continue;
+    const float* gx = s_gx + (rl + 1) * SW + cl + 1;
+    const float* gy = s_gy + (rl + 1) * SW + cl + 1;
+    val += (double)(gx[0] * gx[0] + gy[0] * gy[0]);  // (zero outside the region)
+    // stencil q = p - d reads p through its tap d:  sum_d gx(p - d) Gx[d] + gy(p - d) Gy[d],  Gx[dr][dc] = dr (2 - |dc|),
+    // Gy[dr][dc] = dc (2 - |dr|)  (complete for a pixel inside the image; the outermost ring gets its folded taps below)
+    const float acc = (gx[-SW - 1] + 2.0f * gx[-SW] + gx[-SW + 1]) - (gx[SW - 1] + 2.0f * gx[SW] + gx[SW + 1])  // dr = +1: the row above p; -1: below
+                    + (gy[-SW - 1] + 2.0f * gy[-1] + gy[SW - 1]) - (gy[-SW + 1] + 2.0f * gy[1] + gy[SW + 1]);   // dc = +1: the column left of p; -1: right
+    if (pr >= 1 && pr < h - 1 && pc >= 1 && pc < w - 1) d_img[(int64_t)pr * w + pc] = scale * acc;
+  }
+  // The image's outermost ring: taps of stencils at the border clamp onto it (replicate padding).  With p' = q + d the unclamped
+  // position a tap aims at, the gather of gradmag_grad_kernel -- sum over q, over the taps d with clamp(q + d) = p -- is the sum over
+  // the positions p' that clamp onto p (p itself and its one or three mirror positions outside the image) of the plain nine-term
+  // form at p', stencils outside the region counting zero.  The ring's pixels of this tile are dealt to the threads one each, a
+  // pass of their own: inside the loop above they made every wave of a border tile run both forms (6 of the pass's 12.7 us).
+  if (tr0 == 0 || tr0 + kGmTH >= h || tc0 == 0 || tc0 + kGmTW >= w) {
+    auto plain = [&](int r, int c) {
+      float f = 0.0f;
+#pragma unroll
+      for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+        for (int dc = -1; dc <= 1; ++dc) {
+          const int qr = r - dr, qc = c - dc;
+          const bool ok = qr >= rg.r0 && qr < rg.r1 && qc >= rg.c0 && qc < rg.c1;  // (then q lies within tile + 1 px: p' is within 1 px of p)
+          const int qi = ok ? (qr - tr0 + 1) * SW + qc - tc0 + 1 : 0;
+          const float vx = ok ? s_gx[qi] : 0.0f, vy = ok ? s_gy[qi] : 0.0f;
+          f += vx * ((float)dr * (dc == 0 ? 2.0f : 1.0f)) + vy * ((float)dc * (dr == 0 ? 2.0f : 1.0f));
+        }
+      return f;
+    };
+    // candidates: the tile's first / last row and first / last column (2 (TH + TW) slots; a slot counts if it lies on the ring)
+    for (int i = threadIdx.x; i < 2 * (kGmTH + kGmTW); i += kCostBlock) {
+      int rl, cl;
+      if (i < kGmTW) rl = 0, cl = i;
+      else if (i < 2 * kGmTW) rl = min(kGmTH, h - tr0) - 1, cl = i - kGmTW;
+      else if (i < 2 * kGmTW + kGmTH) rl = i - 2 * kGmTW, cl = 0;
+      else rl = i - 2 * kGmTW - kGmTH, cl = min(kGmTW, w - tc0) - 1;
+      const int pr = tr0 + rl, pc = tc0 + cl;
+      if (pr >= h || pc >= w) continue;
+      const bool on_ring = pr == 0 || pr == h - 1 || pc == 0 || pc == w - 1;
+      // (a corner pixel appears in a row slot and a column slot, a one-row / one-column tile's pixels twice: same value stored twice)
+      if (!on_ring) continue;
+      float acc = 0.0f;
+      for (int a2 = (pr == 0 ? -1 : 0); a2 <= (pr == h - 1 ? 1 : 0); ++a2)
+        for (int b2 = (pc == 0 ? -1 : 0); b2 <= (pc == w - 1 ? 1 : 0); ++b2) acc += plain(pr + a2, pc + b2);
+      d_img[(int64_t)pr * w + pc] = scale * acc;
+    }
+  }
+  __shared__ double red[kCostBlock / kWave];
+  val = block_sum(val, red);
+  if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = val;
+}
+
+__global__ void __launch_bounds__(kCostBlock) gradmag_fused_finalize_kernel(const double* __restrict__ partials, int nparts, int64_t m, float* out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kCostBlock) s += partials[i];
+  __shared__ double red[kCostBlock / kWave];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = (float)(s / (double)m);
+}
+
 inline size_t cost_scratch(int K) { return (size_t)(K > 0 ? K : 0) * kCostGrid * 2 * sizeof(double) + 64; }
 
 template <typename T>
@@ -265,6 +381,34 @@ int gradmag_grad_impl(const T* images, int K, int h, int w, int omit, const T* u
 extern "C" {
 
 size_t ebos_cost_scratch_bytes(int K) { return ebos::cost_scratch(K); }
+
+int64_t ebos_gradient_magnitude_fused_partials(int h, int w) {
+  if (h <= 0 || w <= 0) return 0;
+  return (int64_t)((h + ebos::kGmTH - 1) / ebos::kGmTH) * ((w + ebos::kGmTW - 1) / ebos::kGmTW);
+}
+
+int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit_boundary, const float* upstream, float* out,
+                                      float* d_image, double* partials, int64_t n_partials, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(image && d_image && partials && image != d_image, "ebos_gradient_magnitude_fused: NULL or aliased image / d_image / partials");
+  EBOS_REQUIRE(h > 0 && w > 0, "ebos_gradient_magnitude_fused: bad sizes");
+  const int64_t need = ebos_gradient_magnitude_fused_partials(h, w);
+  if (n_partials < need) {
+    set_error("ebos_gradient_magnitude_fused: %lld partials given, %lld needed", (long long)n_partials, (long long)need);
+    return EBOS_ERR_SCRATCH;
+  }
+  const Region rg = make_region(h, w, omit_boundary);
+  hipStream_t s = as_stream(stream);
+  const dim3 grid((w + kGmTW - 1) / kGmTW, (h + kGmTH - 1) / kGmTH);
+  hipEvent_t t0, t1;
+  if (profile_next_pair(&t0, &t1, EBOS_PROFILE_GRADMAG_FUSED))  // bench.py --config 3: events stamped with this dispatch's begin / end
+    hipExtLaunchKernelGGL(gradmag_fused_kernel, grid, dim3(kCostBlock), 0, s, t0, t1, 0, image, h, w, rg, upstream, d_image, partials);
+  else
+    gradmag_fused_kernel<<<grid, dim3(kCostBlock), 0, s>>>(image, h, w, rg, upstream, d_image, partials);
+  if (out != nullptr) gradmag_fused_finalize_kernel<<<dim3(1), dim3(kCostBlock), 0, s>>>(partials, (int)need, rg.count(), out);
+  EBOS_CHECK_LAUNCH("ebos_gradient_magnitude_fused");
+  return EBOS_OK;
+}
 
 int ebos_image_variance_f32(const float* images, int K, int h, int w, int omit_boundary, float* out, double* moments,
                             void* scratch, size_t scratch_bytes, ebos_stream_t stream) {

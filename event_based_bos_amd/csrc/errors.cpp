@@ -45,7 +45,7 @@ extern "C" {
 int ebos_profile_start(int max_records) { return ebos_profile_start_kernel(EBOS_PROFILE_SLAB_ACCUMULATE, max_records); }
 int ebos_profile_start_kernel(int which, int max_records) {
   using namespace ebos;
-  if (max_records <= 0 || g_prof.on || which < 0 || which > EBOS_PROFILE_SLAB_COMBINE) {
+  if (max_records <= 0 || g_prof.on || which < 0 || which > EBOS_PROFILE_GRADMAG_FUSED) {
     set_error("ebos_profile_start: bad kernel selector / max_records, or profiling already on");
     return EBOS_ERR_INVALID_ARG;
   }

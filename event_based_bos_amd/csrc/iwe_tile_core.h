@@ -226,6 +226,10 @@ struct MomentsIn {
   int64_t n_partials, n_pixels;
   float* out_var;          // written by workgroup 0 (nullable)
   double* moments;         // (mean, M), written by workgroup 0 (nullable)
+  // mode 0: (sum, sum of squares) pairs of the combine pass -> variance, folded into the upstream as an affine map of the IWE;
+  // mode 1: one value partial per workgroup of gradmag_fused_kernel -> out_var[0] = sum / n_pixels, by workgroup 0 only (the upstream
+  //         image is the gradient image itself: nothing to fold; the finalize launch of the contrast value disappears)
+  int mode;
 };
 
 // AP = apron in pixels around the tile (0 forward; 2 backward: the image_gradient regulariser reads neighbours up to 2 px away).
@@ -2109,6 +2113,17 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   const ChunkQueue queue{&s_next};
   EBOS_STAMP_BWD(0);
   if (tr.ty < 0 && !(mj.partials != nullptr && blockIdx.x == 0)) return;  // unused work item (workgroup 0 still reports the variance)
+  const bool var_mj = mj.partials != nullptr && mj.mode == 0;
+  if (mj.partials != nullptr && mj.mode == 1) {  // (uniform) the contrast VALUE of the gradient-magnitude job: workgroup 0 sums its partials
+    if (blockIdx.x == 0) {
+      double sv = 0.0;
+      for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) sv += mj.partials[i];
+      __shared__ double red_v[kBlock / kWave];
+      sv = block_sum(sv, red_v);
+      if (threadIdx.x == 0 && mj.out_var) mj.out_var[0] = (float)(sv / (double)mj.n_pixels);
+    }
+    if (tr.ty < 0) return;
+  }
   const float* flow = flow_arg;
   const int64_t hw = (int64_t)H * W;
   GradImage G;
@@ -2199,7 +2214,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     pre_raw.B = load_craw(tr.g_first + (wave + kBlock / kWave) * kWave + lane, tr, ev);
   }
   double sm = 0.0, sq = 0.0;
-  if (mj.partials != nullptr) {
+  if (var_mj) {
     for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) {
       sm += mj.partials[2 * i];
       sq += mj.partials[2 * i + 1];
@@ -2220,7 +2235,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
     tile_bound_post(mu, mv, s_bound);
   }
-  if (mj.partials != nullptr) {
+  if (var_mj) {
     __shared__ double red_m[2 * kBlock / kWave];
     block_sum2(sm, sq, red_m);
     if (threadIdx.x == 0) {

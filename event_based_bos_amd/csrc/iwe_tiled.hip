@@ -771,6 +771,33 @@ int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, fl
                               adaptive ? job->workspace_bytes : 0, adaptive ? job->part_table : nullptr, stream, mj);
 }
 
+int ebos_gradient_magnitude_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_contrast, const float* upstream,
+                                          float* d_flow, float* d_iwe, double* partials, int64_t n_partials, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(job && flow && out_contrast, "ebos_gradient_magnitude_dense_job: NULL job / flow / out_contrast");
+  EBOS_REQUIRE(job->iwe && job->workspace && d_iwe && partials, "ebos_gradient_magnitude_dense_job: the job needs iwe, a workspace, d_iwe and partials");
+  const int h = job->H + 2 * job->pad_h, w = job->W + 2 * job->pad_w;
+  // accumulate + combine (no variance), then ONE pass over the image for the Sobel value partials and the gradient image
+  int rc = ebos_iwe_dense_slab_f32(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n,
+                                   flow, job->H, job->W, job->tile_h, job->tile_w, job->halo, job->splits, job->pad_h, job->pad_w,
+                                   job->workspace, job->workspace_bytes, job->iwe, 0, job->omit_boundary, nullptr, nullptr,
+                                   job->part_table, stream);
+  if (rc != EBOS_OK) return rc;
+  // value only: the Sobel pass finalizes; value + gradient: the backward kernel's first workgroup sums the value partials
+  rc = ebos_gradient_magnitude_fused_f32(job->iwe, h, w, job->omit_boundary, upstream, d_flow ? nullptr : out_contrast, d_iwe, partials,
+                                         n_partials, stream);
+  if (rc != EBOS_OK || d_flow == nullptr) return rc;
+  const int lo = job->omit_boundary ? 1 : 0;
+  const int64_t npix = (int64_t)(h - 2 * lo > 0 ? h - 2 * lo : 0) * (w - 2 * lo > 0 ? w - 2 * lo : 0);
+  EBOS_REQUIRE(npix >= 1, "ebos_gradient_magnitude_dense_job: empty image region");
+  const MomentsIn mj{partials, ebos_gradient_magnitude_fused_partials(h, w), npix, out_contrast, nullptr, 1};
+  const bool adaptive = job->splits == 0 && job->part_table != nullptr;
+  return dense_tiled_bwd_impl(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n, flow,
+                              job->H, job->W, job->tile_h, job->tile_w, job->halo, job->pad_h, job->pad_w, d_iwe, nullptr, 0, d_flow,
+                              nullptr, nullptr, nullptr, nullptr, adaptive ? job->workspace : nullptr,
+                              adaptive ? job->workspace_bytes : 0, adaptive ? job->part_table : nullptr, stream, mj);
+}
+
 size_t ebos_patch_grad_partials_bytes(int H, int W, int tile_h, int tile_w, int adaptive) {
   using namespace ebos;
   if (H <= 0 || W <= 0 || tile_h <= 0 || tile_w <= 0) return 0;

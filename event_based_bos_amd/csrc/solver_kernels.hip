@@ -255,9 +255,9 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
                                  q->moments, q->part_table, stream);
   if (rc) return rc;
   if (use_gm) {  // contrast = mean squared Sobel gradient of the IWE; its gradient image feeds the backward event kernel
-    rc = ebos_gradient_magnitude_f32(q->iwe, 1, h, w, q->omit_boundary, q->variance, q->cost_scratch, q->cost_scratch_bytes, stream);
-    if (rc) return rc;
-    rc = ebos_gradient_magnitude_grad_f32(q->iwe, 1, h, w, q->omit_boundary, q->upstream, q->d_iwe, stream);
+    // (one Sobel pass: value partials + gradient image; cost_scratch holds the partials)
+    rc = ebos_gradient_magnitude_fused_f32(q->iwe, h, w, q->omit_boundary, q->upstream, q->variance, q->d_iwe,
+                                           reinterpret_cast<double*>(q->cost_scratch), (int64_t)(q->cost_scratch_bytes / sizeof(double)), stream);
     if (rc) return rc;
   }
   size_t off = 0;

@@ -515,20 +515,19 @@ class EventPlan:
         go through ``variance_dense_many`` / ``variance_2dof``, which give every stream its own buffers.  First order only:
         the gradient is produced with the value, ``backward`` is once-differentiable (``create_graph=True`` raises)."""
         halo = _norm_halo(self, halo)
-        if cost == "image_variance":
+        if cost not in ("image_variance", "gradient_magnitude"):
+            raise KeyError(f"unknown contrast cost {cost!r}")
+        if cost == "image_variance" or _slab_ok(self, halo):
             pad2, splits = (int(pad[0]), int(pad[1])), self.resolve_splits(splits)
             if _eager_ok(self, flow, halo):
                 # value and gradient by the one native call, handed back as a tensor whose ``.backward()`` -- when it is called on
                 # the result itself, the objective idiom -- stores the gradient without entering the autograd engine (the engine's
                 # thread hand-off around a Python backward costs more than both event kernels); any other use of the result
                 # attaches the ordinary autograd node first (_EagerLoss)
-                out, d_flow = _run_dense_job(_dense_job(self, pad2, halo, splits, bool(omit_boundary)), flow, True)
+                out, d_flow = _run_dense_job(_dense_job(self, pad2, halo, splits, bool(omit_boundary)), flow, True, cost)
                 return _EagerLoss.wrap(out[0], flow, d_flow)
-            return _FusedVarianceDense.apply(flow, self, pad2, bool(omit_boundary), halo, splits)
-        iwe = self.iwe_dense(flow, pad=pad, halo=halo, splits=splits)
-        if cost == "gradient_magnitude":
-            return ops.gradient_magnitude(iwe, omit_boundary)
-        raise KeyError(f"unknown contrast cost {cost!r}")
+            return _FusedVarianceDense.apply(flow, self, pad2, bool(omit_boundary), halo, splits, cost)
+        return ops.gradient_magnitude(self.iwe_dense(flow, pad=pad, halo=halo, splits=splits), omit_boundary)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -712,6 +711,16 @@ class _DenseJob(object):
                                     self.ws.numel(), ptr(plan.part_table), ptr(self.iwe), ptr(self.moments))
         self.ref = C.addressof(self.struct)
         self.index = plan.device.index
+        self._gm = None
+
+    def gm_buffers(self):
+        """Scratch of the gradient-magnitude job: the gradient image and the Sobel pass's value partials (allocated on first use)."""
+        if self._gm is None:
+            lib = _hip.require_gpu()
+            h, w = self.iwe.shape
+            n = int(lib.ebos_gradient_magnitude_fused_partials(h, w))
+            self._gm = (torch.empty_like(self.iwe), torch.empty(n, dtype=torch.float64, device=self.iwe.device), n)
+        return self._gm
 
 
 def _dense_job(plan: EventPlan, pad, halo, splits, omit) -> _DenseJob:
@@ -723,17 +732,26 @@ def _dense_job(plan: EventPlan, pad, halo, splits, omit) -> _DenseJob:
     return job
 
 
-def _run_dense_job(job: _DenseJob, flow32: torch.Tensor, want_grad: bool):
-    """(variance [1], d variance / d flow [2, H, W] | None) in one native call."""
+def _run_dense_job(job: _DenseJob, flow32: torch.Tensor, want_grad: bool, cost: str = "image_variance"):
+    """(contrast [1], d contrast / d flow [2, H, W] | None) in one native call: the variance (three launches) or the gradient
+    magnitude (four: one Sobel pass yields the value partials and the gradient image, ``ebos_gradient_magnitude_dense_job_f32``)."""
     lib = _hip.require_gpu()
     out = torch.empty(1, dtype=torch.float32, device=flow32.device)
     d_flow = torch.empty_like(flow32) if want_grad else None
+
+    def call():
+        if cost == "image_variance":
+            return lib.ebos_variance_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), None, ptr(d_flow), stream_ptr())
+        d_iwe, partials, n = job.gm_buffers()
+        return lib.ebos_gradient_magnitude_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), None, ptr(d_flow), d_iwe.data_ptr(),
+                                                         partials.data_ptr(), n, stream_ptr())
+
     if _hip.current_device_index() == job.index:
-        rc = lib.ebos_variance_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), None, ptr(d_flow), stream_ptr())
+        rc = call()
     else:
         with _hip.on_device(flow32.device):
-            rc = lib.ebos_variance_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), None, ptr(d_flow), stream_ptr())
-    check(rc, "ebos_variance_dense_job")
+            rc = call()
+    check(rc, "ebos_variance_dense_job" if cost == "image_variance" else "ebos_gradient_magnitude_dense_job")
     return out, d_flow
 
 
@@ -994,15 +1012,15 @@ class _FusedVarianceDense(torch.autograd.Function):
     against 65 us of kernels per fwd + bwd at 10 M events before)."""
 
     @staticmethod
-    def forward(ctx, flow, plan, pad, omit, halo, splits):
+    def forward(ctx, flow, plan, pad, omit, halo, splits, cost="image_variance"):
         lib = _hip.require_gpu()
         fast = flow.dtype == torch.float32 and flow.is_contiguous() and flow.device == plan.device and \
             tuple(flow.shape) == (2,) + tuple(plan.image_size)
         flow32 = flow if fast else _check_flow(plan, flow)
         ctx.fdt = flow.dtype
-        if _slab_ok(plan, halo):  # IWE + variance (+ gradient) in one tile-private pipeline
+        if _slab_ok(plan, halo):  # IWE + contrast (+ gradient) in one tile-private pipeline
             job = _dense_job(plan, pad, halo, splits, omit)
-            out, d_flow = _run_dense_job(job, flow32, ctx.needs_input_grad[0])
+            out, d_flow = _run_dense_job(job, flow32, ctx.needs_input_grad[0], cost)
             ctx.eager = True
             if d_flow is not None:
                 ctx.save_for_backward(d_flow)
@@ -1027,12 +1045,12 @@ class _FusedVarianceDense(torch.autograd.Function):
         if ctx.eager:
             (d_flow,) = ctx.saved_tensors
             d = d_flow * g.to(torch.float32)
-            return (d if ctx.fdt == torch.float32 else d.to(ctx.fdt)), None, None, None, None, None
+            return (d if ctx.fdt == torch.float32 else d.to(ctx.fdt)), None, None, None, None, None, None
         flow32, iwe, moments = ctx.saved_tensors
         plan, pad, omit, halo, splits = ctx.meta
         up = g.to(torch.float32).reshape(1).contiguous()
         d_flow, _ = _launch_dense_bwd(plan, flow32, None, pad, iwe, None, omit, False, halo, moments, up, splits=splits)
-        return d_flow.to(ctx.fdt), None, None, None, None, None
+        return d_flow.to(ctx.fdt), None, None, None, None, None, None
 
 
 class _FusedIwe2Dof(torch.autograd.Function):

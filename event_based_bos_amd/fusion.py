@@ -208,8 +208,8 @@ def carry_iwe_tag(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
     return view
 
 
-def fused_variance(iwe: torch.Tensor, omit_boundary: bool) -> Optional[torch.Tensor]:
-    """Third step of the idiom, ``cost.calculate({"iwe": iwe, ...})`` with the variance contrast on an image that came out of
+def fused_variance(iwe: torch.Tensor, omit_boundary: bool, cost: str = "image_variance") -> Optional[torch.Tensor]:
+    """Third step of the idiom, ``cost.calculate({"iwe": iwe, ...})`` with a contrast cost (variance, or ``cost="gradient_magnitude"``) on an image that came out of
     ``fused_iwe`` and has not been touched since: value AND flow gradient by the objective's one native call
     (``EventPlan.contrast_dense`` -> ``_EagerLoss``: ``backward()`` on the cost, its negation or a weighted multiple stores the
     gradient without the autograd engine; combined with other terms it becomes an ordinary graph node).  The image's own autograd
@@ -224,7 +224,7 @@ def fused_variance(iwe: torch.Tensor, omit_boundary: bool) -> Optional[torch.Ten
     if not _eager_ok(tag_.plan, tag_.flow, _norm_halo(tag_.plan, DEFAULT_HALO)):
         return None
     stats["fused_costs"] = stats.get("fused_costs", 0) + 1
-    return tag_.plan.contrast_dense(tag_.flow, "image_variance", bool(omit_boundary), pad=tag_.pad)
+    return tag_.plan.contrast_dense(tag_.flow, cost, bool(omit_boundary), pad=tag_.pad)
 
 
 def clear_cache() -> None:

@@ -104,8 +104,10 @@ class FusedPatchLoop(object):
         self.moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
         self.upstream = torch.full((1,), -(self.w_gm or self.w_var), **f32)  # loss = -w * contrast
         self.d_iwe = torch.empty_like(self.iwe) if self.w_gm else None
-        self.cost_scratch = (torch.empty(int(self.lib.ebos_cost_scratch_bytes(1)), dtype=torch.uint8, device=dev)
-                             if self.w_gm else None)
+        # (the Sobel pass's value partials: ebos_gradient_magnitude_fused_f32)
+        self.cost_scratch = (torch.empty(max(int(self.lib.ebos_cost_scratch_bytes(1)),
+                                             8 * int(self.lib.ebos_gradient_magnitude_fused_partials(H + 2 * self.pad[0], W + 2 * self.pad[1]))),
+                                         dtype=torch.uint8, device=dev) if self.w_gm else None)
         self.losses = torch.zeros(max(int(capacity), 1), **f32)
         self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
         self.scratch_up = (None if self.sample_grid else
@@ -154,10 +156,9 @@ class FusedPatchLoop(object):
                                               ptr(self.iwe), want_var, int(self.omit),
                                               ptr(self.variance), ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_dense_slab")
         if use_gm:  # contrast = mean squared Sobel gradient; its gradient image is the upstream of the backward kernel
-            check(lib.ebos_gradient_magnitude_f32(ptr(self.iwe), 1, h, w, int(self.omit), ptr(self.variance), ptr(self.cost_scratch),
-                                                  self.cost_scratch.numel(), s), "ebos_gradient_magnitude")
-            check(lib.ebos_gradient_magnitude_grad_f32(ptr(self.iwe), 1, h, w, int(self.omit), ptr(self.upstream), ptr(self.d_iwe), s),
-                  "ebos_gradient_magnitude_grad")
+            check(lib.ebos_gradient_magnitude_fused_f32(ptr(self.iwe), h, w, int(self.omit), ptr(self.upstream), ptr(self.variance),
+                                                        ptr(self.d_iwe), ptr(self.cost_scratch), self.cost_scratch.numel() // 8, s),
+                  "ebos_gradient_magnitude_fused")
         if self.has_reg:  # ... which also reduces the variance partials of the combine pass (no finalize launch)
             check(lib.ebos_flow_regularisers_f32(ptr(self.dense), H, W, self.w_norm, self.w_tv, ptr(self.d_reg),
                                                  ptr(self.reg_partials), None if use_gm else self.ws.data_ptr() + off, n_parts, n_px,

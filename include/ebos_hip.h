@@ -72,7 +72,8 @@ int ebos_profile_stop(float* ms, int cap);
 typedef enum ebos_profile_kernel {
   EBOS_PROFILE_SLAB_ACCUMULATE = 0, /* iwe_slab_accumulate_kernel (what ebos_profile_start selects)                    */
   EBOS_PROFILE_TILED_BWD = 1,       /* iwe_dense_tiled_bwd_kernel of ebos_iwe_{dense,2dof,patch}_tiled_bwd_f32          */
-  EBOS_PROFILE_SLAB_COMBINE = 2     /* the slab combine pass (IWE assembly + variance) of ebos_iwe_*_slab_f32           */
+  EBOS_PROFILE_SLAB_COMBINE = 2,    /* the slab combine pass (IWE assembly + variance) of ebos_iwe_*_slab_f32           */
+  EBOS_PROFILE_GRADMAG_FUSED = 3    /* the Sobel pass of ebos_gradient_magnitude_fused_f32 (value partials + gradient)  */
 } ebos_profile_kernel;
 int ebos_profile_start_kernel(int which, int max_records);
 
@@ -392,6 +393,14 @@ typedef struct ebos_dense_job {
 } ebos_dense_job;
 int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_variance, const float* upstream,
                                 float* d_flow, ebos_stream_t stream);
+/* The same for the gradient-magnitude contrast (BASELINE configs[2]; SURVEY.md A14: mean squared Sobel gradient of the IWE,
+ * src/utils/stat_utils.py:69-92, 117-139): out_contrast[0] = gradient_magnitude(IWE(flow)); with d_flow != NULL also
+ * d_flow [2, H, W] = upstream[0] * d contrast / d flow.  Enqueues accumulate, combine, ONE Sobel pass (value partials + gradient
+ * image, ebos_gradient_magnitude_fused_f32) and the tile-private backward, whose first workgroup sums the value partials: four
+ * launches, no finalize, no host synchronisation.  d_iwe [h, w] f32 and partials [ebos_gradient_magnitude_fused_partials(h, w)]
+ * f64 are scratch of the caller's (job->moments is not used). */
+int ebos_gradient_magnitude_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_contrast, const float* upstream,
+                                          float* d_flow, float* d_iwe, double* partials, int64_t n_partials, ebos_stream_t stream);
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
                                  const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
                                  const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,
@@ -563,6 +572,14 @@ int ebos_gradient_magnitude_f64(const double* images, int K, int h, int w, int o
                                 void* scratch, size_t scratch_bytes, ebos_stream_t stream);
 int ebos_gradient_magnitude_grad_f64(const double* images, int K, int h, int w, int omit_boundary,
                                      const double* upstream, double* d_images, ebos_stream_t stream);
+/* Value AND gradient image of the gradient-magnitude contrast in ONE pass over an LDS-tiled image (the two entry points above read
+ * the image twice, the second one 81 times per pixel): out[0] = mean(gx^2 + gy^2) with (gx, gy) = Sobel 3x3 / 8, replicate padding
+ * (src/utils/stat_utils.py:69-92, 117-139), d_image [h, w] = upstream[0] * d out / d image (upstream: device f32 [1], NULL = 1) --
+ * the bits of ebos_gradient_magnitude_grad_f32.  partials: device f64 [ebos_gradient_magnitude_fused_partials(h, w)], one value
+ * partial per workgroup; out == NULL: no finalize launch (the caller sums the partials: ebos_gradient_magnitude_dense_job_f32). */
+int64_t ebos_gradient_magnitude_fused_partials(int h, int w);
+int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit_boundary, const float* upstream, float* out,
+                                      float* d_image, double* partials, int64_t n_partials, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A16  patch grid -> dense flow  (src/solver/patch_eklt.py:173-204): replicate-pad the grid by

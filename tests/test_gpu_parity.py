@@ -1788,3 +1788,73 @@ def test_fuzz_grid_sampling_route(ebos):
             assert np.linalg.norm(out[True][2] - want) / np.linalg.norm(want) < 1e-3, tag
         done += 1
     assert done >= 25, done
+
+
+@pytest.mark.parametrize("shape,omit", [((37, 53), False), ((37, 53), True), ((96, 130), False), ((16, 64), True), ((3, 5), False)])
+def test_fused_gradient_magnitude_pass_equals_the_two_pass_kernels(ebos, shape, omit):
+    """``ebos_gradient_magnitude_fused_f32`` (one LDS-tiled pass: value + gradient image, f32 stencils) against the two stand-alone
+    fp64 kernels it replaces in the objective and the CPU oracle's autograd: value and gradient image to f32 round-off -- on sizes
+    that are no multiple of the 16 x 64 tile, with and without the boundary ring, down to 3 x 5."""
+    from event_based_bos_amd import _hip
+
+    lib = _hip.require_gpu()
+    h, w = shape
+    img = torch.from_numpy(np.random.RandomState(5).gamma(2.0, 3.0, (h, w))).float().cuda()
+    up = torch.tensor([-1.75], dtype=torch.float32, device="cuda")
+    n = int(lib.ebos_gradient_magnitude_fused_partials(h, w))
+    out, d_img = torch.empty(1, device="cuda"), torch.empty_like(img)
+    partials = torch.empty(n, dtype=torch.float64, device="cuda")
+    _hip.check(lib.ebos_gradient_magnitude_fused_f32(img.data_ptr(), h, w, int(omit), up.data_ptr(), out.data_ptr(), d_img.data_ptr(),
+                                                     partials.data_ptr(), n, _hip.stream_ptr()), "fused")
+    ref_val = ebos.ops.gradient_magnitude(img, omit)
+    x = img.clone().requires_grad_(True)
+    (ebos.ops.gradient_magnitude(x, omit) * up[0]).backward()
+    assert abs(out.item() - ref_val.item()) <= 1e-6 * abs(ref_val.item())
+    assert rel(d_img.cpu().numpy(), x.grad.cpu().numpy()) < 2e-6 and (d_img - x.grad).abs().max().item() < 1e-5 * x.grad.abs().max().item()
+    # against the CPU oracle's autograd (fp64)
+    xo = img.double().cpu().requires_grad_(True)
+    (O.gradient_magnitude(xo, omit, direction="maximize") * float(up[0])).backward()
+    assert rel(d_img.cpu().numpy(), xo.grad.numpy()) < 2e-6
+    with pytest.raises(RuntimeError):
+        _hip.check(lib.ebos_gradient_magnitude_fused_f32(img.data_ptr(), h, w, int(omit), None, out.data_ptr(), d_img.data_ptr(),
+                                                         partials.data_ptr(), n - 1 if n > 1 else 0, _hip.stream_ptr()), "fused")
+
+
+def test_gradient_magnitude_objective_is_one_native_call_with_an_eager_backward(ebos):
+    """``plan.contrast_dense(flow, "gradient_magnitude")`` (BASELINE configs[2]): value and flow gradient by
+    ``ebos_gradient_magnitude_dense_job_f32`` -- same numbers as the image -> ``ops.gradient_magnitude`` -> autograd route, an
+    ``_EagerLoss`` whose ``backward()`` needs no engine, and the cost class of the reference idiom takes the same short cut."""
+    from event_based_bos_amd.event_plan import _EagerLoss
+
+    h, w, n = 96, 128, 30_000
+    ev = O.synth_events(n, h, w, seed=15)
+    fl = G(O.synth_dense_flow(h, w, seed=16, max_val=6.0), torch.float32)
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile="auto")
+    f_ref = fl.clone().requires_grad_(True)
+    ref = ebos.ops.gradient_magnitude(plan.iwe_dense(f_ref), False)
+    (-ref).backward()
+    f = fl.clone().requires_grad_(True)
+    loss = -plan.contrast_dense(f, "gradient_magnitude")
+    assert type(loss) is _EagerLoss
+    loss.backward()
+    assert abs(loss.item() + ref.item()) <= 1e-6 * abs(ref.item())
+    assert rel(f.grad.cpu().numpy(), f_ref.grad.cpu().numpy()) < 1e-6
+    for omit in (False, True):     # value only (no gradient wanted): the Sobel pass finalizes itself
+        with torch.no_grad():
+            v = plan.contrast_dense(fl, "gradient_magnitude", omit)
+        assert abs(v.item() - ebos.ops.gradient_magnitude(plan.iwe_dense(fl), omit).item()) <= 1e-6 * abs(v.item())
+    # fp64 CPU oracle
+    fo = torch.from_numpy(O.synth_dense_flow(h, w, seed=16, max_val=6.0)).float().double().requires_grad_(True)
+    lo = O.gradient_magnitude(O.iwe_dense(torch.from_numpy(ev), fo, (h, w)))
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
+    # the reference idiom: warp_event -> create_iwe -> gradient_magnitude cost -> backward, fused at the cost step
+    wp, ic = ebos.Warp((h, w), normalize_t=True), ebos.EventImageConverter((h, w))
+    cost = ebos.costs.functions["gradient_magnitude"]()
+    f2 = fl.clone().requires_grad_(True)
+    warped, _ = wp.warp_event(G(ev, torch.float32), f2, "dense-flow", "first")
+    l2 = cost.calculate({"iwe": ic.create_iwe(warped, "bilinear_vote", sigma=0), "omit_boundary": False})
+    l2.backward()
+    assert abs(l2.item() - loss.item()) <= 1e-6 * abs(loss.item())
+    print("idiom gradient vs plan gradient", rel(f2.grad.cpu().numpy(), f.grad.cpu().numpy()), ebos.fusion.stats)
+    assert rel(f2.grad.cpu().numpy(), f.grad.cpu().numpy()) < 2e-5   # (the idiom's plan has its own tile: another order of f32 sums)

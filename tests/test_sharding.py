@@ -103,7 +103,7 @@ def test_bench_gpus_flag_launches_the_ranks_itself(config, total, per_rank):
     assert abs(line["max_over_ranks_check"] - 0.002) < 1e-12  # the MAX over ranks took rank 1's value
 
 
-@pytest.mark.parametrize("config,total", [(2, 8), (4, 64), (5, 512)])
+@pytest.mark.parametrize("config,total", [(2, 8), (3, 8), (4, 64), (5, 512)])
 def test_bench_eight_ranks_dry_run(config, total):
     """The job the driver runs for SCALE_rNN.json -- `bench.py --gpus 8` -- through the launcher, the bounded rendezvous, the shard
     assignment of SURVEY 8(e), the barrier, the MAX over ranks and the gather, on gloo: eight ranks seen, every unit owned by
@@ -116,7 +116,7 @@ def test_bench_eight_ranks_dry_run(config, total):
     assert line["units_total"] == total and abs(line["max_over_ranks_check"] - 0.008) < 1e-12
     owned = []
     for r in range(8):
-        units = [r] if config == 2 else shard_units(total, 8, r, "round_robin" if config == 4 else "block")
+        units = [r] if config in (2, 3) else shard_units(total, 8, r, "round_robin" if config == 4 else "block")
         assert seen[r]["units"] == len(units) and seen[r]["first_units"] == list(units[:4])
         owned += list(units)
     assert sorted(owned) == list(range(total))  # a partition: nothing dropped, nothing done twice
