@@ -861,11 +861,11 @@ def run_config3(R):
     P = lambda t: t.data_ptr()
 
     def step():
-        _hip.check(lib.ebos_gradient_magnitude_dense_job_f32(job.ref, P(flow), P(out), None, None, P(d_iwe), P(partials), n_part, stream),
+        _hip.check(lib.ebos_gradient_magnitude_dense_job_f32(job.ref, P(flow), P(out), None, None, None, P(d_iwe), P(partials), n_part, stream),
                    "ebos_gradient_magnitude_dense_job")
 
     def step_fwd_bwd():
-        _hip.check(lib.ebos_gradient_magnitude_dense_job_f32(job.ref, P(flow), P(out), None, P(d_flow), P(d_iwe), P(partials), n_part, stream),
+        _hip.check(lib.ebos_gradient_magnitude_dense_job_f32(job.ref, P(flow), P(out), None, None, P(d_flow), P(d_iwe), P(partials), n_part, stream),
                    "ebos_gradient_magnitude_dense_job")
 
     blocks, sobel_ms = R.timed_blocks(step, lib, profile_kernel=_hip.PROFILE_GRADMAG_FUSED)

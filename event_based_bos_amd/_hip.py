@@ -87,7 +87,8 @@ SIGNATURES = {
     "ebos_iwe_2dof_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "ebos_variance_dense_job_f32": (_I, [_P, _P, _P, _P, _P, _P]),
-    "ebos_gradient_magnitude_dense_job_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "ebos_gradient_magnitude_dense_job_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "ebos_variance_dense_job_signed_f32": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "ebos_gradient_magnitude_fused_partials": (_L, [_I, _I]),
     "ebos_gradient_magnitude_fused_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
     "ebos_iwe_2dof_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),

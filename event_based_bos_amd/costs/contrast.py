@@ -41,8 +41,13 @@ class _ContrastCost(CostBase):
             logger.error(e)
             raise NotImplementedError(e)
         kind = kind_of(iwe)
-        value = self._contrast(to_gpu(iwe), bool(omit_boundary))
-        loss = -value if self.direction == "minimize" else value
+        iwe_gpu = to_gpu(iwe)
+        # the image of the fused idiom, untouched (or never computed): the objective's one native call, the direction's sign applied
+        # inside its kernels
+        loss = fusion.fused_variance(iwe_gpu, bool(omit_boundary), self.name, -1.0 if self.direction == "minimize" else 1.0)
+        if loss is None:
+            value = self._contrast(iwe_gpu, bool(omit_boundary))
+            loss = -value if self.direction == "minimize" else value
         if kind == NUMPY:
             return float(loss.item()) if loss.dim() == 0 else loss.detach().cpu().numpy()
         return back(loss, kind)
@@ -60,8 +65,7 @@ class ImageVariance(_ContrastCost):
         return self._evaluate(arg)
 
     def _contrast(self, iwe_gpu, omit_boundary):
-        fused = fusion.fused_variance(iwe_gpu, omit_boundary)  # the image of the fused idiom, untouched: one native call
-        return fused if fused is not None else ops.image_variance(iwe_gpu, omit_boundary)
+        return ops.image_variance(iwe_gpu, omit_boundary)
 
 
 class GradientMagnitude(_ContrastCost):
@@ -75,5 +79,4 @@ class GradientMagnitude(_ContrastCost):
         return self._evaluate(arg)
 
     def _contrast(self, iwe_gpu, omit_boundary):
-        fused = fusion.fused_variance(iwe_gpu, omit_boundary, "gradient_magnitude")  # (the fused idiom's image: one native call)
-        return fused if fused is not None else ops.gradient_magnitude(iwe_gpu, omit_boundary)
+        return ops.gradient_magnitude(iwe_gpu, omit_boundary)

@@ -226,6 +226,8 @@ struct MomentsIn {
   int64_t n_partials, n_pixels;
   float* out_var;          // written by workgroup 0 (nullable)
   double* moments;         // (mean, M), written by workgroup 0 (nullable)
+  float* out_scaled;       // upstream[0] * value, written by workgroup 0 (nullable): the SIGNED loss of a cost with a direction,
+                           // without a launch of its own to negate a scalar
   // mode 0: (sum, sum of squares) pairs of the combine pass -> variance, folded into the upstream as an affine map of the IWE;
   // mode 1: one value partial per workgroup of gradmag_fused_kernel -> out_var[0] = sum / n_pixels, by workgroup 0 only (the upstream
   //         image is the gradient image itself: nothing to fold; the finalize launch of the contrast value disappears)
@@ -2120,7 +2122,11 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       for (int64_t i = threadIdx.x; i < mj.n_partials; i += kBlock) sv += mj.partials[i];
       __shared__ double red_v[kBlock / kWave];
       sv = block_sum(sv, red_v);
-      if (threadIdx.x == 0 && mj.out_var) mj.out_var[0] = (float)(sv / (double)mj.n_pixels);
+      if (threadIdx.x == 0) {
+        const float v = (float)(sv / (double)mj.n_pixels);
+        if (mj.out_var) mj.out_var[0] = v;
+        if (mj.out_scaled) mj.out_scaled[0] = (upstream ? upstream[0] : 1.0f) * v;
+      }
     }
     if (tr.ty < 0) return;
   }
@@ -2243,6 +2249,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       s_mom[0] = mean;
       if (blockIdx.x == 0) {
         if (mj.out_var) mj.out_var[0] = (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
+        if (mj.out_scaled) mj.out_scaled[0] = (upstream ? upstream[0] : 1.0f) * (float)((sq - sm * mean) / (double)(mj.n_pixels - 1));
         if (mj.moments) {
           mj.moments[0] = mean;
           mj.moments[1] = (double)mj.n_pixels;

@@ -745,8 +745,14 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
 
 int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_variance, const float* upstream,
                                 float* d_flow, ebos_stream_t stream) {
+  return ebos_variance_dense_job_signed_f32(job, flow, out_variance, nullptr, upstream, d_flow, stream);
+}
+
+int ebos_variance_dense_job_signed_f32(const ebos_dense_job* job, const float* flow, float* out_variance, float* out_scaled,
+                                       const float* upstream, float* d_flow, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(job && flow && out_variance, "ebos_variance_dense_job: NULL job / flow / out_variance");
+  EBOS_REQUIRE(out_scaled == nullptr || d_flow != nullptr, "ebos_variance_dense_job: out_scaled comes with the gradient (d_flow)");
   EBOS_REQUIRE(job->iwe && job->moments && job->workspace, "ebos_variance_dense_job: the job needs iwe, moments and a workspace");
   // value + gradient: the forward call leaves the (sum, sum of squares) partials (want_variance = 2) and the backward kernel reduces
   // them itself -- no finalize launch in between; value only: the forward call finalizes
@@ -762,7 +768,7 @@ int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, fl
   if (rc != EBOS_OK) return rc;
   EBOS_REQUIRE(npix >= 2, "ebos_variance_dense_job: the variance needs at least two pixels");
   const MomentsIn mj{reinterpret_cast<const double*>(reinterpret_cast<const char*>(job->workspace) + poff), nparts, npix, out_variance,
-                     job->moments};
+                     job->moments, out_scaled, 0};
   // (upstream == nullptr: the backward kernel takes 1.0f -- no device-resident constant, nothing per-device to cache)
   const bool adaptive = job->splits == 0 && job->part_table != nullptr;
   return dense_tiled_bwd_impl(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n, flow,
@@ -771,11 +777,13 @@ int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, fl
                               adaptive ? job->workspace_bytes : 0, adaptive ? job->part_table : nullptr, stream, mj);
 }
 
-int ebos_gradient_magnitude_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_contrast, const float* upstream,
-                                          float* d_flow, float* d_iwe, double* partials, int64_t n_partials, ebos_stream_t stream) {
+int ebos_gradient_magnitude_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_contrast, float* out_scaled,
+                                          const float* upstream, float* d_flow, float* d_iwe, double* partials, int64_t n_partials,
+                                          ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(job && flow && out_contrast, "ebos_gradient_magnitude_dense_job: NULL job / flow / out_contrast");
   EBOS_REQUIRE(job->iwe && job->workspace && d_iwe && partials, "ebos_gradient_magnitude_dense_job: the job needs iwe, a workspace, d_iwe and partials");
+  EBOS_REQUIRE(out_scaled == nullptr || d_flow != nullptr, "ebos_gradient_magnitude_dense_job: out_scaled comes with the gradient (d_flow)");
   const int h = job->H + 2 * job->pad_h, w = job->W + 2 * job->pad_w;
   // accumulate + combine (no variance), then ONE pass over the image for the Sobel value partials and the gradient image
   int rc = ebos_iwe_dense_slab_f32(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n,
@@ -790,11 +798,12 @@ int ebos_gradient_magnitude_dense_job_f32(const ebos_dense_job* job, const float
   const int lo = job->omit_boundary ? 1 : 0;
   const int64_t npix = (int64_t)(h - 2 * lo > 0 ? h - 2 * lo : 0) * (w - 2 * lo > 0 ? w - 2 * lo : 0);
   EBOS_REQUIRE(npix >= 1, "ebos_gradient_magnitude_dense_job: empty image region");
-  const MomentsIn mj{partials, ebos_gradient_magnitude_fused_partials(h, w), npix, out_contrast, nullptr, 1};
+  const MomentsIn mj{partials, ebos_gradient_magnitude_fused_partials(h, w), npix, out_contrast, nullptr, out_scaled, 1};
   const bool adaptive = job->splits == 0 && job->part_table != nullptr;
   return dense_tiled_bwd_impl(job->xs, job->ys, job->dts, nullptr, job->grp_offsets, job->cpix, job->cdt, job->key_offsets, job->n, flow,
                               job->H, job->W, job->tile_h, job->tile_w, job->halo, job->pad_h, job->pad_w, d_iwe, nullptr, 0, d_flow,
-                              nullptr, nullptr, nullptr, nullptr, adaptive ? job->workspace : nullptr,
+                              nullptr, nullptr, upstream /* (only scales out_scaled here: the Sobel pass applied it to d_iwe) */, nullptr,
+                              adaptive ? job->workspace : nullptr,
                               adaptive ? job->workspace_bytes : 0, adaptive ? job->part_table : nullptr, stream, mj);
 }
 
@@ -818,7 +827,7 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
   const int halo = ha.halo;
   EBOS_REQUIRE(var_partials == nullptr || (var_moments == nullptr && upstream != nullptr && n_var_partials >= 1 && n_var_pixels >= 2),
                "ebos_iwe_patch_tiled_bwd: var_partials needs upstream, no var_moments, and sane counts");
-  const MomentsIn mj{var_partials, n_var_partials, n_var_pixels, out_variance, out_moments};
+  const MomentsIn mj{var_partials, n_var_partials, n_var_pixels, out_variance, out_moments, nullptr, 0};
   EBOS_REQUIRE((w_flow_norm == 0.0f && w_image_gradient == 0.0f) || reg_partials,
                "ebos_iwe_patch_tiled_bwd: regulariser weight given but reg_partials is NULL");
   EBOS_REQUIRE(w_image_gradient == 0.0f || (H >= 2 && W >= 2),

@@ -124,7 +124,7 @@ class EventImageConverter(object):
             assert weight.shape == events.shape[:-1]
         fused = self._try_fused(events, weight)
         if fused is not None:
-            return fusion.carry_iwe_tag(fused, fused.squeeze())
+            return fusion.squeezed(fused)
         img = self._accumulate(events, weight, _hip.SPLAT_BILINEAR, EPS_TENSOR, None)
         return self._finish(img, kind_of(events))
 
@@ -178,7 +178,7 @@ class EventImageConverter(object):
             if img is None:
                 img = self._accumulate(events, weight, _hip.SPLAT_BILINEAR, EPS_TENSOR, None).squeeze()
             else:
-                img = fusion.carry_iwe_tag(img, img.squeeze())
+                img = fusion.squeezed(img)
         elif method == "polarity":
             img = self._polarity(events, weight, EPS_TENSOR, None)
         else:
@@ -191,7 +191,7 @@ class EventImageConverter(object):
             elif img.dim() == 3:
                 img = img[:, None, ...]
             img = self._gaussian_blur3(img, sigma)
-        return back(fusion.carry_iwe_tag(img, torch.squeeze(img)), kind_of(events))
+        return back(fusion.squeezed(img), kind_of(events))
 
     def create_iwe(self, events: NUMPY_TORCH, method: str = "bilinear_vote", sigma: int = 1) -> NUMPY_TORCH:
         """Image of warped events [(b,) H, W].  :51-73"""

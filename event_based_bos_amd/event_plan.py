@@ -460,7 +460,8 @@ class EventPlan:
             v = self.contrast_dense(f, "image_variance", omit_boundary, pad, halo)
             v.backward()
             return v.detach().reshape(1), f.grad
-        return _run_dense_job(_dense_job(self, pad, halo, splits, omit_boundary), flow32, True)
+        out, d_flow = _run_dense_job(_dense_job(self, pad, halo, splits, omit_boundary), flow32, True)
+        return out[:1], d_flow
 
     def variance_dense_many(self, flows: torch.Tensor, omit_boundary: bool = False, pad: Tuple[int, int] = (0, 0),
                             halo: int = DEFAULT_HALO, splits: Optional[int] = None, n_streams: int = 3) -> torch.Tensor:
@@ -505,8 +506,9 @@ class EventPlan:
 
     def contrast_dense(self, flow: torch.Tensor, cost: str = "image_variance", omit_boundary: bool = False,
                        pad: Tuple[int, int] = (0, 0), halo: Optional[int] = DEFAULT_HALO,
-                       splits: Optional[int] = None) -> torch.Tensor:
-        """Contrast of the IWE under ``flow`` (0-d tensor, raw contrast: callers apply the sign).
+                       splits: Optional[int] = None, sign: float = 1.0) -> torch.Tensor:
+        """Contrast of the IWE under ``flow`` (0-d tensor, raw contrast: callers apply the sign -- or pass ``sign=-1.0``, the
+        ``direction="minimize"`` of the cost plugins, and get ``sign * contrast`` with its gradient straight from the kernels).
         Same value and gradient as ``cost(iwe_dense(flow))``, but the variance gradient is folded
         into the backward event kernel (no d_iwe image).
 
@@ -524,10 +526,13 @@ class EventPlan:
                 # the result itself, the objective idiom -- stores the gradient without entering the autograd engine (the engine's
                 # thread hand-off around a Python backward costs more than both event kernels); any other use of the result
                 # attaches the ordinary autograd node first (_EagerLoss)
-                out, d_flow = _run_dense_job(_dense_job(self, pad2, halo, splits, bool(omit_boundary)), flow, True, cost)
-                return _EagerLoss.wrap(out[0], flow, d_flow)
-            return _FusedVarianceDense.apply(flow, self, pad2, bool(omit_boundary), halo, splits, cost)
-        return ops.gradient_magnitude(self.iwe_dense(flow, pad=pad, halo=halo, splits=splits), omit_boundary)
+                sign = float(sign)
+                out, d_flow = _run_dense_job(_dense_job(self, pad2, halo, splits, bool(omit_boundary)), flow, True, cost, sign)
+                return _EagerLoss.wrap(out[1] if sign != 1.0 else out[0], flow, d_flow, sign, applied=sign)
+            v = _FusedVarianceDense.apply(flow, self, pad2, bool(omit_boundary), halo, splits, cost)
+            return v if sign == 1.0 else v * sign
+        v = ops.gradient_magnitude(self.iwe_dense(flow, pad=pad, halo=halo, splits=splits), omit_boundary)
+        return v if sign == 1.0 else v * sign
 
 
 # ----------------------------------------------------------------------------------------------
@@ -732,19 +737,35 @@ def _dense_job(plan: EventPlan, pad, halo, splits, omit) -> _DenseJob:
     return job
 
 
-def _run_dense_job(job: _DenseJob, flow32: torch.Tensor, want_grad: bool, cost: str = "image_variance"):
-    """(contrast [1], d contrast / d flow [2, H, W] | None) in one native call: the variance (three launches) or the gradient
-    magnitude (four: one Sobel pass yields the value partials and the gradient image, ``ebos_gradient_magnitude_dense_job_f32``)."""
+_SIGNS = {}
+
+
+def _sign_constant(device: torch.device, sign: float) -> torch.Tensor:
+    """Device-resident f32 [1] holding ``sign`` (the ``upstream`` of a signed job), made once per (device, value)."""
+    key = (device, float(sign))
+    t = _SIGNS.get(key)
+    if t is None:
+        t = _SIGNS[key] = torch.full((1,), float(sign), dtype=torch.float32, device=device)
+    return t
+
+
+def _run_dense_job(job: _DenseJob, flow32: torch.Tensor, want_grad: bool, cost: str = "image_variance", sign: float = 1.0):
+    """(out [2] = (contrast, sign * contrast), sign * d contrast / d flow [2, H, W] | None) in one native call: the variance (three
+    launches) or the gradient magnitude (four: one Sobel pass yields the value partials and the gradient image,
+    ``ebos_gradient_magnitude_dense_job_f32``).  ``sign`` (the direction of a cost) is applied INSIDE the kernels: no launch negates
+    a scalar or scales the gradient field afterwards; without a gradient only out[0] is written."""
     lib = _hip.require_gpu()
-    out = torch.empty(1, dtype=torch.float32, device=flow32.device)
+    out = torch.empty(2, dtype=torch.float32, device=flow32.device)
     d_flow = torch.empty_like(flow32) if want_grad else None
+    up = None if sign == 1.0 else _sign_constant(flow32.device, sign).data_ptr()
+    scaled = out.data_ptr() + 4 if want_grad else None
 
     def call():
         if cost == "image_variance":
-            return lib.ebos_variance_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), None, ptr(d_flow), stream_ptr())
+            return lib.ebos_variance_dense_job_signed_f32(job.ref, flow32.data_ptr(), out.data_ptr(), scaled, up, ptr(d_flow), stream_ptr())
         d_iwe, partials, n = job.gm_buffers()
-        return lib.ebos_gradient_magnitude_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), None, ptr(d_flow), d_iwe.data_ptr(),
-                                                         partials.data_ptr(), n, stream_ptr())
+        return lib.ebos_gradient_magnitude_dense_job_f32(job.ref, flow32.data_ptr(), out.data_ptr(), scaled, up, ptr(d_flow),
+                                                         d_iwe.data_ptr(), partials.data_ptr(), n, stream_ptr())
 
     if _hip.current_device_index() == job.index:
         rc = call()
@@ -935,10 +956,12 @@ class _EagerLoss(torch.Tensor):
                    "ne", "isnan", "isfinite", "isinf"}
 
     @staticmethod
-    def wrap(value: torch.Tensor, flow: torch.Tensor, d_flow: torch.Tensor, scale: float = 1.0, cell=None) -> "_EagerLoss":
+    def wrap(value: torch.Tensor, flow: torch.Tensor, d_flow: torch.Tensor, scale: float = 1.0, cell=None,
+             applied: float = 1.0) -> "_EagerLoss":
+        """``value`` = scale x contrast; ``d_flow`` = applied x d contrast / d flow (the kernels apply a cost's sign themselves)."""
         t = torch.Tensor._make_subclass(_EagerLoss, value)
-        # flow, shared cell [gradient of the UNSCALED value | None once handed over], attached tensor, factor
-        t._ebos = [flow, cell if cell is not None else [d_flow], None, scale]
+        # flow, shared cell [gradient (None once handed over), the factor it already carries], attached tensor, factor of this object
+        t._ebos = [flow, cell if cell is not None else [d_flow, float(applied)], None, scale]
         return t
 
     def _plain(self) -> torch.Tensor:
@@ -951,7 +974,7 @@ class _EagerLoss(torch.Tensor):
             if st[1][0] is None:  # consumed (by this object or a scaled relative): an ordinary tensor with a freed graph
                 st[2] = _ConsumedGrad.apply(st[0], self._plain())
             else:
-                st[2] = _AttachGrad.apply(st[0], self._plain(), st[1][0], st[3])
+                st[2] = _AttachGrad.apply(st[0], self._plain(), st[1][0], st[3] / st[1][1])
         return st[2]
 
     def _scaled(self, k) -> "_EagerLoss":
@@ -978,7 +1001,7 @@ class _EagerLoss(torch.Tensor):
         if st[2] is not None or create_graph or inputs is not None or cell[0] is None or flow._backward_hooks or \
                 getattr(flow, "_post_accumulate_grad_hooks", None):
             return self._attached().backward(gradient, retain_graph, create_graph, inputs)
-        g, k = cell[0], st[3]
+        g, k = cell[0], st[3] / cell[1]  # (what is left to apply: nothing when the kernels applied this object's factor)
         with torch.no_grad():
             if gradient is not None:
                 f = gradient.to(device=g.device, dtype=torch.float32) * k

@@ -17,15 +17,19 @@ hands the same address (same shape, version 0) to a later window, so the entry d
 flow updated in place between ``warp_event`` and ``create_iwe`` (``optimizer.step()``, ``clamp_``) no longer matches
 the materialised coordinates, and the image is then splatted from those, like the reference.
 
-Policy (env ``EBOS_FUSE_API``): ``f32`` (default) fuses float32 inputs only -- the fused path computes in f32 and a
-float64 caller is given the float64 kernels it asked for; ``all`` also fuses float64 inputs (result cast back);
-``off`` disables it; ``lazy`` (opt-in) is ``f32`` plus a warped-events result that is only COMPUTED if something other than
-``create_iwe`` looks at it (``LazyWarped``): a solver loop that warps, images, evaluates and steps never pays for the 16 bytes per
-event of coordinates it does not read -- at 10 M events they were 220 of the idiom's 296 us.  What the caller gives up: warped
-events that are first looked at AFTER the flow was updated in place can no longer be computed from the flow they belonged to, and
-raise instead.
+Policy (env ``EBOS_FUSE_API``): ``lazy`` (default) fuses float32 GPU inputs and makes the idiom's intermediate results
+DEFERRED: ``warp_event`` returns a ``LazyWarped`` and ``create_iwe`` on it a ``LazyIwe`` -- tensors that know their shape, dtype and
+device at once and compute their values the first time anything reads them.  A solver loop that warps, images, evaluates a contrast
+cost and steps reads neither: the cost step runs the objective's one native call on (events, flow) and the 16 bytes per event of
+warped coordinates (220 of the idiom's 296 us at 10 M events) and the separate image pass are never paid for.  A late read stays
+exact: ``warp_event`` keeps a device copy of the flow as it is at the call (7.4 MB, ~3 us), so a result first read AFTER
+``optimizer.step()`` updated the flow in place holds the OLD flow's coordinates, as the reference's eager tensor would
+(src/warp.py:330-342); that late value is detached from the flow (a gradient into a leaf that has since been overwritten is not
+reproduced).  Only events modified in place before the first read cannot be honoured (they are not copied: 160 MB) and raise.
+``f32``: float32 inputs fused, warped events computed at the call (round 3's default); ``all`` also fuses float64 inputs (result
+cast back); ``off`` disables the fusion.
 
-The third call of the idiom, ``cost.calculate({"iwe": iwe, ...})`` with the variance contrast, is fused too (``fused_variance``):
+The third call of the idiom, ``cost.calculate({"iwe": iwe, ...})`` with a contrast cost, is fused too (``fused_variance``):
 on the untouched image of ``fused_iwe`` it runs the objective's one native call and returns a result whose ``backward()`` does not
 enter the autograd engine (``event_plan._EagerLoss``).
 """
@@ -48,7 +52,7 @@ _plans: "OrderedDict[tuple, tuple]" = OrderedDict()  # key -> (weakref to the ev
 
 
 def policy() -> str:
-    return os.environ.get("EBOS_FUSE_API", "f32").lower()
+    return os.environ.get("EBOS_FUSE_API", "lazy").lower()
 
 
 @dataclass
@@ -63,6 +67,8 @@ class Provenance:
     image_size: Tuple[int, int]
     warped_version: int = 0
     flow_version: int = 0
+    flow_snapshot: Optional[torch.Tensor] = None   # lazy results: the flow as it was at the warp_event call (device copy)
+    flow_slot: Optional[list] = None               # ... and the ring slot that holds it (FlowSnapshots)
 
 
 def eligible(events: torch.Tensor, flow: torch.Tensor, image_size) -> bool:
@@ -75,38 +81,32 @@ def eligible(events: torch.Tensor, flow: torch.Tensor, image_size) -> bool:
 
 
 def lazy_eligible(events: torch.Tensor, flow: torch.Tensor, image_size) -> bool:
-    """``EBOS_FUSE_API=lazy``: float32 GPU events [n, 4] and flow [2, H, W] of one device, the shapes the fused image needs."""
+    """``EBOS_FUSE_API=lazy`` (the default): float32 GPU events [n, 4] and flow [2, H, W] of one device, the shapes the fused image needs."""
     return policy() == "lazy" and type(events) is torch.Tensor and events.is_cuda and events.dim() == 2 and \
         events.dtype == torch.float32 and flow.dtype == torch.float32 and flow.device == events.device and \
         tuple(flow.shape) == (2, int(image_size[0]), int(image_size[1]))
 
 
-class LazyWarped(torch.Tensor):
-    """The warped events of ``Warp.warp_event`` under ``EBOS_FUSE_API=lazy``: shape, dtype and device are there at once, the
-    coordinates are computed the first time anything reads them (every ``torch`` function and tensor method except the metadata
-    queries goes through ``__torch_function__`` and runs on the computed tensor, autograd history included).
-    ``EventImageConverter`` with unit weight does not read them: it builds the image from (events, flow) directly (``fused_iwe``)."""
+class _Deferred(torch.Tensor):
+    """A tensor that knows its shape, dtype and device at once and computes its values the first time anything reads them: every
+    ``torch`` function and tensor method except the metadata queries goes through ``__torch_function__`` and runs on the computed
+    tensor (autograd history included)."""
 
     @staticmethod
-    def make(events: torch.Tensor, flow: torch.Tensor, prov: "Provenance", compute) -> "LazyWarped":
+    def _shell(cls, shape, dtype, device):
         # (a stride-0 view of one element carries shape, dtype and device; nothing reads its 4 bytes)
-        t = torch.Tensor._make_subclass(LazyWarped, torch.empty(1, dtype=events.dtype, device=events.device).expand(events.shape))
-        t._ebos_lazy = [compute, None]  # thunk, computed tensor
-        prov.flow_version = flow._version
-        t._ebos_provenance = prov
-        return t
+        return torch.Tensor._make_subclass(cls, torch.empty(1, dtype=dtype, device=device).expand(shape))
 
     def _real(self) -> torch.Tensor:
         st = self._ebos_lazy
         if st[1] is None:
-            prov = self._ebos_provenance
-            if prov.flow._version != prov.flow_version or prov.events._version != prov.events_version:
-                raise RuntimeError("EBOS_FUSE_API=lazy: these warped events are read for the first time after their flow (or their "
-                                   "events) were modified in place; they can no longer be computed.  Read them before the update, "
-                                   "or run with EBOS_FUSE_API=f32 (warped events computed at the call)")
             st[1] = st[0]()
             st[0] = None
         return st[1]
+
+    @property
+    def computed(self) -> bool:
+        return self._ebos_lazy[1] is not None
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -114,8 +114,91 @@ class LazyWarped(torch.Tensor):
         if func in _LAZY_META:
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
-        args, kwargs = _pytree.tree_map_only(LazyWarped, lambda a: a._real(), (tuple(args), kwargs))
+        args, kwargs = _pytree.tree_map_only(_Deferred, lambda a: a._real(), (tuple(args), kwargs))
         return func(*args, **kwargs)
+
+
+def flow_for_read(prov: "Provenance") -> torch.Tensor:
+    """The flow a deferred result computes its values from: the caller's tensor while it is what it was at the ``warp_event`` call
+    (autograd history kept), else the copy made at that call -- the reference's eager tensors hold the OLD flow's values too."""
+    if prov.events._version != prov.events_version:
+        raise RuntimeError("these warped events (or their image) are read for the first time after their EVENTS were modified in "
+                           "place; they can no longer be computed (the flow is copied at the call, 160 MB of events are not).  "
+                           "Read them before the update, or run with EBOS_FUSE_API=f32 (warped events computed at the call)")
+    if prov.flow._version == prov.flow_version:
+        return prov.flow
+    if prov.flow_snapshot is None:
+        raise RuntimeError("no copy of the flow was kept for this deferred result")
+    return prov.flow_snapshot
+
+
+class LazyWarped(_Deferred):
+    """The warped events of ``Warp.warp_event`` under ``EBOS_FUSE_API=lazy``: computed the first time anything reads them.
+    ``EventImageConverter`` with unit weight does not read them: it builds the image from (events, flow) directly (``fused_iwe``)."""
+
+    @staticmethod
+    def make(events: torch.Tensor, flow: torch.Tensor, prov: "Provenance", compute) -> "LazyWarped":
+        """``compute(flow_tensor)`` -> the warped events of ``events`` under that flow."""
+        t = _Deferred._shell(LazyWarped, events.shape, events.dtype, events.device)
+        prov.flow_version = flow._version
+        t._ebos_provenance = prov
+        t._ebos_lazy = [lambda: compute(flow_for_read(prov)), None]  # thunk, computed tensor
+        return t
+
+
+class LazyIwe(_Deferred):
+    """The image ``EventImageConverter`` makes of an unread ``LazyWarped`` with unit weight: computed (one fused pass over the
+    events, ``EventPlan.iwe_dense``) the first time anything reads it; a contrast cost does not (``fused_variance``)."""
+
+    @staticmethod
+    def make(plan: EventPlan, prov: "Provenance", pad, shape) -> "LazyIwe":
+        t = _Deferred._shell(LazyIwe, shape, prov.flow.dtype, prov.flow.device)
+        t._ebos_iwe_lazy = (plan, prov, pad)
+
+        def compute():
+            fl = flow_for_read(prov)
+            iwe = plan.iwe_dense(fl, pad=pad)
+            stats["fused_images"] += 1
+            iwe._ebos_iwe = IweProvenance(plan, fl, pad, iwe._version, fl._version)
+            return iwe
+
+        t._ebos_lazy = [compute, None]
+        if prov.flow_slot is not None:
+            FlowSnapshots.own(prov.flow_slot, t)
+        return t
+
+
+class FlowSnapshots(object):
+    """Device copies of the flow for deferred results, a small ring per (device, shape): a slot is reused when its previous owner --
+    the ``LazyWarped`` of an earlier call -- is gone or has been read; an owner that is still alive and unread (a caller keeping
+    unread results of several calls) computes its values from the slot first."""
+
+    def __init__(self, slots: int = 3):
+        self.slots, self.rings = slots, {}
+
+    def take(self, flow: torch.Tensor):
+        key = (flow.device, tuple(flow.shape))
+        ring = self.rings.get(key)
+        if ring is None:
+            ring = self.rings[key] = [[[None, []] for _ in range(self.slots)], 0]
+        slots, cursor = ring
+        slot = slots[cursor % self.slots]
+        ring[1] = cursor + 1
+        for ref in slot[1] or ():
+            owner = ref()
+            if owner is not None and not owner.computed:
+                owner._real()  # (rare) its flow copy is about to be overwritten
+        slot[1] = []
+        if slot[0] is None:
+            slot[0] = torch.empty_like(flow, requires_grad=False)
+        with torch.no_grad():
+            slot[0].copy_(flow)
+        return slot
+
+    @staticmethod
+    def own(slot, lazy: "_Deferred") -> None:
+        """``lazy`` (a LazyWarped, or the LazyIwe made of one) computes from this slot's copy if it is read late."""
+        slot[1].append(weakref.ref(lazy))
 
 
 _LAZY_META = {torch.Tensor.shape.__get__, torch.Tensor.dtype.__get__, torch.Tensor.device.__get__, torch.Tensor.is_cuda.__get__,
@@ -133,7 +216,7 @@ def tag(warped: torch.Tensor, prov: Provenance) -> torch.Tensor:
 
 def provenance_of(warped) -> Optional[Provenance]:
     if type(warped) is LazyWarped:
-        if warped._ebos_lazy[1] is not None:  # it has been computed (someone read it): the computed tensor speaks for itself
+        if warped.computed:  # someone read it: the computed tensor speaks for itself
             return provenance_of(warped._ebos_lazy[1])
         prov = warped._ebos_provenance     # never read, so never modified: only its sources can have changed
         if prov.events._version != prov.events_version or prov.flow._version != prov.flow_version:
@@ -183,6 +266,8 @@ def fused_iwe(warped: torch.Tensor, padded_image_size, pad) -> Optional[torch.Te
     if plan.n_dropped:  # the reference raises for out-of-range sources; leave that to the unfused path
         return None
     pad = (int(pad[0]), int(pad[1]))
+    if type(warped) is LazyWarped and not warped.computed and prov.flow.dtype == torch.float32 and warped.dtype == torch.float32:
+        return LazyIwe.make(plan, prov, pad, (H + 2 * pad[0], W + 2 * pad[1]))  # computed if (and when) something reads it
     iwe = plan.iwe_dense(prov.flow, pad=pad)
     stats["fused_images"] += 1
     if iwe.dtype != warped.dtype:
@@ -200,6 +285,14 @@ class IweProvenance:
     flow_version: int
 
 
+def squeezed(img: torch.Tensor) -> torch.Tensor:
+    """``img.squeeze()`` as the converter applies it to its result (src/event_image_converter.py:405,620), keeping the fusion tag;
+    a deferred image whose shape has no unit dimension is returned as it is (squeezing it would compute it)."""
+    if type(img) is LazyIwe and not img.computed and all(int(d) != 1 for d in img.shape):
+        return img
+    return carry_iwe_tag(img, img.squeeze())
+
+
 def carry_iwe_tag(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
     """``view`` is ``src`` reshaped without copying (the converter's ``squeeze``): it IS the image, keep the tag."""
     tag_ = getattr(src, "_ebos_iwe", None)
@@ -208,13 +301,25 @@ def carry_iwe_tag(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
     return view
 
 
-def fused_variance(iwe: torch.Tensor, omit_boundary: bool, cost: str = "image_variance") -> Optional[torch.Tensor]:
+def fused_variance(iwe: torch.Tensor, omit_boundary: bool, cost: str = "image_variance", sign: float = 1.0) -> Optional[torch.Tensor]:
     """Third step of the idiom, ``cost.calculate({"iwe": iwe, ...})`` with a contrast cost (variance, or ``cost="gradient_magnitude"``) on an image that came out of
     ``fused_iwe`` and has not been touched since: value AND flow gradient by the objective's one native call
     (``EventPlan.contrast_dense`` -> ``_EagerLoss``: ``backward()`` on the cost, its negation or a weighted multiple stores the
     gradient without the autograd engine; combined with other terms it becomes an ordinary graph node).  The image's own autograd
     node is simply not used.  None when the short cut does not apply: the image (or the flow) was modified in place, someone
-    asked for the image's gradient (``retain_grad`` / hooks), the flow is not a plain float32 leaf."""
+    asked for the image's gradient (``retain_grad`` / hooks), the flow is not a plain float32 leaf.  ``sign``: the cost's direction
+    (-1 for "minimize"), applied inside the kernels -- the result is ``sign * contrast``."""
+    if type(iwe) is LazyIwe and not iwe.computed:
+        # the deferred image of the idiom, never read: the objective's one native call on (events, flow) -- unless the flow has been
+        # updated in place since warp_event (then the image of the OLD flow is computed from the copy, like any other read)
+        plan, prov, pad = iwe._ebos_iwe_lazy
+        if prov.flow._version != prov.flow_version or prov.events._version != prov.events_version:
+            return None
+        from .event_plan import DEFAULT_HALO, _eager_ok, _norm_halo
+        if not _eager_ok(plan, prov.flow, _norm_halo(plan, DEFAULT_HALO)):
+            return None
+        stats["fused_costs"] = stats.get("fused_costs", 0) + 1
+        return plan.contrast_dense(prov.flow, cost, bool(omit_boundary), pad=pad, sign=sign)
     tag_ = getattr(iwe, "_ebos_iwe", None)
     if tag_ is None or iwe.dim() != 2 or iwe._version != tag_.iwe_version or tag_.flow._version != tag_.flow_version:
         return None
@@ -224,7 +329,7 @@ def fused_variance(iwe: torch.Tensor, omit_boundary: bool, cost: str = "image_va
     if not _eager_ok(tag_.plan, tag_.flow, _norm_halo(tag_.plan, DEFAULT_HALO)):
         return None
     stats["fused_costs"] = stats.get("fused_costs", 0) + 1
-    return tag_.plan.contrast_dense(tag_.flow, cost, bool(omit_boundary), pad=tag_.pad)
+    return tag_.plan.contrast_dense(tag_.flow, cost, bool(omit_boundary), pad=tag_.pad, sign=sign)
 
 
 def clear_cache() -> None:

@@ -84,6 +84,7 @@ class Warp(object):
         self.strict = strict
         # deferred out-of-range check of GPU-tensor calls: device counter per device, (page-locked copy, event, device) in flight
         self._oob_dev, self._oob_pending, self._oob_calls = {}, [], 0
+        self._flow_snapshots = fusion.FlowSnapshots()  # copies of the flow at warp_event time, for deferred results (fusion.py)
 
     def update_property(self, image_size: Optional[tuple] = None, calculate_feature: Optional[bool] = None,
                         normalize_t: Optional[bool] = None, calib_param: Optional[np.ndarray] = None):
@@ -161,10 +162,14 @@ class Warp(object):
             if is_torch(events) and is_torch(motion) and fusion.lazy_eligible(events, motion, self.image_size) and \
                     not self._strict_for(GPU):
                 # opt-in: the coordinates are computed when (if) something reads them; EventImageConverter does not (fusion.py)
+                # (a device copy of the flow as it is NOW: a result read after optimizer.step() holds the old flow's values, as
+                # the reference's eager tensor does, src/warp.py:330-342)
+                slot = self._flow_snapshots.take(motion)
                 prov = fusion.Provenance(events, events._version, motion, ref_mode, frac, direction, bool(self.normalize_t),
-                                         (int(self.image_size[0]), int(self.image_size[1])))
+                                         (int(self.image_size[0]), int(self.image_size[1])), flow_snapshot=slot[0], flow_slot=slot)
                 lazy = fusion.LazyWarped.make(events, motion, prov,
-                                              lambda: self.warp_event_now(events, motion, ref_mode, frac, direction))
+                                              lambda fl: self.warp_event_now(events, fl, ref_mode, frac, direction))
+                fusion.FlowSnapshots.own(slot, lazy)
                 return lazy, self.feature_dense.calculate_feature(skip=not self.calculate_feature)
             warped, feat = self._warp_dense(events, motion, ref_mode, frac, None)
             if is_torch(events) and is_torch(motion) and fusion.eligible(events, motion, self.image_size):

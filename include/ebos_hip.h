@@ -398,9 +398,16 @@ int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, fl
  * d_flow [2, H, W] = upstream[0] * d contrast / d flow.  Enqueues accumulate, combine, ONE Sobel pass (value partials + gradient
  * image, ebos_gradient_magnitude_fused_f32) and the tile-private backward, whose first workgroup sums the value partials: four
  * launches, no finalize, no host synchronisation.  d_iwe [h, w] f32 and partials [ebos_gradient_magnitude_fused_partials(h, w)]
- * f64 are scratch of the caller's (job->moments is not used). */
-int ebos_gradient_magnitude_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_contrast, const float* upstream,
-                                          float* d_flow, float* d_iwe, double* partials, int64_t n_partials, ebos_stream_t stream);
+ * f64 are scratch of the caller's (job->moments is not used).  out_scaled (nullable): see ebos_variance_dense_job_signed_f32. */
+int ebos_gradient_magnitude_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_contrast, float* out_scaled,
+                                          const float* upstream, float* d_flow, float* d_iwe, double* partials, int64_t n_partials,
+                                          ebos_stream_t stream);
+/* ebos_variance_dense_job_f32 with one more output for a cost that has a DIRECTION (the cost plugins of src/costs: "minimize" negates the contrast):
+ * out_scaled[0] = upstream[0] * variance (nullable; needs d_flow), written by the backward kernel's first workgroup beside
+ * out_variance -- the signed loss and its gradient come out of the three launches, no kernel negates a scalar or scales 7.4 MB.
+ * (ebos_gradient_magnitude_dense_job_f32 takes the same out_scaled.) */
+int ebos_variance_dense_job_signed_f32(const ebos_dense_job* job, const float* flow, float* out_variance, float* out_scaled,
+                                       const float* upstream, float* d_flow, ebos_stream_t stream);
 int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* dts, const float* weight,
                                  const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
                                  const int32_t* key_offsets, int64_t n, const float* flow, int H, int W,

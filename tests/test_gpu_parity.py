@@ -515,11 +515,20 @@ def test_reference_idiom_is_fused_lazily(ebos, monkeypatch):
         iwe[5, 5] += 100.0                                                # modified in place: no longer the fused image
     l_mod = cost.calculate({"iwe": iwe, "omit_boundary": False})
     assert ebos.fusion.stats["fused_costs"] == n_costs and abs(l_mod.item() - l0) > 1e-6 * abs(l0)
-    # EBOS_FUSE_API=lazy (opt-in): the warped events are only computed if something other than create_iwe reads them
+    # EBOS_FUSE_API=lazy (the default): warped events and image are only computed if something reads them; the cost step does not
     monkeypatch.setenv("EBOS_FUSE_API", "lazy")
+    n_img = ebos.fusion.stats["fused_images"]
+    fl = G(fl_np, torch.float32).requires_grad_(True)
+    w2, _ = wp.warp_event(ev, fl, "dense-flow", "middle")
+    i2 = ic.create_iwe(w2, "bilinear_vote", sigma=0)
+    assert type(w2) is ebos.fusion.LazyWarped and type(i2) is ebos.fusion.LazyIwe and i2.shape == iwe1.shape and i2.dtype == iwe1.dtype
+    loss2 = cost.calculate({"iwe": i2, "omit_boundary": False})
+    loss2.backward()
+    assert not w2.computed and not i2.computed and ebos.fusion.stats["fused_images"] == n_img   # the loop looked at neither
+    assert w2.shape == w0.shape and w2.dtype == w0.dtype and w2.device == w0.device and not w2.computed
+    assert loss2.item() == l1 and torch.equal(fl.grad, g1)
+    assert torch.equal(i2.detach(), iwe1) and i2.computed and not w2.computed                   # read: the same fused image
     w2, iwe2, l2, g2 = run()
-    assert type(w2) is ebos.fusion.LazyWarped and w2._ebos_lazy[1] is None   # the loop never looked at the coordinates
-    assert w2.shape == w0.shape and w2.dtype == w0.dtype and w2.device == w0.device and w2._ebos_lazy[1] is None
     assert torch.equal(iwe2, iwe1) and l2 == l1 and torch.equal(g2, g1)
     fl = G(fl_np, torch.float32).requires_grad_(True)
     wl, _ = wp.warp_event(ev, fl, "dense-flow", "middle")
@@ -530,15 +539,17 @@ def test_reference_idiom_is_fused_lazily(ebos, monkeypatch):
     shifted = ic.create_iwe(wl, "bilinear_vote", sigma=0)
     assert ebos.fusion.stats["fused_images"] == n_fused
     assert rel(shifted[3:-1, 2:-2].detach().cpu().numpy(), iwe0[2:-2, 2:-2].cpu().numpy()) < 1e-5
+    fl = G(fl_np, torch.float32).requires_grad_(True)
     wl, _ = wp.warp_event(ev, fl, "dense-flow", "middle")
+    il = ic.create_iwe(wl, "bilinear_vote", sigma=0)
     with torch.no_grad():
         fl.mul_(0.5)                                                          # an optimiser step before anyone read them
-    with pytest.raises(RuntimeError, match="EBOS_FUSE_API=lazy"):
+    assert torch.equal(wl, w0) and torch.equal(il, iwe1)                      # ... and they hold the OLD flow's values
+    ev2 = ev.clone()
+    wl, _ = wp.warp_event(ev2, fl, "dense-flow", "middle")
+    ev2[:, 2] += 1.0                                                          # the EVENTS modified before the first read: not copied
+    with pytest.raises(RuntimeError, match="EVENTS were modified"):
         wl.sum()
-    n_fused = ebos.fusion.stats["fused_images"]
-    with pytest.raises(RuntimeError, match="EBOS_FUSE_API=lazy"):            # (the image of the OLD flow cannot be built either)
-        ic.create_iwe(wl, "bilinear_vote", sigma=0)
-    assert ebos.fusion.stats["fused_images"] == n_fused
     monkeypatch.setenv("EBOS_FUSE_API", "f32")
     # a modified copy of the warped events loses the provenance and is splatted as given
     fl = G(fl_np, torch.float32)
@@ -1858,3 +1869,38 @@ def test_gradient_magnitude_objective_is_one_native_call_with_an_eager_backward(
     assert abs(l2.item() - loss.item()) <= 1e-6 * abs(loss.item())
     print("idiom gradient vs plan gradient", rel(f2.grad.cpu().numpy(), f.grad.cpu().numpy()), ebos.fusion.stats)
     assert rel(f2.grad.cpu().numpy(), f.grad.cpu().numpy()) < 2e-5   # (the idiom's plan has its own tile: another order of f32 sums)
+
+
+def test_deferred_results_read_after_an_optimizer_step_hold_the_old_flow(ebos, monkeypatch):
+    """The default (EBOS_FUSE_API=lazy) defers the idiom's warped events and image; ``warp_event`` copies the flow on the device, so
+    a result first read AFTER ``optimizer.step()`` equals what the reference's eager call returned at call time
+    (src/warp.py:330-342: values of the flow as it was) -- bit for bit against this package's eager path, to f32 round-off against
+    the fp64 oracle -- for several iterations whose unread results are all kept alive (the snapshot ring is reused)."""
+    monkeypatch.delenv("EBOS_FUSE_API", raising=False)
+    h, w, n = 90, 120, 40_000
+    ev_np = O.synth_events(n, h, w, seed=31)
+    ev = G(ev_np, torch.float32)
+    wp, ic = ebos.Warp((h, w), normalize_t=True), ebos.EventImageConverter((h, w))
+    cost = ebos.costs.functions["image_variance"]()
+    fl = G(O.synth_dense_flow(h, w, seed=32, max_val=5.0), torch.float32).requires_grad_(True)
+    opt = torch.optim.SGD([fl], lr=50.0)
+    kept = []
+    for it in range(5):
+        opt.zero_grad()
+        flow_then = fl.detach().clone()
+        warped, _ = wp.warp_event(ev, fl, "dense-flow", "first")
+        iwe = ic.create_iwe(warped, "bilinear_vote", sigma=0)
+        loss = cost.calculate({"iwe": iwe, "omit_boundary": False})
+        loss.backward()
+        assert type(warped) is ebos.fusion.LazyWarped and type(iwe) is ebos.fusion.LazyIwe and not warped.computed and not iwe.computed
+        opt.step()                                   # the flow changes in place; nothing has read the results yet
+        assert not torch.equal(fl.detach(), flow_then)
+        kept.append((warped, iwe, flow_then))
+    monkeypatch.setenv("EBOS_FUSE_API", "off")
+    for warped, iwe, flow_then in kept:              # late reads, oldest first
+        w_ref, _ = wp.warp_event(ev, flow_then, "dense-flow", "first")
+        i_ref = ic.create_iwe(w_ref, "bilinear_vote", sigma=0)
+        assert torch.equal(warped, w_ref)
+        assert rel(iwe.cpu().numpy(), i_ref.cpu().numpy()) < 1e-5
+        w_o = O.warp_dense_torch(torch.from_numpy(ev_np).float().double(), flow_then.double().cpu(), "first", normalize_t=True)
+        assert np.abs(warped.cpu().numpy()[:, :2] - w_o.numpy()[:, :2]).max() < 1e-3
