@@ -87,6 +87,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-tail-stream", action="store_true", help="config 4, batched: combine / finalize passes on the same stream as the accumulate passes")
     ap.add_argument("--no-graph", action="store_true", help="config 4: enqueue every window's calls from Python instead of replaying a captured pass")
     ap.add_argument("--no-compact", action="store_true", help="read the 12 B/event (x, y, dt) plan instead of 6 B/event")
+    ap.add_argument("--fractional", action="store_true",
+                    help="config 2 with source coordinates on a 1/64 px grid (undistorted events): the general 12 B/event format, "
+                         "looked up truncated (src/warp.py:334) -- NOT the BASELINE workload")
+    ap.add_argument("--weighted", action="store_true",
+                    help="config 2 with per-event weights (src/event_image_converter.py:576-577: the ds_add_f64 path, 16 B/event) "
+                         "-- NOT the BASELINE workload")
     ap.add_argument("--cpu-sample", type=int, default=N_EVENTS, help="events of the window the CPU baseline is timed on")
     ap.add_argument("--rotating-windows", type=int, default=8, help="distinct 10 M-event plans cycled by the cache-cold leg")
     args = ap.parse_args(argv)
@@ -489,6 +495,14 @@ def run_config2(R):
     n = a.events or N_EVENTS
     t_ingest = time.perf_counter()
     ev, flow_np = synth_window(n, seed=rank, flow_max=a.flow_max)
+    general = a.fractional or a.weighted
+    if a.fractional:  # undistorted events: coordinates off the pixel grid, still inside the image
+        rs_f = np.random.RandomState(4242 + rank)
+        ev[:, 0] += rs_f.randint(0, 64, n) / 64.0
+        ev[:, 1] += rs_f.randint(0, 64, n) / 64.0
+    weights_np = np.random.RandomState(777 + rank).uniform(0.5, 1.5, n).astype(np.float32) if a.weighted else None
+    if general:
+        a.no_compact, a.no_extras = True, True  # (the informative legs are the unit-weight compact plan's)
     ev_gpu = torch.from_numpy(ev).to(dev)
     flow = torch.from_numpy(flow_np).float().to(dev)
     if a.tile[0] <= 0:
@@ -526,12 +540,13 @@ def run_config2(R):
         return pl._compact_ptrs() if (pl.compact and not a.no_compact) else (None, None, None)
 
     cptrs = compact_ptrs(plan)
-    bytes_per_event = 6.0 if cptrs[0] else 12.0
+    weight_p = ebos.event_plan._plan_weight(plan, torch.from_numpy(weights_np).to(dev)) if a.weighted else None  # plan order
+    bytes_per_event = (6.0 if cptrs[0] else 12.0) + (4.0 if a.weighted else 0.0)
 
     def make_step(pl, fl, cp):
         def step():
             # one objective evaluation: tile accumulate -> slab combine (writes the IWE) -> variance
-            _hip.check(lib.ebos_iwe_dense_slab_f32(P(pl.x), P(pl.y), P(pl.dt), None, *cp, P(pl.key_offsets), pl.n, P(fl),
+            _hip.check(lib.ebos_iwe_dense_slab_f32(P(pl.x), P(pl.y), P(pl.dt), P(weight_p) if pl is plan else None, *cp, P(pl.key_offsets), pl.n, P(fl),
                                                    H, W, a.tile[0], a.tile[1], a.halo_code, a.splits, 0, 0, P(ws), nws,
                                                    P(iwe), 1, 0, P(out), P(moments), P(pl.part_table), stream), "ebos_iwe_dense_slab")
         return step
@@ -724,10 +739,13 @@ def run_config2(R):
         ms_per_step = elapsed / a.steps * 1e3
         value = world * n * a.steps / elapsed / 1e6
         # 12 B/event (x, y, dt; p unused) + flow read (8 B/px) + IWE write (4 B/px)
-        algo_bytes = 12.0 * plan.n + 12.0 * H * W
+        algo_bytes = (16.0 if a.weighted else 12.0) * plan.n + 12.0 * H * W  # (16 B/event with weights)
         format_bytes = bytes_per_event * plan.n + 12.0 * H * W  # what the plan format actually stores per event
         k_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
-        roof = roofline_entry("iwe_slab_accumulate_kernel<DENSE,DYN>" if a.halo == "auto" else "iwe_slab_accumulate_kernel", kernel_ms, algo_bytes,
+        kname = "iwe_slab_accumulate_kernel<DENSE,DYN>" if a.halo == "auto" else "iwe_slab_accumulate_kernel"
+        if general or a.no_compact:  # other instantiations: the committed counters are the compact unit-weight kernel's
+            kname = "iwe_slab_accumulate_kernel<XY" + (",W>" if a.weighted else ">")
+        roof = roofline_entry(kname, kernel_ms, algo_bytes,
                               {"measured_copy_GBps": round(copy_gbs, 1),
                                "frac_of_measured_copy": round(algo_bytes / (k_ms * 1e-3) / 1e9 / copy_gbs, 4),
                                "plan_format_bytes": format_bytes,
@@ -737,17 +755,18 @@ def run_config2(R):
             roof["frac_rotating_windows"] = extras["rotating_windows"]["frac"]
         line = base_line(R, value, ms_per_step, blocks, "weak", {
             "workload": ("BASELINE configs[1]: 10M synthetic events, 1280x720 dense per-pixel flow U(-30,30), "
-                         "variance cost, fwd objective (tile accumulate + slab combine + variance)") if (a.flow_max == FLOW_MAX and n == N_EVENTS)
-                        else f"NOT the BASELINE workload: {n} events, flow U(-{a.flow_max:g},{a.flow_max:g})",
+                         "variance cost, fwd objective (tile accumulate + slab combine + variance)") if (a.flow_max == FLOW_MAX and n == N_EVENTS and not general)
+                        else (f"NOT the BASELINE workload: {n} events, flow U(-{a.flow_max:g},{a.flow_max:g})"
+                              + (", source coordinates on a 1/64 px grid (12 B/event format, truncated flow look-up)" if a.fractional else "")
+                              + (", per-event weights U(0.5, 1.5) (f64 LDS accumulation)" if a.weighted else "")),
             "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
-            "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if cptrs[0] else "SoA f32 (x,y,dt), 12 B/event")
+            "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if cptrs[0] else "SoA f32 (x,y,dt), 12 B/event" + (" + f32 weight" if a.weighted else ""))
                       + f", binned by source tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}, splits {a.splits}",
             "parallelism": f"windows sharded, {world} rank(s), no collective"})
         line["roofline"] = roof
         clock = device_clock_hz(dev)
         dyn = a.halo == "auto"
-        line["roofline_issue"] = roofline_issue("iwe_slab_accumulate_kernel<DENSE,DYN>" if dyn else "iwe_slab_accumulate_kernel",
-                                                kernel_ms, clock, plan.n)
+        line["roofline_issue"] = roofline_issue(kname, kernel_ms, clock, plan.n)
         if "roofline_bwd" in extras:
             extras["roofline_bwd_issue"] = roofline_issue("iwe_dense_tiled_bwd_kernel<DENSE,DYN>" if dyn else "iwe_dense_tiled_bwd_kernel",
                                                           [extras["roofline_bwd"]["kernel_ms"]], clock, plan.n)
