@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
   __shared__ Persist P;
   __shared__ int s_spill, s_bad, s_ok;
   __shared__ unsigned s_next;
-  __shared__ float s_gmax[2 * kWaves];
+  __shared__ float s_gmax[3 * kWaves];
   __shared__ unsigned s_win[9];
   __shared__ int s_wmax[2];     // largest window (rows, columns) of the grid in this iteration
   __shared__ double s_mom[4];    // mean, variance, sum of the regulariser partials of the previous iteration
@@ -639,11 +639,14 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       G.a = (float)ga;
       G.c = (float)(-ga * mean);
       G.h = H, G.w = W, G.lo = lo_px;
-      float gmax_t = 0.0f;
+      float gmax_t = 0.0f, gsum_t = 0.0f;  // (max and sum of |staged value|: the scatter's fixed-point unit, bwd_fx_unit)
       auto affine = [&](int R, int C, float v, bool in_window) {
         const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
         const float gv = valid ? G.a * v + G.c : 0.0f;
-        if (in_window) gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);  // (max |staged value|: the scatter's fixed-point unit)
+        if (in_window) {
+          gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
+          gsum_t += fabsf(gv);
+        }
         return gv;
       };
       EBOS_RSTAMP(18);
@@ -663,6 +666,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           if (in) {
             const float m4 = fmaxf(fmaxf(fabsf(gq.x), fabsf(gq.y)), fmaxf(fabsf(gq.z), fabsf(gq.w)));
             gmax_t = fmaxf(gmax_t, (gq.x + gq.y + gq.z + gq.w) == (gq.x + gq.y + gq.z + gq.w) ? m4 : INFINITY);  // (a NaN anywhere: Inf)
+            gsum_t += (fabsf(gq.x) + fabsf(gq.y)) + (fabsf(gq.z) + fabsf(gq.w));
           }
         } else {
           const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
@@ -673,10 +677,11 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       }
       EBOS_RSTAMP(19);
       gmax_t = wave_max_nonneg(gmax_t);
-      if (lane == 0) s_gmax[wave] = gmax_t;
+      gsum_t = wave_sum(gsum_t);
+      if (lane == 0) s_gmax[wave] = gmax_t, s_gmax[2 * kWaves + wave] = gsum_t;
       __syncthreads();
       EBOS_RSTAMP(9);
-      unit = bwd_fx_unit(s_gmax, a.dt_bound);
+      unit = bwd_fx_unit(s_gmax, a.dt_bound, n_q * 4);
       double tot_x = 0.0, tot_y = 0.0;
       const BwdShared bsh{&s_spill, &s_bad, &s_next};
       TileRange tr;

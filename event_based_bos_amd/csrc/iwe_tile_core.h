@@ -1765,13 +1765,23 @@ struct FxUnit {
   bool fx;
   float scale, limit;
 };
-__device__ __forceinline__ FxUnit bwd_fx_unit(const float* s_gmax, float dt_bound) {
+// s_gmax [3 * waves]: per-wave max |staged value|, max events per source pixel, sum |staged value| over the n_window staged values.
+// kFxOutlier: ONE value 2^10 x the window's mean magnitude would leave every other event's contribution ~11 of its 21 bits (a
+// spike of 1e4: 1.9 % error on the neighbouring pixels' gradients, test_backward_fixed_point_unit_under_an_upstream_outlier) --
+// such a tile takes the f64 accumulators.
+constexpr float kFxOutlier = 512.0f;
+__device__ __forceinline__ FxUnit bwd_fx_unit(const float* s_gmax, float dt_bound, int n_window) {
   FxUnit u{true, 1.0f, 0.0f};
-  float gmax = 0.0f, nmax = 1.0f;
+  float gmax = 0.0f, nmax = 1.0f, gsum = 0.0f;
 #pragma unroll
   for (int k = 0; k < kBlock / kWave; ++k) {
     gmax = fmaxf(gmax, s_gmax[k]);
     nmax = fmaxf(nmax, s_gmax[kBlock / kWave + k]);
+    gsum += s_gmax[2 * (kBlock / kWave) + k];
+  }
+  if (gmax * (float)n_window > kFxOutlier * gsum) {  // (max > 512 x mean; also an all-zero window with one value)
+    u.fx = gmax == 0.0f;                              // (nothing staged at all: any unit is exact)
+    if (!u.fx) return u;
   }
   int en;
   frexpf(nmax, &en);                    // nmax < 2^en
@@ -2111,7 +2121,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   __shared__ int s_bad;    // fixed-point scatter: a run sum left its range -> the slice is redone with f64 accumulators
   __shared__ unsigned s_next;  // chunk queue of the lean loop
   __shared__ float s_bound[2 * kBlock / kWave];  // DYN: per-wave maxima of |u|, |v| over the tile
-  __shared__ float s_gmax[2 * kBlock / kWave];   // per-wave maxima of |upstream tile| and of events per source pixel (fixed-point unit)
+  __shared__ float s_gmax[3 * kBlock / kWave];   // per wave: max |upstream tile|, max events per source pixel, sum |upstream tile| (fixed-point unit)
   const ChunkQueue queue{&s_next};
   EBOS_STAMP_BWD(0);
   if (tr.ty < 0 && !(mj.partials != nullptr && blockIdx.x == 0)) return;  // unused work item (workgroup 0 still reports the variance)
@@ -2158,7 +2168,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       nmax_t = max(nmax_t, ko[i + 1] - ko[i]);
     }
   }
-  float gmax_t = 0.0f;  // this thread's max |staged upstream value|
+  float gmax_t = 0.0f, gsum_t = 0.0f;  // this thread's max / sum of |staged upstream value|
   // ---- set-up.  Every global read in flight at once: (1) the raw upstream tile into registers -- unconditional, clamped loads,
   // fully unrolled (a loop of bounds-checked loads is waited for one by one: 5.6 us of set-up per workgroup, in-kernel stamps; not
   // gated by "this item has events": that is known one round trip later than the tile's position) -- (2) GRID: the tile's block of
@@ -2200,6 +2210,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       if (i < n_px) {
         s_g[i] = gv;
         gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);  // (a NaN counts as Inf: such a tile takes the f64 path)
+        gsum_t += fabsf(gv);
       }
     }
   };
@@ -2308,10 +2319,12 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   }
   if (kFxScatter) {
     gmax_t = wave_max_nonneg(gmax_t);
+    gsum_t = wave_sum(gsum_t);
     const float nm = wave_max_nonneg((float)nmax_t);
     if ((threadIdx.x & (kWave - 1)) == 0) {
       s_gmax[threadIdx.x / kWave] = gmax_t;
       s_gmax[kBlock / kWave + threadIdx.x / kWave] = nm;
+      s_gmax[2 * (kBlock / kWave) + threadIdx.x / kWave] = gsum_t;
     }
   }
   __syncthreads();
@@ -2321,7 +2334,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   bool fx = kFxScatter;
   float fx_scale = 1.0f, fx_limit = 0.0f;
   if (fx) {
-    const FxUnit unit = bwd_fx_unit(s_gmax, dt_bound);
+    const FxUnit unit = bwd_fx_unit(s_gmax, dt_bound, win.LH() * win.LW());
     fx = unit.fx, fx_scale = unit.scale, fx_limit = unit.limit;
   }
 
