@@ -1,11 +1,13 @@
 #!/bin/bash
 # Everything the round's profiles/ entries come from, on the GPU box (run through gpurun from the repo root):
 #   tools/collect_round_profiles.sh <tag>        e.g. r03
-# 1. (last, on the counters of step 3) bench.py: default command, --config 4, --config 5, --steps 20 -> gpurun_out/<tag>/bench*.json
+# 1. (last, on the counters of step 3) bench.py: default command, --config 3 / 4 / 5, --fractional, --weighted, --steps 20, and
+#    tools/bench_autograd.py (the Python autograd routes)              -> gpurun_out/<tag>/bench*.json, autograd_path.json
 # 2. rocprofv3 --kernel-trace --stats of the SAME default command     -> gpurun_out/<tag>/kernel_stats_bench.csv
 # 3. rocprofv3 --pmc, four separate passes (FETCH_SIZE | WRITE_SIZE | instruction counts | LDS / wait counters) of
-#    tools/profile_step.py --mode all (dense fwd + bwd, the batched patch-grid pass, the 2-DoF sweep; built halo and run-time
-#    windows)                                                          -> gpurun_out/<tag>/pmc.json, pmc_summary.txt
+#    tools/profile_step.py --mode all (dense fwd + bwd under both contrasts, the batched patch-grid pass, the solver loop as
+#    four launches and as the resident kernel, the 2-DoF sweep; built halo and run-time windows)
+#                                                                      -> gpurun_out/<tag>/pmc.json, pmc_summary.txt
 # (PMC passes carry --kernel-trace only; no sys / hip / memory-copy tracing beside counters.)
 set -u
 TAG=${1:-r03}
@@ -51,6 +53,10 @@ fi
 cp "$OUT/pmc.json" profiles/pmc_latest.json
 cp "$OUT/kernel_stats.json" profiles/kernel_stats_latest.json
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python bench.py --config 3 > "$OUT/bench_config3.json" 2> "$OUT/bench_config3.err"
+python bench.py --fractional --no-cpu-baseline > "$OUT/bench_fractional.json" 2> "$OUT/bench_fractional.err"
+python bench.py --weighted --no-cpu-baseline > "$OUT/bench_weighted.json" 2> "$OUT/bench_weighted.err"
+python tools/bench_autograd.py > "$OUT/autograd_path.json" 2> "$OUT/autograd_path.err"
 python bench.py --config 4 > "$OUT/bench_config4.json" 2> "$OUT/bench_config4.err"
 python bench.py --config 5 > "$OUT/bench_config5.json" 2> "$OUT/bench_config5.err"
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"   # the driver's form

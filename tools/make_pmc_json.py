@@ -51,7 +51,7 @@ templates = {}
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k, full = key_of(r["Kernel_Name"])
-        if not k.startswith(("iwe_", "moments", "patch_grad")):
+        if not k.startswith(("iwe_", "moments", "patch_grad", "gradmag", "cmax_resident")):
             continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         templates.setdefault(k, full[:200])
@@ -71,11 +71,13 @@ try:
 except (OSError, ValueError):
     pass
 for k, e in out.items():
-    mode = "uniform" if "UNIFORM" in k else ("grid" if "GRID" in k else "dense")
+    mode = "uniform" if "UNIFORM" in k else ("grid" if "GRID" in k or k.startswith("cmax_resident") else "dense")
     if mode in sizes:
         e["events"] = sizes[mode].get("events")
         if "batch" in k:
             e["windows"] = sizes[mode].get("windows_per_launch")
+        if k.startswith("cmax_resident"):
+            e["iterations_per_launch"] = sizes[mode].get("resident_iterations_per_launch")
 res = {"source": "rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES | "
                  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU) of tools/profile_step.py --mode all; "
                  "FETCH_SIZE x2 (gfx950 coalesced-read correction)",
