@@ -883,7 +883,9 @@ bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
     set_error("resident solve: needs the grid-sampling route (grad_partials) on a compact plan");
     return false;
   }
-  if (q->splits != 1 || q->pad_h != 0 || q->pad_w != 0) {
+  // splits: 1, or 0 = "adaptive work items" (a table the four-launch pipeline splits crowded tiles by: the resident kernel always
+  // runs one workgroup per tile and does not read it -- same objective, slab sums in another order where a tile was split)
+  if (q->splits > 1 || q->splits < 0 || q->pad_h != 0 || q->pad_w != 0) {
     set_error("resident solve: one work item per tile and no image padding (splits = %d, pad %dx%d)", q->splits, q->pad_h, q->pad_w);
     return false;
   }

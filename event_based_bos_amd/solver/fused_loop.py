@@ -258,28 +258,41 @@ class FusedPatchLoop(object):
 
     def resident_supported(self) -> bool:
         """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_patch_solve_resident_f32)?  Grid-sampling route, variance
-        contrast, one work item per tile, no padding, a tile / halo with a resident kernel, few enough tiles to be co-resident."""
-        if not self.sample_grid or self.w_gm or self.splits != 1 or self.pad != (0, 0):
+        contrast, no padding, a tile / halo with a resident kernel, few enough tiles to be co-resident.  (The resident kernel runs one
+        workgroup per tile whatever the plan's work-item table says: against a pipeline that split crowded tiles it agrees to
+        rounding, not bit for bit.)"""
+        if not self.sample_grid or self.w_gm or self.splits not in (0, 1) or self.pad != (0, 0):
             return False
         import ctypes
 
         return bool(self.lib.ebos_cmax_resident_supported(ctypes.byref(self.problem())))
 
-    def run_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> int:
-        """``n_iter`` iterations as one resident launch; returns its status after synchronising: 0, or a negative code when the
-        launch ended early (-101 a wait passed the cap, -102 a tap left the largest LDS window, -103 geometry) -- theta and the
-        optimiser state are then UNCHANGED and the caller runs the four-launch pipeline (``run`` does)."""
+    def enqueue_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> torch.Tensor:
+        """Enqueue ``n_iter`` iterations as one resident launch on the current stream WITHOUT waiting for it; returns the launch's
+        status word as a 1-element int32 tensor (a stream-ordered copy: 0 = completed, else 1 timeout / 2 spill / 3 geometry --
+        theta and the optimiser state are then unchanged).  For callers that keep several windows in flight and look at the
+        status when they collect results (solver.WindowPipeline); everybody else: ``run``."""
         import ctypes
 
         if self._mailbox is None:
             H, W = self.plan.image_size
             nb = int(self.lib.ebos_cmax_resident_mailbox_bytes(H, W, self.plan.tile[0], self.plan.tile[1]))
             self._mailbox = torch.zeros(nb, dtype=torch.uint8, device=self.plan.device)
-        s = stream_ptr()
         check(self.lib.ebos_cmax_patch_solve_resident_f32(ctypes.byref(self.problem()), int(n_iter), ptr(self._mailbox),
-                                                          self._mailbox.numel(), float(spin_timeout_s), s),
+                                                          self._mailbox.numel(), float(spin_timeout_s), stream_ptr()),
               "ebos_cmax_patch_solve_resident")
-        return int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), s))
+        self.t += int(n_iter)
+        self.last_run_mode = "resident"
+        return self._mailbox[:4].view(torch.int32).clone()
+
+    def run_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> int:
+        """``n_iter`` iterations as one resident launch; returns its status after synchronising: 0, or a negative code when the
+        launch ended early (-101 a wait passed the cap, -102 a tap left the largest LDS window, -103 geometry) -- theta and the
+        optimiser state are then UNCHANGED and the caller runs the four-launch pipeline (``run`` does)."""
+        t, mode = self.t, self.last_run_mode
+        self.enqueue_resident(n_iter, spin_timeout_s)
+        self.t, self.last_run_mode = t, mode   # (``run`` books the iterations once it has seen the status)
+        return int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), stream_ptr()))
 
     def run(self, n_iter: int, native: bool = True, resident: Optional[bool] = None) -> torch.Tensor:
         """``n_iter`` more iterations; returns their losses [n_iter] (device).

@@ -22,7 +22,8 @@ Only the objective family of ``fused_loop`` is pipelined; ``run`` raises for any
 from __future__ import annotations
 
 import ctypes
-from typing import List, Sequence, Tuple
+import os
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -36,10 +37,16 @@ from .contrast_maximization import ContrastMaximization, patch_grid_shape
 
 
 class WindowPipeline(object):
-    def __init__(self, solver: ContrastMaximization, n_concurrent: int = 3, device="cuda"):
+    def __init__(self, solver: ContrastMaximization, n_concurrent: int = 3, device="cuda", resident: Optional[bool] = None):
         if solver.motion_model != "dense-flow":
             raise NotImplementedError("WindowPipeline drives the patch-flow (dense-flow) solver")
         self.solver, self.n_concurrent = solver, max(1, int(n_concurrent))
+        # resident (default: the solver's optimizer.resident, else on unless EBOS_RESIDENT=0): each window's loop as one resident
+        # launch where the geometry allows it; False = four launches per iteration, the windows of a group interleaved on streams
+        if resident is None:
+            resident = getattr(solver, "resident", None)
+        self.resident = bool(resident) if resident is not None else os.environ.get("EBOS_RESIDENT", "1") != "0"
+        self.resident_fallbacks: List[int] = []
         self.device = torch.device(device)
         self.lib = _hip.require_gpu()
         self.histories: List[List[float]] = []
@@ -62,7 +69,8 @@ class WindowPipeline(object):
                                       "call solver.estimate(store.load_event(i0, i1)) per window instead")
         return plan
 
-    def _solve_group(self, plans: Sequence[EventPlan], streams: Sequence[torch.cuda.Stream]) -> List[dict]:
+    def _solve_group(self, plans: Sequence[EventPlan], streams: Sequence[torch.cuda.Stream],
+                     resident: Optional[bool] = None) -> List[dict]:
         """Enqueue the whole coarse-to-fine solve of every plan of the group; nothing here waits for the GPU.
         Only the patch flow and the losses of a window outlive this call: its images, workspace and plan go back to
         the caching allocator (stream-ordered reuse by the next group -- a fresh hipMalloc would wait for the GPU to
@@ -71,6 +79,8 @@ class WindowPipeline(object):
         H, W = s.orig_image_shape
         thetas = [None] * len(plans)
         losses = [[] for _ in plans]
+        statuses = [[] for _ in plans]
+        resident = self.resident if resident is None else resident
         for patch_size, sliding_window, n_iter in s.pyramid_scales():
             gh, gw = patch_grid_shape((H, W), patch_size, sliding_window)
             loops = []
@@ -89,11 +99,20 @@ class WindowPipeline(object):
                         s.flow_terms.get("flow_norm", 0.0), s.flow_terms.get("image_gradient", 0.0), s.omit_boundary, s.pad,
                         s.halo, s.lr, capacity=n_iter, w_gradient_magnitude=s.contrast_terms.get("gradient_magnitude", 0.0),
                         theta_mask=mask))
-            problems = (_hip.CmaxPatchProblem * len(loops))(*[lp.problem() for lp in loops])
-            handles = (ctypes.c_void_p * len(loops))(*[st.cuda_stream for st in streams[:len(loops)]])
-            with _hip.on_device(self.device):
-                check(self.lib.ebos_cmax_patch_solve_many_f32(problems, handles, len(loops), int(n_iter)),
-                      "ebos_cmax_patch_solve_many")
+            if resident and all(lp.resident_supported() for lp in loops):
+                # every window's loop as ONE resident launch (31 us per iteration at 2 M events against 43 as four launches, and
+                # a resident launch owns every CU: the windows of the group run one after the other -- cmax_resident.hip orders
+                # resident launches of different streams itself -- while the ingest stream's short kernels slip in between).
+                # Nothing waits here: the status words are looked at when the results are collected (``run``)
+                for w, lp in enumerate(loops):
+                    with torch.cuda.stream(streams[w]):
+                        statuses[w].append(lp.enqueue_resident(n_iter))
+            else:
+                problems = (_hip.CmaxPatchProblem * len(loops))(*[lp.problem() for lp in loops])
+                handles = (ctypes.c_void_p * len(loops))(*[st.cuda_stream for st in streams[:len(loops)]])
+                with _hip.on_device(self.device):
+                    check(self.lib.ebos_cmax_patch_solve_many_f32(problems, handles, len(loops), int(n_iter)),
+                          "ebos_cmax_patch_solve_many")
             for w, lp in enumerate(loops):
                 with torch.cuda.stream(streams[w]):
                     thetas[w] = lp.theta.clone()
@@ -104,7 +123,7 @@ class WindowPipeline(object):
                       plan.part_table):
                 if t is not None:
                     t.record_stream(streams[w])
-        return [dict(theta=thetas[w], losses=losses[w], patch=last, counts=plans[w].__dict__.get("_counts"))
+        return [dict(theta=thetas[w], losses=losses[w], patch=last, counts=plans[w].__dict__.get("_counts"), status=statuses[w])
                 for w in range(len(plans))]
 
     # ------------------------------------------------------------------ driver
@@ -128,10 +147,22 @@ class WindowPipeline(object):
                 plans, ready = nxt
                 for st in streams[:len(plans)]:
                     st.wait_event(ready)
-                pending += self._solve_group(plans, streams)          # asynchronous: returns once enqueued
+                solved = self._solve_group(plans, streams)            # asynchronous: returns once enqueued
+                for r, wnd in zip(solved, groups[g]):
+                    r["window"] = wnd
+                pending += solved
                 nxt = ingest_group(groups[g + 1]) if g + 1 < len(groups) else None  # ... so this overlaps with it
             for st in streams:
                 st.synchronize()
+            # a resident launch that ended early (a displacement beyond the largest LDS window, a wait past its cap) left its
+            # window's patch flow where it was: such a window is solved again, as four launches per iteration
+            self.resident_fallbacks = [k for k, r in enumerate(pending) if any(int(sw.item()) != 0 for sw in r["status"])]
+            for k in self.resident_fallbacks:
+                with torch.cuda.stream(streams[0]):
+                    plan = self._ingest(store, pending[k]["window"])
+                    redo = self._solve_group([plan], streams[:1], resident=False)[0]
+                streams[0].synchronize()
+                pending[k].update(redo)
             H, W = self.solver.orig_image_shape
             self.histories = [[float(v) for part in r["losses"] for v in part.cpu()] for r in pending]
             self.patch_flows = [r["theta"] for r in pending]

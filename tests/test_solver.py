@@ -127,8 +127,9 @@ def test_fused_loop_follows_the_autograd_loop(terms):
 
 @pytest.mark.gpu
 def test_fused_loop_run_modes_agree():
-    """FusedPatchLoop: the native loop (ebos_cmax_patch_solve_f32) and the per-call Python loop run the same kernels in
-    the same order: losses agree to 1e-5 relative over 30 iterations; a loop can be continued (10 + 20 steps)."""
+    """FusedPatchLoop: the native loop (ebos_cmax_patch_solve_f32), the per-call Python loop and the resident launch
+    (ebos_cmax_patch_solve_resident_f32) run the same arithmetic in the same order: losses agree to 1e-5 relative over 30
+    iterations (resident vs native: exactly); a loop can be continued in another mode (10 + 20 steps)."""
     import torch
 
     import event_based_bos_amd as ebos
@@ -138,15 +139,25 @@ def test_fused_loop_run_modes_agree():
     ev = moving_points(h, w, 500, 40, np.array([4.0, -2.5]), seed=6)
     plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto")
     hist = {}
-    for mode in ("native", "python", "split"):
-        loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, 4, 4)), 1.0, 0.01, 0.02, lr=0.1, capacity=30)
-        if mode == "split":
-            hist[mode] = np.concatenate([loop.run(10).cpu().numpy(), loop.run(20, native=False).cpu().numpy()])
+    for mode in ("native", "resident", "python", "split"):
+        # halo "auto" (the solver's default): the resident kernel always sizes its windows at run time, and the backward scatter's
+        # fixed-point unit follows max |upstream| over the staged WINDOW -- against a built halo it agrees to ~1e-6, not bit for bit
+        loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, 4, 4)), 1.0, 0.01, 0.02, halo="auto", lr=0.1, capacity=30)
+        assert loop.resident_supported(), ebos.load_library().ebos_last_error()
+        if mode == "split":    # 10 iterations of the resident launch (the default mode), continued per call from Python
+            first = loop.run(10).cpu().numpy()
+            assert loop.last_run_mode == "resident"
+            hist[mode] = np.concatenate([first, loop.run(20, native=False).cpu().numpy()])
+        elif mode == "resident":
+            hist[mode] = loop.run(30, resident=True).cpu().numpy()
+            assert loop.last_run_mode == "resident" and loop.resident_status == 0
         else:
-            hist[mode] = loop.run(30, native=mode == "native").cpu().numpy()
+            hist[mode] = loop.run(30, native=mode == "native", resident=False).cpu().numpy()
+            assert loop.last_run_mode == "pipeline"
         assert loop.t == 30 and int(loop.step.item()) == 30
     np.testing.assert_allclose(hist["python"], hist["native"], rtol=1e-5)
     np.testing.assert_allclose(hist["split"], hist["native"], rtol=1e-5)
+    np.testing.assert_array_equal(hist["resident"], hist["native"])   # the resident launch follows the pipeline bit for bit
     with pytest.raises(ValueError):
         loop.run(1)
 
@@ -214,8 +225,17 @@ def test_solver_trajectory_matches_cpu_oracle(blur):
         ref.append(loss.item())
     np.testing.assert_allclose(s.history, ref, rtol=2e-3)
     np.testing.assert_allclose(s.patch_flow.cpu().numpy(), theta.detach().numpy(), atol=5e-2)
-    # blur = 0 runs the fixed kernel pipeline (one native call for the loop); blur = 1 the autograd loop, graph-replayed
+    # blur = 0 runs the fused loop -- as ONE resident launch where the geometry allows it (it does here), and the same
+    # trajectory as four launches per iteration with optimizer.resident = False; blur = 1 the autograd loop, graph-replayed
     assert s.fused == (blur == 0) and s.graphed == (blur == 1)
+    if blur == 0:
+        assert s.loop_mode == "resident"
+        cfg_p = dict(cfg, optimizer=dict(cfg["optimizer"], resident=False))
+        s_p = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_p)
+        s_p.estimate(ev)
+        assert s_p.loop_mode == "pipeline"
+        np.testing.assert_array_equal(np.array(s.history), np.array(s_p.history))
+        np.testing.assert_allclose(s_p.history, ref, rtol=2e-3)
     cfg_e = dict(cfg, optimizer=dict(cfg["optimizer"], graph=False))
     s_e = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_e)
     s_e.estimate(ev)
@@ -325,6 +345,34 @@ def test_window_pipeline_matches_per_window_estimates(n_concurrent, pyramid):
     pipe = ebos.solver.WindowPipeline(solver, n_concurrent=n_concurrent)
     flows = pipe.run(store, windows)
     assert len(flows) == 5 and all(f.shape == (2, h, w) and f.dtype == np.float64 for f in flows)
+    # the default runs every window's loop as ONE resident launch; as four launches per iteration (the windows of a group
+    # interleaved on streams) the trajectories are the same bit for bit
+    assert pipe.resident and pipe.resident_fallbacks == []
+    four = ebos.solver.WindowPipeline(solver, n_concurrent=n_concurrent, resident=False)
+    flows_four = four.run(store, windows)
+    for k in range(5):
+        np.testing.assert_array_equal(np.array(pipe.histories[k]), np.array(four.histories[k]))
+        np.testing.assert_array_equal(flows[k], flows_four[k])
+    # a resident launch that ends early (status != 0: nothing of its window's state changed) -> that window is solved again
+    # as four launches; simulated here by a launch that never happens
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    orig, calls = FusedPatchLoop.enqueue_resident, {"n": 0}
+
+    def ends_early(self, n_iter, spin_timeout_s=2.0):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            return torch.full((1,), 2, dtype=torch.int32, device=self.plan.device)
+        return orig(self, n_iter, spin_timeout_s)
+
+    FusedPatchLoop.enqueue_resident = ends_early
+    try:
+        flows_fb = pipe.run(store, windows)
+    finally:
+        FusedPatchLoop.enqueue_resident = orig
+    assert pipe.resident_fallbacks == [1]
+    for k in range(5):
+        np.testing.assert_array_equal(flows_fb[k], flows[k])
     for k, wnd in enumerate(windows):
         ref = solver.estimate(store.load_event(*wnd))
         assert solver.fused

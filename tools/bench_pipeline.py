@@ -27,9 +27,10 @@ def main():
     ap.add_argument("--events", type=int, default=2_000_000)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--nc", type=int, nargs="+", default=[1, 2, 3, 4], help="windows in flight to try")
-    ap.add_argument("--halo", type=int, default=32, help="solver halo (16: tile 45x80 + 16 for small displacements)")
+    ap.add_argument("--halo", default="auto", help="solver halo: auto (run-time windows, the solver's default) or a built halo (32, 16)")
     ap.add_argument("--repeat", type=int, default=1, help="timed runs per setting (the minimum is reported)")
     a = ap.parse_args()
+    a.halo = a.halo if a.halo == "auto" else int(a.halo)
     n = a.windows * a.events
     rs = np.random.RandomState(0)
     store = ebos.data_loader.RawEventStore({"x": rs.randint(0, W, n).astype(np.int16), "y": rs.randint(0, H, n).astype(np.int16),
@@ -49,8 +50,8 @@ def main():
         solver.estimate(ev)
     torch.cuda.synchronize()
     res["per_window_estimate_ms"] = (time.perf_counter() - t0) / len(host_windows) * 1e3
-    for nc in a.nc:
-        pipe = ebos.solver.WindowPipeline(solver, n_concurrent=nc)
+    for nc, resident in [(nc, r) for r in (True, False) for nc in a.nc]:
+        pipe = ebos.solver.WindowPipeline(solver, n_concurrent=nc, resident=resident)
         pipe.run(store, windows)  # warm: streams, allocator pools, pinned staging
         torch.cuda.synchronize()
         times = []
@@ -59,9 +60,11 @@ def main():
             pipe.run(store, windows)
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) / a.windows * 1e3)
-        res[f"pipeline_{nc}_ms_per_window"] = min(times)
+        tag = f"pipeline_{nc}" + ("_resident" if resident else "_four_launches")
+        res[tag + "_ms_per_window"] = min(times)
+        res[tag + "_fallbacks"] = len(pipe.resident_fallbacks)
         if a.repeat > 1:
-            res[f"pipeline_{nc}_all"] = [round(t, 2) for t in times]
+            res[tag + "_all"] = [round(t, 2) for t in times]
     print(json.dumps(res))
 
 
