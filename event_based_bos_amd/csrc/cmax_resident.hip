@@ -104,7 +104,8 @@ __device__ __forceinline__ void put_granules(unsigned long long* g, unsigned tag
   st_sc1(g + 1, ((unsigned long long)tag << 32) | (b >> 32));
 }
 
-constexpr int kRecGranules = 8;  // a record: (sum, sum of squares, regulariser partial of the previous iteration) = 6 granules, 64-byte stride
+constexpr int kRec1Granules = 4; // S1's record: (the tile's share of sum(IWE)) = 2 granules + its window, 32-byte stride
+constexpr int kRecGranules = 8;  // the loss record: (sum of squares, regulariser partial of the previous iteration) = 4 granules, 64-byte stride
 constexpr int kSpan = 4;         // candidate tiles per axis whose partial cell gradients a cell sums (patch_grad_combine_kernel's)
 constexpr int kResElems = 128;   // elements (2 components x cells) of a tile's cell block the resident kernel holds state for
 
@@ -118,7 +119,7 @@ struct ResidentArgs {
   int* step;
   float *iwe, *slabs, *cell_partials;
   unsigned* status;
-  unsigned long long *flag1, *flag3, *flagi, *rec2, *done;   // mailbox sections (zeroed before every launch)
+  unsigned long long *rec1, *flag3, *flagi, *rec2, *done;    // mailbox sections (zeroed before every launch)
   float* losses;
   int losses_cap, t0, n_iter;
   double lr, beta1, beta2, eps;
@@ -154,17 +155,7 @@ constexpr bool resident_fits() {
 template <int TH, int TW, int AP>
 __device__ __forceinline__ void tile_flow_from_cells(const Lerp* s_rows, const Lerp* s_cols, const float* s_cells, int gi0, int gj0,
                                                      float* s_flow) {
-  constexpr int PH = TH + 2 * AP, PW = TW + 2 * AP;
-  for (int i = threadIdx.x; i < PH * PW; i += kBlock) {
-    const int rl = i / PW, cl = i - rl * PW;
-    Lerp ly = s_rows[rl], lx = s_cols[cl];
-    lx.i0 -= gj0;
-    lx.i1 -= gj0;
-    const float* u0 = s_cells + (ly.i0 - gi0) * kGridCells;
-    const float* u1 = s_cells + (ly.i1 - gi0) * kGridCells;
-    s_flow[i] = grid_bilerp(u0, u1, ly, lx);
-    s_flow[PH * PW + i] = grid_bilerp(u0 + kGridCells * kGridCells, u1 + kGridCells * kGridCells, ly, lx);
-  }
+  cells_to_flow<TH + 2 * AP, TW + 2 * AP>(s_rows, s_cols, s_cells, gi0, gj0, s_flow);
 }
 
 // Register pressure decides this kernel's speed between its phases: kept live across the event loops (each of which wants ~100
@@ -180,6 +171,33 @@ __device__ __forceinline__ KArgs& fresh_args() {
   return *(KArgs*)p;
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Workgroup 0, one whole wave: iteration j's loss record (sum of squares, regulariser partials of iteration j - 1) is complete ->
+// variance(j) = (Q - S mean) / (M - 1) with (S, mean) kept from j's all-to-all; loss(j - 1) = -w variance(j - 1) + regularisers(j - 1)
+// is written, variance(j) kept in s_adam[2] for the next call.  (The order of the additions of Q differs from the four-launch
+// pipeline's -- ~900 combine workgroups there -- in the last bits of a double that is then rounded to the f32 the loss is built from.)
+template <typename Args>
+__device__ __forceinline__ void book_loss(const Args& a, int j, int lane, const double* s_hist, float* s_adam) {
+  const int n_tiles = a.tiles_y * a.tiles_x;
+  double Q = 0.0, R = 0.0;
+  for (int k = lane; k < n_tiles; k += kWave) {
+    const unsigned long long* rec = a.rec2 + ((size_t)(j & 1) * n_tiles + k) * kRecGranules;
+    const unsigned long long g0 = ld_sc1(rec), g1 = ld_sc1(rec + 1), g2 = ld_sc1(rec + 2), g3 = ld_sc1(rec + 3);
+    Q += __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));
+    R += __builtin_bit_cast(double, (g2 & 0xffffffffull) | (g3 << 32));
+  }
+  Q = wave_sum(Q);
+  R = wave_sum(R);
+  if (lane == 0) {
+    const int lo_px = a.omit ? 1 : 0;
+    const double n_px = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
+    const double S = s_hist[(j & 1) * 2], mn = s_hist[(j & 1) * 2 + 1];
+    const float var_f = (float)((Q - S * mn) / (n_px - 1.0));
+    const int t_prev = a.t0 + j - 1;
+    if (j >= 1 && a.losses != nullptr && t_prev < a.losses_cap) a.losses[t_prev] = (float)(-(double)a.w_contrast * (double)s_adam[2] + R);
+    s_adam[2] = var_f;
+  }
+}
 
 struct Persist {  // one workgroup's iteration-invariant geometry
   int g_first, g_last, beg, end;                   // its slice of the plan (TileRange)
@@ -211,7 +229,8 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
   __shared__ float s_gmax[3 * kWaves];
   __shared__ unsigned s_win[9];
   __shared__ int s_wmax[2];     // largest window (rows, columns) of the grid in this iteration
-  __shared__ double s_mom[4];    // mean, variance, sum of the regulariser partials of the previous iteration
+  __shared__ double s_mom[4];    // [0] the mean of the IWE of this iteration
+  __shared__ double s_hist[4];   // workgroup 0: (sum, mean) of the IWE of the last two iterations, by parity (the loss bookkeeping)
   __shared__ double s_reg[2];    // this tile's regulariser value partial: of this iteration, of the previous one
   __shared__ float s_adam[3];    // step size and sqrt(bias correction 2) of the iteration's Adam step; variance of the previous iteration
   __shared__ double s_red[3 * kWaves];
@@ -339,6 +358,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         tile_bound_post(h2 && ch == 0 ? fabsf(th) : 0.0f, h2 && ch == 1 ? fabsf(th) : 0.0f, sh.bound);
       }
       if (threadIdx.x < 2) sh.flag[threadIdx.x] = 0;
+      if (threadIdx.x < 9) s_win[threadIdx.x] = 0xffffffffu;   // (a neighbour beyond the image's edge: no window)
       if (threadIdx.x == 0) {
         sh.next = 2 * kWaves;
         sh.chk = 0ull;
@@ -351,9 +371,13 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       __syncthreads();
       win = tile_bound_read<TH, TW, HALO, true>(sh.bound, a.dt_bound);
       EBOS_RSTAMP(1);
+      // (own: what this tile's image holds inside the valid region -- its share of sum(IWE), exact)
+      OwnSum own{tr.ty * TH - win.HR(), tr.tx * TW - win.HC(), a.omit ? 1 : 0, a.H, a.W, 0.0};
       tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, true, false>(tr, win, s_flow_f, s_acc, sh, ev, a.H, a.W, tiles_x, 0, 0,
-                                                                                    a.slabs, nullptr, nullptr, 0u, nullptr, pre, NoHook{});
+                                                                                    a.slabs, nullptr, nullptr, 0u, nullptr, pre, NoHook{}, own);
       EBOS_RSTAMP(2);
+      const double os = wave_sum(own.acc);
+      if (lane == 0) s_red[wave] = os;
       drain_stores();
       __syncthreads();
     }
@@ -362,19 +386,32 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       done_ok = false;
       break;
     }
-    // ---- S1: the eight neighbours' slabs (and their windows) --------------------------------------------------------------------
+    // ---- S1: the all-to-all of the iteration: every tile's share of sum(IWE) and its window ------------------------------------
+    // The mean of the IWE is all the variance gradient needs of the other tiles, and it does not need the assembled image: sum(IWE)
+    // = the sum over tiles of what each tile's LDS image holds inside the valid region -- exact in a double, so the same number as
+    // the four-launch pipeline's (kCombineExactSum).  It travels with the slab's flag, BEFORE any halo has been exchanged: the
+    // upstream window below is then gathered, mapped and staged in one pass, and the sum of squares (the loss VALUE only) is left
+    // to workgroup 0's bookkeeping one iteration later -- one all-to-all and one neighbour hand-off per iteration instead of three.
     constexpr int kQuads = (kLHmax * kLWmax / 4 + kBlock - 1) / kBlock;
     constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
     // (the window of the UPSTREAM image: the four-launch backward kernel stages at least its speculative 4 px window, and the
     // fixed-point unit of the scatter follows max |staged value| -- same window, same unit, same bits)
     const Win<TH, TW, HALO, true> wb = (win.hr <= kSpecHalo && win.hc <= kSpecHalo) ? Win<TH, TW, HALO, true>{kSpecHalo, kSpecHalo} : win;
-    float4 own[kQuads];  // this workgroup's own contribution to the quads of its upstream window, decoded from its LDS image
+    float4 own_q[kQuads];  // this workgroup's own contribution to the quads of its upstream window, decoded from its LDS image
+    double mean;
+    bool halo_complete;
     {
       KArgs& a = fresh_args();
-      const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, ty = tile / tiles_x, tx = tile - ty * tiles_x;
-      if (threadIdx.x == 0) st_sc1(a.flag1 + tile, ((unsigned long long)ep << 32) | win_pack(win.hr, win.hc));
+      const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, ty = tile / tiles_x, tx = tile - ty * tiles_x, n_tiles = tiles_y * tiles_x;
+      if (threadIdx.x == 0) {
+        double S = 0.0;
+        for (int k = 0; k < kWaves; ++k) S += s_red[k];
+        unsigned long long* rec = a.rec1 + ((size_t)(it & 1) * n_tiles + tile) * kRec1Granules;
+        put_granules(rec, ep, S);
+        st_sc1(rec + 2, ((unsigned long long)ep << 32) | win_pack(win.hr, win.hc));
+      }
       EBOS_RSTAMP(3);
-      {  // while the neighbours' flags travel: the own part of the gather below (needs nothing of theirs)
+      {  // while the records travel: the own part of the gather below (needs nothing of the others)
         const int H = a.H, W = a.W, tr0 = ty * TH, tc0 = tx * TW;
         const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
         const float inv_qw = 1.0f / (float)qw;
@@ -382,68 +419,221 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         const int own_lh = win.LH(), own_pt = win.P(), row0 = tr0 - win.HR(), col0 = tc0 - win.HC(), own_lw = win.LW();
 #pragma unroll
         for (int kq = 0; kq < kQuads; ++kq) {
-          own[kq] = make_float4(0.f, 0.f, 0.f, 0.f);
+          own_q[kq] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (kq * kBlock >= n_q) continue;  // (uniform)
           const int i = threadIdx.x + kq * kBlock;
           const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
           const int r = oy + rl, c = ox + 4 * cq, rr = r - row0, cc = c - col0;
           const bool ok = i < n_q && r >= 0 && r < H && c >= 0 && c < W && (unsigned)rr < (unsigned)own_lh && (unsigned)cc < (unsigned)own_lw;
           const float4 v = lds_image_cells4(s_acc, own_lh, own_pt, ok ? rr : 0, ok ? cc >> 2 : 0, lds_f64);
-          if (ok) own[kq] = v;
+          if (ok) own_q[kq] = v;
         }
       }
-      if (wave == 0) {
-        const int nty = ty + lane / 3 - 1, ntx = tx + lane % 3 - 1;
-        const bool nb = lane < 9 && nty >= 0 && nty < tiles_y && ntx >= 0 && ntx < tiles_x;
-        unsigned long long* f1 = a.flag1 + (nb ? nty * tiles_x + ntx : tile);
-        unsigned wv = 0xffffffffu;
+      double as = 0.0;
+      if (wave * kWave < n_tiles) {
+        const int k = wave * kWave + lane;
+        const unsigned long long* rec = a.rec1 + ((size_t)(it & 1) * n_tiles + min(k, n_tiles - 1)) * kRec1Granules;
+        unsigned long long g[3];
         const bool ok = wave_wait([&]() {
-          const unsigned long long f = ld_sc1(f1);
-          wv = (unsigned)f;
-          return !nb || (unsigned)(f >> 32) >= ep;
+          bool all = true;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            g[j] = ld_sc1(rec + j);
+            all = all && (unsigned)(g[j] >> 32) == ep;
+          }
+          return all;
         }, a.status, a.cap_ticks);
-        if (lane < 9) s_win[lane] = nb ? wv : 0xffffffffu;
-        if (lane == 0 && !ok) s_ok = 0;
-      } else if (threadIdx.x == kWave) {
+        if (ok && k < n_tiles) {
+          as = __builtin_bit_cast(double, (g[0] & 0xffffffffull) | (g[1] << 32));
+          const int nty = k / tiles_x, dy = nty - ty, dx = k - nty * tiles_x - tx;
+          if (dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1) s_win[(dy + 1) * 3 + dx + 1] = (unsigned)g[2];  // a neighbour's window (or this tile's)
+        }
+        const float mh = wave_max_nonneg(ok ? (float)((unsigned)g[2] & 255u) : 255.0f);
+        const float mw = wave_max_nonneg(ok ? (float)(((unsigned)g[2] >> 8) & 255u) : 255.0f);
+        if (lane == 0) {
+          atomicMax(&s_wmax[0], (int)mh);
+          atomicMax(&s_wmax[1], (int)mw);
+          if (!ok) s_ok = 0;
+        }
+      } else if (threadIdx.x == kBlock - kWave) {
         // (an idle wave: Adam's bias corrections of this iteration's step, as torch computes them -- adam_coef, patch_grid.h)
         const AdamCoef coef = adam_coef(a.lr, a.beta1, a.beta2, a.t0 + it + 1);
         s_adam[0] = coef.step_size;
         s_adam[1] = coef.bc2_sqrt;
       }
+      EBOS_RSTAMP(4);
+      as = wave_sum(as);
+      if (lane == 0) s_red[kWaves + wave] = as;
       __syncthreads();
+      if (threadIdx.x == 0) {
+        const int lo_px = a.omit ? 1 : 0;
+        const double n_px = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
+        double S = 0.0;
+        for (int k = 0; k < kWaves; ++k) S += s_red[kWaves + k];
+        const double mn = n_px > 0.0 ? S / n_px : 0.0;
+        s_mom[0] = mn;
+        s_hist[(it & 1) * 2] = S;       // (workgroup 0's bookkeeping reads them one iteration later)
+        s_hist[(it & 1) * 2 + 1] = mn;
+      }
+      __syncthreads();
+      mean = s_mom[0];
+      halo_complete = 2 * s_wmax[0] < TH && 2 * s_wmax[1] < TW;  // (uniform over the GRID: every workgroup saw every window)
     }
     if (!s_ok) { done_ok = false; break; }
-    EBOS_RSTAMP(4);
-    // ---- G: the UPSTREAM WINDOW of the IWE (this tile + the halo the backward sweep reads) = per pixel the sum of the slabs whose
-    // windows reach it, in the combine pass's order (same bits as the four-launch image).  This workgroup's own contribution is
-    // decoded from its LDS image (what it stored to its slab, without the round trip); the neighbours' come from their slabs.  A halo
-    // pixel is complete with the 3 x 3 tiles around THIS tile as long as no tile two away reaches it: hr + hr' < TH, hc + hc' < TW
-    // for any two windows -- checked for the whole grid after the all-to-all (every record carries its window); BOS-sized flows
-    // pass, and nothing of the image then travels through memory.  Otherwise (checked below) the tiles publish their images and the
-    // halo is staged from those, as the four-launch backward kernel does.
+    EBOS_RSTAMP(5);
+    // ---- G: the UPSTREAM WINDOW (this tile + the halo the backward sweep reads): per pixel the sum of the slabs whose windows reach
+    // it, in the combine pass's order (same bits as the four-launch image), mapped to d loss / d IWE = 2 (-w) (IWE - mean) / (M - 1)
+    // and stored to its place in LDS in the same pass.  This workgroup's own contribution is decoded from its LDS image (what it stored
+    // to its slab, without the round trip); the neighbours' come from their slabs.  A halo pixel is complete with the 3 x 3 tiles
+    // around THIS tile as long as no tile two away reaches it: hr + hr' < TH, hc + hc' < TW for any two windows -- known for the whole
+    // grid from the records above; BOS-sized flows pass, and nothing of the image then travels through memory.  Otherwise the raw
+    // window is stored, the tiles publish their images and the halo is staged from those, as the four-launch backward kernel does.
+    const bool publish = !halo_complete || it == n_iter - 1;  // (the image leaves the kernel in its last iteration)
+    BwdPreRaw pre_raw;  // the backward sweep's first two chunks per wave, requested here and decoded behind the barrier
     {
-      float4 wq[kQuads];
       KArgs& a = fresh_args();
       const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
       const int lo_px = a.omit ? 1 : 0;
+      const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
+      const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
+      const float Ga = (float)ga, Gc = (float)(-ga * mean);
       const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(a.slabs, 0xffffffffu);
       const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
       const float inv_qw = 1.0f / (float)qw;
-      double sm = 0.0, sq = 0.0;
+      // (an interior tile's window lies inside the valid region as a whole: no per-pixel tests -- vector instruction issue, not
+      // memory, bounds these passes)
+      const bool all_valid = oy >= lo_px && oy + wb.LH() <= H - lo_px && ox >= lo_px && ox + wb.LW() <= W - lo_px;
+      float* iwe = a.iwe;
+      double sq = 0.0;
+      float gmax_t = 0.0f, gsum_t = 0.0f;  // (max and sum of |staged value|: the scatter's fixed-point unit, bwd_fx_unit)
+      // one quad of the window, assembled: the sum of squares of this tile's own pixels, the image itself when it leaves, the
+      // affine map and the quad's place in LDS
+      auto finish_quad = [&](int i, int r, int c, bool in, bool live, const float4& v) {
+        // this tile's own pixels (quads lie inside a tile as a whole or outside it)
+        if (live && r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) {
+          const float e4[4] = {v.x, v.y, v.z, v.w};
+          if (r >= lo_px && r < H - lo_px) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c + k >= lo_px && c + k < W - lo_px) sq += (double)e4[k] * (double)e4[k];
+          }
+          if (publish) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c + k < W) st_sc1(iwe + (int64_t)r * W + c + k, e4[k]);
+          }
+        }
+        float4 gq = v;
+        if (halo_complete) {
+          if (all_valid) {
+            gq = make_float4(Ga * v.x + Gc, Ga * v.y + Gc, Ga * v.z + Gc, Ga * v.w + Gc);
+          } else {
+            const float e4[4] = {v.x, v.y, v.z, v.w};
+            float o4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const bool valid = r >= lo_px && r < H - lo_px && c + k >= lo_px && c + k < W - lo_px;
+              o4[k] = valid ? Ga * e4[k] + Gc : 0.0f;
+            }
+            gq = make_float4(o4[0], o4[1], o4[2], o4[3]);
+          }
+          if (in) {
+            const float m4 = fmaxf(fmaxf(fabsf(gq.x), fabsf(gq.y)), fmaxf(fabsf(gq.z), fabsf(gq.w)));
+            gmax_t = fmaxf(gmax_t, (gq.x + gq.y + gq.z + gq.w) == (gq.x + gq.y + gq.z + gq.w) ? m4 : INFINITY);  // (a NaN anywhere: Inf)
+            gsum_t += (fabsf(gq.x) + fabsf(gq.y)) + (fabsf(gq.z) + fabsf(gq.w));
+          }
+        }
+        if (in) reinterpret_cast<float4*>(s_g)[i] = gq;   // (the LDS image is dead: every thread decoded its own_q before S1's barriers)
+      };
+      // what needs nothing of the other tiles: the d_flow accumulators are cleared, the tile's flow with its apron is evaluated, the
+      // sweep's first chunks are requested -- placed between the request of the neighbours' slabs and their first use
+      auto independent_work = [&]() {
+        for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
+        tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
+        TileRange trp;
+        trp.ty = trp.tx = 0, trp.slab = tile, trp.part = 0;
+        trp.g_first = rfl(P.g_first), trp.g_last = rfl(P.g_last), trp.beg = rfl(P.beg), trp.end = rfl(P.end);
+        const EvPtrs evp = a.ev;
+        pre_raw.A = load_craw(trp.g_first + wave * kWave + lane, trp, evp);
+        pre_raw.B = load_craw(trp.g_first + (wave + kWaves) * kWave + lane, trp, evp);
+      };
+      if (halo_complete) {
+        // No window is as large as half a tile: a pixel lies in the windows of at most 2 x 2 tiles -- the pair of tile rows
+        // (ty - 1, ty) or (ty, ty + 1) by the half of the tile its row is in (or beyond), likewise for columns -- and this tile is one
+        // of the four.  So a quad has at most THREE slab loads, all of a thread's are in flight before the first is used (as nine
+        // candidates behind per-candidate branches, the second round of quads waited for the first: two memory round trips), and
+        // the additions keep the combine pass's order (tile row, tile column).
+        // Rounds of quads go in pairs: the loads of a pair are requested, the work that needs nothing of the other tiles runs while
+        // they travel (first pair only), then the pair is assembled -- all rounds at once held 64 registers of loads across that work
+        // and spilled.
+        constexpr int kPair = 2;
+#pragma unroll
+        for (int k0 = 0; k0 < kQuads; k0 += kPair) {
+          float4 ld[kPair][4];
+          unsigned meta[kPair];  // bits 0..3: slot s contributes; bits 4..5: the slot that is this tile
+#pragma unroll
+          for (int kk = 0; kk < kPair; ++kk) {
+            const int kq = k0 + kk;
+            meta[kk] = 0u;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) ld[kk][sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kq >= kQuads || kq * kBlock >= n_q) continue;  // (uniform: a small window has fewer quads than the largest one's kQuads per thread)
+            const int i = threadIdx.x + kq * kBlock;
+            const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+            const int r = oy + rl, c = ox + 4 * cq;
+            const bool live = i < n_q && r >= 0 && r < H && c >= 0 && c < W;
+            const int ya = r < tr0 + (TH + 1) / 2 ? ty - 1 : ty, xa = c < tc0 + (TW + 1) / 2 ? tx - 1 : tx;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+              const int nty = ya + (sl >> 1), ntx = xa + (sl & 1);
+              const unsigned w = s_win[(nty - ty + 1) * 3 + (ntx - tx + 1)];   // (0xffffffff: no such tile)
+              const int hr = (int)(w & 255u), hc = (int)((w >> 8) & 255u);
+              const int rr = r - (nty * TH - hr), cc = c - (ntx * TW - hc), lw = TW + 2 * hc, lh = TH + 2 * hr;
+              const bool is_own = nty == ty && ntx == tx;
+              const bool ok = live && w != 0xffffffffu && (unsigned)rr < (unsigned)lh && (unsigned)cc < (unsigned)lw;
+              meta[kk] |= (ok ? 1u : 0u) << sl;
+              if (is_own) meta[kk] |= (unsigned)sl << 4;
+              const bool need = ok && !is_own;
+              if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // (most waves hold no quad a given neighbour reaches)
+                const unsigned slab0 = (unsigned)(nty * tiles_x + ntx) * (unsigned)(kLHmax * kLWmax);
+                ld[kk][sl] = slab_load4(all_slabs, need ? (slab0 + (unsigned)(rr * lw + cc)) * 4u : 0u);
+              }
+            }
+          }
+          if (k0 == 0) independent_work();
+#pragma unroll
+          for (int kk = 0; kk < kPair; ++kk) {
+            const int kq = k0 + kk;
+            if (kq >= kQuads || kq * kBlock >= n_q) continue;
+            const int i = threadIdx.x + kq * kBlock;
+            const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+            const int r = oy + rl, c = ox + 4 * cq;
+            const bool in = i < n_q;
+            const bool live = in && r >= 0 && r < H && c >= 0 && c < W;
+            const unsigned own_slot = (meta[kk] >> 4) & 3u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+              const float4 part = own_slot == (unsigned)sl ? own_q[kq < kQuads ? kq : 0] : ld[kk][sl];
+              if ((meta[kk] >> sl) & 1u) v.x += part.x, v.y += part.y, v.z += part.z, v.w += part.w;
+            }
+            finish_quad(i, r, c, in, live, v);
+          }
+        }
+      } else {
 #pragma unroll
       for (int kq = 0; kq < kQuads; ++kq) {
-        wq[kq] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kq * kBlock >= n_q) continue;  // (uniform: a small window has fewer quads than the largest one's kQuads per thread)
+        if (kq * kBlock >= n_q) continue;  // (uniform)
         const int i = threadIdx.x + kq * kBlock;
         const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
         const int r = oy + rl, c = ox + 4 * cq;
-        const bool live = i < n_q && r >= 0 && r < H && c >= 0 && c < W;
+        const bool in = i < n_q;
+        const bool live = in && r >= 0 && r < H && c >= 0 && c < W;
         float4 part[9];
         bool okk[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          // (what depends on the candidate only is uniform: scalar registers and the scalar unit -- these phases are bound by vector
-          // instruction issue at four waves per SIMD, not by memory)
+          // (what depends on the candidate only is uniform: scalar registers and the scalar unit)
           const unsigned w = (unsigned)rfl((int)s_win[k]);
           const int nty = ty + k / 3 - 1, ntx = tx + k % 3 - 1;
           const int hr = (int)(w & 255u), hc = (int)((w >> 8) & 255u);
@@ -453,7 +643,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           okk[k] = live && w != 0xffffffffu && (unsigned)rr < (unsigned)lh && (unsigned)cc < (unsigned)lw;
           part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (k == 4) {  // this workgroup's own image: decoded from LDS above
-            part[k] = own[kq];
+            part[k] = own_q[kq];
           } else if (w != 0xffffffffu && __builtin_amdgcn_ballot_w64(okk[k]) != 0ull) {
             // (a neighbour's window reaches only the rim of this window: most waves hold no quad of it and skip its load)
             const unsigned byte = okk[k] ? (slab0 + (unsigned)(rr * lw + cc)) * 4u : 0u;
@@ -464,224 +654,100 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
 #pragma unroll
         for (int k = 0; k < 9; ++k)
           if (okk[k]) v.x += part[k].x, v.y += part[k].y, v.z += part[k].z, v.w += part[k].w;
-        wq[kq] = v;
-        // the variance moments: this tile's own pixels (quads lie inside a tile as a whole or outside it)
-        if (live && r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW && r >= lo_px && r < H - lo_px) {
-          const float e4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (c + k >= lo_px && c + k < W - lo_px) {
-              sm += (double)e4[k];
-              sq += (double)e4[k] * (double)e4[k];
-            }
-        }
+        finish_quad(i, r, c, in, live, v);
       }
-      EBOS_RSTAMP(5);
-      block_sum2(sm, sq, s_red);  // (behind its barriers every thread has read what it needs of the LDS image: the backward view may overwrite it)
-      if (threadIdx.x == 0) {
-        unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * (a.tiles_y * tiles_x) + tile) * kRecGranules;
-        put_granules(rec, ep, sm);
-        put_granules(rec + 2, ep, sq);
-        put_granules(rec + 4, ep, s_reg[1]);
-        st_sc1(rec + 6, ((unsigned long long)ep << 32) | win_pack(wb.hr, wb.hc));
+      independent_work();
       }
-      // While the records travel: the raw window goes to its place in LDS (held in registers across the all-to-all it was spilled:
-      // +4 us), the d_flow accumulators are cleared and the tile's flow with its apron is evaluated -- none of it needs the mean.
-#pragma unroll
-      for (int kq = 0; kq < kQuads; ++kq) {
-        const int i = threadIdx.x + kq * kBlock;
-        if (i < n_q) reinterpret_cast<float4*>(s_g)[i] = wq[kq];
-      }
-      for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
-      tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
+      EBOS_RSTAMP(6);
+      sq = wave_sum(sq);
+      gmax_t = wave_max_nonneg(gmax_t);
+      gsum_t = wave_sum(gsum_t);
+      if (lane == 0) s_red[wave] = sq, s_gmax[wave] = gmax_t, s_gmax[2 * kWaves + wave] = gsum_t;
+      if (publish) drain_stores();
     }
-    // the backward sweep's first two chunks per wave, requested before the all-to-all and decoded behind it
-    BwdPreRaw pre_raw;
-    {
+    __syncthreads();
+    EBOS_RSTAMP(7);
+    if (threadIdx.x == 0) {  // the record of the loss value: (sum of squares, regulariser partial of the previous iteration)
       KArgs& a = fresh_args();
-      TileRange tr;
-      tr.ty = tr.tx = 0, tr.slab = tile, tr.part = 0;
-      tr.g_first = rfl(P.g_first), tr.g_last = rfl(P.g_last), tr.beg = rfl(P.beg), tr.end = rfl(P.end);
-      const EvPtrs ev = a.ev;
-      pre_raw.A = load_craw(tr.g_first + wave * kWave + lane, tr, ev);
-      pre_raw.B = load_craw(tr.g_first + (wave + kWaves) * kWave + lane, tr, ev);
+      double Q = 0.0;
+      for (int k = 0; k < kWaves; ++k) Q += s_red[k];
+      unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * (a.tiles_y * a.tiles_x) + tile) * kRecGranules;
+      put_granules(rec, ep, Q);
+      put_granules(rec + 2, ep, s_reg[1]);
     }
-    EBOS_RSTAMP(6);
-    // ---- S2: the one all-to-all: every tile's (sum, sum of squares, regulariser partial of the previous iteration, window) ---------
-    double mean;
-    bool halo_complete;
-    {
-      KArgs& a = fresh_args();
-      const int n_tiles = a.tiles_y * a.tiles_x;
-      const int lo_px = a.omit ? 1 : 0;
-      const double n_px = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
-      double as = 0.0, aq = 0.0, ar = 0.0;
-      if (wave * kWave < n_tiles) {
-        const int k = wave * kWave + lane;
-        const unsigned long long* rec = a.rec2 + ((size_t)(it & 1) * n_tiles + min(k, n_tiles - 1)) * kRecGranules;
-        unsigned long long g[7];
-        const bool ok = wave_wait([&]() {
-          bool all = true;
-#pragma unroll
-          for (int j = 0; j < 7; ++j) {
-            g[j] = ld_sc1(rec + j);
-            all = all && (unsigned)(g[j] >> 32) == ep;
-          }
-          return all;
-        }, a.status, a.cap_ticks);
-        if (ok && k < n_tiles) {
-          as = __builtin_bit_cast(double, (g[0] & 0xffffffffull) | (g[1] << 32));
-          aq = __builtin_bit_cast(double, (g[2] & 0xffffffffull) | (g[3] << 32));
-          ar = __builtin_bit_cast(double, (g[4] & 0xffffffffull) | (g[5] << 32));
-        }
-        const float mh = wave_max_nonneg(ok ? (float)((unsigned)g[6] & 255u) : 255.0f);
-        const float mw = wave_max_nonneg(ok ? (float)(((unsigned)g[6] >> 8) & 255u) : 255.0f);
-        if (lane == 0) {
-          atomicMax(&s_wmax[0], (int)mh);
-          atomicMax(&s_wmax[1], (int)mw);
-          if (!ok) s_ok = 0;
-        }
-      }
-      EBOS_RSTAMP(7);
-      as = wave_sum(as), aq = wave_sum(aq), ar = wave_sum(ar);
-      if (lane == 0) s_red[wave] = as, s_red[kWaves + wave] = aq, s_red[2 * kWaves + wave] = ar;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        double S = 0.0, Q = 0.0, R = 0.0;
-        for (int k = 0; k < kWaves; ++k) S += s_red[k], Q += s_red[kWaves + k], R += s_red[2 * kWaves + k];
-        const double mn = n_px > 0.0 ? S / n_px : 0.0;
-        s_mom[0] = mn;
-        s_mom[1] = (Q - S * mn) / (n_px - 1.0);
-        s_mom[2] = R;
-      }
-      __syncthreads();
-      mean = s_mom[0];
-      halo_complete = 2 * s_wmax[0] < TH && 2 * s_wmax[1] < TW;  // (uniform over the GRID: every workgroup saw every window)
-      if (blockIdx.x == 0 && threadIdx.x == 0) {  // bookkeeping: the loss of the PREVIOUS iteration is complete now
-        const float var_f = (float)s_mom[1];
-        const int t_prev = a.t0 + it - 1;
-        if (it > 0 && a.losses != nullptr && t_prev < a.losses_cap)
-          a.losses[t_prev] = (float)(-(double)a.w_contrast * (double)s_adam[2] + s_mom[2]);
-        s_adam[2] = var_f;
-        a.variance[0] = var_f;
-        a.moments[0] = mean;
-        a.moments[1] = n_px;
-      }
-    }
-    if (!s_ok) { done_ok = false; break; }
-    EBOS_RSTAMP(8);
-    // ---- the image leaves the kernel in its last iteration -- or now, when tiles two apart reach into each other's halos: every
-    // tile publishes its pixels and the halo is read back from the neighbours' (the four-launch pipeline's staging)
-    if (!halo_complete || it == n_iter - 1) {
+    // ---- tiles two apart reach into each other's halos: every tile has published its pixels (above); the halo is read back from the
+    // neighbours' and mapped in a pass of its own (the four-launch pipeline's staging)
+    if (!halo_complete) {
       KArgs& a = fresh_args();
       const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
+      const int lo_px = a.omit ? 1 : 0;
+      const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
+      const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
+      const float Ga = (float)ga, Gc = (float)(-ga * mean);
       const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
       const float inv_qw = 1.0f / (float)qw;
-      float* iwe = a.iwe;
+      const float* iwe = a.iwe;
+      if (threadIdx.x == 0) st_sc1(a.flagi + tile, (unsigned long long)ep);
+      if (wave == 0) {
+        const int nty = ty + lane / 3 - 1, ntx = tx + lane % 3 - 1;
+        const bool nb = lane < 9 && nty >= 0 && nty < tiles_y && ntx >= 0 && ntx < tiles_x;
+        const unsigned long long* f = a.flagi + (nb ? nty * tiles_x + ntx : tile);
+        const bool ok = wave_wait([&]() { return !nb || ld_sc1(f) >= (unsigned long long)ep; }, a.status, a.cap_ticks);
+        if (lane == 0 && !ok) s_ok = 0;
+      }
+      __syncthreads();
+      float gmax_t = 0.0f, gsum_t = 0.0f;
+      if (s_ok) {
+        float4 wq[kQuads];
 #pragma unroll
-      for (int kq = 0; kq < kQuads; ++kq) {
-        const int i = threadIdx.x + kq * kBlock;
-        const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
-        const int r = oy + rl, c = ox + 4 * cq;
-        if (i < n_q && r >= tr0 && r < min(tr0 + TH, H) && c >= tc0 && c < tc0 + TW) {
-          const float4 v = reinterpret_cast<const float4*>(s_g)[i];
-          const float e4[4] = {v.x, v.y, v.z, v.w};
+        for (int kq = 0; kq < kQuads; ++kq) {
+          const int i = min((int)threadIdx.x + kq * kBlock, n_q - 1);
+          const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+          const int R = min(max(oy + rl, 0), H - 1), c = ox + 4 * cq;
+          const float* row = iwe + (int64_t)R * W;
+          wq[kq] = make_float4(ld_sc1(row + min(max(c, 0), W - 1)), ld_sc1(row + min(max(c + 1, 0), W - 1)),
+                               ld_sc1(row + min(max(c + 2, 0), W - 1)), ld_sc1(row + min(max(c + 3, 0), W - 1)));
+        }
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (c + k < W) st_sc1(iwe + (int64_t)r * W + c + k, e4[k]);
+        for (int kq = 0; kq < kQuads; ++kq) {
+          const int i = threadIdx.x + kq * kBlock;
+          if (i >= n_q) continue;
+          const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
+          const int R = oy + rl, C = ox + 4 * cq;
+          const float e4[4] = {wq[kq].x, wq[kq].y, wq[kq].z, wq[kq].w};
+          float o4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool valid = R >= lo_px && R < H - lo_px && C + k >= lo_px && C + k < W - lo_px;
+            o4[k] = valid ? Ga * e4[k] + Gc : 0.0f;
+            gmax_t = fmaxf(gmax_t, o4[k] == o4[k] ? fabsf(o4[k]) : INFINITY);
+            gsum_t += fabsf(o4[k]);
+          }
+          reinterpret_cast<float4*>(s_g)[i] = make_float4(o4[0], o4[1], o4[2], o4[3]);
         }
       }
-      if (!halo_complete) {
-        drain_stores();
-        __syncthreads();
-        if (threadIdx.x == 0) st_sc1(a.flagi + tile, (unsigned long long)ep);
-        if (wave == 0) {
-          const int nty = ty + lane / 3 - 1, ntx = tx + lane % 3 - 1;
-          const bool nb = lane < 9 && nty >= 0 && nty < tiles_y && ntx >= 0 && ntx < tiles_x;
-          const unsigned long long* f = a.flagi + (nb ? nty * tiles_x + ntx : tile);
-          const bool ok = wave_wait([&]() { return !nb || ld_sc1(f) >= (unsigned long long)ep; }, a.status, a.cap_ticks);
-          if (lane == 0 && !ok) s_ok = 0;
-        }
-        __syncthreads();
-        if (s_ok) {
-          float4 wq[kQuads];
-#pragma unroll
-          for (int kq = 0; kq < kQuads; ++kq) {
-            const int i = min((int)threadIdx.x + kq * kBlock, n_q - 1);
-            const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
-            const int R = min(max(oy + rl, 0), H - 1), c = ox + 4 * cq;
-            const float* row = iwe + (int64_t)R * W;
-            wq[kq] = make_float4(ld_sc1(row + min(max(c, 0), W - 1)), ld_sc1(row + min(max(c + 1, 0), W - 1)),
-                                 ld_sc1(row + min(max(c + 2, 0), W - 1)), ld_sc1(row + min(max(c + 3, 0), W - 1)));
-          }
-#pragma unroll
-          for (int kq = 0; kq < kQuads; ++kq) {
-            const int i = threadIdx.x + kq * kBlock;
-            if (i < n_q) reinterpret_cast<float4*>(s_g)[i] = wq[kq];  // (every thread rewrites the quads it read above: no barrier needed)
-          }
-        }
-      }
+      gmax_t = wave_max_nonneg(gmax_t);
+      gsum_t = wave_sum(gsum_t);
+      if (lane == 0) s_gmax[wave] = gmax_t, s_gmax[2 * kWaves + wave] = gsum_t;
+      __syncthreads();
     }
     if (!s_ok) { done_ok = false; break; }
-    // ---- B0 + B1: upstream window of d loss / d IWE = 2 (-w) (IWE - mean) / (M - 1) -> LDS; the sweep ------------------------------------
+    // ---- B1: the sweep -------------------------------------------------------------------------------------------------------------
     FxUnit unit;
     bool fx;
     {
       KArgs& a = fresh_args();
-      const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
+      const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
       const int lo_px = a.omit ? 1 : 0;
       const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
-      const int qw = wb.LW() / 4, n_q = wb.LH() * qw, oy = tr0 - wb.HR(), ox = tc0 - wb.HC();
-      const float inv_qw = 1.0f / (float)qw;
       GradImage G;
       G.g = a.iwe;
       const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
       G.a = (float)ga;
       G.c = (float)(-ga * mean);
       G.h = H, G.w = W, G.lo = lo_px;
-      float gmax_t = 0.0f, gsum_t = 0.0f;  // (max and sum of |staged value|: the scatter's fixed-point unit, bwd_fx_unit)
-      auto affine = [&](int R, int C, float v, bool in_window) {
-        const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-        const float gv = valid ? G.a * v + G.c : 0.0f;
-        if (in_window) {
-          gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
-          gsum_t += fabsf(gv);
-        }
-        return gv;
-      };
-      EBOS_RSTAMP(18);
-      // the affine map of the image (the variance gradient), in place: every thread maps the quads it parked
-      // (an interior tile's window lies inside the valid region as a whole: no per-pixel tests -- vector instruction issue, not
-      // memory, bounds these passes)
-      const bool all_valid = oy >= G.lo && oy + wb.LH() <= G.h - G.lo && ox >= G.lo && ox + wb.LW() <= G.w - G.lo;
-#pragma unroll
-      for (int kq = 0; kq < kQuads; ++kq) {
-        const int i = threadIdx.x + kq * kBlock;
-        const bool in = i < n_q;
-        if (kq * kBlock >= n_q) continue;  // (uniform)
-        const float4 v = reinterpret_cast<const float4*>(s_g)[in ? i : 0];
-        float4 gq;
-        if (all_valid) {
-          gq = make_float4(G.a * v.x + G.c, G.a * v.y + G.c, G.a * v.z + G.c, G.a * v.w + G.c);
-          if (in) {
-            const float m4 = fmaxf(fmaxf(fabsf(gq.x), fabsf(gq.y)), fmaxf(fabsf(gq.z), fabsf(gq.w)));
-            gmax_t = fmaxf(gmax_t, (gq.x + gq.y + gq.z + gq.w) == (gq.x + gq.y + gq.z + gq.w) ? m4 : INFINITY);  // (a NaN anywhere: Inf)
-            gsum_t += (fabsf(gq.x) + fabsf(gq.y)) + (fabsf(gq.z) + fabsf(gq.w));
-          }
-        } else {
-          const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
-          const int R = oy + rl, C = ox + 4 * cq;
-          gq = make_float4(affine(R, C, v.x, in), affine(R, C + 1, v.y, in), affine(R, C + 2, v.z, in), affine(R, C + 3, v.w, in));
-        }
-        if (in) reinterpret_cast<float4*>(s_g)[i] = gq;
-      }
-      EBOS_RSTAMP(19);
-      gmax_t = wave_max_nonneg(gmax_t);
-      gsum_t = wave_sum(gsum_t);
-      if (lane == 0) s_gmax[wave] = gmax_t, s_gmax[2 * kWaves + wave] = gsum_t;
-      __syncthreads();
       EBOS_RSTAMP(9);
-      unit = bwd_fx_unit(s_gmax, a.dt_bound, n_q * 4);
+      unit = bwd_fx_unit(s_gmax, a.dt_bound, wb.LH() * wb.LW());
       double tot_x = 0.0, tot_y = 0.0;
       const BwdShared bsh{&s_spill, &s_bad, &s_next};
       TileRange tr;
@@ -730,6 +796,9 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         const bool ok = wave_wait([&]() { return !act || ld_sc1(f) >= (unsigned long long)ep; }, a.status, a.cap_ticks);
         if (lane == 0 && !ok) s_ok = 0;
       } else {
+        // (workgroup 0, one wave: the loss of iteration it - 2 and the variance of it - 1 -- every workgroup has passed S1 of THIS
+        // iteration, so the records of the previous one are complete)
+        if (blockIdx.x == 0 && wave == 1 && it >= 1) book_loss(a, it - 1, lane, s_hist, s_adam);
         for (int i = threadIdx.x - kWave; i < kCells / 2; i += kBlock - kWave) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
       }
       __syncthreads();
@@ -801,22 +870,29 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     if (ok && k < n_tiles) ar = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));
   }
   ar = block_sum(ar, s_red);
+  // (every workgroup has left the loop: the last iteration's records are complete)
+  if (wave == 1) book_loss(a, n_iter - 1, lane, s_hist, s_adam);
+  __syncthreads();
   if (threadIdx.x == 0) {
     const int t_last = a.t0 + n_iter - 1;
     if (a.losses != nullptr && t_last < a.losses_cap) a.losses[t_last] = (float)(-(double)a.w_contrast * (double)s_adam[2] + ar);
     a.step[0] = a.t0 + n_iter;
+    const int lo_px = a.omit ? 1 : 0;
+    a.variance[0] = s_adam[2];
+    a.moments[0] = s_hist[((n_iter - 1) & 1) * 2 + 1];
+    a.moments[1] = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
   }
 #endif
 }
 
 struct MailboxLayout {
-  size_t off_status, off_flag1, off_flag3, off_flagi, off_rec2, off_done, total;
+  size_t off_status, off_rec1, off_flag3, off_flagi, off_rec2, off_done, total;
 };
 inline MailboxLayout mailbox_layout(int n_tiles) {
   MailboxLayout m;
   m.off_status = 0;
-  m.off_flag1 = 256;
-  m.off_flag3 = m.off_flag1 + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
+  m.off_rec1 = 256;
+  m.off_flag3 = m.off_rec1 + (((size_t)2 * n_tiles * kRec1Granules * 8 + 255) & ~(size_t)255);
   m.off_flagi = m.off_flag3 + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
   m.off_rec2 = m.off_flagi + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
   m.off_done = m.off_rec2 + (size_t)2 * n_tiles * kRecGranules * 8;
@@ -1016,7 +1092,7 @@ int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* q, int n_i
   a.slabs = reinterpret_cast<float*>(q->workspace);
   a.cell_partials = q->grad_partials;
   a.status = reinterpret_cast<unsigned*>(mb + m.off_status);
-  a.flag1 = reinterpret_cast<unsigned long long*>(mb + m.off_flag1);
+  a.rec1 = reinterpret_cast<unsigned long long*>(mb + m.off_rec1);
   a.flag3 = reinterpret_cast<unsigned long long*>(mb + m.off_flag3);
   a.flagi = reinterpret_cast<unsigned long long*>(mb + m.off_flagi);
   a.rec2 = reinterpret_cast<unsigned long long*>(mb + m.off_rec2);

@@ -263,6 +263,26 @@ __device__ __forceinline__ TileGrid tile_grid_begin(const float* __restrict__ gr
   return t;
 }
 
+// The dense flow of a PH x PW pixel block from the block of grid cells in LDS (s_rows [PH], s_cols [PW]: the pixels' row / column
+// interpolation; s_cells [2][kGridCells][kGridCells] starting at cell (gi0, gj0)) -> s_flow [2][PH * PW].
+// (Four consecutive columns per thread -- the row's Lerp and, where the four interpolate between the same two cells, the eight cell
+// values read once: 15 LDS instructions per four pixels instead of 48 -- did not move the pass: 2.24 us for a 45 x 80 tile either way.)
+template <int PH, int PW>
+__device__ __forceinline__ void cells_to_flow(const Lerp* s_rows, const Lerp* s_cols, const float* s_cells, int gi0, int gj0,
+                                              float* s_flow) {
+  constexpr int kPlane = kGridCells * kGridCells;
+  for (int i = threadIdx.x; i < PH * PW; i += kBlock) {
+    const int rl = i / PW, cl = i - rl * PW;
+    Lerp ly = s_rows[rl], lx = s_cols[cl];
+    lx.i0 -= gj0;  // indices into the cell block
+    lx.i1 -= gj0;
+    const float* u0 = s_cells + (ly.i0 - gi0) * kGridCells;
+    const float* u1 = s_cells + (ly.i1 - gi0) * kGridCells;
+    s_flow[i] = grid_bilerp(u0, u1, ly, lx);
+    s_flow[PH * PW + i] = grid_bilerp(u0 + kPlane, u1 + kPlane, ly, lx);
+  }
+}
+
 // second half: cell block -> LDS, then the flow of tile + apron.  Ends with a barrier.
 template <int TH, int TW, int AP>
 __device__ __forceinline__ void tile_grid_finish(const TileGrid& t, float* s_flow, const Lerp* s_lerp, float* s_cells) {
@@ -273,16 +293,7 @@ __device__ __forceinline__ void tile_grid_finish(const TileGrid& t, float* s_flo
     s_cells[(ch * kGridCells + i) * kGridCells + j] = t.cell;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < PH * PW; i += kBlock) {
-    const int rl = i / PW, cl = i - rl * PW;
-    Lerp ly = s_lerp[rl], lx = s_lerp[PH + cl];
-    lx.i0 -= t.gj0;  // indices into the cell block
-    lx.i1 -= t.gj0;
-    const float* u0 = s_cells + (ly.i0 - t.gi0) * kGridCells;
-    const float* u1 = s_cells + (ly.i1 - t.gi0) * kGridCells;
-    s_flow[i] = grid_bilerp(u0, u1, ly, lx);
-    s_flow[PH * PW + i] = grid_bilerp(u0 + kGridCells * kGridCells, u1 + kGridCells * kGridCells, ly, lx);
-  }
+  cells_to_flow<PH, PW>(s_lerp, s_lerp + PH, s_cells, t.gi0, t.gj0, s_flow);
   __syncthreads();
 }
 
@@ -847,6 +858,30 @@ struct TileShared {
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
+// what tile_body's decode pass shows every quad of floats it stores to the slab: nothing, or (resident solver kernel) the sum of
+// the cells that lie inside the image's valid region -- the workgroup's share of sum(IWE), exact in a double (kCombineExactSum)
+struct NoOwn {
+  __device__ __forceinline__ void reset() {}
+  __device__ __forceinline__ void operator()(int, int, const float4&) {}
+};
+struct OwnSum {
+  int R0, C0;   // image row / column of the window's cell (0, 0)
+  int lo, h, w; // valid region [lo, h - lo) x [lo, w - lo)
+  double acc;
+  __device__ __forceinline__ void reset() { acc = 0.0; }
+  __device__ __forceinline__ void operator()(int r, int j, const float4& v) {
+    const int R = R0 + r, C = C0 + 4 * j;
+    if (R < lo || R >= h - lo) return;
+    if (C >= lo && C + 3 < w - lo) {
+      acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    } else {
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (C + k >= lo && C + k < w - lo) acc += (double)e[k];
+    }
+  }
+};
 
 // Everything of one work item after its set-up barrier: the event loop, the rare spill sweep, the decode pass that writes the slab
 // and checks the fixed-point sums (f64 redo if a field wrapped).
@@ -855,11 +890,13 @@ struct NoHook {
 //   pre         the slice's first two chunks, already loaded (persistent kernel), or nullptr
 //   after_loop  called by every wave as it leaves the event loop, before the barrier: the persistent kernel requests the next
 //               window's first chunks there, so that they arrive while this window's image is decoded and stored
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID, bool DYN, bool ZERO, typename Hook>
+//   own         sees every quad the decode pass stores (NoOwn / OwnSum)
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID, bool DYN, bool ZERO, typename Hook,
+          typename Own>
 __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW, HALO, DYN>& win, const float* flow, double* s_acc,
                                           TileShared& sh, const EvPtrs& ev, int H, int W, int tiles_x, int pad_h, int pad_w,
                                           float* __restrict__ slabs, float* spill, unsigned* __restrict__ spill_epoch, unsigned epoch,
-                                          unsigned* __restrict__ halo_tab, const CRaw* pre, Hook&& after_loop) {
+                                          unsigned* __restrict__ halo_tab, const CRaw* pre, Hook&& after_loop, Own& own) {
   constexpr int kLHmax = TH + 2 * HALO, kLWmax = TW + 2 * HALO;
   constexpr int kCells = acc_cells<TH, TW, HALO, DYN>();
   const ChunkQueue queue{&sh.next};
@@ -933,8 +970,10 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
       }
       decoded += ((unsigned long long)a0.x + a0.y) + ((unsigned long long)a1.x + a1.y) + ((unsigned long long)b0.x + b0.y) +
                  ((unsigned long long)b1.x + b1.y);
-      EBOS_SLAB_STORE(slab_quad, make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv,
-                                             ((float)a1.x + (float)b0.y) * kInv, ((float)a1.y + (float)b1.x) * kInv));
+      const float4 v4 = make_float4(((float)a0.x + (float)bmh) * kInv, ((float)a0.y + (float)b0.x) * kInv,
+                                    ((float)a1.x + (float)b0.y) * kInv, ((float)a1.y + (float)b1.x) * kInv);
+      EBOS_SLAB_STORE(slab_quad, v4);
+      own(r, j, v4);
     };
     if (ZERO) {
       // Rows are dealt to WAVES (64 / q rows per wave and step, q = LW / 4 quads per row): a word that two neighbouring quads read
@@ -982,10 +1021,13 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
     // slab = the LDS image as f32, 16 B per lane, fully coalesced plain stores
     const int q = LW / 4;
     const float inv_q = 1.0f / (float)q;
+    own.reset();  // (what the optimistic fixed-point decode showed is void)
     for (int i = threadIdx.x; i < LH * q; i += kBlock) {
       const int r = DYN ? (int)(((float)i + 0.5f) * inv_q) : i / q;
       double* p = &s_acc[r * PT + 4 * (i - r * q)];
-      EBOS_SLAB_STORE(i, make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]));
+      const float4 v4 = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+      EBOS_SLAB_STORE(i, v4);
+      own(r, i - r * q, v4);
       if (ZERO) p[0] = p[1] = p[2] = p[3] = 0.0;
     }
     if (ZERO)
@@ -1063,9 +1105,10 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   }
   __syncthreads();
   const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(sh.bound, dt_bound);
+  NoOwn no_own;
   tile_body<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN, ZERO>(tr, win, flow, s_acc, sh, ev, H, W, tiles_x, pad_h, pad_w, slabs,
                                                                      spill, spill_epoch, epoch, halo_tab, kLeanPre ? pre : nullptr,
-                                                                     NoHook{});
+                                                                     NoHook{}, no_own);
 }
 
 template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
@@ -1186,9 +1229,10 @@ iwe_slab_accumulate_batch_kernel(FwdBatch b, int n, int H, int W, int tiles_x, i
       }
       __syncthreads();
       const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(sh.bound, dt_bound);
+      NoOwn no_own;
       tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, UNIFORM, GRID, DYN, true>(
           tr, win, flow, s_acc, sh, w.ev, H, W, tiles_x, pad_h, pad_w, w.slabs, w.spill, w.spill_epoch, epoch, w.halo_tab, pre,
-          [&]() { if (next_live) request(wn, trn); });
+          [&]() { if (next_live) request(wn, trn); }, no_own);
     } else if (next_live) {
       request(wn, trn);
     }
@@ -1202,6 +1246,11 @@ iwe_slab_accumulate_batch_kernel(FwdBatch b, int n, int H, int W, int tiles_x, i
 // forward B: combine slabs (+ spill) -> IWE, optional variance moments of the row segment
 // ---------------------------------------------------------------------------------------------------
 constexpr int kCombineBlock = 256;
+// flag in the combine kernels' g_lo argument: the partial SUM of a workgroup adds every slab's contribution to a pixel as a double
+// of its own instead of the pixel's f32 total.  The contributions are multiples of the fixed-point unit, so this sum is exact -- and
+// therefore the same number however the image is cut up: the resident solver kernel (cmax_resident.hip) obtains it tile by tile from
+// the LDS images, before any slab has travelled, and must arrive at the mean of this pass bit for bit.
+constexpr int kCombineExactSum = 256;
 
 // halo_tab (DYN accumulate pass; nullptr otherwise): the window (hr, hc) each tile's slabs were stored with -- candidates are found
 // with the largest window HALO, a candidate whose own window does not reach the pixel is skipped
@@ -1219,7 +1268,10 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
   const int R = blockIdx.y, C = blockIdx.x * kCombineBlock + threadIdx.x;
   const int r = R - pad_h, c = C - pad_w;  // un-padded coordinates (may lie in the padding ring)
+  const bool exact = (g_lo & kCombineExactSum) != 0;
+  g_lo &= kCombineExactSum - 1;
   float v = 0.0f;
+  double vd = 0.0;  // (exact: the contributions one by one)
   if (C < w) {
     // tiles whose LDS window [t*T - HALO, t*T + T + HALO) contains r (resp. c)
     int ty0 = (r - HALO - TH + 1 >= 0) ? (r - HALO - TH + 1 + TH - 1) / TH : 0;  // ceil((r - HALO - TH + 1) / TH) clamped at 0
@@ -1241,10 +1293,17 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
         const int s0 = part_off ? part_off[tile] : tile * splits, np = part_off ? part_off[tile + 1] - s0 : splits;
 #ifndef EBOS_PLAIN_SLABS
         const unsigned s_byte = ((unsigned)s0 * (unsigned)(LH * LW) + (unsigned)(rl * lw + cl)) * 4u;
-        for (int p = 0; p < np; ++p) v += slab_load1(all_slabs, s_byte + (unsigned)p * (unsigned)(LH * LW * 4));
+        for (int p = 0; p < np; ++p) {
+          const float t = slab_load1(all_slabs, s_byte + (unsigned)p * (unsigned)(LH * LW * 4));
+          v += t;
+          vd += (double)t;
+        }
 #else
         const float* s = slabs + (int64_t)s0 * (LH * LW) + rl * lw + cl;
-        for (int p = 0; p < np; ++p) v += s[(int64_t)p * (LH * LW)];
+        for (int p = 0; p < np; ++p) {
+          v += s[(int64_t)p * (LH * LW)];
+          vd += (double)s[(int64_t)p * (LH * LW)];
+        }
 #endif
       }
     }
@@ -1252,13 +1311,14 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
     const float sp = spill_used ? spill[gi] : 0.0f;
     if (sp != 0.0f) {
       v += sp;
+      vd += (double)sp;
       spill[gi] = 0.0f;  // keep the spill image zero between calls
     }
     iwe[gi] = v;
   }
   if (partials != nullptr) {
     const bool in = C < w && R >= g_lo && R < h - g_lo && C >= g_lo && C < w - g_lo;
-    double s = in ? (double)v : 0.0, ss = in ? (double)v * (double)v : 0.0;
+    double s = in ? (exact ? vd : (double)v) : 0.0, ss = in ? (double)v * (double)v : 0.0;
     __shared__ double red[2 * kCombineBlock / kWave];
     block_sum2(s, ss, red);
     if (threadIdx.x == 0) {
@@ -1289,7 +1349,10 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
   const int tx_ = threadIdx.x & 63, ty_ = threadIdx.x >> 6;
   const int R = blockIdx.y * kCombineRows + ty_, C = (blockIdx.x * 64 + tx_) * 4;
   const int r = R - pad_h, c = C - pad_w;
+  const bool exact = (g_lo & kCombineExactSum) != 0;  // (uniform) the solver's patch-grid route: see kCombineExactSum
+  g_lo &= kCombineExactSum - 1;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  double vd[4] = {0.0, 0.0, 0.0, 0.0};
   const bool live = R < h && C < w;
   // DYN: the windows of the tiles this workgroup's 4 x 256 pixels can see, fetched ONCE into LDS (a per-candidate global load would
   // put a dependent L2 round trip in front of every slab load: +1.3 us on a 7.8 us pass)
@@ -1372,6 +1435,7 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
       v.y += first[k].y;
       v.z += first[k].z;
       v.w += first[k].w;
+      if (exact) vd[0] += (double)first[k].x, vd[1] += (double)first[k].y, vd[2] += (double)first[k].z, vd[3] += (double)first[k].w;
       for (int p = 1; p < parts[k]; ++p) {
 #ifndef EBOS_PLAIN_SLABS
         const float4 t = slab_load4(all_slabs, byte0[k] + (unsigned)p * (unsigned)(LH * LW * 4));
@@ -1382,6 +1446,7 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
         v.y += t.y;
         v.z += t.z;
         v.w += t.w;
+        if (exact) vd[0] += (double)t.x, vd[1] += (double)t.y, vd[2] += (double)t.z, vd[3] += (double)t.w;
       }
     }
     const int64_t gi = (int64_t)R * w + C;
@@ -1391,6 +1456,7 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
       v.y += s4.y;
       v.z += s4.z;
       v.w += s4.w;
+      if (exact) vd[0] += (double)s4.x, vd[1] += (double)s4.y, vd[2] += (double)s4.z, vd[3] += (double)s4.w;
       *reinterpret_cast<float4*>(spill + gi) = make_float4(0.f, 0.f, 0.f, 0.f);  // keep the spill image zero
     }
     *reinterpret_cast<float4*>(iwe + gi) = v;
@@ -1402,7 +1468,7 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (C + k >= g_lo && C + k < w - g_lo) {
-          s += (double)e[k];
+          s += exact ? vd[k] : (double)e[k];
           ss += (double)e[k] * (double)e[k];
         }
     }
@@ -2064,7 +2130,8 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
     const int i = rem / TW, c = rem - i * TW;
     const float* d = s_f + ch * TH * TW + c;
     const float* wy = s_wy + i * TH;
-    float acc = 0.0f;  // (bounding r to the rows that touch the cell -- about half -- was slower: the bound search is serial)
+    float acc = 0.0f;  // (bounding r to the rows that touch the cell -- about half -- was slower: the bound search is serial; four
+                       // columns per thread with 16-byte reads likewise: 2.2 -> 2.9 us for this half of the epilogue)
 #pragma unroll 9
     for (int r = 0; r < TH; ++r) acc += wy[r] * d[r * TW];
     s_S[idx] = acc;

@@ -143,23 +143,25 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
     ka<<<dim3((unsigned)L.nblk), dim3(kBlock), lds, s>>>(ev, key_offsets, flow, H, W, L.tiles_x, splits, pad_h, pad_w, slabs, spill, gs,
                                                          spill_epoch, epoch, ha.dt_bound, halo_tab);
   int64_t nparts;
+  // the solver's patch-grid route sums the image exactly (kCombineExactSum): the resident form of its loop must find the same mean
+  const int g_lo = (omit ? 1 : 0) | (grid_src != nullptr ? kCombineExactSum : 0);
   if (L.w % 4 == 0 && pad_w % 4 == 0) {
     dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows);
     nparts = (int64_t)gb.x * gb.y;
     auto kc = dyn ? iwe_slab_combine4_kernel<TH, TW, HALO, true> : iwe_slab_combine4_kernel<TH, TW, HALO, false>;
     if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_COMBINE))
       hipExtLaunchKernelGGL(kc, gb, dim3(kCombineBlock), 0, s, t0, t1, 0, slabs, spill, L.tiles_y,
-                            L.tiles_x, splits, H, W, pad_h, pad_w, iwe, omit ? 1 : 0, want_var ? partials : nullptr,
+                            L.tiles_x, splits, H, W, pad_h, pad_w, iwe, g_lo, want_var ? partials : nullptr,
                             splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch, halo_tab);
     else
-      kc<<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W, pad_h, pad_w, iwe, omit ? 1 : 0,
+      kc<<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W, pad_h, pad_w, iwe, g_lo,
                                             want_var ? partials : nullptr, splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch,
                                             halo_tab);
   } else {
     dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
     nparts = (int64_t)gb.x * gb.y;
     iwe_slab_combine_kernel<TH, TW, HALO><<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W,
-                                                                            pad_h, pad_w, iwe, omit ? 1 : 0,
+                                                                            pad_h, pad_w, iwe, g_lo,
                                                                             want_var ? partials : nullptr,
                                                                             splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch,
                                                                             dyn ? halo_tab : nullptr);

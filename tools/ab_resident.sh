@@ -1,0 +1,13 @@
+#!/bin/bash
+# The resident solver kernel's regression loop on the GPU box: its tests, the per-iteration times, optionally the in-kernel stamps.
+#   tools/ab_resident.sh [stamps]
+timeout 900 python -m pytest tests/test_solver.py -m gpu -x -q -s -k "resident or run_modes or trajectory or window_pipeline" 2>&1 | grep -v "^$" | tail -8
+for args in "--events 2000000" "--size 260 346 --events 100000" "--events 10000000" "--events 200000"; do
+  python tools/profile_solver.py $args --halo auto --mode resident 2>&1 | tail -1 | sed -E 's/\(status 0\), //; s/sample_grid.*gradient 0.0: //' 
+done
+python tools/profile_solver.py --events 2000000 --halo auto --mode pipeline 2>&1 | tail -1 | sed -E 's/\(status 0\), //; s/sample_grid.*gradient 0.0: //' 
+if [ "${1:-}" = "stamps" ]; then
+  export EBOS_HIP_LIBRARY=$PWD/event_based_bos_amd/lib/libebos_stamps.so
+  python tools/stamp_resident.py 2>&1 | tail -23
+  python tools/stamp_resident.py --size 260 346 --events 100000 --patch 20 20 2>&1 | tail -23
+fi

@@ -35,21 +35,21 @@ n = -(-H // th) * -(-W // tw)
 buf = (ctypes.c_ulonglong * (n * 32))()
 raw.ebos_debug_read_stamps_resident(buf, n * 32)
 st = np.array(buf[:], dtype=np.float64).reshape(n, 32) * 10.0  # ns
-names = ["F0 cells -> LDS, window, tile flow", "F1 event loop + decode + slab stores issued", "   drain slab stores + barrier + flag1",
-         "S1 wait for the 8 neighbours", "G  gather the upstream window (own LDS image + neighbours' slabs)", "   block sum + record; window -> LDS, clear, tile flow (apron)",
-         "S2 poll all records", "   reduce (mean / variance)", "B0 affine map of the window, barrier", "B1 sweep",
-         "B2 regulariser + tile adjoint (stores issued)", "   drain + barrier + flag3", "S3 wait for the partials' tiles (+ LDS clear)", "A  cell gradients + Adam"]
+phases = [("F0 cells -> window bound, tile flow", 0, 1), ("F1 event loop + decode (+ own sum) + slab stores issued", 1, 2),
+          ("   drain slab stores + barrier + record {sum, window}", 2, 3),
+          ("S1 own part of the gather; poll ALL records (the all-to-all)", 3, 4), ("   reduce -> mean", 4, 5),
+          ("G  gather the upstream window + affine map -> LDS", 5, 6), ("   wave sums, clear, tile flow (apron), prefetch, barrier", 6, 7),
+          ("   (publish path, if any) + fixed-point unit", 7, 9), ("B1 sweep", 9, 10),
+          ("B2 regulariser + tile adjoint (stores issued)", 10, 11), ("   drain + barrier + flag3", 11, 12),
+          ("S3 wait for the partials' tiles (+ LDS clear, loss bookkeeping)", 12, 13), ("A  cell gradients + Adam", 13, 14)]
 print(f"{H}x{W}, {a.events} events, tile {plan.tile}, {n} workgroups; last of {a.iters} iterations")
 tot = st[:, 14] - st[:, 0]
-for i, nm in enumerate(names):
-    d = st[:, i + 1] - st[:, i]
-    print(f"  {nm:62s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
-print(f"  {'iteration (F0 -> A)':62s} median {np.median(tot) / 1e3:6.2f} us   min {tot.min() / 1e3:6.2f}   max {tot.max() / 1e3:6.2f}")
-print(f"  start skew of the iteration across workgroups: {(st[:, 0].max() - st[:, 0].min()) / 1e3:.2f} us")
-if st[:, 18].max() > 0:  # sub-stamps of B0 (vector staging path)
-    for nm, i0, i1 in (("B0: (image publish, if any)", 8, 18), ("B0: affine map of the window in place", 18, 19), ("B0: wave max + barrier", 19, 9)):
-        d = st[:, i1] - st[:, i0]
-        print(f"  {nm:62s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
+for nm, i0, i1 in phases:
+    d = st[:, i1] - st[:, i0]
+    print(f"  {nm:66s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
+print(f"  {'iteration (F0 -> A)':66s} median {np.median(tot) / 1e3:6.2f} us   min {tot.min() / 1e3:6.2f}   max {tot.max() / 1e3:6.2f}")
+print(f"  start skew of the iteration across workgroups: {(st[:, 0].max() - st[:, 0].min()) / 1e3:.2f} us;  arrival skew at S1: "
+      f"{(st[:, 3].max() - st[:, 3].min()) / 1e3:.2f} us")
 bb = (ctypes.c_ulonglong * (n * 8))()
 raw.ebos_debug_read_stamps_resident_bwd(bb, n * 8)
 sb = np.array(bb[:], dtype=np.float64).reshape(n, 8) * 10.0
