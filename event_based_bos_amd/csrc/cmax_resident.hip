@@ -33,6 +33,12 @@
 
 #include "iwe_tile_core.h"
 
+// Timing builds (tools/ablate_resident.sh): EBOS_ABL is a mask of pieces of the iteration to leave out -- results are WRONG on
+// purpose; what a piece costs where it stands is the difference to the whole.  0 in the product.
+#ifndef EBOS_ABL
+#define EBOS_ABL 0
+#endif
+
 namespace ebos {
 namespace {
 
@@ -367,12 +373,13 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         s_next = 2 * kWaves;
         s_wmax[0] = s_wmax[1] = 0;
       }
-      tile_flow_from_cells<TH, TW, 0>(s_lerp + AP, s_lerp + PH + AP, s_cells, gi0, gj0, s_flow_f);
+      if (!(EBOS_ABL & 1)) tile_flow_from_cells<TH, TW, 0>(s_lerp + AP, s_lerp + PH + AP, s_cells, gi0, gj0, s_flow_f);
       __syncthreads();
       win = tile_bound_read<TH, TW, HALO, true>(sh.bound, a.dt_bound);
       EBOS_RSTAMP(1);
       // (own: what this tile's image holds inside the valid region -- its share of sum(IWE), exact)
       OwnSum own{tr.ty * TH - win.HR(), tr.tx * TW - win.HC(), a.omit ? 1 : 0, a.H, a.W, 0.0};
+      if (!(EBOS_ABL & 2048))
       tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, true, false>(tr, win, s_flow_f, s_acc, sh, ev, a.H, a.W, tiles_x, 0, 0,
                                                                                     a.slabs, nullptr, nullptr, 0u, nullptr, pre, NoHook{}, own);
       EBOS_RSTAMP(2);
@@ -425,6 +432,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
           const int r = oy + rl, c = ox + 4 * cq, rr = r - row0, cc = c - col0;
           const bool ok = i < n_q && r >= 0 && r < H && c >= 0 && c < W && (unsigned)rr < (unsigned)own_lh && (unsigned)cc < (unsigned)own_lw;
+          if (EBOS_ABL & 8) continue;
           const float4 v = lds_image_cells4(s_acc, own_lh, own_pt, ok ? rr : 0, ok ? cc >> 2 : 0, lds_f64);
           if (ok) own_q[kq] = v;
         }
@@ -441,7 +449,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             g[j] = ld_sc1(rec + j);
             all = all && (unsigned)(g[j] >> 32) == ep;
           }
-          return all;
+          return all || (EBOS_ABL & 256) != 0;
         }, a.status, a.cap_ticks);
         if (ok && k < n_tiles) {
           as = __builtin_bit_cast(double, (g[0] & 0xffffffffull) | (g[1] << 32));
@@ -548,8 +556,9 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       // what needs nothing of the other tiles: the d_flow accumulators are cleared, the tile's flow with its apron is evaluated, the
       // sweep's first chunks are requested -- placed between the request of the neighbours' slabs and their first use
       auto independent_work = [&]() {
+        if (!(EBOS_ABL & 4))
         for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
-        tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
+        if (!(EBOS_ABL & 2)) tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
         TileRange trp;
         trp.ty = trp.tx = 0, trp.slab = tile, trp.part = 0;
         trp.g_first = rfl(P.g_first), trp.g_last = rfl(P.g_last), trp.beg = rfl(P.beg), trp.end = rfl(P.end);
@@ -593,7 +602,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
               const bool ok = live && w != 0xffffffffu && (unsigned)rr < (unsigned)lh && (unsigned)cc < (unsigned)lw;
               meta[kk] |= (ok ? 1u : 0u) << sl;
               if (is_own) meta[kk] |= (unsigned)sl << 4;
-              const bool need = ok && !is_own;
+              const bool need = ok && !is_own && !(EBOS_ABL & 64);
               if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // (most waves hold no quad a given neighbour reaches)
                 const unsigned slab0 = (unsigned)(nty * tiles_x + ntx) * (unsigned)(kLHmax * kLWmax);
                 ld[kk][sl] = slab_load4(all_slabs, need ? (slab0 + (unsigned)(rr * lw + cc)) * 4u : 0u);
@@ -759,6 +768,8 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       decode_bgroup(pre.B, pre_raw.B, (unsigned)PW, 0u, (unsigned)(AP * PW + AP));
       finish_bgroup<TW>(pre.A);
       finish_bgroup<TW>(pre.B);
+      fx = true;
+      if (!(EBOS_ABL & 32))
       fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, ev, s_flow_b, H, W, 0, 0, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
                                                            unit, a.dt_bound, pre, true, bsh, NoHook{});
       __syncthreads();
@@ -774,6 +785,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       const TileGrad<TH, TW> grad{fx, 1.0f / unit.scale, s_d};
       const float s_norm = a.s_norm, s_tv = a.s_tv;
       const bool any_reg = s_norm != 0.0f || s_tv != 0.0f;
+      if (!(EBOS_ABL & 4096))
       grid_tile_epilogue<TH, TW, HALO, true>(tr, ty * TH, tx * TW, H, W, s_d, s_g, s_flow_b, s_lerp, grad, nullptr, s_norm, s_tv,
                                              any_reg ? &s_reg[0] : nullptr, a.cell_partials + (int64_t)tile * (2 * kGridCells * kGridCells));
       EBOS_RSTAMP(11);
@@ -793,7 +805,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         const int ry = lane / rect_nx, rx = lane - ry * rect_nx;
         const bool act = lane < n_rect;
         const unsigned long long* f = a.flag3 + (rfl(P.rect_ty0) + (act ? ry : 0)) * a.tiles_x + rfl(P.rect_tx0) + (act ? rx : 0);
-        const bool ok = wave_wait([&]() { return !act || ld_sc1(f) >= (unsigned long long)ep; }, a.status, a.cap_ticks);
+        const bool ok = wave_wait([&]() { return !act || ld_sc1(f) >= (unsigned long long)ep || (EBOS_ABL & 512) != 0; }, a.status, a.cap_ticks);
         if (lane == 0 && !ok) s_ok = 0;
       } else {
         // (workgroup 0, one wave: the loss of iteration it - 2 and the variance of it - 1 -- every workgroup has passed S1 of THIS
@@ -824,7 +836,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         for (int q = 0; q < kSpan; ++q) {
           const int cty = min(cty0 + p, tiles_y - 1), ctx = min(ctx0 + q, tiles_x - 1);
           const int li = (int)((cand_b >> (4 * p)) & 15u), lj = (int)((cand_b >> (16 + 4 * q)) & 15u);
-          pv[p][q] = ld_sc1(cp + (((int64_t)(cty * tiles_x + ctx) * 2 + ch) * kGridCells + li) * kGridCells + lj);
+          pv[p][q] = (EBOS_ABL & 1024) ? 0.0f : ld_sc1(cp + (((int64_t)(cty * tiles_x + ctx) * 2 + ch) * kGridCells + li) * kGridCells + lj);
         }
       float g = 0.0f;
 #pragma unroll

@@ -27,6 +27,7 @@ ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile (de
 ap.add_argument("--mode", choices=["auto", "resident", "pipeline"], default="auto", help="one resident launch / four launches per iteration")
 ap.add_argument("--size", type=int, nargs=2, default=None, help="image size (default 720 1280)")
 ap.add_argument("--flow-max", type=float, default=0.0, help="initial patch flows U(-m, m) (0: zeros)")
+ap.add_argument("--lr", type=float, default=0.1, help="Adam's learning rate (0: the flow stays where it starts -- timing builds)")
 a = ap.parse_args()
 if a.size:
     import numpy as np
@@ -39,7 +40,7 @@ plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, 
 gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
 theta0 = torch.zeros((2, gh, gw)) if a.flow_max == 0 else (torch.rand((2, gh, gw), generator=torch.Generator().manual_seed(1)) * 2 - 1) * a.flow_max
 res = {"auto": None, "resident": True, "pipeline": False}[a.mode]
-loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 1.0, a.flow_norm, a.image_gradient, halo=a.halo, lr=0.1, capacity=a.iters + 3,
+loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 1.0, a.flow_norm, a.image_gradient, halo=a.halo, lr=a.lr, capacity=a.iters + 3,
                       sample_grid=False if a.dense else None)
 loop.run(3, resident=res)
 torch.cuda.synchronize()
