@@ -1945,9 +1945,12 @@ struct TileGrad {
   const double* s_d;
   __device__ __forceinline__ float at(int i, int ch) const {
     if (fx) {
+      // (both fields fit 32 signed bits: one v_cvt_f32_i32 each -- converting them as the 64-bit integers they are extracted as is a
+      // ~15-instruction sequence per value, twice per pixel, in a pass bound by instruction issue)
       const long long w = (long long)reinterpret_cast<const unsigned long long*>(s_d)[i];
-      const long long lo = fx_lo(w);
-      return (float)(ch ? fx_hi(w) : lo) * fx_inv;
+      const int lo = (int)(unsigned)(w & 0xffffffffll);
+      const int hi = (int)((w - (long long)lo) >> 32);
+      return (float)(ch ? hi : lo) * fx_inv;
     }
     return (float)s_d[ch * TH * TW + i];
   }
@@ -2139,7 +2142,8 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
     const int i = rem / TW, c = rem - i * TW;
     const float* d = s_f + ch * TH * TW + c;
     const float* wy = s_wy + i * TH;
-    float acc = 0.0f;  // (bounding r to the rows that touch the cell -- about half -- was slower: the bound search is serial; four
+    float acc = 0.0f;  // (bounding r to the rows that touch the cell -- about half -- was slower, with a search for the bounds and with
+                       // their closed form (`support`) alike: +0.4 us per solver iteration, the loop no longer unrolls by 9; four
                        // columns per thread with 16-byte reads likewise: 2.2 -> 2.9 us for this half of the epilogue)
 #pragma unroll 9
     for (int r = 0; r < TH; ++r) acc += wy[r] * d[r * TW];

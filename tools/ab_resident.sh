@@ -5,6 +5,11 @@ timeout 900 python -m pytest tests/test_solver.py -m gpu -x -q -s -k "resident o
 for args in "--events 2000000" "--size 260 346 --events 100000" "--events 10000000" "--events 200000"; do
   python tools/profile_solver.py $args --halo auto --mode resident 2>&1 | tail -1 | sed -E 's/\(status 0\), //; s/sample_grid.*gradient 0.0: //' 
 done
+if [ -f event_based_bos_amd/lib/libebos_prev.so ]; then   # A/B on the same box: the library of the previous build
+  for args in "--events 2000000" "--size 260 346 --events 100000"; do
+    echo -n "PREV: "; EBOS_HIP_LIBRARY=$PWD/event_based_bos_amd/lib/libebos_prev.so python tools/profile_solver.py $args --halo auto --mode resident 2>&1 | tail -1 | grep -o "[0-9]* events.*us/iteration"
+  done
+fi
 python tools/profile_solver.py --events 2000000 --halo auto --mode pipeline 2>&1 | tail -1 | sed -E 's/\(status 0\), //; s/sample_grid.*gradient 0.0: //' 
 if [ "${1:-}" = "stamps" ]; then
   export EBOS_HIP_LIBRARY=$PWD/event_based_bos_amd/lib/libebos_stamps.so
