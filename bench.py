@@ -697,10 +697,18 @@ def run_config2(R):
                 del ev2
                 leg = {"patch_grid": [gh, gw], "objective": "image_variance + 0.001 flow_norm, Adam, 200 iterations timed",
                        "note": "informative, not `value`: forward + backward + Adam step per iteration; run-time LDS windows (halo auto)"}
-                for tag, pl in (("2M_events", plan2), (f"{plan.n // 1_000_000}M_events", plan)):
+                # ... and BASELINE configs[0]'s size: 100 k events at 346x260 (99 tiles of 32 x 32, patches of 20 x 20)
+                small = (260, 346)
+                rs_s = np.random.RandomState(11)
+                ev_s = np.stack([rs_s.randint(0, small[0], 100_000), rs_s.randint(0, small[1], 100_000),
+                                 np.sort(rs_s.uniform(0, 0.5, 100_000)), rs_s.randint(0, 2, 100_000)], 1).astype(np.float64)
+                plan_s = ebos.EventPlan.build(torch.from_numpy(ev_s).to(dev), small, "first", True, tile="auto", emit="compact")
+                for tag, pl, patch in (("2M_events", plan2, (24, 32)), (f"{plan.n // 1_000_000}M_events", plan, (24, 32)),
+                                       ("100k_events_346x260", plan_s, (20, 20))):
                     ent = {"events": pl.n}
+                    g_h, g_w = ebos.solver.patch_grid_shape(pl.image_size, patch, patch)
                     for mode, res in (("four_launches", False), ("resident", True)):
-                        sl = FusedPatchLoop(pl, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.1, capacity=260)
+                        sl = FusedPatchLoop(pl, patch, patch, torch.zeros((2, g_h, g_w)), 1.0, 0.001, 0.0, halo="auto", lr=0.1, capacity=260)
                         if res and not sl.resident_supported():
                             ent[mode] = {"unsupported": (lib.ebos_last_error() or b"").decode()}
                             continue
@@ -718,7 +726,7 @@ def run_config2(R):
                 leg["us_per_iteration"] = min(v["us_per_iteration"] for v in leg["2M_events"].values()
                                               if isinstance(v, dict) and "us_per_iteration" in v)
                 extras["solver_iteration"] = leg
-                del plan2
+                del plan2, plan_s
             except Exception as err:  # the headline measurement must not depend on the solver layer
                 extras["solver_iteration"] = {"error": repr(err)}
 

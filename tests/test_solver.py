@@ -573,6 +573,53 @@ def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
 
 
 @pytest.mark.gpu
+def test_resident_loop_spins_are_bounded():
+    """Every wait of the resident kernel is capped.  Staged here: a one-wave kernel spinning on another stream keeps ONE compute
+    unit from taking its workgroup of a 256-tile grid (a resident workgroup needs the whole register file of its CU), so the other
+    255 wait for a record that does not come: the launch must END with status -101 after the cap (never hang), leave the patch flow,
+    the optimiser state and the step counter untouched, and the four-launch pipeline must then run from that state -- the same
+    losses as a loop that never tried."""
+    import time
+
+    import torch
+
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w = 720, 1280
+    rs = np.random.RandomState(5)
+    ev = np.stack([rs.randint(0, h, 200_000), rs.randint(0, w, 200_000), np.sort(rs.uniform(0, 0.5, 200_000)), rs.randint(0, 2, 200_000)], 1)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev.astype(np.float64)).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    assert plan.tile == (45, 80)
+    gh, gw = ebos.solver.patch_grid_shape((h, w), (24, 32), (24, 32))
+    theta0 = torch.from_numpy(rs.uniform(-1, 1, (2, gh, gw))).float()
+    ref = FusedPatchLoop(plan, (24, 32), (24, 32), theta0, 1.0, 0.001, 0.0, halo="auto", lr=0.1, capacity=16)
+    res = FusedPatchLoop(plan, (24, 32), (24, 32), theta0, 1.0, 0.001, 0.0, halo="auto", lr=0.1, capacity=16)
+    assert res.resident_supported()
+    res.run(1)                      # (warm: module load, LDS attribute, mailbox)
+    assert res.last_run_mode == "resident"
+    res = FusedPatchLoop(plan, (24, 32), (24, 32), theta0, 1.0, 0.001, 0.0, halo="auto", lr=0.1, capacity=16)
+    torch.cuda.synchronize()
+    blocker = torch.cuda.Stream()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(blocker):
+        torch.cuda._sleep(int(4e8))   # one wave, a few hundred ms
+    status = res.run_resident(8, spin_timeout_s=0.02)
+    waited = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    print(f"resident launch beside a spinning wave: status {status} after {waited * 1e3:.1f} ms (blocker done after {(time.perf_counter() - t0) * 1e3:.1f} ms)")
+    assert status == -101, status
+    assert waited < 5.0
+    assert res.t == 0 and int(res.step.item()) == 0
+    np.testing.assert_array_equal(res.theta.cpu().numpy(), theta0.numpy())
+    assert float(res.exp_avg.abs().max()) == 0.0 and float(res.exp_avg_sq.abs().max()) == 0.0
+    l_ref = ref.run(8, resident=False).cpu().numpy()
+    l_res = res.run(8).cpu().numpy()    # the default mode, now unobstructed: resident
+    assert res.last_run_mode == "resident" and res.resident_status == 0
+    np.testing.assert_array_equal(l_res, l_ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size,n_ev,patch,amp", [((96, 128), 20_000, (24, 32), 20.0), ((720, 1280), 400_000, (24, 32), 24.0)])
 def test_resident_loop_with_windows_that_reach_two_tiles_far(size, n_ev, patch, amp):
     """Flows whose LDS windows are larger than half a tile: a halo pixel may then receive events of a tile TWO away, which the
