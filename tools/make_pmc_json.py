@@ -32,6 +32,8 @@ def key_of(name):
     flag = lambda i: len(args) > i and args[i] == "true"
     if base == "iwe_slab_accumulate_kernel":      # <TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN>
         uni, grid, dyn = flag(6), flag(7), flag(8)
+        if len(args) > 5 and args[5] in ("0", "(ebos::(anonymous namespace)::EvFormat)0") and not uni:  # FMT_XY: the general 12 B/event format
+            return "iwe_slab_accumulate_kernel<XY" + (",W>" if flag(3) else ">"), name
     elif base == "iwe_slab_accumulate_batch_kernel":  # <TH, TW, HALO, GRID, DYN, UNIFORM>
         uni, grid, dyn = flag(5), flag(3), flag(4)
     elif base == "iwe_dense_tiled_bwd_kernel":    # <TH, TW, HALO, HAS_W, FMT, UNIFORM, GRID, DYN>
@@ -71,7 +73,7 @@ try:
 except (OSError, ValueError):
     pass
 for k, e in out.items():
-    mode = "uniform" if "UNIFORM" in k else ("grid" if "GRID" in k or k.startswith("cmax_resident") else "dense")
+    mode = "uniform" if "UNIFORM" in k else ("grid" if "GRID" in k or k.startswith("cmax_resident") else ("general" if "<XY" in k else "dense"))
     if mode in sizes:
         e["events"] = sizes[mode].get("events")
         if "batch" in k:

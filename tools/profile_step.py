@@ -24,7 +24,7 @@ import event_based_bos_amd as ebos  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="dense", choices=("dense", "grid", "uniform", "all"))
+    ap.add_argument("--mode", default="dense", choices=("dense", "general", "grid", "uniform", "all"))
     ap.add_argument("--events", type=int, default=10_000_000)
     ap.add_argument("--events-uniform", type=int, default=50_000_000)
     ap.add_argument("--iters", type=int, default=6)
@@ -57,6 +57,25 @@ def main():
         print("dense contrast", -loss.item(), "gradient magnitude", -loss_gm.item())
         sizes["dense"] = {"events": plan.n}
         del plan
+    if args.mode in ("general", "all"):
+        # the general event formats (bench.py --fractional / --weighted): source coordinates on a 1/64 px grid (12 B/event, the warp
+        # looks the flow up at the truncated pixel, src/warp.py:334) and per-event weights (f64 LDS accumulation)
+        n_g = min(args.events, 10_000_000)
+        ev, flow_np = synth_window(n_g, 0)
+        flow = torch.from_numpy(flow_np).float().to(dev)
+        plan_w = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(args.tile))
+        wts = torch.from_numpy(np.random.RandomState(777).uniform(0.5, 1.5, n_g).astype(np.float32)).to(dev)
+        rs = np.random.RandomState(4242)
+        ev[:, 0] += rs.randint(0, 64, n_g) / 64.0
+        ev[:, 1] += rs.randint(0, 64, n_g) / 64.0
+        plan_f = ebos.EventPlan.build(torch.from_numpy(ev).to(dev), (H, W), "first", True, tile=tuple(args.tile))
+        for _ in range(args.iters):
+            iwe_f = plan_f.iwe_dense(flow, halo=args.halo)
+            iwe_w = plan_w.iwe_dense(flow, weight=wts, halo=args.halo)
+        torch.cuda.synchronize()
+        print("general formats: IWE sums", float(iwe_f.sum()), float(iwe_w.sum()))
+        sizes["general"] = {"events": n_g}
+        del plan_f, plan_w, iwe_f, iwe_w
     if args.mode in ("grid", "all"):
         from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
 
