@@ -162,7 +162,14 @@ def test_bench_line_contract_single_gpu():
     assert line["unit"] == "Mevents/s" and line["dtype"] == "f32" and line["higher_is_better"] is True
     assert "workload" in line["config"] and "model" not in line["config"]
     r = line["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # `bound` names the roofline that BINDS when the committed counters were taken on this kernel source (roofline_issue), with the
+    # HBM pricing beside it; "hbm" when there are no counters to say otherwise.  Never "hbm" next to another binding in the summary.
+    assert r["bound"] in ("hbm", "valu_issue", "lds_pipe") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if r["bound"] != "hbm":
+        assert r["bound"] == line["roofline_summary"]["binding"] == line["roofline_issue"]["bound"] and r["hbm_frac"] == r["frac"]
+    for k in ("value_hbm_streaming", "value_incl_plan_build"):   # the regimes a fresh window sees, next to `value`
+        assert k in line and line[k] > 0
     assert abs(line["value"] - 400000 * 20 / (line["ms_per_step"] * 20 * 1e-3) / 1e6) < 0.02 * line["value"]
     assert line["contrast_rel_err"] < 1e-5                      # GPU variance == the CPU baseline leg's own result
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
