@@ -14,14 +14,15 @@
 //              workgroup steps the cells of its own block itself, redundantly and bit-identically -- no broadcast of theta),
 //              which tiles' partial gradients each of its cells sums
 //   LDS        the row / column interpolation tables of the tile (+ 2 px apron), the block of cells
-// and exchanges per iteration, through global memory, only
-//   S1  its LDS image as a slab (write-through) -> flag1 {epoch, window}: the EIGHT NEIGHBOURS are waited for, then every workgroup
-//       sums the slabs over ITS OWN tile's pixels (the combine pass, restricted to what it owns; same order of additions: the image
-//       has the bits of the four-launch pipeline) and stores its tile of the IWE
-//   S2  (sum, sum of squares) of its tile + last iteration's regulariser partial as tagged 8-byte granules: the one all-to-all
-//       of the iteration (mean of the IWE, loss bookkeeping); then the upstream window (tile + halo) is staged from the neighbours'
-//       image tiles
+// and exchanges per iteration, through global memory, in two hand-offs
+//   S1  its LDS image as a slab (write-through) + a record {epoch, its share of sum(IWE), its window}: the ALL-TO-ALL of the
+//       iteration.  The share is summed from the tile's own LDS image in the decode pass -- exact in a double, so the mean is the
+//       four-launch pipeline's bit for bit (kCombineExactSum) -- and is known before any halo has travelled: behind the wait every
+//       workgroup gathers its upstream window (tile + halo: own part from LDS, the neighbours' from their slabs, in the combine
+//       pass's order of additions), maps it to d loss / d IWE and stages it in ONE pass
 //   S3  its <= 16 x 16 partial cell gradients -> flag3: the tiles whose partials its cells sum are waited for (<= 5 x 5), then Adam.
+// The sum of squares of the image (the loss VALUE only) travels in a second record that workgroup 0 alone reads, one iteration
+// later, in the shadow of its S3 wait.
 // Hand-off form (cdna guide, Guideline 16 / MI355X_MICROARCH visibility table, first row): every handed-off byte is an sc1
 // (write-through) store, every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier behind which ONE lane
 // stores the flag (sc1); consumers poll with sc1 loads and read the payload with sc1 loads only -- no fences, no atomics.

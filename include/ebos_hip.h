@@ -702,7 +702,8 @@ typedef struct ebos_cmax_patch_problem {
   int steps_done;              /* Adam steps already applied to theta (the first iteration of a solve is step steps_done + 1) */
   float *dense, *d_dense, *d_reg, *iwe, *variance;
   float* d_iwe;                /* [H + 2 pad_h, W + 2 pad_w]; nullable unless w_gradient_magnitude != 0 */
-  void* cost_scratch;          /* ebos_cost_scratch_bytes(1); nullable unless w_gradient_magnitude != 0 */
+  void* cost_scratch;          /* >= 8 * ebos_gradient_magnitude_fused_partials(H + 2 pad_h, W + 2 pad_w) bytes (the fused Sobel
+                                  pass's value partials); nullable unless w_gradient_magnitude != 0 */
   size_t cost_scratch_bytes;
   double* moments;
   const float* upstream;
