@@ -195,6 +195,11 @@ class EventImageConverter(object):
 
     def create_iwe(self, events: NUMPY_TORCH, method: str = "bilinear_vote", sigma: int = 1) -> NUMPY_TORCH:
         """Image of warped events [(b,) H, W].  :51-73"""
+        if type(events) is fusion.LazyWarped and method == "bilinear_vote" and sigma == 0:
+            # the idiom's second step on warped events nobody has read: the deferred image, straight away
+            img = fusion.lazy_iwe_of(events, self.image_size, self.outer_padding)
+            if img is not None:
+                return img
         if is_numpy(events):
             return self.create_image_from_events_numpy(events, method, sigma=sigma)
         if is_torch(events):

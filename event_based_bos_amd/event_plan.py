@@ -506,7 +506,7 @@ class EventPlan:
 
     def contrast_dense(self, flow: torch.Tensor, cost: str = "image_variance", omit_boundary: bool = False,
                        pad: Tuple[int, int] = (0, 0), halo: Optional[int] = DEFAULT_HALO,
-                       splits: Optional[int] = None, sign: float = 1.0) -> torch.Tensor:
+                       splits: Optional[int] = None, sign: float = 1.0, _eager_checked: bool = False) -> torch.Tensor:
         """Contrast of the IWE under ``flow`` (0-d tensor, raw contrast: callers apply the sign -- or pass ``sign=-1.0``, the
         ``direction="minimize"`` of the cost plugins, and get ``sign * contrast`` with its gradient straight from the kernels).
         Same value and gradient as ``cost(iwe_dense(flow))``, but the variance gradient is folded
@@ -521,7 +521,7 @@ class EventPlan:
             raise KeyError(f"unknown contrast cost {cost!r}")
         if cost == "image_variance" or _slab_ok(self, halo):
             pad2, splits = (int(pad[0]), int(pad[1])), self.resolve_splits(splits)
-            if _eager_ok(self, flow, halo):
+            if _eager_checked or _eager_ok(self, flow, halo):
                 # value and gradient by the one native call, handed back as a tensor whose ``.backward()`` -- when it is called on
                 # the result itself, the objective idiom -- stores the gradient without entering the autograd engine (the engine's
                 # thread hand-off around a Python backward costs more than both event kernels); any other use of the result

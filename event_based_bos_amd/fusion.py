@@ -92,10 +92,19 @@ class _Deferred(torch.Tensor):
     ``torch`` function and tensor method except the metadata queries goes through ``__torch_function__`` and runs on the computed
     tensor (autograd history included)."""
 
+    _SHELLS: dict = {}
+
     @staticmethod
     def _shell(cls, shape, dtype, device):
-        # (a stride-0 view of one element carries shape, dtype and device; nothing reads its 4 bytes)
-        return torch.Tensor._make_subclass(cls, torch.empty(1, dtype=dtype, device=device).expand(shape))
+        # (a stride-0 view of one element carries shape, dtype and device; nothing reads its 4 bytes -- so every shell of one
+        # (shape, dtype, device) can alias ONE such view: a solver loop makes two shells per iteration)
+        key = (tuple(shape), dtype, device)
+        base = _Deferred._SHELLS.get(key)
+        if base is None:
+            if len(_Deferred._SHELLS) > 64:
+                _Deferred._SHELLS.clear()
+            base = _Deferred._SHELLS[key] = torch.empty(1, dtype=dtype, device=device).expand(shape)
+        return torch.Tensor._make_subclass(cls, base)
 
     def _real(self) -> torch.Tensor:
         st = self._ebos_lazy
@@ -254,6 +263,25 @@ def plan_for(prov: Provenance) -> EventPlan:
     return plan
 
 
+def lazy_iwe_of(warped, padded_image_size, pad) -> Optional[torch.Tensor]:
+    """``create_iwe`` on the unread ``LazyWarped`` of the idiom, unit weight, no blur: the deferred image, with nothing of the generic
+    path's container handling in front of it (the loop is bound by host time: DESIGN 4.3 #42).  None: take the generic path."""
+    st = warped._ebos_lazy
+    if st[1] is not None:
+        return None
+    prov = warped._ebos_provenance
+    if prov.events._version != prov.events_version or prov.flow._version != prov.flow_version:
+        return None
+    H, W = prov.image_size
+    ph, pw = int(pad[0]), int(pad[1])
+    if tuple(padded_image_size) != (H + 2 * ph, W + 2 * pw) or H + 2 * ph == 1 or W + 2 * pw == 1:
+        return None  # (the converter squeezes its result: an image with a unit dimension takes the generic path)
+    plan = plan_for(prov)
+    if plan.n_dropped:
+        return None
+    return LazyIwe.make(plan, prov, (ph, pw), (H + 2 * ph, W + 2 * pw))
+
+
 def fused_iwe(warped: torch.Tensor, padded_image_size, pad) -> Optional[torch.Tensor]:
     """IWE of provenance-tagged warped events through the fused kernels, or None if not applicable."""
     prov = provenance_of(warped)
@@ -319,7 +347,7 @@ def fused_variance(iwe: torch.Tensor, omit_boundary: bool, cost: str = "image_va
         if not _eager_ok(plan, prov.flow, _norm_halo(plan, DEFAULT_HALO)):
             return None
         stats["fused_costs"] = stats.get("fused_costs", 0) + 1
-        return plan.contrast_dense(prov.flow, cost, bool(omit_boundary), pad=pad, sign=sign)
+        return plan.contrast_dense(prov.flow, cost, bool(omit_boundary), pad=pad, sign=sign, _eager_checked=True)
     tag_ = getattr(iwe, "_ebos_iwe", None)
     if tag_ is None or iwe.dim() != 2 or iwe._version != tag_.iwe_version or tag_.flow._version != tag_.flow_version:
         return None
