@@ -526,9 +526,14 @@ class EventPlan:
                 # the result itself, the objective idiom -- stores the gradient without entering the autograd engine (the engine's
                 # thread hand-off around a Python backward costs more than both event kernels); any other use of the result
                 # attaches the ordinary autograd node first (_EagerLoss)
+                # A RAW contrast (sign = 1) is about to be negated by its caller -- contrast is maximised by minimising its negative:
+                # the kernels produce -d contrast / d flow, and ``(-loss).backward()`` finds its factor already applied; negating the
+                # 7.4 MB gradient afterwards is a launch of its own (55 -> 50 us per forward + backward at 10 M events).  A caller
+                # that does differentiate the raw contrast pays that launch instead (_EagerLoss applies what is left to apply).
                 sign = float(sign)
-                out, d_flow = _run_dense_job(_dense_job(self, pad2, halo, splits, bool(omit_boundary)), flow, True, cost, sign)
-                return _EagerLoss.wrap(out[1] if sign != 1.0 else out[0], flow, d_flow, sign, applied=sign)
+                spec = -1.0 if sign == 1.0 else sign
+                out, d_flow = _run_dense_job(_dense_job(self, pad2, halo, splits, bool(omit_boundary)), flow, True, cost, spec)
+                return _EagerLoss.wrap(out[1] if sign != 1.0 else out[0], flow, d_flow, sign, applied=spec)
             v = _FusedVarianceDense.apply(flow, self, pad2, bool(omit_boundary), halo, splits, cost)
             return v if sign == 1.0 else v * sign
         v = ops.gradient_magnitude(self.iwe_dense(flow, pad=pad, halo=halo, splits=splits), omit_boundary)
