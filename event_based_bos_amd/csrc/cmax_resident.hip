@@ -913,21 +913,46 @@ inline MailboxLayout mailbox_layout(int n_tiles) {
   return m;
 }
 
-// resident launches of different streams must not interleave their workgroups (two half-resident grids would wait for each other
-// until their caps): each one waits for the previous one's end on its device
-inline int order_resident_launches(hipStream_t s, bool after_launch) {
-  constexpr int kMaxDevices = 64;
-  static hipEvent_t last[kMaxDevices] = {};
+// Resident launches of different streams may only run side by side while ALL their workgroups fit the device at once (two
+// half-resident grids would wait for each other until their caps): per device, the launches in flight and their grid sizes are kept;
+// a new launch first waits for the oldest ones until it fits beside the rest.  (Small sensors -- 99 tiles at 346 x 260 -- thus run
+// two windows at a time; 256 tiles at 1280 x 720 one after the other.)
+struct ResidentInFlight {
+  hipEvent_t done;
+  int workgroups;
+};
+inline int order_resident_launches(hipStream_t s, int workgroups, int n_cu, bool after_launch) {
+  constexpr int kMaxDevices = 64, kMaxInFlight = 8;
+  static ResidentInFlight fl[kMaxDevices][kMaxInFlight] = {};
+  static int n_fl[kMaxDevices] = {};
   static std::atomic_flag lock = ATOMIC_FLAG_INIT;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return EBOS_ERR_LAUNCH;
   while (lock.test_and_set(std::memory_order_acquire)) {}
   int rc = EBOS_OK;
+  ResidentInFlight* f = fl[dev];
+  int& n = n_fl[dev];
+  auto drop_oldest = [&]() {
+    const hipEvent_t ev = f[0].done;   // (the event object is reused by the entry that takes the freed slot)
+    for (int k = 1; k < n; ++k) f[k - 1] = f[k];
+    --n;
+    f[n].done = ev;
+  };
   if (!after_launch) {
-    if (last[dev] != nullptr && hipStreamWaitEvent(s, last[dev], 0) != hipSuccess) rc = EBOS_ERR_LAUNCH;
+    while (n > 0 && hipEventQuery(f[0].done) == hipSuccess) drop_oldest();   // finished launches, oldest first
+    (void)hipGetLastError();                                                  // (hipErrorNotReady is not an error here)
+    int busy = 0;
+    for (int k = 0; k < n; ++k) busy += f[k].workgroups;
+    while (n > 0 && (busy + workgroups > n_cu || n == kMaxInFlight)) {
+      if (hipStreamWaitEvent(s, f[0].done, 0) != hipSuccess) rc = EBOS_ERR_LAUNCH;
+      busy -= f[0].workgroups;
+      drop_oldest();
+    }
   } else {
-    if (last[dev] == nullptr && hipEventCreateWithFlags(&last[dev], hipEventDisableTiming) != hipSuccess) last[dev] = nullptr;
-    if (last[dev] == nullptr || hipEventRecord(last[dev], s) != hipSuccess) rc = EBOS_ERR_LAUNCH;
+    if (n == kMaxInFlight) drop_oldest();  // (another thread's launches filled the table meanwhile)
+    if (f[n].done == nullptr && hipEventCreateWithFlags(&f[n].done, hipEventDisableTiming) != hipSuccess) f[n].done = nullptr;
+    if (f[n].done == nullptr || hipEventRecord(f[n].done, s) != hipSuccess) rc = EBOS_ERR_LAUNCH;
+    else f[n].workgroups = workgroups, ++n;
   }
   lock.clear(std::memory_order_release);
   return rc;
@@ -950,7 +975,7 @@ int launch_resident(const ResidentArgs& a, void* mailbox, size_t mailbox_total, 
       set_error("ebos_cmax_patch_solve_resident: %d workgroups cannot be co-resident (%d CUs x %d)", n_tiles, n_cu, per_cu);
       return EBOS_ERR_UNSUPPORTED;
     }
-    if (int rc = order_resident_launches(s, false)) return rc;
+    if (int rc = order_resident_launches(s, n_tiles, n_cu * per_cu, false)) return rc;
     // (cells no tile's block holds keep a zero gradient, as the four-launch pipeline reports them)
     if (hipMemsetAsync(a.d_theta, 0, (size_t)2 * a.gs.ay.g * a.gs.ax.g * sizeof(float), s) != hipSuccess ||
         hipMemsetAsync(mailbox, 0, mailbox_total, s) != hipSuccess) {
@@ -958,7 +983,7 @@ int launch_resident(const ResidentArgs& a, void* mailbox, size_t mailbox_total, 
       return EBOS_ERR_LAUNCH;
     }
     k<<<dim3((unsigned)n_tiles), dim3(kBlock), lds, s>>>(a);
-    return order_resident_launches(s, true);
+    return order_resident_launches(s, n_tiles, n_cu * per_cu, true);
   } else {
     set_error("ebos_cmax_patch_solve_resident: no resident kernel for tile %dx%d halo %d", TH, TW, HALO);
     return EBOS_ERR_UNSUPPORTED;
@@ -987,7 +1012,8 @@ bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
               halo, q->slide_h, q->slide_w);
     return false;
   }
-  const bool built = (q->tile_h == 45 && q->tile_w == 80 && halo == 32) || (q->tile_h == 32 && q->tile_w == 32 && halo == 32);
+  const bool built = halo == 32 && ((q->tile_h == 45 && q->tile_w == 80) || (q->tile_h == 32 && q->tile_w == 32) ||
+                                    (q->tile_h == 32 && q->tile_w == 64));
   if (!built) {
     set_error("resident solve: no resident kernel built for tile %dx%d halo %d", q->tile_h, q->tile_w, halo);
     return false;
@@ -1126,6 +1152,7 @@ int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* q, int n_i
   int rc = EBOS_ERR_UNSUPPORTED;
   if (q->tile_h == 45 && q->tile_w == 80 && ha.halo == 32) rc = launch_resident<45, 80, 32>(a, mailbox, m.total, s);
   else if (q->tile_h == 32 && q->tile_w == 32 && ha.halo == 32) rc = launch_resident<32, 32, 32>(a, mailbox, m.total, s);
+  else if (q->tile_h == 32 && q->tile_w == 64 && ha.halo == 32) rc = launch_resident<32, 64, 32>(a, mailbox, m.total, s);  // (720 x 640: hot_plate1's ROI)
   if (rc != EBOS_OK) return rc;
   EBOS_CHECK_LAUNCH("ebos_cmax_patch_solve_resident");
   return EBOS_OK;

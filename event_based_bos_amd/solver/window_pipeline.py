@@ -56,6 +56,14 @@ class WindowPipeline(object):
             # high priority: the few short ingest kernels must not queue behind thousands of solver launches (the plan
             # build ends in a host read-back, and the host is what enqueues the next group)
             self.ingest_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            # Resident launches run side by side only while all their workgroups fit the device at once (cmax_resident.hip): a small
+            # sensor's window (99 tiles at 346 x 260) leaves room for a second one, and a group of three would run 2 + 1 -- the group
+            # size is rounded up to a multiple of the windows that fit
+            if self.resident:
+                th, tw = solver.plan_tile()
+                H, W = solver.orig_image_shape
+                fit = max(1, int(torch.cuda.get_device_properties(self.device).multi_processor_count) // (-(-H // th) * -(-W // tw)))
+                self.n_concurrent = -(-self.n_concurrent // fit) * fit
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_concurrent)]
 
     # ------------------------------------------------------------------ stages

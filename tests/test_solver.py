@@ -506,6 +506,7 @@ def test_solver_halo_option_selects_the_small_window_configuration():
     ((96, 128), 20_000, (24, 32), (1.0, 0.01, 0.02)),      # 12 tiles of 32 x 32: the small end (image_gradient on: the apron's cells)
     ((260, 346), 100_000, (20, 20), (1.0, 0.001, 0.0)),    # BASELINE configs[0]'s size: 99 tiles, W % 4 != 0 (scalar image stores)
     ((720, 1280), 400_000, (24, 32), (1.0, 0.001, 0.0)),   # 256 tiles of 45 x 80: one workgroup per CU
+    ((720, 640), 300_000, (24, 32), (1.0, 0.001, 0.01)),   # the ROI of configs/hot_plate1.yaml (columns 320:960): 230 tiles of 32 x 64
 ])
 def test_resident_loop_matches_the_four_launch_pipeline(size, n_ev, patch, terms):
     """The loop of src/solver/generative_max_likelihood.py:306-341 as ONE resident launch (ebos_cmax_patch_solve_resident_f32)

@@ -22,6 +22,7 @@ H, W = 720, 1280
 
 
 def main():
+    global H, W
     ap = argparse.ArgumentParser()
     ap.add_argument("--windows", type=int, default=8)
     ap.add_argument("--events", type=int, default=2_000_000)
@@ -29,8 +30,10 @@ def main():
     ap.add_argument("--nc", type=int, nargs="+", default=[1, 2, 3, 4], help="windows in flight to try")
     ap.add_argument("--halo", default="auto", help="solver halo: auto (run-time windows, the solver's default) or a built halo (32, 16)")
     ap.add_argument("--repeat", type=int, default=1, help="timed runs per setting (the minimum is reported)")
+    ap.add_argument("--size", type=int, nargs=2, default=[720, 1280], help="image size (e.g. 720 640: hot_plate1's ROI, 128 tiles)")
     a = ap.parse_args()
     a.halo = a.halo if a.halo == "auto" else int(a.halo)
+    H, W = a.size
     n = a.windows * a.events
     rs = np.random.RandomState(0)
     store = ebos.data_loader.RawEventStore({"x": rs.randint(0, W, n).astype(np.int16), "y": rs.randint(0, H, n).astype(np.int16),
@@ -41,7 +44,7 @@ def main():
            "patch": {"size": [24, 32], "sliding_window": [24, 32]}, "halo": a.halo,
            "optimizer": {"method": "Adam", "n_iter": a.iters, "parameters": {"lr": 0.1}}}
     solver = ebos.solver.collections["contrast_maximization"]((H, W), (H, W), solver_config=cfg)
-    res = {"windows": a.windows, "events_per_window": a.events, "iterations": a.iters, "halo": a.halo}
+    res = {"windows": a.windows, "events_per_window": a.events, "iterations": a.iters, "halo": a.halo, "size": [H, W]}
     host_windows = [store.load_event(*wnd) for wnd in windows[:2]]
     solver.estimate(host_windows[0])  # warm the process
     torch.cuda.synchronize()
