@@ -158,6 +158,14 @@ def test_fused_loop_run_modes_agree():
     np.testing.assert_allclose(hist["python"], hist["native"], rtol=1e-5)
     np.testing.assert_allclose(hist["split"], hist["native"], rtol=1e-5)
     np.testing.assert_array_equal(hist["resident"], hist["native"])   # the resident launch follows the pipeline bit for bit
+    # EBOS_RESIDENT=0 turns the default off (resident=True still asks for it explicitly)
+    os.environ["EBOS_RESIDENT"] = "0"
+    try:
+        off = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, 4, 4)), 1.0, 0.01, 0.02, halo="auto", lr=0.1, capacity=30)
+        np.testing.assert_array_equal(off.run(30).cpu().numpy(), hist["native"])
+        assert off.last_run_mode == "pipeline"
+    finally:
+        del os.environ["EBOS_RESIDENT"]
     with pytest.raises(ValueError):
         loop.run(1)
 
