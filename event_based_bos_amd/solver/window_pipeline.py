@@ -108,10 +108,10 @@ class WindowPipeline(object):
                         s.halo, s.lr, capacity=n_iter, w_gradient_magnitude=s.contrast_terms.get("gradient_magnitude", 0.0),
                         theta_mask=mask))
             if resident and all(lp.resident_supported() for lp in loops):
-                # every window's loop as ONE resident launch (31 us per iteration at 2 M events against 43 as four launches, and
-                # a resident launch owns every CU: the windows of the group run one after the other -- cmax_resident.hip orders
-                # resident launches of different streams itself -- while the ingest stream's short kernels slip in between).
-                # Nothing waits here: the status words are looked at when the results are collected (``run``)
+                # every window's loop as ONE resident launch (30 us per iteration at 2 M events against 43 as four launches).  A
+                # resident workgroup owns its CU: launches of different streams run side by side only while all their workgroups fit
+                # the device together -- cmax_resident.hip orders them itself -- and the ingest stream's short kernels slip in
+                # between.  Nothing waits here: the status words are looked at when the results are collected (``run``)
                 for w, lp in enumerate(loops):
                     with torch.cuda.stream(streams[w]):
                         statuses[w].append(lp.enqueue_resident(n_iter))
@@ -164,7 +164,10 @@ class WindowPipeline(object):
                 st.synchronize()
             # a resident launch that ended early (a displacement beyond the largest LDS window, a wait past its cap) left its
             # window's patch flow where it was: such a window is solved again, as four launches per iteration
-            self.resident_fallbacks = [k for k, r in enumerate(pending) if any(int(sw.item()) != 0 for sw in r["status"])]
+            words = [sw for r in pending for sw in r["status"]]
+            owner = [k for k, r in enumerate(pending) for _ in r["status"]]
+            bad = torch.cat(words).cpu().numpy() != 0 if words else np.zeros(0, dtype=bool)   # (one read-back for all launches)
+            self.resident_fallbacks = sorted({owner[i] for i in np.flatnonzero(bad)})
             for k in self.resident_fallbacks:
                 with torch.cuda.stream(streams[0]):
                     plan = self._ingest(store, pending[k]["window"])
