@@ -20,7 +20,8 @@
 //       four-launch pipeline's bit for bit (kCombineExactSum) -- and is known before any halo has travelled: behind the wait every
 //       workgroup gathers its upstream window (tile + halo: own part from LDS, the neighbours' from their slabs, in the combine
 //       pass's order of additions), maps it to d loss / d IWE and stages it in ONE pass
-//   S3  its <= 16 x 16 partial cell gradients -> flag3: the tiles whose partials its cells sum are waited for (<= 5 x 5), then Adam.
+//   S3  its <= 16 x 16 partial cell gradients as tagged granules {epoch, value}: every thread that steps a cell element polls the
+//       <= 4 x 4 values its cell sums (the data is its own flag: no flag store behind a drain, no second round trip), then Adam.
 // The sum of squares of the image (the loss VALUE only) travels in a second record that workgroup 0 alone reads, one iteration
 // later, in the shadow of its S3 wait.
 // Hand-off form (cdna guide, Guideline 16 / MI355X_MICROARCH visibility table, first row): every handed-off byte is an sc1
@@ -126,7 +127,7 @@ struct ResidentArgs {
   int* step;
   float *iwe, *slabs, *cell_partials;
   unsigned* status;
-  unsigned long long *rec1, *flag3, *flagi, *rec2, *done;    // mailbox sections (zeroed before every launch)
+  unsigned long long *rec1, *part3, *flagi, *rec2, *done;    // mailbox sections (zeroed before every launch)
   float* losses;
   int losses_cap, t0, n_iter;
   double lr, beta1, beta2, eps;
@@ -567,7 +568,9 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         pre_raw.A = load_craw(trp.g_first + wave * kWave + lane, trp, evp);
         pre_raw.B = load_craw(trp.g_first + (wave + kWaves) * kWave + lane, trp, evp);
       };
-      if (halo_complete) {
+      if (EBOS_ABL & 8192) {
+        independent_work();   // (timing build: no gather, no affine map, nothing staged)
+      } else if (halo_complete) {
         // No window is as large as half a tile: a pixel lies in the windows of at most 2 x 2 tiles -- the pair of tile rows
         // (ty - 1, ty) or (ty, ty + 1) by the half of the tile its row is in (or beyond), likewise for columns -- and this tile is one
         // of the four.  So a quad has at most THREE slab loads, all of a thread's are in flight before the first is used (as nine
@@ -787,71 +790,76 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       const float s_norm = a.s_norm, s_tv = a.s_tv;
       const bool any_reg = s_norm != 0.0f || s_tv != 0.0f;
       if (!(EBOS_ABL & 4096))
+      // (the partial cell gradients leave as tagged granules {epoch, value}: no flag, no drain -- S3 polls the values themselves)
       grid_tile_epilogue<TH, TW, HALO, true>(tr, ty * TH, tx * TW, H, W, s_d, s_g, s_flow_b, s_lerp, grad, nullptr, s_norm, s_tv,
-                                             any_reg ? &s_reg[0] : nullptr, a.cell_partials + (int64_t)tile * (2 * kGridCells * kGridCells));
+                                             any_reg ? &s_reg[0] : nullptr,
+                                             reinterpret_cast<float*>(a.part3 + (size_t)tile * (2 * kGridCells * kGridCells)), ep);
       EBOS_RSTAMP(11);
-      drain_stores();
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        st_sc1(a.flag3 + tile, (unsigned long long)ep);
-        s_reg[1] = any_reg ? s_reg[0] : 0.0;
-      }
+      __syncthreads();  // (the epilogue's LDS buffers are dead: the image may be cleared over them)
+      if (threadIdx.x == 0) s_reg[1] = any_reg ? s_reg[0] : 0.0;
     }
     EBOS_RSTAMP(12);
-    // ---- S3: the partials of the tiles this block's cells sum; meanwhile the other waves clear the LDS image for the next pass ---
+    // ---- S3 + A: every thread that steps a cell element polls the <= kSpan x kSpan partial values its cell sums -- tagged granules,
+    // the data is its own flag -- and applies Adam; meanwhile the other waves clear the LDS image for the next pass (and workgroup 0
+    // keeps the books of the loss) -------------------------------------------------------------------------------------------------
     {
       KArgs& a = fresh_args();
-      if (wave == 0) {
-        const int rect_nx = max(rfl(P.rect_nx), 1), n_rect = rfl(P.rect_ny) * rfl(P.rect_nx);
-        const int ry = lane / rect_nx, rx = lane - ry * rect_nx;
-        const bool act = lane < n_rect;
-        const unsigned long long* f = a.flag3 + (rfl(P.rect_ty0) + (act ? ry : 0)) * a.tiles_x + rfl(P.rect_tx0) + (act ? rx : 0);
-        const bool ok = wave_wait([&]() { return !act || ld_sc1(f) >= (unsigned long long)ep || (EBOS_ABL & 512) != 0; }, a.status, a.cap_ticks);
+      const int n_el = 2 * rfl(P.ni) * rfl(P.nj);
+      if (wave * kWave < n_el) {
+        const int tiles_x = a.tiles_x, tiles_y = a.tiles_y;
+        const int ninj = rfl(P.ni) * rfl(P.nj), nj = rfl(P.nj);
+        const bool has = (int)threadIdx.x < n_el;
+        const int e_ = has ? (int)threadIdx.x : 0;
+        const unsigned cand_a = s_cand_a[e_ % kResElems], cand_b = s_cand_b[e_ % kResElems];
+        float m_e = s_m[e_ % kResElems], v_e = s_v[e_ % kResElems];
+        const int ch = e_ / ninj, rem = e_ - ch * ninj, ci = rem / nj, cj = rem - ci * nj;
+        const unsigned long long* cp = a.part3;
+        const int cty0 = (int)(cand_a & 255u), ctx0 = (int)((cand_a >> 8) & 255u);
+        float mask = 1.0f;
+        if (a.theta_mask != nullptr) mask = a.theta_mask[(int64_t)(rfl(P.gi0) + ci) * a.gs.ax.g + rfl(P.gj0) + cj];
+        float pv[kSpan][kSpan];
+        const bool ok = wave_wait([&]() {
+          bool all = true;
+#pragma unroll
+          for (int p = 0; p < kSpan; ++p)
+#pragma unroll
+            for (int q = 0; q < kSpan; ++q) {
+              const int cty = min(cty0 + p, tiles_y - 1), ctx = min(ctx0 + q, tiles_x - 1);
+              const int li = (int)((cand_b >> (4 * p)) & 15u), lj = (int)((cand_b >> (16 + 4 * q)) & 15u);
+              const bool use = has && ((cand_a >> (16 + p)) & 1u) && ((cand_a >> (20 + q)) & 1u);
+              unsigned long long g = (unsigned long long)ep << 32;
+              if (!(EBOS_ABL & 1024) && __builtin_amdgcn_ballot_w64(use) != 0ull)
+                g = ld_sc1(cp + (((int64_t)(cty * tiles_x + ctx) * 2 + ch) * kGridCells + li) * kGridCells + lj);
+              pv[p][q] = __uint_as_float((unsigned)g);
+              all = all && (!use || (unsigned)(g >> 32) == ep || (EBOS_ABL & 512) != 0);
+            }
+          return all;
+        }, a.status, a.cap_ticks);
         if (lane == 0 && !ok) s_ok = 0;
+        if (has) {
+          float g = 0.0f;
+#pragma unroll
+          for (int p = 0; p < kSpan; ++p)
+#pragma unroll
+            for (int q = 0; q < kSpan; ++q) g += (((cand_a >> (16 + p)) & 1u) && ((cand_a >> (20 + q)) & 1u)) ? pv[p][q] : 0.0f;
+          if (a.theta_mask != nullptr) g *= mask;
+          float th = s_cells[(ch * kGridCells + ci) * kGridCells + cj];
+          adam_update(g, m_e, v_e, th, s_adam[0], s_adam[1], (float)a.beta2, (float)(1.0 - a.beta1), (float)(1.0 - a.beta2), (float)a.eps);
+          s_cells[(ch * kGridCells + ci) * kGridCells + cj] = th;
+          s_m[e_ % kResElems] = m_e, s_v[e_ % kResElems] = v_e, s_gl[e_ % kResElems] = g;
+        }
       } else {
         // (workgroup 0, one wave: the loss of iteration it - 2 and the variance of it - 1 -- every workgroup has passed S1 of THIS
         // iteration, so the records of the previous one are complete)
-        if (blockIdx.x == 0 && wave == 1 && it >= 1) book_loss(a, it - 1, lane, s_hist, s_adam);
-        for (int i = threadIdx.x - kWave; i < kCells / 2; i += kBlock - kWave) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
+        if (blockIdx.x == 0 && wave == kWaves - 1 && it >= 1) book_loss(a, it - 1, lane, s_hist, s_adam);
+        const int first = ((n_el + kWave - 1) / kWave) * kWave;   // (threads of the waves above clear: a multiple of the wave size)
+        for (int i = threadIdx.x - first; i < kCells / 2; i += kBlock - first) reinterpret_cast<double2*>(s_acc)[i] = make_double2(0.0, 0.0);
       }
-      __syncthreads();
     }
-    if (!s_ok) { done_ok = false; break; }
     EBOS_RSTAMP(13);
-    // ---- A: d loss / d theta of this thread's cell element = sum of the partials of the tiles that hold it; Adam ------------------
-    if ((int)threadIdx.x < 2 * rfl(P.ni) * rfl(P.nj)) {
-      KArgs& a = fresh_args();
-      const int tiles_x = a.tiles_x, tiles_y = a.tiles_y;
-      const int ninj = rfl(P.ni) * rfl(P.nj), nj = rfl(P.nj);
-      const unsigned cand_a = s_cand_a[threadIdx.x % kResElems], cand_b = s_cand_b[threadIdx.x % kResElems];
-      float m_e = s_m[threadIdx.x % kResElems], v_e = s_v[threadIdx.x % kResElems];
-      const int ch = (int)threadIdx.x / ninj, rem = (int)threadIdx.x - ch * ninj, ci = rem / nj, cj = rem - ci * nj;
-      const float* cp = a.cell_partials;
-      const int cty0 = (int)(cand_a & 255u), ctx0 = (int)((cand_a >> 8) & 255u);
-      float mask = 1.0f;
-      if (a.theta_mask != nullptr) mask = a.theta_mask[(int64_t)(rfl(P.gi0) + ci) * a.gs.ax.g + rfl(P.gj0) + cj];
-      float pv[kSpan][kSpan];
-#pragma unroll
-      for (int p = 0; p < kSpan; ++p)
-#pragma unroll
-        for (int q = 0; q < kSpan; ++q) {
-          const int cty = min(cty0 + p, tiles_y - 1), ctx = min(ctx0 + q, tiles_x - 1);
-          const int li = (int)((cand_b >> (4 * p)) & 15u), lj = (int)((cand_b >> (16 + 4 * q)) & 15u);
-          pv[p][q] = (EBOS_ABL & 1024) ? 0.0f : ld_sc1(cp + (((int64_t)(cty * tiles_x + ctx) * 2 + ch) * kGridCells + li) * kGridCells + lj);
-        }
-      float g = 0.0f;
-#pragma unroll
-      for (int p = 0; p < kSpan; ++p)
-#pragma unroll
-        for (int q = 0; q < kSpan; ++q) g += (((cand_a >> (16 + p)) & 1u) && ((cand_a >> (20 + q)) & 1u)) ? pv[p][q] : 0.0f;
-      if (a.theta_mask != nullptr) g *= mask;
-      float th = s_cells[(ch * kGridCells + ci) * kGridCells + cj];
-      adam_update(g, m_e, v_e, th, s_adam[0], s_adam[1], (float)a.beta2, (float)(1.0 - a.beta1), (float)(1.0 - a.beta2), (float)a.eps);
-      s_cells[(ch * kGridCells + ci) * kGridCells + cj] = th;
-      s_m[threadIdx.x % kResElems] = m_e, s_v[threadIdx.x % kResElems] = v_e, s_gl[threadIdx.x % kResElems] = g;
-    }
     EBOS_RSTAMP(14);
     __syncthreads();  // the new theta block is in LDS
+    if (!s_ok) { done_ok = false; break; }
   }
   if (!done_ok) return;  // (uniform) nothing of the optimiser state was written: the host falls back from unchanged state
 
@@ -899,14 +907,14 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
 }
 
 struct MailboxLayout {
-  size_t off_status, off_rec1, off_flag3, off_flagi, off_rec2, off_done, total;
+  size_t off_status, off_rec1, off_part3, off_flagi, off_rec2, off_done, total;
 };
 inline MailboxLayout mailbox_layout(int n_tiles) {
   MailboxLayout m;
   m.off_status = 0;
   m.off_rec1 = 256;
-  m.off_flag3 = m.off_rec1 + (((size_t)2 * n_tiles * kRec1Granules * 8 + 255) & ~(size_t)255);
-  m.off_flagi = m.off_flag3 + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
+  m.off_part3 = m.off_rec1 + (((size_t)2 * n_tiles * kRec1Granules * 8 + 255) & ~(size_t)255);
+  m.off_flagi = m.off_part3 + (size_t)n_tiles * (2 * kGridCells * kGridCells) * 8;   // a tile's partial cell gradients as granules
   m.off_rec2 = m.off_flagi + (((size_t)n_tiles * 8 + 255) & ~(size_t)255);
   m.off_done = m.off_rec2 + (size_t)2 * n_tiles * kRecGranules * 8;
   m.total = m.off_done + (((size_t)n_tiles * 16 + 255) & ~(size_t)255);
@@ -1132,7 +1140,7 @@ int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* q, int n_i
   a.cell_partials = q->grad_partials;
   a.status = reinterpret_cast<unsigned*>(mb + m.off_status);
   a.rec1 = reinterpret_cast<unsigned long long*>(mb + m.off_rec1);
-  a.flag3 = reinterpret_cast<unsigned long long*>(mb + m.off_flag3);
+  a.part3 = reinterpret_cast<unsigned long long*>(mb + m.off_part3);
   a.flagi = reinterpret_cast<unsigned long long*>(mb + m.off_flagi);
   a.rec2 = reinterpret_cast<unsigned long long*>(mb + m.off_rec2);
   a.done = reinterpret_cast<unsigned long long*>(mb + m.off_done);

@@ -1970,7 +1970,18 @@ template <int TH, int TW, int HALO, bool SC1>
 __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0, int tc0, int H, int W, double* s_d, float* s_g,
                                                    const float* s_flow, const Lerp* s_lerp, const TileGrad<TH, TW>& grad,
                                                    const float* __restrict__ addend, float s_norm, float s_tv, double* reg_out,
-                                                   float* out) {
+                                                   float* out, unsigned sc1_tag = 0u) {
+  // SC1 (resident solver kernel): `out` holds 8-byte granules {sc1_tag, value} -- the data is its own flag, consumers poll the
+  // granules themselves (no separate flag store behind a drain, no dependent round trip for the values)
+  auto put = [&](int idx, float v) {
+    if constexpr (SC1) {
+      typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+      __hip_atomic_store((gu64_t*)(reinterpret_cast<unsigned long long*>(out) + idx),
+                         ((unsigned long long)sc1_tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      out[idx] = v;
+    }
+  };
   constexpr int AP = kBwdApron, PH = TH + 2 * AP, PW = TW + 2 * AP;
   const int64_t hw = (int64_t)H * W;
   // adjoint of the grid -> dense map on this tile, separable like the stand-alone adjoint: rows first
@@ -2134,7 +2145,10 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
     *reg_out = val;  // (resident kernel: a word of its own LDS)
   }
 #if defined(EBOS_ABL) && (EBOS_ABL & 16)   // (timing build of the resident solver kernel: without the adjoint's sums)
-  if (threadIdx.x < 2 * ni * nj) store_scalar<SC1>(out + threadIdx.x, 0.0f);
+  for (int o = threadIdx.x; o < 2 * ni * nj; o += kBlock) {
+    const int ch = o / (ni * nj), rem = o - ch * (ni * nj);
+    put((ch * kGridCells + rem / nj) * kGridCells + rem % nj, 0.0f);
+  }
   return;
 #endif
   for (int idx = threadIdx.x; idx < 2 * ni * TW; idx += kBlock) {
@@ -2160,7 +2174,7 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
     float acc = 0.0f;
     for (int c = lane; c < TW; c += kWave) acc += wx[c] * S[c];
     acc = wave_sum(acc);
-    if (lane == 0) store_scalar<SC1>(out + (ch * kGridCells + i) * kGridCells + j, acc);
+    if (lane == 0) put((ch * kGridCells + i) * kGridCells + j, acc);
   }
   EBOS_STAMP_BWD(6);
 }

@@ -40,8 +40,8 @@ phases = [("F0 cells -> window bound, tile flow", 0, 1), ("F1 event loop + decod
           ("S1 own part of the gather; poll ALL records (the all-to-all)", 3, 4), ("   reduce -> mean", 4, 5),
           ("G  gather the upstream window + affine map -> LDS", 5, 6), ("   wave sums, clear, tile flow (apron), prefetch, barrier", 6, 7),
           ("   (publish path, if any) + fixed-point unit", 7, 9), ("B1 sweep", 9, 10),
-          ("B2 regulariser + tile adjoint (stores issued)", 10, 11), ("   drain + barrier + flag3", 11, 12),
-          ("S3 wait for the partials' tiles (+ LDS clear, loss bookkeeping)", 12, 13), ("A  cell gradients + Adam", 13, 14)]
+          ("B2 regulariser + tile adjoint (stores issued)", 10, 11), ("   barrier", 11, 12),
+          ("S3 + A: poll the partial values, Adam (+ LDS clear, loss bookkeeping)", 12, 13), ("   (end of the iteration)", 13, 14)]
 print(f"{H}x{W}, {a.events} events, tile {plan.tile}, {n} workgroups; last of {a.iters} iterations")
 tot = st[:, 14] - st[:, 0]
 for nm, i0, i1 in phases:
