@@ -123,6 +123,7 @@ class FusedPatchLoop(object):
         self._mailbox = None          # flags / records / status word of the resident launch (allocated on first use)
         self.resident_status = 0      # status of the last resident launch (0 = completed)
         self.last_run_mode = "pipeline"
+        self._resident_refused = False
         import ctypes as C
         off, n_parts, n_px = C.c_size_t(), C.c_int64(), C.c_int64()
         check(self.lib.ebos_iwe_slab_partials(H, W, plan.tile[0], plan.tile[1], self.halo, self.splits, self.pad[0], self.pad[1],
@@ -287,7 +288,8 @@ class FusedPatchLoop(object):
 
     def run_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> int:
         """``n_iter`` iterations as one resident launch; returns its status after synchronising: 0, or a negative code when the
-        launch ended early (-101 a wait passed the cap, -102 a tap left the largest LDS window, -103 geometry) -- theta and the
+        launch ended early (-101 a wait passed the cap, -102 a tap left the largest LDS window, -103 geometry, -104 one tile far more
+        crowded than the average one: the pipeline's work items split such tiles) -- theta and the
         optimiser state are then UNCHANGED and the caller runs the four-launch pipeline (``run`` does)."""
         t, mode = self.t, self.last_run_mode
         self.enqueue_resident(n_iter, spin_timeout_s)
@@ -307,13 +309,16 @@ class FusedPatchLoop(object):
             raise ValueError(f"capacity {self.losses.numel()} < {self.t} steps done + {n_iter}")
         t0 = self.t
         if resident is None:
-            resident = native and os.environ.get("EBOS_RESIDENT", "1") != "0" and self.resident_supported()
+            # (a launch that ended with -104 -- one tile far more crowded than the average: the pipeline splits such tiles -- is not
+            # tried again on this window)
+            resident = native and os.environ.get("EBOS_RESIDENT", "1") != "0" and not self._resident_refused and self.resident_supported()
         elif resident and not self.resident_supported():
             raise ValueError("resident=True: " + (self.lib.ebos_last_error() or b"").decode())
         self.last_run_mode = "pipeline"
         with _hip.on_device(self.plan.device):
             if resident and n_iter > 0:
                 self.resident_status = self.run_resident(n_iter)
+                self._resident_refused = self.resident_status == -104
                 if self.resident_status == 0:
                     self.t += n_iter
                     self.last_run_mode = "resident"

@@ -744,7 +744,9 @@ int ebos_cmax_patch_solve_many_f32(const ebos_cmax_patch_problem* problems, cons
  *                                  one), or a tap leaves the largest LDS window (the spill path of the four-launch pipeline),
  *                                  the launch ENDS instead of hanging and leaves theta / exp_avg / exp_avg_sq / step untouched.
  *   ebos_cmax_resident_status      synchronises `stream`, returns EBOS_OK or a negative code (-101 spin cap, -102 spill,
- *                                  -103 geometry); on a negative code run ebos_cmax_patch_solve_f32 with the same problem.  */
+ *                                  -103 geometry, -104 one tile holds more than 12 x the average tile's events -- the kernel's own
+ *                                  verdict in its first iteration; EBOS_RESIDENT_MAX_IMBALANCE overrides, 0 = never); on a negative
+ *                                  code run ebos_cmax_patch_solve_f32 with the same problem.  */
 size_t ebos_cmax_resident_mailbox_bytes(int H, int W, int tile_h, int tile_w);
 int ebos_cmax_resident_supported(const ebos_cmax_patch_problem* problem);
 int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* problem, int n_iter, void* mailbox, size_t mailbox_bytes,

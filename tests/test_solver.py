@@ -582,6 +582,44 @@ def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
 
 
 @pytest.mark.gpu
+def test_resident_loop_leaves_crowded_windows_to_the_pipeline():
+    """The resident kernel runs ONE workgroup per tile; the four-launch pipeline splits crowded tiles over several work items.  A
+    window whose fullest tile holds more than 12 x the average tile's events (and >= 32 k of them) ends the resident launch in its
+    first iteration (status -104, nothing changed) and the pipeline runs -- 184 against 95 us per iteration measured with 2 M events
+    in a Gaussian blob of sigma 100 px.  The verdict is the kernel's own (every workgroup sees every tile's count in the records of
+    the first all-to-all): it also covers plans built without a host read-back."""
+    import torch
+
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w, n = 720, 1280, 600_000
+    rs = np.random.RandomState(9)
+    r = np.clip(np.rint(rs.normal(h / 2, 20, n)), 0, h - 1)
+    c = np.clip(np.rint(rs.normal(w / 2, 36, n)), 0, w - 1)
+    ev = np.stack([r, c, np.sort(rs.uniform(0, 0.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    gh, gw = ebos.solver.patch_grid_shape((h, w), (24, 32), (24, 32))
+    ref = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.05, capacity=24)
+    res = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.05, capacity=24)
+    assert res.resident_supported()
+    l_ref = ref.run(8, resident=False).cpu().numpy()
+    l_res = res.run(8).cpu().numpy()
+    assert res.resident_status == -104 and res.last_run_mode == "pipeline"
+    np.testing.assert_array_equal(l_res, l_ref)
+    res.run(8)                                   # ... and the window is not tried again
+    assert res.last_run_mode == "pipeline" and res.t == 16
+    os.environ["EBOS_RESIDENT_MAX_IMBALANCE"] = "0"   # the caller's override: never refuse
+    try:
+        forced = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.05, capacity=24)
+        l_forced = forced.run(8).cpu().numpy()
+        assert forced.last_run_mode == "resident" and forced.resident_status == 0
+        np.testing.assert_allclose(l_forced, l_ref, rtol=1e-5)   # (adaptive work items sum a crowded tile's slabs in another order)
+    finally:
+        del os.environ["EBOS_RESIDENT_MAX_IMBALANCE"]
+
+
+@pytest.mark.gpu
 def test_resident_loop_spins_are_bounded():
     """Every wait of the resident kernel is capped.  Staged here: a one-wave kernel spinning on another stream keeps ONE compute
     unit from taking its workgroup of a 256-tile grid (a resident workgroup needs the whole register file of its CU), so the other

@@ -28,12 +28,19 @@ ap.add_argument("--mode", choices=["auto", "resident", "pipeline"], default="aut
 ap.add_argument("--size", type=int, nargs=2, default=None, help="image size (default 720 1280)")
 ap.add_argument("--flow-max", type=float, default=0.0, help="initial patch flows U(-m, m) (0: zeros)")
 ap.add_argument("--lr", type=float, default=0.1, help="Adam's learning rate (0: the flow stays where it starts -- timing builds)")
+ap.add_argument("--blob", type=float, default=0.0, help="events concentrated in a Gaussian blob of this sigma (columns, px) in the middle of the frame "
+                                                         "(a schlieren object in front of a static background) instead of uniform")
 a = ap.parse_args()
-if a.size:
+if a.size or a.blob > 0:
     import numpy as np
-    H, W = a.size
+    H, W = a.size or (H, W)
     rs = np.random.RandomState(3)
-    ev = np.stack([rs.randint(0, H, a.events), rs.randint(0, W, a.events), np.sort(rs.uniform(0, 0.5, a.events)), rs.randint(0, 2, a.events)], 1).astype(np.float64)
+    if a.blob > 0:
+        r = np.clip(np.rint(rs.normal(H / 2, a.blob * H / W, a.events)), 0, H - 1)
+        c = np.clip(np.rint(rs.normal(W / 2, a.blob, a.events)), 0, W - 1)
+    else:
+        r, c = rs.randint(0, H, a.events), rs.randint(0, W, a.events)
+    ev = np.stack([r, c, np.sort(rs.uniform(0, 0.5, a.events)), rs.randint(0, 2, a.events)], 1).astype(np.float64)
 else:
     ev, _ = synth_window(a.events, 0)
 plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=tuple(a.tile) if a.tile else ebos.event_plan.choose_tile((H, W), 32 if a.halo == "auto" else a.halo))
