@@ -151,11 +151,21 @@ class WindowPipeline(object):
                 return plans, ready
 
             nxt = ingest_group(groups[0]) if groups else None
+            resident = self.resident
             for g in range(len(groups)):
                 plans, ready = nxt
                 for st in streams[:len(plans)]:
                     st.wait_event(ready)
-                solved = self._solve_group(plans, streams)            # asynchronous: returns once enqueued
+                # A recording whose windows the resident kernel refuses (crowded tiles: status -104, or flows beyond its windows) would
+                # otherwise pay for every window twice -- once here and once, one by one, in the re-solve below: as soon as a launch
+                # of an earlier group is KNOWN to have ended early, the rest of the run takes the four launches
+                if resident and g == 1:
+                    # (once per run, one blocking read-back: the first group's verdicts decide for the recording -- the host is
+                    # otherwise so far ahead that no verdict would arrive in time)
+                    first = [sw for r in pending for sw in r["status"]]
+                    if first and bool((torch.cat(first) != 0).any().item()):
+                        resident = False
+                solved = self._solve_group(plans, streams, resident=resident)   # asynchronous: returns once enqueued
                 for r, wnd in zip(solved, groups[g]):
                     r["window"] = wnd
                 pending += solved
@@ -168,12 +178,16 @@ class WindowPipeline(object):
             owner = [k for k, r in enumerate(pending) for _ in r["status"]]
             bad = torch.cat(words).cpu().numpy() != 0 if words else np.zeros(0, dtype=bool)   # (one read-back for all launches)
             self.resident_fallbacks = sorted({owner[i] for i in np.flatnonzero(bad)})
-            for k in self.resident_fallbacks:
-                with torch.cuda.stream(streams[0]):
-                    plan = self._ingest(store, pending[k]["window"])
-                    redo = self._solve_group([plan], streams[:1], resident=False)[0]
-                streams[0].synchronize()
-                pending[k].update(redo)
+            for i in range(0, len(self.resident_fallbacks), len(streams)):   # (in groups, like the first pass)
+                ks = self.resident_fallbacks[i:i + len(streams)]
+                plans, ready = ingest_group([pending[k]["window"] for k in ks])
+                for st in streams[:len(plans)]:
+                    st.wait_event(ready)
+                for k, redo in zip(ks, self._solve_group(plans, streams, resident=False)):
+                    pending[k].update(redo)
+            if self.resident_fallbacks:
+                for st in streams:
+                    st.synchronize()
             H, W = self.solver.orig_image_shape
             self.histories = [[float(v) for part in r["losses"] for v in part.cpu()] for r in pending]
             self.patch_flows = [r["theta"] for r in pending]
