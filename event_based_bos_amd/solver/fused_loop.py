@@ -229,6 +229,17 @@ class FusedPatchLoop(object):
                 loss = loss + self.reg_partials.sum().to(torch.float32)
         return loss, (self.d_theta.clone() if self.theta_mask is None else self.d_theta * self.theta_mask)
 
+    def _resident_problem(self) -> "_hip.CmaxPatchProblem":
+        """``problem()`` for the resident launch: a BUILT halo of 32 becomes "run-time windows of at most 32 px" where the plan knows
+        its |dt| bound -- with every window the full one the resident kernel publishes and re-reads the image in every iteration
+        and scatters in f64 (45.7 us per iteration at 2 M events: no faster than the four launches; 28.9 with run-time windows).
+        Values are the same; the gradient's fixed-point unit follows the staged window, so against the four-launch pipeline at the
+        built halo the trajectory agrees to rounding (~1e-6 per iteration), not bit for bit -- with ``halo="auto"`` it is identical."""
+        q = self.problem()
+        if self.halo >= 0 and self.plan.dt_bound is not None:
+            q.halo = int(self.lib.ebos_halo_auto(int(self.halo), float(self.plan.dt_bound)))
+        return q
+
     def problem(self) -> "_hip.CmaxPatchProblem":
         """The loop's buffers as the ``ebos_cmax_patch_problem`` struct of the C ABI."""
         plan = self.plan
@@ -266,7 +277,7 @@ class FusedPatchLoop(object):
             return False
         import ctypes
 
-        return bool(self.lib.ebos_cmax_resident_supported(ctypes.byref(self.problem())))
+        return bool(self.lib.ebos_cmax_resident_supported(ctypes.byref(self._resident_problem())))
 
     def enqueue_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> torch.Tensor:
         """Enqueue ``n_iter`` iterations as one resident launch on the current stream WITHOUT waiting for it; returns the launch's
@@ -279,7 +290,7 @@ class FusedPatchLoop(object):
             H, W = self.plan.image_size
             nb = int(self.lib.ebos_cmax_resident_mailbox_bytes(H, W, self.plan.tile[0], self.plan.tile[1]))
             self._mailbox = torch.zeros(nb, dtype=torch.uint8, device=self.plan.device)
-        check(self.lib.ebos_cmax_patch_solve_resident_f32(ctypes.byref(self.problem()), int(n_iter), ptr(self._mailbox),
+        check(self.lib.ebos_cmax_patch_solve_resident_f32(ctypes.byref(self._resident_problem()), int(n_iter), ptr(self._mailbox),
                                                           self._mailbox.numel(), float(spin_timeout_s), stream_ptr()),
               "ebos_cmax_patch_solve_resident")
         self.t += int(n_iter)
