@@ -320,8 +320,8 @@ class FusedPatchLoop(object):
             raise ValueError(f"capacity {self.losses.numel()} < {self.t} steps done + {n_iter}")
         t0 = self.t
         if resident is None:
-            # (a launch that ended with -104 -- one tile far more crowded than the average: the pipeline splits such tiles -- is not
-            # tried again on this window)
+            # (a launch that ended with -104 -- one tile far more crowded than the average: the pipeline splits such tiles -- or with
+            # -102 -- displacements beyond the largest LDS window: the pipeline's spill path -- is not tried again on this window)
             resident = native and os.environ.get("EBOS_RESIDENT", "1") != "0" and not self._resident_refused and self.resident_supported()
         elif resident and not self.resident_supported():
             raise ValueError("resident=True: " + (self.lib.ebos_last_error() or b"").decode())
@@ -329,7 +329,7 @@ class FusedPatchLoop(object):
         with _hip.on_device(self.plan.device):
             if resident and n_iter > 0:
                 self.resident_status = self.run_resident(n_iter)
-                self._resident_refused = self.resident_status == -104
+                self._resident_refused = self.resident_status in (-102, -104)   # (flows beyond the windows / a crowded tile: not tried again)
                 if self.resident_status == 0:
                     self.t += n_iter
                     self.last_run_mode = "resident"
