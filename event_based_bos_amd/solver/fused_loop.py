@@ -329,7 +329,9 @@ class FusedPatchLoop(object):
         with _hip.on_device(self.plan.device):
             if resident and n_iter > 0:
                 self.resident_status = self.run_resident(n_iter)
-                self._resident_refused = self.resident_status in (-102, -104)   # (flows beyond the windows / a crowded tile: not tried again)
+                # (a wait past its cap -- the grid could not become co-resident, e.g. another process on the device --, flows beyond
+                # the windows, a crowded tile: not tried again on this window)
+                self._resident_refused = self.resident_status in (-101, -102, -104)
                 if self.resident_status == 0:
                     self.t += n_iter
                     self.last_run_mode = "resident"
