@@ -30,6 +30,14 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _default_policies(monkeypatch):
+    """The tests pin the DEFAULT behaviour (resident solver loop, deferred idiom results, ...): policy variables a shell may carry
+    are taken out of every test's environment; a test that wants one sets it itself."""
+    for var in ("EBOS_RESIDENT", "EBOS_RESIDENT_MAX_IMBALANCE", "EBOS_FUSE_API", "EBOS_STRICT"):
+        monkeypatch.delenv(var, raising=False)
+
+
 @pytest.fixture(scope="session")
 def golden_small():
     return dict(np.load(os.path.join(GOLDEN_DIR, "golden_small.npz"), allow_pickle=False))
