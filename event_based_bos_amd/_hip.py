@@ -127,6 +127,7 @@ SIGNATURES = {
     "ebos_cmax_resident_supported": (_I, [_P]),
     "ebos_cmax_patch_solve_resident_f32": (_I, [_P, _I, _P, _Z, _D, _P]),
     "ebos_cmax_resident_status": (_I, [_P, _P]),
+    "ebos_cmax_resident_iterations": (_I, [_P, _P]),
     "ebos_gauss1d_f32": (_I, _GAUSS),
     "ebos_gauss1d_f64": (_I, _GAUSS),
     "ebos_gauss1d_bwd_f32": (_I, _GAUSS),

@@ -89,8 +89,11 @@ enum ResidentStatus : unsigned {
 
 // A whole wave polls: lane-wise predicate, true when every lane's holds.  Bounded: every 32 polls the status word and the clock
 // (100 MHz) are looked at; false = the launch is over (status set by this wave or seen set).
+// A spill (status = RES_SPILL | iteration << 8) ends only the wait for THAT iteration's records (`spill_it`: the iteration a wait
+// belongs to if it is the all-to-all's, -1 otherwise): every other wait's data still arrives -- the workgroups all finish the
+// iterations before the spill and stop in front of the same all-to-all, from where the launch hands over a consistent state.
 template <typename Pred>
-__device__ __forceinline__ bool wave_wait(Pred&& ready, unsigned* status, unsigned long long cap_ticks) {
+__device__ __forceinline__ bool wave_wait(Pred&& ready, unsigned* status, unsigned long long cap_ticks, int spill_it = -1) {
   unsigned spins = 0;
   unsigned long long t0 = 0;
   for (;;) {
@@ -99,7 +102,9 @@ __device__ __forceinline__ bool wave_wait(Pred&& ready, unsigned* status, unsign
       const unsigned long long now = wall_clock64();
       if (t0 == 0) t0 = now;
       const unsigned st = ld_sc1(status);
-      if (st != RES_OK) return false;
+      if ((st & 255u) == RES_SPILL) {
+        if (spill_it >= 0 && (int)(st >> 8) == spill_it) return false;
+      } else if (st != RES_OK) return false;
       if (now - t0 > cap_ticks) {
         if ((threadIdx.x & (kWave - 1)) == 0) st_sc1(status, (unsigned)RES_TIMEOUT);
         return false;
@@ -347,8 +352,9 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     __syncthreads();
   }
   bool done_ok = true;
+  int it = 0;
 
-  for (int it = 0; it < n_iter; ++it) {
+  for (it = 0; it < n_iter; ++it) {
     const unsigned ep = (unsigned)it + 1u;
     EBOS_RSTAMP(0);
     Win<TH, TW, HALO, true> win{HALO, HALO};
@@ -398,7 +404,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       __syncthreads();
     }
     if (sh.flag[1]) {  // (uniform) a tap left the largest window: the four-launch pipeline's spill path handles that flow
-      if (threadIdx.x == 0) st_sc1(fresh_args().status, (unsigned)RES_SPILL);
+      if (threadIdx.x == 0) st_sc1(fresh_args().status, (unsigned)RES_SPILL | ((unsigned)it << 8));
       done_ok = false;
       break;
     }
@@ -461,7 +467,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             all = all && (unsigned)(g[j] >> 32) == ep;
           }
           return all || (EBOS_ABL & 256) != 0;
-        }, a.status, a.cap_ticks);
+        }, a.status, a.cap_ticks, it);
         if (ok && k < n_tiles) {
           as = __builtin_bit_cast(double, (g[0] & 0xffffffffull) | (g[1] << 32));
           const int nty = k / tiles_x, dy = nty - ty, dx = k - nty * tiles_x - tx;
@@ -884,7 +890,15 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     __syncthreads();  // the new theta block is in LDS
     if (!s_ok) { done_ok = false; break; }
   }
-  if (!done_ok) return;  // (uniform) nothing of the optimiser state was written: the host falls back from unchanged state
+  // A launch that ended early writes nothing of the optimiser state: the host falls back from unchanged state -- except after a
+  // SPILL in iteration `it` >= 1: every workgroup then stands in front of that iteration's all-to-all with `it` completed
+  // iterations behind it (nobody passes an all-to-all whose record is missing, and every other wait's data arrives), and the
+  // launch hands over after those: state, losses and step counter of `it` iterations, the status says -102 and how many.
+  if (!done_ok) {
+    const unsigned st = ld_sc1(fresh_args().status);
+    if ((st & 255u) != RES_SPILL || (int)(st >> 8) != it || it < 1) return;
+    n_iter = it;
+  }
 
   // ---- the state goes back: every cell element by the first tile that holds it ------------------------------------------------------
   KArgs& a = fresh_args();
@@ -921,6 +935,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     const int t_last = a.t0 + n_iter - 1;
     if (a.losses != nullptr && t_last < a.losses_cap) a.losses[t_last] = (float)(-(double)a.w_contrast * (double)s_adam[2] + ar);
     a.step[0] = a.t0 + n_iter;
+    st_sc1(a.status + 1, (unsigned)n_iter);   // the iterations this launch completed (all of them, or those before a spill)
     const int lo_px = a.omit ? 1 : 0;
     a.variance[0] = s_adam[2];
     a.moments[0] = s_hist[((n_iter - 1) & 1) * 2 + 1];
@@ -1202,13 +1217,27 @@ int ebos_cmax_resident_status(const void* mailbox, ebos_stream_t stream) {
     set_error("ebos_cmax_resident_status: cannot read the status word (%s)", hipGetErrorString(hipGetLastError()));
     return EBOS_ERR_LAUNCH;
   }
+  st &= 255u;  // (a spill carries its iteration in the upper bits)
   if (st == RES_OK) return EBOS_OK;
-  set_error("resident solve ended early: %s -- theta and the optimiser state are unchanged; run ebos_cmax_patch_solve_f32",
+  set_error("resident solve ended early: %s -- theta and the optimiser state are unchanged (after a spill: those of the iterations "
+            "ebos_cmax_resident_iterations reports); run ebos_cmax_patch_solve_f32 for the rest",
             st == RES_TIMEOUT ? "a wait passed the spin cap (the grid was not co-resident)"
             : st == RES_SPILL ? "a tap left the largest LDS window"
             : st == RES_IMBALANCED ? "one tile holds far more events than the average one (the pipeline splits crowded tiles)"
                                    : "unsupported cell geometry");
   return -(100 + (int)st);
+}
+
+int ebos_cmax_resident_iterations(const void* mailbox, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(mailbox != nullptr, "ebos_cmax_resident_iterations: NULL mailbox");
+  unsigned words[2] = {0, 0};
+  hipStream_t s = as_stream(stream);
+  if (hipMemcpyAsync(words, mailbox, sizeof(words), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    set_error("ebos_cmax_resident_iterations: cannot read the mailbox (%s)", hipGetErrorString(hipGetLastError()));
+    return EBOS_ERR_LAUNCH;
+  }
+  return (int)words[1];
 }
 
 }  // extern "C"

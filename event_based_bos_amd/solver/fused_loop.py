@@ -122,6 +122,7 @@ class FusedPatchLoop(object):
         self.graphed = False  # kept for callers that report it: this loop is never graph-replayed
         self._mailbox = None          # flags / records / status word of the resident launch (allocated on first use)
         self.resident_status = 0      # status of the last resident launch (0 = completed)
+        self.resident_iterations = 0  # iterations it completed
         self.last_run_mode = "pipeline"
         self._resident_refused = False
         import ctypes as C
@@ -305,7 +306,11 @@ class FusedPatchLoop(object):
         t, mode = self.t, self.last_run_mode
         self.enqueue_resident(n_iter, spin_timeout_s)
         self.t, self.last_run_mode = t, mode   # (``run`` books the iterations once it has seen the status)
-        return int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), stream_ptr()))
+        status = int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), stream_ptr()))
+        # iterations the launch completed: all of them, none -- or, after a spill in iteration k >= 1, the k before it (the state IS
+        # that of k iterations then: the launch hands over instead of discarding its work)
+        self.resident_iterations = int(self.lib.ebos_cmax_resident_iterations(ptr(self._mailbox), stream_ptr()))
+        return status
 
     def run(self, n_iter: int, native: bool = True, resident: Optional[bool] = None) -> torch.Tensor:
         """``n_iter`` more iterations; returns their losses [n_iter] (device).
@@ -315,7 +320,7 @@ class FusedPatchLoop(object):
         ``native`` (default): one C call enqueues the whole loop (ebos_cmax_patch_solve_f32); otherwise one Python call
         per kernel group.  (A HIP-graph replay of the iteration was measured slower than plain launches on ROCm 7.2 --
         172 vs 111 us at 2 M events -- and cannot carry the step number, which is a kernel argument.)"""
-        n_iter = int(n_iter)
+        n_iter = n_total = int(n_iter)
         if self.t + n_iter > self.losses.numel():
             raise ValueError(f"capacity {self.losses.numel()} < {self.t} steps done + {n_iter}")
         t0 = self.t
@@ -336,6 +341,12 @@ class FusedPatchLoop(object):
                     self.t += n_iter
                     self.last_run_mode = "resident"
                     return self.losses[t0:t0 + n_iter]
+                if self.resident_status == -102 and self.resident_iterations > 0:
+                    # a flow left the LDS windows in iteration k: the first k iterations are done (state, losses, step counter);
+                    # the four launches below continue with the rest
+                    self.t += self.resident_iterations
+                    n_iter -= self.resident_iterations
+                    self.last_run_mode = "resident+pipeline"
             if native:
                 import ctypes
 
@@ -345,4 +356,4 @@ class FusedPatchLoop(object):
             else:
                 for _ in range(n_iter):
                     self.iteration()
-        return self.losses[t0:t0 + n_iter]
+        return self.losses[t0:t0 + n_total]

@@ -752,6 +752,11 @@ int ebos_cmax_resident_supported(const ebos_cmax_patch_problem* problem);
 int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* problem, int n_iter, void* mailbox, size_t mailbox_bytes,
                                        double spin_timeout_s, ebos_stream_t stream);
 int ebos_cmax_resident_status(const void* mailbox, ebos_stream_t stream);
+/* The iterations the launch completed (synchronises `stream`): n_iter after status 0; after -102 (a tap left the largest LDS
+ * window in iteration k >= 1) the k iterations before it -- theta, the optimiser state, the step counter and the losses are then
+ * those of k iterations and ebos_cmax_patch_solve_f32 continues with the remaining n_iter - k; 0 after any other negative status
+ * (nothing changed). */
+int ebos_cmax_resident_iterations(const void* mailbox, ebos_stream_t stream);
 
 #ifdef __cplusplus
 }

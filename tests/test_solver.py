@@ -559,8 +559,11 @@ def test_resident_loop_matches_the_four_launch_pipeline(size, n_ev, patch, terms
 
 @pytest.mark.gpu
 def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
-    """A flow whose displacements leave the largest LDS window: the resident launch must END (status -102), leave theta and the
-    optimiser state untouched, and ``run`` must produce the four-launch pipeline's result."""
+    """A flow whose displacements leave the largest LDS window: the resident launch must END (status -102).  In its FIRST iteration
+    it leaves theta and the optimiser state untouched and ``run`` produces the four-launch pipeline's result; when the flow grows
+    past the windows in iteration k >= 1 the launch hands over after its k completed iterations (state, losses, step counter of
+    k iterations: every workgroup stands in front of the same all-to-all) and the pipeline continues -- the same trajectory
+    bit for bit as four launches from the start."""
     import event_based_bos_amd as ebos
     from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
 
@@ -579,6 +582,27 @@ def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
     assert res.last_run_mode == "pipeline" and res.resident_status == -102
     np.testing.assert_array_equal(l_ref, l_res)
     assert torch.equal(ref.theta, res.theta)
+    # a flow that GROWS past the windows: theta starts at 30.5 px (inside the 32 px windows) and a large learning rate pushes
+    # single cells beyond them after a few steps
+    theta1 = torch.full((2, 4, 4), 30.5)
+    mk = lambda: FusedPatchLoop(plan, patch, patch, theta1, 1.0, 0.0, 0.0, halo="auto", lr=0.6, capacity=40)
+    ref, res = mk(), mk()
+    status = res.run_resident(30)
+    k = res.resident_iterations
+    print("resident launch: status", status, "after", k, "completed iterations")
+    assert status == -102 and 1 <= k < 30 and int(res.step.item()) == k
+    l_ref = ref.run(k, resident=False).cpu().numpy()   # (no tap has left a window yet: the pipeline is bit-reproducible here)
+    np.testing.assert_array_equal(res.losses[:k].cpu().numpy(), l_ref)
+    for name in ("theta", "exp_avg", "exp_avg_sq", "d_theta"):
+        np.testing.assert_array_equal(getattr(ref, name).cpu().numpy(), getattr(res, name).cpu().numpy(), err_msg=name)
+    # ... and ``run`` continues with the four launches (whose spill path adds with global float atomics: agreement to rounding)
+    ref, res = mk(), mk()
+    l_ref = ref.run(30, resident=False).cpu().numpy()
+    l_res = res.run(30).cpu().numpy()
+    assert res.resident_status == -102 and res.resident_iterations == k and res.last_run_mode == "resident+pipeline"
+    assert res.t == 30 and int(res.step.item()) == 30
+    np.testing.assert_allclose(l_res, l_ref, rtol=1e-4)
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), atol=1e-2)
 
 
 @pytest.mark.gpu
