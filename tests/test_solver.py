@@ -538,12 +538,13 @@ def test_resident_loop_matches_the_four_launch_pipeline(size, n_ev, patch, terms
     assert res.resident_supported(), ebos.load_library().ebos_last_error()
     ref.run(1, resident=False)
     res.run(1, resident=True)
-    assert res.last_run_mode == "resident" and res.resident_status == 0
+    assert res.last_run_mode == "resident" and res.resident_status == 0 and res.resident_iterations == 1
     assert torch.equal(ref.iwe, res.iwe)                                  # the image of the first iteration: same bits
     np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=1e-6)
     l_ref = ref.run(n_iter - 1, resident=False).cpu().numpy()
     l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
     assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
+    assert res.resident_iterations == n_iter - 1   # (what the LAST launch completed)
     print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
     np.testing.assert_allclose(l_res, l_ref, rtol=1e-6)
     np.testing.assert_allclose(ref.losses[:n_iter].cpu().numpy(), res.losses[:n_iter].cpu().numpy(), rtol=1e-6)
