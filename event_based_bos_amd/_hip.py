@@ -20,7 +20,7 @@ REF_FIRST, REF_LAST, REF_FRACTION, REF_TIMEBASE = 0, 1, 2, 3
 SPLAT_BILINEAR, SPLAT_COUNT, SPLAT_POLARITY = 0, 1, 2
 GAUSS_REFLECT_SCIPY, GAUSS_REFLECT_TORCH = 0, 1
 PROFILE_SLAB_ACCUMULATE, PROFILE_TILED_BWD, PROFILE_SLAB_COMBINE, PROFILE_GRADMAG_FUSED = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipUnavailableError(RuntimeError):
@@ -115,6 +115,11 @@ SIGNATURES = {
     "ebos_patch_grad_partials_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "ebos_iwe_patch_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P,
                                           _P, _P, _P, _Z, _P, _F, _F, _P, _P, _L, _L, _P, _P, _P]),
+    "ebos_iwe_patch_tiled_bwd_blur_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P,
+                                               _P, _Z, _P, _F, _F, _P, _P, _L, _L, _P, _P, _F, _F, _P]),
+    "ebos_blur3_variance_partials": (_L, [_I, _I]),
+    "ebos_blur3_variance_adjoint_f32": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _L, _P]),
+    "ebos_cmax_2dof_solve_f32": (_I, [_P, _I, _P]),
     "ebos_patch_grad_combine_adam_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _I, _P, _P,
                                               _F, _P, _I, _P, _I, _P, _P]),
     "ebos_flow_regularisers_partials": (_I, []),
@@ -149,7 +154,18 @@ class CmaxPatchProblem(C.Structure):
                 [("cost_scratch_bytes", _Z)] +
                 [(k, _P) for k in ("moments", "upstream", "reg_partials", "upsample_scratch", "workspace")] +
                 [("workspace_bytes", _Z), ("losses", _P), ("losses_cap", _I), ("theta_mask", _P), ("grad_partials", _P),
-                 ("grad_partials_bytes", _Z)])
+                 ("grad_partials_bytes", _Z), ("blur_k0", _F), ("blur_k1", _F), ("blur_image", _P)])
+
+
+class Cmax2dofProblem(C.Structure):
+    """``ebos_cmax_2dof_problem`` of include/ebos_hip.h (same field order)."""
+    _fields_ = ([(k, _P) for k in ("xs", "ys", "dts", "grp_offsets", "cpix", "cdt", "key_offsets")] + [("n", _L)] +
+                [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "pad_h", "pad_w", "omit_boundary", "splits")] +
+                [("part_table", _P), ("blur_k0", _F), ("blur_k1", _F)] +
+                [(k, _D) for k in ("lr", "beta1", "beta2", "eps")] +
+                [(k, _P) for k in ("theta", "d_theta", "exp_avg", "exp_avg_sq", "step")] + [("steps_done", _I)] +
+                [(k, _P) for k in ("iwe", "blur_image", "variance", "moments", "upstream", "cost_scratch")] +
+                [("cost_scratch_bytes", _Z), ("workspace", _P), ("workspace_bytes", _Z), ("losses", _P), ("losses_cap", _I)])
 
 
 class DenseJob(C.Structure):

@@ -1,0 +1,86 @@
+// blur3.h -- the 3-tap blur of the tensor branch of create_iwe and its adjoint, as device functions shared by the image kernel of the
+// four-launch pipeline (cost_kernels.hip), the backward event kernels (iwe_tile_core.h) and the resident solver kernel
+// (cmax_resident.hip): one arithmetic, so that the forms of the loop agree to the last bit wherever they see the same image.
+//
+// reference: EventImageConverter.create_image_from_events_tensor -> torchvision gaussian_blur(image, kernel_size=3, sigma)
+// (src/event_image_converter.py:399-404): taps exp(-x^2 / 2 sigma^2) at x = -1, 0, 1 normalised to sum 1, separable, `reflect`
+// padding in torch's sense (d c b | a b c d: the edge sample is not repeated).  With y = B x the contrast is taken on y:
+//     loss = -w var(m . y)        (m: the valid region, omit_boundary)
+//     d loss / d x = B^T u,  u = m . (a y + c),  a = 2 (-w) / (M - 1),  c = -a mean(y)
+//                  = a z + c wgt,   z = B^T (m . y)  (linear in x, needs no mean),   wgt = B^T m  (a function of the position only).
+// B is separable, B = B_rows (x) B_cols; along an axis of L samples
+//     y(i) = k0 x(i - 1) + k1 x(i) + k0 x(i + 1),   x(-1) = x(1),  x(L) = x(L - 2)
+// i.e. the coefficient of x(j) in y(i) is k1 for j == i, k0 for |j - i| == 1 -- doubled where the reflection folds the missing
+// neighbour onto j (i == 0, j == 1 and i == L - 1, j == L - 2) -- and 0 otherwise.  L >= 2 (torch refuses to reflect-pad an axis of 1).
+#pragma once
+#include "common.h"
+
+namespace ebos {
+
+struct Blur3 {
+  float k0, k1;  // taps (k0, k1, k0); k0 == 0: no blur
+};
+
+// coefficient of x(j) in y(i), |j - i| <= 1 assumed by the callers' loops; 0 where i or j lies outside [0, L)
+__device__ __forceinline__ float blur3_coef(int i, int j, int L, const Blur3& b) {
+  if (i < 0 || i >= L || j < 0 || j >= L) return 0.0f;
+  if (i == j) return b.k1;
+  const bool folded = (i == 0 && j == 1) || (i == L - 1 && j == L - 2);
+  return folded ? 2.0f * b.k0 : b.k0;
+}
+
+// y(r, c) from an accessor x(r, c) that is only asked for positions INSIDE the image
+template <typename X>
+__device__ __forceinline__ float blur3_fwd_at(X&& x, int r, int c, int h, int w, const Blur3& b) {
+#pragma clang fp contract(off)
+  float y = 0.0f;
+#pragma unroll
+  for (int dc = -1; dc <= 1; ++dc) {
+    const float cc = blur3_coef(c, c + dc, w, b);
+    float t = 0.0f;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+      const float cr = blur3_coef(r, r + dr, h, b);
+      t += cr != 0.0f && cc != 0.0f ? cr * x(r + dr, c + dc) : 0.0f;
+    }
+    y += cc * t;
+  }
+  return y;
+}
+
+// z(r, c) = (B^T u)(r, c) from an accessor u(r, c) that is only asked for positions inside the image (u = the masked blurred image)
+template <typename U>
+__device__ __forceinline__ float blur3_adj_at(U&& u, int r, int c, int h, int w, const Blur3& b) {
+#pragma clang fp contract(off)
+  float z = 0.0f;
+#pragma unroll
+  for (int dc = -1; dc <= 1; ++dc) {
+    const float cc = blur3_coef(c + dc, c, w, b);
+    float t = 0.0f;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+      const float cr = blur3_coef(r + dr, r, h, b);
+      t += cr != 0.0f && cc != 0.0f ? cr * u(r + dr, c + dc) : 0.0f;
+    }
+    z += cc * t;
+  }
+  return z;
+}
+
+// (B^T m) along one axis: the sum of the coefficients with which x(j) enters the valid outputs lo <= i < L - lo
+__device__ __forceinline__ float blur3_axis_weight(int j, int L, int lo, const Blur3& b) {
+#pragma clang fp contract(off)
+  float s = 0.0f;
+#pragma unroll
+  for (int d = -1; d <= 1; ++d) {
+    const int i = j + d;
+    s += (i >= lo && i < L - lo) ? blur3_coef(i, j, L, b) : 0.0f;
+  }
+  return s;
+}
+__device__ __forceinline__ float blur3_weight(int r, int c, int h, int w, int lo, const Blur3& b) {
+#pragma clang fp contract(off)
+  return blur3_axis_weight(r, h, lo, b) * blur3_axis_weight(c, w, lo, b);
+}
+
+}  // namespace ebos

@@ -12,6 +12,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.h"
+#include "blur3.h"
 
 namespace ebos {
 namespace {
@@ -303,6 +304,64 @@ gradmag_fused_kernel(const float* __restrict__ img, int h, int w, Region rg, con
   if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = val;
 }
 
+// ---- variance of the 3-tap BLURRED image (iwe.blur_sigma > 0, src/event_image_converter.py:399-404), everything the solver loop needs
+// of it in ONE pass: the (sum, sum of squares) partials of the valid blurred pixels, in the layout of the slab combine pass's
+// partials (the backward event kernel reduces them the same way), and z = B^T (m . B x) -- the part of d var / d x that is linear in
+// x; the backward kernel forms a z + c wgt from it once it knows the mean (blur3.h).  A 256-thread workgroup holds a 16 x 64 tile
+// with a 2 px apron in LDS, the masked blurred image on tile + 1 px, and writes its tile of z.  4 H W bytes read + 4 H W written.
+__global__ void __launch_bounds__(kCostBlock)
+blur3_variance_adjoint_kernel(const float* __restrict__ img, int h, int w, Region rg, Blur3 bk, float* __restrict__ z_img,
+                              double* __restrict__ partials) {
+  constexpr int IH = kGmTH + 4, IW = kGmTW + 4, SH = kGmTH + 2, SW = kGmTW + 2;
+  __shared__ float s_img[IH * IW];
+  __shared__ float s_y[SH * SW];
+  const int tr0 = blockIdx.y * kGmTH, tc0 = blockIdx.x * kGmTW;
+  constexpr int kLoads = (IH * IW + kCostBlock - 1) / kCostBlock;
+  float stage[kLoads];
+#pragma unroll
+  for (int k = 0; k < kLoads; ++k) {  // (every load in flight before the first LDS store; positions outside the image are never used)
+    const int i = min((int)threadIdx.x + k * kCostBlock, IH * IW - 1);
+    const int rl = i / IW, cl = i - rl * IW;
+    const int r = min(max(tr0 - 2 + rl, 0), h - 1), c = min(max(tc0 - 2 + cl, 0), w - 1);
+    stage[k] = img[(int64_t)r * w + c];
+  }
+#pragma unroll
+  for (int k = 0; k < kLoads; ++k) {
+    const int i = threadIdx.x + k * kCostBlock;
+    if (i < IH * IW) s_img[i] = stage[k];
+  }
+  __syncthreads();
+  auto x_at = [&](int r, int c) { return s_img[(r - tr0 + 2) * IW + (c - tc0 + 2)]; };
+  double sm = 0.0, sq = 0.0;
+  for (int i = threadIdx.x; i < SH * SW; i += kCostBlock) {
+    const int rl = i / SW, cl = i - rl * SW;
+    const int qr = tr0 - 1 + rl, qc = tc0 - 1 + cl;
+    const bool in = qr >= rg.r0 && qr < rg.r1 && qc >= rg.c0 && qc < rg.c1;   // (the valid region lies inside the image)
+    const float y = in ? blur3_fwd_at(x_at, qr, qc, h, w, bk) : 0.0f;
+    s_y[i] = y;
+    if (in && rl >= 1 && rl <= kGmTH && cl >= 1 && cl <= kGmTW) {  // the tile's own pixels
+      sm += (double)y;
+      sq += (double)y * (double)y;
+    }
+  }
+  __syncthreads();
+  auto u_at = [&](int r, int c) { return s_y[(r - tr0 + 1) * SW + (c - tc0 + 1)]; };
+#pragma unroll
+  for (int k = 0; k < kGmTH * kGmTW / kCostBlock; ++k) {
+    const int i = threadIdx.x + k * kCostBlock;
+    const int rl = i / kGmTW, cl = i - rl * kGmTW;
+    const int pr = tr0 + rl, pc = tc0 + cl;
+    if (pr < h && pc < w) z_img[(int64_t)pr * w + pc] = blur3_adj_at(u_at, pr, pc, h, w, bk);
+  }
+  __shared__ double red[2 * kCostBlock / kWave];
+  block_sum2(sm, sq, red);
+  if (threadIdx.x == 0) {
+    const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    partials[2 * b] = sm;
+    partials[2 * b + 1] = sq;
+  }
+}
+
 __global__ void __launch_bounds__(kCostBlock) gradmag_fused_finalize_kernel(const double* __restrict__ partials, int nparts, int64_t m, float* out) {
   double s = 0.0;
   for (int i = threadIdx.x; i < nparts; i += kCostBlock) s += partials[i];
@@ -407,6 +466,26 @@ int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit
     gradmag_fused_kernel<<<grid, dim3(kCostBlock), 0, s>>>(image, h, w, rg, upstream, d_image, partials);
   if (out != nullptr) gradmag_fused_finalize_kernel<<<dim3(1), dim3(kCostBlock), 0, s>>>(partials, (int)need, rg.count(), out);
   EBOS_CHECK_LAUNCH("ebos_gradient_magnitude_fused");
+  return EBOS_OK;
+}
+
+int64_t ebos_blur3_variance_partials(int h, int w) { return ebos_gradient_magnitude_fused_partials(h, w); }
+
+int ebos_blur3_variance_adjoint_f32(const float* image, int h, int w, int omit_boundary, float k0, float k1, float* z_image,
+                                    double* partials, int64_t n_partials, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(image && z_image && partials && image != z_image, "ebos_blur3_variance_adjoint: NULL or aliased image / z_image / partials");
+  EBOS_REQUIRE(h >= 2 && w >= 2, "ebos_blur3_variance_adjoint: reflect padding needs at least 2 samples per axis (h=%d w=%d)", h, w);
+  EBOS_REQUIRE(k0 > 0.0f && k1 > 0.0f, "ebos_blur3_variance_adjoint: taps must be positive");
+  const int64_t need = ebos_blur3_variance_partials(h, w);
+  if (n_partials < need) {
+    set_error("ebos_blur3_variance_adjoint: %lld partial pairs given, %lld needed", (long long)n_partials, (long long)need);
+    return EBOS_ERR_SCRATCH;
+  }
+  const Region rg = make_region(h, w, omit_boundary);
+  const dim3 grid((w + kGmTW - 1) / kGmTW, (h + kGmTH - 1) / kGmTH);
+  blur3_variance_adjoint_kernel<<<grid, dim3(kCostBlock), 0, as_stream(stream)>>>(image, h, w, rg, Blur3{k0, k1}, z_image, partials);
+  EBOS_CHECK_LAUNCH("ebos_blur3_variance_adjoint");
   return EBOS_OK;
 }
 

@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "patch_grid.h"
+#include "blur3.h"
 
 namespace ebos {
 namespace {
@@ -232,6 +233,10 @@ struct MomentsIn {
   // mode 1: one value partial per workgroup of gradmag_fused_kernel -> out_var[0] = sum / n_pixels, by workgroup 0 only (the upstream
   //         image is the gradient image itself: nothing to fold; the finalize launch of the contrast value disappears)
   int mode;
+  // blur.k0 != 0 (mode 0): the contrast is taken on the 3-tap blurred image y = B x (blur3.h).  The partials are then those of
+  // blur3_variance_adjoint_kernel -- (sum, sum of squares) of the valid blurred pixels -- and g_image is its z = B^T (m . y): the
+  // upstream is a z + c wgt with wgt = B^T m evaluated from the pixel's position, the valid region being part of z and wgt already
+  Blur3 blur;
 };
 
 // AP = apron in pixels around the tile (0 forward; 2 backward: the image_gradient regulariser reads neighbours up to 2 px away).
@@ -1548,9 +1553,17 @@ struct GradImage {
   const float* g;
   float a, c;  // G = a * g + c inside the valid region, 0 outside
   int h, w, lo;
+  // bk.k0 != 0: g is z = B^T (m . B x) of the blurred contrast (MomentsIn::blur) and G = a * g + c * wgt(R, C), wgt = B^T m with
+  // m the valid region of ring `blo`; `lo` is then 0 (the region is part of z and wgt)
+  Blur3 bk = {0.0f, 0.0f};
+  int blo = 0;
+  __device__ __forceinline__ float cw(int R, int C) const { return bk.k0 != 0.0f ? c * blur3_weight(R, C, h, w, blo, bk) : c; }
   __device__ __forceinline__ float at(int R, int C) const {  // padded coordinates
     if (R < lo || R >= h - lo || C < lo || C >= w - lo) return 0.0f;
-    return a * g[(int64_t)R * w + C] + c;
+    return a * g[(int64_t)R * w + C] + cw(R, C);
+  }
+  __device__ __forceinline__ void set_blur(const Blur3& b) {
+    if (b.k0 != 0.0f) bk = b, blo = lo, lo = 0;
   }
 };
 
@@ -2300,7 +2313,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
       const int R = oy + rl + pad_h, C = ox + cl + pad_w;
       const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-      const float gv = valid ? G.a * src[k] + G.c : 0.0f;
+      const float gv = valid ? G.a * src[k] + G.cw(R, C) : 0.0f;
       if (i < n_px) {
         s_g[i] = gv;
         gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);  // (a NaN counts as Inf: such a tile takes the f64 path)
@@ -2367,6 +2380,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     const double a = 2.0 * (upstream ? (double)upstream[0] : 1.0) / ((double)mj.n_pixels - 1.0);  // (null upstream: 1)
     G.a = (float)a;
     G.c = (float)(-a * s_mom[0]);
+    G.set_blur(mj.blur);
   } else {
     if (DYN) __syncthreads();  // publishes s_bound (the reduction above has barriers of its own)
     if (var_moments != nullptr) {
@@ -2614,6 +2628,35 @@ __global__ void __launch_bounds__(256) theta_grad_finalize_kernel(const double* 
   if (threadIdx.x == 0) {
     d_theta[0] = (float)sx;
     d_theta[1] = (float)sy;
+  }
+}
+
+// The 2-DoF Adam loop's last kernel (ebos_cmax_2dof_solve_f32): d loss / d theta from the tiles' partial pairs (the order of
+// theta_grad_finalize_kernel), the loss of the iteration -- upstream * variance, for the parameters BEFORE the update, as torch's
+// loop records it -- and torch.optim.Adam's step on the two parameters.  One workgroup.
+__global__ void __launch_bounds__(256)
+theta_adam_kernel(const double* __restrict__ partials, int ntiles, float* __restrict__ d_theta, float* __restrict__ theta,
+                  float* __restrict__ m, float* __restrict__ v, double lr, double beta1, double beta2, double eps, int t,
+                  int* __restrict__ step, const float* __restrict__ variance, const float* __restrict__ upstream,
+                  float* __restrict__ losses, int losses_cap) {
+  double sx = 0.0, sy = 0.0;
+  for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
+    sx += partials[2 * i];
+    sy += partials[2 * i + 1];
+  }
+  __shared__ double red[8];
+  block_sum2(sx, sy, red);
+  if (threadIdx.x == 0) {
+    const AdamCoef coef = adam_coef(lr, beta1, beta2, t);
+    const float g[2] = {(float)sx, (float)sy};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float mi = m[k], vi = v[k], th = theta[k];
+      adam_update(g[k], mi, vi, th, coef.step_size, coef.bc2_sqrt, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
+      m[k] = mi, v[k] = vi, theta[k] = th, d_theta[k] = g[k];
+    }
+    if (losses != nullptr && t - 1 < losses_cap) losses[t - 1] = upstream[0] * variance[0];
+    step[0] = t;
   }
 }
 

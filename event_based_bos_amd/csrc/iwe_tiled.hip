@@ -240,7 +240,8 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
                      int pad_w, const float* g_image, const float* affine, int g_lo, float* d_flow, float* d_weight,
                      double* partials, const double* var_moments, const float* upstream, const float* addend, float* part_out,
                      hipStream_t s, const GridSrc* grid_src = nullptr, int adaptive = 0, float s_norm = 0.0f, float s_tv = 0.0f,
-                     double* reg_partials = nullptr, MomentsIn mj = MomentsIn{}, const HaloArg& ha = HaloArg{HALO, false, 0.0f}) {
+                     double* reg_partials = nullptr, MomentsIn mj = MomentsIn{}, const HaloArg& ha = HaloArg{HALO, false, 0.0f},
+                     bool finalize_uniform = true) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   size_t lds = (size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float);
   static_assert((size_t)2 * TH * TW * sizeof(double) + (size_t)LH * LW * sizeof(float) <= 160 * 1024,
@@ -305,7 +306,7 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
   if (part_out)
     bwd_parts_combine_kernel<TH, TW, HALO><<<dim3((unsigned)(tiles_y * tiles_x)), dim3(256), 0, s>>>(part_out, ev.part_off, tiles_x, H, W,
                                                                                                   addend, d_flow);
-  if (uniform) theta_grad_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, tiles_y * tiles_x, d_flow);
+  if (uniform && finalize_uniform) theta_grad_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, tiles_y * tiles_x, d_flow);
   return EBOS_OK;
 }
 
@@ -816,20 +817,116 @@ size_t ebos_patch_grad_partials_bytes(int H, int W, int tile_h, int tile_w, int 
   return items * 2 * kGridCells * kGridCells * sizeof(float);
 }
 
-int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const int32_t* key_offsets,
-                                 int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w,
-                                 int H, int W, int tile_h, int tile_w, int halo_arg, int pad_h, int pad_w, const float* g_image,
-                                 const float* affine, int g_lo, const double* var_moments, const float* upstream,
-                                 const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
-                                 float w_flow_norm, float w_image_gradient, double* reg_partials, const double* var_partials,
-                                 int64_t n_var_partials,
-                                 int64_t n_var_pixels, float* out_variance, double* out_moments, ebos_stream_t stream) {
+// ---- the 2-DoF Adam loop natively (motion_model "2d-translation", configs/hot_plate1.yaml:47,65,70: Adam, 600 iterations, blur_sigma 3;
+// the loop of src/solver/generative_max_likelihood.py:306-341 on loss = -w var([blur3] IWE(theta))) ---------------------------------
+// One C call enqueues n_iter iterations of: accumulate (UNIFORM) + combine [+ the blur's image pass] -> backward (UNIFORM; every
+// workgroup reduces the variance partials itself, workgroup 0 reports the variance) -> partial pairs summed, loss recorded, Adam
+// step.  Four launches per iteration (five with the blur), nothing read back: the Python loop it replaces synchronised once per
+// iteration (float(loss)) around ~35 launches.
+static int cmax_2dof_check(const ebos_cmax_2dof_problem* q) {
+  using namespace ebos;
+  EBOS_REQUIRE(q != nullptr && q->steps_done >= 0, "ebos_cmax_2dof_solve: NULL problem or negative steps_done");
+  EBOS_REQUIRE(q->key_offsets && ((q->grp_offsets && q->cpix && q->cdt) || (q->xs && q->ys && q->dts) || q->n == 0),
+               "ebos_cmax_2dof_solve: NULL plan buffers");
+  EBOS_REQUIRE(q->theta && q->d_theta && q->exp_avg && q->exp_avg_sq && q->step && q->iwe && q->variance && q->moments && q->upstream &&
+                   q->workspace,
+               "ebos_cmax_2dof_solve: NULL buffer");
+  EBOS_REQUIRE(q->n >= 0 && q->H > 0 && q->W > 0 && q->pad_h >= 0 && q->pad_w >= 0 && q->splits >= 0 && q->splits <= 64,
+               "ebos_cmax_2dof_solve: bad sizes");
+  EBOS_REQUIRE(q->splits != 0 || q->part_table, "ebos_cmax_2dof_solve: splits = 0 (adaptive work items) needs the plan's part_table");
+  EBOS_REQUIRE(q->blur_k0 == 0.0f || (q->blur_k0 > 0.0f && q->blur_k1 > 0.0f && q->blur_image && q->cost_scratch),
+               "ebos_cmax_2dof_solve: the blurred contrast needs positive taps, blur_image and cost_scratch");
+  EBOS_REQUIRE(q->lr >= 0.0 && q->beta1 >= 0.0 && q->beta1 < 1.0 && q->beta2 >= 0.0 && q->beta2 < 1.0 && q->eps >= 0.0,
+               "ebos_cmax_2dof_solve: bad hyper-parameters");
+  return EBOS_OK;
+}
+
+int ebos_cmax_2dof_solve_f32(const ebos_cmax_2dof_problem* q, int n_iter, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(n_iter >= 0, "ebos_cmax_2dof_solve: negative n_iter");
+  if (int rc = cmax_2dof_check(q)) return rc;
+  const HaloArg ha = decode_halo(q->halo);
+  const int halo = ha.halo, tile_h = q->tile_h, tile_w = q->tile_w;
+  if (!slab_config_ok(tile_h, tile_w, halo)) {
+    set_error("ebos_cmax_2dof_solve: no kernel built for tile %dx%d halo %d (see ebos_slab_config)", tile_h, tile_w, halo);
+    return EBOS_ERR_UNSUPPORTED;
+  }
+  const size_t need = ebos_iwe_slab_workspace_bytes(q->H, q->W, tile_h, tile_w, halo, q->splits, q->pad_h, q->pad_w);
+  if (q->workspace_bytes < need) {
+    set_error("ebos_cmax_2dof_solve: workspace too small (%zu < %zu)", q->workspace_bytes, need);
+    return EBOS_ERR_SCRATCH;
+  }
+  const int h = q->H + 2 * q->pad_h, w = q->W + 2 * q->pad_w, lo = q->omit_boundary ? 1 : 0;
+  const bool blur = q->blur_k0 != 0.0f;
+  const int64_t n_blur = blur ? ebos_blur3_variance_partials(h, w) : 0;
+  if (blur && q->cost_scratch_bytes < (size_t)n_blur * 16) {
+    set_error("ebos_cmax_2dof_solve: cost_scratch too small (%zu < %zu)", q->cost_scratch_bytes, (size_t)n_blur * 16);
+    return EBOS_ERR_SCRATCH;
+  }
+  size_t off = 0;
+  int64_t n_parts = 0, n_px = 0;
+  if (int rc = ebos_iwe_slab_partials(q->H, q->W, tile_h, tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->omit_boundary, &off, &n_parts,
+                                      &n_px))
+    return rc;
+  EBOS_REQUIRE(n_px >= 2, "ebos_cmax_2dof_solve: the variance needs at least two valid pixels");
+  hipStream_t s = as_stream(stream);
+  char* ws = reinterpret_cast<char*>(q->workspace);
+  const int n_tiles_ = ((q->H + tile_h - 1) / tile_h) * ((q->W + tile_w - 1) / tile_w);
+  const int32_t* pt = q->part_table;
+  const EvPtrs evf{q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, pt, pt ? pt + n_tiles_ + 1 : nullptr,
+                   pt ? pt + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
+  const EvPtrs evb{q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr};
+  // the backward kernel's tile partials live in the slab section of the workspace (dead once the image is combined)
+  double* tile_partials = reinterpret_cast<double*>(q->workspace);
+  const double* var_partials = blur ? reinterpret_cast<const double*>(q->cost_scratch) : reinterpret_cast<const double*>(ws + off);
+  const MomentsIn mj{var_partials, blur ? n_blur : n_parts, n_px, q->variance, q->moments, nullptr, 0, Blur3{q->blur_k0, q->blur_k1}};
+  const float* g_image = blur ? q->blur_image : q->iwe;
+  for (int it = 0; it < n_iter; ++it) {
+    const int t = q->steps_done + it + 1;
+    int rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL)                                                                                                    \
+  launch_slab_fwd<TH, TW, HL>(evf, q->key_offsets, q->theta, true, q->H, q->W, q->splits, q->pad_h, q->pad_w, ws, q->iwe, blur ? 0 : 2, \
+                              q->omit_boundary, nullptr, nullptr, (int)ACC_FX, s, nullptr, ha)
+    EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+    if (rc != EBOS_OK) return rc;
+    if (blur) {
+      rc = ebos_blur3_variance_adjoint_f32(q->iwe, h, w, q->omit_boundary, q->blur_k0, q->blur_k1, q->blur_image,
+                                           reinterpret_cast<double*>(q->cost_scratch), n_blur, stream);
+      if (rc != EBOS_OK) return rc;
+    }
+    rc = EBOS_ERR_UNSUPPORTED;
+#define EBOS_CALL(TH, TW, HL)                                                                                                    \
+  launch_tiled_bwd<TH, TW, HL>(evb, q->key_offsets, q->theta, true, q->H, q->W, q->pad_h, q->pad_w, g_image, nullptr, lo, q->d_theta,  \
+                               nullptr, tile_partials, nullptr, q->upstream, nullptr, nullptr, s, nullptr, 0, 0.0f, 0.0f, nullptr, mj, ha, \
+                               false)
+    EBOS_SLAB_DISPATCH(EBOS_CALL)
+#undef EBOS_CALL
+    if (rc != EBOS_OK) return rc;
+    theta_adam_kernel<<<dim3(1), dim3(256), 0, s>>>(tile_partials, n_tiles_, q->d_theta, q->theta, q->exp_avg, q->exp_avg_sq, q->lr,
+                                                    q->beta1, q->beta2, q->eps, t, q->step, q->variance, q->upstream, q->losses,
+                                                    q->losses_cap);
+  }
+  EBOS_CHECK_LAUNCH("ebos_cmax_2dof_solve");
+  return EBOS_OK;
+}
+
+static int patch_tiled_bwd_impl(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const int32_t* key_offsets,
+                               int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w,
+                               int H, int W, int tile_h, int tile_w, int halo_arg, int pad_h, int pad_w, const float* g_image,
+                               const float* affine, int g_lo, const double* var_moments, const float* upstream,
+                               const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
+                               float w_flow_norm, float w_image_gradient, double* reg_partials, const double* var_partials,
+                               int64_t n_var_partials, int64_t n_var_pixels, float* out_variance, double* out_moments,
+                               ebos::Blur3 blur, ebos_stream_t stream) {
   using namespace ebos;
   const HaloArg ha = decode_halo(halo_arg);
   const int halo = ha.halo;
   EBOS_REQUIRE(var_partials == nullptr || (var_moments == nullptr && upstream != nullptr && n_var_partials >= 1 && n_var_pixels >= 2),
                "ebos_iwe_patch_tiled_bwd: var_partials needs upstream, no var_moments, and sane counts");
-  const MomentsIn mj{var_partials, n_var_partials, n_var_pixels, out_variance, out_moments, nullptr, 0};
+  EBOS_REQUIRE(blur.k0 == 0.0f || (var_partials != nullptr && affine == nullptr && blur.k0 > 0.0f && blur.k1 > 0.0f),
+               "ebos_iwe_patch_tiled_bwd_blur: needs the partials of ebos_blur3_variance_adjoint_f32, no affine map, positive taps");
+  const MomentsIn mj{var_partials, n_var_partials, n_var_pixels, out_variance, out_moments, nullptr, 0, blur};
   EBOS_REQUIRE((w_flow_norm == 0.0f && w_image_gradient == 0.0f) || reg_partials,
                "ebos_iwe_patch_tiled_bwd: regulariser weight given but reg_partials is NULL");
   EBOS_REQUIRE(w_image_gradient == 0.0f || (H >= 2 && W >= 2),
@@ -869,6 +966,33 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
   if (rc != EBOS_OK) return rc;
   EBOS_CHECK_LAUNCH("ebos_iwe_patch_tiled_bwd");
   return EBOS_OK;
+}
+
+int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const int32_t* key_offsets,
+                                 int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w,
+                                 int H, int W, int tile_h, int tile_w, int halo_arg, int pad_h, int pad_w, const float* g_image,
+                                 const float* affine, int g_lo, const double* var_moments, const float* upstream,
+                                 const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
+                                 float w_flow_norm, float w_image_gradient, double* reg_partials, const double* var_partials,
+                                 int64_t n_var_partials,
+                                 int64_t n_var_pixels, float* out_variance, double* out_moments, ebos_stream_t stream) {
+  return patch_tiled_bwd_impl(grp_offsets, cpix, cdt, key_offsets, n, grid, gh, gw, patch_h, patch_w, slide_h, slide_w, H, W, tile_h,
+                              tile_w, halo_arg, pad_h, pad_w, g_image, affine, g_lo, var_moments, upstream, addend, grad_partials,
+                              grad_partials_bytes, part_table, w_flow_norm, w_image_gradient, reg_partials, var_partials,
+                              n_var_partials, n_var_pixels, out_variance, out_moments, ebos::Blur3{0.0f, 0.0f}, stream);
+}
+
+int ebos_iwe_patch_tiled_bwd_blur_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const int32_t* key_offsets,
+                                      int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w,
+                                      int H, int W, int tile_h, int tile_w, int halo_arg, int pad_h, int pad_w, const float* z_image,
+                                      int g_lo, const float* upstream, float* grad_partials, size_t grad_partials_bytes,
+                                      const int32_t* part_table, float w_flow_norm, float w_image_gradient, double* reg_partials,
+                                      const double* blur_partials, int64_t n_blur_partials, int64_t n_var_pixels, float* out_variance,
+                                      double* out_moments, float blur_k0, float blur_k1, ebos_stream_t stream) {
+  return patch_tiled_bwd_impl(grp_offsets, cpix, cdt, key_offsets, n, grid, gh, gw, patch_h, patch_w, slide_h, slide_w, H, W, tile_h,
+                              tile_w, halo_arg, pad_h, pad_w, z_image, nullptr, g_lo, nullptr, upstream, nullptr, grad_partials,
+                              grad_partials_bytes, part_table, w_flow_norm, w_image_gradient, reg_partials, blur_partials,
+                              n_blur_partials, n_var_pixels, out_variance, out_moments, ebos::Blur3{blur_k0, blur_k1}, stream);
 }
 
 }  // extern "C"

@@ -225,6 +225,19 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
                "ebos_cmax_patch_solve: exactly one of w_variance / w_gradient_magnitude must be non-zero");
   EBOS_REQUIRE(q->w_gradient_magnitude == 0.0f || (q->d_iwe && q->cost_scratch),
                "ebos_cmax_patch_solve: the gradient-magnitude contrast needs d_iwe and cost_scratch");
+  if (q->blur_k0 != 0.0f) {  // the variance of the 3-tap blurred image (iwe.blur_sigma > 0)
+    EBOS_REQUIRE(q->blur_k0 > 0.0f && q->blur_k1 > 0.0f && q->blur_image && q->cost_scratch,
+                 "ebos_cmax_patch_solve: the blurred contrast needs positive taps, blur_image and cost_scratch");
+    if (q->grad_partials == nullptr || q->w_gradient_magnitude != 0.0f) {
+      set_error("ebos_cmax_patch_solve: the blurred contrast runs on the grid-sampling route (grad_partials) with the variance contrast only");
+      return EBOS_ERR_UNSUPPORTED;
+    }
+    const size_t need = (size_t)16 * (size_t)ebos_blur3_variance_partials(q->H + 2 * q->pad_h, q->W + 2 * q->pad_w);
+    if (q->cost_scratch_bytes < need) {
+      set_error("ebos_cmax_patch_solve: cost_scratch too small for the blur's partials (%zu < %zu)", q->cost_scratch_bytes, need);
+      return EBOS_ERR_SCRATCH;
+    }
+  }
   return EBOS_OK;
 }
 
@@ -241,12 +254,13 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
     if (rc) return rc;
   }
   const bool use_gm = q->w_gradient_magnitude != 0.0f;
+  const bool blur = q->blur_k0 != 0.0f;  // (grid route, variance contrast: cmax_check_problem)
   const int h = q->H + 2 * q->pad_h, w = q->W + 2 * q->pad_w;
   const float contrast_weight = use_gm ? q->w_gradient_magnitude : q->w_variance;
   if (grid)
     rc = ebos_iwe_patch_slab_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h, q->patch_w,
                                  q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w,
-                                 q->workspace, q->workspace_bytes, q->iwe, use_gm ? 0 : 2, q->omit_boundary, q->variance, q->moments,
+                                 q->workspace, q->workspace_bytes, q->iwe, (use_gm || blur) ? 0 : 2, q->omit_boundary, q->variance, q->moments,
                                  q->part_table, stream);  // (variance: partials only; the regulariser or backward kernel reduces them)
   else
     rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
@@ -272,6 +286,30 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
     rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials,
                                     use_gm ? nullptr : var_partials, n_parts, n_px, q->variance, q->moments, stream);
     if (rc) return rc;
+  }
+  if (grid && blur) {
+    // the blurred contrast: one pass over the image -> (sum, sum of squares) partials of the blurred pixels + z = B^T (m . B x);
+    // the backward kernel reduces the partials and forms its upstream a z + c wgt itself (blur3.h)
+    const int64_t n_blur = ebos_blur3_variance_partials(h, w);
+    const int lo = q->omit_boundary ? 1 : 0;
+    const int64_t n_valid = (int64_t)(h - 2 * lo > 0 ? h - 2 * lo : 0) * (w - 2 * lo > 0 ? w - 2 * lo : 0);
+    rc = ebos_blur3_variance_adjoint_f32(q->iwe, h, w, q->omit_boundary, q->blur_k0, q->blur_k1, q->blur_image,
+                                         reinterpret_cast<double*>(q->cost_scratch), n_blur, stream);
+    if (rc) return rc;
+    rc = ebos_iwe_patch_tiled_bwd_blur_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h,
+                                           q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h,
+                                           q->pad_w, q->blur_image, lo, q->upstream, q->grad_partials, q->grad_partials_bytes,
+                                           q->splits == 0 ? q->part_table : nullptr, fuse_norm ? q->w_flow_norm : 0.0f,
+                                           fuse_norm ? q->w_image_gradient : 0.0f, q->reg_partials,
+                                           reinterpret_cast<const double*>(q->cost_scratch), n_blur, n_valid, q->variance, q->moments,
+                                           q->blur_k0, q->blur_k1, stream);
+    if (rc) return rc;
+    const int n_items = (int)(ebos_patch_grad_partials_bytes(q->H, q->W, q->tile_h, q->tile_w, q->splits == 0) / 2048);
+    return ebos_patch_grad_combine_adam_f32(q->grad_partials, q->splits == 0 ? q->part_table : nullptr, q->tile_h, q->tile_w, q->gh,
+                                            q->gw, q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->d_theta, q->theta,
+                                            q->exp_avg, q->exp_avg_sq, q->lr, q->beta1, q->beta2, q->eps, t, q->step, q->variance,
+                                            -contrast_weight, q->reg_partials, fuse_norm ? n_items : 0, q->losses, q->losses_cap,
+                                            q->theta_mask, stream);
   }
   if (grid) {
     rc = ebos_iwe_patch_tiled_bwd_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h,

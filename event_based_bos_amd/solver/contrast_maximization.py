@@ -229,11 +229,12 @@ class ContrastMaximizationMixin(object):
             return self.objective(plan, dense)
 
         if self.fused_loop and fused_loop.supported(self.contrast_terms, self.flow_terms, self.blur_sigma, self.opt_method,
-                                                    plan, self.halo):
+                                                    plan, self.halo, sliding_window):
             loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms.get("image_variance", 0.0),
                                              self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
                                              self.omit_boundary, self.pad, self.halo, self.lr, capacity=n_iter,
-                                             w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0), theta_mask=mask)
+                                             w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0), theta_mask=mask,
+                                             blur_sigma=self.blur_sigma)
             losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
             self.graphed, self.fused, self.loop_mode = loop.graphed, True, loop.last_run_mode
             self.history += [float(v) for v in losses.cpu()]
@@ -360,22 +361,45 @@ class ContrastMaximizationMixin(object):
             total = total + wgt * fn(iwe, self.omit_boundary)
         return -total
 
+    def _translation_loop_fused(self, plan: EventPlan) -> bool:
+        """Can the 2-DoF Adam loop run natively (``fused_loop.Fused2dofLoop``: ebos_cmax_2dof_solve_f32)?  The variance contrast
+        (optionally of the 3-tap blurred image) on a binned plan -- compact, or the (x, y, dt) format of fractional (undistorted)
+        source coordinates -- with a tile-private kernel configuration."""
+        from ..event_plan import _slab_ok
+
+        return (self.fused_loop and set(self.contrast_terms) == {"image_variance"} and not self.flow_terms
+                and (plan.compact or plan.x is not None) and self.halo is not None and _slab_ok(plan, self.halo) and (not self.blur_sigma or min(plan.image_size) >= 2))
+
+    def _adam_translation(self, plan: EventPlan, theta0: torch.Tensor, n_iter: int) -> torch.Tensor:
+        """``n_iter`` Adam steps on (trans_x, trans_y) from ``theta0``: natively when the objective allows it (one C call
+        enqueues the whole loop, no host synchronisation per iteration), else through autograd."""
+        if self._translation_loop_fused(plan):
+            loop = fused_loop.Fused2dofLoop(plan, theta0, self.contrast_terms["image_variance"], self.omit_boundary, self.pad,
+                                            self.halo, self.lr, capacity=max(n_iter, 1), blur_sigma=self.blur_sigma)
+            losses = loop.run(n_iter)
+            self.fused, self.loop_mode = True, loop.last_run_mode
+            self.history += [float(v) for v in losses.cpu()]
+            return loop.theta
+        self.fused = False
+        theta = theta0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([theta], lr=self.lr)
+        for _ in range(n_iter):
+            opt.zero_grad(set_to_none=True)
+            loss = self._translation_loss(plan, theta)
+            loss.backward()
+            opt.step()
+            self.history.append(float(loss.detach()))
+        return theta.detach()
+
     def _estimate_translation(self, plan: EventPlan) -> torch.Tensor:
         """``optimizer.method: grid`` -- exhaustive sweep over the parameter ranges (the optuna grid sampler of
         src/solver/generative_max_likelihood.py:238-255), optionally refined by ``refine_iters`` Adam steps;
         ``Adam`` -- n_iter Adam steps on (trans_x, trans_y) from the warm start (or zero), the loop shape of :306-341."""
         if self.opt_method == "Adam":
             start = self._warm_start()
-            theta = (torch.zeros(2, dtype=torch.float32, device=plan.device) if start is None else
-                     to_gpu(start, device=plan.device, dtype=torch.float32).reshape(2)).clone().requires_grad_(True)
-            opt = torch.optim.Adam([theta], lr=self.lr)
-            for _ in range(self.n_iter):
-                opt.zero_grad(set_to_none=True)
-                loss = self._translation_loss(plan, theta)
-                loss.backward()
-                opt.step()
-                self.history.append(float(loss.detach()))
-            return theta.detach()
+            theta0 = (torch.zeros(2, dtype=torch.float32, device=plan.device) if start is None else
+                      to_gpu(start, device=plan.device, dtype=torch.float32).reshape(2))
+            return self._adam_translation(plan, theta0, self.n_iter)
         if self.opt_method not in ("grid", "sweep"):
             raise NotImplementedError(f"optimizer.method {self.opt_method!r} for a 2-DoF motion model: Adam or grid")
         rx, ry = self._param_range("trans_x"), self._param_range("trans_y")
@@ -388,15 +412,7 @@ class ContrastMaximizationMixin(object):
         self.sweep_grid, self.sweep_contrast = grid, var
         theta = grid[int(torch.argmax(var).item())]
         if self.refine_iters > 0:  # optimizer.refine_iters: Adam from the best grid point (gradient of the 2-DoF kernels)
-            theta = theta.clone().requires_grad_(True)
-            opt = torch.optim.Adam([theta], lr=self.lr)
-            for _ in range(self.refine_iters):
-                opt.zero_grad(set_to_none=True)
-                loss = self._translation_loss(plan, theta)
-                loss.backward()
-                opt.step()
-                self.history.append(float(loss.detach()))
-            theta = theta.detach()
+            theta = self._adam_translation(plan, theta, self.refine_iters)
         return theta
 
 

@@ -39,18 +39,43 @@ from .._hip import check, ptr, stream_ptr
 from ..event_plan import EventPlan, _slab_ok, _workspace
 
 FLOW_TERMS = ("flow_norm", "image_gradient")
+RESIDENT_BLUR = False  # (set once the resident kernel blurs its gathered window)
+
+
+def blur_taps(sigma: float) -> Tuple[float, float]:
+    """(k0, k1) of the 3-tap blur of the tensor branch of create_iwe: torchvision gaussian_blur(kernel_size=3, sigma),
+    taps exp(-x^2 / 2 sigma^2) at x = -1, 0, 1 normalised to sum 1 (src/event_image_converter.py:399-404)."""
+    import math
+
+    e = math.exp(-0.5 / (float(sigma) ** 2))
+    return e / (1.0 + 2.0 * e), 1.0 / (1.0 + 2.0 * e)
+
+
+def blur_supported(plan: EventPlan, halo, sliding_window, contrast_terms: Dict[str, float]) -> bool:
+    """iwe.blur_sigma > 0 inside the fixed pipeline: the variance contrast on the grid-sampling route (the blur's image pass
+    feeds the GRID backward kernel; csrc/blur3.h), images of at least 2 x 2 pixels (torch's reflect padding)."""
+    from ..event_plan import _norm_halo
+
+    if set(contrast_terms) != {"image_variance"} or not plan.compact or min(plan.image_size) < 2:
+        return False
+    lib = _hip.load_library()
+    return bool(lib.ebos_patch_fused_supported(plan.tile[0], plan.tile[1], int(_norm_halo(plan, halo)), int(sliding_window[0]),
+                                               int(sliding_window[1])))
 
 
 def objective_supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], blur_sigma: float, plan: EventPlan,
-                        halo) -> bool:
-    """The objective family of the fixed kernel pipeline: one contrast term + the two flow regularisers, no blur."""
-    return (len(contrast_terms) == 1 and set(contrast_terms) <= {"image_variance", "gradient_magnitude"}
-            and set(flow_terms) <= set(FLOW_TERMS) and not blur_sigma and halo is not None and _slab_ok(plan, halo))
+                        halo, sliding_window=None) -> bool:
+    """The objective family of the fixed kernel pipeline: one contrast term + the two flow regularisers; the 3-tap blur of the
+    IWE (iwe.blur_sigma) with the variance contrast on the grid-sampling route (``sliding_window`` given)."""
+    if not (len(contrast_terms) == 1 and set(contrast_terms) <= {"image_variance", "gradient_magnitude"}
+            and set(flow_terms) <= set(FLOW_TERMS) and halo is not None and _slab_ok(plan, halo)):
+        return False
+    return not blur_sigma or (sliding_window is not None and blur_supported(plan, halo, sliding_window, contrast_terms))
 
 
 def supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], blur_sigma: float, method: str,
-              plan: EventPlan, halo) -> bool:
-    return method == "Adam" and objective_supported(contrast_terms, flow_terms, blur_sigma, plan, halo)
+              plan: EventPlan, halo, sliding_window=None) -> bool:
+    return method == "Adam" and objective_supported(contrast_terms, flow_terms, blur_sigma, plan, halo, sliding_window)
 
 
 class FusedPatchLoop(object):
@@ -58,7 +83,7 @@ class FusedPatchLoop(object):
                  w_variance: float, w_flow_norm: float = 0.0, w_image_gradient: float = 0.0, omit_boundary: bool = False,
                  pad: int = 0, halo: int = 32, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, capacity: int = 1024,
                  splits: Optional[int] = None, w_gradient_magnitude: float = 0.0, theta_mask: Optional[torch.Tensor] = None,
-                 sample_grid: Optional[bool] = None):
+                 sample_grid: Optional[bool] = None, blur_sigma: float = 0.0):
         self.lib = _hip.require_gpu()
         self.plan, self.patch, self.slide = plan, tuple(int(v) for v in patch_size), tuple(int(v) for v in sliding_window)
         self.w_var, self.w_norm, self.w_tv = float(w_variance), float(w_flow_norm), float(w_image_gradient)
@@ -92,6 +117,13 @@ class FusedPatchLoop(object):
         if sample_grid is None and os.environ.get("EBOS_SAMPLE_GRID", "1") == "0":  # A/B switch for measurements
             can = False
         self.sample_grid = can if sample_grid is None else bool(sample_grid)
+        # iwe.blur_sigma > 0: the contrast of the 3-tap blurred image (ebos_blur3_variance_adjoint_f32 between the combine and the
+        # backward pass; the backward kernel folds the variance gradient in as a z + c wgt, csrc/blur3.h)
+        self.blur_sigma = float(blur_sigma or 0.0)
+        self.blur = blur_taps(self.blur_sigma) if self.blur_sigma > 0 else (0.0, 0.0)
+        if self.blur_sigma > 0 and (not self.sample_grid or self.w_gm):
+            raise ValueError("blur_sigma > 0: the fixed pipeline takes the variance contrast on the grid-sampling route only "
+                             "(fused_loop.blur_supported)")
         # with grid sampling the backward kernel evaluates the flow regularisers per tile, from the flow it holds in LDS
         self.fuse_norm = self.sample_grid and (self.w_tv != 0.0 or self.w_norm != 0.0)
         self.has_reg = self.has_reg and not self.fuse_norm  # from here on: "the regulariser LAUNCH is needed"
@@ -100,14 +132,15 @@ class FusedPatchLoop(object):
         self.n_reg = int(self.lib.ebos_flow_regularisers_partials()) if self.has_reg else 0
         self.d_reg = torch.empty((2, H, W), **f32) if self.has_reg else None
         self.iwe = torch.empty((H + 2 * self.pad[0], W + 2 * self.pad[1]), **f32)
+        self.blur_image = torch.empty_like(self.iwe) if self.blur_sigma > 0 else None
         self.variance = torch.empty(1, **f32)
         self.moments = torch.empty((1, 2), dtype=torch.float64, device=dev)
         self.upstream = torch.full((1,), -(self.w_gm or self.w_var), **f32)  # loss = -w * contrast
         self.d_iwe = torch.empty_like(self.iwe) if self.w_gm else None
         # (the Sobel pass's value partials: ebos_gradient_magnitude_fused_f32)
         self.cost_scratch = (torch.empty(max(int(self.lib.ebos_cost_scratch_bytes(1)),
-                                             8 * int(self.lib.ebos_gradient_magnitude_fused_partials(H + 2 * self.pad[0], W + 2 * self.pad[1]))),
-                                         dtype=torch.uint8, device=dev) if self.w_gm else None)
+                                             16 * int(self.lib.ebos_gradient_magnitude_fused_partials(H + 2 * self.pad[0], W + 2 * self.pad[1]))),
+                                         dtype=torch.uint8, device=dev) if (self.w_gm or self.blur_sigma > 0) else None)
         self.losses = torch.zeros(max(int(capacity), 1), **f32)
         self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
         self.scratch_up = (None if self.sample_grid else
@@ -188,6 +221,8 @@ class FusedPatchLoop(object):
               "ebos_iwe_dense_tiled_bwd")
 
     def iteration(self) -> None:
+        if self.blur_sigma > 0:
+            raise NotImplementedError("blur_sigma > 0: run(native=True) -- the blurred contrast is part of the natively enqueued loop")
         lib, plan, s = self.lib, self.plan, stream_ptr()
         H, W = plan.image_size
         gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
@@ -214,6 +249,8 @@ class FusedPatchLoop(object):
         lib, plan, s = self.lib, self.plan, stream_ptr()
         H, W = plan.image_size
         gh, gw, (ph, pw), (sh, sw) = self.gh, self.gw, self.patch, self.slide
+        if self.blur_sigma > 0:
+            raise NotImplementedError("blur_sigma > 0: value_and_grad is not part of the blurred pipeline (use the autograd objective)")
         with _hip.on_device(plan.device):
             self.theta.copy_(theta.detach().to(self.theta))
             self._forward_backward(lib, plan, s)
@@ -267,6 +304,7 @@ class FusedPatchLoop(object):
         q.theta_mask = ptr(self.theta_mask)
         q.grad_partials = ptr(self.grad_partials)
         q.grad_partials_bytes = self.grad_partials.numel() * 4 if self.grad_partials is not None else 0
+        q.blur_k0, q.blur_k1, q.blur_image = self.blur[0], self.blur[1], ptr(self.blur_image)
         return q
 
     def resident_supported(self) -> bool:
@@ -275,6 +313,8 @@ class FusedPatchLoop(object):
         workgroup per tile whatever the plan's work-item table says: against a pipeline that split crowded tiles it agrees to
         rounding, not bit for bit.)"""
         if not self.sample_grid or self.w_gm or self.splits not in (0, 1) or self.pad != (0, 0):
+            return False
+        if self.blur_sigma > 0 and not RESIDENT_BLUR:
             return False
         import ctypes
 
@@ -347,6 +387,8 @@ class FusedPatchLoop(object):
                     self.t += self.resident_iterations
                     n_iter -= self.resident_iterations
                     self.last_run_mode = "resident+pipeline"
+            if not native and self.blur_sigma > 0:
+                raise NotImplementedError("blur_sigma > 0 needs native=True")
             if native:
                 import ctypes
 
@@ -357,3 +399,84 @@ class FusedPatchLoop(object):
                 for _ in range(n_iter):
                     self.iteration()
         return self.losses[t0:t0 + n_total]
+
+
+class Fused2dofLoop(object):
+    """The Adam loop of the 2-DoF motion model ("2d-translation" / "rigid-optical-flow": x' = x + dt theta, src/warp.py:364-383)
+    on loss(theta) = -w var([blur3] IWE(theta)), enqueued natively (ebos_cmax_2dof_solve_f32): four launches per iteration (five
+    with iwe.blur_sigma > 0), no host synchronisation -- the loop shape of src/solver/generative_max_likelihood.py:306-341 that
+    configs/hot_plate1.yaml:47,65,70 selects (Adam, n_iter 600, blur_sigma 3)."""
+
+    def __init__(self, plan: EventPlan, theta0: torch.Tensor, w_variance: float = 1.0, omit_boundary: bool = False, pad: int = 0,
+                 halo="auto", lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, capacity: int = 1024,
+                 splits: Optional[int] = None, blur_sigma: float = 0.0):
+        from ..event_plan import _norm_halo
+
+        self.lib = _hip.require_gpu()
+        if not plan.binned or (not plan.compact and plan.x is None):
+            raise ValueError("Fused2dofLoop needs a binned plan with the compact events or the (x, y, dt) arrays")
+        self.plan = plan
+        self.w_var, self.omit, self.pad = float(w_variance), bool(omit_boundary), (int(pad), int(pad))
+        self.halo = int(_norm_halo(plan, halo))
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        dev = plan.device
+        H, W = plan.image_size
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.theta = theta0.detach().to(**f32).reshape(2).contiguous().clone()
+        self.d_theta = torch.zeros_like(self.theta)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.theta), torch.zeros_like(self.theta)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.t = 0
+        self.blur_sigma = float(blur_sigma or 0.0)
+        self.blur = blur_taps(self.blur_sigma) if self.blur_sigma > 0 else (0.0, 0.0)
+        h, w = H + 2 * self.pad[0], W + 2 * self.pad[1]
+        if self.blur_sigma > 0 and min(h, w) < 2:
+            raise ValueError("blur_sigma > 0 needs an image of at least 2 x 2 pixels (reflect padding)")
+        self.iwe = torch.empty((h, w), **f32)
+        self.blur_image = torch.empty_like(self.iwe) if self.blur_sigma > 0 else None
+        self.cost_scratch = (torch.empty(16 * int(self.lib.ebos_blur3_variance_partials(h, w)), dtype=torch.uint8, device=dev)
+                             if self.blur_sigma > 0 else None)
+        self.variance = torch.zeros(1, **f32)
+        self.moments = torch.zeros((1, 2), dtype=torch.float64, device=dev)
+        self.upstream = torch.full((1,), -self.w_var, **f32)  # loss = -w * contrast
+        self.losses = torch.zeros(max(int(capacity), 1), **f32)
+        self.splits = plan.resolve_splits(splits)
+        self.ws = _workspace(plan, self.pad, self.halo, self.splits)
+        self.last_run_mode = "pipeline"
+
+    def problem(self) -> "_hip.Cmax2dofProblem":
+        plan = self.plan
+        H, W = plan.image_size
+        gp, cp, cd = plan._compact_ptrs()
+        q = _hip.Cmax2dofProblem()
+        q.xs, q.ys, q.dts = ptr(plan.x), ptr(plan.y), ptr(plan.dt)
+        q.grp_offsets, q.cpix, q.cdt, q.key_offsets, q.n = gp, cp, cd, ptr(plan.key_offsets), plan.n
+        q.H, q.W, q.tile_h, q.tile_w, q.halo = H, W, plan.tile[0], plan.tile[1], self.halo
+        q.pad_h, q.pad_w, q.omit_boundary = self.pad[0], self.pad[1], int(self.omit)
+        q.splits, q.part_table = self.splits, ptr(plan.part_table)
+        q.blur_k0, q.blur_k1 = self.blur
+        q.lr, q.beta1, q.beta2, q.eps = self.lr, self.betas[0], self.betas[1], self.eps
+        q.theta, q.d_theta, q.exp_avg, q.exp_avg_sq, q.step = (ptr(self.theta), ptr(self.d_theta), ptr(self.exp_avg),
+                                                               ptr(self.exp_avg_sq), ptr(self.step))
+        q.steps_done = self.t
+        q.iwe, q.blur_image, q.variance, q.moments, q.upstream = (ptr(self.iwe), ptr(self.blur_image), ptr(self.variance),
+                                                                  ptr(self.moments), ptr(self.upstream))
+        q.cost_scratch = ptr(self.cost_scratch)
+        q.cost_scratch_bytes = self.cost_scratch.numel() if self.cost_scratch is not None else 0
+        q.workspace, q.workspace_bytes = ptr(self.ws), self.ws.numel()
+        q.losses, q.losses_cap = ptr(self.losses), self.losses.numel()
+        return q
+
+    def run(self, n_iter: int) -> torch.Tensor:
+        """``n_iter`` more Adam iterations; returns their losses [n_iter] (device, no synchronisation)."""
+        import ctypes
+
+        n_iter = int(n_iter)
+        if self.t + n_iter > self.losses.numel():
+            raise ValueError(f"capacity {self.losses.numel()} < {self.t} steps done + {n_iter}")
+        t0 = self.t
+        with _hip.on_device(self.plan.device):
+            check(self.lib.ebos_cmax_2dof_solve_f32(ctypes.byref(self.problem()), n_iter, stream_ptr()), "ebos_cmax_2dof_solve")
+        self.t += n_iter
+        self.last_run_mode = "pipeline"
+        return self.losses[t0:t0 + n_iter]

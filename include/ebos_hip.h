@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EBOS_ABI_VERSION 1
+#define EBOS_ABI_VERSION 2
 
 typedef void* ebos_stream_t; /* hipStream_t */
 
@@ -491,6 +491,19 @@ int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpi
                                  double* reg_partials,
                                  const double* var_partials, int64_t n_var_partials, int64_t n_var_pixels,
                                  float* out_variance, double* out_moments, ebos_stream_t stream);
+/* The same backward for the contrast of the 3-tap BLURRED image (iwe.blur_sigma > 0, src/event_image_converter.py:399-404):
+ * z_image / blur_partials are what ebos_blur3_variance_adjoint_f32 made of the IWE; the kernel reduces the partials (variance of the
+ * blurred image -> out_variance / out_moments), and its upstream is a z + c wgt(pixel) with a = 2 upstream / (M - 1),
+ * c = -a mean, wgt = B^T (valid region) evaluated from the pixel's position (csrc/blur3.h). */
+int ebos_iwe_patch_tiled_bwd_blur_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
+                                      const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw,
+                                      int patch_h, int patch_w, int slide_h, int slide_w, int H, int W, int tile_h,
+                                      int tile_w, int halo, int pad_h, int pad_w, const float* z_image, int g_lo,
+                                      const float* upstream, float* grad_partials, size_t grad_partials_bytes,
+                                      const int32_t* part_table, float w_flow_norm, float w_image_gradient,
+                                      double* reg_partials, const double* blur_partials, int64_t n_blur_partials,
+                                      int64_t n_var_pixels, float* out_variance, double* out_moments, float blur_k0,
+                                      float blur_k1, ebos_stream_t stream);
 int ebos_patch_grad_combine_adam_f32(const float* grad_partials, const int32_t* part_table, int tile_h, int tile_w,
                                      int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w, int H, int W,
                                      float* d_grid, float* theta, float* exp_avg, float* exp_avg_sq, double lr,
@@ -587,6 +600,16 @@ int ebos_gradient_magnitude_grad_f64(const double* images, int K, int h, int w, 
 int64_t ebos_gradient_magnitude_fused_partials(int h, int w);
 int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit_boundary, const float* upstream, float* out,
                                       float* d_image, double* partials, int64_t n_partials, ebos_stream_t stream);
+
+/* Variance of the 3-tap blurred image y = B x -- torchvision gaussian_blur(kernel_size = 3): taps (k0, k1, k0) =
+ * exp(-x^2 / 2 sigma^2) at x = -1, 0, 1 normalised to sum 1, reflect padding without edge repeat,
+ * src/event_image_converter.py:399-404 -- prepared for the solver loop in ONE pass over the image: partials
+ * [ebos_blur3_variance_partials(h, w)][2] f64 = (sum, sum of squares) of the valid blurred pixels per 16 x 64 tile (the layout of
+ * the slab combine pass's partials), and z_image [h, w] = B^T (m . y), the part of d var(y) / d x that is linear in x
+ * (m = the valid region, omit_boundary).  h, w >= 2 (torch refuses to reflect-pad an axis of one sample). */
+int64_t ebos_blur3_variance_partials(int h, int w);
+int ebos_blur3_variance_adjoint_f32(const float* image, int h, int w, int omit_boundary, float k0, float k1, float* z_image,
+                                    double* partials, int64_t n_partials, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * A16  patch grid -> dense flow  (src/solver/patch_eklt.py:173-204): replicate-pad the grid by
@@ -718,12 +741,57 @@ typedef struct ebos_cmax_patch_problem {
                                   ebos_patch_fused_supported and the compact plan); `dense` is then only written when a flow
                                   regulariser is on, d_dense / upsample_scratch are not used */
   size_t grad_partials_bytes;  /* ebos_patch_grad_partials_bytes(H, W, tile_h, tile_w, splits == 0) */
+  /* ABI 2: iwe.blur_sigma > 0 -- the variance is taken on the 3-tap blurred IWE (src/event_image_converter.py:399-404).
+   * blur_k0 = 0: no blur.  Otherwise the taps (blur_k0, blur_k1, blur_k0), blur_image [H + 2 pad_h, W + 2 pad_w] and cost_scratch
+   * >= 16 * ebos_blur3_variance_partials(H + 2 pad_h, W + 2 pad_w) bytes; variance contrast on the grid-sampling route only
+   * (grad_partials != NULL). */
+  float blur_k0, blur_k1;
+  float* blur_image;
 } ebos_cmax_patch_problem;
 int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* problem, int n_iter, ebos_stream_t stream);
 /* Several independent windows at once (windows are the unit that shards): problem w runs on
  * streams[w]; launches are enqueued iteration-major so that the windows' kernels interleave on the GPU. */
 int ebos_cmax_patch_solve_many_f32(const ebos_cmax_patch_problem* problems, const ebos_stream_t* streams,
                                    int n_problems, int n_iter);
+
+/* The Adam loop of the 2-DoF motion model natively (motion_model "2d-translation" with optimizer Adam, n_iter 600 and
+ * iwe.blur_sigma 3 is what configs/hot_plate1.yaml:47,65,70 selects; loop: src/solver/generative_max_likelihood.py:306-341):
+ *     loss(theta) = -w_variance * var([blur3] IWE(x + dt theta)),   theta = (trans_x, trans_y)   (src/warp.py:364-383)
+ * n_iter iterations enqueued by one C call, four launches each (five with the blur), no host synchronisation.
+ *   plan:    xs / ys / dts and / or the compact trio (grp_offsets / cpix / cdt), key_offsets, tile, halo, pad, omit_boundary,
+ *            splits, part_table as ebos_iwe_2dof_slab_f32
+ *   state:   theta / d_theta / exp_avg / exp_avg_sq [2] f32, step [1] int32; steps_done = Adam steps already applied
+ *   images:  iwe [H + 2 pad_h, W + 2 pad_w]; blur_image of the same shape and cost_scratch >= 16 * ebos_blur3_variance_partials
+ *            bytes when blur_k0 != 0 (taps blur_k0, blur_k1, blur_k0)
+ *   scalars: variance [1] f32 and moments [2] f64 receive the contrast of the last iteration; upstream [1] f32 = -w_variance
+ *   losses:  [losses_cap] f32, entry `step` written per iteration with the loss BEFORE the update (nullable) */
+typedef struct ebos_cmax_2dof_problem {
+  const float *xs, *ys, *dts;  /* the plan's (x, y, dt) arrays: needed when the compact trio is NULL (fractional -- undistorted --
+                                  source coordinates, data.warp: true in configs/hot_plate1.yaml:7), else nullable */
+  const int32_t* grp_offsets;
+  const uint16_t* cpix;
+  const float* cdt;
+  const int32_t* key_offsets;
+  int64_t n;
+  int H, W, tile_h, tile_w, halo, pad_h, pad_w, omit_boundary;
+  int splits;
+  const int32_t* part_table;
+  float blur_k0, blur_k1;
+  double lr, beta1, beta2, eps;
+  float *theta, *d_theta, *exp_avg, *exp_avg_sq;
+  int* step;
+  int steps_done;
+  float *iwe, *blur_image, *variance;
+  double* moments;
+  const float* upstream;
+  void* cost_scratch;
+  size_t cost_scratch_bytes;
+  void* workspace;
+  size_t workspace_bytes;
+  float* losses;
+  int losses_cap;
+} ebos_cmax_2dof_problem;
+int ebos_cmax_2dof_solve_f32(const ebos_cmax_2dof_problem* problem, int n_iter, ebos_stream_t stream);
 
 
 /* ---- the same loop as ONE resident launch (csrc/cmax_resident.hip) -------------------------------------------------------------

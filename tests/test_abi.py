@@ -51,7 +51,7 @@ def test_argument_counts_match_header():
 def test_host_only_entry_points(lib):
     from event_based_bos_amd import _hip
 
-    assert lib.ebos_version() == 1
+    assert lib.ebos_version() == _hip.ABI_VERSION == 2
     assert b"gfx950" in lib.ebos_build_info()
     cfgs = _hip.tiled_configs()
     assert (64, 64, 32) in cfgs and all(len(c) == 3 for c in cfgs)
@@ -159,7 +159,7 @@ def test_header_is_plain_c(tmp_path):
 
 
 @pytest.mark.parametrize("c_name,py_name", [("ebos_cmax_patch_problem", "CmaxPatchProblem"), ("ebos_dense_job", "DenseJob"),
-                                             ("ebos_slab_window", "SlabWindow")])
+                                             ("ebos_slab_window", "SlabWindow"), ("ebos_cmax_2dof_problem", "Cmax2dofProblem")])
 def test_problem_struct_layout_matches_the_ctypes_mirror(tmp_path, c_name, py_name):
     """The structs of the ABI as a C compiler lays them out == the ctypes.Structure the host layer fills (size and every
     field offset): a field added on one side only, or a changed order, shows here and not as a wild pointer on the GPU."""

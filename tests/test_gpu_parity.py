@@ -1938,3 +1938,67 @@ def test_backward_fixed_point_unit_under_an_upstream_outlier(ebos, spike):
     print(f"spike {spike:g}: gradient rel-L2 {rel(got, want):.2e}; in the outlier's tile, away from it: max error {err.max():.3e}, "
           f"mean {err.mean():.3e} against a typical |gradient| of {typical:.3e} ({err.max() / typical:.2e} / {err.mean() / typical:.2e})")
     assert err.max() < 2e-3 * typical
+
+
+@pytest.mark.parametrize("shape,omit,sigma", [((37, 53), False, 3.0), ((37, 53), True, 1.0), ((96, 130), False, 1.0), ((16, 64), True, 3.0),
+                                               ((2, 2), False, 3.0), ((3, 5), True, 0.7), ((260, 346), False, 3.0)])
+def test_blur3_variance_adjoint_pass_vs_oracle(ebos, shape, omit, sigma):
+    """``ebos_blur3_variance_adjoint_f32`` (iwe.blur_sigma > 0 in the solver loop, src/event_image_converter.py:399-404): the
+    partials give mean and variance of the oracle's blurred image (fp64) and z is the oracle's B^T (m . B x) -- autograd of
+    0.5 sum (m . blur(x))^2 -- on sizes that are no multiple of the 16 x 64 tile, with and without the boundary ring, down to 2 x 2;
+    the position weight the backward kernel folds the mean in with is B^T m, i.e. autograd of sum(m . blur(x))."""
+    from event_based_bos_amd import _hip
+    from event_based_bos_amd.solver.fused_loop import blur_taps
+
+    lib = _hip.require_gpu()
+    h, w = shape
+    img = torch.from_numpy(np.random.RandomState(7).gamma(2.0, 3.0, (h, w))).float().cuda()
+    k0, k1 = blur_taps(sigma)
+    n = int(lib.ebos_blur3_variance_partials(h, w))
+    z = torch.empty_like(img)
+    partials = torch.zeros((n, 2), dtype=torch.float64, device="cuda")
+    _hip.check(lib.ebos_blur3_variance_adjoint_f32(img.data_ptr(), h, w, int(omit), k0, k1, z.data_ptr(), partials.data_ptr(), n,
+                                                   _hip.stream_ptr()), "blur3")
+    xo = img.double().cpu().requires_grad_(True)
+    y = O.gaussian_blur3_torch(xo, sigma)
+    ym = y[1:-1, 1:-1] if omit else y
+    if ym.numel() == 0:
+        assert partials.abs().sum().item() == 0.0
+        return
+    s, ss = partials.sum(0).cpu().numpy()
+    assert abs(s - ym.sum().item()) <= 2e-6 * abs(ym.sum().item())
+    assert abs(ss - (ym ** 2).sum().item()) <= 2e-6 * (ym ** 2).sum().item()
+    (0.5 * (ym ** 2).sum()).backward()
+    assert rel(z.cpu().numpy(), xo.grad.numpy()) < 2e-6
+    with pytest.raises(RuntimeError):
+        _hip.check(lib.ebos_blur3_variance_adjoint_f32(img.data_ptr(), h, w, int(omit), k0, k1, z.data_ptr(), partials.data_ptr(), n - 1,
+                                                       _hip.stream_ptr()), "blur3")
+    with pytest.raises(RuntimeError):  # torch refuses to reflect-pad an axis of one sample
+        _hip.check(lib.ebos_blur3_variance_adjoint_f32(img.data_ptr(), 1, h * w, int(omit), k0, k1, z.data_ptr(), partials.data_ptr(), n,
+                                                       _hip.stream_ptr()), "blur3")
+
+
+@pytest.mark.parametrize("omit,pad,sigma,tv", [(False, 0, 1.0, 0.0), (True, 0, 3.0, 0.01), (False, 3, 3.0, 0.0)])
+def test_blurred_patch_loop_first_step_vs_oracle_autograd(ebos, omit, pad, sigma, tv):
+    """One iteration of the native patch-flow loop with iwe.blur_sigma > 0 (combine -> blur image pass -> GRID backward with the
+    position-weighted mean term): loss and d loss / d theta against the fp64 oracle's autograd through upsample -> warp -> vote ->
+    gaussian_blur3 -> var (+ regularisers), with the boundary ring, image padding and both flow regularisers."""
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w, n = 96, 128, 40_000
+    patch = (24, 32)
+    ev = O.synth_events(n, h, w, seed=21)
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+    th0 = np.random.RandomState(22).uniform(-4.0, 4.0, (2, gh, gw))
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile="auto", emit="compact")
+    loop = FusedPatchLoop(plan, patch, patch, G(th0, torch.float32), 1.0, 0.002, tv, omit, pad, "auto", lr=0.1, capacity=4, blur_sigma=sigma)
+    losses = loop.run(1, resident=False)
+    to = torch.from_numpy(th0).float().double().requires_grad_(True)
+    dense = O.upsample_patch_flow(to, (h, w), patch, patch)
+    iwe = O.gaussian_blur3_torch(O.iwe_dense(torch.from_numpy(ev), dense, (h, w), (pad, pad)), sigma)
+    lo = O.image_variance(iwe, omit) + 0.002 * O.flow_norm(dense)
+    if tv:
+        lo = lo + tv * O.image_gradient_tv(dense, torch.ones((h, w), dtype=torch.float64))
+    lo.backward()
+    assert abs(losses[0].item() - lo.item()) <= 1e-5 * abs(lo.item())
+    assert rel(loop.d_theta.cpu().numpy(), to.grad.numpy()) < 1e-3

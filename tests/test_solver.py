@@ -233,22 +233,73 @@ def test_solver_trajectory_matches_cpu_oracle(blur):
         ref.append(loss.item())
     np.testing.assert_allclose(s.history, ref, rtol=2e-3)
     np.testing.assert_allclose(s.patch_flow.cpu().numpy(), theta.detach().numpy(), atol=5e-2)
-    # blur = 0 runs the fused loop -- as ONE resident launch where the geometry allows it (it does here), and the same
-    # trajectory as four launches per iteration with optimizer.resident = False; blur = 1 the autograd loop, graph-replayed
-    assert s.fused == (blur == 0) and s.graphed == (blur == 1)
+    # both run the fused loop (no autograd graph): blur = 0 as ONE resident launch where the geometry allows it (it does here);
+    # blur = 1 natively too -- the blur's image pass between combine and backward (csrc/blur3.h)
+    assert s.fused and not s.graphed
+    assert s.loop_mode in (("resident",) if blur == 0 else ("resident", "pipeline"))
+    cfg_p = dict(cfg, optimizer=dict(cfg["optimizer"], resident=False))
+    s_p = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_p)
+    s_p.estimate(ev)
+    assert s_p.loop_mode == "pipeline"
     if blur == 0:
-        assert s.loop_mode == "resident"
-        cfg_p = dict(cfg, optimizer=dict(cfg["optimizer"], resident=False))
-        s_p = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_p)
-        s_p.estimate(ev)
-        assert s_p.loop_mode == "pipeline"
         np.testing.assert_array_equal(np.array(s.history), np.array(s_p.history))
-        np.testing.assert_allclose(s_p.history, ref, rtol=2e-3)
-    cfg_e = dict(cfg, optimizer=dict(cfg["optimizer"], graph=False))
+    else:  # (the resident loop takes the mean of the blurred image from position-weighted tile sums: agreement to rounding)
+        np.testing.assert_allclose(s.history, s_p.history, rtol=2e-5)
+    np.testing.assert_allclose(s_p.history, ref, rtol=2e-3)
+    # ... and the autograd objective (optimizer.fused: false), graph-replayed and eager: the same trajectory
+    cfg_a = dict(cfg, optimizer=dict(cfg["optimizer"], fused=False))
+    s_a = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_a)
+    s_a.estimate(ev)
+    assert not s_a.fused and s_a.graphed
+    np.testing.assert_allclose(s_p.history, s_a.history, rtol=2e-5)
+    cfg_e = dict(cfg, optimizer=dict(cfg["optimizer"], fused=False, graph=False))
     s_e = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_e)
     s_e.estimate(ev)
-    assert not s_e.graphed
-    np.testing.assert_allclose(s.history, s_e.history, rtol=1e-5)
+    assert not s_e.graphed and not s_e.fused
+    np.testing.assert_allclose(s_a.history, s_e.history, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blur,omit,pad,frac", [(0, False, 0, False), (3, False, 0, False), (1, True, 0, False), (3, False, 2, False),
+                                                (3, False, 0, True), (0, True, 1, True)])
+def test_translation_adam_loop_is_native_and_matches_cpu_oracle(blur, omit, pad, frac):
+    """motion_model 2d-translation + Adam (+ iwe.blur_sigma 3): what the reference's configs/hot_plate1.yaml:47,65,70 selects.  The loop
+    runs natively (ebos_cmax_2dof_solve_f32: no host synchronisation per iteration) and follows the fp64 oracle's Adam loop
+    (warp_2dof -> bilinear vote -> [gaussian_blur3] -> var, torch.optim.Adam).  frac: fractional source coordinates, as the
+    reference's loader produces with data.warp: true (configs/hot_plate1.yaml:7: undistorted events) -- the (x, y, dt) plan format."""
+    import event_based_bos_amd as ebos
+
+    h, w, n_iter = 60, 78, 12
+    ev = moving_points(h, w, 300, 30, np.array([3.0, 2.0]), seed=4)
+    if frac:
+        ev[:, :2] = np.clip(ev[:, :2] + np.random.RandomState(9).uniform(-0.45, 0.45, (len(ev), 2)), 0, [h - 1, w - 1])
+    cfg = load_cfg()["solver"]
+    cfg.update(motion_model="2d-translation", cost_with_weight={"image_variance": 1.0}, omit_boundary=omit, outer_padding=pad,
+               optimizer={"method": "Adam", "n_iter": n_iter, "parameters": {"lr": 0.2}},
+               iwe={"method": "bilinear_vote", "blur_sigma": blur})
+    s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    flow = s.estimate(ev)
+    assert s.fused and s.loop_mode in ("pipeline", "resident")
+    theta = torch.zeros(2, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([theta], lr=0.2)
+    tev = torch.from_numpy(ev)
+    ref = []
+    for _ in range(n_iter):
+        opt.zero_grad()
+        iwe = O.iwe_2dof(tev, theta, (h, w), (pad, pad), "first", True)
+        iwe = O.gaussian_blur3_torch(iwe, float(blur)) if blur else iwe
+        loss = O.image_variance(iwe, omit)
+        loss.backward()
+        opt.step()
+        ref.append(loss.item())
+    np.testing.assert_allclose(s.history, ref, rtol=2e-4)
+    np.testing.assert_allclose(-flow[:, 0, 0], theta.detach().numpy(), atol=2e-3)
+    # the autograd loop (optimizer.fused: false) is the same objective through the general kernels
+    cfg_a = dict(cfg, optimizer=dict(cfg["optimizer"], fused=False))
+    s_a = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_a)
+    s_a.estimate(ev)
+    assert not s_a.fused
+    np.testing.assert_allclose(s.history, s_a.history, rtol=2e-4)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,8 @@
+set -x
+mkdir -p gpurun_out/r05c
+cd /root/repo
+timeout 900 python -m pytest tests/test_solver.py -x -q -m gpu -k "translation or trajectory" > gpurun_out/r05c/test_solver.log 2>&1; tail -15 gpurun_out/r05c/test_solver.log
+python tools/run_cmax.py --config_file tests/golden/config_hot_plate1.json --height 260 --width 346 > gpurun_out/r05c/run_cmax_ref_346x260.json 2> gpurun_out/r05c/err1.txt
+python tools/run_cmax.py --config_file tests/golden/config_hot_plate1.json > gpurun_out/r05c/run_cmax_ref_720x1280.json 2> gpurun_out/r05c/err2.txt
+python tools/run_cmax.py --config_file configs/cmax_hot_plate1.yaml --n-iter 600 > gpurun_out/r05c/run_cmax_own_600.json 2> gpurun_out/r05c/err3.txt
+cat gpurun_out/r05c/*.json; tail -n 3 gpurun_out/r05c/err*.txt
