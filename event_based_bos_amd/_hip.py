@@ -131,6 +131,8 @@ SIGNATURES = {
     "ebos_cmax_resident_mailbox_bytes": (_Z, [_I, _I, _I, _I]),
     "ebos_cmax_resident_supported": (_I, [_P]),
     "ebos_cmax_patch_solve_resident_f32": (_I, [_P, _I, _P, _Z, _D, _P]),
+    "ebos_cmax_2dof_resident_supported": (_I, [_P]),
+    "ebos_cmax_2dof_solve_resident_f32": (_I, [_P, _I, _P, _Z, _D, _P]),
     "ebos_cmax_resident_status": (_I, [_P, _P]),
     "ebos_cmax_resident_iterations": (_I, [_P, _P]),
     "ebos_gauss1d_f32": (_I, _GAUSS),
@@ -161,7 +163,7 @@ class Cmax2dofProblem(C.Structure):
     """``ebos_cmax_2dof_problem`` of include/ebos_hip.h (same field order)."""
     _fields_ = ([(k, _P) for k in ("xs", "ys", "dts", "grp_offsets", "cpix", "cdt", "key_offsets")] + [("n", _L)] +
                 [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "pad_h", "pad_w", "omit_boundary", "splits")] +
-                [("part_table", _P), ("blur_k0", _F), ("blur_k1", _F)] +
+                [("part_table", _P), ("w_variance", _F), ("blur_k0", _F), ("blur_k1", _F)] +
                 [(k, _D) for k in ("lr", "beta1", "beta2", "eps")] +
                 [(k, _P) for k in ("theta", "d_theta", "exp_avg", "exp_avg_sq", "step")] + [("steps_done", _I)] +
                 [(k, _P) for k in ("iwe", "blur_image", "variance", "moments", "upstream", "cost_scratch")] +

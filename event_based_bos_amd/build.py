@@ -23,7 +23,8 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libebos_hip.so")
 
 SOURCES = ["errors.cpp", "warp_kernels.hip", "splat_kernels.hip", "event_plan.hip", "plan_lean.hip", "iwe_fused.hip", "iwe_tiled.hip",
-           "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip", "solver_kernels.hip", "cmax_resident.hip"]
+           "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip", "solver_kernels.hip", "cmax_resident.hip",
+           "cmax_resident_45x80.hip", "cmax_resident_32x32.hip", "cmax_resident_32x64.hip"]
 
 # -munsafe-fp-atomics: hardware global_atomic_add_f32/f64 and ds_add_f32 instead of CAS loops.
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC",
@@ -44,11 +45,12 @@ def _needs_rebuild(target: str, deps: List[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-# per-file flags.  cmax_resident.hip: one kernel with a dozen phases inside an iteration loop -- LICM hoists every phase's
+# per-file flags.  cmax_resident_<tile>.hip (kernel: cmax_resident_core.h): one kernel with a dozen phases inside an iteration loop -- LICM hoists every phase's
 # thread-index arithmetic out of that loop, where it stays live across all phases, is spilled, and comes back through scratch
 # loads each followed by a full vmcnt(0) wait (5.5 us for four pixels per thread in the epilogue).  MachineSink's
 # sink-insts-to-avoid-spills puts those computations back next to their uses: 41 -> 7 spilled VGPRs.
-PER_FILE_FLAGS = {"cmax_resident.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"]}
+_RESIDENT_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills=1"]
+PER_FILE_FLAGS = {f"cmax_resident_{t}.hip": _RESIDENT_FLAGS for t in ("45x80", "32x32", "32x64")}
 
 
 def _compile(src: str, extra: List[str]) -> str:
@@ -72,7 +74,7 @@ def build_library(force: bool = False, keep_temps: bool = False, verbose: bool =
             os.remove(os.path.join(OBJ_DIR, f))
     extra = ["-save-temps=obj"] if keep_temps else []
     extra += os.environ.get("EBOS_EXTRA_FLAGS", "").split()  # e.g. -DEBOS_STAMPS for the diagnostic build
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get("EBOS_BUILD_JOBS", "7")), len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, extra), SOURCES))
     if force or _needs_rebuild(LIB_PATH, objs):
         cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs

@@ -888,6 +888,48 @@ struct OwnSum {
   }
 };
 
+// ... or (bk.k0 != 0) for the contrast of the 3-tap blurred image (blur3.h), the tile's share of sum(m . B x) = sum_p wgt(p) x(p), wgt = B^T m:
+// interior pixels all carry the same weight (summed as above, scaled once at the end), the few rows / columns next to the image's
+// border their own
+struct OwnSumBlur {
+  int R0, C0;
+  int lo, h, w;
+  Blur3 bk;
+  double acc, acc_b;  // interior pixels (unit weight so far), border pixels (weighted)
+  __device__ __forceinline__ void reset() { acc = 0.0, acc_b = 0.0; }
+  __device__ __forceinline__ void operator()(int r, int j, const float4& v) {
+    const int R = R0 + r, C = C0 + 4 * j;
+    if (bk.k0 == 0.0f) {  // (uniform) no blur: OwnSum's exact sum over the valid region
+      if (R < lo || R >= h - lo) return;
+      if (C >= lo && C + 3 < w - lo) {
+        acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      } else {
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (C + k >= lo && C + k < w - lo) acc += (double)e[k];
+      }
+      return;
+    }
+    if (R < 0 || R >= h) return;
+    if (R >= lo + 2 && R < h - lo - 2 && C >= lo + 2 && C + 3 < w - lo - 2) {
+      acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      return;
+    }
+    const float wr = blur3_axis_weight(R, h, lo, bk);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (C + k >= 0 && C + k < w) acc_b += (double)(wr * blur3_axis_weight(C + k, w, lo, bk)) * (double)e[k];
+  }
+  // the weight of an interior pixel: three valid outputs per axis read it
+  __device__ __forceinline__ double total() const {
+    if (bk.k0 == 0.0f) return acc;
+    const float wi = blur3_axis_weight(lo + 2, max(h, 2 * lo + 5), lo, bk);
+    return (double)(wi * wi) * acc + acc_b;
+  }
+};
+
 // Everything of one work item after its set-up barrier: the event loop, the rare spill sweep, the decode pass that writes the slab
 // and checks the fixed-point sums (f64 redo if a field wrapped).
 //   DYN         the LDS window `win` was chosen at run time; halo_tab [tiles] tells the combine pass
@@ -1557,10 +1599,15 @@ struct GradImage {
   // m the valid region of ring `blo`; `lo` is then 0 (the region is part of z and wgt)
   Blur3 bk = {0.0f, 0.0f};
   int blo = 0;
-  __device__ __forceinline__ float cw(int R, int C) const { return bk.k0 != 0.0f ? c * blur3_weight(R, C, h, w, blo, bk) : c; }
+  // the upstream value at (R, C) from the image's value there (the blurred form with explicit roundings: the resident solver
+  // kernel evaluates the same expression on its gathered window)
+  __device__ __forceinline__ float map(float src, int R, int C) const {
+    if (bk.k0 != 0.0f) return __fmaf_rn(a, src, c * blur3_weight(R, C, h, w, blo, bk));
+    return a * src + c;
+  }
   __device__ __forceinline__ float at(int R, int C) const {  // padded coordinates
     if (R < lo || R >= h - lo || C < lo || C >= w - lo) return 0.0f;
-    return a * g[(int64_t)R * w + C] + cw(R, C);
+    return map(g[(int64_t)R * w + C], R, C);
   }
   __device__ __forceinline__ void set_blur(const Blur3& b) {
     if (b.k0 != 0.0f) bk = b, blo = lo, lo = 0;
@@ -2313,7 +2360,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
       const int R = oy + rl + pad_h, C = ox + cl + pad_w;
       const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
-      const float gv = valid ? G.a * src[k] + G.cw(R, C) : 0.0f;
+      const float gv = valid ? G.map(src[k], R, C) : 0.0f;
       if (i < n_px) {
         s_g[i] = gv;
         gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);  // (a NaN counts as Inf: such a tile takes the f64 path)

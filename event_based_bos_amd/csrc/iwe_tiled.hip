@@ -834,6 +834,7 @@ static int cmax_2dof_check(const ebos_cmax_2dof_problem* q) {
   EBOS_REQUIRE(q->n >= 0 && q->H > 0 && q->W > 0 && q->pad_h >= 0 && q->pad_w >= 0 && q->splits >= 0 && q->splits <= 64,
                "ebos_cmax_2dof_solve: bad sizes");
   EBOS_REQUIRE(q->splits != 0 || q->part_table, "ebos_cmax_2dof_solve: splits = 0 (adaptive work items) needs the plan's part_table");
+  EBOS_REQUIRE(q->w_variance != 0.0f, "ebos_cmax_2dof_solve: w_variance is 0 (the device word `upstream` holds -w_variance)");
   EBOS_REQUIRE(q->blur_k0 == 0.0f || (q->blur_k0 > 0.0f && q->blur_k1 > 0.0f && q->blur_image && q->cost_scratch),
                "ebos_cmax_2dof_solve: the blurred contrast needs positive taps, blur_image and cost_scratch");
   EBOS_REQUIRE(q->lr >= 0.0 && q->beta1 >= 0.0 && q->beta1 < 1.0 && q->beta2 >= 0.0 && q->beta2 < 1.0 && q->eps >= 0.0,

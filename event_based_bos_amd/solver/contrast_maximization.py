@@ -376,7 +376,7 @@ class ContrastMaximizationMixin(object):
         if self._translation_loop_fused(plan):
             loop = fused_loop.Fused2dofLoop(plan, theta0, self.contrast_terms["image_variance"], self.omit_boundary, self.pad,
                                             self.halo, self.lr, capacity=max(n_iter, 1), blur_sigma=self.blur_sigma)
-            losses = loop.run(n_iter)
+            losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
             self.fused, self.loop_mode = True, loop.last_run_mode
             self.history += [float(v) for v in losses.cpu()]
             return loop.theta

@@ -39,7 +39,7 @@ from .._hip import check, ptr, stream_ptr
 from ..event_plan import EventPlan, _slab_ok, _workspace
 
 FLOW_TERMS = ("flow_norm", "image_gradient")
-RESIDENT_BLUR = False  # (set once the resident kernel blurs its gathered window)
+RESIDENT_BLUR = True   # the resident kernel blurs its gathered window in LDS (EBOS_RESIDENT_BLUR=0: the blurred loop stays four + one launches)
 
 
 def blur_taps(sigma: float) -> Tuple[float, float]:
@@ -314,7 +314,7 @@ class FusedPatchLoop(object):
         rounding, not bit for bit.)"""
         if not self.sample_grid or self.w_gm or self.splits not in (0, 1) or self.pad != (0, 0):
             return False
-        if self.blur_sigma > 0 and not RESIDENT_BLUR:
+        if self.blur_sigma > 0 and not (RESIDENT_BLUR and os.environ.get("EBOS_RESIDENT_BLUR", "1") != "0"):
             return False
         import ctypes
 
@@ -443,6 +443,45 @@ class Fused2dofLoop(object):
         self.splits = plan.resolve_splits(splits)
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.last_run_mode = "pipeline"
+        self._mailbox = None
+        self.resident_status = 0
+        self.resident_iterations = 0
+        self._resident_refused = False
+
+    def _resident_problem(self) -> "_hip.Cmax2dofProblem":
+        """``problem()`` for the resident launch: a BUILT halo becomes "run-time windows of at most that many pixels" where the plan
+        knows its |dt| bound (as ``FusedPatchLoop._resident_problem``)."""
+        q = self.problem()
+        if self.halo >= 0 and self.plan.dt_bound is not None:
+            q.halo = int(self.lib.ebos_halo_auto(int(self.halo), float(self.plan.dt_bound)))
+        return q
+
+    def resident_supported(self) -> bool:
+        """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_2dof_solve_resident_f32)?  Compact plan, no padding, a tile /
+        halo with a resident kernel."""
+        import ctypes
+
+        if not self.plan.compact or self.splits not in (0, 1) or self.pad != (0, 0):
+            return False
+        if self.blur_sigma > 0 and os.environ.get("EBOS_RESIDENT_BLUR", "1") == "0":
+            return False
+        return bool(self.lib.ebos_cmax_2dof_resident_supported(ctypes.byref(self._resident_problem())))
+
+    def run_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> int:
+        """``n_iter`` iterations as one resident launch; returns its status after synchronising (0, or -101 ... -104 as
+        ``FusedPatchLoop.run_resident``; after -102 ``resident_iterations`` of them are done and handed over)."""
+        import ctypes
+
+        if self._mailbox is None:
+            H, W = self.plan.image_size
+            nb = int(self.lib.ebos_cmax_resident_mailbox_bytes(H, W, self.plan.tile[0], self.plan.tile[1]))
+            self._mailbox = torch.zeros(nb, dtype=torch.uint8, device=self.plan.device)
+        check(self.lib.ebos_cmax_2dof_solve_resident_f32(ctypes.byref(self._resident_problem()), int(n_iter), ptr(self._mailbox),
+                                                         self._mailbox.numel(), float(spin_timeout_s), stream_ptr()),
+              "ebos_cmax_2dof_solve_resident")
+        status = int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), stream_ptr()))
+        self.resident_iterations = int(self.lib.ebos_cmax_resident_iterations(ptr(self._mailbox), stream_ptr()))
+        return status
 
     def problem(self) -> "_hip.Cmax2dofProblem":
         plan = self.plan
@@ -454,6 +493,7 @@ class Fused2dofLoop(object):
         q.H, q.W, q.tile_h, q.tile_w, q.halo = H, W, plan.tile[0], plan.tile[1], self.halo
         q.pad_h, q.pad_w, q.omit_boundary = self.pad[0], self.pad[1], int(self.omit)
         q.splits, q.part_table = self.splits, ptr(plan.part_table)
+        q.w_variance = self.w_var
         q.blur_k0, q.blur_k1 = self.blur
         q.lr, q.beta1, q.beta2, q.eps = self.lr, self.betas[0], self.betas[1], self.eps
         q.theta, q.d_theta, q.exp_avg, q.exp_avg_sq, q.step = (ptr(self.theta), ptr(self.d_theta), ptr(self.exp_avg),
@@ -467,16 +507,34 @@ class Fused2dofLoop(object):
         q.losses, q.losses_cap = ptr(self.losses), self.losses.numel()
         return q
 
-    def run(self, n_iter: int) -> torch.Tensor:
-        """``n_iter`` more Adam iterations; returns their losses [n_iter] (device, no synchronisation)."""
+    def run(self, n_iter: int, resident: Optional[bool] = None) -> torch.Tensor:
+        """``n_iter`` more Adam iterations; returns their losses [n_iter] (device).  ``resident`` (default: whenever
+        ``resident_supported()``; ``EBOS_RESIDENT=0`` turns the default off): the whole loop as ONE resident launch (one
+        synchronisation, to read its status); a launch that ends early leaves the state untouched -- or, after a hand-over in
+        iteration k, that of k iterations -- and the four (five) launches per iteration below run the rest."""
         import ctypes
 
-        n_iter = int(n_iter)
+        n_iter = n_total = int(n_iter)
         if self.t + n_iter > self.losses.numel():
             raise ValueError(f"capacity {self.losses.numel()} < {self.t} steps done + {n_iter}")
         t0 = self.t
+        if resident is None:
+            resident = os.environ.get("EBOS_RESIDENT", "1") != "0" and not self._resident_refused and self.resident_supported()
+        elif resident and not self.resident_supported():
+            raise ValueError("resident=True: " + (self.lib.ebos_last_error() or b"").decode())
+        self.last_run_mode = "pipeline"
         with _hip.on_device(self.plan.device):
+            if resident and n_iter > 0:
+                self.resident_status = self.run_resident(n_iter)
+                self._resident_refused = self.resident_status in (-101, -102, -104)
+                if self.resident_status == 0:
+                    self.t += n_iter
+                    self.last_run_mode = "resident"
+                    return self.losses[t0:t0 + n_iter]
+                if self.resident_status == -102 and self.resident_iterations > 0:
+                    self.t += self.resident_iterations
+                    n_iter -= self.resident_iterations
+                    self.last_run_mode = "resident+pipeline"
             check(self.lib.ebos_cmax_2dof_solve_f32(ctypes.byref(self.problem()), n_iter, stream_ptr()), "ebos_cmax_2dof_solve")
         self.t += n_iter
-        self.last_run_mode = "pipeline"
-        return self.losses[t0:t0 + n_iter]
+        return self.losses[t0:t0 + n_total]

@@ -72,7 +72,7 @@ class WindowPipeline(object):
         plan = store.plan(window[0], window[1], s.orig_image_shape, s.warp_direction, True, tile=s.plan_tile(), device=self.device,
                           deferred=True, emit="compact")  # no host read-back: the host never waits for the GPU until the end;
         # lean build: the fused loop reads only the compact events and offsets (0.09 ms instead of 0.4 per 2 M-event window)
-        if not fused_loop.supported(s.contrast_terms, s.flow_terms, s.blur_sigma, s.opt_method, plan, s.halo):
+        if not fused_loop.supported(s.contrast_terms, s.flow_terms, s.blur_sigma, s.opt_method, plan, s.halo, s.sliding_window):
             raise NotImplementedError("this solver configuration is outside the fused objective family: "
                                       "call solver.estimate(store.load_event(i0, i1)) per window instead")
         return plan
@@ -88,6 +88,7 @@ class WindowPipeline(object):
         thetas = [None] * len(plans)
         losses = [[] for _ in plans]
         statuses = [[] for _ in plans]
+        modes = [[] for _ in plans]
         resident = self.resident if resident is None else resident
         for patch_size, sliding_window, n_iter in s.pyramid_scales():
             gh, gw = patch_grid_shape((H, W), patch_size, sliding_window)
@@ -106,7 +107,7 @@ class WindowPipeline(object):
                         plan, patch_size, sliding_window, init, s.contrast_terms.get("image_variance", 0.0),
                         s.flow_terms.get("flow_norm", 0.0), s.flow_terms.get("image_gradient", 0.0), s.omit_boundary, s.pad,
                         s.halo, s.lr, capacity=n_iter, w_gradient_magnitude=s.contrast_terms.get("gradient_magnitude", 0.0),
-                        theta_mask=mask))
+                        theta_mask=mask, blur_sigma=s.blur_sigma))
             if resident and all(lp.resident_supported() for lp in loops):
                 # every window's loop as ONE resident launch (30 us per iteration at 2 M events against 43 as four launches).  A
                 # resident workgroup owns its CU: launches of different streams run side by side only while all their workgroups fit
@@ -115,7 +116,10 @@ class WindowPipeline(object):
                 for w, lp in enumerate(loops):
                     with torch.cuda.stream(streams[w]):
                         statuses[w].append(lp.enqueue_resident(n_iter))
+                    modes[w].append("resident")
             else:
+                for w in range(len(loops)):
+                    modes[w].append("pipeline")
                 problems = (_hip.CmaxPatchProblem * len(loops))(*[lp.problem() for lp in loops])
                 handles = (ctypes.c_void_p * len(loops))(*[st.cuda_stream for st in streams[:len(loops)]])
                 with _hip.on_device(self.device):
@@ -131,8 +135,8 @@ class WindowPipeline(object):
                       plan.part_table):
                 if t is not None:
                     t.record_stream(streams[w])
-        return [dict(theta=thetas[w], losses=losses[w], patch=last, counts=plans[w].__dict__.get("_counts"), status=statuses[w])
-                for w in range(len(plans))]
+        return [dict(theta=thetas[w], losses=losses[w], patch=last, counts=plans[w].__dict__.get("_counts"), status=statuses[w],
+                     modes=modes[w]) for w in range(len(plans))]
 
     # ------------------------------------------------------------------ driver
     def run(self, store: RawEventStore, windows: Sequence[Tuple[int, int]]) -> List[np.ndarray]:
@@ -161,10 +165,15 @@ class WindowPipeline(object):
                 # of an earlier group is KNOWN to have ended early, the rest of the run takes the four launches
                 if resident and g == 1:
                     # (once per run, one blocking read-back: the first group's verdicts decide for the recording -- the host is
-                    # otherwise so far ahead that no verdict would arrive in time)
+                    # otherwise so far ahead that no verdict would arrive in time.  The status words are copies enqueued on the
+                    # windows' side streams: those are waited for first -- read from the current stream, the words would be
+                    # whatever the allocator left in them)
                     first = [sw for r in pending for sw in r["status"]]
-                    if first and bool((torch.cat(first) != 0).any().item()):
-                        resident = False
+                    if first:
+                        for st in streams:
+                            st.synchronize()
+                        if bool((torch.cat(first) != 0).any().item()):
+                            resident = False
                 solved = self._solve_group(plans, streams, resident=resident)   # asynchronous: returns once enqueued
                 for r, wnd in zip(solved, groups[g]):
                     r["window"] = wnd
@@ -191,6 +200,7 @@ class WindowPipeline(object):
             H, W = self.solver.orig_image_shape
             self.histories = [[float(v) for part in r["losses"] for v in part.cpu()] for r in pending]
             self.patch_flows = [r["theta"] for r in pending]
+            self.window_modes = [list(r["modes"]) for r in pending]   # per window and pyramid scale: how its final solve ran
             self.dropped_events = [int(r["counts"][0].item()) if r["counts"] is not None else 0 for r in pending]
             return [ops.upsample_patch_flow(r["theta"], r["patch"][0], r["patch"][1], (H, W)).cpu().numpy().astype(np.float64)
                     for r in pending]

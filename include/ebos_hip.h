@@ -776,6 +776,8 @@ typedef struct ebos_cmax_2dof_problem {
   int H, W, tile_h, tile_w, halo, pad_h, pad_w, omit_boundary;
   int splits;
   const int32_t* part_table;
+  float w_variance;            /* > 0; the device word `upstream` below holds -w_variance (the four launches read the device word, the
+                                  resident launch the host value) */
   float blur_k0, blur_k1;
   double lr, beta1, beta2, eps;
   float *theta, *d_theta, *exp_avg, *exp_avg_sq;
@@ -819,6 +821,14 @@ size_t ebos_cmax_resident_mailbox_bytes(int H, int W, int tile_h, int tile_w);
 int ebos_cmax_resident_supported(const ebos_cmax_patch_problem* problem);
 int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* problem, int n_iter, void* mailbox, size_t mailbox_bytes,
                                        double spin_timeout_s, ebos_stream_t stream);
+/* The 2-DoF Adam loop (ebos_cmax_2dof_solve_f32) as ONE resident launch: same problem struct, same mailbox / spin cap / status
+ * protocol as ebos_cmax_patch_solve_resident_f32 (ebos_cmax_resident_status / _iterations read its mailbox too).  Compact plans,
+ * splits <= 1, no padding, the tiles (45, 80) / (32, 32) / (32, 64) with halo 32.  Every workgroup sums all tiles' partial pairs of
+ * d loss / d theta itself and steps the two parameters redundantly; with blur_k0 != 0 the gathered window is blurred in LDS
+ * (windows up to ~12 px; larger displacements hand over with -102 like a spill). */
+int ebos_cmax_2dof_resident_supported(const ebos_cmax_2dof_problem* problem);
+int ebos_cmax_2dof_solve_resident_f32(const ebos_cmax_2dof_problem* problem, int n_iter, void* mailbox, size_t mailbox_bytes,
+                                      double spin_timeout_s, ebos_stream_t stream);
 int ebos_cmax_resident_status(const void* mailbox, ebos_stream_t stream);
 /* The iterations the launch completed (synchronises `stream`): n_iter after status 0; after -102 (a tap left the largest LDS
  * window in iteration k >= 1) the k iterations before it -- theta, the optimiser state, the step counter and the losses are then

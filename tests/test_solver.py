@@ -439,9 +439,55 @@ def test_window_pipeline_matches_per_window_estimates(n_concurrent, pyramid):
         assert len(pipe.histories[k]) == len(solver.history) and dev[:10].max() < 1e-4 and dev.max() < 2e-2, dev
         assert np.abs(flows[k] - ref).max() < 0.05
     # configurations outside the fused objective family are refused, not silently run differently
-    cfg2 = dict(cfg, iwe={"method": "bilinear_vote", "blur_sigma": 1})
+    cfg2 = dict(cfg, cost_with_weight={"image_variance": 1.0, "gradient_magnitude": 0.5})
     with pytest.raises(NotImplementedError):
         ebos.solver.WindowPipeline(ebos.solver.collections["cmax"]((h, w), (h, w), solver_config=cfg2)).run(store, windows[:1])
+    # iwe.blur_sigma > 0 is part of the family since round 5 (the blur's image pass inside the native loop)
+    cfg3 = dict(cfg, iwe={"method": "bilinear_vote", "blur_sigma": 1})
+    s3 = ebos.solver.collections["cmax"]((h, w), (h, w), solver_config=cfg3)
+    f3 = ebos.solver.WindowPipeline(s3, n_concurrent=n_concurrent).run(store, windows[:2])
+    for k in range(2):
+        ref = s3.estimate(store.load_event(*windows[k]))
+        assert s3.fused and np.abs(f3[k] - ref).max() < 0.05
+
+
+@pytest.mark.gpu
+def test_window_pipeline_reads_the_first_groups_verdicts_in_order():
+    """the early verdict at the second group is read AFTER the first group's side streams have finished.
+    Windows whose events crowd one tile (> 12 x the average tile, >= 32 k events) make the resident launches of group 0 really
+    end with -104: the later groups must then run as four launches from the start (no second solve), and the results are those
+    of a pipeline that never tried the resident kernel."""
+    import event_based_bos_amd as ebos
+
+    h, w = 260, 346
+    rs = np.random.RandomState(3)
+    cols, rows, ts, ps, bounds = [], [], [], [], [0]
+    for k in range(4):
+        n_c, n_u = 45_000, 15_000
+        r = np.concatenate([rs.randint(100, 125, n_c), rs.randint(0, h, n_u)])
+        c = np.concatenate([rs.randint(200, 222, n_c), rs.randint(0, w, n_u)])
+        rows.append(r); cols.append(c); ps.append(rs.randint(0, 2, len(r)))
+        ts.append(np.sort(rs.randint(0, 20000, len(r))) + 1_000_000 + 30000 * k)
+        bounds.append(bounds[-1] + len(r))
+    store = ebos.data_loader.RawEventStore({"x": np.concatenate(cols), "y": np.concatenate(rows), "t": np.concatenate(ts),
+                                            "p": np.concatenate(ps)})
+    windows = [(bounds[k], bounds[k + 1]) for k in range(4)]
+    cfg = load_cfg()["solver"]
+    cfg.update(patch={"size": [20, 26], "sliding_window": [20, 26]}, cost_with_weight={"image_variance": 1.0, "flow_norm": 0.01},
+               iwe={"method": "bilinear_vote", "blur_sigma": 0}, optimizer={"method": "Adam", "n_iter": 12, "parameters": {"lr": 0.1}})
+    solver = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    pipe = ebos.solver.WindowPipeline(solver, n_concurrent=2)
+    assert pipe.resident and pipe.n_concurrent == 2
+    flows = pipe.run(store, windows)
+    assert pipe.resident_fallbacks == [0, 1], pipe.resident_fallbacks          # group 0: -104, solved again as four launches
+    assert all(m == ["pipeline"] for m in pipe.window_modes), pipe.window_modes  # groups >= 1: never tried resident
+    four = ebos.solver.WindowPipeline(solver, n_concurrent=2, resident=False)
+    flows_four = four.run(store, windows)
+    # (a crowded tile's upstream window is one sharp peak: bwd_fx_unit gives it the f64 accumulators, whose atomics round in the order
+    # they arrive -- the two runs agree to the last bits of a float, not bit for bit)
+    for k in range(4):
+        np.testing.assert_allclose(np.array(pipe.histories[k]), np.array(four.histories[k]), rtol=1e-5)
+        np.testing.assert_allclose(flows[k], flows_four[k], rtol=0, atol=1e-4)
 
 
 @pytest.mark.gpu
@@ -607,6 +653,112 @@ def test_resident_loop_matches_the_four_launch_pipeline(size, n_ev, patch, terms
     a = ref.run(10, resident=True).cpu().numpy()
     b = res.run(10, resident=False).cpu().numpy()
     np.testing.assert_allclose(a, b, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,n_ev,patch,omit,sigma", [
+    ((96, 128), 20_000, (24, 32), False, 1.0),      # 12 tiles of 32 x 32
+    ((260, 346), 100_000, (20, 20), True, 3.0),     # BASELINE configs[0]'s size, with the boundary ring
+    ((720, 1280), 400_000, (24, 32), False, 3.0),   # 256 tiles of 45 x 80
+    ((720, 640), 300_000, (24, 32), True, 1.0),     # 230 tiles of 32 x 64
+])
+def test_resident_loop_with_the_blurred_contrast_matches_the_pipeline(size, n_ev, patch, omit, sigma):
+    """iwe.blur_sigma > 0 inside the ONE-launch loop: the resident kernel gathers its upstream window with a 2 px
+    apron, blurs it and applies the blur's adjoint in LDS (csrc/blur3.h: the functions of the pipeline's image pass); the mean of
+    the blurred image comes from position-weighted tile sums, so the two forms of the loop agree to rounding (1e-6 relative per
+    loss over 200 iterations), not bit for bit.  The raw image that leaves the kernel is the pipeline's bit for bit."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w = size
+    rs = np.random.RandomState(13)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+    theta0 = torch.from_numpy(rs.uniform(-3, 3, (2, gh, gw))).float()
+    n_iter = 200
+
+    def make():
+        return FusedPatchLoop(plan, patch, patch, theta0, 1.0, 0.001, 0.01, omit, halo="auto", lr=0.05, capacity=n_iter + 20, blur_sigma=sigma)
+
+    ref, res = make(), make()
+    assert res.resident_supported(), ebos.load_library().ebos_last_error()
+    l1_ref = ref.run(1, resident=False).cpu().numpy()
+    l1_res = res.run(1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.resident_status == 0 and res.resident_iterations == 1
+    assert torch.equal(ref.iwe, res.iwe)
+    np.testing.assert_allclose(l1_res, l1_ref, rtol=1e-6)
+    np.testing.assert_allclose(res.d_theta.cpu().numpy(), ref.d_theta.cpu().numpy(), rtol=1e-4, atol=1e-8)
+    l_ref = ref.run(n_iter - 1, resident=False).cpu().numpy()
+    l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
+    print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
+    np.testing.assert_allclose(l_res, l_ref, rtol=2e-5)
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_resident_blurred_loop_hands_over_when_the_windows_outgrow_its_lds_region():
+    """The blurred resident loop keeps the raw and the blurred window in the LDS region of the largest upstream window: windows up to
+    ~12 px (45 x 80) / ~16 px (32 x 32).  A flow that needs more ends the launch like a spill -- status -102 with the completed
+    iterations handed over -- and ``run`` continues with the pipeline: the trajectory is the pipeline's to rounding."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w, n_ev, patch = 96, 128, 20_000, (24, 32)
+    rs = np.random.RandomState(12)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    theta0 = torch.full((2, 4, 4), 20.0)   # 20 px: inside the 32 px windows, beyond what the blurred gather keeps in LDS
+    ref = FusedPatchLoop(plan, patch, patch, theta0, 1.0, 0.01, 0.0, halo="auto", lr=0.05, capacity=16, blur_sigma=1.0)
+    res = FusedPatchLoop(plan, patch, patch, theta0, 1.0, 0.01, 0.0, halo="auto", lr=0.05, capacity=16, blur_sigma=1.0)
+    assert res.resident_supported()
+    l_res = res.run(6).cpu().numpy()
+    assert res.resident_status == -102 and res.resident_iterations == 0 and res.last_run_mode == "pipeline"
+    l_ref = ref.run(6, resident=False).cpu().numpy()
+    np.testing.assert_array_equal(l_res, l_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,n_ev,omit,sigma", [((96, 128), 20_000, False, 0.0), ((260, 346), 100_000, True, 3.0),
+                                                  ((720, 1280), 400_000, False, 3.0), ((720, 640), 300_000, False, 0.0)])
+def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma):
+    """The 2-DoF Adam loop (configs/hot_plate1.yaml:47: 2d-translation) as ONE resident launch (ebos_cmax_2dof_solve_resident_f32)
+    against ebos_cmax_2dof_solve_f32: the first image bit for bit, losses / theta / Adam state to rounding over 150 iterations (the
+    tiles' partial pairs are f64 sums of per-lane f64 sums drawn from a dynamic chunk queue: the last bits depend on the draw)."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import Fused2dofLoop
+
+    h, w = size
+    rs = np.random.RandomState(14)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    theta0 = torch.tensor([1.5, -2.5])
+    n_iter = 150
+
+    def make():
+        return Fused2dofLoop(plan, theta0, 1.0, omit, 0, "auto", lr=0.05, capacity=n_iter + 20, blur_sigma=sigma)
+
+    ref, res = make(), make()
+    assert res.resident_supported(), ebos.load_library().ebos_last_error()
+    l1_ref = ref.run(1, resident=False).cpu().numpy()
+    l1_res = res.run(1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.resident_status == 0 and res.resident_iterations == 1
+    assert torch.equal(ref.iwe, res.iwe)
+    np.testing.assert_allclose(l1_res, l1_ref, rtol=1e-6)
+    np.testing.assert_allclose(res.d_theta.cpu().numpy(), ref.d_theta.cpu().numpy(), rtol=1e-4, atol=1e-9)
+    l_ref = ref.run(n_iter - 1, resident=False).cpu().numpy()
+    l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
+    print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
+    np.testing.assert_allclose(l_res, l_ref, rtol=2e-5)
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(res.exp_avg.cpu().numpy(), ref.exp_avg.cpu().numpy(), rtol=2e-2, atol=1e-7)
+    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=2e-5)
+    a = ref.run(10, resident=True).cpu().numpy()      # continued by the other mode
+    b = res.run(10, resident=False).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-5)
 
 
 @pytest.mark.gpu
