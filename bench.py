@@ -571,7 +571,10 @@ def run_config2(R):
         buf = (ctypes.c_float * 100)()
         got = lib.ebos_profile_stop(buf, 100)
         comb = [buf[i] for i in range(got)]
-        extras["combine_kernel_ms"] = {"mean": round(statistics.mean(comb), 4), "min": round(min(comb), 4), "max": round(max(comb), 4)}
+        if comb:
+            extras["combine_kernel_ms"] = {"mean": round(statistics.mean(comb), 4), "min": round(min(comb), 4), "max": round(max(comb), 4)}
+        else:
+            extras["combine_kernel_ms"] = None
 
         # (2) forward + backward of the objective, direct C-ABI calls:
         #     slab forward + variance -> tile-private backward (variance gradient folded in from the moments)
@@ -723,6 +726,33 @@ def run_config2(R):
                     if "us_per_iteration" in ent.get("resident", {}):
                         ent["losses_identical"] = ent["resident"]["last_loss"] == ent["four_launches"]["last_loss"]
                     leg[tag] = ent
+                # ... and what the shipped YAMLs select: iwe.blur_sigma > 0 (configs/cmax_hot_plate1.yaml: dense-flow
+                # patches, blur 1) and the 2-DoF model with Adam and blur 3 (the reference's configs/hot_plate1.yaml:47,65,70), at
+                # BASELINE configs[0]'s size and at 2 M events / 1280x720
+                from event_based_bos_amd.solver.fused_loop import Fused2dofLoop
+
+                for tag, pl, patch in (("100k_events_346x260", plan_s, (20, 20)), ("2M_events", plan2, (24, 32))):
+                    g_h, g_w = ebos.solver.patch_grid_shape(pl.image_size, patch, patch)
+                    for name, make in (("blur1_patch", lambda: FusedPatchLoop(pl, patch, patch, torch.zeros((2, g_h, g_w)), 1.0, 0.001, 0.0,
+                                                                              halo="auto", lr=0.02, capacity=260, blur_sigma=1.0)),
+                                       ("blur3_2dof", lambda: Fused2dofLoop(pl, torch.zeros(2), 1.0, halo="auto", lr=0.02, capacity=260,
+                                                                            blur_sigma=3.0)),
+                                       ("2dof", lambda: Fused2dofLoop(pl, torch.zeros(2), 1.0, halo="auto", lr=0.02, capacity=260))):
+                        ent = {}
+                        for mode, res in (("pipeline", False), ("resident", True)):
+                            sl = make()
+                            if res and not sl.resident_supported():
+                                ent[mode] = {"unsupported": (lib.ebos_last_error() or b"").decode()}
+                                continue
+                            sl.run(10, resident=res)
+                            torch.cuda.synchronize()
+                            t4 = time.perf_counter()
+                            losses = sl.run(200, resident=res)
+                            torch.cuda.synchronize()
+                            ent[mode] = {"us_per_iteration": round((time.perf_counter() - t4) / 200 * 1e6, 1), "ran_as": sl.last_run_mode,
+                                         "last_loss": float(losses[-1])}
+                            del sl
+                        leg[tag][name] = ent
                 leg["us_per_iteration"] = min(v["us_per_iteration"] for v in leg["2M_events"].values()
                                               if isinstance(v, dict) and "us_per_iteration" in v)
                 extras["solver_iteration"] = leg

@@ -29,10 +29,56 @@ __device__ __forceinline__ float blur3_coef(int i, int j, int L, const Blur3& b)
   return folded ? 2.0f * b.k0 : b.k0;
 }
 
+// Away from the border every coefficient is a plain tap (forward: the pixel's 3 x 3 neighbourhood inside the image; adjoint: the
+// pixel two away from the border): the general forms below term for term -- same roundings -- without their ~150 compares and
+// selects per pixel.  A caller whose whole window is interior calls this directly (a uniform choice per tile: the passes over an LDS
+// window are bound by instruction issue).
+template <typename X>
+__device__ __forceinline__ float blur3_interior(X&& x, int r, int c, const Blur3& b) {
+#pragma clang fp contract(off)
+  float y = 0.0f;
+#pragma unroll
+  for (int dc = -1; dc <= 1; ++dc) {
+    float t = 0.0f;
+    t += b.k0 * x(r - 1, c + dc);
+    t += b.k1 * x(r, c + dc);
+    t += b.k0 * x(r + 1, c + dc);
+    y += (dc == 0 ? b.k1 : b.k0) * t;
+  }
+  return y;
+}
+
+// ... four horizontally adjacent interior pixels at once: the three rows as quads (a = columns c - 4 .. c - 1, b = c .. c + 3,
+// c = c + 4 .. c + 7; of a and c one column each is used).  Column sums are shared between neighbouring pixels; every output is
+// blur3_interior's term for term.  All in named registers: arrays indexed through a pointer end up in scratch.
+__device__ __forceinline__ float4 blur3_interior_quad(const float4& ua, const float4& ub, const float4& uc, const float4& ma,
+                                                      const float4& mb, const float4& mc, const float4& da, const float4& db,
+                                                      const float4& dc, const Blur3& b) {
+#pragma clang fp contract(off)
+  auto col = [&](float u, float m, float d) {
+    float t = 0.0f;
+    t += b.k0 * u;
+    t += b.k1 * m;
+    t += b.k0 * d;
+    return t;
+  };
+  const float t0 = col(ua.w, ma.w, da.w), t1 = col(ub.x, mb.x, db.x), t2 = col(ub.y, mb.y, db.y), t3 = col(ub.z, mb.z, db.z),
+              t4 = col(ub.w, mb.w, db.w), t5 = col(uc.x, mc.x, dc.x);
+  auto out = [&](float l, float m, float r) {
+    float y = 0.0f;
+    y += b.k0 * l;
+    y += b.k1 * m;
+    y += b.k0 * r;
+    return y;
+  };
+  return make_float4(out(t0, t1, t2), out(t1, t2, t3), out(t2, t3, t4), out(t3, t4, t5));
+}
+
 // y(r, c) from an accessor x(r, c) that is only asked for positions INSIDE the image
 template <typename X>
 __device__ __forceinline__ float blur3_fwd_at(X&& x, int r, int c, int h, int w, const Blur3& b) {
 #pragma clang fp contract(off)
+  if (r >= 1 && r < h - 1 && c >= 1 && c < w - 1) return blur3_interior(x, r, c, b);
   float y = 0.0f;
 #pragma unroll
   for (int dc = -1; dc <= 1; ++dc) {
@@ -52,6 +98,7 @@ __device__ __forceinline__ float blur3_fwd_at(X&& x, int r, int c, int h, int w,
 template <typename U>
 __device__ __forceinline__ float blur3_adj_at(U&& u, int r, int c, int h, int w, const Blur3& b) {
 #pragma clang fp contract(off)
+  if (r >= 2 && r < h - 2 && c >= 2 && c < w - 2) return blur3_interior(u, r, c, b);  // (no folded coefficient reads this pixel)
   float z = 0.0f;
 #pragma unroll
   for (int dc = -1; dc <= 1; ++dc) {
@@ -80,6 +127,13 @@ __device__ __forceinline__ float blur3_axis_weight(int j, int L, int lo, const B
 }
 __device__ __forceinline__ float blur3_weight(int r, int c, int h, int w, int lo, const Blur3& b) {
 #pragma clang fp contract(off)
+  if (r >= lo + 2 && r < h - lo - 2 && c >= lo + 2 && c < w - lo - 2) {  // three valid outputs per axis read the pixel, none folded
+    float wi = 0.0f;
+    wi += b.k0;
+    wi += b.k1;
+    wi += b.k0;
+    return wi * wi;
+  }
   return blur3_axis_weight(r, h, lo, b) * blur3_axis_weight(c, w, lo, b);
 }
 

@@ -107,8 +107,9 @@ bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
     support(ax, gj, q->W, &lo, &hi);
     if (lo < hi) span_x = std::max(span_x, (hi - 1) / q->tile_w - lo / q->tile_w + 1);
   }
-  if (span_y > kSpan || span_x > kSpan) {
-    set_error("resident solve: a grid cell's support spans %dx%d tiles (<= %d per axis)", span_y, span_x, kSpan);
+  // (cells that span more than kSpan tiles on an axis -- the edge cells of a coarse scale -- are summed tile by tile in S3)
+  if (span_y > 16 || span_x > 16) {
+    set_error("resident solve: a grid cell's support spans %dx%d tiles (<= 16 per axis)", span_y, span_x);
     return false;
   }
   // ... and the cells of a tile's block (tile + apron) sum at most 64 tiles in all (one lane of the waiting wave each)

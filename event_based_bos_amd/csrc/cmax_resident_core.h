@@ -38,6 +38,7 @@
 #include <cstdlib>
 
 #include "iwe_tile_core.h"
+#include "handoff.h"
 
 // Timing builds (tools/ablate_resident.sh): EBOS_ABL is a mask of pieces of the iteration to leave out -- results are WRONG on
 // purpose; what a piece costs where it stands is the difference to the whole.  0 in the product.
@@ -47,24 +48,6 @@
 
 namespace ebos {
 namespace {
-
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) unsigned gu32;
-typedef __attribute__((address_space(1))) float gf32;
-
-__device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long* p) {
-  return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned ld_sc1(const unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load((gf32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store((gf32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// every storing wave, before the barrier behind which the flag is stored (inline asm: invisible to the pass that drops waits)
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // In-kernel phase stamps (diagnostic builds: EBOS_EXTRA_FLAGS=-DEBOS_STAMPS): workgroup b, phase k of the LAST iteration ->
 // g_rstamps[b * 32 + k] (100 MHz clock); read with ebos_debug_read_stamps_resident, tools/stamp_resident.py
@@ -117,17 +100,12 @@ __device__ __forceinline__ bool wave_wait(Pred&& ready, unsigned* status, unsign
   }
 }
 
-// a double as two tagged 8-byte granules {tag, 32 bits}: the data is the flag (cdna guide, R2)
-__device__ __forceinline__ void put_granules(unsigned long long* g, unsigned tag, double v) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  st_sc1(g, ((unsigned long long)tag << 32) | (b & 0xffffffffull));
-  st_sc1(g + 1, ((unsigned long long)tag << 32) | (b >> 32));
-}
-
 constexpr int kRec1Granules = 4; // S1's record: (the tile's share of sum(IWE)) = 2 granules + its window, 32-byte stride
 constexpr int kRecGranules = 8;  // the loss record: (sum of squares, regulariser partial of the previous iteration) = 4 granules, 64-byte stride
 constexpr int kSpan = 4;         // candidate tiles per axis whose partial cell gradients a cell sums (patch_grad_combine_kernel's)
-constexpr int kResElems = 128;   // elements (2 components x cells) of a tile's cell block the resident kernel holds state for
+constexpr int kStoredCands = 128;
+constexpr int kResElems = 256;   // elements (2 components x cells) of a tile's cell block the resident kernel holds state for
+                                 // (tile 45 x 80 with 8 x 8 patches -- the finest scale of the reference's pyramid, patch_eklt_pyramid2.py:55-83 -- has 234)
 
 struct ResidentArgs {
   EvPtrs ev;
@@ -221,6 +199,50 @@ __device__ __forceinline__ void book_loss(const Args& a, int j, int lane, const 
   }
 }
 
+// Which tiles' partial cell gradients cell (gi, gj) sums -- the arithmetic of patch_grad_combine_kernel (flow_upsample.hip): <= kSpan
+// candidate tiles per axis from the cell's conservative pixel support; a candidate counts if its own cell block holds the cell.
+//   cand_a = first candidate tile per axis (2 x 8 bits) | validity masks (2 x 4 bits) | bit 24: tile (ty, tx) is the FIRST that
+//            holds the cell (it writes the cell back at the end) | bit 25: more than kSpan candidates on an axis (a wide cell)
+//   cand_b = the cell's index in each candidate's block, 4 bits each (rows: bits 0..15, columns: 16..31)
+// Recomputed where it is needed (once per iteration, by the <= 256 threads that step a cell element: a few hundred instructions)
+// instead of kept: two more words per element in LDS were what held the cell block at 128 elements.
+template <int TH, int TW>
+__device__ __forceinline__ void cell_candidates(const Axis& ay, const Axis& ax, int gi, int gj, int H, int W, int tiles_y, int tiles_x,
+                                                int ty, int tx, unsigned& cand_a, unsigned& cand_b) {
+  int r_lo, r_hi, c_lo, c_hi;
+  support(ay, gi, H, &r_lo, &r_hi);
+  support(ax, gj, W, &c_lo, &c_hi);
+  const int cty0 = r_lo / TH, ctx0 = c_lo / TW;
+  const int ty_n = r_lo < r_hi ? (r_hi - 1) / TH - cty0 + 1 : 0, tx_n = c_lo < c_hi ? (c_hi - 1) / TW - ctx0 + 1 : 0;
+  const bool too_many = ty_n > kSpan || tx_n > kSpan;
+  int first_ty = -1, first_tx = -1;
+  unsigned yv = 0, xv = 0;
+  cand_b = 0;
+#pragma unroll
+  for (int k = 0; k < kSpan; ++k) {
+    const int cty = min(cty0 + k, tiles_y - 1), ctx = min(ctx0 + k, tiles_x - 1);
+    const int bi0 = lerp_at(ay, cty * TH).i0, bi1 = lerp_at(ay, min(cty * TH + TH, H) - 1).i1;
+    const int bj0 = lerp_at(ax, ctx * TW).i0, bj1 = lerp_at(ax, min(ctx * TW + TW, W) - 1).i1;
+    const bool oky = k < ty_n && gi >= bi0 && gi <= bi1, okx = k < tx_n && gj >= bj0 && gj <= bj1;
+    cand_b |= (unsigned)(oky ? gi - bi0 : 0) << (4 * k);
+    cand_b |= (unsigned)(okx ? gj - bj0 : 0) << (16 + 4 * k);
+    yv |= (unsigned)oky << k;
+    xv |= (unsigned)okx << k;
+    if (oky && first_ty < 0) first_ty = cty;
+    if (okx && first_tx < 0) first_tx = ctx;
+  }
+  if (too_many) {  // a cell at the grid's edge of a coarse scale (its support takes in the replicate padding): plain loops, as
+                   // patch_grad_combine_kernel's second branch -- S3 sums such a cell's tiles one by one, in the same order
+    first_ty = first_tx = -1;
+    for (int cty = cty0; cty < cty0 + ty_n && first_ty < 0; ++cty)
+      if (gi >= lerp_at(ay, cty * TH).i0 && gi <= lerp_at(ay, min(cty * TH + TH, H) - 1).i1) first_ty = cty;
+    for (int ctx = ctx0; ctx < ctx0 + tx_n && first_tx < 0; ++ctx)
+      if (gj >= lerp_at(ax, ctx * TW).i0 && gj <= lerp_at(ax, min(ctx * TW + TW, W) - 1).i1) first_tx = ctx;
+  }
+  cand_a = (unsigned)(cty0 & 255) | ((unsigned)(ctx0 & 255) << 8) | (yv << 16) | (xv << 20) |
+           ((unsigned)(first_ty == ty && first_tx == tx) << 24) | ((unsigned)too_many << 25);
+}
+
 struct Persist {  // one workgroup's iteration-invariant geometry
   int g_first, g_last, beg, end;                   // its slice of the plan (TileRange)
   int gi0, ni, gj0, nj;                            // the block of grid cells tile + apron touch
@@ -266,8 +288,11 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
 
   // ---- once: interpolation tables of tile + apron, the block of cells they touch, this thread's element of it -------------------
   // per element of the cell block (thread e < 2 ni nj), in LDS rather than in registers that would be live across every phase:
-  __shared__ float s_m[kResElems], s_v[kResElems], s_gl[kResElems];  // Adam's exp_avg / exp_avg_sq, the last gradient
-  __shared__ unsigned s_cand_a[kResElems], s_cand_b[kResElems];      // which tiles' partials the element's cell sums (below)
+  __shared__ float s_m[kResElems], s_v[kResElems];                   // Adam's exp_avg / exp_avg_sq (the gradient goes to d_theta as it is formed)
+  __shared__ float s_gl[2];                                          // UNI: the last gradient
+  // which tiles' partials an element's cell sums (cell_candidates): kept for the first kStoredCands elements -- every cell block but
+  // that of the finest pyramid scale at 45 x 80 tiles fits --, recomputed per iteration by the waves beyond (whole waves: no divergence)
+  __shared__ unsigned s_cand_a[kStoredCands], s_cand_b[kStoredCands];
   int n_iter;
   {
     KArgs& a = fresh_args();
@@ -319,39 +344,12 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     const int64_t gidx = ((int64_t)ch * ay.g + gi) * ax.g + gj;
     if (has) {
       s_cells[(ch * kGridCells + ci) * kGridCells + cj] = a.theta[gidx];
-      s_m[e_ % kResElems] = a.exp_avg[gidx], s_v[e_ % kResElems] = a.exp_avg_sq[gidx], s_gl[e_ % kResElems] = 0.0f;
+      s_m[e_ % kResElems] = a.exp_avg[gidx], s_v[e_ % kResElems] = a.exp_avg_sq[gidx];
     }
-    // which tiles' partial cell gradients this cell sums (the arithmetic of patch_grad_combine_kernel, flow_upsample.hip): <= kSpan
-    // candidate tiles per axis from the cell's conservative pixel support; a candidate counts if its own cell block holds the cell.
-    // cand_a = first candidate tile per axis (2 x 8 bits) | validity masks (2 x 4 bits); cand_b = the cell's index in each
-    // candidate's block, 4 bits each (rows: bits 0..15, columns: 16..31)
-    {
-      unsigned cand_a = 0, cand_b = 0;
-      int r_lo, r_hi, c_lo, c_hi;
-      support(ay, gi, H, &r_lo, &r_hi);
-      support(ax, gj, W, &c_lo, &c_hi);
-      const int cty0 = r_lo / TH, ctx0 = c_lo / TW;
-      const int ty_n = r_lo < r_hi ? (r_hi - 1) / TH - cty0 + 1 : 0, tx_n = c_lo < c_hi ? (c_hi - 1) / TW - ctx0 + 1 : 0;
-      if (has && (ty_n > kSpan || tx_n > kSpan || cty0 > 255 || ctx0 > 255)) st_sc1(a.status, (unsigned)RES_GEOMETRY);
-      int first_ty = -1, first_tx = -1;
-      unsigned yv = 0, xv = 0;
-#pragma unroll
-      for (int k = 0; k < kSpan; ++k) {
-        const int cty = min(cty0 + k, tiles_y - 1), ctx = min(ctx0 + k, tiles_x - 1);
-        const int bi0 = lerp_at(ay, cty * TH).i0, bi1 = lerp_at(ay, min(cty * TH + TH, H) - 1).i1;
-        const int bj0 = lerp_at(ax, ctx * TW).i0, bj1 = lerp_at(ax, min(ctx * TW + TW, W) - 1).i1;
-        const bool oky = k < ty_n && gi >= bi0 && gi <= bi1, okx = k < tx_n && gj >= bj0 && gj <= bj1;
-        cand_b |= (unsigned)(oky ? gi - bi0 : 0) << (4 * k);
-        cand_b |= (unsigned)(okx ? gj - bj0 : 0) << (16 + 4 * k);
-        yv |= (unsigned)oky << k;
-        xv |= (unsigned)okx << k;
-        if (oky && first_ty < 0) first_ty = cty;
-        if (okx && first_tx < 0) first_tx = ctx;
-      }
-      // (bit 24: this tile is the first that holds the cell and writes it back at the end)
-      cand_a = (unsigned)(cty0 & 255) | ((unsigned)(ctx0 & 255) << 8) | (yv << 16) | (xv << 20) |
-               ((unsigned)(first_ty == ty && first_tx == tx) << 24);
-      if (has) s_cand_a[e_ % kResElems] = cand_a, s_cand_b[e_ % kResElems] = cand_b;
+    if (has && e_ < kStoredCands) {
+      unsigned cand_a, cand_b;
+      cell_candidates<TH, TW>(ay, ax, gi, gj, H, W, tiles_y, tiles_x, ty, tx, cand_a, cand_b);
+      s_cand_a[e_] = cand_a, s_cand_b[e_] = cand_b;
     }
     if (threadIdx.x == 0) {
       const TileRange tr = tile_range<FMT_COMPACT>(key_offsets, ev, TH * TW, tiles_x, 1);
@@ -552,7 +550,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         // two away reaches into it, and the raw + blurred windows fit the LDS region)
         const int hrm = max(s_wmax[0], kSpecHalo), hcm = max(s_wmax[1], kSpecHalo);
         const int lh = TH + 2 * hrm, lw = TW + 2 * hcm;
-        const bool fits = 2 * hrm + 2 <= TH && 2 * hcm + 4 <= TW && (lh + 4) * (lw + 8) + (lh + 2) * (lw + 2) <= kLHmax * kLWmax;
+        const bool fits = 2 * hrm + 2 <= TH && 2 * hcm + 4 <= TW && (lh + 4) * (lw + 8) + (lh + 2) * (lw + 8) <= kLHmax * kLWmax;
         if (!fits || !halo_complete) {
           if (threadIdx.x == 0) st_sc1(a.status, (unsigned)RES_SPILL | ((unsigned)it << 8));
           s_ok_local = false;
@@ -751,42 +749,116 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       independent_work();
       }
       if (blur_on) {
-        // ---- blurred contrast: raw window (s_g, [wx]) -> masked blurred window (behind it, upstream window + 1 px) -> upstream
-        // window a z + c wgt, z = B^T (m . B x) (s_g again, [wb]): the arithmetic of the pipeline's image pass and backward staging
-        // (blur3_fwd_at / blur3_adj_at / GradImage::map), on what this workgroup gathered
+        // ---- blurred contrast: raw window (s_g, [wx]) -> masked blurred window (behind it: upstream window + 1 row / 4 columns per
+        // side, i.e. the raw window's columns) -> upstream window a z + c wgt, z = B^T (m . B x) (s_g again, [wb]): the arithmetic of
+        // the pipeline's image pass and backward staging (blur3.h, GradImage::map), on what this workgroup gathered.  The passes are
+        // bound by instruction issue, and the iteration by its slowest tile: EVERY tile takes the interior form four pixels per
+        // thread and step (shared column sums, 16-byte LDS accesses; next to the image's border it reads the window's zeros and
+        // computes values nobody wants); a tile on the border then recomputes its few hundred pixels beside the border with the
+        // general form, one per thread -- as a per-pixel choice inside the main loop every wave of a border tile ran both forms and
+        // those 60 of 256 tiles took 17 us where the others took 9 (in-kernel stamps).
         const Blur3 bk = a.blur;
         const int xw = wx.LW(), xoy = tr0 - wx.HR(), xox = tc0 - wx.HC();
-        const int bh = wb.LH() + 2, bw = wb.LW() + 2, boy = tr0 - wb.HR() - 1, box = tc0 - wb.HC() - 1;
+        const int bh = wb.LH() + 2, bw = xw, boy = xoy + 1, box = xox, bq = bw / 4;
         float* s_b = s_g + wx.LH() * xw;
+        // pixels of the rectangle [r0, r0 + nr) x [c0, c0 + nc) OUTSIDE the box [lo_b, H - lo_b) x [lo_b, W - lo_b): top and bottom
+        // strips whole, left and right strips between them; f(r, c) once per pixel, dealt to the threads
+        auto for_border = [&](int r0, int nr, int c0, int nc, int lo_b, auto&& f) {
+          const int rt = min(max(lo_b - r0, 0), nr), rb = min(max(r0 + nr - (H - lo_b), 0), nr - rt);   // rows above / below the box
+          const int cl_ = min(max(lo_b - c0, 0), nc), cr_ = min(max(c0 + nc - (W - lo_b), 0), nc - cl_);  // columns left / right of it
+          for (int i = threadIdx.x; i < (rt + rb) * nc; i += kBlock) {
+            const int k = i / nc, c = c0 + i - k * nc;
+            f(k < rt ? r0 + k : r0 + nr - rb + (k - rt), c);
+          }
+          const int nm = nr - rt - rb, ns = cl_ + cr_;
+          for (int i = threadIdx.x; i < nm * ns; i += kBlock) {
+            const int k = i / ns, q = i - k * ns;
+            f(r0 + rt + k, q < cl_ ? c0 + q : c0 + nc - cr_ + (q - cl_));
+          }
+        };
+        const int vlo = max(lo_px, 1);
         __syncthreads();
         {
-          const float inv_bw = 1.0f / (float)bw;
+          const bool inner = boy >= vlo && boy + bh <= H - vlo && box + 3 >= vlo && box + bw - 3 <= W - vlo;
+          const float inv_q = 1.0f / (float)(bq - 2);
+          const float4* A4 = reinterpret_cast<const float4*>(s_g);
           auto x_at = [&](int r, int c) { return s_g[(r - xoy) * xw + (c - xox)]; };
-          for (int i = threadIdx.x; i < bh * bw; i += kBlock) {
-            const int rl = (int)(((float)i + 0.5f) * inv_bw), cl = i - rl * bw;
-            const int r = boy + rl, c = box + cl;
-            const bool valid = r >= lo_px && r < H - lo_px && c >= lo_px && c < W - lo_px;
-            const float y = valid ? blur3_fwd_at(x_at, r, c, H, W, bk) : 0.0f;
-            s_b[i] = y;
-            if (valid && r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) sq += (double)y * (double)y;  // this tile's own pixels
+          for (int i = threadIdx.x; i < bh * (bq - 2); i += kBlock) {   // (the window's outermost quads: one column each, below)
+            const int rl = (int)(((float)i + 0.5f) * inv_q), cq = i - rl * (bq - 2) + 1;
+            const float4* m = A4 + (rl + 1) * bq + cq;
+            const float4 y4 = blur3_interior_quad(m[-bq - 1], m[-bq], m[-bq + 1], m[-1], m[0], m[1], m[bq - 1], m[bq], m[bq + 1], bk);
+            reinterpret_cast<float4*>(s_b)[rl * bq + cq] = y4;
+            const int r = boy + rl, c = box + 4 * cq;
+            if (r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) {   // this tile's own pixels (the border's: below)
+              if (inner || (r >= vlo && r < H - vlo && c >= vlo && c + 3 < W - vlo)) {
+                sq += ((double)y4.x * (double)y4.x + (double)y4.y * (double)y4.y) + ((double)y4.z * (double)y4.z + (double)y4.w * (double)y4.w);
+              } else if (r >= vlo && r < H - vlo) {
+                const float e4[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (c + k >= vlo && c + k < W - vlo) sq += (double)e4[k] * (double)e4[k];
+              }
+            }
+          }
+          for (int i = threadIdx.x; i < 2 * bh; i += kBlock) {   // the column left / right of the upstream window
+            const int rl = i >> 1, cl = (i & 1) ? bw - 4 : 3;
+            s_b[rl * bw + cl] = blur3_interior(x_at, boy + rl, box + cl, bk);
+          }
+          if (!inner) {  // (uniform) the pixels beside the image's border, and those outside the valid region
+            __syncthreads();
+            for_border(boy, bh, box + 3, bw - 6, vlo, [&](int r, int c) {
+              const bool valid = r >= lo_px && r < H - lo_px && c >= lo_px && c < W - lo_px;
+              const float y = valid ? blur3_fwd_at(x_at, r, c, H, W, bk) : 0.0f;
+              s_b[(r - boy) * bw + (c - box)] = y;
+              if (r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) sq += (double)y * (double)y;
+            });
           }
         }
         __syncthreads();
         {
-          GradImage Gm;  // (only map() is used: the staged value of a pixel from z and its position)
-          Gm.g = nullptr, Gm.a = Ga, Gm.c = Gc, Gm.h = H, Gm.w = W, Gm.lo = lo_px;
-          Gm.set_blur(bk);
-          const int gw = wb.LW(), goy = tr0 - wb.HR(), gox = tc0 - wb.HC();
-          const float inv_gw = 1.0f / (float)gw;
-          auto u_at = [&](int r, int c) { return s_b[(r - boy) * bw + (c - box)]; };
-          for (int i = threadIdx.x; i < wb.LH() * gw; i += kBlock) {
-            const int rl = (int)(((float)i + 0.5f) * inv_gw), cl = i - rl * gw;
-            const int r = goy + rl, c = gox + cl;
-            const bool live = r >= 0 && r < H && c >= 0 && c < W;
-            const float gv = live ? Gm.map(blur3_adj_at(u_at, r, c, H, W, bk), r, c) : 0.0f;
-            s_g[i] = gv;
-            gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
-            gsum_t += fabsf(gv);
+          const int gw = wb.LW(), goy = tr0 - wb.HR(), gox = tc0 - wb.HC(), gq = gw / 4;
+          const int ilo = lo_px + 2;
+          const bool inner = goy >= ilo && goy + wb.LH() <= H - ilo && gox >= ilo && gox + gw <= W - ilo;
+          float wi = 0.0f;  // (blur3_weight's interior value, its additions in its order)
+          wi += bk.k0, wi += bk.k1, wi += bk.k0;
+          const float cw_in = Gc * (wi * wi);
+          const float inv_q = 1.0f / (float)gq;
+          const float4* B4 = reinterpret_cast<const float4*>(s_b);
+          for (int i = threadIdx.x; i < wb.LH() * gq; i += kBlock) {
+            const int rl = (int)(((float)i + 0.5f) * inv_q), cq = i - rl * gq;
+            const float4* m = B4 + (rl + 1) * bq + cq + 1;
+            const float4 z4 = blur3_interior_quad(m[-bq - 1], m[-bq], m[-bq + 1], m[-1], m[0], m[1], m[bq - 1], m[bq], m[bq + 1], bk);
+            // (GradImage::map with the interior weight)
+            const float4 g4 = make_float4(__fmaf_rn(Ga, z4.x, cw_in), __fmaf_rn(Ga, z4.y, cw_in), __fmaf_rn(Ga, z4.z, cw_in), __fmaf_rn(Ga, z4.w, cw_in));
+            reinterpret_cast<float4*>(s_g)[i] = g4;
+            const int r = goy + rl, c = gox + 4 * cq;
+            if (inner || (r >= ilo && r < H - ilo && c >= ilo && c + 3 < W - ilo)) {
+              const float m4 = fmaxf(fmaxf(fabsf(g4.x), fabsf(g4.y)), fmaxf(fabsf(g4.z), fabsf(g4.w)));
+              gmax_t = fmaxf(gmax_t, (g4.x + g4.y + g4.z + g4.w) == (g4.x + g4.y + g4.z + g4.w) ? m4 : INFINITY);
+              gsum_t += (fabsf(g4.x) + fabsf(g4.y)) + (fabsf(g4.z) + fabsf(g4.w));
+            } else if (r >= ilo && r < H - ilo) {
+              const float e4[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (c + k >= ilo && c + k < W - ilo) {
+                  gmax_t = fmaxf(gmax_t, e4[k] == e4[k] ? fabsf(e4[k]) : INFINITY);
+                  gsum_t += fabsf(e4[k]);
+                }
+            }
+          }
+          if (!inner) {  // (uniform) beside the border: folded coefficients, position-dependent weights; outside the image: 0
+            GradImage Gm;  // (only map() is used: the staged value of a pixel from z and its position)
+            Gm.g = nullptr, Gm.a = Ga, Gm.c = Gc, Gm.h = H, Gm.w = W, Gm.lo = lo_px;
+            Gm.set_blur(bk);
+            auto u_at = [&](int r, int c) { return s_b[(r - boy) * bw + (c - box)]; };
+            __syncthreads();
+            for_border(goy, wb.LH(), gox, gw, ilo, [&](int r, int c) {
+              const bool live = r >= 0 && r < H && c >= 0 && c < W;
+              const float gv = live ? Gm.map(blur3_adj_at(u_at, r, c, H, W, bk), r, c) : 0.0f;
+              s_g[(r - goy) * gw + (c - gox)] = gv;
+              gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
+              gsum_t += fabsf(gv);
+            });
           }
         }
       }
@@ -993,15 +1065,24 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         const int ninj = rfl(P.ni) * rfl(P.nj), nj = rfl(P.nj);
         const bool has = (int)threadIdx.x < n_el;
         const int e_ = has ? (int)threadIdx.x : 0;
-        const unsigned cand_a = s_cand_a[e_ % kResElems], cand_b = s_cand_b[e_ % kResElems];
         float m_e = s_m[e_ % kResElems], v_e = s_v[e_ % kResElems];
         const int ch = e_ / ninj, rem = e_ - ch * ninj, ci = rem / nj, cj = rem - ci * nj;
+        unsigned cand_a, cand_b;
+        if (wave * kWave < kStoredCands) {  // (wave-uniform)
+          cand_a = s_cand_a[e_ % kStoredCands], cand_b = s_cand_b[e_ % kStoredCands];
+        } else {
+          const Axis ay = a.gs.ay, ax = a.gs.ax;
+          cell_candidates<TH, TW>(ay, ax, rfl(P.gi0) + ci, rfl(P.gj0) + cj, a.H, a.W, tiles_y, tiles_x, tile / tiles_x,
+                                  tile - (tile / tiles_x) * tiles_x, cand_a, cand_b);
+        }
         const unsigned long long* cp = a.part3;
         const int cty0 = (int)(cand_a & 255u), ctx0 = (int)((cand_a >> 8) & 255u);
         float mask = 1.0f;
         if (a.theta_mask != nullptr) mask = a.theta_mask[(int64_t)(rfl(P.gi0) + ci) * a.gs.ax.g + rfl(P.gj0) + cj];
         float pv[kSpan][kSpan];
-        const bool ok = wave_wait([&]() {
+        const bool wide = has && ((cand_a >> 25) & 1u);
+        float wide_sum = 0.0f;
+        bool ok = wave_wait([&]() {
           bool all = true;
 #pragma unroll
           for (int p = 0; p < kSpan; ++p)
@@ -1009,7 +1090,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             for (int q = 0; q < kSpan; ++q) {
               const int cty = min(cty0 + p, tiles_y - 1), ctx = min(ctx0 + q, tiles_x - 1);
               const int li = (int)((cand_b >> (4 * p)) & 15u), lj = (int)((cand_b >> (16 + 4 * q)) & 15u);
-              const bool use = has && ((cand_a >> (16 + p)) & 1u) && ((cand_a >> (20 + q)) & 1u);
+              const bool use = has && !wide && ((cand_a >> (16 + p)) & 1u) && ((cand_a >> (20 + q)) & 1u);
               unsigned long long g = (unsigned long long)ep << 32;
               if (!(EBOS_ABL & 1024) && __builtin_amdgcn_ballot_w64(use) != 0ull)
                 g = ld_sc1(cp + (((int64_t)(cty * tiles_x + ctx) * 2 + ch) * kGridCells + li) * kGridCells + lj);
@@ -1018,6 +1099,36 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             }
           return all;
         }, a.status, a.cap_ticks);
+        if (__builtin_amdgcn_ballot_w64(wide) != 0ull) {
+          // wide cells (the edge cells of a coarse scale: their support takes in the replicate padding and spans more than kSpan
+          // tiles): every tile of the support whose block holds the cell, one by one -- tile row, tile column: the order of
+          // patch_grad_combine_kernel's plain loops
+          ok = wave_wait([&]() {
+            bool all = true;
+            if (wide) {
+              const Axis ay = a.gs.ay, ax = a.gs.ax;
+              const int gi = rfl(P.gi0) + ci, gj = rfl(P.gj0) + cj;
+              int r_lo, r_hi, c_lo, c_hi;
+              support(ay, gi, a.H, &r_lo, &r_hi);
+              support(ax, gj, a.W, &c_lo, &c_hi);
+              float acc = 0.0f;
+              if (r_lo < r_hi && c_lo < c_hi)
+                for (int cty = r_lo / TH; cty <= (r_hi - 1) / TH; ++cty) {
+                  const int bi0 = lerp_at(ay, cty * TH).i0, bi1 = lerp_at(ay, min(cty * TH + TH, a.H) - 1).i1;
+                  if (gi < bi0 || gi > bi1) continue;
+                  for (int ctx = c_lo / TW; ctx <= (c_hi - 1) / TW; ++ctx) {
+                    const int bj0 = lerp_at(ax, ctx * TW).i0, bj1 = lerp_at(ax, min(ctx * TW + TW, a.W) - 1).i1;
+                    if (gj < bj0 || gj > bj1) continue;
+                    const unsigned long long g = ld_sc1(cp + (((int64_t)(cty * tiles_x + ctx) * 2 + ch) * kGridCells + (gi - bi0)) * kGridCells + (gj - bj0));
+                    all = all && (unsigned)(g >> 32) == ep;
+                    acc += __uint_as_float((unsigned)g);
+                  }
+                }
+              wide_sum = acc;
+            }
+            return all;
+          }, a.status, a.cap_ticks) && ok;
+        }
         if (lane == 0 && !ok) s_ok = 0;
         if (has) {
           float g = 0.0f;
@@ -1025,11 +1136,14 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           for (int p = 0; p < kSpan; ++p)
 #pragma unroll
             for (int q = 0; q < kSpan; ++q) g += (((cand_a >> (16 + p)) & 1u) && ((cand_a >> (20 + q)) & 1u)) ? pv[p][q] : 0.0f;
+          if (wide) g = wide_sum;
           if (a.theta_mask != nullptr) g *= mask;
           float th = s_cells[(ch * kGridCells + ci) * kGridCells + cj];
           adam_update(g, m_e, v_e, th, s_adam[0], s_adam[1], (float)a.beta2, (float)(1.0 - a.beta1), (float)(1.0 - a.beta2), (float)a.eps);
           s_cells[(ch * kGridCells + ci) * kGridCells + cj] = th;
-          s_m[e_ % kResElems] = m_e, s_v[e_ % kResElems] = v_e, s_gl[e_ % kResElems] = g;
+          s_m[e_ % kResElems] = m_e, s_v[e_ % kResElems] = v_e;
+          // (d_theta: the last gradient, by the first tile that holds the cell -- stored as it is formed instead of kept)
+          if ((cand_a >> 24) & 1u) a.d_theta[((int64_t)ch * a.gs.ay.g + rfl(P.gi0) + ci) * a.gs.ax.g + rfl(P.gj0) + cj] = g;
         }
       } else {
         // (workgroup 0, one wave: the loss of iteration it - 2 and the variance of it - 1 -- every workgroup has passed S1 of THIS
@@ -1063,14 +1177,23 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       a.exp_avg_sq[threadIdx.x] = s_v[threadIdx.x];
       a.d_theta[threadIdx.x] = s_gl[threadIdx.x];
     }
-  } else if ((int)threadIdx.x < 2 * rfl(P.ni) * rfl(P.nj) && ((s_cand_a[threadIdx.x % kResElems] >> 24) & 1u)) {
+  } else if ((int)threadIdx.x < 2 * rfl(P.ni) * rfl(P.nj)) {
     const int ninj = rfl(P.ni) * rfl(P.nj), nj = rfl(P.nj);
     const int ch = (int)threadIdx.x / ninj, rem = (int)threadIdx.x - ch * ninj, ci = rem / nj, cj = rem - ci * nj;
     const int64_t gidx = ((int64_t)ch * a.gs.ay.g + rfl(P.gi0) + ci) * a.gs.ax.g + rfl(P.gj0) + cj;
+    unsigned cand_a, cand_b;
+    if ((int)threadIdx.x < kStoredCands) {
+      cand_a = s_cand_a[threadIdx.x], cand_b = s_cand_b[threadIdx.x];
+    } else {
+      const Axis ay = a.gs.ay, ax = a.gs.ax;
+      cell_candidates<TH, TW>(ay, ax, rfl(P.gi0) + ci, rfl(P.gj0) + cj, a.H, a.W, a.tiles_y, a.tiles_x, tile / a.tiles_x,
+                              tile - (tile / a.tiles_x) * a.tiles_x, cand_a, cand_b);
+    }
+    if ((cand_a >> 24) & 1u) {
     a.theta[gidx] = s_cells[(ch * kGridCells + ci) * kGridCells + cj];
     a.exp_avg[gidx] = s_m[threadIdx.x % kResElems];
     a.exp_avg_sq[gidx] = s_v[threadIdx.x % kResElems];
-    a.d_theta[gidx] = s_gl[threadIdx.x % kResElems];
+    }
   }
   if (n_iter <= 0) return;
   // the last iteration's loss: its regulariser partials travel through the `done` granules; workgroup 0 gathers them

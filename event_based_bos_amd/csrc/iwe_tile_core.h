@@ -1299,6 +1299,57 @@ constexpr int kCombineBlock = 256;
 // the LDS images, before any slab has travelled, and must arrive at the mean of this pass bit for bit.
 constexpr int kCombineExactSum = 256;
 
+// The variance without a finalize launch: every combine workgroup stores its partial pair write-through, drains and takes a number
+// from a counter in the workspace; the LAST one reduces all pairs in moments_finalize_block's fixed order (same bits as the
+// one-workgroup launch it replaces, which cost a kernel boundary and ~1 us of its own behind the combine pass) and leaves the
+// counter at zero for the next call.  counter == nullptr: partials only (the caller reduces them).
+constexpr int kFinalizeGroup = 32;
+struct FinalizeIn {
+  unsigned* counter;   // [32 * (1 + groups)] words: the top counter, then one per group of kFinalizeGroup workgroups, 128 bytes apart
+  float* out_var;
+  double* moments;
+  long long n_pixels;
+};
+template <bool SC1 = false>
+__device__ __forceinline__ void moments_finalize_block(const double* __restrict__ partials, int64_t nparts, int64_t m, float* out,
+                                                       double* moments);
+__device__ __forceinline__ void combine_store_partial(double* __restrict__ partials, int64_t b, int64_t nparts, double s, double ss,
+                                                      const FinalizeIn& fin) {
+  __shared__ int s_last_;
+  if (fin.counter == nullptr) {
+    if (threadIdx.x == 0) {
+      partials[2 * b] = s;
+      partials[2 * b + 1] = ss;
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    typedef __attribute__((address_space(1))) double gf64_;
+    typedef __attribute__((address_space(1))) unsigned gu32_;
+    __hip_atomic_store((gf64_*)(partials + 2 * b), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (write-through)
+    __hip_atomic_store((gf64_*)(partials + 2 * b + 1), ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Two levels: same-address atomics serialise at the memory side (~88 per us: ~900 workgroups on ONE counter cost 10 us, the
+    // whole pass ran 8 us longer than with a finalize launch).  Groups of kFinalizeGroup workgroups count on a counter of their
+    // own -- 128 bytes apart, different channels --, the last of each group counts on the top counter.
+    const int64_t g = b / kFinalizeGroup, n_groups = (nparts + kFinalizeGroup - 1) / kFinalizeGroup;
+    const unsigned in_group = (unsigned)min((int64_t)kFinalizeGroup, nparts - g * kFinalizeGroup);
+    gu32_* cg = (gu32_*)(fin.counter + 32 * (1 + g));
+    bool last = __hip_atomic_fetch_add(cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1u;
+    if (last) {
+      __hip_atomic_store(cg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add((gu32_*)fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)n_groups - 1u;
+    }
+    s_last_ = last;
+  }
+  __syncthreads();
+  if (!s_last_) return;
+  if (threadIdx.x == 0) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (coherent loads: the pairs were written by workgroups of other XCDs, and a line of this XCD's L2 that holds a neighbour's pair
+  // from a write of its own would serve the others' stale)
+  moments_finalize_block<true>(partials, nparts, fin.n_pixels, fin.out_var, fin.moments);
+}
+
 // halo_tab (DYN accumulate pass; nullptr otherwise): the window (hr, hc) each tile's slabs were stored with -- candidates are found
 // with the largest window HALO, a candidate whose own window does not reach the pixel is skipped
 template <int TH, int TW, int HALO>
@@ -1306,7 +1357,7 @@ __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
                         int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
                         const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch,
-                        const unsigned* __restrict__ halo_tab) {
+                        const unsigned* __restrict__ halo_tab, FinalizeIn fin) {
   const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
 #ifndef EBOS_PLAIN_SLABS
   const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(slabs, 0xffffffffu);  // (offsets stay below the workspace size: < 4 GiB)
@@ -1368,11 +1419,7 @@ iwe_slab_combine_kernel(const float* __restrict__ slabs, float* spill, int tiles
     double s = in ? (exact ? vd : (double)v) : 0.0, ss = in ? (double)v * (double)v : 0.0;
     __shared__ double red[2 * kCombineBlock / kWave];
     block_sum2(s, ss, red);
-    if (threadIdx.x == 0) {
-      const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-      partials[2 * b] = s;
-      partials[2 * b + 1] = ss;
-    }
+    combine_store_partial(partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, (int64_t)gridDim.x * gridDim.y, s, ss, fin);
   }
 }
 
@@ -1385,7 +1432,7 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
                                                int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo,
                                                double* __restrict__ partials, const int32_t* __restrict__ part_off,
                                                const unsigned* __restrict__ spill_epoch, unsigned epoch,
-                                               const unsigned* __restrict__ halo_tab) {
+                                               const unsigned* __restrict__ halo_tab, const FinalizeIn& fin = FinalizeIn{nullptr, nullptr, nullptr, 0}) {
   const bool spill_used = *spill_epoch == epoch;  // (uniform) some workgroup of THIS call's accumulate pass wrote spill taps
 #ifndef EBOS_PLAIN_SLABS
   const __amdgpu_buffer_rsrc_t all_slabs = slab_rsrc(slabs, 0xffffffffu);  // (offsets stay below the workspace size: < 4 GiB)
@@ -1521,11 +1568,8 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
     }
     __shared__ double red[2 * kCombineBlock / kWave];
     block_sum2(s, ss, red);
-    if (threadIdx.x == 0) {
-      const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-      partials[2 * b] = s;
-      partials[2 * b + 1] = ss;
-    }
+    // (the batched kernel's grid has windows in z: its partials are per window and it passes no counter)
+    combine_store_partial(partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, (int64_t)gridDim.x * gridDim.y, s, ss, fin);
   }
 }
 
@@ -1534,9 +1578,9 @@ __global__ void __launch_bounds__(kCombineBlock)
 iwe_slab_combine4_kernel(const float* __restrict__ slabs, float* spill, int tiles_y, int tiles_x, int splits, int H,
                          int W, int pad_h, int pad_w, float* __restrict__ iwe, int g_lo, double* __restrict__ partials,
                          const int32_t* __restrict__ part_off, const unsigned* __restrict__ spill_epoch, unsigned epoch,
-                         const unsigned* __restrict__ halo_tab) {
+                         const unsigned* __restrict__ halo_tab, FinalizeIn fin) {
   combine4_block<TH, TW, HALO, DYN>(slabs, spill, tiles_y, tiles_x, splits, H, W, pad_h, pad_w, iwe, g_lo, partials, part_off,
-                                    spill_epoch, epoch, halo_tab);
+                                    spill_epoch, epoch, halo_tab, fin);
 }
 
 template <int TH, int TW, int HALO, bool DYN = false>
@@ -1550,6 +1594,7 @@ iwe_slab_combine4_batch_kernel(FwdBatch b, int tiles_y, int tiles_x, int splits,
 }
 
 // one workgroup: partials -> out (unbiased variance), moments (mean, M).  Fixed summation order.
+template <bool SC1>
 __device__ __forceinline__ void moments_finalize_block(const double* __restrict__ partials, int64_t nparts, int64_t m, float* out,
                                                        double* moments) {
   // four (sum, sum of squares) pairs per thread in flight at once: rolled, the loop waited for each 16-byte load in turn -- at the
@@ -1560,7 +1605,16 @@ __device__ __forceinline__ void moments_finalize_block(const double* __restrict_
   for (int64_t base = threadIdx.x; base < nparts; base += 4 * (int64_t)blockDim.x) {
     double2 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = pairs[min(base + k * (int64_t)blockDim.x, nparts - 1)];
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = min(base + k * (int64_t)blockDim.x, nparts - 1);
+      if (SC1) {
+        typedef __attribute__((address_space(1))) double gf64_;
+        v[k].x = __hip_atomic_load((gf64_*)(partials + 2 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[k].y = __hip_atomic_load((gf64_*)(partials + 2 * i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        v[k] = pairs[i];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (base + k * (int64_t)blockDim.x < nparts) {
@@ -2750,7 +2804,7 @@ constexpr int kNumSlabConfigs = sizeof(kSlabConfigs) / sizeof(kSlabConfigs[0]);
 struct SlabLayout {
   int tiles_y, tiles_x, nblk, h, w, combine_blocks;
   size_t slab_cells;   // per workgroup
-  size_t off_spill, off_partials, off_epoch, off_halo, total;
+  size_t off_spill, off_partials, off_epoch, off_halo, off_counters, total;
 };
 
 // `halo` arguments of the C ABI: h >= 0 is a built halo; EBOS_HALO_AUTO(max_halo, q) = -(max_halo + 256 q) asks for run-time
@@ -2782,7 +2836,9 @@ inline SlabLayout slab_layout(int H, int W, int th, int tw, int halo, int splits
   L.off_partials = L.off_spill + align((size_t)L.h * L.w * sizeof(float));
   L.off_epoch = L.off_partials + align((size_t)L.combine_blocks * 2 * sizeof(double));  // SpillEpoch word
   L.off_halo = L.off_epoch + 256;  // [tiles] window (hr, hc) of each tile's slabs (run-time windows)
-  L.total = L.off_halo + align((size_t)L.tiles_y * L.tiles_x * sizeof(unsigned));
+  // counters of the combine pass's last-workgroup reduction (FinalizeIn): 128 bytes each, one per kFinalizeGroup workgroups + the top one
+  L.off_counters = L.off_halo + align((size_t)L.tiles_y * L.tiles_x * sizeof(unsigned));
+  L.total = L.off_counters + align((size_t)(2 + (L.combine_blocks + kFinalizeGroup - 1) / kFinalizeGroup) * 128);
   return L;
 }
 

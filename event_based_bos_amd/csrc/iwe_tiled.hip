@@ -33,6 +33,8 @@
 #include "iwe_tile_core.h"
 
 namespace ebos {
+
+
 namespace {
 
 // SpillEpoch: every forward call gets a number of its own (never 0: a zero-filled workspace matches no call).  Host-side state
@@ -145,6 +147,11 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   int64_t nparts;
   // the solver's patch-grid route sums the image exactly (kCombineExactSum): the resident form of its loop must find the same mean
   const int g_lo = (omit ? 1 : 0) | (grid_src != nullptr ? kCombineExactSum : 0);
+  // want_var == 1: the combine pass's last workgroup reduces the partials itself (FinalizeIn: no finalize launch); its counters
+  // have a section of the workspace (zero between calls)
+  const int lo_ = omit ? 1 : 0;
+  const long long m_valid = (long long)(L.h - 2 * lo_ > 0 ? L.h - 2 * lo_ : 0) * (L.w - 2 * lo_ > 0 ? L.w - 2 * lo_ : 0);
+  const FinalizeIn fin{want_var == 1 ? reinterpret_cast<unsigned*>(ws + L.off_counters) : nullptr, out_var, moments, m_valid};
   if (L.w % 4 == 0 && pad_w % 4 == 0) {
     dim3 gb((L.w / 4 + 63) / 64, (L.h + kCombineRows - 1) / kCombineRows);
     nparts = (int64_t)gb.x * gb.y;
@@ -152,11 +159,11 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
     if (profile_next_pair(&t0, &t1, EBOS_PROFILE_SLAB_COMBINE))
       hipExtLaunchKernelGGL(kc, gb, dim3(kCombineBlock), 0, s, t0, t1, 0, slabs, spill, L.tiles_y,
                             L.tiles_x, splits, H, W, pad_h, pad_w, iwe, g_lo, want_var ? partials : nullptr,
-                            splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch, halo_tab);
+                            splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch, halo_tab, fin);
     else
       kc<<<gb, dim3(kCombineBlock), 0, s>>>(slabs, spill, L.tiles_y, L.tiles_x, splits, H, W, pad_h, pad_w, iwe, g_lo,
                                             want_var ? partials : nullptr, splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch,
-                                            halo_tab);
+                                            halo_tab, fin);
   } else {
     dim3 gb((L.w + kCombineBlock - 1) / kCombineBlock, L.h);
     nparts = (int64_t)gb.x * gb.y;
@@ -164,13 +171,9 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
                                                                             pad_h, pad_w, iwe, g_lo,
                                                                             want_var ? partials : nullptr,
                                                                             splits == 0 ? ev.part_off : nullptr, spill_epoch, epoch,
-                                                                            dyn ? halo_tab : nullptr);
+                                                                            dyn ? halo_tab : nullptr, fin);
   }
-  if (want_var == 1) {  // want_var == 2: the caller reduces the partials itself (ebos_iwe_slab_partials)
-    const int lo = omit ? 1 : 0;
-    const int64_t m = (int64_t)(L.h - 2 * lo > 0 ? L.h - 2 * lo : 0) * (L.w - 2 * lo > 0 ? L.w - 2 * lo : 0);
-    moments_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(partials, nparts, m, out_var, moments);
-  }
+  (void)nparts;  // (want_var == 2: the caller reduces the partials itself, ebos_iwe_slab_partials; 1: the combine pass's last workgroup did)
   return EBOS_OK;
 }
 

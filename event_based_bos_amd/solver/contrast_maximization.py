@@ -115,6 +115,7 @@ class ContrastMaximizationMixin(object):
         # the four launches per iteration.  ``loop_mode`` = what the last fused loop actually ran ("resident" / "pipeline").
         self.resident = ocfg.get("resident", None)
         self.loop_mode: Optional[str] = None
+        self.loop_modes: List[str] = []   # ... of every pyramid scale of the last estimate, coarse to fine
         self.history: List[float] = []
 
     # ------------------------------------------------------------------ objective pieces
@@ -200,7 +201,7 @@ class ContrastMaximizationMixin(object):
 
     def _estimate_patch_flow(self, plan: EventPlan) -> torch.Tensor:
         H, W = self.orig_image_shape
-        self.history, self.patch_flow_per_scale = [], []
+        self.history, self.patch_flow_per_scale, self.loop_modes = [], [], []
         theta = None
         for patch_size, sliding_window, n_iter in self.pyramid_scales():
             gh, gw = patch_grid_shape((H, W), patch_size, sliding_window)
@@ -237,6 +238,7 @@ class ContrastMaximizationMixin(object):
                                              blur_sigma=self.blur_sigma)
             losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
             self.graphed, self.fused, self.loop_mode = loop.graphed, True, loop.last_run_mode
+            self.loop_modes.append(loop.last_run_mode)  # (per pyramid scale, coarse to fine)
             self.history += [float(v) for v in losses.cpu()]
             return loop.theta
         self.fused = False

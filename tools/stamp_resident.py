@@ -17,6 +17,7 @@ ap.add_argument("--size", type=int, nargs=2, default=[720, 1280])
 ap.add_argument("--patch", type=int, nargs=2, default=[24, 32])
 ap.add_argument("--iters", type=int, default=60)
 ap.add_argument("--flow-max", type=float, default=0.0)
+ap.add_argument("--blur", type=float, default=0.0, help="iwe.blur_sigma of the objective (0: none)")
 a = ap.parse_args()
 lib = _hip.require_gpu()
 raw = ctypes.CDLL(os.environ.get("EBOS_HIP_LIBRARY", _hip.LIB_PATH))
@@ -26,7 +27,7 @@ ev = np.stack([rs.randint(0, H, a.events), rs.randint(0, W, a.events), np.sort(r
 plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto", emit="compact")
 gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
 theta0 = torch.zeros((2, gh, gw)) if a.flow_max == 0 else (torch.rand((2, gh, gw), generator=torch.Generator().manual_seed(1)) * 2 - 1) * a.flow_max
-loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 1.0, 0.001, 0.0, lr=0.1, capacity=a.iters + 8, halo="auto")
+loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 1.0, 0.001, 0.0, lr=0.02 if a.blur else 0.1, capacity=a.iters + 8, halo="auto", blur_sigma=a.blur)
 loop.run(a.iters, resident=True)
 torch.cuda.synchronize()
 assert loop.last_run_mode == "resident", loop.resident_status
@@ -42,7 +43,7 @@ phases = [("F0 cells -> window bound, tile flow", 0, 1), ("F1 event loop + decod
           ("   (publish path, if any) + fixed-point unit", 7, 9), ("B1 sweep", 9, 10),
           ("B2 regulariser + tile adjoint (stores issued)", 10, 11), ("   barrier", 11, 12),
           ("S3 + A: poll the partial values, Adam (+ LDS clear, loss bookkeeping)", 12, 13), ("   (end of the iteration)", 13, 14)]
-print(f"{H}x{W}, {a.events} events, tile {plan.tile}, {n} workgroups; last of {a.iters} iterations")
+print(f"{H}x{W}, {a.events} events, tile {plan.tile}, {n} workgroups, blur_sigma {a.blur}; last of {a.iters} iterations")
 tot = st[:, 14] - st[:, 0]
 for nm, i0, i1 in phases:
     d = st[:, i1] - st[:, i0]
