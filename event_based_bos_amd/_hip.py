@@ -73,6 +73,7 @@ SIGNATURES = {
     "ebos_plan_lean_scratch_bytes": (_Z, [_L, _I, _I, _I, _I]),
     "ebos_plan_lean": (_I, [_I, _P, _P, _P, _P, _D, _L, _I, _D, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
     "ebos_plan_compact_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _L, _P]),
+    "ebos_plan_compact_frac_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     "ebos_iwe_dense_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_iwe_dense_tiled_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ebos_tiled_config": (_I, [C.POINTER(C.c_int), _I]),
@@ -161,7 +162,7 @@ class CmaxPatchProblem(C.Structure):
 
 class Cmax2dofProblem(C.Structure):
     """``ebos_cmax_2dof_problem`` of include/ebos_hip.h (same field order)."""
-    _fields_ = ([(k, _P) for k in ("xs", "ys", "dts", "grp_offsets", "cpix", "cdt", "key_offsets")] + [("n", _L)] +
+    _fields_ = ([(k, _P) for k in ("xs", "ys", "dts", "grp_offsets", "cpix", "cdt", "cfx", "cfy", "key_offsets")] + [("n", _L)] +
                 [(k, _I) for k in ("H", "W", "tile_h", "tile_w", "halo", "pad_h", "pad_w", "omit_boundary", "splits")] +
                 [("part_table", _P), ("w_variance", _F), ("blur_k0", _F), ("blur_k1", _F)] +
                 [(k, _D) for k in ("lr", "beta1", "beta2", "eps")] +

@@ -252,8 +252,11 @@ struct Persist {  // one workgroup's iteration-invariant geometry
 // UNI: the 2-DoF motion model (theta = (trans_x, trans_y), x' = x + dt theta, src/warp.py:364-383) instead of the patch grid: no
 // interpolation tables, no cell block; the tiles' partial pairs of d loss / d theta travel as one record per tile, every workgroup
 // sums ALL of them (in the order of the four-launch loop's last kernel) and steps the two parameters itself.
-template <int TH, int TW, int HALO, bool UNI>
+// FRAC (UNI only): the compact plan carries fractional source coordinates (undistorted events: data.warp: true in the reference's
+// configs/hot_plate1.yaml:7): the event loops are the general ones of the compact format, whose groups hold the fractions.
+template <int TH, int TW, int HALO, bool UNI, bool FRAC = false>
 __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_unused) {
+  static_assert(!FRAC || UNI, "fractional source coordinates: the 2-DoF kernels only (the fixed-point backward sweep assumes integer pixels)");
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the stub: the body copies structs out of the constant address space)
   constexpr int kLHmax = TH + 2 * HALO, kLWmax = TW + 2 * HALO;
   constexpr int kCells = acc_cells<TH, TW, HALO, true>();
@@ -422,7 +425,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       // position-weighted)
       OwnSumBlur own{tr.ty * TH - win.HR(), tr.tx * TW - win.HC(), a.omit ? 1 : 0, a.H, a.W, a.blur, 0.0, 0.0};
       if (!(EBOS_ABL & 2048))
-      tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, UNI, !UNI, true, false>(tr, win, UNI ? s_cells : s_flow_f, s_acc, sh, ev, a.H, a.W,
+      tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, UNI, !UNI, true, false, FRAC>(tr, win, UNI ? s_cells : s_flow_f, s_acc, sh, ev, a.H, a.W,
                                                                                   tiles_x, 0, 0, a.slabs, nullptr, nullptr, 0u, nullptr, pre,
                                                                                   NoHook{}, own);
       EBOS_RSTAMP(2);
@@ -1252,10 +1255,10 @@ int order_resident_launches(hipStream_t s, int workgroups, int n_cu, bool after_
 
 namespace {
 
-template <int TH, int TW, int HALO, bool UNI>
+template <int TH, int TW, int HALO, bool UNI, bool FRAC = false>
 int launch_resident(const ResidentArgs& a, void* mailbox, size_t mailbox_total, hipStream_t s) {
   if constexpr (resident_fits<TH, TW, HALO>()) {
-    auto k = cmax_resident_kernel<TH, TW, HALO, UNI>;
+    auto k = cmax_resident_kernel<TH, TW, HALO, UNI, FRAC>;
     constexpr size_t lds = resident_lds_bytes<TH, TW, HALO>();
     if (int rc = reserve_lds(k, lds, "ebos_cmax_solve_resident")) return rc;
     int dev = 0, n_cu = 0, per_cu = 0;
@@ -1337,7 +1340,7 @@ inline ResidentArgs resident_args(const ebos_cmax_2dof_problem* q, int n_iter, v
   const HaloArg ha = decode_halo(q->halo);
   ResidentArgs a{};
   resident_common_args(a, q->H, q->W, q->tile_h, q->tile_w, mailbox, n_iter, q->steps_done, spin_timeout_s, ha);
-  a.ev = EvPtrs{nullptr, nullptr, nullptr, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr};
+  a.ev = EvPtrs{nullptr, nullptr, nullptr, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr, q->cfx, q->cfy};
   a.key_offsets = q->key_offsets;
   a.gs = GridSrc{};
   a.theta = q->theta, a.d_theta = q->d_theta, a.exp_avg = q->exp_avg, a.exp_avg_sq = q->exp_avg_sq;
@@ -1364,6 +1367,8 @@ int resident_tile_launch(const ebos_cmax_patch_problem* q, const ebos_cmax_2dof_
   const int H = q ? q->H : q2->H, W = q ? q->W : q2->W;
   const MailboxLayout m = mailbox_layout(((H + TH - 1) / TH) * ((W + TW - 1) / TW));
   if (q != nullptr) return launch_resident<TH, TW, HALO, false>(resident_args(q, n_iter, mailbox, spin_timeout_s), mailbox, m.total, s);
+  if (q2->cfx != nullptr)  // fractional source coordinates
+    return launch_resident<TH, TW, HALO, true, true>(resident_args(q2, n_iter, mailbox, spin_timeout_s, w_variance2), mailbox, m.total, s);
   return launch_resident<TH, TW, HALO, true>(resident_args(q2, n_iter, mailbox, spin_timeout_s, w_variance2), mailbox, m.total, s);
 }
 

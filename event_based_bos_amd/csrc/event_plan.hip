@@ -298,10 +298,13 @@ compact_offsets_kernel(const int32_t* __restrict__ key_offsets, int tile_px, int
   if (threadIdx.x == 0) grp_offsets[n_tiles] = s_carry;
 }
 
+// cfx / cfy (nullable): the fractional parts x - floor(x), y - floor(y) of the source coordinates per slot -- the compact plan of a
+// window of undistorted events (ebos_plan_compact_frac_f32)
 __global__ void __launch_bounds__(256)
 compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
                     const int32_t* __restrict__ key_offsets, int tile_h, int tile_w, int tiles_x,
-                    const int32_t* __restrict__ grp_offsets, uint16_t* __restrict__ cpix, float* __restrict__ cdt) {
+                    const int32_t* __restrict__ grp_offsets, uint16_t* __restrict__ cpix, float* __restrict__ cdt,
+                    float* __restrict__ cfx = nullptr, float* __restrict__ cfy = nullptr) {
   const int t = blockIdx.x;
   const int tile_px = tile_h * tile_w;
   const int32_t beg = key_offsets[(int64_t)t * tile_px], end = key_offsets[(int64_t)(t + 1) * tile_px];
@@ -310,12 +313,18 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
   for (int64_t o = out0 + threadIdx.x; o < out1; o += blockDim.x) {
     const int64_t src = beg + (o - out0);
     if (src < end) {
-      const int r = (int)xs[src] - r0, c = (int)ys[src] - c0;
+      const float x = xs[src], y = ys[src];
+      const int r = (int)x - r0, c = (int)y - c0;
       cpix[o] = (uint16_t)((r << 8) | c);
       cdt[o] = dts[src];
+      if (cfx != nullptr) {  // (what load_group computes for the (x, y, dt) format: the same numbers)
+        cfx[o] = x - (float)(int)x;
+        cfy[o] = y - (float)(int)y;
+      }
     } else {
       cpix[o] = 0;
       cdt[o] = __builtin_nanf("");
+      if (cfx != nullptr) cfx[o] = 0.0f, cfy[o] = 0.0f;
     }
   }
 }
@@ -586,6 +595,29 @@ int ebos_plan_compact_f32(const float* xs, const float* ys, const float* dts, co
   compact_fill_kernel<<<dim3(n_tiles), dim3(256), 0, s>>>(xs, ys, dts, key_offsets, tile_h, tile_w, tiles_x, grp_offsets, cpix,
                                                           cdt);
   EBOS_CHECK_LAUNCH("ebos_plan_compact");
+  return EBOS_OK;
+}
+
+int ebos_plan_compact_frac_f32(const float* xs, const float* ys, const float* dts, const int32_t* key_offsets, int64_t n, int H,
+                               int W, int tile_h, int tile_w, int32_t* grp_offsets, uint16_t* cpix, float* cdt, float* cfx,
+                               float* cfy, int64_t capacity_slots, ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(key_offsets && grp_offsets && cpix && cdt && cfx && cfy, "ebos_plan_compact_frac: NULL buffer");
+  EBOS_REQUIRE((xs && ys && dts) || n == 0, "ebos_plan_compact_frac: NULL event buffer");
+  EBOS_REQUIRE(H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && tile_h <= 256 && tile_w <= 256 && n >= 0,
+               "ebos_plan_compact_frac: bad sizes (tiles up to 256 x 256)");
+  const int tiles_y = (H + tile_h - 1) / tile_h, tiles_x = (W + tile_w - 1) / tile_w;
+  const int n_tiles = tiles_y * tiles_x;
+  if (capacity_slots < n + 3 * (int64_t)n_tiles + 4) {
+    set_error("ebos_plan_compact_frac: capacity %lld < n + 3 tiles + 4 = %lld", (long long)capacity_slots,
+              (long long)(n + 3 * (int64_t)n_tiles + 4));
+    return EBOS_ERR_SCRATCH;
+  }
+  hipStream_t s = as_stream(stream);
+  compact_offsets_kernel<<<dim3(1), dim3(256), 0, s>>>(key_offsets, tile_h * tile_w, n_tiles, grp_offsets);
+  compact_fill_kernel<<<dim3(n_tiles), dim3(256), 0, s>>>(xs, ys, dts, key_offsets, tile_h, tile_w, tiles_x, grp_offsets, cpix,
+                                                          cdt, cfx, cfy);
+  EBOS_CHECK_LAUNCH("ebos_plan_compact_frac");
   return EBOS_OK;
 }
 

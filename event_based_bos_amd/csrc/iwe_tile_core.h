@@ -79,6 +79,11 @@ struct EvPtrs {
   const int32_t* part_off;
   const int32_t* item_tile;
   const int32_t* item_part;
+  // compact plan with FRACTIONAL source coordinates (undistorted events: data.warp in the reference's configs): the fractions
+  // x - floor(x), y - floor(y) per slot, laid out like cdt; nullptr = integer source pixels.  Read by the general loops of the
+  // compact format (FRAC kernels: the resident 2-DoF loop) -- the lean hot loops assume integer pixels.
+  const float* cfx;
+  const float* cfy;
 };
 
 struct Group {  // 4 consecutive events of one lane
@@ -160,6 +165,11 @@ __device__ __forceinline__ void load_group(Group& g, int32_t grp, const TileRang
       g.cs[e] = tile_c0 + (int)(pp[e] & 255u);
       g.fx[e] = 0.0f;
       g.fy[e] = 0.0f;
+    }
+    if (p.cfx != nullptr) {  // (uniform) fractional source coordinates
+      const float4 FX = reinterpret_cast<const float4*>(p.cfx)[j], FY = reinterpret_cast<const float4*>(p.cfy)[j];
+      g.fx[0] = FX.x, g.fx[1] = FX.y, g.fx[2] = FX.z, g.fx[3] = FX.w;
+      g.fy[0] = FY.x, g.fy[1] = FY.y, g.fy[2] = FY.z, g.fy[3] = FY.w;
     }
   } else {
     const float4 D = reinterpret_cast<const float4*>(p.dts)[j];
@@ -307,12 +317,20 @@ constexpr int kBwdApron = 2;  // pixels of flow the GRID backward kernel keeps a
 struct CGroup {
   unsigned pr[4], pc[4];  // tile-local source row / column
   float dt[4];
+  float fx[4], fy[4];     // fractional part of the source coordinate (0 unless the plan carries fractions: EvPtrs::cfx)
 };
 template <int TH, int TW>
 __device__ __forceinline__ void load_cgroup(CGroup& g, int32_t grp, const TileRange& tr, const EvPtrs& p) {
   const int32_t j = max(min(grp, tr.g_last), tr.g_first);
   const float4 D = reinterpret_cast<const float4*>(p.cdt)[j];
   const uint2 P = reinterpret_cast<const uint2*>(p.cpix)[j];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) g.fx[e] = g.fy[e] = 0.0f;
+  if (p.cfx != nullptr) {  // (uniform)
+    const float4 FX = reinterpret_cast<const float4*>(p.cfx)[j], FY = reinterpret_cast<const float4*>(p.cfy)[j];
+    g.fx[0] = FX.x, g.fx[1] = FX.y, g.fx[2] = FX.z, g.fx[3] = FX.w;
+    g.fy[0] = FY.x, g.fy[1] = FY.y, g.fy[2] = FY.z, g.fy[3] = FY.w;
+  }
   g.dt[0] = D.x; g.dt[1] = D.y; g.dt[2] = D.z; g.dt[3] = D.w;
   g.pr[0] = (P.x >> 8) & 255u; g.pc[0] = P.x & 255u;
   g.pr[1] = P.x >> 24;         g.pc[1] = (P.x >> 16) & 255u;
@@ -670,8 +688,10 @@ enum Pass { PASS_MAIN = 0, PASS_SPILL = 1 };
 
 // UNIFORM: one translation theta for all events (2-DoF model, src/warp.py:364-383: x' = x + dt * theta, i.e. a
 // dense flow of -theta everywhere) -- the two flow gathers disappear.
+// FRAC: the compact plan carries fractional source coordinates (EvPtrs::cfx / cfy): every pass takes the general loop below, whose
+// groups hold the fractions (load_group); the lean loop assumes integer pixels.
 template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false,
-          bool PAIRS = false>
+          bool PAIRS = false, bool FRAC = false>
 __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                      const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                      float* spill, bool* any_spill, const ChunkQueue& queue,
@@ -687,7 +707,7 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
   unsigned long long added = 0;  // FX: integer total this thread put into LDS
   bool spilled = false;
   if (tr.g_first > tr.g_last) return 0;
-  if (FMT == FMT_COMPACT && PASS == PASS_MAIN && !HAS_W)  // the lean hot loop (fixed point, or its exact f64 redo)
+  if (FMT == FMT_COMPACT && PASS == PASS_MAIN && !HAS_W && !FRAC)  // the lean hot loop (fixed point, or its exact f64 redo)
     return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID, DYN, PAIRS>(tr, s_acc, ev, flow, H, W, any_spill, queue, win, pre);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
@@ -751,7 +771,7 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
           atomic_add(&s_acc[cell + dn + 1], (double)(fs * fcq));
         }
       } else if (!inside && wv != 0.0f && f.ok) {  // beyond the halo: spill image (zero-invariant scratch)
-        if (FMT == FMT_COMPACT && !HAS_W) added += 1ull << kFxShift;  // (lean path: the checksum leaves these events out)
+        if (FMT == FMT_COMPACT && !HAS_W && !FRAC) added += 1ull << kFxShift;  // (lean path: the checksum leaves these events out)
         const float w00 = a * b * wv, w10 = f.fr * b * wv, w01 = a * f.fc * wv, w11 = f.fr * f.fc * wv;
         const int R = f.R + pad_h, C = f.C + pad_w;
         const bool r0 = R >= 0 && R < h, r1 = R + 1 >= 0 && R + 1 < h;
@@ -938,8 +958,9 @@ struct OwnSumBlur {
 //   after_loop  called by every wave as it leaves the event loop, before the barrier: the persistent kernel requests the next
 //               window's first chunks there, so that they arrive while this window's image is decoded and stored
 //   own         sees every quad the decode pass stores (NoOwn / OwnSum)
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID, bool DYN, bool ZERO, typename Hook,
-          typename Own>
+//   FRAC        the compact plan carries fractional source coordinates (EvPtrs::cfx): the general loop instead of the lean one
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID, bool DYN, bool ZERO, bool FRAC = false,
+          typename Hook, typename Own>
 __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW, HALO, DYN>& win, const float* flow, double* s_acc,
                                           TileShared& sh, const EvPtrs& ev, int H, int W, int tiles_x, int pad_h, int pad_w,
                                           float* __restrict__ slabs, float* spill, unsigned* __restrict__ spill_epoch, unsigned epoch,
@@ -955,7 +976,7 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
   unsigned long long added;
   // run-time-window kernels: where a source pixel holds several events (>= 4 on average over the tile), neighbouring lanes are
   // given groups two apart (PAIRS), so that the lanes of one wave instruction hold other pixels' events (accumulate_compact_fx)
-  constexpr bool kCanPair = DYN && FMT == FMT_COMPACT && !HAS_W && MODE == ACC_FX;
+  constexpr bool kCanPair = DYN && FMT == FMT_COMPACT && !HAS_W && MODE == ACC_FX && !FRAC;
   // (... and where the window is small: at 30 px flows the plain mapping has few address conflicts to begin with and is 1 us faster)
   // (... or where the pixels are so full -- >= 24 events each: the 50 M-event window of the 2-DoF sweep holds 54 -- that even a 30 px
   // displacement leaves several events of a pixel on one word: 33.9 -> 33.1 ms per 512-hypothesis sweep)
@@ -964,10 +985,10 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
     added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN, kCanPair>(
         tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, nullptr);
   else
-    added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN>(
+    added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN, false, FRAC>(
         tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, pre);
   after_loop();
-  constexpr bool kLeanLoop = FMT == FMT_COMPACT && !HAS_W;  // accumulate_compact_fx: counts nothing per event
+  constexpr bool kLeanLoop = FMT == FMT_COMPACT && !HAS_W && !FRAC;  // accumulate_compact_fx: counts nothing per event
   if (kLeanLoop && threadIdx.x == 0 && tr.g_first <= tr.g_last)  // 2^20 units per event of the slice (padding slots excluded)
     added += (unsigned long long)(min(tr.end, tr.beg + 4 * (tr.g_last - tr.g_first + 1)) - tr.beg) << kFxShift;
   if (spilled) sh.flag[1] = 1;  // benign race: every writer stores 1
@@ -979,8 +1000,8 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
   if (sh.flag[1] && spill_epoch != nullptr && threadIdx.x == 0) *spill_epoch = epoch;  // benign race: every writer stores the same value
   if (sh.flag[1] && spill != nullptr)  // rare: taps beyond the halo go to the spill image with global atomics (lean path: minus their units;
                                        // no spill image: the resident kernel ends its launch on a spill instead)
-    added -= accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID, DYN>(tr, s_acc, ev, flow, H, W, pad_h, pad_w,
-                                                                                              spill, nullptr, queue, win);
+    added -= accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_SPILL, FMT, UNIFORM, GRID, DYN, false, FRAC>(tr, s_acc, ev, flow, H, W, pad_h,
+                                                                                                           pad_w, spill, nullptr, queue, win);
 
   // (the slab stride is the LARGEST window's: a run-time window fills the first LH * LW floats of its slab)
   float4* out = reinterpret_cast<float4*>(slabs + (int64_t)tr.slab * (kLHmax * kLWmax));
@@ -1058,8 +1079,8 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
       for (int i = threadIdx.x; i < kCells; i += kBlock) s_acc[i] = 0.0;
       if (threadIdx.x == 0) sh.next = 2 * (kBlock / kWave);  // the redo draws its chunks afresh
       __syncthreads();
-      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM, GRID, DYN>(tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill,
-                                                                                         nullptr, queue, win);
+      accumulate_slice<TH, TW, HALO, HAS_W, ACC_F64, PASS_MAIN, FMT, UNIFORM, GRID, DYN, false, FRAC>(tr, s_acc, ev, flow, H, W, pad_h, pad_w,
+                                                                                                      spill, nullptr, queue, win);
       __syncthreads();
       f64_flush = true;
     }
@@ -1874,7 +1895,7 @@ __device__ __forceinline__ void bwd_compact_slice(const TileRange& tr, double* s
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float edt = cur.dt[e];
-      const float lx = -edt * fu[e], ly = -edt * fv[e];
+      const float lx = cur.fx[e] - edt * fu[e], ly = cur.fy[e] - edt * fv[e];  // (fractions: 0 for integer source pixels)
       const float r0 = floorf(lx + kEps), c0 = floorf(ly + kEps);
       const float fr = lx - r0, fc = ly - c0;
       const int rl = (int)cur.pr[e] + HR + (int)r0, cl = (int)cur.pc[e] + HC + (int)c0;
@@ -2835,10 +2856,10 @@ inline SlabLayout slab_layout(int H, int W, int th, int tw, int halo, int splits
   L.off_spill = align((size_t)L.nblk * L.slab_cells * sizeof(float));
   L.off_partials = L.off_spill + align((size_t)L.h * L.w * sizeof(float));
   L.off_epoch = L.off_partials + align((size_t)L.combine_blocks * 2 * sizeof(double));  // SpillEpoch word
-  L.off_halo = L.off_epoch + 256;  // [tiles] window (hr, hc) of each tile's slabs (run-time windows)
   // counters of the combine pass's last-workgroup reduction (FinalizeIn): 128 bytes each, one per kFinalizeGroup workgroups + the top one
-  L.off_counters = L.off_halo + align((size_t)L.tiles_y * L.tiles_x * sizeof(unsigned));
-  L.total = L.off_counters + align((size_t)(2 + (L.combine_blocks + kFinalizeGroup - 1) / kFinalizeGroup) * 128);
+  L.off_counters = L.off_epoch + 256;
+  L.off_halo = L.off_counters + align((size_t)(2 + (L.combine_blocks + kFinalizeGroup - 1) / kFinalizeGroup) * 128);  // [tiles] window (hr, hc) of each tile's slabs (run-time windows): the LAST section
+  L.total = L.off_halo + align((size_t)L.tiles_y * L.tiles_x * sizeof(unsigned));
   return L;
 }
 

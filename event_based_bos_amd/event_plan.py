@@ -178,6 +178,12 @@ class EventPlan:
     def _compact_ptrs(self):
         return (ptr(self.grp_offsets), ptr(self.cpix), ptr(self.cdt)) if self.compact else (None, None, None)
 
+    @property
+    def frac_compact(self):
+        """(grp_offsets, cpix, cdt, cfx, cfy) of a plan whose source coordinates are fractional (undistorted events) -- the compact
+        layout with the fractions per slot, read by the resident 2-DoF loop --, or None."""
+        return self.__dict__.get("_frac")
+
     # ------------------------------------------------------------------------------------------
     @staticmethod
     def build(events: torch.Tensor, image_size: Tuple[int, int], direction: Union[str, float] = "first",
@@ -321,12 +327,28 @@ class EventPlan:
             with _hip.on_device(dev):
                 check(lib.ebos_plan_compact_f32(ptr(xs), ptr(ys), ptr(dts), ptr(key_offsets), kept, H, W, th, tw,
                                                 ptr(grp_offsets), ptr(cpix), ptr(cdt), cap, stream_ptr()), "ebos_plan_compact")
+        frac = None
+        if fractional > 0 and th <= 256 and tw <= 256:
+            # fractional source coordinates (undistorted events): the compact layout WITH the fractions per slot -- the same
+            # information as (x, y, dt), in the form the resident 2-DoF loop reads (run-time windows, one launch); every other
+            # operator keeps the (x, y, dt) arrays: ``compact`` stays False
+            n_tiles = tiles_y * tiles_x
+            cap = kept + 3 * n_tiles + 8
+            f_grp = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            f_pix = torch.zeros(cap, dtype=torch.int16, device=dev)
+            f_dt = torch.full((cap,), float("nan"), dtype=torch.float32, device=dev)
+            f_x, f_y = torch.zeros(cap, dtype=torch.float32, device=dev), torch.zeros(cap, dtype=torch.float32, device=dev)
+            with _hip.on_device(dev):
+                check(lib.ebos_plan_compact_frac_f32(ptr(xs), ptr(ys), ptr(dts), ptr(key_offsets), kept, H, W, th, tw, ptr(f_grp),
+                                                     ptr(f_pix), ptr(f_dt), ptr(f_x), ptr(f_y), cap, stream_ptr()), "ebos_plan_compact_frac")
+            frac = (f_grp, f_pix, f_dt, f_x, f_y)
         part_table = torch.empty(5 * tiles_y * tiles_x + 1, dtype=torch.int32, device=dev)
         with _hip.on_device(dev):
             check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), PART_FIXED_EVENTS, ptr(part_table), stream_ptr()),
                   "ebos_plan_parts")
         out = EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt, part_table, self.dt_bound)
+        out.__dict__["_frac"] = frac  # (grp_offsets, cpix, cdt, cfx, cfy) of a window with fractional source coordinates, or None
         out.__dict__["_counts"], out.__dict__["_deferred"] = counts, bool(deferred)
         out.__dict__["_parts_used"] = None if deferred else int(part_table[tiles_y * tiles_x].item())
         return out

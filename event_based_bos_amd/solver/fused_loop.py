@@ -454,14 +454,18 @@ class Fused2dofLoop(object):
         q = self.problem()
         if self.halo >= 0 and self.plan.dt_bound is not None:
             q.halo = int(self.lib.ebos_halo_auto(int(self.halo), float(self.plan.dt_bound)))
+        fr = self.plan.frac_compact
+        if not self.plan.compact and fr is not None:  # fractional source coordinates: the compact layout with the fractions
+            q.grp_offsets, q.cpix, q.cdt, q.cfx, q.cfy = (ptr(t) for t in fr)
         return q
 
     def resident_supported(self) -> bool:
-        """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_2dof_solve_resident_f32)?  Compact plan, no padding, a tile /
-        halo with a resident kernel."""
+        """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_2dof_solve_resident_f32)?  Compact plan -- of integer source
+        pixels, or with the fractions of undistorted events (``EventPlan.frac_compact``) --, no padding, a tile / halo with a
+        resident kernel."""
         import ctypes
 
-        if not self.plan.compact or self.splits not in (0, 1) or self.pad != (0, 0):
+        if not (self.plan.compact or self.plan.frac_compact is not None) or self.splits not in (0, 1) or self.pad != (0, 0):
             return False
         if self.blur_sigma > 0 and os.environ.get("EBOS_RESIDENT_BLUR", "1") == "0":
             return False

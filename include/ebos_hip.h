@@ -267,6 +267,13 @@ int ebos_plan_lean(int source, const void* events, const int16_t* col, const int
 int ebos_plan_compact_f32(const float* xs, const float* ys, const float* dts, const int32_t* key_offsets, int64_t n,
                           int H, int W, int tile_h, int tile_w, int32_t* grp_offsets, uint16_t* cpix, float* cdt,
                           int64_t capacity_slots, ebos_stream_t stream);
+/* The compact plan of a window whose source coordinates are FRACTIONAL (undistorted events: data.warp: true in the reference's
+ * configs/hot_plate1.yaml:7; the flow is looked up at the truncated coordinate, src/warp.py:334): cpix / cdt as above from floor(x),
+ * floor(y), plus cfx / cfy [capacity_slots] f32 = x - floor(x), y - floor(y) per slot (0 in padding slots).  Same information as
+ * the (x, y, dt) arrays it is made from; read by the resident 2-DoF launch (ebos_cmax_2dof_problem::cfx / cfy). */
+int ebos_plan_compact_frac_f32(const float* xs, const float* ys, const float* dts, const int32_t* key_offsets, int64_t n,
+                               int H, int W, int tile_h, int tile_w, int32_t* grp_offsets, uint16_t* cpix, float* cdt,
+                               float* cfx, float* cfy, int64_t capacity_slots, ebos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused hot path, dense flow: A3 + A7 in one pass, nothing materialised
@@ -771,6 +778,9 @@ typedef struct ebos_cmax_2dof_problem {
   const int32_t* grp_offsets;
   const uint16_t* cpix;
   const float* cdt;
+  const float *cfx, *cfy;      /* compact plan of FRACTIONAL source coordinates (ebos_plan_compact_frac_f32): x - floor(x), y - floor(y)
+                                  per slot, laid out like cdt; NULL = integer source pixels.  Read by the resident launch only (the four
+                                  launches then take xs / ys / dts) */
   const int32_t* key_offsets;
   int64_t n;
   int H, W, tile_h, tile_w, halo, pad_h, pad_w, omit_boundary;

@@ -725,19 +725,25 @@ def test_resident_blurred_loop_hands_over_when_the_windows_outgrow_its_lds_regio
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,n_ev,omit,sigma", [((96, 128), 20_000, False, 0.0), ((260, 346), 100_000, True, 3.0),
-                                                  ((720, 1280), 400_000, False, 3.0), ((720, 640), 300_000, False, 0.0)])
-def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma):
+@pytest.mark.parametrize("size,n_ev,omit,sigma,frac", [((96, 128), 20_000, False, 0.0, False), ((260, 346), 100_000, True, 3.0, False),
+                                                       ((720, 1280), 400_000, False, 3.0, False), ((720, 640), 300_000, False, 0.0, False),
+                                                       ((260, 346), 100_000, False, 3.0, True), ((720, 1280), 400_000, True, 0.0, True)])
+def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma, frac):
     """The 2-DoF Adam loop (configs/hot_plate1.yaml:47: 2d-translation) as ONE resident launch (ebos_cmax_2dof_solve_resident_f32)
     against ebos_cmax_2dof_solve_f32: the first image bit for bit, losses / theta / Adam state to rounding over 150 iterations (the
-    tiles' partial pairs are f64 sums of per-lane f64 sums drawn from a dynamic chunk queue: the last bits depend on the draw)."""
+    tiles' partial pairs are f64 sums of per-lane f64 sums drawn from a dynamic chunk queue: the last bits depend on the draw).
+    frac: fractional source coordinates (undistorted events, data.warp: true in configs/hot_plate1.yaml:7) -- the resident launch
+    reads the compact layout with the fractions per slot (EventPlan.frac_compact), the four launches the (x, y, dt) arrays."""
     import event_based_bos_amd as ebos
     from event_based_bos_amd.solver.fused_loop import Fused2dofLoop
 
     h, w = size
     rs = np.random.RandomState(14)
     ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    if frac:
+        ev[:, :2] = np.clip(ev[:, :2] + rs.randint(0, 64, (n_ev, 2)) / 64.0, 0, [h - 1, w - 1])
     plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    assert plan.compact == (not frac) and (plan.frac_compact is not None) == frac
     theta0 = torch.tensor([1.5, -2.5])
     n_iter = 150
 
@@ -756,13 +762,17 @@ def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma
     l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
     assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
     print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
-    np.testing.assert_allclose(l_res, l_ref, rtol=2e-5)
-    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=1e-3)
-    np.testing.assert_allclose(res.exp_avg.cpu().numpy(), ref.exp_avg.cpu().numpy(), rtol=2e-2, atol=1e-7)
-    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=2e-5)
+    # (frac: the four launches form x' = x + dt theta from the ABSOLUTE coordinate in f32, the resident loop from the fraction --
+    # positions differ by ~1e-4 px at x ~ 1000, and 150 normalised Adam steps on structure-less events carry that along)
+    np.testing.assert_allclose(l_res, l_ref, rtol=1e-4 if frac else 2e-5)
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=0.2 if frac else 1e-3)
+    if not frac:
+        np.testing.assert_allclose(res.exp_avg.cpu().numpy(), ref.exp_avg.cpu().numpy(), rtol=2e-2, atol=1e-7)
+    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=1e-4 if frac else 2e-5)
     a = ref.run(10, resident=True).cpu().numpy()      # continued by the other mode
     b = res.run(10, resident=False).cpu().numpy()
-    np.testing.assert_allclose(a, b, rtol=2e-5)
+    if not frac:
+        np.testing.assert_allclose(a, b, rtol=2e-5)
 
 
 @pytest.mark.gpu
