@@ -217,7 +217,9 @@ def pmc_traffic(kernel):
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None, {"traffic_note": "profiles/pmc_latest.json missing"}
-    stamp = {"traffic_commit": rec.get("commit"), "traffic_kernel": rec.get("kernel_template"),
+    # (traffic_kernel: the kernel the traffic figure belongs to -- the entry asked for, with the template it was collected on)
+    tmpl = (rec.get("kernels", {}).get(kernel, {}) or {}).get("kernel_template") or rec.get("kernel_template")
+    stamp = {"traffic_commit": rec.get("commit"), "traffic_kernel": f"{kernel} [{tmpl}]" if tmpl else kernel,
              "traffic_source_blob": rec.get("source_blob_sha")}
     now = git_blob_sha(os.path.join(ROOT, DOMINANT_SOURCE))
     if rec.get("source_blob_sha") is None or rec.get("source_blob_sha") != now:

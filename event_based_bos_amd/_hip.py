@@ -119,6 +119,7 @@ SIGNATURES = {
     "ebos_iwe_patch_tiled_bwd_blur_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P,
                                                _P, _Z, _P, _F, _F, _P, _P, _L, _L, _P, _P, _F, _F, _P]),
     "ebos_blur3_variance_partials": (_L, [_I, _I]),
+    "ebos_cmax_cost_scratch_bytes": (_Z, [_I, _I]),
     "ebos_blur3_variance_adjoint_f32": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _L, _P]),
     "ebos_cmax_2dof_solve_f32": (_I, [_P, _I, _P]),
     "ebos_patch_grad_combine_adam_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _D, _D, _D, _D, _I, _P, _P,

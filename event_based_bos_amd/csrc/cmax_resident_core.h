@@ -73,6 +73,14 @@ enum ResidentStatus : unsigned {
                        // with 2 M events in a Gaussian blob of sigma 100 px
 };
 
+// The launch's verdict: the FIRST one stands (with plain stores a spill could overwrite a timeout, and the workgroups
+// that read one verdict left without the write-back the others, reading the other, performed).
+__device__ __forceinline__ void raise_status(unsigned* status, unsigned code) {
+  typedef __attribute__((address_space(1))) unsigned gu32s;
+  unsigned expected = 0u;  // RES_OK
+  __hip_atomic_compare_exchange_strong((gu32s*)status, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // A whole wave polls: lane-wise predicate, true when every lane's holds.  Bounded: every 32 polls the status word and the clock
 // (100 MHz) are looked at; false = the launch is over (status set by this wave or seen set).
 // A spill (status = RES_SPILL | iteration << 8) ends only the wait for THAT iteration's records (`spill_it`: the iteration a wait
@@ -92,7 +100,7 @@ __device__ __forceinline__ bool wave_wait(Pred&& ready, unsigned* status, unsign
         if (spill_it >= 0 && (int)(st >> 8) == spill_it) return false;
       } else if (st != RES_OK) return false;
       if (now - t0 > cap_ticks) {
-        if ((threadIdx.x & (kWave - 1)) == 0) st_sc1(status, (unsigned)RES_TIMEOUT);
+        if ((threadIdx.x & (kWave - 1)) == 0) raise_status(status, (unsigned)RES_TIMEOUT);
         return false;
       }
     }
@@ -340,7 +348,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     const int gi0 = s_lerp[0].i0, ni = s_lerp[PH - 1].i1 - gi0 + 1;
     const int gj0 = s_lerp[PH].i0, nj = s_lerp[PH + PW - 1].i1 - gj0 + 1;
     const bool has = (int)threadIdx.x < 2 * ni * nj;  // this thread steps element (ch, gi0 + ci, gj0 + cj) of the cell block
-    if (2 * ni * nj > kResElems && threadIdx.x == 0) st_sc1(a.status, (unsigned)RES_GEOMETRY);
+    if (2 * ni * nj > kResElems && threadIdx.x == 0) raise_status(a.status, (unsigned)RES_GEOMETRY);
     const int e_ = has ? (int)threadIdx.x : 0;
     const int ch = e_ / (ni * nj), ci = (e_ - ch * (ni * nj)) / nj, cj = e_ - ch * (ni * nj) - ci * nj;
     const int gi = gi0 + ci, gj = gj0 + cj;
@@ -368,7 +376,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       support(ax, gj0 + nj - 1, W, &dummy, &hi);
       P.rect_tx0 = lo / TW;
       P.rect_nx = lo < hi ? min((hi - 1) / TW, tiles_x - 1) - P.rect_tx0 + 1 : 0;
-      if (P.rect_ny * P.rect_nx > kWave) st_sc1(a.status, (unsigned)RES_GEOMETRY);
+      if (P.rect_ny * P.rect_nx > kWave) raise_status(a.status, (unsigned)RES_GEOMETRY);
       s_ok = 1;
       s_imb[0] = s_imb[1] = 0;
       s_reg[0] = s_reg[1] = 0.0;
@@ -435,7 +443,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       __syncthreads();
     }
     if (sh.flag[1]) {  // (uniform) a tap left the largest window: the four-launch pipeline's spill path handles that flow
-      if (threadIdx.x == 0) st_sc1(fresh_args().status, (unsigned)RES_SPILL | ((unsigned)it << 8));
+      if (threadIdx.x == 0) raise_status(fresh_args().status, (unsigned)RES_SPILL | ((unsigned)it << 8));
       done_ok = false;
       break;
     }
@@ -555,13 +563,17 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         const int lh = TH + 2 * hrm, lw = TW + 2 * hcm;
         const bool fits = 2 * hrm + 2 <= TH && 2 * hcm + 4 <= TW && (lh + 4) * (lw + 8) + (lh + 2) * (lw + 8) <= kLHmax * kLWmax;
         if (!fits || !halo_complete) {
-          if (threadIdx.x == 0) st_sc1(a.status, (unsigned)RES_SPILL | ((unsigned)it << 8));
+          if (threadIdx.x == 0) raise_status(a.status, (unsigned)RES_SPILL | ((unsigned)it << 8));
           s_ok_local = false;
         }
       }
-      if (it == 0 && a.max_imbalance > 0.0f && s_imb[0] >= 512 &&   // (>= 32 k events on the fullest tile: below that nothing is slow)
-          (float)s_imb[0] * (float)n_tiles > a.max_imbalance * (float)s_imb[1]) {
-        if (threadIdx.x == 0) st_sc1(a.status, (unsigned)RES_IMBALANCED);
+      // (>= 32 k events on the fullest tile: below that nothing is slow.  Second rule, from profiles/r05m_skew_solver.json: a fullest
+      // tile of >= 120 k events that is more than 3 x the average one -- 10 M events in a blob of sigma 200 px: 242 k, 6.2 x -- took
+      // 315 us per iteration here against 116 with the pipeline's split tiles; at 2 M events the same blob, 48 k, still wins here)
+      const float imb_ratio = (float)s_imb[0] * (float)n_tiles / fmaxf((float)s_imb[1], 1.0f);
+      if (it == 0 && a.max_imbalance > 0.0f && s_imb[0] >= 512 &&
+          (imb_ratio > a.max_imbalance || (s_imb[0] >= 1875 && imb_ratio > 0.25f * a.max_imbalance))) {
+        if (threadIdx.x == 0) raise_status(a.status, (unsigned)RES_IMBALANCED);
         s_ok_local = false;
       }
     }
@@ -1204,6 +1216,8 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
   if (threadIdx.x == 0) put_granules(a.done + (size_t)tile * 2, (unsigned)n_iter, s_reg[1]);
   if (blockIdx.x != 0) return;
   double ar = 0.0;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
   if (wave * kWave < n_tiles) {
     const int k = wave * kWave + lane;
     const unsigned long long* rec = a.done + (size_t)min(k, n_tiles - 1) * 2;
@@ -1213,8 +1227,16 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       return (unsigned)(g0 >> 32) == (unsigned)n_iter && (unsigned)(g1 >> 32) == (unsigned)n_iter;
     }, a.status, a.cap_ticks);
     if (ok && k < n_tiles) ar = __builtin_bit_cast(double, (g0 & 0xffffffffull) | (g1 << 32));
+    if (!ok && lane == 0) s_bad = 1;
   }
   ar = block_sum(ar, s_red);
+  if (s_bad) {
+    // Some workgroup never published its `done` granule for these n_iter iterations: it left on another verdict (a wait past its
+    // cap while the others handed over after a spill) and did NOT write its cells back -- the state in memory is a mixture.  Say
+    // so: the completed-iterations word reads -1 and the host refuses to continue from it (ebos_cmax_resident_iterations).
+    if (threadIdx.x == 0) st_sc1(a.status + 1, 0xffffffffu);
+    return;
+  }
   // (every workgroup has left the loop: the last iteration's records are complete)
   if (wave == 1) book_loss(a, n_iter - 1, lane, s_hist, s_adam);
   __syncthreads();

@@ -471,6 +471,12 @@ int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit
 
 int64_t ebos_blur3_variance_partials(int h, int w) { return ebos_gradient_magnitude_fused_partials(h, w); }
 
+size_t ebos_cmax_cost_scratch_bytes(int h, int w) {
+  const size_t tiles = (size_t)ebos_gradient_magnitude_fused_partials(h, w);
+  const size_t a = ebos::cost_scratch(1), b = 16 * tiles + 64;  // (the blur's pairs: 16 B per tile; the Sobel pass's values: 8)
+  return a > b ? a : b;
+}
+
 int ebos_blur3_variance_adjoint_f32(const float* image, int h, int w, int omit_boundary, float k0, float k1, float* z_image,
                                     double* partials, int64_t n_partials, ebos_stream_t stream) {
   using namespace ebos;

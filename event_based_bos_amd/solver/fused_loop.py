@@ -138,8 +138,7 @@ class FusedPatchLoop(object):
         self.upstream = torch.full((1,), -(self.w_gm or self.w_var), **f32)  # loss = -w * contrast
         self.d_iwe = torch.empty_like(self.iwe) if self.w_gm else None
         # (the Sobel pass's value partials: ebos_gradient_magnitude_fused_f32)
-        self.cost_scratch = (torch.empty(max(int(self.lib.ebos_cost_scratch_bytes(1)),
-                                             16 * int(self.lib.ebos_gradient_magnitude_fused_partials(H + 2 * self.pad[0], W + 2 * self.pad[1]))),
+        self.cost_scratch = (torch.empty(int(self.lib.ebos_cmax_cost_scratch_bytes(H + 2 * self.pad[0], W + 2 * self.pad[1])),
                                          dtype=torch.uint8, device=dev) if (self.w_gm or self.blur_sigma > 0) else None)
         self.losses = torch.zeros(max(int(capacity), 1), **f32)
         self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
@@ -322,9 +321,13 @@ class FusedPatchLoop(object):
 
     def enqueue_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> torch.Tensor:
         """Enqueue ``n_iter`` iterations as one resident launch on the current stream WITHOUT waiting for it; returns the launch's
-        status word as a 1-element int32 tensor (a stream-ordered copy: 0 = completed, else 1 timeout / 2 spill / 3 geometry --
-        theta and the optimiser state are then unchanged).  For callers that keep several windows in flight and look at the
-        status when they collect results (solver.WindowPipeline); everybody else: ``run``."""
+        status word as a 1-element int32 tensor (a stream-ordered copy).  0 = completed.  Otherwise the low 8 bits say why it ended
+        early -- 1 a wait passed its cap, 2 a tap left the largest LDS window (bits 8 and up: the iteration k it happened in), 3
+        geometry, 4 a crowded tile -- and theta / exp_avg / exp_avg_sq / step / losses are unchanged, EXCEPT after a spill in
+        iteration k >= 1: the launch then handed over the state of its k completed iterations (``ebos_cmax_resident_iterations``).
+        ``self.t`` is advanced by ``n_iter`` here regardless: a caller that sees a non-zero word must not continue this loop
+        object (solver.WindowPipeline solves such a window again from its start); everybody else: ``run``, which books what
+        really happened."""
         import ctypes
 
         if self._mailbox is None:
@@ -340,9 +343,11 @@ class FusedPatchLoop(object):
 
     def run_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> int:
         """``n_iter`` iterations as one resident launch; returns its status after synchronising: 0, or a negative code when the
-        launch ended early (-101 a wait passed the cap, -102 a tap left the largest LDS window, -103 geometry, -104 one tile far more
-        crowded than the average one: the pipeline's work items split such tiles) -- theta and the
-        optimiser state are then UNCHANGED and the caller runs the four-launch pipeline (``run`` does)."""
+        launch ended early (-101 a wait passed the cap, -102 a tap left the largest LDS window -- or, with the blurred contrast, the
+        windows outgrew the blur's LDS region --, -103 geometry, -104 one tile far more crowded than the average one: the
+        pipeline's work items split such tiles).  theta and the optimiser state are then UNCHANGED -- except after -102 in iteration
+        k >= 1: ``self.resident_iterations`` = k iterations were completed and handed over (state, losses, step counter are those of
+        k iterations) -- and the caller runs the four-launch pipeline for the rest (``run`` does)."""
         t, mode = self.t, self.last_run_mode
         self.enqueue_resident(n_iter, spin_timeout_s)
         self.t, self.last_run_mode = t, mode   # (``run`` books the iterations once it has seen the status)
@@ -350,6 +355,9 @@ class FusedPatchLoop(object):
         # iterations the launch completed: all of them, none -- or, after a spill in iteration k >= 1, the k before it (the state IS
         # that of k iterations then: the launch hands over instead of discarding its work)
         self.resident_iterations = int(self.lib.ebos_cmax_resident_iterations(ptr(self._mailbox), stream_ptr()))
+        if self.resident_iterations < 0:
+            raise RuntimeError("resident launch ended with two different verdicts among its workgroups (a wait past its cap AND a "
+                               "hand-over): theta and the optimiser state are partly written -- rebuild the loop from a saved state")
         return status
 
     def run(self, n_iter: int, native: bool = True, resident: Optional[bool] = None) -> torch.Tensor:
@@ -485,6 +493,9 @@ class Fused2dofLoop(object):
               "ebos_cmax_2dof_solve_resident")
         status = int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), stream_ptr()))
         self.resident_iterations = int(self.lib.ebos_cmax_resident_iterations(ptr(self._mailbox), stream_ptr()))
+        if self.resident_iterations < 0:
+            raise RuntimeError("resident launch ended with two different verdicts among its workgroups: theta and the optimiser "
+                               "state are partly written -- rebuild the loop from a saved state")
         return status
 
     def problem(self) -> "_hip.Cmax2dofProblem":

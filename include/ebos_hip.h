@@ -615,6 +615,10 @@ int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit
  * the slab combine pass's partials), and z_image [h, w] = B^T (m . y), the part of d var(y) / d x that is linear in x
  * (m = the valid region, omit_boundary).  h, w >= 2 (torch refuses to reflect-pad an axis of one sample). */
 int64_t ebos_blur3_variance_partials(int h, int w);
+/* cost_scratch of ebos_cmax_patch_problem / ebos_cmax_2dof_problem for an image of h x w pixels (padding included): enough for the
+ * value partials of the fused Sobel pass (w_gradient_magnitude != 0) and for the blur's partial pairs (blur_k0 != 0).  ABI 2:
+ * ebos_cost_scratch_bytes(1), which ABI 1 documented for this buffer, is too small for the Sobel partials of images beyond ~0.5 MP. */
+size_t ebos_cmax_cost_scratch_bytes(int h, int w);
 int ebos_blur3_variance_adjoint_f32(const float* image, int h, int w, int omit_boundary, float k0, float k1, float* z_image,
                                     double* partials, int64_t n_partials, ebos_stream_t stream);
 
@@ -732,8 +736,8 @@ typedef struct ebos_cmax_patch_problem {
   int steps_done;              /* Adam steps already applied to theta (the first iteration of a solve is step steps_done + 1) */
   float *dense, *d_dense, *d_reg, *iwe, *variance;
   float* d_iwe;                /* [H + 2 pad_h, W + 2 pad_w]; nullable unless w_gradient_magnitude != 0 */
-  void* cost_scratch;          /* >= 8 * ebos_gradient_magnitude_fused_partials(H + 2 pad_h, W + 2 pad_w) bytes (the fused Sobel
-                                  pass's value partials); nullable unless w_gradient_magnitude != 0 */
+  void* cost_scratch;          /* >= ebos_cmax_cost_scratch_bytes(H + 2 pad_h, W + 2 pad_w) (the fused Sobel pass's value partials / the
+                                  blur's partial pairs); nullable unless w_gradient_magnitude != 0 or blur_k0 != 0 */
   size_t cost_scratch_bytes;
   double* moments;
   const float* upstream;
@@ -822,7 +826,11 @@ int ebos_cmax_2dof_solve_f32(const ebos_cmax_2dof_problem* problem, int n_iter, 
  *                                  checks tiles <= CUs x occupancy and orders resident launches of one device behind each other --
  *                                  but if a wait still passes the cap (another process's resident grid interleaved with this
  *                                  one), or a tap leaves the largest LDS window (the spill path of the four-launch pipeline),
- *                                  the launch ENDS instead of hanging and leaves theta / exp_avg / exp_avg_sq / step untouched.
+ *                                  the launch ENDS instead of hanging and leaves theta / exp_avg / exp_avg_sq / step untouched --
+ *                                  except after a spill in iteration k >= 1, when it hands over the state of its k completed
+ *                                  iterations (ebos_cmax_resident_iterations = k; continue with ebos_cmax_patch_solve_f32 and
+ *                                  steps_done + k).  The first verdict of a launch stands; should its workgroups have left on
+ *                                  two different ones, ebos_cmax_resident_iterations returns -1: the state is partly written.
  *   ebos_cmax_resident_status      synchronises `stream`, returns EBOS_OK or a negative code (-101 spin cap, -102 spill,
  *                                  -103 geometry, -104 one tile holds more than 12 x the average tile's events -- the kernel's own
  *                                  verdict in its first iteration; EBOS_RESIDENT_MAX_IMBALANCE overrides, 0 = never); on a negative

@@ -26,9 +26,14 @@ H, W = 720, 1280
 def window(n, sigma, rs):
     if sigma is None:
         r, c = rs.randint(0, H, n), rs.randint(0, W, n)
-    else:
-        r = np.clip(np.rint(rs.normal(H / 2, sigma * H / W, n)), 0, H - 1)
-        c = np.clip(np.rint(rs.normal(W / 2, sigma, n)), 0, W - 1)
+    else:  # a Gaussian blob around the image centre; samples outside the sensor are drawn again (clipping them would pile
+        # thousands of events onto single border pixels: a hot-pixel benchmark, not a schlieren object)
+        r, c = np.empty(0), np.empty(0)
+        while len(r) < n:
+            rr, cc = np.rint(rs.normal(H / 2, sigma * H / W, n)), np.rint(rs.normal(W / 2, sigma, n))
+            ok = (rr >= 0) & (rr < H) & (cc >= 0) & (cc < W)
+            r, c = np.concatenate([r, rr[ok]]), np.concatenate([c, cc[ok]])
+        r, c = r[:n], c[:n]
     return np.stack([r, c, np.sort(rs.uniform(0, 0.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
 
 
