@@ -695,7 +695,8 @@ template <int TH, int TW, int HALO, bool HAS_W, int MODE, int PASS, int FMT, boo
 __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                      const float* __restrict__ flow, int H, int W, int pad_h, int pad_w,
                                                      float* spill, bool* any_spill, const ChunkQueue& queue,
-                                                     const Win<TH, TW, HALO, DYN>& win, const CRaw* pre = nullptr) {
+                                                     const Win<TH, TW, HALO, DYN>& win, const CRaw* pre = nullptr,
+                                                     float wscale = kFxScale) {
   const int LH = win.LH(), LW = win.LW(), PT = win.P();
   unsigned long long* s_fx = reinterpret_cast<unsigned long long*>(s_acc);
   const int h = H + 2 * pad_h, w = W + 2 * pad_w;
@@ -751,7 +752,8 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
           // |x| < 2^22 -- one FMA + one integer subtract per tap instead of fma + floor + convert
           constexpr float kMagic = 12582912.0f;
           constexpr int kMagicBits = 0x4B400000;
-          const float as = a * (ws * kFxScale), fs = frq * (ws * kFxScale);
+          const float wsc = HAS_W ? wscale : kFxScale;  // (weights: normalised by the slice's max |w|, TileShared::wscale)
+          const float as = a * (ws * wsc), fs = frq * (ws * wsc);
           const unsigned q00 = (unsigned)(__float_as_int(__fmaf_rn(as, b, kMagic)) - kMagicBits);
           const unsigned q10 = (unsigned)(__float_as_int(__fmaf_rn(fs, b, kMagic)) - kMagicBits);
           const unsigned q01 = (unsigned)(__float_as_int(__fmaf_rn(as, fcq, kMagic)) - kMagicBits);
@@ -879,6 +881,10 @@ struct TileShared {
   int flag[2];             // [0] fixed-point overflow, [1] some event left the LDS window
   unsigned next;           // chunk queue of the lean loop
   float bound[2 * kBlock / kWave];  // DYN: per-wave maxima of |u|, |v| over the tile
+  // per-event weights in fixed point (HAS_W, ACC_FX): a weight enters as w / max |w| of the work item's slice in the 2^20 unit
+  // (wscale = 2^20 / max |w|) and the decode pass gives the factor back (wdec = max |w| / 2^20): 2 ds_add_u64 per event instead of
+  // 4 ds_add_f64.  A slice with a negative (or non-finite) weight runs in f64 from the start (accumulate_tile).
+  float wscale, wdec;
 };
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
@@ -986,7 +992,7 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
         tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, nullptr);
   else
     added = accumulate_slice<TH, TW, HALO, HAS_W, MODE, PASS_MAIN, FMT, UNIFORM, GRID, DYN, false, FRAC>(
-        tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, pre);
+        tr, s_acc, ev, flow, H, W, pad_h, pad_w, spill, &spilled, queue, win, pre, HAS_W ? sh.wscale : kFxScale);
   after_loop();
   constexpr bool kLeanLoop = FMT == FMT_COMPACT && !HAS_W && !FRAC;  // accumulate_compact_fx: counts nothing per event
   if (kLeanLoop && threadIdx.x == 0 && tr.g_first <= tr.g_last)  // 2^20 units per event of the slice (padding slots excluded)
@@ -1024,7 +1030,7 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
     uint2* pa = reinterpret_cast<uint2*>(s_acc);
     uint2* pb = pa + LH * PT / 2;
     unsigned long long decoded = 0;
-    constexpr float kInv = (float)kFxInv;
+    const float kInv = HAS_W ? sh.wdec : (float)kFxInv;  // (a compile-time constant without weights)
     // cells 4j..4j+3 of row r <- A words 2j, 2j+1 and B words 2j-1, 2j, 2j+1 (pair (4j-1, 4j): its lo field belongs to the previous quad)
     auto decode_quad = [&](int r, int j, int slab_quad) {
       const int wrow = r * (PT / 2);
@@ -1156,6 +1162,41 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   if (threadIdx.x == 0) {
     sh.next = 2 * (kBlock / kWave);
     sh.chk = 0ull;
+    sh.wscale = kFxScale;
+    sh.wdec = (float)kFxInv;
+  }
+  if (HAS_W && MODE == ACC_FX) {  // max |w| over this work item's events: the unit its weights are quantised in (TileShared)
+    float am = 0.0f;
+    bool odd = false;  // a negative, NaN or Inf weight: the unsigned fields cannot hold it -- the slice takes the exact f64 pass
+    for (int32_t g = tr.g_first + threadIdx.x; g <= tr.g_last; g += kBlock) {
+      const float4 Wv = reinterpret_cast<const float4*>(ev.w)[g];
+      const float ww[4] = {Wv.x, Wv.y, Wv.z, Wv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int32_t i = 4 * g + e;
+        if (i >= tr.beg && i < tr.end) {
+          am = fmaxf(am, fabsf(ww[e]));
+          odd |= !(ww[e] >= 0.0f && ww[e] < 3.0e38f);
+        }
+      }
+    }
+    am = wave_max_nonneg(am);
+    const bool any_odd = __builtin_amdgcn_ballot_w64(odd) != 0ull;
+    __shared__ float s_wmax[kBlock / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) s_wmax[threadIdx.x / kWave] = any_odd ? INFINITY : am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.0f;
+      for (int k = 0; k < kBlock / kWave; ++k) m = fmaxf(m, s_wmax[k]);
+      if (m > 0.0f && m < 3.0e38f) {
+        sh.wscale = kFxScale / m;
+        sh.wdec = m * (float)kFxInv;
+      } else if (!(m < 3.0e38f)) {
+        // (a single negative weight wraps nothing the checksum could see -- its field just reads as a huge positive number: the
+        // slice's verdict is set here, and the work item runs in f64 from the start, below)
+        sh.flag[0] = 1;
+      }
+    }
   }
   if (DYN) {  // a bound on this tile's displacements: |flow| over the tile (dense), the cells its pixels interpolate (GRID), theta
     if (UNIFORM) {
@@ -1174,6 +1215,16 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   __syncthreads();
   const Win<TH, TW, HALO, DYN> win = tile_bound_read<TH, TW, HALO, DYN>(sh.bound, dt_bound);
   NoOwn no_own;
+  if constexpr (HAS_W && MODE == ACC_FX) {
+    if (sh.flag[0]) {  // (uniform) a negative / non-finite weight in this slice: doubles, as before weights had a fixed-point form
+      __syncthreads();
+      if (threadIdx.x == 0) sh.flag[0] = 0;
+      __syncthreads();
+      tile_body<TH, TW, HALO, HAS_W, ACC_F64, FMT, UNIFORM, GRID, DYN, ZERO>(tr, win, flow, s_acc, sh, ev, H, W, tiles_x, pad_h, pad_w, slabs,
+                                                                            spill, spill_epoch, epoch, halo_tab, nullptr, NoHook{}, no_own);
+      return;
+    }
+  }
   tile_body<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN, ZERO>(tr, win, flow, s_acc, sh, ev, H, W, tiles_x, pad_h, pad_w, slabs,
                                                                      spill, spill_epoch, epoch, halo_tab, kLeanPre ? pre : nullptr,
                                                                      NoHook{}, no_own);

@@ -101,7 +101,8 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   unsigned* spill_epoch = reinterpret_cast<unsigned*>(ws + L.off_epoch);
   unsigned* halo_tab = reinterpret_cast<unsigned*>(ws + L.off_halo);
   const unsigned epoch = next_spill_epoch();
-  // unit weights -> verified fixed point (2 ds_add_u64 per event); per-event weights -> f64 (any magnitude/sign)
+  // unit weights -> verified fixed point (2 ds_add_u64 per event); per-event weights -> fixed point in units of the slice's max |w|,
+  // exact f64 redo where a field wraps (overflow, negative weights)
   void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*, GridSrc, unsigned*, unsigned, float,
              unsigned*);
   const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
@@ -114,7 +115,8 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
                       : iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_XY, true>)                                 \
            : (compact ? iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_COMPACT, false>                           \
                       : iwe_slab_accumulate_kernel<TH, TW, HALO, HW, MD, FMT_XY, false>))
-  if (ev.w) ka = EBOS_PICK(true, ACC_F64);
+  // (per-event weights: fixed point too, in units of the slice's max |w| -- TileShared::wscale; EBOS_SLAB_ACC=f64 forces doubles)
+  if (ev.w) ka = acc_mode == ACC_F64 ? EBOS_PICK(true, ACC_F64) : EBOS_PICK(true, ACC_FX);
   else if (acc_mode == ACC_F64) ka = EBOS_PICK(false, ACC_F64);
   else ka = EBOS_PICK(false, ACC_FX);
 #undef EBOS_PICK
