@@ -94,6 +94,14 @@ def main():
             loop.run(args.iters, resident=False)   # four launches per iteration
             loop.run(args.iters)                   # the resident kernel: ONE launch of args.iters iterations
             print("patch-grid loop, halo", halo, "second run:", loop.last_run_mode)
+        # ... and the 2-DoF Adam loop (configs/hot_plate1.yaml:47): four launches per iteration, then ONE resident launch
+        from event_based_bos_amd.solver.fused_loop import Fused2dofLoop
+
+        l2 = Fused2dofLoop(plans[0], torch.tensor([1.0, -0.5]), 1.0, halo="auto", lr=0.05, capacity=2 * args.iters + 2)
+        l2.run(args.iters, resident=False)
+        l2.run(args.iters)
+        print("2-DoF loop, second run:", l2.last_run_mode)
+        del l2
         torch.cuda.synchronize()
         print("grid variances", batch.variances[:2].tolist())
         sizes["grid"] = {"events": n, "windows_per_launch": nw, "resident_iterations_per_launch": args.iters}
