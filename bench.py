@@ -737,6 +737,9 @@ def run_config2(R):
                     g_h, g_w = ebos.solver.patch_grid_shape(pl.image_size, patch, patch)
                     for name, make in (("blur1_patch", lambda: FusedPatchLoop(pl, patch, patch, torch.zeros((2, g_h, g_w)), 1.0, 0.001, 0.0,
                                                                               halo="auto", lr=0.02, capacity=260, blur_sigma=1.0)),
+                                       ("gradient_magnitude_patch", lambda: FusedPatchLoop(pl, patch, patch, torch.zeros((2, g_h, g_w)), 0.0, 0.001,
+                                                                                           0.0, halo="auto", lr=0.02, capacity=260,
+                                                                                           w_gradient_magnitude=1.0)),
                                        ("blur3_2dof", lambda: Fused2dofLoop(pl, torch.zeros(2), 1.0, halo="auto", lr=0.02, capacity=260,
                                                                             blur_sigma=3.0)),
                                        ("2dof", lambda: Fused2dofLoop(pl, torch.zeros(2), 1.0, halo="auto", lr=0.02, capacity=260))):

@@ -66,8 +66,12 @@ bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
     set_error("resident solve: one work item per tile and no image padding (splits = %d, pad %dx%d)", q->splits, q->pad_h, q->pad_w);
     return false;
   }
-  if (q->w_gradient_magnitude != 0.0f || q->w_variance == 0.0f) {
-    set_error("resident solve: the variance contrast only");
+  if ((q->w_gradient_magnitude != 0.0f) == (q->w_variance != 0.0f)) {
+    set_error("resident solve: exactly one of w_variance / w_gradient_magnitude must be non-zero");
+    return false;
+  }
+  if (q->w_gradient_magnitude != 0.0f && q->blur_k0 != 0.0f) {
+    set_error("resident solve: the blurred image goes with the variance contrast only");
     return false;
   }
   if (!ebos_patch_fused_supported(q->tile_h, q->tile_w, q->halo, q->slide_h, q->slide_w)) {

@@ -39,6 +39,7 @@
 
 #include "iwe_tile_core.h"
 #include "handoff.h"
+#include "sobel3.h"
 
 // Timing builds (tools/ablate_resident.sh): EBOS_ABL is a mask of pieces of the iteration to leave out -- results are WRONG on
 // purpose; what a piece costs where it stands is the difference to the whole.  0 in the product.
@@ -137,6 +138,7 @@ struct ResidentArgs {
   unsigned long long cap_ticks;
   float max_imbalance;   // leave with RES_IMBALANCED when (events of the fullest tile) > max_imbalance x (events of the average tile); 0: never
   Blur3 blur;            // k0 != 0: the contrast of the 3-tap blurred image (iwe.blur_sigma > 0, blur3.h)
+  int gm;                // the gradient-magnitude contrast (sobel3.h) instead of the variance; patch-flow problems only
 };
 
 // LDS of the kernel: the forward view (accumulators + the tile's flow) and the backward view (d_flow accumulators + upstream window +
@@ -200,7 +202,8 @@ __device__ __forceinline__ void book_loss(const Args& a, int j, int lane, const 
     const int lo_px = a.omit ? 1 : 0;
     const double n_px = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
     const double S = s_hist[(j & 1) * 2], mn = s_hist[(j & 1) * 2 + 1];
-    const float var_f = (float)((Q - S * mn) / (n_px - 1.0));
+    // (gradient magnitude: Q is the sum of the squared Sobel pairs, the contrast their mean -- gradmag_fused_finalize_kernel)
+    const float var_f = a.gm ? (float)(Q / n_px) : (float)((Q - S * mn) / (n_px - 1.0));
     const int t_prev = a.t0 + j - 1;
     if (j >= 1 && a.losses != nullptr && t_prev < a.losses_cap) a.losses[t_prev] = (float)(-(double)a.w_contrast * (double)s_adam[2] + R);
     s_adam[2] = var_f;
@@ -462,8 +465,12 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     // and that the raw image two around it -- the GATHER window wx is the upstream window plus 2 rows / 4 columns (quads) per side.
     // Raw window (at s_g) and blurred window (behind it) share the LDS region of the largest upstream window: windows up to ~12 px at
     // 45 x 80; beyond that -- or where a tile two away reaches into the gather window -- the launch hands over to the pipeline below.
+    // Gradient-magnitude contrast (sobel3.h): the same gather window -- Sobel pairs one pixel around the upstream window, the raw image
+    // two around it.  gx lives where the d_flow accumulators will (cleared behind the passes instead of in front of them).
     const bool blur_on = fresh_args().blur.k0 != 0.0f;  // (uniform)
-    const Win<TH, TW, HALO, true> wx = blur_on ? Win<TH, TW, HALO, true>{wb.hr + 2, wb.hc + 4} : wb;
+    const bool gm_on = !UNI && fresh_args().gm != 0;    // (uniform)
+    const bool raw_on = blur_on || gm_on;               // the gather stages the RAW window; the contrast's passes follow
+    const Win<TH, TW, HALO, true> wx = raw_on ? Win<TH, TW, HALO, true>{wb.hr + 2, wb.hc + 4} : wb;
     float4 own_q[kQuads];  // this workgroup's own contribution to the quads of its upstream window, decoded from its LDS image
     double mean;
     bool halo_complete;
@@ -556,12 +563,14 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       __syncthreads();
       mean = s_mom[0];
       halo_complete = 2 * s_wmax[0] < TH && 2 * s_wmax[1] < TW;  // (uniform over the GRID: every workgroup saw every window)
-      if (blur_on) {
+      if (raw_on) {
         // (uniform over the grid, from the LARGEST window: every gather window lies within the 3 x 3 tiles around its own, no tile
-        // two away reaches into it, and the raw + blurred windows fit the LDS region)
+        // two away reaches into it, and the raw + blurred windows fit the LDS region -- with the Sobel pairs: raw window + gy there,
+        // gx in the d_flow accumulators' region)
         const int hrm = max(s_wmax[0], kSpecHalo), hcm = max(s_wmax[1], kSpecHalo);
         const int lh = TH + 2 * hrm, lw = TW + 2 * hcm;
-        const bool fits = 2 * hrm + 2 <= TH && 2 * hcm + 4 <= TW && (lh + 4) * (lw + 8) + (lh + 2) * (lw + 8) <= kLHmax * kLWmax;
+        const bool fits = 2 * hrm + 2 <= TH && 2 * hcm + 4 <= TW &&
+                          (lh + 4) * (lw + 8) + (lh + 2) * (lw + 8) <= kLHmax * kLWmax && (!gm_on || (lh + 2) * (lw + 8) <= 4 * TH * TW);
         if (!fits || !halo_complete) {
           if (threadIdx.x == 0) raise_status(a.status, (unsigned)RES_SPILL | ((unsigned)it << 8));
           s_ok_local = false;
@@ -611,7 +620,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         // this tile's own pixels (quads lie inside a tile as a whole or outside it)
         if (live && r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) {
           const float e4[4] = {v.x, v.y, v.z, v.w};
-          if (!blur_on && r >= lo_px && r < H - lo_px) {  // (blurred contrast: the sum of squares is the blurred image's, below)
+          if (!raw_on && r >= lo_px && r < H - lo_px) {  // (blurred contrast: the sum of squares is the blurred image's, below)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
               if (c + k >= lo_px && c + k < W - lo_px) sq += (double)e4[k] * (double)e4[k];
@@ -623,7 +632,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           }
         }
         float4 gq = v;
-        if (blur_on) {
+        if (raw_on) {
           if (!live) gq = make_float4(0.f, 0.f, 0.f, 0.f);  // (the RAW window is staged: zero outside the image)
         } else if (halo_complete) {
           if (all_valid) {
@@ -649,7 +658,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       // what needs nothing of the other tiles: the d_flow accumulators are cleared, the tile's flow with its apron is evaluated, the
       // sweep's first chunks are requested -- placed between the request of the neighbours' slabs and their first use
       auto independent_work = [&]() {
-        if (!(EBOS_ABL & 4))
+        if (!(EBOS_ABL & 4) && !gm_on)  // (gradient magnitude: the Sobel pairs use the region first)
         for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);  // [2][TH * TW]
         if constexpr (!UNI)
           if (!(EBOS_ABL & 2)) tile_flow_from_cells<TH, TW, AP>(s_lerp, s_lerp + PH, s_cells, rfl(P.gi0), rfl(P.gj0), s_flow_b);
@@ -763,6 +772,21 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       }
       independent_work();
       }
+      // pixels of the rectangle [r0, r0 + nr) x [c0, c0 + nc) OUTSIDE the box [lo_b, H - lo_b) x [lo_b, W - lo_b): top and bottom
+      // strips whole, left and right strips between them; f(r, c) once per pixel, dealt to the threads
+      auto for_border = [&](int r0, int nr, int c0, int nc, int lo_b, auto&& f) {
+        const int rt = min(max(lo_b - r0, 0), nr), rb = min(max(r0 + nr - (H - lo_b), 0), nr - rt);   // rows above / below the box
+        const int cl_ = min(max(lo_b - c0, 0), nc), cr_ = min(max(c0 + nc - (W - lo_b), 0), nc - cl_);  // columns left / right of it
+        for (int i = threadIdx.x; i < (rt + rb) * nc; i += kBlock) {
+          const int k = i / nc, c = c0 + i - k * nc;
+          f(k < rt ? r0 + k : r0 + nr - rb + (k - rt), c);
+        }
+        const int nm = nr - rt - rb, ns = cl_ + cr_;
+        for (int i = threadIdx.x; i < nm * ns; i += kBlock) {
+          const int k = i / ns, q = i - k * ns;
+          f(r0 + rt + k, q < cl_ ? c0 + q : c0 + nc - cr_ + (q - cl_));
+        }
+      };
       if (blur_on) {
         // ---- blurred contrast: raw window (s_g, [wx]) -> masked blurred window (behind it: upstream window + 1 row / 4 columns per
         // side, i.e. the raw window's columns) -> upstream window a z + c wgt, z = B^T (m . B x) (s_g again, [wb]): the arithmetic of
@@ -776,21 +800,6 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         const int xw = wx.LW(), xoy = tr0 - wx.HR(), xox = tc0 - wx.HC();
         const int bh = wb.LH() + 2, bw = xw, boy = xoy + 1, box = xox, bq = bw / 4;
         float* s_b = s_g + wx.LH() * xw;
-        // pixels of the rectangle [r0, r0 + nr) x [c0, c0 + nc) OUTSIDE the box [lo_b, H - lo_b) x [lo_b, W - lo_b): top and bottom
-        // strips whole, left and right strips between them; f(r, c) once per pixel, dealt to the threads
-        auto for_border = [&](int r0, int nr, int c0, int nc, int lo_b, auto&& f) {
-          const int rt = min(max(lo_b - r0, 0), nr), rb = min(max(r0 + nr - (H - lo_b), 0), nr - rt);   // rows above / below the box
-          const int cl_ = min(max(lo_b - c0, 0), nc), cr_ = min(max(c0 + nc - (W - lo_b), 0), nc - cl_);  // columns left / right of it
-          for (int i = threadIdx.x; i < (rt + rb) * nc; i += kBlock) {
-            const int k = i / nc, c = c0 + i - k * nc;
-            f(k < rt ? r0 + k : r0 + nr - rb + (k - rt), c);
-          }
-          const int nm = nr - rt - rb, ns = cl_ + cr_;
-          for (int i = threadIdx.x; i < nm * ns; i += kBlock) {
-            const int k = i / ns, q = i - k * ns;
-            f(r0 + rt + k, q < cl_ ? c0 + q : c0 + nc - cr_ + (q - cl_));
-          }
-        };
         const int vlo = max(lo_px, 1);
         __syncthreads();
         {
@@ -876,6 +885,119 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             });
           }
         }
+      }
+      if constexpr (!UNI)
+      if (gm_on) {
+        // ---- gradient-magnitude contrast: raw window (s_g, [wx]) -> Sobel pairs on upstream window + 1 row / 4 columns per side
+        // (gx where the d_flow accumulators will be, gy behind the raw window) -> upstream window s . gather of the nine stencils around each pixel (s_g again,
+        // [wb]): the arithmetic of the pipeline's image pass (gradmag_fused_kernel through sobel3.h) on what this workgroup gathered.
+        // As with the blur, EVERY tile runs the plain quad form over its whole window; a tile at the image's border first fills the
+        // ring one pixel outside the image with the border's pixels (replicate padding), afterwards clears the pairs of the stencils
+        // outside the valid region and recomputes the image's outermost ring with the folded form, one pixel per thread.
+        const int xw = wx.LW(), xh = wx.LH(), xoy = tr0 - wx.HR(), xox = tc0 - wx.HC();
+        const int bh = wb.LH() + 2, bw = xw, boy = xoy + 1, box = xox, bq = bw / 4;
+        float* s_gx = reinterpret_cast<float*>(s_d);   // (windows up to ~12 px at 45 x 80 and 32 x 32: as the blur's)
+        float* s_gy = s_g + xh * xw;
+        __syncthreads();
+        if (xoy < 0 || xoy + xh > H || xox < 0 || xox + xw > W) {  // (uniform) the raw window leaves the image
+          for (int i = threadIdx.x; i < 2 * (xw + xh); i += kBlock) {
+            int r, c;
+            if (i < 2 * xw) {
+              r = (i & 1) ? H : -1, c = xox + (i >> 1);
+            } else {
+              const int k = i - 2 * xw;
+              c = (k & 1) ? W : -1, r = xoy + (k >> 1);
+            }
+            if (r >= xoy && r < xoy + xh && c >= xox && c < xox + xw && r >= -1 && r <= H && c >= -1 && c <= W)
+              s_g[(r - xoy) * xw + (c - xox)] = s_g[(min(max(r, 0), H - 1) - xoy) * xw + (min(max(c, 0), W - 1) - xox)];
+          }
+          __syncthreads();
+        }
+        {
+          const bool inner = boy >= lo_px && boy + bh <= H - lo_px && box + 3 >= lo_px && box + bw - 3 <= W - lo_px;
+          const float inv_q = 1.0f / (float)(bq - 2);
+          const float4* A4 = reinterpret_cast<const float4*>(s_g);
+          for (int i = threadIdx.x; i < bh * (bq - 2); i += kBlock) {   // (the window's outermost quads: one column each, below)
+            const int rl = (int)(((float)i + 0.5f) * inv_q), cq = i - rl * (bq - 2) + 1;
+            const float4* m = A4 + (rl + 1) * bq + cq;
+            float4 x4, y4;
+            sobel3_pair_quad(m[-bq - 1], m[-bq], m[-bq + 1], m[-1], m[0], m[1], m[bq - 1], m[bq], m[bq + 1], x4, y4);
+            reinterpret_cast<float4*>(s_gx)[rl * bq + cq] = x4;
+            reinterpret_cast<float4*>(s_gy)[rl * bq + cq] = y4;
+            const int r = boy + rl, c = box + 4 * cq;
+            if (r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) {   // this tile's own stencils: its share of the contrast's value
+              const float e4[4] = {sobel3_energy(x4.x, y4.x), sobel3_energy(x4.y, y4.y), sobel3_energy(x4.z, y4.z), sobel3_energy(x4.w, y4.w)};
+              if (inner || (r >= lo_px && r < H - lo_px && c >= lo_px && c + 3 < W - lo_px)) {
+                sq += ((double)e4[0] + (double)e4[1]) + ((double)e4[2] + (double)e4[3]);
+              } else if (r >= lo_px && r < H - lo_px) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (c + k >= lo_px && c + k < W - lo_px) sq += (double)e4[k];
+              }
+            }
+          }
+          for (int i = threadIdx.x; i < 2 * bh; i += kBlock) {   // the column left / right of the upstream window
+            const int rl = i >> 1, cl = (i & 1) ? bw - 4 : 3;
+            const float* p = s_g + (rl + 1) * xw + cl;
+            float vx, vy;
+            sobel3_pair(p[-xw - 1], p[-xw], p[-xw + 1], p[-1], p[1], p[xw - 1], p[xw], p[xw + 1], vx, vy);
+            s_gx[rl * bw + cl] = vx, s_gy[rl * bw + cl] = vy;
+          }
+          if (!inner) {  // (uniform) stencils outside the valid region count zero
+            __syncthreads();
+            for_border(boy, bh, box + 3, bw - 6, lo_px, [&](int r, int c) {
+              s_gx[(r - boy) * bw + (c - box)] = 0.0f;
+              s_gy[(r - boy) * bw + (c - box)] = 0.0f;
+            });
+          }
+        }
+        __syncthreads();
+        {
+          const int gw = wb.LW(), goy = tr0 - wb.HR(), gox = tc0 - wb.HC(), gq = gw / 4;
+          const bool inner = goy >= 1 && goy + wb.LH() <= H - 1 && gox >= 1 && gox + gw <= W - 1;
+          const float scale = sobel3_adjoint_scale(-(double)a.w_contrast, n_px);
+          const float inv_q = 1.0f / (float)gq;
+          const float4* X4 = reinterpret_cast<const float4*>(s_gx);
+          const float4* Y4 = reinterpret_cast<const float4*>(s_gy);
+          for (int i = threadIdx.x; i < wb.LH() * gq; i += kBlock) {
+            const int rl = (int)(((float)i + 0.5f) * inv_q), cq = i - rl * gq;
+            const float4* x = X4 + (rl + 1) * bq + cq + 1;
+            const float4* y = Y4 + (rl + 1) * bq + cq + 1;
+            const float4 acc = sobel3_adjoint_quad(x[-bq - 1], x[-bq], x[-bq + 1], x[bq - 1], x[bq], x[bq + 1], y[-bq - 1], y[-bq], y[-bq + 1],
+                                                   y[-1], y[0], y[1], y[bq - 1], y[bq], y[bq + 1]);
+            const float4 g4 = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
+            reinterpret_cast<float4*>(s_g)[i] = g4;
+            const int r = goy + rl, c = gox + 4 * cq;
+            if (inner || (r >= 1 && r < H - 1 && c >= 1 && c + 3 < W - 1)) {
+              const float m4 = fmaxf(fmaxf(fabsf(g4.x), fabsf(g4.y)), fmaxf(fabsf(g4.z), fabsf(g4.w)));
+              gmax_t = fmaxf(gmax_t, (g4.x + g4.y + g4.z + g4.w) == (g4.x + g4.y + g4.z + g4.w) ? m4 : INFINITY);
+              gsum_t += (fabsf(g4.x) + fabsf(g4.y)) + (fabsf(g4.z) + fabsf(g4.w));
+            } else if (r >= 1 && r < H - 1) {
+              const float e4[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (c + k >= 1 && c + k < W - 1) {
+                  gmax_t = fmaxf(gmax_t, e4[k] == e4[k] ? fabsf(e4[k]) : INFINITY);
+                  gsum_t += fabsf(e4[k]);
+                }
+            }
+          }
+          if (!inner) {  // (uniform) the image's outermost ring: folded taps; outside the image: 0
+            auto gxy = [&](int qr, int qc, float& vx, float& vy) {
+              vx = s_gx[(qr - boy) * bw + (qc - box)], vy = s_gy[(qr - boy) * bw + (qc - box)];
+            };
+            __syncthreads();
+            for_border(goy, wb.LH(), gox, gw, 1, [&](int r, int c) {
+              const bool live = r >= 0 && r < H && c >= 0 && c < W;
+              const float gv = live ? scale * sobel3_adjoint_ring(gxy, r, c, H, W, lo_px, H - lo_px, lo_px, W - lo_px) : 0.0f;
+              s_g[(r - goy) * gw + (c - gox)] = gv;
+              gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
+              gsum_t += fabsf(gv);
+            });
+          }
+        }
+        __syncthreads();  // (the pairs are dead: their region becomes the d_flow accumulators)
+        for (int i = threadIdx.x; i < TH * TW; i += kBlock) reinterpret_cast<double2*>(s_d)[i] = make_double2(0.0, 0.0);
       }
       EBOS_RSTAMP(6);
       sq = wave_sum(sq);
@@ -1348,7 +1470,8 @@ inline ResidentArgs resident_args(const ebos_cmax_patch_problem* q, int n_iter, 
   a.cell_partials = q->grad_partials;
   a.losses = q->losses, a.losses_cap = q->losses_cap;
   a.lr = q->lr, a.beta1 = q->beta1, a.beta2 = q->beta2, a.eps = q->eps;
-  a.w_contrast = q->w_variance;
+  a.gm = q->w_gradient_magnitude != 0.0f ? 1 : 0;
+  a.w_contrast = a.gm ? q->w_gradient_magnitude : q->w_variance;
   a.s_norm = q->w_flow_norm / (float)((int64_t)q->H * q->W);
   a.s_tv = q->w_image_gradient / (float)(2 * (int64_t)q->H * q->W);
   a.omit = q->omit_boundary ? 1 : 0;

@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "blur3.h"
+#include "sobel3.h"
 
 namespace ebos {
 namespace {
@@ -237,14 +238,14 @@ gradmag_fused_kernel(const float* __restrict__ img, int h, int w, Region rg, con
     const int rl = i / SW, cl = i - rl * SW;
     const int qr = tr0 - 1 + rl, qc = tc0 - 1 + cl;  // the stencil's centre
     const float* p = s_img + (rl + 1) * IW + cl + 1;
-    const float a00 = p[-IW - 1], a01 = p[-IW], a02 = p[-IW + 1], a10 = p[-1], a12 = p[1], a20 = p[IW - 1], a21 = p[IW], a22 = p[IW + 1];
     const bool in = qr >= rg.r0 && qr < rg.r1 && qc >= rg.c0 && qc < rg.c1;
-    // Gx = [[-1,-2,-1],[0,0,0],[1,2,1]] (row derivative); Gy = [[-1,0,1],[-2,0,2],[-1,0,1]] (column derivative)
-    s_gx[i] = in ? ((a20 + 2.0f * a21 + a22) - (a00 + 2.0f * a01 + a02)) * 0.125f : 0.0f;
-    s_gy[i] = in ? ((a02 + 2.0f * a12 + a22) - (a00 + 2.0f * a10 + a20)) * 0.125f : 0.0f;
+    float vx, vy;  // (sobel3.h: the arithmetic shared with the resident solver kernel)
+    sobel3_pair(p[-IW - 1], p[-IW], p[-IW + 1], p[-1], p[1], p[IW - 1], p[IW], p[IW + 1], vx, vy);
+    s_gx[i] = in ? vx : 0.0f;
+    s_gy[i] = in ? vy : 0.0f;
   }
   __syncthreads();
-  const float scale = (float)(2.0 * (upstream ? (double)upstream[0] : 1.0) / (double)rg.count() * 0.125);
+  const float scale = sobel3_adjoint_scale(upstream ? (double)upstream[0] : 1.0, (double)rg.count());
   double val = 0.0;
 #pragma unroll
   for (int k = 0; k < kGmTH * kGmTW / kCostBlock; ++k) {
@@ -254,11 +255,11 @@ gradmag_fused_kernel(const float* __restrict__ img, int h, int w, Region rg, con
     if (pr >= h || pc >= w) continue;
     const float* gx = s_gx + (rl + 1) * SW + cl + 1;
     const float* gy = s_gy + (rl + 1) * SW + cl + 1;
-    val += (double)(gx[0] * gx[0] + gy[0] * gy[0]);  // (zero outside the region)
+    val += (double)sobel3_energy(gx[0], gy[0]);  // (zero outside the region)
     // stencil q = p - d reads p through its tap d:  sum_d gx(p - d) Gx[d] + gy(p - d) Gy[d],  Gx[dr][dc] = dr (2 - |dc|),
     // Gy[dr][dc] = dc (2 - |dr|)  (complete for a pixel inside the image; the outermost ring gets its folded taps below)
-    const float acc = (gx[-SW - 1] + 2.0f * gx[-SW] + gx[-SW + 1]) - (gx[SW - 1] + 2.0f * gx[SW] + gx[SW + 1])  // dr = +1: the row above p; -1: below
-                    + (gy[-SW - 1] + 2.0f * gy[-1] + gy[SW - 1]) - (gy[-SW + 1] + 2.0f * gy[1] + gy[SW + 1]);   // dc = +1: the column left of p; -1: right
+    const float acc = sobel3_adjoint_interior(gx[-SW - 1], gx[-SW], gx[-SW + 1], gx[SW - 1], gx[SW], gx[SW + 1], gy[-SW - 1], gy[-1],
+                                              gy[SW - 1], gy[-SW + 1], gy[1], gy[SW + 1]);
     if (pr >= 1 && pr < h - 1 && pc >= 1 && pc < w - 1) d_img[(int64_t)pr * w + pc] = scale * acc;
   }
   // The image's outermost ring: taps of stencils at the border clamp onto it (replicate padding).  With p' = q + d the unclamped
@@ -267,19 +268,9 @@ gradmag_fused_kernel(const float* __restrict__ img, int h, int w, Region rg, con
   // form at p', stencils outside the region counting zero.  The ring's pixels of this tile are dealt to the threads one each, a
   // pass of their own: inside the loop above they made every wave of a border tile run both forms (6 of the pass's 12.7 us).
   if (tr0 == 0 || tr0 + kGmTH >= h || tc0 == 0 || tc0 + kGmTW >= w) {
-    auto plain = [&](int r, int c) {
-      float f = 0.0f;
-#pragma unroll
-      for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-        for (int dc = -1; dc <= 1; ++dc) {
-          const int qr = r - dr, qc = c - dc;
-          const bool ok = qr >= rg.r0 && qr < rg.r1 && qc >= rg.c0 && qc < rg.c1;  // (then q lies within tile + 1 px: p' is within 1 px of p)
-          const int qi = ok ? (qr - tr0 + 1) * SW + qc - tc0 + 1 : 0;
-          const float vx = ok ? s_gx[qi] : 0.0f, vy = ok ? s_gy[qi] : 0.0f;
-          f += vx * ((float)dr * (dc == 0 ? 2.0f : 1.0f)) + vy * ((float)dc * (dr == 0 ? 2.0f : 1.0f));
-        }
-      return f;
+    auto gxy = [&](int qr, int qc, float& vx, float& vy) {   // (a stencil inside the region lies within tile + 1 px)
+      const int qi = (qr - tr0 + 1) * SW + qc - tc0 + 1;
+      vx = s_gx[qi], vy = s_gy[qi];
     };
     // candidates: the tile's first / last row and first / last column (2 (TH + TW) slots; a slot counts if it lies on the ring)
     for (int i = threadIdx.x; i < 2 * (kGmTH + kGmTW); i += kCostBlock) {
@@ -293,10 +284,7 @@ gradmag_fused_kernel(const float* __restrict__ img, int h, int w, Region rg, con
       const bool on_ring = pr == 0 || pr == h - 1 || pc == 0 || pc == w - 1;
       // (a corner pixel appears in a row slot and a column slot, a one-row / one-column tile's pixels twice: same value stored twice)
       if (!on_ring) continue;
-      float acc = 0.0f;
-      for (int a2 = (pr == 0 ? -1 : 0); a2 <= (pr == h - 1 ? 1 : 0); ++a2)
-        for (int b2 = (pc == 0 ? -1 : 0); b2 <= (pc == w - 1 ? 1 : 0); ++b2) acc += plain(pr + a2, pc + b2);
-      d_img[(int64_t)pr * w + pc] = scale * acc;
+      d_img[(int64_t)pr * w + pc] = scale * sobel3_adjoint_ring(gxy, pr, pc, h, w, rg.r0, rg.r1, rg.c0, rg.c1);
     }
   }
   __shared__ double red[kCostBlock / kWave];

@@ -307,11 +307,13 @@ class FusedPatchLoop(object):
         return q
 
     def resident_supported(self) -> bool:
-        """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_patch_solve_resident_f32)?  Grid-sampling route, variance
-        contrast, no padding, a tile / halo with a resident kernel, few enough tiles to be co-resident.  (The resident kernel runs one
-        workgroup per tile whatever the plan's work-item table says: against a pipeline that split crowded tiles it agrees to
-        rounding, not bit for bit.)"""
-        if not self.sample_grid or self.w_gm or self.splits not in (0, 1) or self.pad != (0, 0):
+        """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_patch_solve_resident_f32)?  Grid-sampling route, either
+        contrast (the blurred image with the variance only), no padding, a tile / halo with a resident kernel, few enough tiles to
+        be co-resident.  (The resident kernel runs one workgroup per tile whatever the plan's work-item table says: against a
+        pipeline that split crowded tiles it agrees to rounding, not bit for bit.)"""
+        if not self.sample_grid or self.splits not in (0, 1) or self.pad != (0, 0):
+            return False
+        if self.w_gm and os.environ.get("EBOS_RESIDENT_GM", "1") == "0":
             return False
         if self.blur_sigma > 0 and not (RESIDENT_BLUR and os.environ.get("EBOS_RESIDENT_BLUR", "1") != "0"):
             return False

@@ -119,6 +119,8 @@ def test_fused_loop_follows_the_autograd_loop(terms):
         s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
         s.estimate(ev)
         assert s.fused == fused and s.graphed == (not fused)
+        if fused:  # either contrast as ONE resident launch (moving points at 4 px: the windows stay inside its LDS regions)
+            assert s.loop_mode == "resident", s.loop_mode
         out[fused] = (np.array(s.history), s.patch_flow.cpu().numpy())
     rel_dev = np.abs(out[True][0] - out[False][0]) / np.abs(out[False][0])
     print("max relative deviation per iteration", np.round(rel_dev, 6), "flow", np.abs(out[True][1] - out[False][1]).max())
@@ -703,6 +705,63 @@ def test_resident_loop_with_the_blurred_contrast_matches_the_pipeline(size, n_ev
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size,n_ev,patch,omit", [
+    ((96, 128), 20_000, (24, 32), False),      # 12 tiles of 32 x 32: every tile touches the image's border
+    ((260, 346), 100_000, (20, 20), True),     # BASELINE configs[0]'s size, with the boundary ring; partial last tiles
+    ((720, 1280), 400_000, (24, 32), False),   # 256 tiles of 45 x 80
+    ((720, 640), 300_000, (24, 32), True),     # 230 tiles of 32 x 64
+])
+def test_resident_loop_with_the_gradient_magnitude_contrast(size, n_ev, patch, omit):
+    """The `gradient_magnitude` contrast (src/costs/gradient_magnitude.py: mean squared Sobel / 8 gradient, replicate padding) inside
+    the ONE-launch loop: the resident kernel gathers its upstream window with a 2 px apron, forms the Sobel pairs
+    and their adjoint in LDS with the functions of the pipeline's image pass (csrc/sobel3.h).  First iteration against the fp64
+    oracle's autograd (loss 1e-5, patch-flow gradient rel-L2 1e-3); against the four-launch pipeline the raw image bit for bit and
+    losses / flows to rounding over 60 iterations."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w = size
+    rs = np.random.RandomState(17)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+    theta0 = torch.from_numpy(rs.uniform(-3, 3, (2, gh, gw))).float()
+    n_iter, w_gm, w_norm = 60, 2.0, 0.001
+
+    def make():
+        return FusedPatchLoop(plan, patch, patch, theta0, 0.0, w_norm, 0.0, omit, halo="auto", lr=0.02, capacity=n_iter + 20,
+                              w_gradient_magnitude=w_gm)
+
+    ref, res = make(), make()
+    assert res.resident_supported(), ebos.load_library().ebos_last_error()
+    l1_ref = ref.run(1, resident=False).cpu().numpy()
+    l1_res = res.run(1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.resident_status == 0 and res.resident_iterations == 1
+    assert torch.equal(ref.iwe, res.iwe)
+    np.testing.assert_allclose(l1_res, l1_ref, rtol=1e-6)
+    print("d_theta: max abs deviation", (res.d_theta - ref.d_theta).abs().max().item(), "of", ref.d_theta.abs().max().item())
+    np.testing.assert_allclose(res.d_theta.cpu().numpy(), ref.d_theta.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    if n_ev <= 100_000:  # the oracle: fp64 autograd of the same objective at theta0
+        t64 = theta0.double().requires_grad_(True)
+        dense = O.upsample_patch_flow(t64, (h, w), patch, patch)
+        loss = w_gm * O.gradient_magnitude(O.iwe_dense(torch.from_numpy(ev), dense, (h, w)), omit) + w_norm * O.flow_norm(dense)
+        loss.backward()
+        assert abs(float(l1_res[0]) - loss.item()) <= 1e-5 * abs(loss.item()), (l1_res, loss.item())
+        assert O.rel_l2(res.d_theta.cpu().numpy(), t64.grad.numpy()) < 1e-3
+    l_ref = ref.run(n_iter - 1, resident=False).cpu().numpy()
+    l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
+    print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
+    np.testing.assert_allclose(l_res, l_ref, rtol=2e-5)
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=5e-3)
+    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=2e-5)
+    # continued by the other mode
+    a = ref.run(5, resident=True).cpu().numpy()
+    b = res.run(5, resident=False).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-5)
+
+
+@pytest.mark.gpu
 def test_resident_blurred_loop_hands_over_when_the_windows_outgrow_its_lds_region():
     """The blurred resident loop keeps the raw and the blurred window in the LDS region of the largest upstream window: windows up to
     ~12 px (45 x 80) / ~16 px (32 x 32).  A flow that needs more ends the launch like a spill -- status -102 with the completed
@@ -722,6 +781,13 @@ def test_resident_blurred_loop_hands_over_when_the_windows_outgrow_its_lds_regio
     assert res.resident_status == -102 and res.resident_iterations == 0 and res.last_run_mode == "pipeline"
     l_ref = ref.run(6, resident=False).cpu().numpy()
     np.testing.assert_array_equal(l_res, l_ref)
+    # ... the gradient-magnitude contrast keeps its raw window and the Sobel pairs the same way: same limit, same hand-over
+    ref = FusedPatchLoop(plan, patch, patch, theta0, 0.0, 0.01, 0.0, halo="auto", lr=0.05, capacity=16, w_gradient_magnitude=1.0)
+    res = FusedPatchLoop(plan, patch, patch, theta0, 0.0, 0.01, 0.0, halo="auto", lr=0.05, capacity=16, w_gradient_magnitude=1.0)
+    assert res.resident_supported()
+    l_res = res.run(6).cpu().numpy()
+    assert res.resident_status == -102 and res.resident_iterations == 0 and res.last_run_mode == "pipeline"
+    np.testing.assert_array_equal(l_res, ref.run(6, resident=False).cpu().numpy())
 
 
 @pytest.mark.gpu
