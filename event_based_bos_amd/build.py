@@ -24,7 +24,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libebos_hip.so")
 
 SOURCES = ["errors.cpp", "warp_kernels.hip", "splat_kernels.hip", "event_plan.hip", "plan_lean.hip", "iwe_fused.hip", "iwe_tiled.hip",
            "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip", "solver_kernels.hip", "cmax_resident.hip",
-           "cmax_resident_45x80.hip", "cmax_resident_32x32.hip", "cmax_resident_32x64.hip"]
+           "cmax_resident_45x80.hip", "cmax_resident_32x32.hip", "cmax_resident_32x64.hip",
+           "cmax_resident_45x80_2dof.hip", "cmax_resident_32x32_2dof.hip", "cmax_resident_32x64_2dof.hip"]
 
 # -munsafe-fp-atomics: hardware global_atomic_add_f32/f64 and ds_add_f32 instead of CAS loops.
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC",
@@ -50,7 +51,7 @@ def _needs_rebuild(target: str, deps: List[str]) -> bool:
 # loads each followed by a full vmcnt(0) wait (5.5 us for four pixels per thread in the epilogue).  MachineSink's
 # sink-insts-to-avoid-spills puts those computations back next to their uses: 41 -> 7 spilled VGPRs.
 _RESIDENT_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills=1"]
-PER_FILE_FLAGS = {f"cmax_resident_{t}.hip": _RESIDENT_FLAGS for t in ("45x80", "32x32", "32x64")}
+PER_FILE_FLAGS = {f"cmax_resident_{t}{p}.hip": _RESIDENT_FLAGS for t in ("45x80", "32x32", "32x64") for p in ("", "_2dof")}
 
 
 def _compile(src: str, extra: List[str]) -> str:
@@ -75,7 +76,10 @@ def build_library(force: bool = False, keep_temps: bool = False, verbose: bool =
     extra = ["-save-temps=obj"] if keep_temps else []
     extra += os.environ.get("EBOS_EXTRA_FLAGS", "").split()  # e.g. -DEBOS_STAMPS for the diagnostic build
     with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get("EBOS_BUILD_JOBS", "7")), len(SOURCES))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, extra), SOURCES))
+        # (the slow units first: the resident kernels' take minutes, everything else seconds)
+        order = sorted(SOURCES, key=lambda s: 0 if s.endswith("_2dof.hip") else (1 if s.startswith("cmax_resident_") else 2))
+        built = dict(zip(order, ex.map(lambda s: _compile(s, extra), order)))
+        objs = [built[s] for s in SOURCES]
     if force or _needs_rebuild(LIB_PATH, objs):
         cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -214,9 +214,9 @@ int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* q, int n_i
   }
   hipStream_t s = as_stream(stream);
   int rc = EBOS_ERR_UNSUPPORTED;
-  if (q->tile_h == 45 && q->tile_w == 80 && ha.halo == 32) rc = resident_launch_45x80(q, nullptr, 0.0f, n_iter, mailbox, spin_timeout_s, s);
-  else if (q->tile_h == 32 && q->tile_w == 32 && ha.halo == 32) rc = resident_launch_32x32(q, nullptr, 0.0f, n_iter, mailbox, spin_timeout_s, s);
-  else if (q->tile_h == 32 && q->tile_w == 64 && ha.halo == 32) rc = resident_launch_32x64(q, nullptr, 0.0f, n_iter, mailbox, spin_timeout_s, s);  // (720 x 640: hot_plate1's ROI)
+  if (q->tile_h == 45 && q->tile_w == 80 && ha.halo == 32) rc = resident_launch_45x80(q, n_iter, mailbox, spin_timeout_s, s);
+  else if (q->tile_h == 32 && q->tile_w == 32 && ha.halo == 32) rc = resident_launch_32x32(q, n_iter, mailbox, spin_timeout_s, s);
+  else if (q->tile_h == 32 && q->tile_w == 64 && ha.halo == 32) rc = resident_launch_32x64(q, n_iter, mailbox, spin_timeout_s, s);  // (720 x 640: hot_plate1's ROI)
   if (rc != EBOS_OK) return rc;
   EBOS_CHECK_LAUNCH("ebos_cmax_patch_solve_resident");
   return EBOS_OK;
@@ -251,9 +251,9 @@ int ebos_cmax_2dof_solve_resident_f32(const ebos_cmax_2dof_problem* q, int n_ite
   }
   hipStream_t s = as_stream(stream);
   int rc = EBOS_ERR_UNSUPPORTED;
-  if (q->tile_h == 45 && q->tile_w == 80 && ha.halo == 32) rc = resident_launch_45x80(nullptr, q, q->w_variance, n_iter, mailbox, spin_timeout_s, s);
-  else if (q->tile_h == 32 && q->tile_w == 32 && ha.halo == 32) rc = resident_launch_32x32(nullptr, q, q->w_variance, n_iter, mailbox, spin_timeout_s, s);
-  else if (q->tile_h == 32 && q->tile_w == 64 && ha.halo == 32) rc = resident_launch_32x64(nullptr, q, q->w_variance, n_iter, mailbox, spin_timeout_s, s);
+  if (q->tile_h == 45 && q->tile_w == 80 && ha.halo == 32) rc = resident_launch_2dof_45x80(q, q->w_variance, n_iter, mailbox, spin_timeout_s, s);
+  else if (q->tile_h == 32 && q->tile_w == 32 && ha.halo == 32) rc = resident_launch_2dof_32x32(q, q->w_variance, n_iter, mailbox, spin_timeout_s, s);
+  else if (q->tile_h == 32 && q->tile_w == 64 && ha.halo == 32) rc = resident_launch_2dof_32x64(q, q->w_variance, n_iter, mailbox, spin_timeout_s, s);
   if (rc != EBOS_OK) return rc;
   EBOS_CHECK_LAUNCH("ebos_cmax_2dof_solve_resident");
   return EBOS_OK;

@@ -1,0 +1,12 @@
+// cmax_resident_45x80_2dof.hip -- the resident solver kernels of the 2-DoF problem (plain / blurred variance x integer / fractional
+// source coordinates) for source tiles of 45 x 80 pixels with a 32 px largest window: see cmax_resident_core.h.
+#include "cmax_resident_core.h"
+
+namespace ebos {
+
+int resident_launch_2dof_45x80(const ebos_cmax_2dof_problem* q, float w_variance, int n_iter, void* mailbox, double spin_timeout_s,
+                             hipStream_t s) {
+  return resident_2dof_launch<45, 80, 32>(q, w_variance, n_iter, mailbox, spin_timeout_s, s);
+}
+
+}  // namespace ebos

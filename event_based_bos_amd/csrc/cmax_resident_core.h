@@ -265,9 +265,14 @@ struct Persist {  // one workgroup's iteration-invariant geometry
 // sums ALL of them (in the order of the four-launch loop's last kernel) and steps the two parameters itself.
 // FRAC (UNI only): the compact plan carries fractional source coordinates (undistorted events: data.warp: true in the reference's
 // configs/hot_plate1.yaml:7): the event loops are the general ones of the compact format, whose groups hold the fractions.
-template <int TH, int TW, int HALO, bool UNI, bool FRAC = false>
+// CONTRAST: which contrast the loop maximises -- a template parameter, not an argument: as run-time branches the blur's and the Sobel
+// passes' code cost the plain variance loop 1.3 us per iteration (register pressure in the event loop and the gather: 28.0 -> 29.3 us
+// at 2 M events) although it never ran.
+enum ResidentContrast : int { RC_VARIANCE = 0, RC_BLURRED_VARIANCE = 1, RC_GRADIENT_MAGNITUDE = 2 };
+template <int TH, int TW, int HALO, bool UNI, bool FRAC = false, int CONTRAST = RC_VARIANCE>
 __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_unused) {
   static_assert(!FRAC || UNI, "fractional source coordinates: the 2-DoF kernels only (the fixed-point backward sweep assumes integer pixels)");
+  static_assert(!(UNI && CONTRAST == RC_GRADIENT_MAGNITUDE), "the 2-DoF problem takes the variance contrast (plain or blurred)");
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the stub: the body copies structs out of the constant address space)
   constexpr int kLHmax = TH + 2 * HALO, kLWmax = TW + 2 * HALO;
   constexpr int kCells = acc_cells<TH, TW, HALO, true>();
@@ -434,13 +439,24 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       EBOS_RSTAMP(1);
       // (own: what this tile's image holds inside the valid region -- its share of sum(IWE), exact; with the blur: of sum(m . B x),
       // position-weighted)
-      OwnSumBlur own{tr.ty * TH - win.HR(), tr.tx * TW - win.HC(), a.omit ? 1 : 0, a.H, a.W, a.blur, 0.0, 0.0};
-      if (!(EBOS_ABL & 2048))
-      tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, UNI, !UNI, true, false, FRAC>(tr, win, UNI ? s_cells : s_flow_f, s_acc, sh, ev, a.H, a.W,
-                                                                                  tiles_x, 0, 0, a.slabs, nullptr, nullptr, 0u, nullptr, pre,
-                                                                                  NoHook{}, own);
+      auto body = [&](auto& own) {
+        if (!(EBOS_ABL & 2048))
+        tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, UNI, !UNI, true, false, FRAC>(tr, win, UNI ? s_cells : s_flow_f, s_acc, sh, ev, a.H, a.W,
+                                                                                    tiles_x, 0, 0, a.slabs, nullptr, nullptr, 0u, nullptr, pre,
+                                                                                    NoHook{}, own);
+      };
+      double os;
+      if constexpr (CONTRAST == RC_BLURRED_VARIANCE) {
+        OwnSumBlur own{tr.ty * TH - win.HR(), tr.tx * TW - win.HC(), a.omit ? 1 : 0, a.H, a.W, a.blur, 0.0, 0.0};
+        body(own);
+        os = own.total();
+      } else {
+        OwnSum own{tr.ty * TH - win.HR(), tr.tx * TW - win.HC(), a.omit ? 1 : 0, a.H, a.W, 0.0};
+        body(own);
+        os = own.acc;
+      }
       EBOS_RSTAMP(2);
-      const double os = wave_sum(own.total());
+      os = wave_sum(os);
       if (lane == 0) s_red[wave] = os;
       drain_stores();
       __syncthreads();
@@ -467,9 +483,9 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     // 45 x 80; beyond that -- or where a tile two away reaches into the gather window -- the launch hands over to the pipeline below.
     // Gradient-magnitude contrast (sobel3.h): the same gather window -- Sobel pairs one pixel around the upstream window, the raw image
     // two around it.  gx lives where the d_flow accumulators will (cleared behind the passes instead of in front of them).
-    const bool blur_on = fresh_args().blur.k0 != 0.0f;  // (uniform)
-    const bool gm_on = !UNI && fresh_args().gm != 0;    // (uniform)
-    const bool raw_on = blur_on || gm_on;               // the gather stages the RAW window; the contrast's passes follow
+    constexpr bool blur_on = CONTRAST == RC_BLURRED_VARIANCE;
+    constexpr bool gm_on = CONTRAST == RC_GRADIENT_MAGNITUDE;
+    constexpr bool raw_on = blur_on || gm_on;           // the gather stages the RAW window; the contrast's passes follow
     const Win<TH, TW, HALO, true> wx = raw_on ? Win<TH, TW, HALO, true>{wb.hr + 2, wb.hc + 4} : wb;
     float4 own_q[kQuads];  // this workgroup's own contribution to the quads of its upstream window, decoded from its LDS image
     double mean;
@@ -563,7 +579,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       __syncthreads();
       mean = s_mom[0];
       halo_complete = 2 * s_wmax[0] < TH && 2 * s_wmax[1] < TW;  // (uniform over the GRID: every workgroup saw every window)
-      if (raw_on) {
+      if constexpr (raw_on) {
         // (uniform over the grid, from the LARGEST window: every gather window lies within the 3 x 3 tiles around its own, no tile
         // two away reaches into it, and the raw + blurred windows fit the LDS region -- with the Sobel pairs: raw window + gy there,
         // gx in the d_flow accumulators' region)
@@ -787,7 +803,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           f(r0 + rt + k, q < cl_ ? c0 + q : c0 + nc - cr_ + (q - cl_));
         }
       };
-      if (blur_on) {
+      if constexpr (blur_on) {
         // ---- blurred contrast: raw window (s_g, [wx]) -> masked blurred window (behind it: upstream window + 1 row / 4 columns per
         // side, i.e. the raw window's columns) -> upstream window a z + c wgt, z = B^T (m . B x) (s_g again, [wb]): the arithmetic of
         // the pipeline's image pass and backward staging (blur3.h, GradImage::map), on what this workgroup gathered.  The passes are
@@ -886,8 +902,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           }
         }
       }
-      if constexpr (!UNI)
-      if (gm_on) {
+      if constexpr (gm_on) {
         // ---- gradient-magnitude contrast: raw window (s_g, [wx]) -> Sobel pairs on upstream window + 1 row / 4 columns per side
         // (gx where the d_flow accumulators will be, gy behind the raw window) -> upstream window s . gather of the nine stencils around each pixel (s_g again,
         // [wb]): the arithmetic of the pipeline's image pass (gradmag_fused_kernel through sobel3.h) on what this workgroup gathered.
@@ -1088,7 +1103,8 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       G.a = (float)ga;
       G.c = (float)(-ga * mean);
       G.h = H, G.w = W, G.lo = lo_px;
-      G.set_blur(a.blur);
+      if constexpr (blur_on) G.set_blur(a.blur);
+      else G.set_blur(Blur3{0.0f, 0.0f});
       EBOS_RSTAMP(9);
       unit = bwd_fx_unit(s_gmax, a.dt_bound, wb.LH() * wb.LW());
       const BwdShared bsh{&s_spill, &s_bad, &s_next};
@@ -1399,10 +1415,10 @@ int order_resident_launches(hipStream_t s, int workgroups, int n_cu, bool after_
 
 namespace {
 
-template <int TH, int TW, int HALO, bool UNI, bool FRAC = false>
+template <int TH, int TW, int HALO, bool UNI, bool FRAC = false, int CONTRAST = RC_VARIANCE>
 int launch_resident(const ResidentArgs& a, void* mailbox, size_t mailbox_total, hipStream_t s) {
   if constexpr (resident_fits<TH, TW, HALO>()) {
-    auto k = cmax_resident_kernel<TH, TW, HALO, UNI, FRAC>;
+    auto k = cmax_resident_kernel<TH, TW, HALO, UNI, FRAC, CONTRAST>;
     constexpr size_t lds = resident_lds_bytes<TH, TW, HALO>();
     if (int rc = reserve_lds(k, lds, "ebos_cmax_solve_resident")) return rc;
     int dev = 0, n_cu = 0, per_cu = 0;
@@ -1505,26 +1521,38 @@ inline ResidentArgs resident_args(const ebos_cmax_2dof_problem* q, int n_iter, v
   return a;
 }
 
-// one translation unit per tile shape defines its launcher with this body (EBOS_RESIDENT_TILE_UNIT)
+// Two translation units per tile shape define its launchers with these bodies: cmax_resident_<tile>.hip the patch-grid kernels (one per
+// contrast), cmax_resident_<tile>_2dof.hip the 2-DoF ones (plain / blurred variance x integer / fractional source coordinates)
 template <int TH, int TW, int HALO>
-int resident_tile_launch(const ebos_cmax_patch_problem* q, const ebos_cmax_2dof_problem* q2, float w_variance2, int n_iter, void* mailbox,
-                         double spin_timeout_s, hipStream_t s) {
-  const int H = q ? q->H : q2->H, W = q ? q->W : q2->W;
-  const MailboxLayout m = mailbox_layout(((H + TH - 1) / TH) * ((W + TW - 1) / TW));
-  if (q != nullptr) return launch_resident<TH, TW, HALO, false>(resident_args(q, n_iter, mailbox, spin_timeout_s), mailbox, m.total, s);
-  if (q2->cfx != nullptr)  // fractional source coordinates
-    return launch_resident<TH, TW, HALO, true, true>(resident_args(q2, n_iter, mailbox, spin_timeout_s, w_variance2), mailbox, m.total, s);
-  return launch_resident<TH, TW, HALO, true>(resident_args(q2, n_iter, mailbox, spin_timeout_s, w_variance2), mailbox, m.total, s);
+int resident_patch_launch(const ebos_cmax_patch_problem* q, int n_iter, void* mailbox, double spin_timeout_s, hipStream_t s) {
+  const MailboxLayout m = mailbox_layout(((q->H + TH - 1) / TH) * ((q->W + TW - 1) / TW));
+  const ResidentArgs a = resident_args(q, n_iter, mailbox, spin_timeout_s);
+  if (a.gm) return launch_resident<TH, TW, HALO, false, false, RC_GRADIENT_MAGNITUDE>(a, mailbox, m.total, s);
+  if (a.blur.k0 != 0.0f) return launch_resident<TH, TW, HALO, false, false, RC_BLURRED_VARIANCE>(a, mailbox, m.total, s);
+  return launch_resident<TH, TW, HALO, false, false, RC_VARIANCE>(a, mailbox, m.total, s);
+}
+template <int TH, int TW, int HALO>
+int resident_2dof_launch(const ebos_cmax_2dof_problem* q, float w_variance, int n_iter, void* mailbox, double spin_timeout_s, hipStream_t s) {
+  const MailboxLayout m = mailbox_layout(((q->H + TH - 1) / TH) * ((q->W + TW - 1) / TW));
+  const ResidentArgs a = resident_args(q, n_iter, mailbox, spin_timeout_s, w_variance);
+  const bool blur = a.blur.k0 != 0.0f;
+  if (q->cfx != nullptr)  // fractional source coordinates
+    return blur ? launch_resident<TH, TW, HALO, true, true, RC_BLURRED_VARIANCE>(a, mailbox, m.total, s)
+                : launch_resident<TH, TW, HALO, true, true, RC_VARIANCE>(a, mailbox, m.total, s);
+  return blur ? launch_resident<TH, TW, HALO, true, false, RC_BLURRED_VARIANCE>(a, mailbox, m.total, s)
+              : launch_resident<TH, TW, HALO, true, false, RC_VARIANCE>(a, mailbox, m.total, s);
 }
 
 }  // namespace
 
-// the per-tile-shape launchers (cmax_resident_<TH>x<TW>.hip); exactly one of q / q2 is non-NULL
-int resident_launch_45x80(const ebos_cmax_patch_problem* q, const ebos_cmax_2dof_problem* q2, float w_variance2, int n_iter, void* mailbox,
-                          double spin_timeout_s, hipStream_t s);
-int resident_launch_32x32(const ebos_cmax_patch_problem* q, const ebos_cmax_2dof_problem* q2, float w_variance2, int n_iter, void* mailbox,
-                          double spin_timeout_s, hipStream_t s);
-int resident_launch_32x64(const ebos_cmax_patch_problem* q, const ebos_cmax_2dof_problem* q2, float w_variance2, int n_iter, void* mailbox,
-                          double spin_timeout_s, hipStream_t s);
+// the per-tile-shape launchers (cmax_resident_<TH>x<TW>.hip, cmax_resident_<TH>x<TW>_2dof.hip)
+#define EBOS_RESIDENT_LAUNCHERS(TILE)                                                                                                     \
+  int resident_launch_##TILE(const ebos_cmax_patch_problem* q, int n_iter, void* mailbox, double spin_timeout_s, hipStream_t s);         \
+  int resident_launch_2dof_##TILE(const ebos_cmax_2dof_problem* q, float w_variance, int n_iter, void* mailbox, double spin_timeout_s,   \
+                                  hipStream_t s);
+EBOS_RESIDENT_LAUNCHERS(45x80)
+EBOS_RESIDENT_LAUNCHERS(32x32)
+EBOS_RESIDENT_LAUNCHERS(32x64)
+#undef EBOS_RESIDENT_LAUNCHERS
 
 }  // namespace ebos

@@ -7,6 +7,6 @@ python -m event_based_bos_amd.build > /dev/null
 mkdir -p /tmp/ebos_stamps
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -fPIC -fno-gpu-rdc -Wno-unused-function -Iinclude \
   -Ievent_based_bos_amd/csrc -DEBOS_STAMPS -DEBOS_STAMPS_EPI -mllvm -sink-insts-to-avoid-spills=1 -x hip -c event_based_bos_amd/csrc/cmax_resident_45x80.hip -o /tmp/ebos_stamps/cmax_resident_45x80.o
-OBJS=$(ls event_based_bos_amd/lib/obj/*.o | grep -v cmax_resident_45x80)
+OBJS=$(ls event_based_bos_amd/lib/obj/*.o | grep -v "cmax_resident_45x80\.o")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o event_based_bos_amd/lib/libebos_stamps.so /tmp/ebos_stamps/cmax_resident_45x80.o $OBJS
 ls -la event_based_bos_amd/lib/libebos_stamps.so

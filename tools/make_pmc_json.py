@@ -40,8 +40,11 @@ def key_of(name):
         uni, grid, dyn = flag(5), flag(6), flag(7)
     elif base in ("iwe_slab_combine4_kernel", "iwe_slab_combine4_batch_kernel"):  # <TH, TW, HALO, DYN>
         uni, grid, dyn = False, False, flag(3)
-    elif base == "cmax_resident_kernel":          # <TH, TW, HALO, UNI, FRAC>: the patch-grid loop, or the 2-DoF one
-        return base + ("<UNI,FRAC>" if flag(3) and flag(4) else ("<UNI>" if flag(3) else "")), name
+    elif base == "cmax_resident_kernel":          # <TH, TW, HALO, UNI, FRAC, CONTRAST>: the patch-grid loop, or the 2-DoF one
+        tags = (["UNI"] if flag(3) else []) + (["FRAC"] if flag(4) else [])
+        contrast = args[5].strip() if len(args) > 5 else "0"
+        tags += {"0": [], "1": ["BLUR"], "2": ["GM"]}.get(contrast, [contrast])
+        return base + ("<" + ",".join(tags) + ">" if tags else ""), name
     else:
         return base, name
     kind = "UNIFORM" if uni else ("GRID" if grid else "DENSE")
