@@ -504,7 +504,9 @@ def run_config2(R):
         ev[:, 1] += rs_f.randint(0, 64, n) / 64.0
     weights_np = np.random.RandomState(777 + rank).uniform(0.5, 1.5, n).astype(np.float32) if a.weighted else None
     if general:
-        a.no_compact, a.no_extras = True, True  # (the informative legs are the unit-weight compact plan's)
+        a.no_extras = True  # (the informative legs are the unit-weight compact plan's)
+    if a.fractional:
+        a.no_compact = True  # (the compact format holds integer source pixels; per-event weights ride along with it in plan order)
     ev_gpu = torch.from_numpy(ev).to(dev)
     flow = torch.from_numpy(flow_np).float().to(dev)
     if a.tile[0] <= 0:
@@ -525,7 +527,8 @@ def run_config2(R):
         return pl, first, best
 
     _, _, plan_build_full_ms = time_build("full")
-    plan, plan_first_ms, plan_build_ms = time_build("full" if a.no_compact else "compact")
+    # (per-event weights are permuted like the events: the full build keeps the permutation)
+    plan, plan_first_ms, plan_build_ms = time_build("full" if (a.no_compact or a.weighted) else "compact")
     ingest_s = time.perf_counter() - t_ingest  # host synthesis + upload + the timed plan builds: what a rank spends before its first step
     del ev_gpu
     a.halo_code = ebos.event_plan.resolve_halo(plan, a.halo)  # an int for the C ABI ('auto' -> EBOS_HALO_AUTO(32, 64 max|dt|))
@@ -786,8 +789,10 @@ def run_config2(R):
         format_bytes = bytes_per_event * plan.n + 12.0 * H * W  # what the plan format actually stores per event
         k_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
         kname = "iwe_slab_accumulate_kernel<DENSE,DYN>" if a.halo == "auto" else "iwe_slab_accumulate_kernel"
-        if general or a.no_compact:  # other instantiations: the committed counters are the compact unit-weight kernel's
+        if not cptrs[0]:  # other instantiations: the committed counters are the compact unit-weight kernel's
             kname = "iwe_slab_accumulate_kernel<XY" + (",W>" if a.weighted else ">")
+        elif a.weighted:
+            kname = "iwe_slab_accumulate_kernel<W>"
         roof = roofline_entry(kname, kernel_ms, algo_bytes,
                               {"measured_copy_GBps": round(copy_gbs, 1),
                                "frac_of_measured_copy": round(algo_bytes / (k_ms * 1e-3) / 1e9 / copy_gbs, 4),
@@ -801,9 +806,10 @@ def run_config2(R):
                          "variance cost, fwd objective (tile accumulate + slab combine + variance)") if (a.flow_max == FLOW_MAX and n == N_EVENTS and not general)
                         else (f"NOT the BASELINE workload: {n} events, flow U(-{a.flow_max:g},{a.flow_max:g})"
                               + (", source coordinates on a 1/64 px grid (12 B/event format, truncated flow look-up)" if a.fractional else "")
-                              + (", per-event weights U(0.5, 1.5) (f64 LDS accumulation)" if a.weighted else "")),
+                              + (", per-event weights U(0.5, 1.5) (fixed point in units of the slice's max |w|)" if a.weighted else "")),
             "events_per_gpu": n, "events_in_plan": plan.n, "height": H, "width": W,
-            "layout": ("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if cptrs[0] else "SoA f32 (x,y,dt), 12 B/event" + (" + f32 weight" if a.weighted else ""))
+            "layout": (("compact SoA (u16 tile-local pixel + f32 dt, 6 B/event)" if cptrs[0] else "SoA f32 (x,y,dt), 12 B/event")
+                       + (" + f32 weight in plan order" if a.weighted else ""))
                       + f", binned by source tile {a.tile[0]}x{a.tile[1]}, halo {a.halo}, splits {a.splits}",
             "parallelism": f"windows sharded, {world} rank(s), no collective"})
         line["roofline"] = roof

@@ -144,6 +144,23 @@ __device__ __forceinline__ TileRange tile_range(const int32_t* __restrict__ key_
   return r;
 }
 
+// Per-event weights are stored in PLAN order (the caller permutes them like the events).  A group of the (x, y, dt) format is four
+// consecutive plan indices 4 j .. 4 j + 3; a group of the compact format is four consecutive events of its TILE, whose slots are the
+// tile's plan indices in order (padded to a multiple of four at the tile's end): group j of a work item that starts at group g_first /
+// plan index beg holds beg + 4 (j - g_first) .. + 3 -- not 16-byte aligned in general (a dword-aligned 16-byte load; the weight array
+// is padded by a group).
+template <int FMT>
+__device__ __forceinline__ int32_t group_plan_index(int32_t j, const TileRange& tr) {
+  return FMT == FMT_COMPACT ? tr.beg + 4 * (j - tr.g_first) : 4 * j;
+}
+template <int FMT>
+__device__ __forceinline__ float4 load_weights4(const float* __restrict__ w, int32_t j, const TileRange& tr) {
+  float4 v;
+  if (FMT == FMT_COMPACT) __builtin_memcpy(&v, w + group_plan_index<FMT>(j, tr), sizeof(float4));
+  else v = reinterpret_cast<const float4*>(w)[j];
+  return v;
+}
+
 // Branch-free: group indices past the slice are clamped (the loops never PROCESS such a group, they only prefetch
 // it).  Predicated loads would become exec-masked branches and hipcc then waits vmcnt(0) for them, draining the
 // prefetch that is supposed to stay in flight.
@@ -154,13 +171,15 @@ __device__ __forceinline__ void load_group(Group& g, int32_t grp, const TileRang
   if (FMT == FMT_COMPACT) {
     const float4 D = reinterpret_cast<const float4*>(p.cdt)[j];
     const uint2 P = reinterpret_cast<const uint2*>(p.cpix)[j];
-    const float dd[4] = {D.x, D.y, D.z, D.w};
+    float4 Wv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (HAS_W) Wv = load_weights4<FMT_COMPACT>(p.w, j, tr);
+    const float dd[4] = {D.x, D.y, D.z, D.w}, ww[4] = {Wv.x, Wv.y, Wv.z, Wv.w};
     const unsigned pp[4] = {P.x & 0xffffu, P.x >> 16, P.y & 0xffffu, P.y >> 16};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool live = dd[e] == dd[e];  // padding slots carry NaN
       g.dt[e] = live ? dd[e] : 0.0f;
-      g.w[e] = live ? 1.0f : 0.0f;
+      g.w[e] = live ? ww[e] : 0.0f;
       g.rs[e] = tile_r0 + (int)(pp[e] >> 8);
       g.cs[e] = tile_c0 + (int)(pp[e] & 255u);
       g.fx[e] = 0.0f;
@@ -505,11 +524,17 @@ __device__ __forceinline__ int32_t chunk_group(int32_t g_first, int c, int lane)
 // their ds_add_u64 no longer meet on the same words: SQ_LDS_ADDR_CONFLICT per launch is 0.33 M at 30 px flows but 2.3 M at 6 px,
 // 4.8 M at 2 px and 5.8 M at 0.5 px with the plain mapping -- the loop ran 18.5 / 22.0 / 27.7 / 30.4 us; BOS flows are the small
 // ones (profiles/r03_small_flow_conflicts.txt).  A lane's two groups are adjacent in memory: its loads stay coalesced.
-template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false, bool DYN = false, bool PAIRS = false>
+// HAS_W (plain mapping, fixed point): per-event weights ride along in plan order (load_weights4, 10 B / event).  An event's unit is
+// then U = rint(w * wscale) <= 2^20 (wscale = 2^20 / max |w| of the slice, TileShared) instead of the constant 2^20, split between
+// the four taps by the same exact scheme; the units put inside the window are summed per lane (the return value) -- three
+// multiply-adds and a 64-bit add per event on top of the unit-weight loop.
+template <int TH, int TW, int HALO, bool UNIFORM, int MODE = ACC_FX, bool GRID = false, bool DYN = false, bool PAIRS = false,
+          bool HAS_W = false>
 __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRange& tr, double* s_acc, const EvPtrs& ev,
                                                           const float* __restrict__ flow, int H, int W, bool* any_spill,
                                                           const ChunkQueue& queue, const Win<TH, TW, HALO, DYN>& win,
-                                                          const CRaw* pre = nullptr) {
+                                                          const CRaw* pre = nullptr, float wscale = kFxScale) {
+  static_assert(!HAS_W || (MODE == ACC_FX && !PAIRS && !DYN), "per-event weights: the plain fixed-point loop on the largest window");
   const int LH = win.LH(), LW = win.LW(), HR = win.HR(), HC = win.HC(), PT = win.P();  // (compile-time constants unless DYN)
   const unsigned kPlane = LH * PT / 2;  // words per plane
   const unsigned kDummy = LH * PT;      // first word of the dummy region (PT / 2 + 2 words)
@@ -552,8 +577,10 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   constexpr int kWaves = kBlock / kWave;
   char* const s_bytes = reinterpret_cast<char*>(s_acc);
-  // the four events of one group into the LDS image (fu / fv: their flow, gathered one step earlier)
-  auto deposit = [&](const CGroupQ& cur, const float* fu, const float* fv, bool lane_live) {
+  unsigned long long added = 0ull;  // HAS_W: the units this lane put inside the window
+  // the four events of one group into the LDS image (fu / fv: their flow, gathered one step earlier; wq: their weights)
+  auto deposit = [&](const CGroupQ& cur, const float* fu, const float* fv, bool lane_live, const float4& wq4 = float4{}) {
+    const float wq[4] = {wq4.x, wq4.y, wq4.z, wq4.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) EBOS_KLOOP {
       const float lx = -cur.dt[e] * EBOS_KOFF(fu[e], 0.37f), ly = -cur.dt[e] * EBOS_KOFF(fv[e], -0.21f);  // source coordinates are integers: x' = rs + lx
@@ -582,8 +609,14 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
       // columns -- every tap is a non-negative integer and the four sum to 2^20 whatever the rounding, so the checksum
       // of a wave is 2^20 x (events it put inside the window): a mask population count, no per-event arithmetic.
       const float b = 1.0f - fc;
-      const float t0 = __fmaf_rn(fr, -kFxScale, kFxScale + kMagic);  // magic + A0,  A0 = rint(2^20 (1 - fr))
-      const float a0 = t0 - kMagic, a1 = kFxScale - a0;               // A0, A1 = 2^20 - A0 as floats (exact)
+      float unit = kFxScale;  // (a compile-time constant without weights)
+      if (HAS_W) {            // U = rint(w * wscale): an integer-valued float <= 2^20 (w >= 0 and finite: the set-up's pre-pass saw to it)
+        const float tu = __fmaf_rn(wq[e], wscale, kMagic);
+        unit = tu - kMagic;
+        added += inside ? (unsigned long long)(unsigned)(__float_as_int(tu) - kMagicBits) : 0ull;
+      }
+      const float t0 = __fmaf_rn(fr, -unit, unit + kMagic);  // magic + A0,  A0 = rint(U (1 - fr))   (U = 2^20 without weights)
+      const float a0 = t0 - kMagic, a1 = unit - a0;           // A0, A1 = U - A0 as floats (exact)
       const float u0 = __fmaf_rn(a0, b, kMagic), u1 = __fmaf_rn(a1, b, kMagic);
       const float t1 = a1 + kMagic;
       const unsigned q00 = (unsigned)(__float_as_int(u0) - kMagicBits);
@@ -641,6 +674,10 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   // chunk c covers groups [g_first + 64 c, g_first + 64 c + 64); this wave starts with chunks `wave` and `wave + 16`
   int c_cur = wave, c_nxt = wave + kWaves;
   CGroupQ cur, nxt;
+  float4 w_cur = float4{}, w_nxt = float4{};
+  auto weights_of = [&](int c) {  // (clamped like the group loads: a chunk past the slice is only ever prefetched)
+    return load_weights4<FMT_COMPACT>(ev.w, max(min(chunk_group(tr.g_first, c, lane), tr.g_last), tr.g_first), tr);
+  };
   if (pre != nullptr) {  // (persistent batched kernel: this window's first two chunks were requested during the previous window)
     decode_craw(cur, pre[0], hc4);
     decode_craw(nxt, pre[1], hc4);
@@ -648,6 +685,7 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
     load_cgroup_q(cur, chunk_group(tr.g_first, c_cur, lane), tr, ev, hc4);
     load_cgroup_q(nxt, chunk_group(tr.g_first, c_nxt, lane), tr, ev, hc4);
   }
+  if (HAS_W) w_cur = weights_of(c_cur), w_nxt = weights_of(c_nxt);
   float fu[4], fv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) fetch(cur.pr[e], cur.pcq[e], fu[e], fv[e]);
@@ -659,10 +697,14 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
     const int c_nn = queue.pull();
     CGroupQ nn;
     load_cgroup_q(nn, chunk_group(tr.g_first, c_nn, lane), tr, ev, hc4);
+    float4 w_nn = float4{};
+    if (HAS_W) w_nn = weights_of(c_nn);
     const bool lane_live = grp <= g_last;  // the last chunk of the slice may be partial
-    deposit(cur, fu, fv, lane_live);
+    deposit(cur, fu, fv, lane_live, w_cur);
     cur = nxt;
     nxt = nn;
+    w_cur = w_nxt;
+    w_nxt = w_nn;
     c_cur = c_nxt;
     c_nxt = c_nn;
 #pragma unroll
@@ -676,7 +718,8 @@ __device__ __forceinline__ unsigned long long accumulate_compact_fx(const TileRa
   // Checksum: nothing is counted per event.  Every finite event whose taps are inside the window adds exactly 2^20 units, so the
   // kernel expects 2^20 x (events of the slice - events the spill pass took over); a non-finite event (NaN / Inf flow or time)
   // makes the sums disagree and the slice is redone by the exact f64 loop, which is correct for it as well.
-  return 0ull;
+  // (HAS_W: the units of the events inside the window, counted as they were added.)
+  return added;
 }
 
 // PASS_MAIN: the lean hot loop -- every tap that lands inside the LDS window is accumulated, branch-free (dead or
@@ -710,6 +753,9 @@ __device__ __forceinline__ unsigned long long accumulate_slice(const TileRange& 
   if (tr.g_first > tr.g_last) return 0;
   if (FMT == FMT_COMPACT && PASS == PASS_MAIN && !HAS_W && !FRAC)  // the lean hot loop (fixed point, or its exact f64 redo)
     return accumulate_compact_fx<TH, TW, HALO, UNIFORM, MODE, GRID, DYN, PAIRS>(tr, s_acc, ev, flow, H, W, any_spill, queue, win, pre);
+  if constexpr (FMT == FMT_COMPACT && PASS == PASS_MAIN && HAS_W && !FRAC && MODE == ACC_FX && !DYN && !PAIRS)  // ... with per-event weights
+    return accumulate_compact_fx<TH, TW, HALO, UNIFORM, ACC_FX, GRID, false, false, true>(tr, s_acc, ev, flow, H, W, any_spill, queue, win,
+                                                                                       nullptr, wscale);
   // 3-stage software pipeline per lane:  16-byte SoA loads of group k+2 | flow gathers of group k+1 | LDS adds of
   // group k.  Everything is unconditional (clamped indices), so hipcc counts the queue and waits with vmcnt(N > 0).
   const int32_t g_last = tr.g_last;
@@ -1169,11 +1215,11 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
     float am = 0.0f;
     bool odd = false;  // a negative, NaN or Inf weight: the unsigned fields cannot hold it -- the slice takes the exact f64 pass
     for (int32_t g = tr.g_first + threadIdx.x; g <= tr.g_last; g += kBlock) {
-      const float4 Wv = reinterpret_cast<const float4*>(ev.w)[g];
+      const float4 Wv = load_weights4<FMT>(ev.w, g, tr);
       const float ww[4] = {Wv.x, Wv.y, Wv.z, Wv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int32_t i = 4 * g + e;
+        const int32_t i = group_plan_index<FMT>(g, tr) + e;
         if (i >= tr.beg && i < tr.end) {
           am = fmaxf(am, fabsf(ww[e]));
           odd |= !(ww[e] >= 0.0f && ww[e] < 3.0e38f);
@@ -2664,7 +2710,8 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
         const float wv = cur.w[e];
         // plan index of this slot: FMT_XY groups are aligned to the plan, compact groups to the tile
         const int32_t i = FMT == FMT_COMPACT ? tr.beg + 4 * (grp - tr.g_first) + e : 4 * grp + e;
-        const bool live = FMT == FMT_COMPACT ? (wv != 0.0f) : (i >= tr.beg && i < tr.end);  // (XY weights may be 0)
+        // (a real weight may be 0 -- its d_weight is still wanted: only unit-weight compact groups mark their padding by w == 0)
+        const bool live = (FMT == FMT_COMPACT && !HAS_W) ? (wv != 0.0f) : (i >= tr.beg && i < tr.end);
         if (!live) continue;
         const float edt = cur.dt[e];
         const Taps f = warped_taps(cur.rs[e], cur.cs[e], cur.fx[e] - edt * fu[e], cur.fy[e] - edt * fv[e]);

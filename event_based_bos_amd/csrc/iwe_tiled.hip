@@ -105,9 +105,11 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   // exact f64 redo where a field wraps (overflow, negative weights)
   void (*ka)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, int, float*, float*, GridSrc, unsigned*, unsigned, float,
              unsigned*);
-  const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
+  // (a compact plan holds integer source pixels; per-event weights ride along in plan order: load_weights4 -- 10 B / event instead
+  // of the (x, y, dt) format's 16)
+  const bool compact = ev.cpix != nullptr;
   // run-time windows: the lean loop only (compact plan, unit weights, fixed point); anything else runs the largest window
-  const bool dyn = ha.dyn && compact && acc_mode == ACC_FX;
+  const bool dyn = ha.dyn && compact && ev.w == nullptr && acc_mode == ACC_FX;
   if (dyn) lds = (size_t)acc_cells<TH, TW, HALO, true>() * sizeof(double);
   GridSrc gs{};
 #define EBOS_PICK(HW, MD)                                                                                              \
@@ -256,8 +258,8 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
     set_error("ebos_iwe_*_tiled_bwd: a %dx%d flow gradient does not fit 32-bit byte offsets", H, W);
     return EBOS_ERR_UNSUPPORTED;
   }
-  const bool compact = ev.cpix != nullptr && ev.w == nullptr;  // per-event weights are in plan order: (x, y, dt) format
-  const bool dyn = ha.dyn && compact;  // run-time windows: the lean loop only
+  const bool compact = ev.cpix != nullptr;  // (per-event weights ride along in plan order: load_weights4)
+  const bool dyn = ha.dyn && compact && ev.w == nullptr;  // run-time windows: the lean loop only
   void (*kb)(EvPtrs, const int32_t*, const float*, int, int, int, int, int, const float*, const float*, int, float*, float*, double*,
              const double*, const float*, const float*, float*, GridSrc, int, float, float, double*, MomentsIn, float);
   if (grid_src != nullptr) {

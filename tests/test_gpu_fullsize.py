@@ -260,3 +260,51 @@ def test_general_event_formats_at_1280x720_vs_oracle():
     print(f"[the same, un-filtered] IWE rel-L2 {O.rel_l2(iwe_g2, iwe_r2):.2e}, d/d flow {O.rel_l2(gf_g2, gf_r2):.2e}, "
           f"d/d weight {O.rel_l2(gw_g2, gw_r2):.2e}")
     assert O.rel_l2(iwe_g2, iwe_r2) < 1e-4 and O.rel_l2(gw_g2, gw_r2) < 1e-3
+
+
+def test_weighted_integer_pixel_events_at_1280x720_vs_oracle():
+    """Per-event weights on raw sensor events (integer source pixels), at the sensor's size: the compact 6 B/event format with the
+    weights riding along in plan order (10 B/event: csrc/iwe_tile_core.h load_weights4, the fixed-point loop in units of the slice's
+    max |w|) instead of the 16 B/event (x, y, dt, w) format -- src/event_image_converter.py:576-577, 608-613.  2 M events, weights
+    U(0.25, 2) with exact zeros among them (an event of weight 0 still has a d loss / d weight), against the fp64 oracle: IWE rel-L2
+    < 1e-4, d loss / d flow and d loss / d weight rel-L2 < 1e-3 (events within 5e-4 px of a kink of the vote dropped).  One
+    negative weight sends its tile through the exact f64 pass: same bars."""
+    import event_based_bos_amd as ebos
+
+    n = 2_000_000
+    rs = np.random.RandomState(31)
+    ev = np.stack([rs.randint(0, H, n), rs.randint(0, W, n), np.sort(rs.uniform(0.0, 0.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
+    fl = np.random.RandomState(32).uniform(-12.0, 12.0, (2, H, W))
+    wt = rs.uniform(0.25, 2.0, n)
+    wt[rs.randint(0, n, 1000)] = 0.0
+    warped = O.warp_dense_torch(torch.from_numpy(ev), torch.from_numpy(fl), "first", True).numpy().reshape(-1, 4)
+    keep = ~(np.abs(warped[:, :2] - np.rint(warped[:, :2])) < 5e-4).any(1)
+    keep[[0, -1]] = True
+    ev, wt = ev[keep], wt[keep]
+
+    def oracle(wv):
+        f = torch.from_numpy(fl).requires_grad_(True)
+        wg = torch.from_numpy(wv).requires_grad_(True)
+        iwe = O.iwe_dense(torch.from_numpy(ev), f, (H, W), weight=wg)
+        loss = O.image_variance(iwe)
+        loss.backward()
+        return iwe.detach().numpy(), loss.item(), f.grad.numpy(), wg.grad.numpy()
+
+    def hip(wv):
+        plan = ebos.EventPlan.build(torch.from_numpy(ev).float().cuda(), (H, W), "first", True, tile="auto")
+        assert plan.binned and plan.compact and not plan.lean     # the full build: compact events AND the permutation
+        f = torch.from_numpy(fl).float().cuda().requires_grad_(True)
+        wg = torch.from_numpy(wv).float().cuda().requires_grad_(True)
+        iwe = plan.iwe_dense(f, weight=wg)
+        loss = -ebos.ops.image_variance(iwe)
+        loss.backward()
+        return iwe.detach().cpu().numpy(), loss.item(), f.grad.cpu().numpy(), wg.grad.cpu().numpy()
+
+    for tag, wv in (("weights >= 0", wt), ("one negative weight", np.concatenate([wt[:1000], [-1.5], wt[1001:]]))):
+        iwe_r, l_r, gf_r, gw_r = oracle(wv)
+        iwe_g, l_g, gf_g, gw_g = hip(wv)
+        e_iwe, e_f, e_w = O.rel_l2(iwe_g, iwe_r), O.rel_l2(gf_g, gf_r), O.rel_l2(gw_g, gw_r)
+        print(f"[integer pixels + weights ({tag}), {len(ev)} events] IWE rel-L2 {e_iwe:.2e}, loss rel {abs(l_g - l_r) / abs(l_r):.2e}, "
+              f"d/d flow {e_f:.2e}, d/d weight {e_w:.2e}")
+        assert e_iwe < 1e-4 and abs(l_g - l_r) < 1e-5 * abs(l_r) and e_f < 1e-3 and e_w < 1e-3
+        assert np.isfinite(gw_g).all() and np.abs(gw_g[wv == 0.0]).max() > 0.0   # (weight 0: the sampled upstream image, not a skipped slot)

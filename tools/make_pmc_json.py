@@ -34,6 +34,8 @@ def key_of(name):
         uni, grid, dyn = flag(6), flag(7), flag(8)
         if len(args) > 5 and args[5] in ("0", "(ebos::(anonymous namespace)::EvFormat)0") and not uni:  # FMT_XY: the general 12 B/event format
             return "iwe_slab_accumulate_kernel<XY" + (",W>" if flag(3) else ">"), name
+        if flag(3) and not uni:  # per-event weights on the compact format (10 B/event)
+            return "iwe_slab_accumulate_kernel<W>", name
     elif base == "iwe_slab_accumulate_batch_kernel":  # <TH, TW, HALO, GRID, DYN, UNIFORM>
         uni, grid, dyn = flag(5), flag(3), flag(4)
     elif base == "iwe_dense_tiled_bwd_kernel":    # <TH, TW, HALO, HAS_W, FMT, UNIFORM, GRID, DYN>
