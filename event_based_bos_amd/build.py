@@ -24,6 +24,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libebos_hip.so")
 
 SOURCES = ["errors.cpp", "warp_kernels.hip", "splat_kernels.hip", "event_plan.hip", "plan_lean.hip", "iwe_fused.hip", "iwe_tiled.hip",
            "cost_kernels.hip", "flow_upsample.hip", "image_filters.hip", "solver_kernels.hip", "cmax_resident.hip",
+           "iwe_tiled_64x64x32.hip", "iwe_tiled_45x80x32.hip", "iwe_tiled_32x64x32.hip", "iwe_tiled_32x32x32.hip", "iwe_tiled_64x64x16.hip",
+           "iwe_tiled_45x80x16.hip", "iwe_tiled_32x32x16.hip", "iwe_tiled_32x32x8.hip",
            "cmax_resident_45x80.hip", "cmax_resident_32x32.hip", "cmax_resident_32x64.hip",
            "cmax_resident_45x80_2dof.hip", "cmax_resident_32x32_2dof.hip", "cmax_resident_32x64_2dof.hip"]
 
@@ -76,8 +78,8 @@ def build_library(force: bool = False, keep_temps: bool = False, verbose: bool =
     extra = ["-save-temps=obj"] if keep_temps else []
     extra += os.environ.get("EBOS_EXTRA_FLAGS", "").split()  # e.g. -DEBOS_STAMPS for the diagnostic build
     with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get("EBOS_BUILD_JOBS", "7")), len(SOURCES))) as ex:
-        # (the slow units first: the resident kernels' take minutes, everything else seconds)
-        order = sorted(SOURCES, key=lambda s: 0 if s.endswith("_2dof.hip") else (1 if s.startswith("cmax_resident_") else 2))
+        # (the slow units first: a tile configuration's kernels take 20 - 30 s, most other units a few)
+        order = sorted(SOURCES, key=lambda s: 0 if s.startswith("iwe_tiled_") else (1 if s.startswith("cmax_resident_") else 2))
         built = dict(zip(order, ex.map(lambda s: _compile(s, extra), order)))
         objs = [built[s] for s in SOURCES]
     if force or _needs_rebuild(LIB_PATH, objs):

@@ -830,11 +830,11 @@ def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma
     print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
     # (frac: the four launches form x' = x + dt theta from the ABSOLUTE coordinate in f32, the resident loop from the fraction --
     # positions differ by ~1e-4 px at x ~ 1000, and 150 normalised Adam steps on structure-less events carry that along)
-    np.testing.assert_allclose(l_res, l_ref, rtol=1e-4 if frac else 2e-5)
+    np.testing.assert_allclose(l_res, l_ref, rtol=3e-4 if frac else 2e-5)
     np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=0.2 if frac else 1e-3)
     if not frac:
         np.testing.assert_allclose(res.exp_avg.cpu().numpy(), ref.exp_avg.cpu().numpy(), rtol=2e-2, atol=1e-7)
-    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=1e-4 if frac else 2e-5)
+    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=3e-4 if frac else 2e-5)
     a = ref.run(10, resident=True).cpu().numpy()      # continued by the other mode
     b = res.run(10, resident=False).cpu().numpy()
     if not frac:
