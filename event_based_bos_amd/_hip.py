@@ -158,7 +158,7 @@ class CmaxPatchProblem(C.Structure):
                 [("cost_scratch_bytes", _Z)] +
                 [(k, _P) for k in ("moments", "upstream", "reg_partials", "upsample_scratch", "workspace")] +
                 [("workspace_bytes", _Z), ("losses", _P), ("losses_cap", _I), ("theta_mask", _P), ("grad_partials", _P),
-                 ("grad_partials_bytes", _Z), ("blur_k0", _F), ("blur_k1", _F), ("blur_image", _P)])
+                 ("grad_partials_bytes", _Z), ("blur_k0", _F), ("blur_k1", _F), ("blur_image", _P), ("cfx", _P), ("cfy", _P)])
 
 
 class Cmax2dofProblem(C.Structure):

@@ -56,8 +56,10 @@ namespace {
 // the geometry / objective a resident launch takes; reason in ebos_last_error otherwise
 bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
   const int halo = decode_halo(q->halo).halo;
-  if (q->grad_partials == nullptr || !q->grp_offsets || !q->cpix || !q->cdt) {
-    set_error("resident solve: needs the grid-sampling route (grad_partials) on a compact plan");
+  // (integer source pixels: the loop object of the grid-sampling route, whose four launches can take over; fractional ones: the
+  // compact arrays with the fractions per slot -- that window's four-launch loop runs on the dense route)
+  if (!q->grp_offsets || !q->cpix || !q->cdt || (q->grad_partials == nullptr && q->cfx == nullptr) || (q->cfx == nullptr) != (q->cfy == nullptr)) {
+    set_error("resident solve: needs a compact plan -- of the grid-sampling route (grad_partials), or with the fractions of undistorted events (cfx / cfy)");
     return false;
   }
   // splits: 1, or 0 = "adaptive work items" (a table the four-launch pipeline splits crowded tiles by: the resident kernel always
@@ -208,7 +210,7 @@ int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* q, int n_i
     set_error("ebos_cmax_patch_solve_resident: workspace too small (%zu < %zu)", q->workspace_bytes, need);
     return EBOS_ERR_SCRATCH;
   }
-  if (q->grad_partials_bytes < ebos_patch_grad_partials_bytes(q->H, q->W, q->tile_h, q->tile_w, 0)) {
+  if (q->grad_partials != nullptr && q->grad_partials_bytes < ebos_patch_grad_partials_bytes(q->H, q->W, q->tile_h, q->tile_w, 0)) {
     set_error("ebos_cmax_patch_solve_resident: grad_partials too small");
     return EBOS_ERR_SCRATCH;
   }

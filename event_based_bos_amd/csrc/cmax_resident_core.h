@@ -263,15 +263,15 @@ struct Persist {  // one workgroup's iteration-invariant geometry
 // UNI: the 2-DoF motion model (theta = (trans_x, trans_y), x' = x + dt theta, src/warp.py:364-383) instead of the patch grid: no
 // interpolation tables, no cell block; the tiles' partial pairs of d loss / d theta travel as one record per tile, every workgroup
 // sums ALL of them (in the order of the four-launch loop's last kernel) and steps the two parameters itself.
-// FRAC (UNI only): the compact plan carries fractional source coordinates (undistorted events: data.warp: true in the reference's
-// configs/hot_plate1.yaml:7): the event loops are the general ones of the compact format, whose groups hold the fractions.
+// FRAC: the compact plan carries fractional source coordinates (undistorted events: data.warp: true in the reference's
+// configs/hot_plate1.yaml:7): the event loops are the general ones of the compact format, whose groups hold the fractions; the
+// patch-grid kernel then sweeps backward into f64 accumulators (the fixed-point sweep's groups hold integer pixels).
 // CONTRAST: which contrast the loop maximises -- a template parameter, not an argument: as run-time branches the blur's and the Sobel
 // passes' code cost the plain variance loop 1.3 us per iteration (register pressure in the event loop and the gather: 28.0 -> 29.3 us
 // at 2 M events) although it never ran.
 enum ResidentContrast : int { RC_VARIANCE = 0, RC_BLURRED_VARIANCE = 1, RC_GRADIENT_MAGNITUDE = 2 };
 template <int TH, int TW, int HALO, bool UNI, bool FRAC = false, int CONTRAST = RC_VARIANCE>
 __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_unused) {
-  static_assert(!FRAC || UNI, "fractional source coordinates: the 2-DoF kernels only (the fixed-point backward sweep assumes integer pixels)");
   static_assert(!(UNI && CONTRAST == RC_GRADIENT_MAGNITUDE), "the 2-DoF problem takes the variance contrast (plain or blurred)");
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the stub: the body copies structs out of the constant address space)
   constexpr int kLHmax = TH + 2 * HALO, kLWmax = TW + 2 * HALO;
@@ -1119,6 +1119,10 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         unit.fx = false, unit.scale = 1.0f, unit.limit = 0.0f;
         fx = bwd_lean_sweeps<TH, TW, HALO, true, false, true>(tr, s_d, s_g, ev, s_cells, H, W, 0, 0, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
                                                              unit, a.dt_bound, pre, false, bsh, NoHook{});
+      } else if constexpr (FRAC) {
+        unit.fx = false, unit.scale = 1.0f, unit.limit = 0.0f;  // (the general sweep: fractions per slot, f64 accumulators)
+        fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, ev, s_flow_b, H, W, 0, 0, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
+                                                             unit, a.dt_bound, pre, false, bsh, NoHook{});
       } else {
       decode_bgroup(pre.A, pre_raw.A, (unsigned)PW, 0u, (unsigned)(AP * PW + AP));  // (the tile's flow in LDS: element indices, pitch PW)
       decode_bgroup(pre.B, pre_raw.B, (unsigned)PW, 0u, (unsigned)(AP * PW + AP));
@@ -1475,7 +1479,7 @@ inline ResidentArgs resident_args(const ebos_cmax_patch_problem* q, int n_iter, 
   const HaloArg ha = decode_halo(q->halo);
   ResidentArgs a{};
   resident_common_args(a, q->H, q->W, q->tile_h, q->tile_w, mailbox, n_iter, q->steps_done, spin_timeout_s, ha);
-  a.ev = EvPtrs{nullptr, nullptr, nullptr, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr};
+  a.ev = EvPtrs{nullptr, nullptr, nullptr, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr, q->cfx, q->cfy};
   a.key_offsets = q->key_offsets;
   a.gs = GridSrc{make_axis(q->gh, q->patch_h, q->slide_h, q->H), make_axis(q->gw, q->patch_w, q->slide_w, q->W)};
   a.theta = q->theta, a.d_theta = q->d_theta, a.exp_avg = q->exp_avg, a.exp_avg_sq = q->exp_avg_sq;
@@ -1527,6 +1531,11 @@ template <int TH, int TW, int HALO>
 int resident_patch_launch(const ebos_cmax_patch_problem* q, int n_iter, void* mailbox, double spin_timeout_s, hipStream_t s) {
   const MailboxLayout m = mailbox_layout(((q->H + TH - 1) / TH) * ((q->W + TW - 1) / TW));
   const ResidentArgs a = resident_args(q, n_iter, mailbox, spin_timeout_s);
+  if (q->cfx != nullptr) {  // fractional source coordinates
+    if (a.gm) return launch_resident<TH, TW, HALO, false, true, RC_GRADIENT_MAGNITUDE>(a, mailbox, m.total, s);
+    if (a.blur.k0 != 0.0f) return launch_resident<TH, TW, HALO, false, true, RC_BLURRED_VARIANCE>(a, mailbox, m.total, s);
+    return launch_resident<TH, TW, HALO, false, true, RC_VARIANCE>(a, mailbox, m.total, s);
+  }
   if (a.gm) return launch_resident<TH, TW, HALO, false, false, RC_GRADIENT_MAGNITUDE>(a, mailbox, m.total, s);
   if (a.blur.k0 != 0.0f) return launch_resident<TH, TW, HALO, false, false, RC_BLURRED_VARIANCE>(a, mailbox, m.total, s);
   return launch_resident<TH, TW, HALO, false, false, RC_VARIANCE>(a, mailbox, m.total, s);

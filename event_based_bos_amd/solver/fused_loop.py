@@ -275,6 +275,9 @@ class FusedPatchLoop(object):
         q = self.problem()
         if self.halo >= 0 and self.plan.dt_bound is not None:
             q.halo = int(self.lib.ebos_halo_auto(int(self.halo), float(self.plan.dt_bound)))
+        frac = self.plan.frac_compact
+        if frac is not None:  # a window of undistorted events: the compact layout with the fractions per slot (FRAC kernels)
+            q.grp_offsets, q.cpix, q.cdt, q.cfx, q.cfy = (ptr(t) for t in frac)
         return q
 
     def problem(self) -> "_hip.CmaxPatchProblem":
@@ -311,7 +314,12 @@ class FusedPatchLoop(object):
         contrast (the blurred image with the variance only), no padding, a tile / halo with a resident kernel, few enough tiles to
         be co-resident.  (The resident kernel runs one workgroup per tile whatever the plan's work-item table says: against a
         pipeline that split crowded tiles it agrees to rounding, not bit for bit.)"""
-        if not self.sample_grid or self.splits not in (0, 1) or self.pad != (0, 0):
+        frac = self.plan.frac_compact is not None   # fractional source coordinates: the four launches run the dense route, the resident
+        # launch the compact layout with the fractions per slot (62 -> 33 us per iteration at 2 M events); no blur there (its image
+        # pass belongs to the grid-sampling route: nothing could take over)
+        if not (self.sample_grid or (frac and not self.blur_sigma)) or self.splits not in (0, 1) or self.pad != (0, 0):
+            return False
+        if frac and os.environ.get("EBOS_RESIDENT_FRAC", "1") == "0":
             return False
         if self.w_gm and os.environ.get("EBOS_RESIDENT_GM", "1") == "0":
             return False

@@ -758,6 +758,10 @@ typedef struct ebos_cmax_patch_problem {
    * (grad_partials != NULL). */
   float blur_k0, blur_k1;
   float* blur_image;
+  /* the resident launch on a window of FRACTIONAL source coordinates (undistorted events: data.warp in the reference's configs):
+   * with cfx / cfy non-NULL, grp_offsets / cpix / cdt / cfx / cfy are the arrays of ebos_plan_compact_frac_f32.  Only
+   * ebos_cmax_patch_solve_resident_f32 reads them: the four-launch loop of such a window runs on xs / ys / dts (grad_partials NULL). */
+  const float *cfx, *cfy;
 } ebos_cmax_patch_problem;
 int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* problem, int n_iter, ebos_stream_t stream);
 /* Several independent windows at once (windows are the unit that shards): problem w runs on

@@ -842,6 +842,71 @@ def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size,n_ev,patch,terms,gm", [
+    ((96, 128), 20_000, (24, 32), (1.0, 0.01, 0.02), 0.0),       # 12 tiles of 32 x 32, both flow regularisers
+    ((260, 346), 100_000, (20, 20), (1.0, 0.001, 0.0), 0.0),     # BASELINE configs[0]'s size
+    ((720, 1280), 400_000, (24, 32), (0.0, 0.001, 0.0), 1.5),    # 256 tiles of 45 x 80, the gradient-magnitude contrast
+])
+def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch, terms, gm):
+    """Undistorted events (data.warp: true, configs/hot_plate1.yaml:7) have fractional source coordinates: the four-launch loop of
+    such a window runs on the (x, y, dt) arrays through a dense flow field (upsample, general event kernels, adjoint of the
+    upsample); the resident launch reads the compact layout with the fractions per slot (EventPlan.frac_compact, FRAC kernels:
+    general forward loop, f64 backward sweep).  First iteration against the fp64 oracle's autograd (loss 1e-5, patch-flow gradient
+    rel-L2 1e-3 where the oracle is affordable) and against the four launches; 60 iterations to rounding (the four launches form x'
+    from the absolute f32 coordinate, the resident loop from the fraction: ~1e-4 px apart at x ~ 1000); a resident run is continued
+    by the four launches."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w = size
+    rs = np.random.RandomState(19)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    ev[:, :2] = np.clip(ev[:, :2] + rs.randint(0, 64, (n_ev, 2)) / 64.0, 0, [h - 1, w - 1])
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto")
+    assert not plan.compact and plan.frac_compact is not None
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+    theta0 = torch.from_numpy(rs.uniform(-3, 3, (2, gh, gw))).float()
+    n_iter = 60
+
+    def make():
+        return FusedPatchLoop(plan, patch, patch, theta0, *terms, halo="auto", lr=0.02, capacity=n_iter + 20, w_gradient_magnitude=gm)
+
+    ref, res = make(), make()
+    assert not res.sample_grid and res.resident_supported(), ebos.load_library().ebos_last_error()
+    l1_ref = ref.run(1, resident=False).cpu().numpy()
+    l1_res = res.run(1, resident=True).cpu().numpy()
+    assert ref.last_run_mode == "pipeline" and res.last_run_mode == "resident" and res.resident_status == 0 and res.resident_iterations == 1
+    e_iwe = float((res.iwe - ref.iwe).norm() / ref.iwe.norm())
+    e_g = float((res.d_theta - ref.d_theta).norm() / ref.d_theta.norm())
+    print(f"first iteration: IWE rel-L2 {e_iwe:.2e}, loss rel {abs(l1_res[0] / l1_ref[0] - 1):.2e}, d_theta rel-L2 {e_g:.2e}")
+    assert e_iwe < 1e-5 and abs(l1_res[0] / l1_ref[0] - 1) < 1e-5 and e_g < 1e-3
+    if n_ev <= 100_000:  # the oracle: fp64 autograd of the same objective at theta0
+        t64 = theta0.double().requires_grad_(True)
+        dense = O.upsample_patch_flow(t64, (h, w), patch, patch)
+        iwe = O.iwe_dense(torch.from_numpy(ev), dense, (h, w))
+        loss = terms[0] * O.image_variance(iwe) + terms[1] * O.flow_norm(dense)
+        if terms[2]:
+            loss = loss + terms[2] * O.image_gradient_tv(dense, torch.ones((h, w), dtype=torch.float64))
+        loss.backward()
+        assert abs(float(l1_res[0]) - loss.item()) <= 1e-5 * abs(loss.item()), (l1_res, loss.item())
+        assert O.rel_l2(res.d_theta.cpu().numpy(), t64.grad.numpy()) < 1e-3
+    l_ref = ref.run(n_iter - 1, resident=False).cpu().numpy()
+    l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
+    print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
+    np.testing.assert_allclose(l_res, l_ref, rtol=1e-4)
+    # (structure-less events: a cell whose gradient is rounding noise takes Adam's +-lr steps in either direction -- a few cells
+    # walk apart by up to n_iter x lr while the losses agree to 1e-4; the bulk stays together)
+    dev = (res.theta - ref.theta).abs().cpu().numpy()
+    assert np.median(dev) < 1e-2 and dev.mean() < 3e-2 and dev.max() <= n_iter * 0.02 + 1e-3, (np.median(dev), dev.mean(), dev.max())
+    # continued by the four launches
+    b = res.run(5, resident=False).cpu().numpy()
+    a = ref.run(5, resident=False).cpu().numpy()
+    assert res.last_run_mode == "pipeline"
+    np.testing.assert_allclose(a, b, rtol=1e-4)
+
+
+@pytest.mark.gpu
 def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
     """A flow whose displacements leave the largest LDS window: the resident launch must END (status -102).  In its FIRST iteration
     it leaves theta and the optimiser state untouched and ``run`` produces the four-launch pipeline's result; when the flow grows
