@@ -116,6 +116,8 @@ SIGNATURES = {
     "ebos_patch_grad_partials_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "ebos_iwe_patch_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P,
                                           _P, _P, _P, _Z, _P, _F, _F, _P, _P, _L, _L, _P, _P, _P]),
+    "ebos_iwe_dense_tiled_bwd_blur_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _Z, _P,
+                                                _P, _L, _L, _P, _P, _F, _F, _P]),
     "ebos_iwe_patch_tiled_bwd_blur_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P,
                                                _P, _Z, _P, _F, _F, _P, _P, _L, _L, _P, _P, _F, _F, _P]),
     "ebos_blur3_variance_partials": (_L, [_I, _I]),

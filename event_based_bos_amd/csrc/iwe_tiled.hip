@@ -519,6 +519,22 @@ int ebos_iwe_dense_tiled_bwd_f32(const float* xs, const float* ys, const float* 
                               part_table, stream, ebos::MomentsIn{});
 }
 
+int ebos_iwe_dense_tiled_bwd_blur_f32(const float* xs, const float* ys, const float* dts, const int32_t* grp_offsets, const uint16_t* cpix,
+                                      const float* cdt, const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
+                                      int tile_w, int halo, int pad_h, int pad_w, const float* z_image, int g_lo, const float* upstream,
+                                      const float* addend, float* d_flow, void* workspace, size_t workspace_bytes,
+                                      const int32_t* part_table, const double* blur_partials, int64_t n_blur_partials,
+                                      int64_t n_var_pixels, float* out_variance, double* out_moments, float blur_k0, float blur_k1,
+                                      ebos_stream_t stream) {
+  using namespace ebos;
+  EBOS_REQUIRE(blur_partials != nullptr && upstream != nullptr && n_blur_partials >= 1 && n_var_pixels >= 2 && blur_k0 > 0.0f && blur_k1 > 0.0f,
+               "ebos_iwe_dense_tiled_bwd_blur: needs the partials of ebos_blur3_variance_adjoint_f32, upstream and positive taps");
+  const MomentsIn mj{blur_partials, n_blur_partials, n_var_pixels, out_variance, out_moments, nullptr, 0, Blur3{blur_k0, blur_k1}};
+  return dense_tiled_bwd_impl(xs, ys, dts, nullptr, grp_offsets, cpix, cdt, key_offsets, n, flow, H, W, tile_h, tile_w, halo, pad_h, pad_w,
+                              z_image, nullptr, g_lo, d_flow, nullptr, nullptr, upstream, addend, workspace, workspace_bytes, part_table,
+                              stream, mj);
+}
+
 int ebos_variance_dense_job_f32(const ebos_dense_job* job, const float* flow, float* out_variance, const float* upstream,
                                 float* d_flow, ebos_stream_t stream) {
   return ebos_variance_dense_job_signed_f32(job, flow, out_variance, nullptr, upstream, d_flow, stream);

@@ -228,8 +228,8 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
   if (q->blur_k0 != 0.0f) {  // the variance of the 3-tap blurred image (iwe.blur_sigma > 0)
     EBOS_REQUIRE(q->blur_k0 > 0.0f && q->blur_k1 > 0.0f && q->blur_image && q->cost_scratch,
                  "ebos_cmax_patch_solve: the blurred contrast needs positive taps, blur_image and cost_scratch");
-    if (q->grad_partials == nullptr || q->w_gradient_magnitude != 0.0f) {
-      set_error("ebos_cmax_patch_solve: the blurred contrast runs on the grid-sampling route (grad_partials) with the variance contrast only");
+    if (q->w_gradient_magnitude != 0.0f) {
+      set_error("ebos_cmax_patch_solve: the blurred image goes with the variance contrast only");
       return EBOS_ERR_UNSUPPORTED;
     }
     const size_t need = (size_t)16 * (size_t)ebos_blur3_variance_partials(q->H + 2 * q->pad_h, q->W + 2 * q->pad_w);
@@ -254,7 +254,7 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
     if (rc) return rc;
   }
   const bool use_gm = q->w_gradient_magnitude != 0.0f;
-  const bool blur = q->blur_k0 != 0.0f;  // (grid route, variance contrast: cmax_check_problem)
+  const bool blur = q->blur_k0 != 0.0f;  // (variance contrast: cmax_check_problem)
   const int h = q->H + 2 * q->pad_h, w = q->W + 2 * q->pad_w;
   const float contrast_weight = use_gm ? q->w_gradient_magnitude : q->w_variance;
   if (grid)
@@ -265,7 +265,7 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
   else
     rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
                                  q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->workspace,
-                                 q->workspace_bytes, q->iwe, use_gm ? 0 : (has_reg ? 2 : 1), q->omit_boundary, q->variance,
+                                 q->workspace_bytes, q->iwe, (use_gm || blur) ? 0 : (has_reg ? 2 : 1), q->omit_boundary, q->variance,
                                  q->moments, q->part_table, stream);
   if (rc) return rc;
   if (use_gm) {  // contrast = mean squared Sobel gradient of the IWE; its gradient image feeds the backward event kernel
@@ -284,7 +284,7 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
   const double* var_partials = reinterpret_cast<const double*>(static_cast<const char*>(q->workspace) + off);
   if (has_reg) {  // the regulariser pass also reduces the variance moments the combine pass left (no finalize launch)
     rc = ebos_flow_regularisers_f32(q->dense, q->H, q->W, q->w_flow_norm, q->w_image_gradient, q->d_reg, q->reg_partials,
-                                    use_gm ? nullptr : var_partials, n_parts, n_px, q->variance, q->moments, stream);
+                                    (use_gm || blur) ? nullptr : var_partials, n_parts, n_px, q->variance, q->moments, stream);
     if (rc) return rc;
   }
   if (grid && blur) {
@@ -329,6 +329,19 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
                                             -contrast_weight, q->reg_partials, fuse_norm ? n_items : (has_reg ? ebos::kRegGrid : 0),
                                             q->losses, q->losses_cap, q->theta_mask, stream);
   }
+  if (blur) {  // dense route: the same image pass; the backward kernel reduces its partials, reports the variance and folds a z + c wgt
+    const int64_t n_blur = ebos_blur3_variance_partials(h, w);
+    const int lo = q->omit_boundary ? 1 : 0;
+    const int64_t n_valid = (int64_t)(h - 2 * lo > 0 ? h - 2 * lo : 0) * (w - 2 * lo > 0 ? w - 2 * lo : 0);
+    rc = ebos_blur3_variance_adjoint_f32(q->iwe, h, w, q->omit_boundary, q->blur_k0, q->blur_k1, q->blur_image,
+                                         reinterpret_cast<double*>(q->cost_scratch), n_blur, stream);
+    if (rc) return rc;
+    rc = ebos_iwe_dense_tiled_bwd_blur_f32(q->xs, q->ys, q->dts, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense, q->H, q->W,
+                                           q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w, q->blur_image, lo, q->upstream,
+                                           has_reg ? q->d_reg : nullptr, q->d_dense, q->workspace, q->workspace_bytes,
+                                           q->splits == 0 ? q->part_table : nullptr, reinterpret_cast<const double*>(q->cost_scratch), n_blur,
+                                           n_valid, q->variance, q->moments, q->blur_k0, q->blur_k1, stream);
+  } else
   rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
                                     q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,
                                     use_gm ? q->d_iwe : q->iwe, nullptr, use_gm ? 0 : (q->omit_boundary ? 1 : 0), q->d_dense, nullptr,

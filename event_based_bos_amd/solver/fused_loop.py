@@ -52,15 +52,10 @@ def blur_taps(sigma: float) -> Tuple[float, float]:
 
 
 def blur_supported(plan: EventPlan, halo, sliding_window, contrast_terms: Dict[str, float]) -> bool:
-    """iwe.blur_sigma > 0 inside the fixed pipeline: the variance contrast on the grid-sampling route (the blur's image pass
-    feeds the GRID backward kernel; csrc/blur3.h), images of at least 2 x 2 pixels (torch's reflect padding)."""
-    from ..event_plan import _norm_halo
-
-    if set(contrast_terms) != {"image_variance"} or not plan.compact or min(plan.image_size) < 2:
-        return False
-    lib = _hip.load_library()
-    return bool(lib.ebos_patch_fused_supported(plan.tile[0], plan.tile[1], int(_norm_halo(plan, halo)), int(sliding_window[0]),
-                                               int(sliding_window[1])))
+    """iwe.blur_sigma > 0 inside the fixed pipeline: the variance contrast (the blur's image pass feeds the backward kernel of either
+    route -- grid sampling, or the dense flow field of windows with fractional source coordinates; csrc/blur3.h), images of at
+    least 2 x 2 pixels (torch's reflect padding)."""
+    return set(contrast_terms) == {"image_variance"} and min(plan.image_size) >= 2
 
 
 def objective_supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], blur_sigma: float, plan: EventPlan,
@@ -121,8 +116,8 @@ class FusedPatchLoop(object):
         # backward pass; the backward kernel folds the variance gradient in as a z + c wgt, csrc/blur3.h)
         self.blur_sigma = float(blur_sigma or 0.0)
         self.blur = blur_taps(self.blur_sigma) if self.blur_sigma > 0 else (0.0, 0.0)
-        if self.blur_sigma > 0 and (not self.sample_grid or self.w_gm):
-            raise ValueError("blur_sigma > 0: the fixed pipeline takes the variance contrast on the grid-sampling route only "
+        if self.blur_sigma > 0 and self.w_gm:
+            raise ValueError("blur_sigma > 0: the fixed pipeline takes the blurred image with the variance contrast only "
                              "(fused_loop.blur_supported)")
         # with grid sampling the backward kernel evaluates the flow regularisers per tile, from the flow it holds in LDS
         self.fuse_norm = self.sample_grid and (self.w_tv != 0.0 or self.w_norm != 0.0)
@@ -315,9 +310,8 @@ class FusedPatchLoop(object):
         be co-resident.  (The resident kernel runs one workgroup per tile whatever the plan's work-item table says: against a
         pipeline that split crowded tiles it agrees to rounding, not bit for bit.)"""
         frac = self.plan.frac_compact is not None   # fractional source coordinates: the four launches run the dense route, the resident
-        # launch the compact layout with the fractions per slot (62 -> 33 us per iteration at 2 M events); no blur there (its image
-        # pass belongs to the grid-sampling route: nothing could take over)
-        if not (self.sample_grid or (frac and not self.blur_sigma)) or self.splits not in (0, 1) or self.pad != (0, 0):
+        # launch the compact layout with the fractions per slot (62 -> 31 us per iteration at 2 M events)
+        if not (self.sample_grid or frac) or self.splits not in (0, 1) or self.pad != (0, 0):
             return False
         if frac and os.environ.get("EBOS_RESIDENT_FRAC", "1") == "0":
             return False

@@ -511,6 +511,15 @@ int ebos_iwe_patch_tiled_bwd_blur_f32(const int32_t* grp_offsets, const uint16_t
                                       double* reg_partials, const double* blur_partials, int64_t n_blur_partials,
                                       int64_t n_var_pixels, float* out_variance, double* out_moments, float blur_k0,
                                       float blur_k1, ebos_stream_t stream);
+/* ... and on the dense-flow route (windows of fractional source coordinates: the (x, y, dt) arrays; or compact ones): d loss / d flow
+ * [2, H, W] of the blurred contrast, arguments as ebos_iwe_dense_tiled_bwd_f32 / ebos_iwe_patch_tiled_bwd_blur_f32. */
+int ebos_iwe_dense_tiled_bwd_blur_f32(const float* xs, const float* ys, const float* dts, const int32_t* grp_offsets, const uint16_t* cpix,
+                                      const float* cdt, const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
+                                      int tile_w, int halo, int pad_h, int pad_w, const float* z_image, int g_lo, const float* upstream,
+                                      const float* addend, float* d_flow, void* workspace, size_t workspace_bytes,
+                                      const int32_t* part_table, const double* blur_partials, int64_t n_blur_partials,
+                                      int64_t n_var_pixels, float* out_variance, double* out_moments, float blur_k0, float blur_k1,
+                                      ebos_stream_t stream);
 int ebos_patch_grad_combine_adam_f32(const float* grad_partials, const int32_t* part_table, int tile_h, int tile_w,
                                      int gh, int gw, int patch_h, int patch_w, int slide_h, int slide_w, int H, int W,
                                      float* d_grid, float* theta, float* exp_avg, float* exp_avg_sq, double lr,
@@ -754,8 +763,7 @@ typedef struct ebos_cmax_patch_problem {
   size_t grad_partials_bytes;  /* ebos_patch_grad_partials_bytes(H, W, tile_h, tile_w, splits == 0) */
   /* ABI 2: iwe.blur_sigma > 0 -- the variance is taken on the 3-tap blurred IWE (src/event_image_converter.py:399-404).
    * blur_k0 = 0: no blur.  Otherwise the taps (blur_k0, blur_k1, blur_k0), blur_image [H + 2 pad_h, W + 2 pad_w] and cost_scratch
-   * >= 16 * ebos_blur3_variance_partials(H + 2 pad_h, W + 2 pad_w) bytes; variance contrast on the grid-sampling route only
-   * (grad_partials != NULL). */
+   * >= 16 * ebos_blur3_variance_partials(H + 2 pad_h, W + 2 pad_w) bytes; the variance contrast only. */
   float blur_k0, blur_k1;
   float* blur_image;
   /* the resident launch on a window of FRACTIONAL source coordinates (undistorted events: data.warp in the reference's configs):

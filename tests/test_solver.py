@@ -842,12 +842,14 @@ def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,n_ev,patch,terms,gm", [
-    ((96, 128), 20_000, (24, 32), (1.0, 0.01, 0.02), 0.0),       # 12 tiles of 32 x 32, both flow regularisers
-    ((260, 346), 100_000, (20, 20), (1.0, 0.001, 0.0), 0.0),     # BASELINE configs[0]'s size
-    ((720, 1280), 400_000, (24, 32), (0.0, 0.001, 0.0), 1.5),    # 256 tiles of 45 x 80, the gradient-magnitude contrast
+@pytest.mark.parametrize("size,n_ev,patch,terms,gm,blur", [
+    ((96, 128), 20_000, (24, 32), (1.0, 0.01, 0.02), 0.0, 0.0),       # 12 tiles of 32 x 32, both flow regularisers
+    ((260, 346), 100_000, (20, 20), (1.0, 0.001, 0.0), 0.0, 0.0),     # BASELINE configs[0]'s size
+    ((720, 1280), 400_000, (24, 32), (0.0, 0.001, 0.0), 1.5, 0.0),    # 256 tiles of 45 x 80, the gradient-magnitude contrast
+    ((260, 346), 100_000, (20, 20), (1.0, 0.001, 0.01), 0.0, 3.0),    # iwe.blur_sigma 3 (configs/hot_plate1.yaml:65) on the dense route
+    ((96, 128), 20_000, (24, 32), (1.0, 0.0, 0.0), 0.0, 1.0),
 ])
-def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch, terms, gm):
+def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch, terms, gm, blur):
     """Undistorted events (data.warp: true, configs/hot_plate1.yaml:7) have fractional source coordinates: the four-launch loop of
     such a window runs on the (x, y, dt) arrays through a dense flow field (upsample, general event kernels, adjoint of the
     upsample); the resident launch reads the compact layout with the fractions per slot (EventPlan.frac_compact, FRAC kernels:
@@ -869,7 +871,8 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
     n_iter = 60
 
     def make():
-        return FusedPatchLoop(plan, patch, patch, theta0, *terms, halo="auto", lr=0.02, capacity=n_iter + 20, w_gradient_magnitude=gm)
+        return FusedPatchLoop(plan, patch, patch, theta0, *terms, halo="auto", lr=0.02, capacity=n_iter + 20, w_gradient_magnitude=gm,
+                              blur_sigma=blur)
 
     ref, res = make(), make()
     assert not res.sample_grid and res.resident_supported(), ebos.load_library().ebos_last_error()
@@ -884,6 +887,7 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
         t64 = theta0.double().requires_grad_(True)
         dense = O.upsample_patch_flow(t64, (h, w), patch, patch)
         iwe = O.iwe_dense(torch.from_numpy(ev), dense, (h, w))
+        iwe = O.gaussian_blur3_torch(iwe, blur) if blur else iwe
         loss = terms[0] * O.image_variance(iwe) + terms[1] * O.flow_norm(dense)
         if terms[2]:
             loss = loss + terms[2] * O.image_gradient_tv(dense, torch.ones((h, w), dtype=torch.float64))
