@@ -121,15 +121,6 @@ bool slab_config_ok(int th, int tw, int halo) {
 
 extern "C" {
 
-#ifdef EBOS_STAMPS
-int ebos_debug_read_stamps(unsigned long long* host, int count) {  // diagnostic builds only
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_stamps), sizeof(unsigned long long) * count);
-}
-int ebos_debug_read_stamps_bwd(unsigned long long* host, int count) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_stamps_bwd), sizeof(unsigned long long) * count);
-}
-#endif
-
 int ebos_slab_config(int* out, int cap) {
   using namespace ebos;
   for (int i = 0; i < kNumSlabConfigs && i < cap && out != nullptr; ++i) {

@@ -6,3 +6,15 @@
 namespace ebos {
 EBOS_DEFINE_SLAB_OPS(45, 80, 32)
 }  // namespace ebos
+
+// diagnostic builds only (tools/build_stamps_lib.sh): the in-kernel stamps of THIS unit's kernels
+extern "C" {
+#ifdef EBOS_STAMPS
+int ebos_debug_read_stamps(unsigned long long* host, int count) {  // diagnostic builds only
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_stamps), sizeof(unsigned long long) * count);
+}
+int ebos_debug_read_stamps_bwd(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ebos::g_stamps_bwd), sizeof(unsigned long long) * count);
+}
+#endif
+}

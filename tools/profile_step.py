@@ -94,6 +94,14 @@ def main():
             loop.run(args.iters, resident=False)   # four launches per iteration
             loop.run(args.iters)                   # the resident kernel: ONE launch of args.iters iterations
             print("patch-grid loop, halo", halo, "second run:", loop.last_run_mode)
+        # ... the other contrasts of the resident patch-grid loop: blurred variance (iwe.blur_sigma 1), gradient magnitude
+        for kw in ({"blur_sigma": 1.0}, {"w_gradient_magnitude": 1.0}):
+            w_var = 0.0 if "w_gradient_magnitude" in kw else 1.0
+            lc = FusedPatchLoop(plans[0], (24, 32), (24, 32), torch.zeros_like(grids[0]), w_var, 0.001, 0.0, halo="auto", lr=0.02,
+                                capacity=2 * args.iters + 2, **kw)
+            lc.run(args.iters)
+            print("patch-grid loop", kw, "ran as", lc.last_run_mode)
+            del lc
         # ... and the 2-DoF Adam loop (configs/hot_plate1.yaml:47): four launches per iteration, then ONE resident launch
         from event_based_bos_amd.solver.fused_loop import Fused2dofLoop
 
