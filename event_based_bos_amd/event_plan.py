@@ -175,6 +175,23 @@ class EventPlan:
         n_tiles = (self.part_table.numel() - 1) // 5
         return 1 if used is not None and used <= n_tiles else 0
 
+    # The optimiser LOOPS (FusedPatchLoop / Fused2dofLoop: forward + backward + step per iteration) pay ~24 us per iteration for the
+    # passes that sum the parts of the adaptive work items, and ~0.5 us per 1000 events their fullest tile holds beyond the average
+    # one when every tile is ONE work item (2 M events at 1280x720, DESIGN 4.4 #62: fullest tile 2 x the average 66.9 us adaptive
+    # against 48.8 with one item per tile, 6 x 70.9 against 63.4, 21 x 95 against 197): adaptive where that excess is large enough
+    LOOP_ADAPTIVE_MIN_EXCESS = 48_000
+
+    def resolve_loop_splits(self, splits: Optional[int]) -> int:
+        """``resolve_splits`` for an optimiser loop: the adaptive work items only where the fullest tile holds at least
+        ``LOOP_ADAPTIVE_MIN_EXCESS`` events more than the average tile."""
+        s = self.resolve_splits(splits)
+        fullest = self.__dict__.get("_fullest_tile")
+        if splits is None and s == 0 and fullest is not None:
+            n_tiles = (self.part_table.numel() - 1) // 5
+            if fullest - self.n / max(n_tiles, 1) < self.LOOP_ADAPTIVE_MIN_EXCESS:
+                return 1
+        return s
+
     def _compact_ptrs(self):
         return (ptr(self.grp_offsets), ptr(self.cpix), ptr(self.cdt)) if self.compact else (None, None, None)
 
@@ -350,7 +367,11 @@ class EventPlan:
                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt, part_table, self.dt_bound)
         out.__dict__["_frac"] = frac  # (grp_offsets, cpix, cdt, cfx, cfy) of a window with fractional source coordinates, or None
         out.__dict__["_counts"], out.__dict__["_deferred"] = counts, bool(deferred)
-        out.__dict__["_parts_used"] = None if deferred else int(part_table[tiles_y * tiles_x].item())
+        used = fullest = None
+        if not deferred:
+            used, fullest = (int(v) for v in torch.cat([part_table[tiles_y * tiles_x:tiles_y * tiles_x + 1],
+                                                        _fullest_tile(key_offsets, th * tw)]).tolist())
+        out.__dict__["_parts_used"], out.__dict__["_fullest_tile"] = used, fullest
         return out
 
     def counts(self) -> Tuple[int, int]:
@@ -598,15 +619,22 @@ def _build_lean(source: int, events, raw, image_size, direction, normalize_t, ti
         check(rc, "ebos_plan_lean")
         check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), PART_FIXED_EVENTS, ptr(part_table), stream_ptr()),
               "ebos_plan_parts")
-    dropped, used = 0, None
-    if not deferred:  # the one host read-back of the build: (outside the image, fractional sources, work items in use)
-        dropped, fractional, used = (int(v) for v in torch.cat([counts, part_table[n_tiles:n_tiles + 1]]).tolist())
+    dropped, used, fullest = 0, None, None
+    if not deferred:  # the one host read-back of the build: (outside the image, fractional sources, work items in use, fullest tile)
+        dropped, fractional, used, fullest = (int(v) for v in torch.cat([counts, part_table[n_tiles:n_tiles + 1],
+                                                                         _fullest_tile(key_offsets, th * tw)]).tolist())
         if fractional:
             return None  # fractional (undistorted) source coordinates: the (x, y, dt) format of the full build
     plan = EventPlan(None, None, None, None, (H, W), n - dropped, n, (th, tw), key_offsets, None, dropped, grp_offsets, cpix, cdt,
                      part_table, dt_bound_for(direction, normalize_t))
     plan.__dict__["_counts"], plan.__dict__["_deferred"], plan.__dict__["_parts_used"] = counts, bool(deferred), used
+    plan.__dict__["_fullest_tile"] = fullest
     return plan
+
+
+def _fullest_tile(key_offsets: torch.Tensor, tile_px: int) -> torch.Tensor:
+    """[1] int32: events of the fullest source tile (part of the build's one read-back)."""
+    return key_offsets[::tile_px].diff().max().reshape(1).to(torch.int32)
 
 
 def _check_flow(plan: EventPlan, flow: torch.Tensor) -> torch.Tensor:

@@ -136,7 +136,7 @@ class FusedPatchLoop(object):
         self.cost_scratch = (torch.empty(int(self.lib.ebos_cmax_cost_scratch_bytes(H + 2 * self.pad[0], W + 2 * self.pad[1])),
                                          dtype=torch.uint8, device=dev) if (self.w_gm or self.blur_sigma > 0) else None)
         self.losses = torch.zeros(max(int(capacity), 1), **f32)
-        self.splits = plan.resolve_splits(splits)  # 0 = the plan's adaptive work items
+        self.splits = plan.resolve_loop_splits(splits)  # 0 = the plan's adaptive work items
         self.scratch_up = (None if self.sample_grid else
                            torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32))
         self.grad_partials = (torch.empty(int(self.lib.ebos_patch_grad_partials_bytes(H, W, plan.tile[0], plan.tile[1],
@@ -452,7 +452,7 @@ class Fused2dofLoop(object):
         self.moments = torch.zeros((1, 2), dtype=torch.float64, device=dev)
         self.upstream = torch.full((1,), -self.w_var, **f32)  # loss = -w * contrast
         self.losses = torch.zeros(max(int(capacity), 1), **f32)
-        self.splits = plan.resolve_splits(splits)
+        self.splits = plan.resolve_loop_splits(splits)
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.last_run_mode = "pipeline"
         self._mailbox = None
