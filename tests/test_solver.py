@@ -1097,3 +1097,107 @@ def test_pyramid_runs_resident_at_every_scale_at_1280x720():
     assert s_p.loop_modes == ["pipeline"] * 4
     np.testing.assert_array_equal(np.array(s.history), np.array(s_p.history))
     np.testing.assert_array_equal(flow, flow_p)
+
+
+@pytest.mark.gpu
+def test_fuzz_resident_loops_against_the_launches_and_the_oracle():
+    """Seeded fuzz of the ONE-launch loops over what interacts inside the resident kernels: image size (tiles cut by the border, one
+    to ~60 tiles, the three resident tile shapes), patch size and sliding window (overlapping patches, cells shared by several
+    tiles), event clustering (blobs, borders), integer and fractional source coordinates, the contrast (variance, blurred variance,
+    gradient magnitude), both flow regularisers, the boundary ring, the motion model (patch grid / 2-DoF).  Three iterations as one
+    resident launch against the same iterations as launches: the first loss to 1e-5, the flows to a small multiple of lr; and the first
+    iteration against the fp64 oracle's autograd: loss 1e-5, gradient rel-L2 1e-2 (and 1e-4 against the launches' gradient)."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import Fused2dofLoop, FusedPatchLoop
+
+    lib = ebos.load_library()
+    rs = np.random.RandomState(int(os.environ.get("EBOS_FUZZ_SEED", 515)))
+    done = {"patch": 0, "2dof": 0, "frac": 0, "gm": 0, "blur": 0}
+    for case in range(48):
+        h, w = int(rs.randint(40, 300)), int(rs.randint(48, 400))
+        n = int(rs.choice([300, 5000, 40000]))
+        kind = rs.randint(3)
+        if kind == 0:
+            r, c = rs.randint(0, h, n), rs.randint(0, w, n)
+        elif kind == 1:   # a blob (moderately crowded tiles: the launch must not refuse)
+            r, c = np.clip(np.rint(rs.normal(h / 2, h / 5, n)), 0, h - 1), np.clip(np.rint(rs.normal(w / 3, w / 5, n)), 0, w - 1)
+        else:             # the image's borders
+            r, c = rs.choice([0, 1, h - 2, h - 1], n), rs.randint(0, w, n)
+        ev = np.stack([r, c, np.sort(rs.uniform(2.0, 2.4, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
+        frac = bool(rs.randint(3) == 0)
+        if frac:
+            ev[:, :2] = np.clip(ev[:, :2] + rs.randint(0, 64, (n, 2)) / 64.0, 0, [h - 1, w - 1])
+        model = "2dof" if rs.randint(3) == 0 else "patch"
+        contrast = ["var", "blur", "gm"][rs.randint(3)] if model == "patch" else ["var", "blur"][rs.randint(2)]
+        sigma = float(rs.choice([1.0, 3.0])) if contrast == "blur" else 0.0
+        omit = bool(rs.randint(2))
+        amp = float(rs.choice([0.5, 3.0, 6.0]))
+        plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto")
+        tag = f"case {case}: {h}x{w} tile {plan.tile} n {n} kind {kind} frac {frac} {model} {contrast} sigma {sigma} omit {omit} amp {amp}"
+        if model == "patch":
+            patch = (int(rs.randint(8, 40)), int(rs.randint(8, 48)))
+            slide = (int(rs.randint(max(4, patch[0] // 2), patch[0] + 1)), int(rs.randint(max(4, patch[1] // 2), patch[1] + 1)))
+            if patch[0] > h or patch[1] > w or not lib.ebos_patch_fused_supported(plan.tile[0], plan.tile[1], 32, slide[0], slide[1]):
+                continue
+            gh, gw = ebos.solver.patch_grid_shape((h, w), patch, slide)
+            theta0 = rs.uniform(-amp, amp, (2, gh, gw))
+            w_norm, w_tv = [(0.0, 0.0), (0.02, 0.0), (0.01, 0.02)][rs.randint(3)]
+            w_var, w_gm = (0.0, 1.5) if contrast == "gm" else (2.0, 0.0)
+            tag += f" patch {patch} slide {slide} reg {(w_norm, w_tv)}"
+
+            def make():
+                return FusedPatchLoop(plan, patch, slide, torch.from_numpy(theta0).float(), w_var, w_norm, w_tv, omit, halo="auto", lr=0.01,
+                                      capacity=8, w_gradient_magnitude=w_gm, blur_sigma=sigma)
+        else:
+            theta0 = rs.uniform(-amp, amp, 2)
+
+            def make():
+                return Fused2dofLoop(plan, torch.from_numpy(theta0).float(), 2.0, omit, 0, "auto", lr=0.01, capacity=8, blur_sigma=sigma)
+        ref, res = make(), make()
+        if not res.resident_supported():
+            continue
+        l_res = res.run(3, resident=True).cpu().numpy()
+        if res.last_run_mode != "resident":   # (a crowded window: refused in its first iteration -- the launches ran)
+            assert res.resident_status in (-102, -104), (tag, res.resident_status)
+            continue
+        l_ref = ref.run(3, resident=False).cpu().numpy()
+        assert abs(l_res[0] / l_ref[0] - 1) < 1e-5, (tag, l_res, l_ref)
+        np.testing.assert_allclose(l_res, l_ref, rtol=2e-3, err_msg=tag)
+        assert (res.theta - ref.theta).abs().max().item() <= 2 * 3 * 0.01 + 1e-6, tag   # (a near-zero gradient may step either way)
+        # the oracle: the first iteration's loss and gradient
+        tev = torch.from_numpy(ev)
+        if model == "patch":
+            t64 = torch.from_numpy(theta0).float().double().requires_grad_(True)
+            dense = O.upsample_patch_flow(t64, (h, w), patch, slide)
+            iwe = O.iwe_dense(tev, dense, (h, w))
+        else:
+            t64 = torch.from_numpy(theta0).float().double().requires_grad_(True)
+            iwe = O.iwe_2dof(tev, t64, (h, w))
+        iwe = O.gaussian_blur3_torch(iwe, sigma) if sigma else iwe
+        if contrast == "gm":
+            loss = w_gm * O.gradient_magnitude(iwe, omit)
+        else:
+            loss = 2.0 * O.image_variance(iwe, omit)
+        if model == "patch" and (w_norm or w_tv):
+            loss = loss + w_norm * O.flow_norm(dense) + w_tv * O.image_gradient_tv(dense, torch.ones((h, w), dtype=torch.float64))
+        loss.backward()
+        res1 = make()
+        l1 = res1.run(1, resident=True).cpu().numpy()
+        assert res1.last_run_mode == "resident", tag
+        assert abs(float(l1[0]) - loss.item()) <= 1e-5 * abs(loss.item()) + 1e-9, (tag, l1, loss.item())
+        want = t64.grad.numpy()
+        if n >= 5000 and np.linalg.norm(want) > 0:
+            # (the bar of the flow gradient is 1e-3 on BASELINE's configurations; a fuzzed case may sit next to a stationary point,
+            # where the gradient is the small difference of large per-event terms and f32's share of it grows: what is pinned tightly
+            # here is that the resident launch computes what the launches compute -- their common deviation stays below 1e-2)
+            got = res1.d_theta.cpu().numpy().reshape(want.shape)
+            ref1 = make()
+            ref1.run(1, resident=False)
+            assert O.rel_l2(got, ref1.d_theta.cpu().numpy().reshape(want.shape)) < 1e-4, tag
+            assert O.rel_l2(got, want) < 1e-2, (tag, O.rel_l2(got, want))
+        done[model] += 1
+        done["frac"] += frac
+        done["gm"] += contrast == "gm"
+        done["blur"] += contrast == "blur"
+    print("cases run:", done)
+    assert done["patch"] >= 10 and done["2dof"] >= 5 and done["frac"] >= 5 and done["gm"] >= 3 and done["blur"] >= 5, done
