@@ -51,6 +51,19 @@ def blur_taps(sigma: float) -> Tuple[float, float]:
     return e / (1.0 + 2.0 * e), 1.0 / (1.0 + 2.0 * e)
 
 
+def crowded_for_resident(plan: EventPlan) -> bool:
+    """The resident kernels' own refusal rule (RES_IMBALANCED, csrc/cmax_resident_core.h: one workgroup per tile waits for the fullest
+    tile) applied on the host where the plan knows its fullest tile: such a window goes to the launches without a refused launch and
+    a status read-back first.  ``EBOS_RESIDENT_MAX_IMBALANCE`` (the kernel's override) switches the host check off."""
+    fullest = plan.__dict__.get("_fullest_tile")
+    if fullest is None or plan.tile is None or "EBOS_RESIDENT_MAX_IMBALANCE" in os.environ:
+        return False
+    H, W = plan.image_size
+    n_tiles = ((H + plan.tile[0] - 1) // plan.tile[0]) * ((W + plan.tile[1] - 1) // plan.tile[1])
+    ratio = fullest * n_tiles / max(plan.n, 1)
+    return fullest >= 512 * 64 and (ratio > 12.0 or (fullest >= 1875 * 64 and ratio > 3.0))
+
+
 def blur_supported(plan: EventPlan, halo, sliding_window, contrast_terms: Dict[str, float]) -> bool:
     """iwe.blur_sigma > 0 inside the fixed pipeline: the variance contrast (the blur's image pass feeds the backward kernel of either
     route -- grid sampling, or the dense flow field of windows with fractional source coordinates; csrc/blur3.h), images of at
@@ -317,6 +330,8 @@ class FusedPatchLoop(object):
             return False
         if self.w_gm and os.environ.get("EBOS_RESIDENT_GM", "1") == "0":
             return False
+        if crowded_for_resident(self.plan):
+            return False
         if self.blur_sigma > 0 and not (RESIDENT_BLUR and os.environ.get("EBOS_RESIDENT_BLUR", "1") != "0"):
             return False
         import ctypes
@@ -480,6 +495,8 @@ class Fused2dofLoop(object):
         if not (self.plan.compact or self.plan.frac_compact is not None) or self.splits not in (0, 1) or self.pad != (0, 0):
             return False
         if self.blur_sigma > 0 and os.environ.get("EBOS_RESIDENT_BLUR", "1") == "0":
+            return False
+        if crowded_for_resident(self.plan):
             return False
         return bool(self.lib.ebos_cmax_2dof_resident_supported(ctypes.byref(self._resident_problem())))
 

@@ -898,7 +898,8 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
     l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
     assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
     print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
-    np.testing.assert_allclose(l_res, l_ref, rtol=1e-4)
+    np.testing.assert_allclose(l_res, l_ref, rtol=5e-4)   # (the f64 sweep's LDS atomics round in the order they arrive: run to run the
+    # deviation over 60 iterations moved between 4e-5 and 1e-4)
     # (structure-less events: a cell whose gradient is rounding noise takes Adam's +-lr steps in either direction -- a few cells
     # walk apart by up to n_iter x lr while the losses agree to 1e-4; the bulk stays together)
     dev = (res.theta - ref.theta).abs().cpu().numpy()
@@ -907,7 +908,7 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
     b = res.run(5, resident=False).cpu().numpy()
     a = ref.run(5, resident=False).cpu().numpy()
     assert res.last_run_mode == "pipeline"
-    np.testing.assert_allclose(a, b, rtol=1e-4)
+    np.testing.assert_allclose(a, b, rtol=5e-4)
 
 
 @pytest.mark.gpu
@@ -975,8 +976,16 @@ def test_resident_loop_leaves_crowded_windows_to_the_pipeline():
     r = np.clip(np.rint(rs.normal(h / 2, 20, n)), 0, h - 1)
     c = np.clip(np.rint(rs.normal(w / 2, 36, n)), 0, w - 1)
     ev = np.stack([r, c, np.sort(rs.uniform(0, 0.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
-    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    # (a plan built WITH the host read-back knows its fullest tile: the host applies the same rule and never launches)
+    known = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
     gh, gw = ebos.solver.patch_grid_shape((h, w), (24, 32), (24, 32))
+    early = FusedPatchLoop(known, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.05, capacity=24)
+    assert not early.resident_supported()
+    early.run(2)
+    assert early.last_run_mode == "pipeline" and early.resident_status == 0
+    # ... a plan built without it (build_raw(..., deferred=True): what WindowPipeline builds) does not -- here: the same build, told to forget
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    plan.__dict__["_fullest_tile"] = None
     ref = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.05, capacity=24)
     res = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.05, capacity=24)
     assert res.resident_supported()
