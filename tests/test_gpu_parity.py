@@ -1460,9 +1460,13 @@ def test_fuzz_fused_path_against_oracle(ebos):
             gn = float(ft.grad.detach().norm())
             if gn > 0 and amp > 0:  # at zero flow every event sits on the kink of the bilinear vote
                 assert float((fg.grad.cpu().double() - ft.grad).norm()) / gn < 1e-3, tag
-        # per-event weights (f64 LDS accumulators, weights and their gradient in input order)
+        # per-event weights (weights and their gradient in input order).  Negative weights: the slices that hold one take the f64 LDS
+        # accumulators; every other weighted case: weights >= 0 with exact zeros among them -- the fixed-point loops in units of the
+        # slice's max |w| (integer source pixels: the weighted lean loop on the compact format)
         if case % 3 == 0:
             wts = rs.uniform(-1.0, 2.0, n)
+            if case % 6 == 0:
+                wts = np.abs(wts) * (rs.uniform(size=n) > 0.1)
             wt = torch.from_numpy(wts).requires_grad_(True)
             ft2 = torch.from_numpy(flow).requires_grad_(True)
             exp_w = O.iwe_dense(tev, ft2, (h, w), pad=(pad, pad), direction=direction, weight=wt)
