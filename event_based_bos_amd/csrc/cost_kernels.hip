@@ -210,6 +210,9 @@ gradmag_grad_kernel(const T* __restrict__ images, int h, int w, Region rg, const
 // SURVEY 8(d)'s cost-kernel bytes, once.
 constexpr int kGmTH = 16, kGmTW = 64;
 
+// GRAD = false: the value partials only (d_img is not touched) -- an objective EVALUATION needs neither the gather of the nine stencils
+// nor 4 H W bytes of gradient image (9.6 -> 6 us at 1280 x 720).
+template <bool GRAD>
 __global__ void __launch_bounds__(kCostBlock)
 gradmag_fused_kernel(const float* __restrict__ img, int h, int w, Region rg, const float* __restrict__ upstream, float* __restrict__ d_img,
                      double* __restrict__ partials) {
@@ -234,6 +237,24 @@ gradmag_fused_kernel(const float* __restrict__ img, int h, int w, Region rg, con
     if (i < IH * IW) s_img[i] = stage[k];
   }
   __syncthreads();
+  if constexpr (!GRAD) {  // the tile's own stencils, summed where they are formed
+    double val = 0.0;
+#pragma unroll
+    for (int k = 0; k < kGmTH * kGmTW / kCostBlock; ++k) {
+      const int i = threadIdx.x + k * kCostBlock;
+      const int rl = i / kGmTW, cl = i - rl * kGmTW;
+      const int qr = tr0 + rl, qc = tc0 + cl;
+      const float* p = s_img + (rl + 2) * IW + cl + 2;
+      float vx, vy;
+      sobel3_pair(p[-IW - 1], p[-IW], p[-IW + 1], p[-1], p[1], p[IW - 1], p[IW], p[IW + 1], vx, vy);
+      const bool in = qr >= rg.r0 && qr < rg.r1 && qc >= rg.c0 && qc < rg.c1;   // (the region lies inside the image)
+      val += in ? (double)sobel3_energy(vx, vy) : 0.0;
+    }
+    __shared__ double red_v[kCostBlock / kWave];
+    val = block_sum(val, red_v);
+    if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = val;
+    return;
+  }
   for (int i = threadIdx.x; i < SH * SW; i += kCostBlock) {
     const int rl = i / SW, cl = i - rl * SW;
     const int qr = tr0 - 1 + rl, qc = tc0 - 1 + cl;  // the stencil's centre
@@ -437,7 +458,8 @@ int64_t ebos_gradient_magnitude_fused_partials(int h, int w) {
 int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit_boundary, const float* upstream, float* out,
                                       float* d_image, double* partials, int64_t n_partials, ebos_stream_t stream) {
   using namespace ebos;
-  EBOS_REQUIRE(image && d_image && partials && image != d_image, "ebos_gradient_magnitude_fused: NULL or aliased image / d_image / partials");
+  EBOS_REQUIRE(image && partials && image != d_image, "ebos_gradient_magnitude_fused: NULL image / partials, or d_image aliases image");
+  EBOS_REQUIRE(d_image != nullptr || out != nullptr, "ebos_gradient_magnitude_fused: neither a value nor a gradient image asked for");
   EBOS_REQUIRE(h > 0 && w > 0, "ebos_gradient_magnitude_fused: bad sizes");
   const int64_t need = ebos_gradient_magnitude_fused_partials(h, w);
   if (n_partials < need) {
@@ -449,9 +471,12 @@ int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit
   const dim3 grid((w + kGmTW - 1) / kGmTW, (h + kGmTH - 1) / kGmTH);
   hipEvent_t t0, t1;
   if (profile_next_pair(&t0, &t1, EBOS_PROFILE_GRADMAG_FUSED))  // bench.py --config 3: events stamped with this dispatch's begin / end
-    hipExtLaunchKernelGGL(gradmag_fused_kernel, grid, dim3(kCostBlock), 0, s, t0, t1, 0, image, h, w, rg, upstream, d_image, partials);
+    hipExtLaunchKernelGGL(d_image ? gradmag_fused_kernel<true> : gradmag_fused_kernel<false>, grid, dim3(kCostBlock), 0, s, t0, t1, 0, image, h, w,
+                          rg, upstream, d_image, partials);
+  else if (d_image != nullptr)
+    gradmag_fused_kernel<true><<<grid, dim3(kCostBlock), 0, s>>>(image, h, w, rg, upstream, d_image, partials);
   else
-    gradmag_fused_kernel<<<grid, dim3(kCostBlock), 0, s>>>(image, h, w, rg, upstream, d_image, partials);
+    gradmag_fused_kernel<false><<<grid, dim3(kCostBlock), 0, s>>>(image, h, w, rg, upstream, d_image, partials);
   if (out != nullptr) gradmag_fused_finalize_kernel<<<dim3(1), dim3(kCostBlock), 0, s>>>(partials, (int)need, rg.count(), out);
   EBOS_CHECK_LAUNCH("ebos_gradient_magnitude_fused");
   return EBOS_OK;

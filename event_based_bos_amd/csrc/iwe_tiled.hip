@@ -575,8 +575,9 @@ int ebos_gradient_magnitude_dense_job_f32(const ebos_dense_job* job, const float
                                    job->part_table, stream);
   if (rc != EBOS_OK) return rc;
   // value only: the Sobel pass finalizes; value + gradient: the backward kernel's first workgroup sums the value partials
-  rc = ebos_gradient_magnitude_fused_f32(job->iwe, h, w, job->omit_boundary, upstream, d_flow ? nullptr : out_contrast, d_iwe, partials,
-                                         n_partials, stream);
+  // (a value-only call needs no gradient image: the Sobel pass then skips the gather of the nine stencils and 4 H W bytes of stores)
+  rc = ebos_gradient_magnitude_fused_f32(job->iwe, h, w, job->omit_boundary, upstream, d_flow ? nullptr : out_contrast,
+                                         d_flow ? d_iwe : nullptr, partials, n_partials, stream);
   if (rc != EBOS_OK || d_flow == nullptr) return rc;
   const int lo = job->omit_boundary ? 1 : 0;
   const int64_t npix = (int64_t)(h - 2 * lo > 0 ? h - 2 * lo : 0) * (w - 2 * lo > 0 ? w - 2 * lo : 0);

@@ -612,7 +612,8 @@ int ebos_gradient_magnitude_grad_f64(const double* images, int K, int h, int w, 
  * the image twice, the second one 81 times per pixel): out[0] = mean(gx^2 + gy^2) with (gx, gy) = Sobel 3x3 / 8, replicate padding
  * (src/utils/stat_utils.py:69-92, 117-139), d_image [h, w] = upstream[0] * d out / d image (upstream: device f32 [1], NULL = 1) --
  * the bits of ebos_gradient_magnitude_grad_f32.  partials: device f64 [ebos_gradient_magnitude_fused_partials(h, w)], one value
- * partial per workgroup; out == NULL: no finalize launch (the caller sums the partials: ebos_gradient_magnitude_dense_job_f32). */
+ * partial per workgroup; out == NULL: no finalize launch (the caller sums the partials: ebos_gradient_magnitude_dense_job_f32);
+ * d_image == NULL (with out != NULL): the value only -- no gather of the stencils, no gradient image written. */
 int64_t ebos_gradient_magnitude_fused_partials(int h, int w);
 int ebos_gradient_magnitude_fused_f32(const float* image, int h, int w, int omit_boundary, const float* upstream, float* out,
                                       float* d_image, double* partials, int64_t n_partials, ebos_stream_t stream);

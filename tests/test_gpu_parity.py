@@ -1830,6 +1830,11 @@ def test_fused_gradient_magnitude_pass_equals_the_two_pass_kernels(ebos, shape, 
     xo = img.double().cpu().requires_grad_(True)
     (O.gradient_magnitude(xo, omit, direction="maximize") * float(up[0])).backward()
     assert rel(d_img.cpu().numpy(), xo.grad.numpy()) < 2e-6
+    # value only (d_image NULL): the same value from the lighter form of the pass (an objective evaluation needs no gradient image)
+    out2 = torch.empty(1, device="cuda")
+    _hip.check(lib.ebos_gradient_magnitude_fused_f32(img.data_ptr(), h, w, int(omit), up.data_ptr(), out2.data_ptr(), None,
+                                                     partials.data_ptr(), n, _hip.stream_ptr()), "fused value")
+    assert abs(out2.item() - out.item()) <= 1e-7 * abs(out.item())
     with pytest.raises(RuntimeError):
         _hip.check(lib.ebos_gradient_magnitude_fused_f32(img.data_ptr(), h, w, int(omit), None, out.data_ptr(), d_img.data_ptr(),
                                                          partials.data_ptr(), n - 1 if n > 1 else 0, _hip.stream_ptr()), "fused")
