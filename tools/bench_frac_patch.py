@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""One solver iteration of the patch-flow loop on integer-pixel and on fractional (undistorted) source coordinates, 2 M and 100 k events
+at 1280x720: what ran (grid-sampling / dense route, resident / launches) and its time -- DESIGN 4.4 #59.
+
+    python tools/bench_frac_patch.py
+"""
 import time, numpy as np, torch, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import event_based_bos_amd as ebos
 from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
 H, W = 720, 1280

@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""The four-launch solver loop under clustered events: the plan's adaptive work items (splits 0) against one work item per tile
+(splits 1) and what ``EventPlan.resolve_loop_splits`` picks (splits None) -- DESIGN 4.4 #62.
+
+    python tools/bench_skew_splits.py
+"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np, torch
 import event_based_bos_amd as ebos

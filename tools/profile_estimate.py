@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""Host-side profile (cProfile) and warm timings of ``ContrastMaximization.estimate`` for the two shipped YAMLs (the reference's
+configs/hot_plate1.yaml as parsed data at 346x260, and configs/cmax_hot_plate1.yaml): where a window's time goes outside the kernels.
+
+    python tools/profile_estimate.py
+"""
 import cProfile, pstats, io, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np, torch
 import event_based_bos_amd as ebos
