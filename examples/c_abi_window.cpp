@@ -6,7 +6,8 @@
 //   * mass:      sum(IWE) == number of events whose four taps stay inside the image (zero flow: all of them)
 //   * gradient:  a finite difference of the variance along the direction "towards zero flow" matches <d_flow, direction>
 // and then hands the whole Adam loop of a patch-flow solver to the library (ebos_cmax_patch_solve_f32: 4 kernel launches per
-// iteration, the event kernels sample the patch grid themselves) and checks that the loss falls.
+// iteration, the event kernels sample the patch grid themselves), checks that the loss falls, and runs the same loop once more as ONE
+// resident launch (ebos_cmax_patch_solve_resident_f32: mailbox, status, fallback), whose losses must be the four launches' bit for bit.
 //
 //   hipcc --offload-arch=gfx950 -std=c++17 -Iinclude examples/c_abi_window.cpp \
 //         -Levent_based_bos_amd/lib -lebos_hip -Wl,-rpath,$PWD/event_based_bos_amd/lib -o examples/c_abi_window
@@ -195,6 +196,47 @@ int main(int argc, char** argv) {
   for (float l : h_losses)
     if (!std::isfinite(l)) { std::fprintf(stderr, "non-finite loss\n"); return 8; }
   if (!(h_losses[n_iter - 1] < h_losses[0]) || !(mean_abs < 1.5)) { std::fprintf(stderr, "the solver did not improve the objective\n"); return 8; }
+
+  // ---- the same loop as ONE resident launch (ebos_cmax_patch_solve_resident_f32): one workgroup per source tile stays on its CU for all
+  // iterations.  Protocol: ask _supported, give it a mailbox, read the status afterwards; a negative status says why the launch ended
+  // early -- theta and the optimiser state are then unchanged (or, after -102, those of the completed iterations the mailbox reports)
+  // and the four launches above take over.  With run-time windows (EBOS_HALO_AUTO: normalised time, |dt| <= 1) in BOTH forms the
+  // two run the same arithmetic in the same order: the losses must be the same bits.
+  auto reset = [&]() -> int {
+    std::vector<float> t0(n_grid, 1.5f), z(n_grid, 0.0f);
+    const int zero_step = 0;
+    if (hipMemcpy(theta, t0.data(), n_grid * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(m1, z.data(), n_grid * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m2, z.data(), n_grid * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(q.step, &zero_step, 4, hipMemcpyHostToDevice) != hipSuccess)
+      return 2;
+    return 0;
+  };
+  q.halo = ebos_halo_auto(HALO, 1.0);
+  q.steps_done = 0;
+  if (reset() || ebos_cmax_patch_solve_f32(&q, n_iter, nullptr) != 0) { std::fprintf(stderr, "solve (run-time windows) failed: %s\n", ebos_last_error()); return 7; }
+  std::vector<float> l_four(n_iter), l_res(n_iter);
+  HIP_OK(hipMemcpy(l_four.data(), q.losses, n_iter * 4, hipMemcpyDeviceToHost));
+  if (!ebos_cmax_resident_supported(&q)) {
+    std::printf("(resident launch not available for this geometry: %s)\nOK\n", ebos_last_error());
+    return 0;
+  }
+  const size_t mb_bytes = ebos_cmax_resident_mailbox_bytes(H, W, TH, TW);
+  auto* mailbox = dev_alloc<char>(mb_bytes);
+  if (reset()) return 2;
+  if (ebos_cmax_patch_solve_resident_f32(&q, n_iter, mailbox, mb_bytes, 2.0 /* s: cap of every in-kernel wait */, nullptr) != 0) {
+    std::fprintf(stderr, "resident solve failed: %s\n", ebos_last_error());
+    return 9;
+  }
+  const int status = ebos_cmax_resident_status(mailbox, nullptr), done = ebos_cmax_resident_iterations(mailbox, nullptr);
+  if (status != 0) {  // not an error of the library: this window is the launches' (what a caller does: continue with ebos_cmax_patch_solve_f32)
+    std::printf("resident launch ended early (status %d after %d iterations): %s\nOK\n", status, done, ebos_last_error());
+    return 0;
+  }
+  HIP_OK(hipMemcpy(l_res.data(), q.losses, n_iter * 4, hipMemcpyDeviceToHost));
+  int same = 0;
+  for (int i = 0; i < n_iter; ++i) same += l_res[i] == l_four[i];
+  std::printf("resident:    %d iterations as ONE launch, loss %.6f -> %.6f, %d of %d losses bit-identical to the four-launch loop\n", done,
+              l_res[0], l_res[n_iter - 1], same, n_iter);
+  if (done != n_iter || same != n_iter) { std::fprintf(stderr, "the resident loop differs from the four-launch loop\n"); return 10; }
   std::printf("OK\n");
   return 0;
 }

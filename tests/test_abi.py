@@ -123,8 +123,9 @@ def test_product_never_imports_oracle():
 @pytest.mark.gpu
 def test_c_abi_is_usable_without_python(tmp_path, lib):
     """examples/c_abi_window.cpp: a plain host program (hipcc, no torch) drives the library through include/ebos_hip.h --
-    raw sensor columns -> plan -> objective -> gradient -> 40 Adam iterations of the native patch-flow solver loop -- and checks
-    mass conservation, a finite-difference derivative and that the loss falls, itself."""
+    raw sensor columns -> plan -> objective -> gradient -> 40 Adam iterations of the native patch-flow solver loop, as launches and as
+    one resident launch -- and checks mass conservation, a finite-difference derivative, that the loss falls and that the two forms
+    of the loop agree bit for bit, itself."""
     import shutil
     import subprocess
 
@@ -140,6 +141,8 @@ def test_c_abi_is_usable_without_python(tmp_path, lib):
     run = subprocess.run([exe, "150000"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.strip().endswith("OK"), (run.stdout[-1000:], run.stderr[-1000:])
     assert "solver:" in run.stdout, run.stdout[-1000:]
+    # ... and the same loop as ONE resident launch through the mailbox / status protocol: the four launches' losses bit for bit
+    assert "resident:" in run.stdout and "40 of 40 losses bit-identical" in run.stdout, run.stdout[-1000:]
     print(run.stdout)
 
 
