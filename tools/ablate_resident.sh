@@ -1,5 +1,5 @@
 #!/bin/bash
-# Timing builds of the resident solver kernel (cmax_resident.hip, EBOS_ABL): each leaves pieces of the iteration out (results wrong
+# Timing builds of the resident solver kernels (cmax_resident_core.h, EBOS_ABL; the patch-grid units of the 45 x 80 and 32 x 32 tiles): each leaves pieces of the iteration out (results wrong
 # on purpose) -- what a piece costs WHERE IT STANDS is the difference to the whole.  In-kernel stamps cannot tell: a stamp orders the
 # code around it, and the phases of a workgroup overlap across waves.
 #   tools/ablate_resident.sh build "0 1 2 ..."   (here: cross-compiles lib/libebos_abl<mask>.so)
@@ -9,11 +9,12 @@ MASKS=${2:-"0 1 2 4 8 16 32 64 128 256 512 1024 2048 4096"}
 if [ "$1" = "build" ]; then
   python -m event_based_bos_amd.build > /dev/null
   mkdir -p /tmp/ebos_abl
-  OBJS=$(ls event_based_bos_amd/lib/obj/*.o | grep -v cmax_resident)
+  OBJS=$(ls event_based_bos_amd/lib/obj/*.o | grep -v "cmax_resident_45x80\.o" | grep -v "cmax_resident_32x32\.o")
+  CC="/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -fPIC -fno-gpu-rdc -Wno-unused-function -Iinclude -Ievent_based_bos_amd/csrc -mllvm -sink-insts-to-avoid-spills=1"
   for M in $MASKS; do
-    ( /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -fPIC -fno-gpu-rdc -Wno-unused-function -Iinclude \
-        -Ievent_based_bos_amd/csrc -DEBOS_ABL=$M -mllvm -sink-insts-to-avoid-spills=1 -x hip -c event_based_bos_amd/csrc/cmax_resident.hip -o /tmp/ebos_abl/r$M.o && \
-      /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o event_based_bos_amd/lib/libebos_abl$M.so /tmp/ebos_abl/r$M.o $OBJS ) &
+    ( $CC -DEBOS_ABL=$M -x hip -c event_based_bos_amd/csrc/cmax_resident_45x80.hip -o /tmp/ebos_abl/a$M.o && \
+      $CC -DEBOS_ABL=$M -x hip -c event_based_bos_amd/csrc/cmax_resident_32x32.hip -o /tmp/ebos_abl/b$M.o && \
+      /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o event_based_bos_amd/lib/libebos_abl$M.so /tmp/ebos_abl/a$M.o /tmp/ebos_abl/b$M.o $OBJS ) &
     while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 1; done
   done
   wait
