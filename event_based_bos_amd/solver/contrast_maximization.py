@@ -99,6 +99,9 @@ class ContrastMaximizationMixin(object):
         # from a bound on its own displacements; BOS flows are a few pixels), bounded by the largest built halo; an integer
         # = that built halo for every tile.  Either way displacements beyond a window are handled exactly (spill path).
         self.halo = "auto" if cfg.get("halo", "auto") == "auto" else int(cfg.get("halo"))
+        # `tile` (optional, [rows, cols]): the source tile of the window plans instead of the one that fills the GPU best with ONE
+        # window -- a recording's windows are independent, and larger tiles let more of them run side by side (WindowPipeline)
+        self.tile = tuple(int(v) for v in cfg["tile"]) if cfg.get("tile") else None
         # optimizer.graph: capture one whole iteration (upsample -> fused objective -> backward -> Adam update) into a
         # HIP graph and replay it.  Measured on MI355X / ROCm 7.2 (tools/bench_solver.py, 2 M events at 1280x720):
         # 0.195 ms per replayed iteration against 0.68 ms for the eager loop (interpreter + autograd overhead around
@@ -173,6 +176,8 @@ class ContrastMaximizationMixin(object):
         (``halo: 16`` -- windows whose displacements stay within ~16 px -- selects the smaller LDS windows)."""
         from ..event_plan import choose_tile
 
+        if self.tile is not None:
+            return self.tile
         return choose_tile(self.orig_image_shape, 32 if self.halo == "auto" else self.halo)
 
     def pyramid_scales(self):

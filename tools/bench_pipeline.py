@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--halo", default="auto", help="solver halo: auto (run-time windows, the solver's default) or a built halo (32, 16)")
     ap.add_argument("--repeat", type=int, default=1, help="timed runs per setting (the minimum is reported)")
     ap.add_argument("--size", type=int, nargs=2, default=[720, 1280], help="image size (e.g. 720 640: hot_plate1's ROI, 128 tiles)")
+    ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile of the window plans (default: the one that fills the GPU with one window)")
+    ap.add_argument("--blur", type=float, default=0.0, help="iwe.blur_sigma")
     a = ap.parse_args()
     a.halo = a.halo if a.halo == "auto" else int(a.halo)
     H, W = a.size
@@ -41,10 +43,10 @@ def main():
                                             "p": rs.randint(0, 2, n).astype(bool)})
     windows = [(k * a.events, (k + 1) * a.events) for k in range(a.windows)]
     cfg = {"motion_model": "dense-flow", "warp_direction": "first", "cost_with_weight": {"image_variance": 1.0, "flow_norm": 0.001},
-           "patch": {"size": [24, 32], "sliding_window": [24, 32]}, "halo": a.halo,
+           "patch": {"size": [24, 32], "sliding_window": [24, 32]}, "halo": a.halo, "tile": a.tile, "iwe": {"method": "bilinear_vote", "blur_sigma": a.blur},
            "optimizer": {"method": "Adam", "n_iter": a.iters, "parameters": {"lr": 0.1}}}
     solver = ebos.solver.collections["contrast_maximization"]((H, W), (H, W), solver_config=cfg)
-    res = {"windows": a.windows, "events_per_window": a.events, "iterations": a.iters, "halo": a.halo, "size": [H, W]}
+    res = {"windows": a.windows, "events_per_window": a.events, "iterations": a.iters, "halo": a.halo, "size": [H, W], "tile": list(solver.plan_tile())}
     host_windows = [store.load_event(*wnd) for wnd in windows[:2]]
     solver.estimate(host_windows[0])  # warm the process
     torch.cuda.synchronize()
