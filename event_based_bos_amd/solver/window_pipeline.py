@@ -36,6 +36,28 @@ from . import fused_loop
 from .contrast_maximization import ContrastMaximization, patch_grid_shape
 
 
+# The pipelines of a process share their streams.  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default),
+# in creation order: two streams that land on the same queue run their kernels one after the other -- resident launches of two
+# windows that fit the device side by side then take turns (346 x 260, 100 k events, two windows in flight: 10.5 ms per window
+# instead of 5.6, for every SECOND pipeline object of a process: its fresh streams aliased the first one's).  Streams created once
+# keep the mapping the first pipeline got; where more windows in flight are wanted than queues exist, GPU_MAX_HW_QUEUES=8 in the
+# environment of the process (before its first HIP call) gives every stream a queue of its own.
+_STREAM_POOL = {}
+
+
+def _pooled_streams(device: torch.device, n: int):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    pool = _STREAM_POOL.setdefault(key, {"ingest": None, "solve": []})
+    with _hip.on_device(device):
+        if pool["ingest"] is None:
+            # high priority: the few short ingest kernels must not queue behind thousands of solver launches (the plan
+            # build ends in a host read-back, and the host is what enqueues the next group)
+            pool["ingest"] = torch.cuda.Stream(device=device, priority=-1)
+        while len(pool["solve"]) < n:
+            pool["solve"].append(torch.cuda.Stream(device=device))
+    return pool["ingest"], pool["solve"][:n]
+
+
 class WindowPipeline(object):
     def __init__(self, solver: ContrastMaximization, n_concurrent: int = 3, device="cuda", resident: Optional[bool] = None):
         if solver.motion_model != "dense-flow":
@@ -50,12 +72,10 @@ class WindowPipeline(object):
         self.device = torch.device(device)
         self.lib = _hip.require_gpu()
         self.histories: List[List[float]] = []
-        # the streams live as long as the pipeline: torch's caching allocator pools blocks per stream, so fresh streams
-        # per run would turn every buffer of every window into a new hipMalloc
+        # the streams live as long as the process (_pooled_streams): torch's caching allocator pools blocks per stream, so fresh
+        # streams per run would turn every buffer of every window into a new hipMalloc -- and fresh streams per pipeline may alias
+        # hardware queues
         with _hip.on_device(self.device):
-            # high priority: the few short ingest kernels must not queue behind thousands of solver launches (the plan
-            # build ends in a host read-back, and the host is what enqueues the next group)
-            self.ingest_stream = torch.cuda.Stream(device=self.device, priority=-1)
             # Resident launches run side by side only while all their workgroups fit the device at once (cmax_resident.hip): a small
             # sensor's window (99 tiles at 346 x 260) leaves room for a second one, and a group of three would run 2 + 1 -- the group
             # size is rounded up to a multiple of the windows that fit
@@ -64,7 +84,7 @@ class WindowPipeline(object):
                 H, W = solver.orig_image_shape
                 fit = max(1, int(torch.cuda.get_device_properties(self.device).multi_processor_count) // (-(-H // th) * -(-W // tw)))
                 self.n_concurrent = -(-self.n_concurrent // fit) * fit
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_concurrent)]
+            self.ingest_stream, self.streams = _pooled_streams(self.device, self.n_concurrent)
 
     # ------------------------------------------------------------------ stages
     def _ingest(self, store: RawEventStore, window: Tuple[int, int]) -> EventPlan:
