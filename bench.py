@@ -761,6 +761,31 @@ def run_config2(R):
                                          "last_loss": float(losses[-1])}
                             del sl
                         leg[tag][name] = ent
+                # ... and undistorted events (data.warp: true, configs/hot_plate1.yaml:7: fractional source coordinates): the patch loop's
+                # launches run the dense route on the (x, y, dt) arrays, the resident launch the compact layout with the fractions
+                for tag, (hh, ww), n_f, patch in (("2M_events", (H, W), 2_000_000, (24, 32)), ("100k_events_346x260", small, 100_000, (20, 20))):
+                    rs_f = np.random.RandomState(13)
+                    ev_f = np.stack([rs_f.randint(0, hh, n_f) + rs_f.randint(0, 64, n_f) / 64.0, rs_f.randint(0, ww, n_f) + rs_f.randint(0, 64, n_f) / 64.0,
+                                     np.sort(rs_f.uniform(0, 0.5, n_f)), rs_f.randint(0, 2, n_f)], 1)
+                    ev_f[:, :2] = np.clip(ev_f[:, :2], 0, [hh - 1, ww - 1])
+                    pl_f = ebos.EventPlan.build(torch.from_numpy(ev_f).to(dev), (hh, ww), "first", True, tile="auto")
+                    g_h, g_w = ebos.solver.patch_grid_shape((hh, ww), patch, patch)
+                    ent = {}
+                    for mode, res in (("pipeline", False), ("resident", True)):
+                        sl = FusedPatchLoop(pl_f, patch, patch, torch.zeros((2, g_h, g_w)), 1.0, 0.001, 0.0, halo="auto", lr=0.02, capacity=260)
+                        if res and not sl.resident_supported():
+                            ent[mode] = {"unsupported": (lib.ebos_last_error() or b"").decode()}
+                            continue
+                        sl.run(10, resident=res)
+                        torch.cuda.synchronize()
+                        t4 = time.perf_counter()
+                        losses = sl.run(200, resident=res)
+                        torch.cuda.synchronize()
+                        ent[mode] = {"us_per_iteration": round((time.perf_counter() - t4) / 200 * 1e6, 1), "ran_as": sl.last_run_mode,
+                                     "last_loss": float(losses[-1])}
+                        del sl
+                    leg[tag]["patch_fractional_events"] = ent
+                    del pl_f, ev_f
                 leg["us_per_iteration"] = min(v["us_per_iteration"] for v in leg["2M_events"].values()
                                               if isinstance(v, dict) and "us_per_iteration" in v)
                 extras["solver_iteration"] = leg
