@@ -830,9 +830,11 @@ int ebos_cmax_2dof_solve_f32(const ebos_cmax_2dof_problem* problem, int n_iter, 
  * in registers / LDS, and exchanges only slabs, (sum, sum of squares) records and partial cell gradients with its neighbours
  * through `workspace`, `grad_partials` and `mailbox`.  Same `problem` struct, same results (IWE bit-identical; losses to ~1e-7).
  *
- *   ebos_cmax_resident_supported   1 when `problem` can run resident: grid-sampling route on a compact plan, variance contrast,
- *                                  splits == 1, no padding, tile / halo with a resident kernel ((45, 80, 32), (32, 32, 32)),
- *                                  cells whose supports span <= 4 tiles per axis; 0 otherwise (reason: ebos_last_error)
+ *   ebos_cmax_resident_supported   1 when `problem` can run resident: a compact plan -- of the grid-sampling route (grad_partials), or
+ *                                  with the fractions of undistorted events (cfx / cfy) --, either contrast (the blurred image with
+ *                                  the variance only), splits 0 or 1, no padding, tile / halo with a resident kernel ((45, 80, 32),
+ *                                  (32, 32, 32), (32, 64, 32)), cell blocks of <= 256 elements per tile, cells whose supports span
+ *                                  <= 16 tiles per axis; 0 otherwise (reason: ebos_last_error)
  *   mailbox                        device memory of ebos_cmax_resident_mailbox_bytes(...): flags, records, the status word;
  *                                  cleared by every call
  *   spin_timeout_s                 cap of every in-kernel wait (seconds; e.g. 2.0).  The grid must be co-resident -- the call
@@ -845,9 +847,11 @@ int ebos_cmax_2dof_solve_f32(const ebos_cmax_2dof_problem* problem, int n_iter, 
  *                                  steps_done + k).  The first verdict of a launch stands; should its workgroups have left on
  *                                  two different ones, ebos_cmax_resident_iterations returns -1: the state is partly written.
  *   ebos_cmax_resident_status      synchronises `stream`, returns EBOS_OK or a negative code (-101 spin cap, -102 spill,
- *                                  -103 geometry, -104 one tile holds more than 12 x the average tile's events -- the kernel's own
- *                                  verdict in its first iteration; EBOS_RESIDENT_MAX_IMBALANCE overrides, 0 = never); on a negative
- *                                  code run ebos_cmax_patch_solve_f32 with the same problem.  */
+ *                                  -103 geometry, -104 one tile holds more than 12 x the average tile's events (and >= 32 k of them),
+ *                                  or >= 120 k events and more than 3 x -- the kernel's own verdict in its first iteration;
+ *                                  EBOS_RESIDENT_MAX_IMBALANCE overrides, 0 = never); on a negative code run
+ *                                  ebos_cmax_patch_solve_f32 with the same problem.  -102 is also how the blurred and the
+ *                                  gradient-magnitude loops hand over when the windows outgrow their LDS regions (~12 px).  */
 size_t ebos_cmax_resident_mailbox_bytes(int H, int W, int tile_h, int tile_w);
 int ebos_cmax_resident_supported(const ebos_cmax_patch_problem* problem);
 int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* problem, int n_iter, void* mailbox, size_t mailbox_bytes,

@@ -1106,6 +1106,19 @@ def test_pyramid_runs_resident_at_every_scale_at_1280x720():
     assert s_p.loop_modes == ["pipeline"] * 4
     np.testing.assert_array_equal(np.array(s.history), np.array(s_p.history))
     np.testing.assert_array_equal(flow, flow_p)
+    # the same recording undistorted (data.warp: true: fractional source coordinates) with the YAMLs' blur: every scale resident too
+    # (FRAC kernels), against the launches of the dense route to rounding
+    rs = np.random.RandomState(2)
+    evf = ev.copy()
+    evf[:, :2] = np.clip(evf[:, :2] + rs.randint(0, 64, (len(ev), 2)) / 64.0, 0, [h - 1, w - 1])
+    cfg_f = dict(cfg, iwe={"method": "bilinear_vote", "blur_sigma": 1})
+    s_f = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg_f)
+    s_f.estimate(evf)
+    assert s_f.fused and s_f.loop_modes == ["resident"] * 4, s_f.loop_modes
+    s_fp = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=dict(cfg_f, optimizer=dict(cfg["optimizer"], resident=False)))
+    s_fp.estimate(evf)
+    assert s_fp.fused and s_fp.loop_modes == ["pipeline"] * 4
+    np.testing.assert_allclose(np.array(s_f.history), np.array(s_fp.history), rtol=2e-3)
 
 
 @pytest.mark.gpu
