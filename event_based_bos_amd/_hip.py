@@ -113,6 +113,10 @@ SIGNATURES = {
     "ebos_iwe_slab_batch_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _Z, _I, _I, _P, _P]),
     "ebos_iwe_patch_slab_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I,
                                      _P, _P, _P, _P]),
+    "ebos_iwe_patch_slab_frac_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P,
+                                          _I, _I, _P, _P, _P, _P]),
+    "ebos_iwe_patch_tiled_bwd_frac_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P,
+                                               _P, _P, _P, _Z, _P, _F, _F, _P, _P, _L, _L, _P, _P, _F, _F, _P]),
     "ebos_patch_grad_partials_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "ebos_iwe_patch_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P,
                                           _P, _P, _P, _Z, _P, _F, _F, _P, _P, _L, _L, _P, _P, _P]),

@@ -1159,7 +1159,9 @@ __device__ __forceinline__ void tile_body(const TileRange& tr, const Win<TH, TW,
 
 // set-up of one work item: LDS clear (first window of a workgroup), tile range, GRID: the tile's flow into LDS, DYN: the window
 // from a bound on the tile's displacements.  Returns false for an unused work item of an adaptive plan (nothing to do).
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false, bool ZERO = false>
+// FRAC: a compact plan that carries the fractions of undistorted events (EvPtrs::cfx / cfy): the general loop on the compact slots
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false, bool ZERO = false,
+          bool FRAC = false>
 __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t* __restrict__ key_offsets,
                                                 const float* __restrict__ flow_arg, int H, int W, int tiles_x, int splits, int pad_h,
                                                 int pad_w, float* __restrict__ slabs, float* spill, const GridSrc& gs,
@@ -1183,7 +1185,7 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
   if (tr.ty < 0) return;  // unused work item of an adaptive plan: its slab is never read
   // the lean loop's first two chunks per wave, requested here: they arrive under the rest of the set-up and its barrier instead of
   // a round trip after it (the persistent batched kernel requests them a whole window ahead)
-  constexpr bool kLeanPre = FMT == FMT_COMPACT && !HAS_W && MODE == ACC_FX;
+  constexpr bool kLeanPre = FMT == FMT_COMPACT && !HAS_W && MODE == ACC_FX && !FRAC;
   CRaw pre[2];
   if (kLeanPre) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -1271,18 +1273,19 @@ __device__ __forceinline__ void accumulate_tile(const EvPtrs& ev, const int32_t*
       return;
     }
   }
-  tile_body<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN, ZERO>(tr, win, flow, s_acc, sh, ev, H, W, tiles_x, pad_h, pad_w, slabs,
-                                                                     spill, spill_epoch, epoch, halo_tab, kLeanPre ? pre : nullptr,
-                                                                     NoHook{}, no_own);
+  tile_body<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN, ZERO, FRAC>(tr, win, flow, s_acc, sh, ev, H, W, tiles_x, pad_h, pad_w, slabs,
+                                                                           spill, spill_epoch, epoch, halo_tab, kLeanPre ? pre : nullptr,
+                                                                           NoHook{}, no_own);
 }
 
-template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
+template <int TH, int TW, int HALO, bool HAS_W, int MODE, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false, bool FRAC = false>
 __global__ void __launch_bounds__(kBlock)
 iwe_slab_accumulate_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
                            int tiles_x, int splits, int pad_h, int pad_w, float* __restrict__ slabs, float* spill, GridSrc gs,
                            unsigned* __restrict__ spill_epoch, unsigned epoch, float dt_bound, unsigned* __restrict__ halo_tab) {
-  accumulate_tile<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN>(ev, key_offsets, flow_arg, H, W, tiles_x, splits, pad_h, pad_w,
-                                                                      slabs, spill, gs, spill_epoch, epoch, dt_bound, halo_tab);
+  accumulate_tile<TH, TW, HALO, HAS_W, MODE, FMT, UNIFORM, GRID, DYN, false, FRAC>(ev, key_offsets, flow_arg, H, W, tiles_x, splits, pad_h,
+                                                                                  pad_w, slabs, spill, gs, spill_epoch, epoch, dt_bound,
+                                                                                  halo_tab);
 }
 
 // ---- several independent windows of one geometry in ONE launch (ebos_iwe_slab_batch_f32) ---------------------------------
@@ -2420,7 +2423,8 @@ __device__ __forceinline__ void grid_tile_epilogue(const TileRange& tr, int tr0,
 // (flow_upsample.hip) sums the tiles that touch a cell.  `adaptive`: work items of the plan's part table.
 // DYN: the LDS window of the upstream image is chosen per tile at run time (Win), from the same bound as the forward pass's --
 // the 63 KB per workgroup that a 32 px halo stages shrink to what the tile's displacements can reach.
-template <int TH, int TW, int HALO, bool HAS_W, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false>
+// FRAC: a compact plan with the fractions of undistorted events: the sweep is the f64 one (the fixed-point sweep's groups hold integer pixels)
+template <int TH, int TW, int HALO, bool HAS_W, int FMT, bool UNIFORM, bool GRID = false, bool DYN = false, bool FRAC = false>
 __global__ void __launch_bounds__(kBlock)
 iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, const float* __restrict__ flow_arg, int H, int W,
                            int tiles_x, int pad_h, int pad_w, const float* __restrict__ g_image,
@@ -2484,7 +2488,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   // Fixed-point scatter (bwd_compact_slice, ACC_FX): its unit depends on the largest event count of a source pixel of the tile --
   // the per-pixel counts of the WHOLE tile (an upper bound for a part of it), read off the plan's key offsets while everything
   // else loads
-  constexpr bool kFxScatter = (FMT == FMT_COMPACT) && !HAS_W && !UNIFORM;
+  constexpr bool kFxScatter = (FMT == FMT_COMPACT) && !HAS_W && !UNIFORM && !FRAC;
   int nmax_t = 1;
   if (kFxScatter && tr.ty >= 0) {
     const int32_t* ko = key_offsets + (int64_t)(tr.ty * tiles_x + tr.tx) * (TH * TW);

@@ -167,11 +167,14 @@ static int iwe_slab_entry(const ebos::GridSrc* grid_src, const float* xs, const 
                             const int32_t* key_offsets, int64_t n, const float* flow, int H, int W, int tile_h,
                             int tile_w, int halo_arg, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
-                            double* moments, const int32_t* part_table, ebos_stream_t stream) {
+                            double* moments, const int32_t* part_table, ebos_stream_t stream, const float* cfx = nullptr,
+                            const float* cfy = nullptr) {
   using namespace ebos;
   const HaloArg ha = decode_halo(halo_arg);
   const int halo = ha.halo;
   EBOS_REQUIRE(flow && iwe && key_offsets && workspace, "ebos_iwe_dense_slab: NULL flow/iwe/key_offsets/workspace");
+  EBOS_REQUIRE((cfx == nullptr) == (cfy == nullptr) && (cfx == nullptr || (grid_src != nullptr && grp_offsets && cpix && cdt)),
+               "ebos_iwe_patch_slab_frac: cfx / cfy come together, with the compact arrays, on the grid-sampling entry");
   EBOS_REQUIRE(((xs && ys && dts) || (grp_offsets && cpix && cdt)) || n == 0, "ebos_iwe_dense_slab: NULL event buffer");
   EBOS_REQUIRE(n >= 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0 && splits >= 0 && splits <= 64,
                "ebos_iwe_dense_slab: bad sizes (splits=%d)", splits);
@@ -190,7 +193,7 @@ static int iwe_slab_entry(const ebos::GridSrc* grid_src, const float* xs, const 
   char* ws = reinterpret_cast<char*>(workspace);
   const int n_tiles_ = ((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w);
   const EvPtrs evp{xs, ys, dts, weight, grp_offsets, cpix, cdt, part_table, part_table ? part_table + n_tiles_ + 1 : nullptr,
-                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
+                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr, cfx, cfy};
   static const int acc_mode = [] {  // EBOS_SLAB_ACC=f64 forces the f64 accumulator (debug / A-B runs)
     const char* e = getenv("EBOS_SLAB_ACC");
     return (e && e[0] == 'f') ? (int)ACC_F64 : (int)ACC_FX;
@@ -234,6 +237,16 @@ int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, co
                             int W, int tile_h, int tile_w, int halo, int splits, int pad_h, int pad_w, void* workspace,
                             size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary, float* out_variance,
                             double* moments, const int32_t* part_table, ebos_stream_t stream) {
+  return ebos_iwe_patch_slab_frac_f32(grp_offsets, cpix, cdt, nullptr, nullptr, key_offsets, n, grid, gh, gw, patch_h, patch_w, slide_h,
+                                      slide_w, H, W, tile_h, tile_w, halo, splits, pad_h, pad_w, workspace, workspace_bytes, iwe,
+                                      want_variance, omit_boundary, out_variance, moments, part_table, stream);
+}
+
+int ebos_iwe_patch_slab_frac_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const float* cfx, const float* cfy,
+                                 const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w,
+                                 int slide_h, int slide_w, int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h,
+                                 int pad_w, void* workspace, size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary,
+                                 float* out_variance, double* moments, const int32_t* part_table, ebos_stream_t stream) {
   using namespace ebos;
   EBOS_REQUIRE(grid && gh > 0 && gw > 0 && patch_h > 0 && patch_w > 0 && slide_h > 0 && slide_w > 0,
                "ebos_iwe_patch_slab: bad patch grid (%dx%d, patch %dx%d, slide %dx%d)", gh, gw, patch_h, patch_w, slide_h, slide_w);
@@ -246,7 +259,7 @@ int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, co
   const GridSrc gs{make_axis(gh, patch_h, slide_h, H), make_axis(gw, patch_w, slide_w, W)};
   return iwe_slab_entry(&gs, nullptr, nullptr, nullptr, nullptr, grp_offsets, cpix, cdt, key_offsets, n, grid, H, W, tile_h, tile_w, halo,
                         splits, pad_h, pad_w, workspace, workspace_bytes, iwe, want_variance, omit_boundary, out_variance, moments,
-                        part_table, stream);
+                        part_table, stream, cfx, cfy);
 }
 
 int ebos_iwe_slab_batch_f32(const ebos_slab_window* windows, int n_windows, int gh, int gw, int patch_h, int patch_w, int slide_h,
@@ -694,8 +707,9 @@ static int patch_tiled_bwd_impl(const int32_t* grp_offsets, const uint16_t* cpix
                                const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
                                float w_flow_norm, float w_image_gradient, double* reg_partials, const double* var_partials,
                                int64_t n_var_partials, int64_t n_var_pixels, float* out_variance, double* out_moments,
-                               ebos::Blur3 blur, ebos_stream_t stream) {
+                               ebos::Blur3 blur, ebos_stream_t stream, const float* cfx = nullptr, const float* cfy = nullptr) {
   using namespace ebos;
+  EBOS_REQUIRE((cfx == nullptr) == (cfy == nullptr), "ebos_iwe_patch_tiled_bwd_frac: cfx / cfy come together");
   const HaloArg ha = decode_halo(halo_arg);
   const int halo = ha.halo;
   EBOS_REQUIRE(var_partials == nullptr || (var_moments == nullptr && upstream != nullptr && n_var_partials >= 1 && n_var_pixels >= 2),
@@ -729,7 +743,7 @@ static int patch_tiled_bwd_impl(const int32_t* grp_offsets, const uint16_t* cpix
   hipStream_t s = as_stream(stream);
   const int n_tiles_ = ((H + tile_h - 1) / tile_h) * ((W + tile_w - 1) / tile_w);
   const EvPtrs evp{nullptr, nullptr, nullptr, nullptr, grp_offsets, cpix, cdt, part_table, part_table ? part_table + n_tiles_ + 1 : nullptr,
-                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
+                   part_table ? part_table + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr, cfx, cfy};
   const GridSrc gs{make_axis(gh, patch_h, slide_h, H), make_axis(gw, patch_w, slide_w, W)};
   int rc = EBOS_ERR_UNSUPPORTED;
   rc = slab_ops(tile_h, tile_w, halo)->bwd(evp, key_offsets, grid, false, H, W, pad_h, pad_w, g_image, affine, g_lo, nullptr, nullptr, nullptr,
@@ -766,6 +780,22 @@ int ebos_iwe_patch_tiled_bwd_blur_f32(const int32_t* grp_offsets, const uint16_t
                               tile_w, halo_arg, pad_h, pad_w, z_image, nullptr, g_lo, nullptr, upstream, nullptr, grad_partials,
                               grad_partials_bytes, part_table, w_flow_norm, w_image_gradient, reg_partials, blur_partials,
                               n_blur_partials, n_var_pixels, out_variance, out_moments, ebos::Blur3{blur_k0, blur_k1}, stream);
+}
+
+/* the grid-sampling backward pass on a compact plan that carries the fractions of undistorted events (ebos_plan_compact_frac_f32);
+ * blur_k0 == 0: the plain contrast (arguments as ebos_iwe_patch_tiled_bwd_f32 with var_partials), else the blurred one (as _blur_f32) */
+int ebos_iwe_patch_tiled_bwd_frac_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const float* cfx, const float* cfy,
+                                      const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w,
+                                      int slide_h, int slide_w, int H, int W, int tile_h, int tile_w, int halo_arg, int pad_h, int pad_w,
+                                      const float* g_image, int g_lo, const double* var_moments, const float* upstream,
+                                      const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
+                                      float w_flow_norm, float w_image_gradient, double* reg_partials, const double* var_partials,
+                                      int64_t n_var_partials, int64_t n_var_pixels, float* out_variance, double* out_moments,
+                                      float blur_k0, float blur_k1, ebos_stream_t stream) {
+  return patch_tiled_bwd_impl(grp_offsets, cpix, cdt, key_offsets, n, grid, gh, gw, patch_h, patch_w, slide_h, slide_w, H, W, tile_h,
+                              tile_w, halo_arg, pad_h, pad_w, g_image, nullptr, g_lo, var_moments, upstream, addend, grad_partials,
+                              grad_partials_bytes, part_table, w_flow_norm, w_image_gradient, reg_partials, var_partials,
+                              n_var_partials, n_var_pixels, out_variance, out_moments, ebos::Blur3{blur_k0, blur_k1}, stream, cfx, cfy);
 }
 
 }  // extern "C"

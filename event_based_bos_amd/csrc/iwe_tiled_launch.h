@@ -81,6 +81,9 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
       }
       ka = dyn ? iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, true>
                : iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, false>;
+      if (ev.cfx != nullptr)  // the compact slots carry the fractions of undistorted events: the general loop on them
+        ka = dyn ? iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, true, true>
+                 : iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, true, false, true>;
       lds += grid_lds_extra<TH, TW, 0>();
       gs = *grid_src;
     } else {
@@ -218,6 +221,9 @@ int launch_tiled_bwd(const EvPtrs& ev, const int32_t* key_offsets, const float* 
       }
       kb = dyn ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, true, true>
                : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, true, false>;
+      if (ev.cfx != nullptr)  // ... with the fractions of undistorted events: the f64 sweep
+        kb = dyn ? iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, true, true, true>
+                 : iwe_dense_tiled_bwd_kernel<TH, TW, HALO, false, FMT_COMPACT, false, true, false, true>;
       lds = grid_bwd_lds<TH, TW, HALO>();
       if (int rc = reserve_lds(kb, lds, "ebos_iwe_patch_tiled_bwd")) return rc;
       const unsigned grid = (unsigned)(tiles_y * tiles_x * (adaptive ? kAdaptiveItemsPerTile : 1));

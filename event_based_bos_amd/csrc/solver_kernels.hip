@@ -206,6 +206,7 @@ int ebos_cmax_adam_step_f32(float* theta, const float* grad, float* exp_avg, flo
 static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
   using namespace ebos;
   EBOS_REQUIRE(q != nullptr && q->steps_done >= 0, "ebos_cmax_patch_solve: NULL problem or negative steps_done");
+  EBOS_REQUIRE((q->cfx == nullptr) == (q->cfy == nullptr), "ebos_cmax_patch_solve: cfx / cfy come together");
   EBOS_REQUIRE(q->theta && q->d_theta && q->exp_avg && q->exp_avg_sq && q->step && q->iwe && q->variance && q->moments &&
                    q->upstream && q->workspace && q->reg_partials,
                "ebos_cmax_patch_solve: NULL buffer");
@@ -217,6 +218,8 @@ static int cmax_check_problem(const ebos_cmax_patch_problem* q) {
                  "ebos_patch_fused_supported", q->tile_h, q->tile_w, q->halo, q->slide_h, q->slide_w);
   } else {
     EBOS_REQUIRE(q->dense && q->d_dense && q->upsample_scratch, "ebos_cmax_patch_solve: NULL dense / d_dense / upsample_scratch");
+    EBOS_REQUIRE(q->cfx == nullptr || (q->xs && q->ys && q->dts),
+                 "ebos_cmax_patch_solve: a window of fractional source coordinates on the dense route needs xs / ys / dts");
   }
   // (grid sampling: the backward kernel evaluates the regularisers from the tile's flow, no d_reg image)
   EBOS_REQUIRE(!has_reg_ || q->d_reg || q->grad_partials != nullptr,
@@ -255,15 +258,21 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
   }
   const bool use_gm = q->w_gradient_magnitude != 0.0f;
   const bool blur = q->blur_k0 != 0.0f;  // (variance contrast: cmax_check_problem)
+  // dense route: compact arrays that carry fractions (cfx / cfy) are the grid-sampling and the resident kernels' -- the dense-flow
+  // kernels read such a window from xs / ys / dts
+  const bool frac = q->cfx != nullptr;
+  const int32_t* d_grp = frac ? nullptr : q->grp_offsets;
+  const uint16_t* d_cpix = frac ? nullptr : q->cpix;
+  const float* d_cdt = frac ? nullptr : q->cdt;
   const int h = q->H + 2 * q->pad_h, w = q->W + 2 * q->pad_w;
   const float contrast_weight = use_gm ? q->w_gradient_magnitude : q->w_variance;
-  if (grid)
-    rc = ebos_iwe_patch_slab_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h, q->patch_w,
-                                 q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w,
-                                 q->workspace, q->workspace_bytes, q->iwe, (use_gm || blur) ? 0 : 2, q->omit_boundary, q->variance, q->moments,
-                                 q->part_table, stream);  // (variance: partials only; the regulariser or backward kernel reduces them)
+  if (grid)  // (cfx / cfy: the compact slots carry the fractions of undistorted events; NULL: integer source pixels)
+    rc = ebos_iwe_patch_slab_frac_f32(q->grp_offsets, q->cpix, q->cdt, q->cfx, q->cfy, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h,
+                                      q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h,
+                                      q->pad_w, q->workspace, q->workspace_bytes, q->iwe, (use_gm || blur) ? 0 : 2, q->omit_boundary,
+                                      q->variance, q->moments, q->part_table, stream);  // (variance: partials only; the regulariser or backward kernel reduces them)
   else
-    rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense,
+    rc = ebos_iwe_dense_slab_f32(q->xs, q->ys, q->dts, nullptr, d_grp, d_cpix, d_cdt, q->key_offsets, q->n, q->dense,
                                  q->H, q->W, q->tile_h, q->tile_w, q->halo, q->splits, q->pad_h, q->pad_w, q->workspace,
                                  q->workspace_bytes, q->iwe, (use_gm || blur) ? 0 : (has_reg ? 2 : 1), q->omit_boundary, q->variance,
                                  q->moments, q->part_table, stream);
@@ -296,11 +305,11 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
     rc = ebos_blur3_variance_adjoint_f32(q->iwe, h, w, q->omit_boundary, q->blur_k0, q->blur_k1, q->blur_image,
                                          reinterpret_cast<double*>(q->cost_scratch), n_blur, stream);
     if (rc) return rc;
-    rc = ebos_iwe_patch_tiled_bwd_blur_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h,
-                                           q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h,
-                                           q->pad_w, q->blur_image, lo, q->upstream, q->grad_partials, q->grad_partials_bytes,
-                                           q->splits == 0 ? q->part_table : nullptr, fuse_norm ? q->w_flow_norm : 0.0f,
-                                           fuse_norm ? q->w_image_gradient : 0.0f, q->reg_partials,
+    rc = ebos_iwe_patch_tiled_bwd_frac_f32(q->grp_offsets, q->cpix, q->cdt, q->cfx, q->cfy, q->key_offsets, q->n, q->theta, q->gh, q->gw,
+                                           q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo,
+                                           q->pad_h, q->pad_w, q->blur_image, lo, nullptr, q->upstream, nullptr, q->grad_partials,
+                                           q->grad_partials_bytes, q->splits == 0 ? q->part_table : nullptr,
+                                           fuse_norm ? q->w_flow_norm : 0.0f, fuse_norm ? q->w_image_gradient : 0.0f, q->reg_partials,
                                            reinterpret_cast<const double*>(q->cost_scratch), n_blur, n_valid, q->variance, q->moments,
                                            q->blur_k0, q->blur_k1, stream);
     if (rc) return rc;
@@ -312,14 +321,15 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
                                             q->theta_mask, stream);
   }
   if (grid) {
-    rc = ebos_iwe_patch_tiled_bwd_f32(q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->theta, q->gh, q->gw, q->patch_h,
-                                      q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,
-                                      use_gm ? q->d_iwe : q->iwe, nullptr, use_gm ? 0 : (q->omit_boundary ? 1 : 0),
-                                      (use_gm || !has_reg) ? nullptr : q->moments, use_gm ? nullptr : q->upstream,
-                                      has_reg ? q->d_reg : nullptr, q->grad_partials, q->grad_partials_bytes,
-                                      q->splits == 0 ? q->part_table : nullptr, fuse_norm ? q->w_flow_norm : 0.0f,
-                                      fuse_norm ? q->w_image_gradient : 0.0f, q->reg_partials,
-                                      (use_gm || has_reg) ? nullptr : var_partials, n_parts, n_px, q->variance, q->moments, stream);
+    rc = ebos_iwe_patch_tiled_bwd_frac_f32(q->grp_offsets, q->cpix, q->cdt, q->cfx, q->cfy, q->key_offsets, q->n, q->theta, q->gh, q->gw,
+                                           q->patch_h, q->patch_w, q->slide_h, q->slide_w, q->H, q->W, q->tile_h, q->tile_w, q->halo,
+                                           q->pad_h, q->pad_w, use_gm ? q->d_iwe : q->iwe, use_gm ? 0 : (q->omit_boundary ? 1 : 0),
+                                           (use_gm || !has_reg) ? nullptr : q->moments, use_gm ? nullptr : q->upstream,
+                                           has_reg ? q->d_reg : nullptr, q->grad_partials, q->grad_partials_bytes,
+                                           q->splits == 0 ? q->part_table : nullptr, fuse_norm ? q->w_flow_norm : 0.0f,
+                                           fuse_norm ? q->w_image_gradient : 0.0f, q->reg_partials,
+                                           (use_gm || has_reg) ? nullptr : var_partials, n_parts, n_px, q->variance, q->moments, 0.0f, 0.0f,
+                                           stream);
     if (rc) return rc;
     const int n_items = (int)(ebos_patch_grad_partials_bytes(q->H, q->W, q->tile_h, q->tile_w, q->splits == 0) / 2048);
     // partial cell gradients -> d_theta, the Adam step of every grid element and the loss of the iteration
@@ -336,13 +346,13 @@ static int cmax_enqueue_iteration(const ebos_cmax_patch_problem* q, int t, ebos_
     rc = ebos_blur3_variance_adjoint_f32(q->iwe, h, w, q->omit_boundary, q->blur_k0, q->blur_k1, q->blur_image,
                                          reinterpret_cast<double*>(q->cost_scratch), n_blur, stream);
     if (rc) return rc;
-    rc = ebos_iwe_dense_tiled_bwd_blur_f32(q->xs, q->ys, q->dts, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n, q->dense, q->H, q->W,
+    rc = ebos_iwe_dense_tiled_bwd_blur_f32(q->xs, q->ys, q->dts, d_grp, d_cpix, d_cdt, q->key_offsets, q->n, q->dense, q->H, q->W,
                                            q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w, q->blur_image, lo, q->upstream,
                                            has_reg ? q->d_reg : nullptr, q->d_dense, q->workspace, q->workspace_bytes,
                                            q->splits == 0 ? q->part_table : nullptr, reinterpret_cast<const double*>(q->cost_scratch), n_blur,
                                            n_valid, q->variance, q->moments, q->blur_k0, q->blur_k1, stream);
   } else
-  rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, q->key_offsets, q->n,
+  rc = ebos_iwe_dense_tiled_bwd_f32(q->xs, q->ys, q->dts, nullptr, d_grp, d_cpix, d_cdt, q->key_offsets, q->n,
                                     q->dense, q->H, q->W, q->tile_h, q->tile_w, q->halo, q->pad_h, q->pad_w,
                                     use_gm ? q->d_iwe : q->iwe, nullptr, use_gm ? 0 : (q->omit_boundary ? 1 : 0), q->d_dense, nullptr,
                                     use_gm ? nullptr : q->moments, use_gm ? nullptr : q->upstream,

@@ -125,6 +125,13 @@ class FusedPatchLoop(object):
         if sample_grid is None and os.environ.get("EBOS_SAMPLE_GRID", "1") == "0":  # A/B switch for measurements
             can = False
         self.sample_grid = can if sample_grid is None else bool(sample_grid)
+        # A window of fractional source coordinates (undistorted events): the natively enqueued loop (run / ebos_cmax_patch_solve_f32)
+        # and the resident launch take the grid-sampling kernels on the compact layout WITH the fractions (general event loops:
+        # ebos_iwe_patch_slab_frac_f32 / _tiled_bwd_frac_f32); the per-call Python forms (iteration, value_and_grad) keep the dense route
+        # on (x, y, dt).  EBOS_FRAC_GRID=0: dense route everywhere (A/B).
+        self.native_grid = self.sample_grid or bool(
+            plan.frac_compact is not None and os.environ.get("EBOS_FRAC_GRID", "1") != "0" and sample_grid is not False
+            and self.lib.ebos_patch_fused_supported(plan.tile[0], plan.tile[1], self.halo, self.slide[0], self.slide[1]))
         # iwe.blur_sigma > 0: the contrast of the 3-tap blurred image (ebos_blur3_variance_adjoint_f32 between the combine and the
         # backward pass; the backward kernel folds the variance gradient in as a z + c wgt, csrc/blur3.h)
         self.blur_sigma = float(blur_sigma or 0.0)
@@ -154,9 +161,9 @@ class FusedPatchLoop(object):
                            torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32))
         self.grad_partials = (torch.empty(int(self.lib.ebos_patch_grad_partials_bytes(H, W, plan.tile[0], plan.tile[1],
                                                                                      int(self.splits == 0))) // 4, **f32)
-                              if self.sample_grid else None)
-        if self.fuse_norm:  # one value partial per work item of the backward kernel
-            self.n_reg = self.grad_partials.numel() // 512
+                              if self.native_grid else None)
+        if self.fuse_norm or (self.native_grid and (self.w_tv != 0.0 or self.w_norm != 0.0)):
+            self.n_reg = max(self.n_reg, self.grad_partials.numel() // 512)  # one value partial per work item of the backward kernel
         self.reg_partials = torch.zeros(max(self.n_reg, 1), dtype=torch.float64, device=dev)
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.graphed = False  # kept for callers that report it: this loop is never graph-replayed
@@ -315,6 +322,8 @@ class FusedPatchLoop(object):
         q.grad_partials = ptr(self.grad_partials)
         q.grad_partials_bytes = self.grad_partials.numel() * 4 if self.grad_partials is not None else 0
         q.blur_k0, q.blur_k1, q.blur_image = self.blur[0], self.blur[1], ptr(self.blur_image)
+        if self.native_grid and not self.sample_grid:  # fractional source coordinates: the compact layout with the fractions per slot
+            q.grp_offsets, q.cpix, q.cdt, q.cfx, q.cfy = (ptr(t) for t in plan.frac_compact)
         return q
 
     def resident_supported(self) -> bool:

@@ -487,6 +487,13 @@ int ebos_iwe_patch_slab_f32(const int32_t* grp_offsets, const uint16_t* cpix, co
                             int splits, int pad_h, int pad_w, void* workspace, size_t workspace_bytes, float* iwe,
                             int want_variance, int omit_boundary, float* out_variance, double* moments,
                             const int32_t* part_table, ebos_stream_t stream);
+/* ... on a window of FRACTIONAL source coordinates (undistorted events): the arrays of ebos_plan_compact_frac_f32 -- the compact slots
+ * with x - floor(x), y - floor(y) per slot.  The general event loop on the compact layout (cfx == cfy == NULL: ebos_iwe_patch_slab_f32). */
+int ebos_iwe_patch_slab_frac_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const float* cfx, const float* cfy,
+                                 const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w,
+                                 int slide_h, int slide_w, int H, int W, int tile_h, int tile_w, int halo, int splits, int pad_h,
+                                 int pad_w, void* workspace, size_t workspace_bytes, float* iwe, int want_variance, int omit_boundary,
+                                 float* out_variance, double* moments, const int32_t* part_table, ebos_stream_t stream);
 size_t ebos_patch_grad_partials_bytes(int H, int W, int tile_h, int tile_w, int adaptive);
 int ebos_iwe_patch_tiled_bwd_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt,
                                  const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw,
@@ -511,6 +518,17 @@ int ebos_iwe_patch_tiled_bwd_blur_f32(const int32_t* grp_offsets, const uint16_t
                                       double* reg_partials, const double* blur_partials, int64_t n_blur_partials,
                                       int64_t n_var_pixels, float* out_variance, double* out_moments, float blur_k0,
                                       float blur_k1, ebos_stream_t stream);
+/* The grid-sampling backward pass on a compact plan that carries the fractions of undistorted events (f64 sweep); blur_k0 == 0: the
+ * plain contrast (g_image = the IWE, var_partials of the combine pass), else the blurred one (g_image = z_image, var_partials = the
+ * blur pass's pairs) -- the arguments of the two entries above. */
+int ebos_iwe_patch_tiled_bwd_frac_f32(const int32_t* grp_offsets, const uint16_t* cpix, const float* cdt, const float* cfx, const float* cfy,
+                                      const int32_t* key_offsets, int64_t n, const float* grid, int gh, int gw, int patch_h, int patch_w,
+                                      int slide_h, int slide_w, int H, int W, int tile_h, int tile_w, int halo, int pad_h, int pad_w,
+                                      const float* g_image, int g_lo, const double* var_moments, const float* upstream,
+                                      const float* addend, float* grad_partials, size_t grad_partials_bytes, const int32_t* part_table,
+                                      float w_flow_norm, float w_image_gradient, double* reg_partials, const double* var_partials,
+                                      int64_t n_var_partials, int64_t n_var_pixels, float* out_variance, double* out_moments,
+                                      float blur_k0, float blur_k1, ebos_stream_t stream);
 /* ... and on the dense-flow route (windows of fractional source coordinates: the (x, y, dt) arrays; or compact ones): d loss / d flow
  * [2, H, W] of the blurred contrast, arguments as ebos_iwe_dense_tiled_bwd_f32 / ebos_iwe_patch_tiled_bwd_blur_f32. */
 int ebos_iwe_dense_tiled_bwd_blur_f32(const float* xs, const float* ys, const float* dts, const int32_t* grp_offsets, const uint16_t* cpix,
@@ -768,8 +786,9 @@ typedef struct ebos_cmax_patch_problem {
   float blur_k0, blur_k1;
   float* blur_image;
   /* the resident launch on a window of FRACTIONAL source coordinates (undistorted events: data.warp in the reference's configs):
-   * with cfx / cfy non-NULL, grp_offsets / cpix / cdt / cfx / cfy are the arrays of ebos_plan_compact_frac_f32.  Only
-   * ebos_cmax_patch_solve_resident_f32 reads them: the four-launch loop of such a window runs on xs / ys / dts (grad_partials NULL). */
+   * with cfx / cfy non-NULL, grp_offsets / cpix / cdt / cfx / cfy are the arrays of ebos_plan_compact_frac_f32.  The resident launch
+   * reads them, and so does the four-launch loop when grad_partials is given (grid-sampling route on the fractions: general event
+   * loops); with grad_partials NULL the launches run the dense route on xs / ys / dts. */
   const float *cfx, *cfy;
 } ebos_cmax_patch_problem;
 int ebos_cmax_patch_solve_f32(const ebos_cmax_patch_problem* problem, int n_iter, ebos_stream_t stream);

@@ -850,13 +850,14 @@ def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma
     ((96, 128), 20_000, (24, 32), (1.0, 0.0, 0.0), 0.0, 1.0),
 ])
 def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch, terms, gm, blur):
-    """Undistorted events (data.warp: true, configs/hot_plate1.yaml:7) have fractional source coordinates: the four-launch loop of
-    such a window runs on the (x, y, dt) arrays through a dense flow field (upsample, general event kernels, adjoint of the
-    upsample); the resident launch reads the compact layout with the fractions per slot (EventPlan.frac_compact, FRAC kernels:
-    general forward loop, f64 backward sweep).  First iteration against the fp64 oracle's autograd (loss 1e-5, patch-flow gradient
-    rel-L2 1e-3 where the oracle is affordable) and against the four launches; 60 iterations to rounding (the four launches form x'
-    from the absolute f32 coordinate, the resident loop from the fraction: ~1e-4 px apart at x ~ 1000); a resident run is continued
-    by the four launches."""
+    """Undistorted events (data.warp: true, configs/hot_plate1.yaml:7) have fractional source coordinates.  The natively enqueued
+    four-launch loop and the resident launch read the compact layout with the fractions per slot (EventPlan.frac_compact; FRAC
+    kernels: general forward loop, f64 backward sweep -- the grid-sampling route); the per-call Python forms, and
+    ``sample_grid=False``, run the (x, y, dt) arrays through a dense flow field (upsample, general event kernels, adjoint of the
+    upsample).  First iteration against the fp64 oracle's autograd (loss 1e-5, patch-flow gradient rel-L2 1e-3 where the oracle is
+    affordable), against the four launches (the same arithmetic: to the last bits of the f64 atomics) and against the dense route
+    (which forms x' from the absolute f32 coordinate instead of the fraction: ~1e-4 px apart at x ~ 1000); 60 iterations to
+    rounding; a resident run is continued by the four launches."""
     import event_based_bos_amd as ebos
     from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
 
@@ -875,10 +876,16 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
                               blur_sigma=blur)
 
     ref, res = make(), make()
-    assert not res.sample_grid and res.resident_supported(), ebos.load_library().ebos_last_error()
+    assert not res.sample_grid and res.native_grid and res.resident_supported(), ebos.load_library().ebos_last_error()
     l1_ref = ref.run(1, resident=False).cpu().numpy()
     l1_res = res.run(1, resident=True).cpu().numpy()
     assert ref.last_run_mode == "pipeline" and res.last_run_mode == "resident" and res.resident_status == 0 and res.resident_iterations == 1
+    # the dense route on the same window (sample_grid=False: what a tile / sliding window outside ebos_patch_fused_supported gets)
+    dense = FusedPatchLoop(plan, patch, patch, theta0, *terms, halo="auto", lr=0.02, capacity=4, w_gradient_magnitude=gm, blur_sigma=blur,
+                           sample_grid=False)
+    assert not dense.native_grid
+    l1_dense = dense.run(1, resident=False).cpu().numpy()
+    assert abs(l1_dense[0] / l1_ref[0] - 1) < 1e-5 and float((dense.d_theta - ref.d_theta).norm() / ref.d_theta.norm()) < 1e-3
     e_iwe = float((res.iwe - ref.iwe).norm() / ref.iwe.norm())
     e_g = float((res.d_theta - ref.d_theta).norm() / ref.d_theta.norm())
     print(f"first iteration: IWE rel-L2 {e_iwe:.2e}, loss rel {abs(l1_res[0] / l1_ref[0] - 1):.2e}, d_theta rel-L2 {e_g:.2e}")
