@@ -668,9 +668,11 @@ int ebos_cmax_2dof_solve_f32(const ebos_cmax_2dof_problem* q, int n_iter, ebos_s
   char* ws = reinterpret_cast<char*>(q->workspace);
   const int n_tiles_ = ((q->H + tile_h - 1) / tile_h) * ((q->W + tile_w - 1) / tile_w);
   const int32_t* pt = q->part_table;
+  // (cfx / cfy: the compact slots carry the fractions of undistorted events -- the general loops on the compact layout, the resident
+  // FRAC kernels' arithmetic)
   const EvPtrs evf{q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, pt, pt ? pt + n_tiles_ + 1 : nullptr,
-                   pt ? pt + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr};
-  const EvPtrs evb{q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr};
+                   pt ? pt + n_tiles_ + 1 + kAdaptiveItemsPerTile * n_tiles_ : nullptr, q->cfx, q->cfy};
+  const EvPtrs evb{q->xs, q->ys, q->dts, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr, q->cfx, q->cfy};
   // the backward kernel's tile partials live in the slab section of the workspace (dead once the image is combined)
   double* tile_partials = reinterpret_cast<double*>(q->workspace);
   const double* var_partials = blur ? reinterpret_cast<const double*>(q->cost_scratch) : reinterpret_cast<const double*>(ws + off);

@@ -73,6 +73,14 @@ int launch_slab_fwd(const EvPtrs& ev, const int32_t* key_offsets, const float* f
   if (dyn)
     ka = uniform ? iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, true, false, true>
                  : iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, false, false, true>;
+  if (compact && ev.cfx != nullptr && grid_src == nullptr) {  // the compact slots carry the fractions of undistorted events: the general loop on them (the patch grid: below)
+    if (!uniform || ev.w != nullptr || acc_mode != ACC_FX) {
+      set_error("ebos_iwe_*_slab: fractions per compact slot (cfx / cfy) go with the 2-DoF model or the patch grid, unit weights");
+      return EBOS_ERR_UNSUPPORTED;
+    }
+    ka = dyn ? iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, true, false, true, true>
+             : iwe_slab_accumulate_kernel<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, true, false, false, true>;
+  }
   if (grid_src != nullptr) {  // `flow` is a patch grid, sampled per tile inside the kernel (compact unit-weight plans)
     if constexpr (grid_fwd_fits<TH, TW, HALO>()) {
       if (!compact || uniform) {

@@ -535,6 +535,10 @@ class Fused2dofLoop(object):
         q = _hip.Cmax2dofProblem()
         q.xs, q.ys, q.dts = ptr(plan.x), ptr(plan.y), ptr(plan.dt)
         q.grp_offsets, q.cpix, q.cdt, q.key_offsets, q.n = gp, cp, cd, ptr(plan.key_offsets), plan.n
+        if plan.frac_compact is not None and os.environ.get("EBOS_FRAC_GRID", "1") != "0":
+            # fractional source coordinates: the compact layout with the fractions per slot (the launches and the resident kernel then
+            # run the same arithmetic; EBOS_FRAC_GRID=0: the launches on the (x, y, dt) arrays)
+            q.grp_offsets, q.cpix, q.cdt, q.cfx, q.cfy = (ptr(t) for t in plan.frac_compact)
         q.H, q.W, q.tile_h, q.tile_w, q.halo = H, W, plan.tile[0], plan.tile[1], self.halo
         q.pad_h, q.pad_w, q.omit_boundary = self.pad[0], self.pad[1], int(self.omit)
         q.splits, q.part_table = self.splits, ptr(plan.part_table)

@@ -798,8 +798,8 @@ def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma
     """The 2-DoF Adam loop (configs/hot_plate1.yaml:47: 2d-translation) as ONE resident launch (ebos_cmax_2dof_solve_resident_f32)
     against ebos_cmax_2dof_solve_f32: the first image bit for bit, losses / theta / Adam state to rounding over 150 iterations (the
     tiles' partial pairs are f64 sums of per-lane f64 sums drawn from a dynamic chunk queue: the last bits depend on the draw).
-    frac: fractional source coordinates (undistorted events, data.warp: true in configs/hot_plate1.yaml:7) -- the resident launch
-    reads the compact layout with the fractions per slot (EventPlan.frac_compact), the four launches the (x, y, dt) arrays."""
+    frac: fractional source coordinates (undistorted events, data.warp: true in configs/hot_plate1.yaml:7) -- both forms read the
+    compact layout with the fractions per slot (EventPlan.frac_compact); EBOS_FRAC_GRID=0 puts the launches on the (x, y, dt) arrays."""
     import event_based_bos_amd as ebos
     from event_based_bos_amd.solver.fused_loop import Fused2dofLoop
 
@@ -824,6 +824,15 @@ def test_resident_2dof_loop_matches_the_four_launch_loop(size, n_ev, omit, sigma
     assert torch.equal(ref.iwe, res.iwe)
     np.testing.assert_allclose(l1_res, l1_ref, rtol=1e-6)
     np.testing.assert_allclose(res.d_theta.cpu().numpy(), ref.d_theta.cpu().numpy(), rtol=1e-4, atol=1e-9)
+    if frac:  # the launches on the (x, y, dt) arrays (EBOS_FRAC_GRID=0: x' from the absolute f32 coordinate): the same step to rounding
+        os.environ["EBOS_FRAC_GRID"] = "0"
+        try:
+            xy = make()
+            l1_xy = xy.run(1, resident=False).cpu().numpy()
+        finally:
+            del os.environ["EBOS_FRAC_GRID"]
+        np.testing.assert_allclose(l1_xy, l1_ref, rtol=1e-5)
+        np.testing.assert_allclose(xy.d_theta.cpu().numpy(), ref.d_theta.cpu().numpy(), rtol=2e-3, atol=1e-7)
     l_ref = ref.run(n_iter - 1, resident=False).cpu().numpy()
     l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
     assert res.last_run_mode == "resident" and res.t == n_iter and int(res.step.item()) == n_iter
