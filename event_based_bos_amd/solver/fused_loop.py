@@ -117,21 +117,18 @@ class FusedPatchLoop(object):
         self.has_reg = self.w_norm != 0.0 or self.w_tv != 0.0
         # sample_grid (default: whenever supported): the event kernels evaluate the patch grid -> dense map per tile
         # themselves (ebos_iwe_patch_*): no upsample / adjoint launches, no [2, H, W] flow and gradient fields
-        can = bool(plan.compact and self.lib.ebos_patch_fused_supported(plan.tile[0], plan.tile[1], self.halo, self.slide[0],
-                                                                        self.slide[1]))
+        # (a window of fractional source coordinates -- undistorted events -- takes them on the compact layout WITH the fractions per
+        # slot: general event loops, ebos_iwe_patch_slab_frac_f32 / _tiled_bwd_frac_f32; EBOS_FRAC_GRID=0: its dense route, A/B)
+        frac_ok = plan.frac_compact is not None and os.environ.get("EBOS_FRAC_GRID", "1") != "0"
+        can = bool((plan.compact or frac_ok) and self.lib.ebos_patch_fused_supported(plan.tile[0], plan.tile[1], self.halo, self.slide[0],
+                                                                                    self.slide[1]))
         if sample_grid and not can:
             raise ValueError(f"sample_grid: tile {plan.tile} / halo {self.halo} / sliding window {self.slide} is outside "
                              "ebos_patch_fused_supported (or the plan is not compact)")
         if sample_grid is None and os.environ.get("EBOS_SAMPLE_GRID", "1") == "0":  # A/B switch for measurements
             can = False
         self.sample_grid = can if sample_grid is None else bool(sample_grid)
-        # A window of fractional source coordinates (undistorted events): the natively enqueued loop (run / ebos_cmax_patch_solve_f32)
-        # and the resident launch take the grid-sampling kernels on the compact layout WITH the fractions (general event loops:
-        # ebos_iwe_patch_slab_frac_f32 / _tiled_bwd_frac_f32); the per-call Python forms (iteration, value_and_grad) keep the dense route
-        # on (x, y, dt).  EBOS_FRAC_GRID=0: dense route everywhere (A/B).
-        self.native_grid = self.sample_grid or bool(
-            plan.frac_compact is not None and os.environ.get("EBOS_FRAC_GRID", "1") != "0" and sample_grid is not False
-            and self.lib.ebos_patch_fused_supported(plan.tile[0], plan.tile[1], self.halo, self.slide[0], self.slide[1]))
+        self.native_grid = self.sample_grid  # (kept for callers of the round's first form, where the two differed for fractional plans)
         # iwe.blur_sigma > 0: the contrast of the 3-tap blurred image (ebos_blur3_variance_adjoint_f32 between the combine and the
         # backward pass; the backward kernel folds the variance gradient in as a z + c wgt, csrc/blur3.h)
         self.blur_sigma = float(blur_sigma or 0.0)
@@ -161,9 +158,9 @@ class FusedPatchLoop(object):
                            torch.empty(int(self.lib.ebos_upsample_bwd_scratch_bytes(self.gh, W)) // 4, **f32))
         self.grad_partials = (torch.empty(int(self.lib.ebos_patch_grad_partials_bytes(H, W, plan.tile[0], plan.tile[1],
                                                                                      int(self.splits == 0))) // 4, **f32)
-                              if self.native_grid else None)
-        if self.fuse_norm or (self.native_grid and (self.w_tv != 0.0 or self.w_norm != 0.0)):
-            self.n_reg = max(self.n_reg, self.grad_partials.numel() // 512)  # one value partial per work item of the backward kernel
+                              if self.sample_grid else None)
+        if self.fuse_norm:  # one value partial per work item of the backward kernel
+            self.n_reg = self.grad_partials.numel() // 512
         self.reg_partials = torch.zeros(max(self.n_reg, 1), dtype=torch.float64, device=dev)
         self.ws = _workspace(plan, self.pad, self.halo, self.splits)
         self.graphed = False  # kept for callers that report it: this loop is never graph-replayed
@@ -194,10 +191,10 @@ class FusedPatchLoop(object):
         want_var = 0 if use_gm else (2 if (self.has_reg or grid) else 1)
         off, n_parts, n_px = self._var_partials
         if grid:
-            check(lib.ebos_iwe_patch_slab_f32(*plan._compact_ptrs(), ptr(plan.key_offsets), plan.n, ptr(self.theta), gh, gw, ph, pw,
-                                              sh, sw, H, W, plan.tile[0], plan.tile[1], self.halo, self.splits, self.pad[0],
-                                              self.pad[1], ptr(self.ws), self.ws.numel(), ptr(self.iwe), want_var, int(self.omit),
-                                              ptr(self.variance), ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_patch_slab")
+            check(lib.ebos_iwe_patch_slab_frac_f32(*self._grid_ptrs(), ptr(plan.key_offsets), plan.n, ptr(self.theta), gh, gw, ph, pw,
+                                                   sh, sw, H, W, plan.tile[0], plan.tile[1], self.halo, self.splits, self.pad[0],
+                                                   self.pad[1], ptr(self.ws), self.ws.numel(), ptr(self.iwe), want_var, int(self.omit),
+                                                   ptr(self.variance), ptr(self.moments), ptr(plan.part_table), s), "ebos_iwe_patch_slab")
         else:
             check(lib.ebos_iwe_dense_slab_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                               ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
@@ -213,17 +210,17 @@ class FusedPatchLoop(object):
                                                  ptr(self.reg_partials), None if use_gm else self.ws.data_ptr() + off, n_parts, n_px,
                                                  ptr(self.variance), ptr(self.moments), s), "ebos_flow_regularisers")
         if grid:  # -> partial cell gradients per tile; _grid_gradient() sums them (and applies Adam)
-            check(lib.ebos_iwe_patch_tiled_bwd_f32(*plan._compact_ptrs(), ptr(plan.key_offsets), plan.n, ptr(self.theta), gh, gw, ph, pw,
-                                                   sh, sw, H, W, plan.tile[0], plan.tile[1], self.halo, self.pad[0], self.pad[1],
-                                                   ptr(self.d_iwe if use_gm else self.iwe), None, 0 if use_gm else int(self.omit),
-                                                   ptr(self.moments) if (self.has_reg and not use_gm) else None,
-                                                   None if use_gm else ptr(self.upstream),
-                                                   ptr(self.d_reg), ptr(self.grad_partials), self.grad_partials.numel() * 4,
-                                                   ptr(plan.part_table) if self.splits == 0 else None,
-                                                   self.w_norm if self.fuse_norm else 0.0, self.w_tv if self.fuse_norm else 0.0,
-                                                   ptr(self.reg_partials),
-                                                   None if (use_gm or self.has_reg) else self.ws.data_ptr() + off, n_parts, n_px,
-                                                   ptr(self.variance), ptr(self.moments), s), "ebos_iwe_patch_tiled_bwd")
+            check(lib.ebos_iwe_patch_tiled_bwd_frac_f32(*self._grid_ptrs(), ptr(plan.key_offsets), plan.n, ptr(self.theta), gh, gw, ph, pw,
+                                                        sh, sw, H, W, plan.tile[0], plan.tile[1], self.halo, self.pad[0], self.pad[1],
+                                                        ptr(self.d_iwe if use_gm else self.iwe), 0 if use_gm else int(self.omit),
+                                                        ptr(self.moments) if (self.has_reg and not use_gm) else None,
+                                                        None if use_gm else ptr(self.upstream),
+                                                        ptr(self.d_reg), ptr(self.grad_partials), self.grad_partials.numel() * 4,
+                                                        ptr(plan.part_table) if self.splits == 0 else None,
+                                                        self.w_norm if self.fuse_norm else 0.0, self.w_tv if self.fuse_norm else 0.0,
+                                                        ptr(self.reg_partials),
+                                                        None if (use_gm or self.has_reg) else self.ws.data_ptr() + off, n_parts, n_px,
+                                                        ptr(self.variance), ptr(self.moments), 0.0, 0.0, s), "ebos_iwe_patch_tiled_bwd")
             return
         check(lib.ebos_iwe_dense_tiled_bwd_f32(ptr(plan.x), ptr(plan.y), ptr(plan.dt), None, *plan._compact_ptrs(),
                                                ptr(plan.key_offsets), plan.n, ptr(self.dense), H, W, plan.tile[0], plan.tile[1],
@@ -322,9 +319,17 @@ class FusedPatchLoop(object):
         q.grad_partials = ptr(self.grad_partials)
         q.grad_partials_bytes = self.grad_partials.numel() * 4 if self.grad_partials is not None else 0
         q.blur_k0, q.blur_k1, q.blur_image = self.blur[0], self.blur[1], ptr(self.blur_image)
-        if self.native_grid and not self.sample_grid:  # fractional source coordinates: the compact layout with the fractions per slot
-            q.grp_offsets, q.cpix, q.cdt, q.cfx, q.cfy = (ptr(t) for t in plan.frac_compact)
+        if self.sample_grid and not plan.compact:  # fractional source coordinates: the compact layout with the fractions per slot
+            q.grp_offsets, q.cpix, q.cdt, q.cfx, q.cfy = self._grid_ptrs()
         return q
+
+    def _grid_ptrs(self):
+        """(grp_offsets, cpix, cdt, cfx, cfy) of the grid-sampling entries: the compact plan, or -- fractional source coordinates -- the
+        compact layout with the fractions per slot."""
+        plan = self.plan
+        if plan.compact:
+            return plan._compact_ptrs() + (None, None)
+        return tuple(ptr(t) for t in plan.frac_compact)
 
     def resident_supported(self) -> bool:
         """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_patch_solve_resident_f32)?  Grid-sampling route, either

@@ -885,14 +885,17 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
                               blur_sigma=blur)
 
     ref, res = make(), make()
-    assert not res.sample_grid and res.native_grid and res.resident_supported(), ebos.load_library().ebos_last_error()
+    assert res.sample_grid and res.resident_supported(), ebos.load_library().ebos_last_error()
     l1_ref = ref.run(1, resident=False).cpu().numpy()
     l1_res = res.run(1, resident=True).cpu().numpy()
     assert ref.last_run_mode == "pipeline" and res.last_run_mode == "resident" and res.resident_status == 0 and res.resident_iterations == 1
     # the dense route on the same window (sample_grid=False: what a tile / sliding window outside ebos_patch_fused_supported gets)
     dense = FusedPatchLoop(plan, patch, patch, theta0, *terms, halo="auto", lr=0.02, capacity=4, w_gradient_magnitude=gm, blur_sigma=blur,
                            sample_grid=False)
-    assert not dense.native_grid
+    assert not dense.sample_grid
+    if not blur:  # ... and the per-call Python form of the grid route (what the scipy optimisers drive): the natively enqueued step's numbers
+        l_v, g_v = make().value_and_grad(theta0.cuda())
+        assert abs(float(l_v) / l1_ref[0] - 1) < 1e-6 and float((g_v - ref.d_theta).norm() / ref.d_theta.norm()) < 1e-5
     l1_dense = dense.run(1, resident=False).cpu().numpy()
     assert abs(l1_dense[0] / l1_ref[0] - 1) < 1e-5 and float((dense.d_theta - ref.d_theta).norm() / ref.d_theta.norm()) < 1e-3
     e_iwe = float((res.iwe - ref.iwe).norm() / ref.iwe.norm())
