@@ -329,6 +329,36 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
   }
 }
 
+// The binning scatter leaves the events of one source pixel in the order its atomics arrived: two builds of one window differ in it.
+// For integer source pixels that order is invisible (the lean build canonicalises it anyway); with fractions per slot the kernels'
+// run sums see it in their last bits, and an optimiser loop amplifies those -- two solves of one window drifted apart.  One thread
+// per source pixel puts its slots into a canonical order: by (dt, fx, fy), insertion sort (runs are a handful of events; a run
+// beyond kCanonMax -- a hot pixel -- is left as it is).
+constexpr int kCanonMax = 64;
+__global__ void __launch_bounds__(256)
+compact_frac_canon_kernel(const int32_t* __restrict__ key_offsets, int tile_px, int64_t n_keys, const int32_t* __restrict__ grp_offsets,
+                          float* __restrict__ cdt, float* __restrict__ cfx, float* __restrict__ cfy) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_keys) return;
+  const int32_t b = key_offsets[k], e = key_offsets[k + 1];
+  const int len = e - b;
+  if (len < 2 || len > kCanonMax) return;
+  const int64_t t = k / tile_px;
+  const int64_t o0 = (int64_t)grp_offsets[t] * 4 + (b - key_offsets[t * tile_px]);  // the run's first slot
+  auto before = [](float d0, float x0, float y0, float d1, float x1, float y1) {
+    return d0 < d1 || (d0 == d1 && (x0 < x1 || (x0 == x1 && y0 < y1)));
+  };
+  for (int i = 1; i < len; ++i) {
+    const float d = cdt[o0 + i], x = cfx[o0 + i], y = cfy[o0 + i];
+    int j = i - 1;
+    while (j >= 0 && before(d, x, y, cdt[o0 + j], cfx[o0 + j], cfy[o0 + j])) {
+      cdt[o0 + j + 1] = cdt[o0 + j], cfx[o0 + j + 1] = cfx[o0 + j], cfy[o0 + j + 1] = cfy[o0 + j];
+      --j;
+    }
+    cdt[o0 + j + 1] = d, cfx[o0 + j + 1] = x, cfy[o0 + j + 1] = y;
+  }
+}
+
 // Adaptive work items: cut heavy tiles into parts of at most tau events, parts(t) = max(1, ceil(load(t) / tau)).
 // A work item is one workgroup and a CU holds one of them at a time (LDS), so with F = the fixed work of an item
 // (LDS clear, decode, slab store) expressed in events, a pass lasts about
@@ -617,6 +647,9 @@ int ebos_plan_compact_frac_f32(const float* xs, const float* ys, const float* dt
   compact_offsets_kernel<<<dim3(1), dim3(256), 0, s>>>(key_offsets, tile_h * tile_w, n_tiles, grp_offsets);
   compact_fill_kernel<<<dim3(n_tiles), dim3(256), 0, s>>>(xs, ys, dts, key_offsets, tile_h, tile_w, tiles_x, grp_offsets, cpix,
                                                           cdt, cfx, cfy);
+  const int64_t n_keys = (int64_t)n_tiles * tile_h * tile_w;
+  compact_frac_canon_kernel<<<dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, s>>>(key_offsets, tile_h * tile_w, n_keys, grp_offsets, cdt,
+                                                                                      cfx, cfy);
   EBOS_CHECK_LAUNCH("ebos_plan_compact_frac");
   return EBOS_OK;
 }

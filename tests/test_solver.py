@@ -931,6 +931,36 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("resident", [True, False])
+def test_two_builds_of_a_fractional_window_solve_identically(resident):
+    """The binning scatter orders the events of one source pixel as its atomics arrive; the fractional compact layout is put into a
+    canonical order afterwards (by dt, fx, fy: compact_frac_canon_kernel), so two plans of one window hold the same slots and two
+    solves walk the same trajectory bit for bit -- the run sums of the backward sweep see the slot order in their last bits, and
+    Adam amplified those into 0.1 px after a few hundred iterations."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w, n_ev, patch = 260, 346, 100_000, (20, 26)
+    rs = np.random.RandomState(23)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    ev[:, :2] = np.clip(ev[:, :2] + rs.uniform(0, 1, (n_ev, 2)), 0, [h - 1, w - 1])
+    ev[: n_ev // 50, :2] = ev[0, :2]            # a hot pixel beyond the canonical-order bound keeps its order of arrival ...
+    ev[: n_ev // 50, 2] = ev[0, 2]              # ... which is invisible when its events are identical
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+    theta0 = torch.from_numpy(rs.uniform(-2, 2, (2, gh, gw))).float()
+    runs = []
+    for _ in range(3):
+        plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto")
+        loop = FusedPatchLoop(plan, patch, patch, theta0, 1.0, 0.001, 0.0, halo="auto", lr=0.03, capacity=100, blur_sigma=1.0)
+        losses = loop.run(80, resident=resident).cpu().numpy().copy()
+        assert loop.last_run_mode == ("resident" if resident else "pipeline")
+        runs.append([a.cpu().numpy().copy() for a in plan.frac_compact[1:]] + [losses, loop.theta.cpu().numpy().copy()])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
     """A flow whose displacements leave the largest LDS window: the resident launch must END (status -102).  In its FIRST iteration
     it leaves theta and the optimiser state untouched and ``run`` produces the four-launch pipeline's result; when the flow grows

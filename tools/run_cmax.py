@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--width", type=int, default=None, help="override data.width (and the ROI columns) -- e.g. 346")
     ap.add_argument("--n-events", type=int, default=100_000)
     ap.add_argument("--n-iter", type=int, default=None, help="override solver.optimizer.n_iter")
+    ap.add_argument("--warp", action="store_true", help="data.warp: true -- undistorted events (fractional source coordinates), as configs/hot_plate1.yaml:7")
     args = ap.parse_args()
     cfg = load_config(args.config_file)
     d, cp = cfg["data"], cfg.setdefault("common_params", {})
@@ -71,6 +72,8 @@ def main():
     for k, v in (("xmin", 0), ("xmax", d["height"]), ("ymin", 0), ("ymax", d["width"])):
         cp.setdefault(k, v)
     d.setdefault("n_events", args.n_events)
+    if args.warp:
+        d["warp"] = True
     ebos.utils.propagate_config(cfg)                                   # src/utils/config_utils.py:42-88
     scfg = cfg["solver"]
     overrides = {}
