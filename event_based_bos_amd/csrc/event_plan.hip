@@ -373,7 +373,17 @@ plan_parts_kernel(const int32_t* __restrict__ key_offsets, int n_tiles, int tile
   __shared__ long long red[1024 / kWave];
   __shared__ long long s_bcast;
   __shared__ int s_max;
-  auto load_of = [&](int t) { return key_offsets[(int64_t)(t + 1) * tile_px] - key_offsets[(int64_t)t * tile_px]; };
+  // the tiles' loads are read ~40 times (two searches, the ranking): kept in LDS (a window of more tiles reads them from memory --
+  // with one 913 us launch per plan on a clustered 1280 x 720 window before, most of it the ranking's global loads)
+  constexpr int kCached = 4096;
+  __shared__ int s_load[kCached], s_parts[kCached];
+  const bool cached = n_tiles <= kCached;
+  auto load_global = [&](int t) { return key_offsets[(int64_t)(t + 1) * tile_px] - key_offsets[(int64_t)t * tile_px]; };
+  if (cached) {
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) s_load[t] = load_global(t);
+    __syncthreads();
+  }
+  auto load_of = [&](int t) { return cached ? s_load[t] : load_global(t); };
   auto items_at = [&](int tau) {  // block-uniform result
     long long cnt = 0;
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) cnt += max(1, (load_of(t) + tau - 1) / tau);
@@ -424,33 +434,36 @@ plan_parts_kernel(const int32_t* __restrict__ key_offsets, int n_tiles, int tile
     return;
   }
   __shared__ int s_used;
+  if (cached) {
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) s_parts[t] = max(1, (s_load[t] + lo - 1) / lo);
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     int off = 0;
     for (int t = 0; t < n_tiles; ++t) {
       part_off[t] = off;
-      off += max(1, (load_of(t) + lo - 1) / lo);
+      off += cached ? s_parts[t] : max(1, (load_of(t) + lo - 1) / lo);
     }
     part_off[n_tiles] = off;
     s_used = off;
   }
   __syncthreads();  // part_off is read below by other threads (global memory written by this workgroup: fence not needed
   __threadfence_block();  // across a barrier within one workgroup, kept explicit)
-  // work items heaviest first (greedy longest-processing-time order of the dispatcher): rank sort, one (tile, part)
-  // per thread-iteration.  The item load is the events of that part; ties break on the slab index.
+  // work items heaviest first (greedy longest-processing-time order of the dispatcher): rank by the events of a part, ties on the
+  // slab index.  The parts of one tile carry the same load and consecutive slabs: they take consecutive ranks behind every part
+  // of a heavier tile and of an equally heavy earlier one -- one pass over the tiles per tile.
   const int used = s_used;
   for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
-    const int parts = part_off[t + 1] - part_off[t], load = load_of(t);
+    const int parts = cached ? s_parts[t] : part_off[t + 1] - part_off[t], load = load_of(t);
+    const int mine = (load + parts - 1) / parts;
+    int rank = 0;
+    for (int u = 0; u < n_tiles; ++u) {
+      const int pu = cached ? s_parts[u] : part_off[u + 1] - part_off[u], lu = (load_of(u) + pu - 1) / pu;
+      if (lu > mine || (lu == mine && u < t)) rank += pu;
+    }
     for (int k = 0; k < parts; ++k) {
-      const int slab = part_off[t] + k;
-      const int mine = (load + parts - 1) / parts;
-      int rank = 0;
-      for (int u = 0; u < n_tiles; ++u) {
-        const int pu = part_off[u + 1] - part_off[u], lu = (load_of(u) + pu - 1) / pu;
-        if (lu > mine) rank += pu;
-        else if (lu == mine) rank += max(0, min(pu, slab - part_off[u]));  // equal load: earlier slabs first
-      }
-      item_tile[rank] = t;
-      item_part[rank] = k;
+      item_tile[rank + k] = t;
+      item_part[rank + k] = k;
     }
   }
   for (int i = used + threadIdx.x; i < n_items; i += blockDim.x) {

@@ -194,8 +194,17 @@ patch_grad_combine_kernel(const float* __restrict__ partials, const int32_t* __r
         if (gj < gj0 || gj > gj1) continue;
         const int tile = ty * tiles_x + tx;
         const int it0 = part_off ? part_off[tile] : tile, it1 = part_off ? part_off[tile + 1] : tile + 1;
-        for (int it = it0; it < it1; ++it)
-          acc += partials[(((int64_t)it * 2 + ch) * kGridCells + (gi - gi0)) * kGridCells + (gj - gj0)];
+        // (a crowded tile of an adaptive plan has tens of work items: eight loads in flight per round trip, added in order)
+        constexpr int kItemBatch = 8;
+        for (int it = it0; it < it1; it += kItemBatch) {
+          float t[kItemBatch];
+#pragma unroll
+          for (int j = 0; j < kItemBatch; ++j)
+            t[j] = partials[(((int64_t)min(it + j, it1 - 1) * 2 + ch) * kGridCells + (gi - gi0)) * kGridCells + (gj - gj0)];
+#pragma unroll
+          for (int j = 0; j < kItemBatch; ++j)
+            if (it + j < it1) acc += t[j];
+        }
       }
     }
   }

@@ -1651,17 +1651,29 @@ __device__ __forceinline__ void combine4_block(const float* __restrict__ slabs, 
       v.z += first[k].z;
       v.w += first[k].w;
       if (exact) vd[0] += (double)first[k].x, vd[1] += (double)first[k].y, vd[2] += (double)first[k].z, vd[3] += (double)first[k].w;
-      for (int p = 1; p < parts[k]; ++p) {
+      // (a crowded tile of an adaptive plan has tens of parts: eight slab loads in flight per round trip -- one by one the pass took
+      // 21.6 us on a window whose fullest tile holds 21 x the average, against 9 on a uniform one; the additions keep their order)
+      constexpr int kPartBatch = 8;
+      for (int p = 1; p < parts[k]; p += kPartBatch) {
+        float4 t[kPartBatch];
+#pragma unroll
+        for (int j = 0; j < kPartBatch; ++j) {
+          const unsigned q = (unsigned)min(p + j, parts[k] - 1);
 #ifndef EBOS_PLAIN_SLABS
-        const float4 t = slab_load4(all_slabs, byte0[k] + (unsigned)p * (unsigned)(LH * LW * 4));
+          t[j] = slab_load4(all_slabs, byte0[k] + q * (unsigned)(LH * LW * 4));
 #else
-        const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slabs) + byte0[k] + (size_t)p * (LH * LW * 4));
+          t[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slabs) + byte0[k] + (size_t)q * (LH * LW * 4));
 #endif
-        v.x += t.x;
-        v.y += t.y;
-        v.z += t.z;
-        v.w += t.w;
-        if (exact) vd[0] += (double)t.x, vd[1] += (double)t.y, vd[2] += (double)t.z, vd[3] += (double)t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < kPartBatch; ++j) {
+          if (p + j >= parts[k]) break;
+          v.x += t[j].x;
+          v.y += t[j].y;
+          v.z += t[j].z;
+          v.w += t[j].w;
+          if (exact) vd[0] += (double)t[j].x, vd[1] += (double)t[j].y, vd[2] += (double)t[j].z, vd[3] += (double)t[j].w;
+        }
       }
     }
     const int64_t gi = (int64_t)R * w + C;

@@ -43,19 +43,23 @@ def main():
     ap.add_argument("--sigma", type=float, nargs="*", default=[400, 200, 100, 50])
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--modes", nargs="*", default=["pipeline", "resident", "resident_forced"])
+    ap.add_argument("--no-uniform", action="store_true", help="skip the uniform window (for a kernel trace of one distribution)")
     a = ap.parse_args()
     lib = ebos._hip.require_gpu()
     patch = (24, 32)
     gh, gw = ebos.solver.patch_grid_shape((H, W), patch, patch)
     rows = []
     for n in a.events:
-        for sigma in [None] + list(a.sigma):
+        for sigma in ([] if a.no_uniform else [None]) + list(a.sigma):
             rs = np.random.RandomState(0)
             plan = ebos.EventPlan.build(torch.from_numpy(window(n, sigma, rs)).cuda(), (H, W), "first", True, tile="auto", emit="compact")
             tiles = plan.key_offsets[::plan.tile[0] * plan.tile[1]].diff().float()
             row = {"events": n, "sigma_px": sigma, "fullest_tile_over_average": round(float(tiles.max() / tiles.mean()), 1)}
             last = {}
             for mode, res, env in (("pipeline", False, None), ("resident", True, None), ("resident_forced", True, "0")):
+                if mode not in a.modes:
+                    continue
                 if env is None:
                     os.environ.pop("EBOS_RESIDENT_MAX_IMBALANCE", None)
                 else:
@@ -63,7 +67,8 @@ def main():
                 sl = FusedPatchLoop(plan, patch, patch, torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.1,
                                     capacity=a.iters + 20)
                 if res and not sl.resident_supported():
-                    row[mode] = {"unsupported": (lib.ebos_last_error() or b"").decode()}
+                    row[mode] = {"unsupported": (lib.ebos_last_error() or b"").decode() or
+                                 "crowded window: refused by the host-side check (crowded_for_resident), run() takes the four launches"}
                     continue
                 sl.run(10, resident=None if res else False)
                 torch.cuda.synchronize()
