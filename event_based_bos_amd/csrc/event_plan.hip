@@ -300,6 +300,7 @@ compact_offsets_kernel(const int32_t* __restrict__ key_offsets, int tile_px, int
 
 // cfx / cfy (nullable): the fractional parts x - floor(x), y - floor(y) of the source coordinates per slot -- the compact plan of a
 // window of undistorted events (ebos_plan_compact_frac_f32)
+constexpr int kCanonMax = 64;
 __global__ void __launch_bounds__(256)
 compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
                     const int32_t* __restrict__ key_offsets, int tile_h, int tile_w, int tiles_x,
@@ -310,52 +311,53 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
   const int32_t beg = key_offsets[(int64_t)t * tile_px], end = key_offsets[(int64_t)(t + 1) * tile_px];
   const int64_t out0 = (int64_t)grp_offsets[t] * 4, out1 = (int64_t)grp_offsets[t + 1] * 4;
   const int r0 = (t / tiles_x) * tile_h, c0 = (t % tiles_x) * tile_w;
-  for (int64_t o = out0 + threadIdx.x; o < out1; o += blockDim.x) {
+  for (int64_t o = out0 + blockIdx.y * blockDim.x + threadIdx.x; o < out1; o += (int64_t)gridDim.y * blockDim.x) {
     const int64_t src = beg + (o - out0);
     if (src < end) {
       const float x = xs[src], y = ys[src];
       const int r = (int)x - r0, c = (int)y - c0;
-      cpix[o] = (uint16_t)((r << 8) | c);
-      cdt[o] = dts[src];
       if (cfx != nullptr) {  // (what load_group computes for the (x, y, dt) format: the same numbers)
-        cfx[o] = x - (float)(int)x;
-        cfy[o] = y - (float)(int)y;
+        const float dt = dts[src], fx = x - (float)(int)x, fy = y - (float)(int)y;
+        // The binning scatter leaves the events of one source pixel in the order its atomics arrived: two builds of one window
+        // differ in it.  For integer source pixels that order is invisible (and the lean build's is canonical); with fractions per
+        // slot the kernels' run sums see it in their last bits, and an optimiser loop amplifies those -- two solves of one window
+        // drifted apart.  So an event takes the slot of its RANK in its pixel's run by (dt, fx, fy) (equal events: equal slots
+        // whatever their order); a run beyond kCanonMax events -- a hot pixel -- keeps its order of arrival.
+        const int64_t key = (int64_t)t * tile_px + r * tile_w + c;
+        const int32_t kb = key_offsets[key], ke = key_offsets[key + 1];
+        int64_t slot = o;
+        if (ke - kb > 1 && ke - kb <= kCanonMax) {
+          int rank = 0;
+          for (int32_t j0 = kb; j0 < ke; j0 += 4) {  // (four events' loads in flight: the longest run's chain of round trips bounds the pass)
+            float xj[4], yj[4], dj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int32_t j = min(j0 + u, ke - 1);
+              xj[u] = xs[j], yj[u] = ys[j], dj[u] = dts[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int32_t j = j0 + u;
+              const float fxj = xj[u] - (float)(int)xj[u], fyj = yj[u] - (float)(int)yj[u];
+              const bool before = dj[u] < dt || (dj[u] == dt && (fxj < fx || (fxj == fx && (fyj < fy || (fyj == fy && j < src)))));
+              rank += (j < ke && before) ? 1 : 0;
+            }
+          }
+          slot = out0 + (kb - beg) + rank;
+        }
+        cpix[slot] = (uint16_t)((r << 8) | c);
+        cdt[slot] = dt;
+        cfx[slot] = fx;
+        cfy[slot] = fy;
+      } else {
+        cpix[o] = (uint16_t)((r << 8) | c);
+        cdt[o] = dts[src];
       }
     } else {
       cpix[o] = 0;
       cdt[o] = __builtin_nanf("");
       if (cfx != nullptr) cfx[o] = 0.0f, cfy[o] = 0.0f;
     }
-  }
-}
-
-// The binning scatter leaves the events of one source pixel in the order its atomics arrived: two builds of one window differ in it.
-// For integer source pixels that order is invisible (the lean build canonicalises it anyway); with fractions per slot the kernels'
-// run sums see it in their last bits, and an optimiser loop amplifies those -- two solves of one window drifted apart.  One thread
-// per source pixel puts its slots into a canonical order: by (dt, fx, fy), insertion sort (runs are a handful of events; a run
-// beyond kCanonMax -- a hot pixel -- is left as it is).
-constexpr int kCanonMax = 64;
-__global__ void __launch_bounds__(256)
-compact_frac_canon_kernel(const int32_t* __restrict__ key_offsets, int tile_px, int64_t n_keys, const int32_t* __restrict__ grp_offsets,
-                          float* __restrict__ cdt, float* __restrict__ cfx, float* __restrict__ cfy) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_keys) return;
-  const int32_t b = key_offsets[k], e = key_offsets[k + 1];
-  const int len = e - b;
-  if (len < 2 || len > kCanonMax) return;
-  const int64_t t = k / tile_px;
-  const int64_t o0 = (int64_t)grp_offsets[t] * 4 + (b - key_offsets[t * tile_px]);  // the run's first slot
-  auto before = [](float d0, float x0, float y0, float d1, float x1, float y1) {
-    return d0 < d1 || (d0 == d1 && (x0 < x1 || (x0 == x1 && y0 < y1)));
-  };
-  for (int i = 1; i < len; ++i) {
-    const float d = cdt[o0 + i], x = cfx[o0 + i], y = cfy[o0 + i];
-    int j = i - 1;
-    while (j >= 0 && before(d, x, y, cdt[o0 + j], cfx[o0 + j], cfy[o0 + j])) {
-      cdt[o0 + j + 1] = cdt[o0 + j], cfx[o0 + j + 1] = cfx[o0 + j], cfy[o0 + j + 1] = cfy[o0 + j];
-      --j;
-    }
-    cdt[o0 + j + 1] = d, cfx[o0 + j + 1] = x, cfy[o0 + j + 1] = y;
   }
 }
 
@@ -658,11 +660,9 @@ int ebos_plan_compact_frac_f32(const float* xs, const float* ys, const float* dt
   }
   hipStream_t s = as_stream(stream);
   compact_offsets_kernel<<<dim3(1), dim3(256), 0, s>>>(key_offsets, tile_h * tile_w, n_tiles, grp_offsets);
-  compact_fill_kernel<<<dim3(n_tiles), dim3(256), 0, s>>>(xs, ys, dts, key_offsets, tile_h, tile_w, tiles_x, grp_offsets, cpix,
-                                                          cdt, cfx, cfy);
-  const int64_t n_keys = (int64_t)n_tiles * tile_h * tile_w;
-  compact_frac_canon_kernel<<<dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, s>>>(key_offsets, tile_h * tile_w, n_keys, grp_offsets, cdt,
-                                                                                      cfx, cfy);
+  // (the rank loop makes an event several loads: four workgroups per tile)
+  compact_fill_kernel<<<dim3(n_tiles, 4), dim3(256), 0, s>>>(xs, ys, dts, key_offsets, tile_h, tile_w, tiles_x, grp_offsets, cpix,
+                                                             cdt, cfx, cfy);
   EBOS_CHECK_LAUNCH("ebos_plan_compact_frac");
   return EBOS_OK;
 }

@@ -327,10 +327,17 @@ class EventPlan:
                                           ptr(xs), ptr(ys), ptr(dts), ptr(ps), ptr(perm), ptr(key_offsets), ptr(counts),
                                           counts.data_ptr() + 4, ptr(scratch), nbytes, stream_ptr()),
                   "ebos_bin_events")
+        # (the work items depend on key_offsets only: enqueued in front of the read-back, which then carries their count as well)
+        part_table = torch.empty(5 * tiles_y * tiles_x + 1, dtype=torch.int32, device=dev)
+        with _hip.on_device(dev):
+            check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), PART_FIXED_EVENTS, ptr(part_table), stream_ptr()),
+                  "ebos_plan_parts")
+        used = fullest = None
         if deferred:
             dropped, fractional = 0, 0
-        else:
-            dropped, fractional = (int(v) for v in counts.tolist())  # one-off sync at plan-build time
+        else:  # the ONE host read-back of the build: (outside the image, fractional sources, work items in use, fullest tile)
+            dropped, fractional, used, fullest = (int(v) for v in torch.cat([counts, part_table[tiles_y * tiles_x:tiles_y * tiles_x + 1],
+                                                                             _fullest_tile(key_offsets, th * tw)]).tolist())
         kept = n - dropped
         src_perm = perm[:kept] if self.perm is None else self.perm[perm[:kept].long()]
         grp_offsets = cpix = cdt = None
@@ -359,18 +366,10 @@ class EventPlan:
                 check(lib.ebos_plan_compact_frac_f32(ptr(xs), ptr(ys), ptr(dts), ptr(key_offsets), kept, H, W, th, tw, ptr(f_grp),
                                                      ptr(f_pix), ptr(f_dt), ptr(f_x), ptr(f_y), cap, stream_ptr()), "ebos_plan_compact_frac")
             frac = (f_grp, f_pix, f_dt, f_x, f_y)
-        part_table = torch.empty(5 * tiles_y * tiles_x + 1, dtype=torch.int32, device=dev)
-        with _hip.on_device(dev):
-            check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), PART_FIXED_EVENTS, ptr(part_table), stream_ptr()),
-                  "ebos_plan_parts")
         out = EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt, part_table, self.dt_bound)
         out.__dict__["_frac"] = frac  # (grp_offsets, cpix, cdt, cfx, cfy) of a window with fractional source coordinates, or None
         out.__dict__["_counts"], out.__dict__["_deferred"] = counts, bool(deferred)
-        used = fullest = None
-        if not deferred:
-            used, fullest = (int(v) for v in torch.cat([part_table[tiles_y * tiles_x:tiles_y * tiles_x + 1],
-                                                        _fullest_tile(key_offsets, th * tw)]).tolist())
         out.__dict__["_parts_used"], out.__dict__["_fullest_tile"] = used, fullest
         return out
 

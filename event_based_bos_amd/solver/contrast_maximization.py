@@ -149,7 +149,12 @@ class ContrastMaximizationMixin(object):
         ev = to_gpu(events)
         # (the objective uses unit weights: the lean build -- compact events + offsets only -- is all it reads; windows with
         # fractional, i.e. undistorted, coordinates fall back to the full build inside)
-        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile=self.plan_tile(), emit="compact")
+        # (a stream of undistorted events -- data.warp: true -- is fractional window after window: once a window fell back, the lean
+        # attempt -- its kernels and its read-back, ~0.3 ms of a 100 k-event window's build -- is skipped until a full build finds
+        # integer coordinates again; either build is valid for either kind of window)
+        plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile=self.plan_tile(),
+                               emit="full" if getattr(self, "_fractional_stream", False) else "compact")
+        self._fractional_stream = plan.frac_compact is not None
         self.history = []
         # The optimisation loops below call loss.backward() thousands of times on graphs of one or two nodes: with the autograd
         # engine's device thread each call pays two thread hand-offs (~35 us of a ~100 us iteration, tools/bench_autograd.py);

@@ -934,7 +934,7 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
 @pytest.mark.parametrize("resident", [True, False])
 def test_two_builds_of_a_fractional_window_solve_identically(resident):
     """The binning scatter orders the events of one source pixel as its atomics arrive; the fractional compact layout is put into a
-    canonical order afterwards (by dt, fx, fy: compact_frac_canon_kernel), so two plans of one window hold the same slots and two
+    canonical order (an event takes the slot of its rank by dt, fx, fy: compact_fill_kernel), so two plans of one window hold the same slots and two
     solves walk the same trajectory bit for bit -- the run sums of the backward sweep see the slot order in their last bits, and
     Adam amplified those into 0.1 px after a few hundred iterations."""
     import event_based_bos_amd as ebos
