@@ -114,6 +114,50 @@ __device__ __forceinline__ float blur3_adj_at(U&& u, int r, int c, int h, int w,
   return z;
 }
 
+// The same two values from an accessor that may be asked for the WHOLE 3 x 3 neighbourhood (an LDS window with an apron: positions
+// outside the image hold something finite or not -- they are read and discarded): all nine loads are in flight before the first
+// product, where the forms above branch around every load they do not need.  Term for term the forms above: same bits.
+template <typename X>
+__device__ __forceinline__ float blur3_fwd_at_dense(X&& x, int r, int c, int h, int w, const Blur3& b) {
+#pragma clang fp contract(off)
+  float v[3][3];
+#pragma unroll
+  for (int dc = -1; dc <= 1; ++dc)
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) v[dc + 1][dr + 1] = x(r + dr, c + dc);
+  const float cr[3] = {blur3_coef(r, r - 1, h, b), blur3_coef(r, r, h, b), blur3_coef(r, r + 1, h, b)};
+  float y = 0.0f;
+#pragma unroll
+  for (int dc = -1; dc <= 1; ++dc) {
+    const float cc = blur3_coef(c, c + dc, w, b);
+    float t = 0.0f;
+#pragma unroll
+    for (int dr = 0; dr < 3; ++dr) t += cr[dr] != 0.0f && cc != 0.0f ? cr[dr] * v[dc + 1][dr] : 0.0f;
+    y += cc * t;
+  }
+  return y;
+}
+template <typename U>
+__device__ __forceinline__ float blur3_adj_at_dense(U&& u, int r, int c, int h, int w, const Blur3& b) {
+#pragma clang fp contract(off)
+  float v[3][3];
+#pragma unroll
+  for (int dc = -1; dc <= 1; ++dc)
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) v[dc + 1][dr + 1] = u(r + dr, c + dc);
+  const float cr[3] = {blur3_coef(r - 1, r, h, b), blur3_coef(r, r, h, b), blur3_coef(r + 1, r, h, b)};
+  float z = 0.0f;
+#pragma unroll
+  for (int dc = -1; dc <= 1; ++dc) {
+    const float cc = blur3_coef(c + dc, c, w, b);
+    float t = 0.0f;
+#pragma unroll
+    for (int dr = 0; dr < 3; ++dr) t += cr[dr] != 0.0f && cc != 0.0f ? cr[dr] * v[dc + 1][dr] : 0.0f;
+    z += cc * t;
+  }
+  return z;
+}
+
 // (B^T m) along one axis: the sum of the coefficients with which x(j) enters the valid outputs lo <= i < L - lo
 __device__ __forceinline__ float blur3_axis_weight(int j, int L, int lo, const Blur3& b) {
 #pragma clang fp contract(off)

@@ -823,6 +823,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           const float inv_q = 1.0f / (float)(bq - 2);
           const float4* A4 = reinterpret_cast<const float4*>(s_g);
           auto x_at = [&](int r, int c) { return s_g[(r - xoy) * xw + (c - xox)]; };
+          if (!(EBOS_ABL & 16384))
           for (int i = threadIdx.x; i < bh * (bq - 2); i += kBlock) {   // (the window's outermost quads: one column each, below)
             const int rl = (int)(((float)i + 0.5f) * inv_q), cq = i - rl * (bq - 2) + 1;
             const float4* m = A4 + (rl + 1) * bq + cq;
@@ -844,11 +845,11 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             const int rl = i >> 1, cl = (i & 1) ? bw - 4 : 3;
             s_b[rl * bw + cl] = blur3_interior(x_at, boy + rl, box + cl, bk);
           }
-          if (!inner) {  // (uniform) the pixels beside the image's border, and those outside the valid region
+          if (!inner && !(EBOS_ABL & 65536)) {  // (uniform) the pixels beside the image's border, and those outside the valid region
             __syncthreads();
             for_border(boy, bh, box + 3, bw - 6, vlo, [&](int r, int c) {
               const bool valid = r >= lo_px && r < H - lo_px && c >= lo_px && c < W - lo_px;
-              const float y = valid ? blur3_fwd_at(x_at, r, c, H, W, bk) : 0.0f;
+              const float y = valid ? blur3_fwd_at_dense(x_at, r, c, H, W, bk) : 0.0f;  // (the raw window reaches >= 1 pixel further)
               s_b[(r - boy) * bw + (c - box)] = y;
               if (r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) sq += (double)y * (double)y;
             });
@@ -864,6 +865,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           const float cw_in = Gc * (wi * wi);
           const float inv_q = 1.0f / (float)gq;
           const float4* B4 = reinterpret_cast<const float4*>(s_b);
+          if (!(EBOS_ABL & 32768))
           for (int i = threadIdx.x; i < wb.LH() * gq; i += kBlock) {
             const int rl = (int)(((float)i + 0.5f) * inv_q), cq = i - rl * gq;
             const float4* m = B4 + (rl + 1) * bq + cq + 1;
@@ -886,7 +888,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
                 }
             }
           }
-          if (!inner) {  // (uniform) beside the border: folded coefficients, position-dependent weights; outside the image: 0
+          if (!inner && !(EBOS_ABL & 65536)) {  // (uniform) beside the border: folded coefficients, position-dependent weights; outside the image: 0
             GradImage Gm;  // (only map() is used: the staged value of a pixel from z and its position)
             Gm.g = nullptr, Gm.a = Ga, Gm.c = Gc, Gm.h = H, Gm.w = W, Gm.lo = lo_px;
             Gm.set_blur(bk);
@@ -894,7 +896,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             __syncthreads();
             for_border(goy, wb.LH(), gox, gw, ilo, [&](int r, int c) {
               const bool live = r >= 0 && r < H && c >= 0 && c < W;
-              const float gv = live ? Gm.map(blur3_adj_at(u_at, r, c, H, W, bk), r, c) : 0.0f;
+              const float gv = live ? Gm.map(blur3_adj_at_dense(u_at, r, c, H, W, bk), r, c) : 0.0f;  // (s_b: one row / four columns further)
               s_g[(r - goy) * gw + (c - gox)] = gv;
               gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
               gsum_t += fabsf(gv);
