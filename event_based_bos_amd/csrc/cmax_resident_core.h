@@ -1000,13 +1000,14 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             }
           }
           if (!inner) {  // (uniform) the image's outermost ring: folded taps; outside the image: 0
-            auto gxy = [&](int qr, int qc, float& vx, float& vy) {
-              vx = s_gx[(qr - boy) * bw + (qc - box)], vy = s_gy[(qr - boy) * bw + (qc - box)];
+            auto gxy = [&](int qr, int qc, float& vx, float& vy) {  // (any position: the address is clamped into the pairs' window)
+              const int o = min(max(qr - boy, 0), bh - 1) * bw + min(max(qc - box, 0), bw - 1);
+              vx = s_gx[o], vy = s_gy[o];
             };
             __syncthreads();
             for_border(goy, wb.LH(), gox, gw, 1, [&](int r, int c) {
               const bool live = r >= 0 && r < H && c >= 0 && c < W;
-              const float gv = live ? scale * sobel3_adjoint_ring(gxy, r, c, H, W, lo_px, H - lo_px, lo_px, W - lo_px) : 0.0f;
+              const float gv = live ? scale * sobel3_adjoint_ring_dense(gxy, r, c, H, W, lo_px, H - lo_px, lo_px, W - lo_px) : 0.0f;
               s_g[(r - goy) * gw + (c - gox)] = gv;
               gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);
               gsum_t += fabsf(gv);

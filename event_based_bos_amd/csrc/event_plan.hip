@@ -408,6 +408,9 @@ plan_parts_kernel(const int32_t* __restrict__ key_offsets, int n_tiles, int tile
   // no tau can beat one part per tile by 20 % when even the average CU load does not (the common, even window):
   // skip the two searches (~35 workgroup-wide reductions)
   if ((long long)(lmax + fixed_events) * 80 * n_cu <= (total + (long long)n_tiles * fixed_events) * 100) lo = hi;
+  // ... nor where the fixed work dominates even the fullest tile (a small window on few tiles: (lmax - tau) / (lmax + F) < 20 % for
+  // every tau once lmax < F / 4) -- the searches took 26 us of a 100 k-event window's build
+  if ((long long)lmax * 4 < fixed_events) lo = hi;
   while (lo < hi) {  // smallest tau whose parts fit the budget
     const int mid = lo + (hi - lo) / 2;
     if (items_at(mid) <= n_items) hi = mid;

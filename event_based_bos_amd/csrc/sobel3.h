@@ -89,6 +89,32 @@ __device__ __forceinline__ float sobel3_adjoint_ring(GXY&& gxy, int pr, int pc, 
   return acc;
 }
 
+// The same value from an accessor that may be asked for ANY stencil position (an LDS window: it clamps the address itself) -- all
+// nine pairs of a plain form are requested before the first product, where the form above branches around each pair it does not
+// need.  A pair outside the valid region counts zero, as above: same bits.
+template <typename GXY>
+__device__ __forceinline__ float sobel3_adjoint_ring_dense(GXY&& gxy, int pr, int pc, int h, int w, int r0, int r1, int c0, int c1) {
+#pragma clang fp contract(off)
+  auto plain = [&](int r, int c) {
+    float vx[9], vy[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gxy(r - (k / 3 - 1), c - (k % 3 - 1), vx[k], vy[k]);
+    float f = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int dr = k / 3 - 1, dc = k % 3 - 1, qr = r - dr, qc = c - dc;
+      const bool ok = qr >= r0 && qr < r1 && qc >= c0 && qc < c1;
+      const float ux = ok ? vx[k] : 0.0f, uy = ok ? vy[k] : 0.0f;
+      f += ux * ((float)dr * (dc == 0 ? 2.0f : 1.0f)) + uy * ((float)dc * (dr == 0 ? 2.0f : 1.0f));
+    }
+    return f;
+  };
+  float acc = 0.0f;
+  for (int a2 = (pr == 0 ? -1 : 0); a2 <= (pr == h - 1 ? 1 : 0); ++a2)
+    for (int b2 = (pc == 0 ? -1 : 0); b2 <= (pc == w - 1 ? 1 : 0); ++b2) acc += plain(pr + a2, pc + b2);
+  return acc;
+}
+
 // one stencil's term of the contrast's value
 __device__ __forceinline__ float sobel3_energy(float gx, float gy) {
 #pragma clang fp contract(off)

@@ -25,6 +25,8 @@ ap.add_argument("--image-gradient", type=float, default=0.0)
 ap.add_argument("--halo", type=lambda v: v if v == "auto" else int(v), default=32, help="a built halo, or auto (run-time windows per tile)")
 ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile (default: choose_tile for the halo)")
 ap.add_argument("--mode", choices=["auto", "resident", "pipeline"], default="auto", help="one resident launch / four launches per iteration")
+ap.add_argument("--gm", type=float, default=0.0, help="weight of the gradient_magnitude contrast (replaces the variance: its weight becomes 0)")
+ap.add_argument("--blur", type=float, default=0.0, help="iwe.blur_sigma")
 ap.add_argument("--size", type=int, nargs=2, default=None, help="image size (default 720 1280)")
 ap.add_argument("--flow-max", type=float, default=0.0, help="initial patch flows U(-m, m) (0: zeros)")
 ap.add_argument("--lr", type=float, default=0.1, help="Adam's learning rate (0: the flow stays where it starts -- timing builds)")
@@ -47,8 +49,8 @@ plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, 
 gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
 theta0 = torch.zeros((2, gh, gw)) if a.flow_max == 0 else (torch.rand((2, gh, gw), generator=torch.Generator().manual_seed(1)) * 2 - 1) * a.flow_max
 res = {"auto": None, "resident": True, "pipeline": False}[a.mode]
-loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 1.0, a.flow_norm, a.image_gradient, halo=a.halo, lr=a.lr, capacity=a.iters + 3,
-                      sample_grid=False if a.dense else None)
+loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 0.0 if a.gm else 1.0, a.flow_norm, a.image_gradient, halo=a.halo, lr=a.lr, capacity=a.iters + 3,
+                      sample_grid=False if a.dense else None, w_gradient_magnitude=a.gm, blur_sigma=a.blur)
 loop.run(3, resident=res)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
