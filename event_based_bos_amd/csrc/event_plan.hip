@@ -322,7 +322,7 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
         // differ in it.  For integer source pixels that order is invisible (and the lean build's is canonical); with fractions per
         // slot the kernels' run sums see it in their last bits, and an optimiser loop amplifies those -- two solves of one window
         // drifted apart.  So an event takes the slot of its RANK in its pixel's run by (dt, fx, fy) (equal events: equal slots
-        // whatever their order); a run beyond kCanonMax events -- a hot pixel -- keeps its order of arrival.
+        // whatever their order); a run beyond kCanonMax events -- a hot pixel -- is sorted by compact_canon_hot_kernel afterwards.
         const int64_t key = (int64_t)t * tile_px + r * tile_w + c;
         const int32_t kb = key_offsets[key], ke = key_offsets[key + 1];
         int64_t slot = o;
@@ -358,6 +358,67 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
       cdt[o] = __builtin_nanf("");
       if (cfx != nullptr) cfx[o] = 0.0f, cfy[o] = 0.0f;
     }
+  }
+}
+
+// ... and the runs beyond kCanonMax (hot pixels: one sensor pixel firing hundreds of times in a window) are sorted in place by the same
+// key, one workgroup per tile, a bitonic network in LDS per hot run of up to kCanonHot events (longer ones keep their order of
+// arrival).  Equal keys are equal slots, so the network's instability is invisible.  A tile without a hot run -- nearly every tile
+// -- leaves after one pass over its key offsets.
+constexpr int kCanonHot = 4096;
+__global__ void __launch_bounds__(1024)
+compact_canon_hot_kernel(const int32_t* __restrict__ key_offsets, int tile_px, const int32_t* __restrict__ grp_offsets,
+                         float* __restrict__ cdt, float* __restrict__ cfx, float* __restrict__ cfy) {
+  __shared__ float s_dt[kCanonHot], s_fx[kCanonHot], s_fy[kCanonHot];
+  constexpr int kList = 64;
+  __shared__ int s_list[kList];
+  __shared__ int s_n;
+  const int t = blockIdx.x;
+  const int32_t* __restrict__ ko = key_offsets + (int64_t)t * tile_px;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < tile_px; k += blockDim.x) {
+    const int len = ko[k + 1] - ko[k];
+    if (len > kCanonMax && len <= kCanonHot) {
+      const int i = atomicAdd(&s_n, 1);
+      if (i < kList) s_list[i] = k;   // (the list's order is the atomics': the runs are independent of each other)
+    }
+  }
+  __syncthreads();
+  const int n_hot = min(s_n, kList);
+  const int64_t out0 = (int64_t)grp_offsets[t] * 4;
+  const int32_t beg = ko[0];
+  for (int h = 0; h < n_hot; ++h) {
+    const int k = s_list[h];
+    const int32_t kb = ko[k];
+    const int len = ko[k + 1] - kb;
+    const int64_t o0 = out0 + (kb - beg);
+    int n2 = 1;
+    while (n2 < len) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {   // (padding sorts behind every event)
+      s_dt[i] = i < len ? cdt[o0 + i] : __builtin_inff();
+      s_fx[i] = i < len ? cfx[o0 + i] : 0.0f;
+      s_fy[i] = i < len ? cfy[o0 + i] : 0.0f;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = threadIdx.x; i < n2 / 2; i += blockDim.x) {
+          const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+          const bool ascending = (lo & size) == 0;
+          const float da = s_dt[lo], xa = s_fx[lo], ya = s_fy[lo], db = s_dt[hi], xb = s_fx[hi], yb = s_fy[hi];
+          const bool a_after_b = da > db || (da == db && (xa > xb || (xa == xb && ya > yb)));
+          const bool b_after_a = db > da || (da == db && (xb > xa || (xa == xb && yb > ya)));
+          if (ascending ? a_after_b : b_after_a) {
+            s_dt[lo] = db, s_fx[lo] = xb, s_fy[lo] = yb;
+            s_dt[hi] = da, s_fx[hi] = xa, s_fy[hi] = ya;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = threadIdx.x; i < len; i += blockDim.x) cdt[o0 + i] = s_dt[i], cfx[o0 + i] = s_fx[i], cfy[o0 + i] = s_fy[i];
+    __syncthreads();
   }
 }
 
@@ -666,6 +727,7 @@ int ebos_plan_compact_frac_f32(const float* xs, const float* ys, const float* dt
   // (the rank loop makes an event several loads: four workgroups per tile)
   compact_fill_kernel<<<dim3(n_tiles, 4), dim3(256), 0, s>>>(xs, ys, dts, key_offsets, tile_h, tile_w, tiles_x, grp_offsets, cpix,
                                                              cdt, cfx, cfy);
+  compact_canon_hot_kernel<<<dim3(n_tiles), dim3(1024), 0, s>>>(key_offsets, tile_h * tile_w, grp_offsets, cdt, cfx, cfy);
   EBOS_CHECK_LAUNCH("ebos_plan_compact_frac");
   return EBOS_OK;
 }

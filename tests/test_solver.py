@@ -934,7 +934,7 @@ def test_resident_patch_loop_on_fractional_source_coordinates(size, n_ev, patch,
 @pytest.mark.parametrize("resident", [True, False])
 def test_two_builds_of_a_fractional_window_solve_identically(resident):
     """The binning scatter orders the events of one source pixel as its atomics arrive; the fractional compact layout is put into a
-    canonical order (an event takes the slot of its rank by dt, fx, fy: compact_fill_kernel), so two plans of one window hold the same slots and two
+    canonical order (an event takes the slot of its rank by dt, fx, fy: compact_fill_kernel; hot pixels: compact_canon_hot_kernel), so two plans of one window hold the same slots and two
     solves walk the same trajectory bit for bit -- the run sums of the backward sweep see the slot order in their last bits, and
     Adam amplified those into 0.1 px after a few hundred iterations."""
     import event_based_bos_amd as ebos
@@ -944,8 +944,11 @@ def test_two_builds_of_a_fractional_window_solve_identically(resident):
     rs = np.random.RandomState(23)
     ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
     ev[:, :2] = np.clip(ev[:, :2] + rs.uniform(0, 1, (n_ev, 2)), 0, [h - 1, w - 1])
-    ev[: n_ev // 50, :2] = ev[0, :2]            # a hot pixel beyond the canonical-order bound keeps its order of arrival ...
-    ev[: n_ev // 50, 2] = ev[0, 2]              # ... which is invisible when its events are identical
+    hot = n_ev // 40                            # a hot sensor pixel: 2 500 events, random times, a few fraction pairs (the LDS sort of
+    ev[:hot, 0] = 100 + rs.choice([0.25, 0.75], hot)      # compact_canon_hot_kernel; short runs are ranked by the fill itself)
+    ev[:hot, 1] = 200 + rs.choice([0.125, 0.5], hot)
+    ev[:hot, 2] = rs.uniform(0, 0.5, hot)
+    ev = ev[np.argsort(ev[:, 2], kind="stable")]
     gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
     theta0 = torch.from_numpy(rs.uniform(-2, 2, (2, gh, gw))).float()
     runs = []
@@ -958,6 +961,17 @@ def test_two_builds_of_a_fractional_window_solve_identically(resident):
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             np.testing.assert_array_equal(a, b)
+    # the hot pixel's slots are in the canonical order: ascending (dt, fx, fy)
+    th, tw = plan.tile
+    f_grp, f_pix, f_dt, f_x, f_y = (a.cpu().numpy() for a in plan.frac_compact)
+    t = (100 // th) * (-(-w // tw)) + 200 // tw
+    sl = slice(4 * f_grp[t], 4 * f_grp[t + 1])
+    sel = (f_pix[sl].astype(np.int64) & 0xffff) == (((100 % th) << 8) | (200 % tw))
+    sel &= np.isfinite(f_dt[sl])
+    d, x, y = f_dt[sl][sel], f_x[sl][sel], f_y[sl][sel]
+    assert len(d) >= hot
+    order = np.lexsort((y, x, d))
+    np.testing.assert_array_equal(np.stack([d, x, y]), np.stack([d[order], x[order], y[order]]))
 
 
 @pytest.mark.gpu
