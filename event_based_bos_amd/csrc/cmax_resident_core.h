@@ -790,17 +790,27 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       }
       // pixels of the rectangle [r0, r0 + nr) x [c0, c0 + nc) OUTSIDE the box [lo_b, H - lo_b) x [lo_b, W - lo_b): top and bottom
       // strips whole, left and right strips between them; f(r, c) once per pixel, dealt to the threads
+      // (ONE loop over both kinds of strip, the row of an item from a reciprocal: the few waves that hold border pixels run a long
+      // chain of instructions while the others wait at the next barrier -- as two loops with integer divisions the chain was twice as long)
       auto for_border = [&](int r0, int nr, int c0, int nc, int lo_b, auto&& f) {
         const int rt = min(max(lo_b - r0, 0), nr), rb = min(max(r0 + nr - (H - lo_b), 0), nr - rt);   // rows above / below the box
         const int cl_ = min(max(lo_b - c0, 0), nc), cr_ = min(max(c0 + nc - (W - lo_b), 0), nc - cl_);  // columns left / right of it
-        for (int i = threadIdx.x; i < (rt + rb) * nc; i += kBlock) {
-          const int k = i / nc, c = c0 + i - k * nc;
-          f(k < rt ? r0 + k : r0 + nr - rb + (k - rt), c);
-        }
-        const int nm = nr - rt - rb, ns = cl_ + cr_;
-        for (int i = threadIdx.x; i < nm * ns; i += kBlock) {
-          const int k = i / ns, q = i - k * ns;
-          f(r0 + rt + k, q < cl_ ? c0 + q : c0 + nc - cr_ + (q - cl_));
+        const int n_tb = (rt + rb) * nc, nm = nr - rt - rb, ns = cl_ + cr_;
+        const float inv_nc = 1.0f / (float)max(nc, 1), inv_ns = 1.0f / (float)max(ns, 1);
+        auto div = [](int i, int n, float inv) {  // i / n for 0 <= i < 2^22
+          int k = (int)(((float)i + 0.5f) * inv);
+          const int rem = i - k * n;
+          k += rem >= n ? 1 : (rem < 0 ? -1 : 0);
+          return k;
+        };
+        for (int i = threadIdx.x; i < n_tb + nm * ns; i += kBlock) {
+          if (i < n_tb) {
+            const int k = div(i, nc, inv_nc), c = c0 + i - k * nc;
+            f(k < rt ? r0 + k : r0 + nr - rb + (k - rt), c);
+          } else {
+            const int j = i - n_tb, k = div(j, ns, inv_ns), q = j - k * ns;
+            f(r0 + rt + k, q < cl_ ? c0 + q : c0 + nc - cr_ + (q - cl_));
+          }
         }
       };
       if constexpr (blur_on) {
@@ -849,7 +859,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             __syncthreads();
             for_border(boy, bh, box + 3, bw - 6, vlo, [&](int r, int c) {
               const bool valid = r >= lo_px && r < H - lo_px && c >= lo_px && c < W - lo_px;
-              const float y = valid ? blur3_fwd_at_dense(x_at, r, c, H, W, bk) : 0.0f;  // (the raw window reaches >= 1 pixel further)
+              const float y = (valid && !(EBOS_ABL & 262144)) ? blur3_fwd_at_dense(x_at, r, c, H, W, bk) : 0.0f;  // (the raw window reaches >= 1 pixel further)
               s_b[(r - boy) * bw + (c - box)] = y;
               if (r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) sq += (double)y * (double)y;
             });
@@ -888,7 +898,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
                 }
             }
           }
-          if (!inner && !(EBOS_ABL & 65536)) {  // (uniform) beside the border: folded coefficients, position-dependent weights; outside the image: 0
+          if (!inner && !(EBOS_ABL & 131072)) {  // (uniform) beside the border: folded coefficients, position-dependent weights; outside the image: 0
             GradImage Gm;  // (only map() is used: the staged value of a pixel from z and its position)
             Gm.g = nullptr, Gm.a = Ga, Gm.c = Gc, Gm.h = H, Gm.w = W, Gm.lo = lo_px;
             Gm.set_blur(bk);
