@@ -23,6 +23,33 @@ PROFILE_SLAB_ACCUMULATE, PROFILE_TILED_BWD, PROFILE_SLAB_COMBINE, PROFILE_GRADMA
 ABI_VERSION = 2
 
 
+
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says otherwise) in creation order, and
+# two streams on one queue run their kernels one after the other: resident solver launches of different windows then take turns instead
+# of running side by side (solver.WindowPipeline: four 346 x 260 windows in flight take 3.5 ms each on queues of their own, 6.3 ms on
+# shared ones).  The variable is read when the runtime initialises: where the process has not said anything and has not touched the GPU
+# yet, ask for 8 queues; ``hw_queues()`` is what the pipeline may count on.
+_HW_QUEUES = 4
+if "GPU_MAX_HW_QUEUES" in os.environ:
+    try:
+        _HW_QUEUES = max(1, int(os.environ["GPU_MAX_HW_QUEUES"]))
+    except ValueError:
+        pass
+else:
+    try:
+        import torch as _torch
+        if not _torch.cuda.is_initialized():
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+            _HW_QUEUES = 8
+    except Exception:  # pragma: no cover
+        pass
+
+
+def hw_queues() -> int:
+    """Hardware queues this process's HIP streams are spread over (GPU_MAX_HW_QUEUES as the runtime saw or will see it)."""
+    return _HW_QUEUES
+
+
 class HipUnavailableError(RuntimeError):
     """The HIP extension (or a GPU to run it on) is missing.  Nothing falls back to the CPU."""
 

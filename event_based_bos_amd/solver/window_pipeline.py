@@ -58,6 +58,9 @@ def _pooled_streams(device: torch.device, n: int):
     return pool["ingest"], pool["solve"][:n]
 
 
+RESIDENT_TILES = ((32, 32), (32, 64), (45, 80))   # the tiles with resident kernels (cmax_resident_<tile>.hip; halo 32 / run-time windows)
+
+
 class WindowPipeline(object):
     def __init__(self, solver: ContrastMaximization, n_concurrent: int = 3, device="cuda", resident: Optional[bool] = None):
         if solver.motion_model != "dense-flow":
@@ -79,17 +82,36 @@ class WindowPipeline(object):
             # Resident launches run side by side only while all their workgroups fit the device at once (cmax_resident.hip): a small
             # sensor's window (99 tiles at 346 x 260) leaves room for a second one, and a group of three would run 2 + 1 -- the group
             # size is rounded up to a multiple of the windows that fit
+            self.tile = tuple(solver.plan_tile())
             if self.resident:
-                th, tw = solver.plan_tile()
                 H, W = solver.orig_image_shape
-                fit = max(1, int(torch.cuda.get_device_properties(self.device).multi_processor_count) // (-(-H // th) * -(-W // tw)))
+                n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+                wgs = lambda t: -(-H // t[0]) * -(-W // t[1])   # noqa: E731  (one workgroup per source tile, one workgroup per CU)
+                # An iteration of a resident loop on a small sensor is latency (two grid-wide exchanges), not work: fewer, larger
+                # tiles per window cost a window alone a little and let more windows run side by side.  Unless the solver names its
+                # tile, the pipeline takes the resident tile with the most workgroups for which the requested windows all fit
+                # (346 x 260: two windows -> 32 x 32, 99 workgroups each; four -> 32 x 64, 54; eight -> 45 x 80, 30).
+                if solver.tile is None and solver.halo in ("auto", 32):
+                    slides = [sl for _, sl, _ in solver.pyramid_scales()]
+                    usable = [t for t in RESIDENT_TILES   # (every scale's sliding window on the grid-sampling route with this tile)
+                              if all(self.lib.ebos_patch_fused_supported(t[0], t[1], 32, int(sl[0]), int(sl[1])) for sl in slides)]
+                    # (each window in flight needs a hardware queue of its own beside the ingest and the default stream's)
+                    want = max(1, min(self.n_concurrent, _hip.hw_queues() - 2))
+                    fits = [t for t in usable if wgs(t) * want <= n_cu]
+                    if fits:
+                        self.tile = max(fits, key=wgs)
+                    elif wgs(self.tile) > n_cu // 2:   # (not even two of the default tile: keep it, one window at a time)
+                        pass
+                    elif usable:
+                        self.tile = min(usable, key=wgs)
+                fit = max(1, n_cu // wgs(self.tile))
                 self.n_concurrent = -(-self.n_concurrent // fit) * fit
             self.ingest_stream, self.streams = _pooled_streams(self.device, self.n_concurrent)
 
     # ------------------------------------------------------------------ stages
     def _ingest(self, store: RawEventStore, window: Tuple[int, int]) -> EventPlan:
         s = self.solver
-        plan = store.plan(window[0], window[1], s.orig_image_shape, s.warp_direction, True, tile=s.plan_tile(), device=self.device,
+        plan = store.plan(window[0], window[1], s.orig_image_shape, s.warp_direction, True, tile=self.tile, device=self.device,
                           deferred=True, emit="compact")  # no host read-back: the host never waits for the GPU until the end;
         # lean build: the fused loop reads only the compact events and offsets (0.09 ms instead of 0.4 per 2 M-event window)
         if not fused_loop.supported(s.contrast_terms, s.flow_terms, s.blur_sigma, s.opt_method, plan, s.halo, s.sliding_window):

@@ -380,6 +380,45 @@ def test_reference_hot_plate1_config_drives_the_solver(size):
 
 
 @pytest.mark.gpu
+def test_window_pipeline_picks_the_tile_for_the_windows_in_flight():
+    """At BASELINE configs[0]'s size an iteration of the resident loop is latency, not work: the pipeline takes the resident tile with
+    the most workgroups for which the requested windows all fit the device (two windows: 32 x 32 tiles, 99 workgroups each; three
+    or four: 32 x 64, 54; eight: 45 x 80, 30 -- given a hardware queue per window, ``_hip.hw_queues()``); a tile named by the solver
+    stays; a sensor whose default tile fills the device keeps it.  The flows are those of per-window ``estimate`` on the default
+    tile (another tile sums the slabs in another order: 1e-3 px)."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd import _hip
+
+    h, w = 260, 346
+    cfg = load_cfg()["solver"]
+    cfg.update(patch={"size": [20, 26], "sliding_window": [20, 26]}, cost_with_weight={"image_variance": 1.0, "flow_norm": 0.01},
+               iwe={"method": "bilinear_vote", "blur_sigma": 0}, optimizer={"method": "Adam", "n_iter": 30, "parameters": {"lr": 0.05}})
+    solver = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    assert tuple(solver.plan_tile()) == (32, 32)
+    expect = {1: (32, 32), 2: (32, 32), 3: (32, 64), 4: (32, 64), 6: (45, 80) if _hip.hw_queues() >= 8 else (32, 64)}
+    if _hip.hw_queues() < 6:  # (shared hardware queues: more than two resident launches would take turns)
+        expect = {k: (32, 32) for k in expect}
+    for k, tile in expect.items():
+        assert ebos.solver.WindowPipeline(solver, n_concurrent=k).tile == tile, (k, tile)
+    assert ebos.solver.WindowPipeline(solver, n_concurrent=4, resident=False).tile == (32, 32)
+    named = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=dict(cfg, tile=[45, 80]))
+    assert ebos.solver.WindowPipeline(named, n_concurrent=3).tile == (45, 80)
+    big = ebos.solver.collections["contrast_maximization"]((720, 1280), (720, 1280), solver_config=cfg)
+    assert ebos.solver.WindowPipeline(big, n_concurrent=3).tile == (45, 80)
+    rs = np.random.RandomState(5)
+    n, k_win = 20_000, 4
+    store = ebos.data_loader.RawEventStore({"x": rs.randint(0, w, n * k_win).astype(np.int16), "y": rs.randint(0, h, n * k_win).astype(np.int16),
+                                            "t": np.sort(rs.randint(0, 8000 * k_win, n * k_win)).astype(np.int32) + 1_000_000,
+                                            "p": rs.randint(0, 2, n * k_win).astype(bool)})
+    windows = [(i * n, (i + 1) * n) for i in range(k_win)]
+    pipe = ebos.solver.WindowPipeline(solver, n_concurrent=3)
+    flows = pipe.run(store, windows)
+    assert pipe.resident_fallbacks == []
+    for wnd, f in zip(windows, flows):
+        np.testing.assert_allclose(f, solver.estimate(store.load_event(*wnd)), atol=2e-3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_concurrent,pyramid", [(1, False), (2, False), (3, True)])
 def test_window_pipeline_matches_per_window_estimates(n_concurrent, pyramid):
     """WindowPipeline (raw-column ingest on its own stream, n_concurrent windows solved at once on separate streams by
