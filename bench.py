@@ -761,7 +761,7 @@ def run_config2(R):
                                          "last_loss": float(losses[-1])}
                             del sl
                         leg[tag][name] = ent
-                # ... and undistorted events (data.warp: true, configs/hot_plate1.yaml:7: fractional source coordinates): the patch loop's
+                # ... and events with fractional source coordinates (sub-pixel rectified or pre-warped): the patch loop's
                 # launches run the dense route on the (x, y, dt) arrays, the resident launch the compact layout with the fractions
                 for tag, (hh, ww), n_f, patch in (("2M_events", (H, W), 2_000_000, (24, 32)), ("100k_events_346x260", small, 100_000, (20, 20))):
                     rs_f = np.random.RandomState(13)

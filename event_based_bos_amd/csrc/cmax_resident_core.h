@@ -263,8 +263,8 @@ struct Persist {  // one workgroup's iteration-invariant geometry
 // UNI: the 2-DoF motion model (theta = (trans_x, trans_y), x' = x + dt theta, src/warp.py:364-383) instead of the patch grid: no
 // interpolation tables, no cell block; the tiles' partial pairs of d loss / d theta travel as one record per tile, every workgroup
 // sums ALL of them (in the order of the four-launch loop's last kernel) and steps the two parameters itself.
-// FRAC: the compact plan carries fractional source coordinates (undistorted events: data.warp: true in the reference's
-// configs/hot_plate1.yaml:7): the event loops are the general ones of the compact format, whose groups hold the fractions; the
+// FRAC: the compact plan carries fractional source coordinates (events rectified with a sub-pixel map or already warped by an earlier stage):
+// the event loops are the general ones of the compact format, whose groups hold the fractions; the
 // patch-grid kernel then sweeps backward into f64 accumulators (the fixed-point sweep's groups hold integer pixels).
 // CONTRAST: which contrast the loop maximises -- a template parameter, not an argument: as run-time branches the blur's and the Sobel
 // passes' code cost the plain variance loop 1.3 us per iteration (register pressure in the event loop and the gather: 28.0 -> 29.3 us

@@ -79,7 +79,7 @@ struct EvPtrs {
   const int32_t* part_off;
   const int32_t* item_tile;
   const int32_t* item_part;
-  // compact plan with FRACTIONAL source coordinates (undistorted events: data.warp in the reference's configs): the fractions
+  // compact plan with FRACTIONAL source coordinates (sub-pixel rectified or pre-warped events): the fractions
   // x - floor(x), y - floor(y) per slot, laid out like cdt; nullptr = integer source pixels.  Read by the general loops of the
   // compact format (FRAC kernels: the resident 2-DoF loop) -- the lean hot loops assume integer pixels.
   const float* cfx;

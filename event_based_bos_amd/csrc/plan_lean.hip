@@ -346,11 +346,105 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
     }
   }
   __syncthreads();
-  if (staged) {
-    for (int i = threadIdx.x; i < len; i += kLeanBlock) {
-      cpix[out0 + i] = s_px[i];
-      cdt[out0 + i] = s_dt[i];
+  // The cursors hand out a pixel's slots in the order the atomics arrive: two builds of one window differ in it, and a kernel that
+  // sums a group's events in slot order before it accumulates exactly (the 2-DoF backward sweep) sees that in the last bit of its
+  // gradient -- which an optimiser amplifies: two solves of one window drifted apart after a few dozen iterations.  So every pixel's
+  // run leaves in ascending dt (equal dt: equal slots whatever their order): an event takes the slot of its RANK in its run, counted
+  // over the run in LDS (O(run) reads per event); a hot pixel (a run beyond kLeanCanon) is first sorted in place by the whole
+  // workgroup, a bitonic network.  A staged bin is ranked where it stands; an overfull one comes back from memory in chunks of whole
+  // pixels (a run that does not fit the staging area on its own keeps its order of arrival).
+  constexpr int kLeanCanon = 1024, kHotList = 32;
+  __shared__ int32_t s_hot[kHotList];
+  __shared__ int32_t s_nhot;
+  auto run_end = [&](int pi) { return pi + 1 < n_pix ? s_cnt[pi + 1] : len; };
+  int p_lo = 0;
+  while (p_lo < n_pix) {   // (uniform) chunks of whole pixels [p_lo, p_hi): events [c0, c1) of the segment; a staged bin is ONE chunk
+    const int c0 = s_cnt[p_lo];
+    int p_hi = n_pix;
+    if (!staged) {   // the pixels whose runs end within sort_cap events of c0 (binary search on the exclusive offsets)
+      int lo = p_lo, hi = n_pix;
+      while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (run_end(mid) - c0 <= sort_cap) lo = mid + 1;
+        else hi = mid;
+      }
+      p_hi = lo;
+      if (p_hi == p_lo) {   // one run larger than the staging area: left as it arrived
+        p_lo += 1;
+        continue;
+      }
     }
+    const int c1 = p_hi < n_pix ? s_cnt[p_hi] : len, m = c1 - c0;
+    if (threadIdx.x == 0) s_nhot = 0;
+    if (!staged) {
+      __threadfence();
+      __syncthreads();
+      // (written by this workgroup a moment ago: not from this CU's L1; eight loads per thread in flight -- one at a time the ~20
+      // round trips of a chunk were most of an overfull bin's time)
+      constexpr int kU = 8;
+      for (int i0 = threadIdx.x; i0 < m; i0 += kU * kLeanBlock) {
+        unsigned v[kU];
+        uint16_t q[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int i = min(i0 + u * kLeanBlock, m - 1);
+          v[u] = __hip_atomic_load(reinterpret_cast<unsigned*>(cdt + out0 + c0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q[u] = __hip_atomic_load(cpix + out0 + c0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+          if (i0 + u * kLeanBlock < m) s_dt[i0 + u * kLeanBlock] = __int_as_float((int)v[u]), s_px[i0 + u * kLeanBlock] = q[u];
+      }
+    }
+    __syncthreads();
+    for (int pi = p_lo + threadIdx.x; pi < p_hi; pi += kLeanBlock)
+      if (run_end(pi) - s_cnt[pi] > kLeanCanon) {
+        const int k = atomicAdd(&s_nhot, 1);
+        if (k < kHotList) s_hot[k] = pi;
+      }
+    __syncthreads();
+    const int n_hot = min(s_nhot, kHotList);
+    for (int h = 0; h < n_hot; ++h) {   // (uniform) a hot pixel: bitonic network with every comparator ascending -- the first stage of
+      const int pi = s_hot[h];          // a merge pairs i with its mirror image in the block, the others i with i + stride --, so the
+      const int rb = s_cnt[pi] - c0, L = run_end(pi) - c0 - rb;   // virtual +inf beyond the run's end never moves: any length, in place
+      float* v = s_dt + rb;
+      int n2 = 1;
+      while (n2 < L) n2 <<= 1;
+      for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+          for (int t = threadIdx.x; t < n2 / 2; t += kLeanBlock) {
+            const int blk = t / stride, off = t - blk * stride, lo = blk * 2 * stride + off;
+            const int hi = stride == (size >> 1) ? blk * 2 * stride + (2 * stride - 1 - off) : lo + stride;
+            if (hi < L) {
+              const float x = v[lo], y = v[hi];
+              if (x > y) v[lo] = y, v[hi] = x;
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    // every event to the slot of its rank in its pixel's run (the hot runs stand sorted already, as do those of a list that overflowed
+    // -- as they arrived)
+    for (int i = threadIdx.x; i < m; i += kLeanBlock) {
+      const unsigned px = (unsigned)s_px[i];
+      const int pi = ((int)(px >> 8) - r0) * g.tw + (int)(px & 255u);
+      const int rb = s_cnt[pi] - c0, re = run_end(pi) - c0;
+      const float d = s_dt[i];
+      int slot = i;
+      if (re - rb > 1 && re - rb <= kLeanCanon) {
+        int rank = 0;
+        for (int j = rb; j < re; ++j) {
+          const float dj = s_dt[j];
+          rank += (dj < d || (dj == d && j < i)) ? 1 : 0;
+        }
+        slot = rb + rank;
+      }
+      if (staged) cpix[out0 + i] = (uint16_t)px;   // (a run's slots all carry its pixel)
+      cdt[out0 + c0 + slot] = d;
+    }
+    __syncthreads();
+    p_lo = p_hi;
   }
   if (band == g.sub - 1) {  // padding slots of the tile's last group: dt = NaN (no liveness logic in the hot kernels)
     const int64_t end = (int64_t)grp_offsets[tile + 1] * 4;

@@ -149,7 +149,7 @@ class ContrastMaximizationMixin(object):
         ev = to_gpu(events)
         # (the objective uses unit weights: the lean build -- compact events + offsets only -- is all it reads; windows with
         # fractional, i.e. undistorted, coordinates fall back to the full build inside)
-        # (a stream of undistorted events -- data.warp: true -- is fractional window after window: once a window fell back, the lean
+        # (a stream of sub-pixel rectified events is fractional window after window: once a window fell back, the lean
         # attempt -- its kernels and its read-back, ~0.3 ms of a 100 k-event window's build -- is skipped until a full build finds
         # integer coordinates again; either build is valid for either kind of window)
         plan = EventPlan.build(ev, self.orig_image_shape, self.warp_direction, True, tile=self.plan_tile(),

@@ -267,8 +267,8 @@ int ebos_plan_lean(int source, const void* events, const int16_t* col, const int
 int ebos_plan_compact_f32(const float* xs, const float* ys, const float* dts, const int32_t* key_offsets, int64_t n,
                           int H, int W, int tile_h, int tile_w, int32_t* grp_offsets, uint16_t* cpix, float* cdt,
                           int64_t capacity_slots, ebos_stream_t stream);
-/* The compact plan of a window whose source coordinates are FRACTIONAL (undistorted events: data.warp: true in the reference's
- * configs/hot_plate1.yaml:7; the flow is looked up at the truncated coordinate, src/warp.py:334): cpix / cdt as above from floor(x),
+/* The compact plan of a window whose source coordinates are FRACTIONAL (events rectified with a sub-pixel map or already warped by an earlier stage;
+ * the flow is looked up at the truncated coordinate, src/warp.py:334): cpix / cdt as above from floor(x),
  * floor(y), plus cfx / cfy [capacity_slots] f32 = x - floor(x), y - floor(y) per slot (0 in padding slots).  Same information as
  * the (x, y, dt) arrays it is made from; read by the resident 2-DoF launch (ebos_cmax_2dof_problem::cfx / cfy). */
 int ebos_plan_compact_frac_f32(const float* xs, const float* ys, const float* dts, const int32_t* key_offsets, int64_t n,
@@ -785,7 +785,7 @@ typedef struct ebos_cmax_patch_problem {
    * >= 16 * ebos_blur3_variance_partials(H + 2 pad_h, W + 2 pad_w) bytes; the variance contrast only. */
   float blur_k0, blur_k1;
   float* blur_image;
-  /* the resident launch on a window of FRACTIONAL source coordinates (undistorted events: data.warp in the reference's configs):
+  /* the resident launch on a window of FRACTIONAL source coordinates (sub-pixel rectified or pre-warped events):
    * with cfx / cfy non-NULL, grp_offsets / cpix / cdt / cfx / cfy are the arrays of ebos_plan_compact_frac_f32.  The resident launch
    * reads them, and so does the four-launch loop when grad_partials is given (grid-sampling route on the fractions: general event
    * loops); with grad_partials NULL the launches run the dense route on xs / ys / dts. */
@@ -810,7 +810,7 @@ int ebos_cmax_patch_solve_many_f32(const ebos_cmax_patch_problem* problems, cons
  *   losses:  [losses_cap] f32, entry `step` written per iteration with the loss BEFORE the update (nullable) */
 typedef struct ebos_cmax_2dof_problem {
   const float *xs, *ys, *dts;  /* the plan's (x, y, dt) arrays: needed when the compact trio is NULL (fractional -- undistorted --
-                                  source coordinates, data.warp: true in configs/hot_plate1.yaml:7), else nullable */
+                                  source coordinates), else nullable */
   const int32_t* grp_offsets;
   const uint16_t* cpix;
   const float* cdt;

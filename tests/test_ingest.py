@@ -249,3 +249,52 @@ def test_lean_build_falls_back_for_fractional_sources_and_runs_deferred():
     assert sync.n == n - dropped and lazy.n == n and lazy.lean and lazy.counts() == (dropped, 0)
     a_img, b_img = lazy.iwe_dense(flow, halo=16), sync.iwe_dense(flow, halo=16)
     assert float((a_img - b_img).abs().max()) <= 4e-7 * float(b_img.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["uniform", "hot_pixels", "blob"])
+def test_lean_builds_of_one_window_are_identical_and_solve_identically(kind):
+    """The lean build's cursors hand out a pixel's slots in the order their atomics arrive; every pixel's run leaves the bin sort in
+    ascending dt (ranked in LDS; hot pixels by a bitonic network; overfull bins in chunks): two builds of one window hold the same
+    arrays, each run is sorted, the events are those of the full build -- and the 2-DoF Adam loop, whose backward sweep sums a
+    group's events in slot order, walks the same trajectory bit for bit (two solves of one integer window drifted apart after ~35
+    iterations before)."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import Fused2dofLoop
+
+    h, w, n = 720, 1280, 1_000_000
+    rs = np.random.RandomState(3)
+    if kind == "blob":   # 28 events per pixel in the middle: overfull bins, chunked
+        r, c = np.empty(0), np.empty(0)
+        while len(r) < n:
+            rr, cc = np.rint(rs.normal(h / 2, 56, n)), np.rint(rs.normal(w / 2, 100, n))
+            ok = (rr >= 0) & (rr < h) & (cc >= 0) & (cc < w)
+            r, c = np.concatenate([r, rr[ok]]), np.concatenate([c, cc[ok]])
+        r, c = r[:n], c[:n]
+    else:
+        r, c = rs.randint(0, h, n).astype(np.float64), rs.randint(0, w, n).astype(np.float64)
+    if kind == "hot_pixels":
+        r[:3000], c[:3000] = 100, 200          # one sensor pixel firing 3 000 times, another 12 000 times
+        r[3000:15000], c[3000:15000] = 300, 700
+    ev = np.stack([r, c, rs.uniform(0, 0.5, n), rs.randint(0, 2, n)], 1)
+    ev = torch.from_numpy(ev[np.argsort(ev[:, 2], kind="stable")]).cuda()
+    plans = [ebos.EventPlan.build(ev, (h, w), "first", True, tile="auto", emit="compact") for _ in range(3)]
+    assert all(p.lean for p in plans)
+    used = 4 * int(plans[0].grp_offsets[-1])
+    for p in plans[1:]:
+        assert torch.equal(plans[0].cpix[:used], p.cpix[:used]) and torch.equal(plans[0].cdt[:used].view(torch.int32), p.cdt[:used].view(torch.int32))
+    full = ebos.EventPlan.build(ev, (h, w), "first", True, tile="auto", emit="full")
+    th, tw = plans[0].tile
+    ko, grp = plans[0].key_offsets.cpu().numpy(), plans[0].grp_offsets.cpu().numpy().astype(np.int64)
+    cdt, fdt = plans[0].cdt.cpu().numpy(), full.cdt.cpu().numpy()
+    for t in range(len(grp) - 1):
+        offs = ko[t * th * tw:(t + 1) * th * tw + 1] - ko[t * th * tw]
+        seg, fseg = cdt[4 * grp[t]:4 * grp[t] + offs[-1]], fdt[4 * grp[t]:4 * grp[t] + offs[-1]]
+        runs = np.repeat(np.arange(th * tw), np.diff(offs))
+        np.testing.assert_array_equal(seg, fseg[np.lexsort((fseg, runs))])     # the full build's events, every run in ascending dt
+    losses = []
+    for p in plans:
+        loop = Fused2dofLoop(p, torch.zeros(2), 1.0, False, 0, "auto", lr=0.05, capacity=128, blur_sigma=3.0)
+        losses.append(loop.run(100).cpu().numpy().copy())
+    np.testing.assert_array_equal(losses[0], losses[1])
+    np.testing.assert_array_equal(losses[0], losses[2])

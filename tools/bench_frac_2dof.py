@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One iteration of the resident 2-DoF loop on integer-pixel and on fractional (undistorted) source coordinates, with and without the
-3-tap blur, at BASELINE configs[0]'s size and at 1280x720 -- what the reference's configs/hot_plate1.yaml (data.warp: true, blur 3) pays
+3-tap blur, at BASELINE configs[0]'s size and at 1280x720 -- what the loop of the reference's configs/hot_plate1.yaml (2-DoF, blur 3) pays
 for the fractions.
 
     python tools/bench_frac_2dof.py

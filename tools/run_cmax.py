@@ -40,8 +40,13 @@ def synthetic_window(cfg):
     t = rs.uniform(0, 1, (len(pts), per_point))
     x = (pts[:, None, 0] + t * flow[:, None, 0]).reshape(-1)
     y = (pts[:, None, 1] + t * flow[:, None, 1]).reshape(-1)
-    if not d.get("warp", False):  # `data.warp: true` (configs/hot_plate1.yaml:7): the loader undistorts the events, their
-        x, y = np.rint(x), np.rint(y)  # coordinates are then fractional; raw sensor events sit on integer pixels
+    # raw sensor events sit on integer pixels -- what the reference's loaders hand out (src/data_loader/ccs.py:57-66 reads the int16
+    # columns; `data.warp` there warps the FRAMES with a homography, ccs.py:85-86,152-153; src/utils/event_utils.py:242-266 truncates
+    # undistorted coordinates to int32).  --fractional keeps the sub-pixel coordinates (events rectified with a sub-pixel map).
+    # (On integer pixels the variance has a local optimum at zero flow -- an event that sits on a pixel centre is not smeared --: the
+    # 2-DoF Adam loop of the reference's YAML, started at zero, stays there on this synthetic window; the run then times the loop.)
+    if not d.get("fractional_events", False):
+        x, y = np.rint(x), np.rint(y)
     ev = np.stack([x, y, 10.0 + 0.0083 * t.reshape(-1), rs.randint(0, 2, x.size)], 1)
     ev = ev[(ev[:, 0] >= 0) & (ev[:, 0] < h) & (ev[:, 1] >= 0) & (ev[:, 1] < w)]
     return ev[np.argsort(ev[:, 2], kind="stable")], (h, w)
@@ -62,7 +67,8 @@ def main():
     ap.add_argument("--width", type=int, default=None, help="override data.width (and the ROI columns) -- e.g. 346")
     ap.add_argument("--n-events", type=int, default=100_000)
     ap.add_argument("--n-iter", type=int, default=None, help="override solver.optimizer.n_iter")
-    ap.add_argument("--warp", action="store_true", help="data.warp: true -- undistorted events (fractional source coordinates), as configs/hot_plate1.yaml:7")
+    ap.add_argument("--fractional", action="store_true", help="keep the synthetic events' sub-pixel coordinates (events rectified with a sub-pixel map) "
+                                                            "instead of rounding them to the sensor's integer pixels")
     args = ap.parse_args()
     cfg = load_config(args.config_file)
     d, cp = cfg["data"], cfg.setdefault("common_params", {})
@@ -72,8 +78,8 @@ def main():
     for k, v in (("xmin", 0), ("xmax", d["height"]), ("ymin", 0), ("ymax", d["width"])):
         cp.setdefault(k, v)
     d.setdefault("n_events", args.n_events)
-    if args.warp:
-        d["warp"] = True
+    if args.fractional:
+        d["fractional_events"] = True
     ebos.utils.propagate_config(cfg)                                   # src/utils/config_utils.py:42-88
     scfg = cfg["solver"]
     overrides = {}
