@@ -53,6 +53,21 @@ int order_resident_launches(hipStream_t s, int workgroups, int n_cu, bool after_
 
 namespace {
 
+// a resident workgroup owns its CU (LDS): the grid must fit the device at once -- said by the `supported` queries already, so that a
+// caller's fallback is taken before a launch is refused (720 x 640 on 32 x 32 tiles: 460 workgroups)
+bool tiles_fit_device(int n_tiles, const char* what) {
+  int dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    set_error("%s: cannot query the device", what);
+    return false;
+  }
+  if (n_tiles > n_cu) {
+    set_error("%s: %d workgroups cannot be co-resident on %d CUs", what, n_tiles, n_cu);
+    return false;
+  }
+  return true;
+}
+
 // the geometry / objective a resident launch takes; reason in ebos_last_error otherwise
 bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
   const int halo = decode_halo(q->halo).halo;
@@ -92,6 +107,7 @@ bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
     set_error("resident solve: %d tiles (one record per thread: <= %d)", tiles_y * tiles_x, kBlock);
     return false;
   }
+  if (!tiles_fit_device(tiles_y * tiles_x, "resident solve")) return false;
   if (((q->tile_h + 2 * kBwdApron) / q->slide_h + 3) * ((q->tile_w + 2 * kBwdApron) / q->slide_w + 3) * 2 > kResElems) {
     set_error("resident solve: sliding window %dx%d: a tile's block of grid cells has more than %d elements", q->slide_h, q->slide_w, kResElems);
     return false;
@@ -165,6 +181,7 @@ bool resident_2dof_ok(const ebos_cmax_2dof_problem* q) {
     set_error("resident 2-DoF solve: %d tiles (one record per thread: <= %d)", tiles_y * tiles_x, kBlock);
     return false;
   }
+  if (!tiles_fit_device(tiles_y * tiles_x, "resident 2-DoF solve")) return false;
   if (q->blur_k0 != 0.0f && (q->blur_k0 < 0.0f || q->blur_k1 <= 0.0f || q->H < 2 || q->W < 2)) {
     set_error("resident 2-DoF solve: bad blur taps / image smaller than 2 x 2");
     return false;

@@ -389,6 +389,30 @@ def test_reference_hot_plate1_config_drives_the_solver(size, fractional):
 
 
 @pytest.mark.gpu
+def test_resident_queries_refuse_a_grid_that_cannot_be_co_resident():
+    """720 x 640 (hot_plate1's region of interest) on 32 x 32 tiles is 460 workgroups: more than the device has CUs.  The ``supported``
+    queries say so (a refused LAUNCH would raise), and ``run`` takes the four launches."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import Fused2dofLoop, FusedPatchLoop
+
+    h, w, n = 720, 640, 50_000
+    rs = np.random.RandomState(0)
+    ev = np.stack([rs.randint(0, h, n), rs.randint(0, w, n), np.sort(rs.uniform(0, 0.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile=(32, 32), emit="compact")
+    two = Fused2dofLoop(plan, torch.tensor([1.0, -0.5]), 1.0, False, 0, "auto", lr=0.01, capacity=16, blur_sigma=3.0)
+    assert not two.resident_supported() and b"co-resident" in ebos.load_library().ebos_last_error()
+    two.run(5)
+    assert two.last_run_mode == "pipeline"
+    gh, gw = ebos.solver.patch_grid_shape((h, w), (24, 32), (24, 32))
+    patch = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0.001, 0.0, halo="auto", lr=0.01, capacity=16)
+    assert not patch.resident_supported()
+    patch.run(5)
+    assert patch.last_run_mode == "pipeline"
+    ok = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile=(32, 64), emit="compact")   # 230 workgroups
+    assert Fused2dofLoop(ok, torch.tensor([1.0, -0.5]), 1.0, False, 0, "auto", lr=0.01, capacity=16).resident_supported()
+
+
+@pytest.mark.gpu
 def test_window_pipeline_picks_the_tile_for_the_windows_in_flight():
     """At BASELINE configs[0]'s size an iteration of the resident loop is latency, not work: the pipeline takes the resident tile with
     the most workgroups for which the requested windows all fit the device (two windows: 32 x 32 tiles, 99 workgroups each; three
