@@ -514,9 +514,11 @@ class Fused2dofLoop(object):
             return False
         return bool(self.lib.ebos_cmax_2dof_resident_supported(ctypes.byref(self._resident_problem())))
 
-    def run_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> int:
-        """``n_iter`` iterations as one resident launch; returns its status after synchronising (0, or -101 ... -104 as
-        ``FusedPatchLoop.run_resident``; after -102 ``resident_iterations`` of them are done and handed over)."""
+    def enqueue_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> torch.Tensor:
+        """Enqueue ``n_iter`` iterations as one resident launch on the current stream WITHOUT waiting for it; returns the launch's
+        status word as a 1-element int32 tensor (a stream-ordered copy; 0 = completed -- as ``FusedPatchLoop.enqueue_resident``).
+        ``self.t`` is advanced by ``n_iter`` regardless: a caller that sees a non-zero word solves the window again
+        (solver.WindowPipeline does); everybody else: ``run``."""
         import ctypes
 
         if self._mailbox is None:
@@ -526,6 +528,16 @@ class Fused2dofLoop(object):
         check(self.lib.ebos_cmax_2dof_solve_resident_f32(ctypes.byref(self._resident_problem()), int(n_iter), ptr(self._mailbox),
                                                          self._mailbox.numel(), float(spin_timeout_s), stream_ptr()),
               "ebos_cmax_2dof_solve_resident")
+        self.t += int(n_iter)
+        self.last_run_mode = "resident"
+        return self._mailbox[:4].view(torch.int32).clone()
+
+    def run_resident(self, n_iter: int, spin_timeout_s: float = 2.0) -> int:
+        """``n_iter`` iterations as one resident launch; returns its status after synchronising (0, or -101 ... -104 as
+        ``FusedPatchLoop.run_resident``; after -102 ``resident_iterations`` of them are done and handed over)."""
+        t, mode = self.t, self.last_run_mode
+        self.enqueue_resident(n_iter, spin_timeout_s)
+        self.t, self.last_run_mode = t, mode   # (``run`` books the iterations once it has seen the status)
         status = int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), stream_ptr()))
         self.resident_iterations = int(self.lib.ebos_cmax_resident_iterations(ptr(self._mailbox), stream_ptr()))
         if self.resident_iterations < 0:

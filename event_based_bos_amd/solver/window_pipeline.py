@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from .. import _hip, ops
-from .._hip import check
+from .._hip import check, stream_ptr
 from ..data_loader import RawEventStore
 from ..event_plan import EventPlan
 from . import fused_loop
@@ -63,8 +63,10 @@ RESIDENT_TILES = ((32, 32), (32, 64), (45, 80))   # the tiles with resident kern
 
 class WindowPipeline(object):
     def __init__(self, solver: ContrastMaximization, n_concurrent: int = 3, device="cuda", resident: Optional[bool] = None):
-        if solver.motion_model != "dense-flow":
-            raise NotImplementedError("WindowPipeline drives the patch-flow (dense-flow) solver")
+        # the patch-flow solver, or the 2-DoF Adam loop of the reference's shipped YAML (configs/hot_plate1.yaml:47,70)
+        self.two_dof = solver.motion_model in ("2d-translation", "rigid-optical-flow")
+        if solver.motion_model != "dense-flow" and not (self.two_dof and solver.opt_method == "Adam"):
+            raise NotImplementedError("WindowPipeline drives the patch-flow (dense-flow) solver and the 2-DoF Adam loop")
         self.solver, self.n_concurrent = solver, max(1, int(n_concurrent))
         # resident (default: the solver's optimizer.resident, else on unless EBOS_RESIDENT=0): each window's loop as one resident
         # launch where the geometry allows it; False = four launches per iteration, the windows of a group interleaved on streams
@@ -92,7 +94,7 @@ class WindowPipeline(object):
                 # tile, the pipeline takes the resident tile with the most workgroups for which the requested windows all fit
                 # (346 x 260: two windows -> 32 x 32, 99 workgroups each; four -> 32 x 64, 54; eight -> 45 x 80, 30).
                 if solver.tile is None and solver.halo in ("auto", 32):
-                    slides = [sl for _, sl, _ in solver.pyramid_scales()]
+                    slides = [] if self.two_dof else [sl for _, sl, _ in solver.pyramid_scales()]
                     usable = [t for t in RESIDENT_TILES   # (every scale's sliding window on the grid-sampling route with this tile)
                               if all(self.lib.ebos_patch_fused_supported(t[0], t[1], 32, int(sl[0]), int(sl[1])) for sl in slides)]
                     # (each window in flight needs a hardware queue of its own beside the ingest and the default stream's)
@@ -114,6 +116,11 @@ class WindowPipeline(object):
         plan = store.plan(window[0], window[1], s.orig_image_shape, s.warp_direction, True, tile=self.tile, device=self.device,
                           deferred=True, emit="compact")  # no host read-back: the host never waits for the GPU until the end;
         # lean build: the fused loop reads only the compact events and offsets (0.09 ms instead of 0.4 per 2 M-event window)
+        if self.two_dof:
+            if not s._translation_loop_fused(plan):
+                raise NotImplementedError("this 2-DoF configuration is outside the native loop (variance contrast, optionally blurred, no "
+                                          "regulariser): call solver.estimate(store.load_event(i0, i1)) per window instead")
+            return plan
         if not fused_loop.supported(s.contrast_terms, s.flow_terms, s.blur_sigma, s.opt_method, plan, s.halo, s.sliding_window):
             raise NotImplementedError("this solver configuration is outside the fused objective family: "
                                       "call solver.estimate(store.load_event(i0, i1)) per window instead")
@@ -132,6 +139,8 @@ class WindowPipeline(object):
         statuses = [[] for _ in plans]
         modes = [[] for _ in plans]
         resident = self.resident if resident is None else resident
+        if self.two_dof:
+            return self._solve_group_2dof(plans, streams, resident)
         for patch_size, sliding_window, n_iter in s.pyramid_scales():
             gh, gw = patch_grid_shape((H, W), patch_size, sliding_window)
             loops = []
@@ -179,6 +188,28 @@ class WindowPipeline(object):
                     t.record_stream(streams[w])
         return [dict(theta=thetas[w], losses=losses[w], patch=last, counts=plans[w].__dict__.get("_counts"), status=statuses[w],
                      modes=modes[w]) for w in range(len(plans))]
+
+    def _solve_group_2dof(self, plans: Sequence[EventPlan], streams: Sequence[torch.cuda.Stream], resident: bool) -> List[dict]:
+        """The 2-DoF Adam loop (``Fused2dofLoop``) of every plan of the group, each on its stream: one resident launch per window, or
+        the natively enqueued four (five) launches per iteration.  Nothing waits for the GPU."""
+        s = self.solver
+        out = []
+        for w, plan in enumerate(plans):
+            with torch.cuda.stream(streams[w]):
+                loop = fused_loop.Fused2dofLoop(plan, torch.zeros(2), s.contrast_terms["image_variance"], s.omit_boundary, s.pad, s.halo, s.lr,
+                                                capacity=max(s.n_iter, 1), blur_sigma=s.blur_sigma)
+                status, mode = [], "pipeline"
+                if resident and loop.resident_supported():
+                    status, mode = [loop.enqueue_resident(s.n_iter)], "resident"
+                else:
+                    with _hip.on_device(self.device):
+                        check(self.lib.ebos_cmax_2dof_solve_f32(ctypes.byref(loop.problem()), int(s.n_iter), stream_ptr()), "ebos_cmax_2dof_solve")
+                out.append(dict(theta=loop.theta.clone(), losses=[loop.losses[:s.n_iter].clone()], patch=None,
+                                counts=plan.__dict__.get("_counts"), status=status, modes=[mode]))
+            for t in (plan.x, plan.y, plan.dt, plan.p, plan.key_offsets, plan.perm, plan.grp_offsets, plan.cpix, plan.cdt, plan.part_table):
+                if t is not None:
+                    t.record_stream(streams[w])
+        return out
 
     # ------------------------------------------------------------------ driver
     def run(self, store: RawEventStore, windows: Sequence[Tuple[int, int]]) -> List[np.ndarray]:
@@ -244,5 +275,7 @@ class WindowPipeline(object):
             self.patch_flows = [r["theta"] for r in pending]
             self.window_modes = [list(r["modes"]) for r in pending]   # per window and pyramid scale: how its final solve ran
             self.dropped_events = [int(r["counts"][0].item()) if r["counts"] is not None else 0 for r in pending]
+            if self.two_dof:   # dense flow equivalent of theta: -theta everywhere (src/warp.py:186-187), as ``estimate`` returns it
+                return [np.broadcast_to((-r["theta"]).cpu().numpy().astype(np.float64).reshape(2, 1, 1), (2, H, W)).copy() for r in pending]
             return [ops.upsample_patch_flow(r["theta"], r["patch"][0], r["patch"][1], (H, W)).cpu().numpy().astype(np.float64)
                     for r in pending]

@@ -1358,3 +1358,34 @@ def test_fuzz_resident_loops_against_the_launches_and_the_oracle():
         done["blur"] += contrast == "blur"
     print("cases run:", done)
     assert done["patch"] >= 10 and done["2dof"] >= 5 and done["frac"] >= 5 and done["gm"] >= 3 and done["blur"] >= 5, done
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blur", [0.0, 3.0])
+def test_window_pipeline_drives_the_2dof_adam_loop(blur):
+    """The reference's shipped YAML selects the 2-DoF model with Adam (configs/hot_plate1.yaml:47,70): the pipeline runs that loop too,
+    one resident launch per window, several windows side by side -- the theta and losses of per-window ``estimate`` (the pipeline
+    picks its own tile and reads the raw sensor columns: sums in another order, 1e-4 relative)."""
+    import event_based_bos_amd as ebos
+
+    h, w = 260, 346
+    rs = np.random.RandomState(9)
+    n, k_win = 30_000, 5
+    store = ebos.data_loader.RawEventStore({"x": rs.randint(0, w, n * k_win).astype(np.int16), "y": rs.randint(0, h, n * k_win).astype(np.int16),
+                                            "t": np.sort(rs.randint(0, 8000 * k_win, n * k_win)).astype(np.int32) + 1_000_000,
+                                            "p": rs.randint(0, 2, n * k_win).astype(bool)})
+    windows = [(i * n, (i + 1) * n) for i in range(k_win)]
+    cfg = load_cfg()["solver"]
+    cfg.update(motion_model="2d-translation", parameters=["trans_x", "trans_y"], cost_with_weight={"image_variance": 1.0},
+               iwe={"method": "bilinear_vote", "blur_sigma": blur}, optimizer={"method": "Adam", "n_iter": 50, "parameters": {"lr": 0.05}})
+    solver = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
+    pipe = ebos.solver.WindowPipeline(solver, n_concurrent=3)
+    flows = pipe.run(store, windows)
+    assert pipe.resident_fallbacks == [] and all(m == ["resident"] for m in pipe.window_modes)
+    four = ebos.solver.WindowPipeline(solver, n_concurrent=3, resident=False).run(store, windows)
+    for k, wnd in enumerate(windows):
+        ref = solver.estimate(store.load_event(*wnd))
+        assert flows[k].shape == (2, h, w) and solver.loop_mode == "resident"
+        np.testing.assert_allclose(np.array(pipe.histories[k]), np.array(solver.history), rtol=1e-4)
+        np.testing.assert_allclose(flows[k], ref, atol=2e-3)
+        np.testing.assert_allclose(four[k], ref, atol=2e-3)

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--size", type=int, nargs=2, default=[720, 1280], help="image size (e.g. 720 640: hot_plate1's ROI, 128 tiles)")
     ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile of the window plans (default: the one that fills the GPU with one window)")
     ap.add_argument("--blur", type=float, default=0.0, help="iwe.blur_sigma")
+    ap.add_argument("--two-dof", action="store_true", help="the 2-DoF Adam loop (configs/hot_plate1.yaml:47,70 of the reference) instead of the patch flow")
     a = ap.parse_args()
     a.halo = a.halo if a.halo == "auto" else int(a.halo)
     H, W = a.size
@@ -45,8 +46,11 @@ def main():
     cfg = {"motion_model": "dense-flow", "warp_direction": "first", "cost_with_weight": {"image_variance": 1.0, "flow_norm": 0.001},
            "patch": {"size": [24, 32], "sliding_window": [24, 32]}, "halo": a.halo, "tile": a.tile, "iwe": {"method": "bilinear_vote", "blur_sigma": a.blur},
            "optimizer": {"method": "Adam", "n_iter": a.iters, "parameters": {"lr": 0.1}}}
+    if a.two_dof:
+        cfg.update(motion_model="2d-translation", parameters=["trans_x", "trans_y"], cost_with_weight={"image_variance": 1.0},
+                   optimizer={"method": "Adam", "n_iter": a.iters, "parameters": {"lr": 0.05}})
     solver = ebos.solver.collections["contrast_maximization"]((H, W), (H, W), solver_config=cfg)
-    res = {"windows": a.windows, "events_per_window": a.events, "iterations": a.iters, "halo": a.halo, "size": [H, W], "tile": list(solver.plan_tile())}
+    res = {"motion_model": cfg["motion_model"], "blur_sigma": a.blur, "windows": a.windows, "events_per_window": a.events, "iterations": a.iters, "halo": a.halo, "size": [H, W], "tile": list(solver.plan_tile())}
     host_windows = [store.load_event(*wnd) for wnd in windows[:2]]
     solver.estimate(host_windows[0])  # warm the process
     torch.cuda.synchronize()
