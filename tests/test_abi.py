@@ -201,7 +201,7 @@ def test_problem_struct_layout_matches_the_ctypes_mirror(tmp_path, c_name, py_na
 
 
 def test_hardware_queue_default_is_set_before_the_gpu_is_touched():
-    """Importing the package asks for GPU_MAX_HW_QUEUES=8 when the process has said nothing (HIP reads the variable when its runtime
+    """Importing the package asks for GPU_MAX_HW_QUEUES=16 when the process has said nothing (HIP reads the variable when its runtime
     initialises; WindowPipeline counts on a queue per window in flight) and leaves a value the process chose alone."""
     import subprocess
     import sys
@@ -209,6 +209,6 @@ def test_hardware_queue_default_is_set_before_the_gpu_is_touched():
     code = "import os, event_based_bos_amd as e; print(os.environ.get('GPU_MAX_HW_QUEUES'), e._hip.hw_queues())"
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    assert subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True).stdout.split() == ["8", "8"]
+    assert subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True).stdout.split() == ["16", "16"]
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True).stdout.split() == ["4", "4"]

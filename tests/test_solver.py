@@ -428,7 +428,7 @@ def test_window_pipeline_picks_the_tile_for_the_windows_in_flight():
                iwe={"method": "bilinear_vote", "blur_sigma": 0}, optimizer={"method": "Adam", "n_iter": 30, "parameters": {"lr": 0.05}})
     solver = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
     assert tuple(solver.plan_tile()) == (32, 32)
-    expect = {1: (32, 32), 2: (32, 32), 3: (32, 64), 4: (32, 64), 6: (45, 80) if _hip.hw_queues() >= 8 else (32, 64)}
+    expect = {1: (32, 32), 2: (32, 32), 3: (32, 64), 4: (32, 64), 8: (45, 80) if _hip.hw_queues() >= 10 else (32, 64)}
     if _hip.hw_queues() < 6:  # (shared hardware queues: more than two resident launches would take turns)
         expect = {k: (32, 32) for k in expect}
     for k, tile in expect.items():
