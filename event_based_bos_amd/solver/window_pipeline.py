@@ -196,7 +196,7 @@ class WindowPipeline(object):
         out = []
         for w, plan in enumerate(plans):
             with torch.cuda.stream(streams[w]):
-                loop = fused_loop.Fused2dofLoop(plan, torch.zeros(2), s.contrast_terms["image_variance"], s.omit_boundary, s.pad, s.halo, s.lr,
+                loop = fused_loop.Fused2dofLoop(plan, torch.zeros(2, dtype=torch.float32, device=self.device), s.contrast_terms["image_variance"], s.omit_boundary, s.pad, s.halo, s.lr,
                                                 capacity=max(s.n_iter, 1), blur_sigma=s.blur_sigma)
                 status, mode = [], "pipeline"
                 if resident and loop.resident_supported():
