@@ -5,13 +5,14 @@
 # masks of the blur: 16384 forward interior loop, 32768 adjoint interior loop, 65536 forward border fix-up, 131072 adjoint border fix-up
 cd "$(dirname "$0")/.."
 MASKS=${2:-"0 16384 32768 65536 131072 245760"}
+UNIT=${UNIT:-32x32}   # the resident 2-DoF unit to rebuild (32x32 | 32x64 | 45x80); run: TILE="45 80" picks the plan's tile
 if [ "$1" = "build" ]; then
   python -m event_based_bos_amd.build > /dev/null
   mkdir -p /tmp/ebos_abl
-  OBJS=$(ls event_based_bos_amd/lib/obj/*.o | grep -v "cmax_resident_32x32_2dof\.o")
+  OBJS=$(ls event_based_bos_amd/lib/obj/*.o | grep -v "cmax_resident_${UNIT}_2dof\.o")
   CC="/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -fPIC -fno-gpu-rdc -Wno-unused-function -Iinclude -Ievent_based_bos_amd/csrc -mllvm -sink-insts-to-avoid-spills=1"
   for M in $MASKS; do
-    ( $CC -DEBOS_ABL=$M -x hip -c event_based_bos_amd/csrc/cmax_resident_32x32_2dof.hip -o /tmp/ebos_abl/c$M.o && \
+    ( $CC -DEBOS_ABL=$M -x hip -c event_based_bos_amd/csrc/cmax_resident_${UNIT}_2dof.hip -o /tmp/ebos_abl/c$M.o && \
       /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o event_based_bos_amd/lib/libebos_abl$M.so /tmp/ebos_abl/c$M.o $OBJS ) &
     while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 1; done
   done
@@ -20,7 +21,7 @@ if [ "$1" = "build" ]; then
 else
   for M in $MASKS; do
     echo -n "mask $M: "
-    EBOS_HIP_LIBRARY=$PWD/event_based_bos_amd/lib/libebos_abl$M.so python tools/bench_frac_2dof.py 2>&1 | grep "260x346" | grep -o "[a-z]* coordinates, blur [0-9.]*: {'resident': [0-9.]*" | tr '\n' ';'
+    EBOS_HIP_LIBRARY=$PWD/event_based_bos_amd/lib/libebos_abl$M.so TILE="${TILE:-}" python tools/bench_frac_2dof.py 2>&1 | grep "260x346" | grep -o "[a-z]* coordinates, blur [0-9.]*: {'resident': [0-9.]*" | tr '\n' ';'
     echo
   done
 fi

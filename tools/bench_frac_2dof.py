@@ -16,7 +16,8 @@ for (H, W), n in (((260, 346), 100_000), ((720, 1280), 2_000_000)):
         ev = np.stack([rs.randint(0, H, n), rs.randint(0, W, n), np.sort(rs.uniform(0, 0.5, n)), rs.randint(0, 2, n)], 1).astype(np.float64)
         if frac:
             ev[:, :2] = np.clip(ev[:, :2] + rs.randint(0, 64, (n, 2)) / 64.0, 0, [H - 1, W - 1])
-        plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto")
+        tile = tuple(int(v) for v in os.environ["TILE"].split()) if os.environ.get("TILE") else "auto"   # (TILE="45 80": timing builds)
+        plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=tile)
         for sigma in (0.0, 3.0):
             out = {}
             for res in (True, False):
