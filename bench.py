@@ -42,6 +42,11 @@ import subprocess
 import sys
 import time
 
+# HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise) and reads the variable when its runtime
+# initialises; the package asks for 16 at import (_hip.hw_queues: the window pipeline keeps a queue per window in flight) -- this
+# process touches the GPU before it imports the package, so it says so itself
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -84,7 +89,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative legs (fwd+bwd, streams, rotating windows, solver)")
     ap.add_argument("--batch", type=int, default=64, help="config 4: windows per ebos_iwe_slab_batch_f32 call (16 per launch inside); 0 = one call per window")
-    ap.add_argument("--no-tail-stream", action="store_true", help="config 4, batched: combine / finalize passes on the same stream as the accumulate passes")
+    ap.add_argument("--tail-stream", action="store_true", help="config 4, batched: combine / finalize passes of a batch on a second stream beside the next "
+                                                               "batch's accumulate pass (measured SLOWER wherever the two really overlap: 1.11 against 0.96 ms per pass "
+                                                               "with a hardware queue per stream; the default is one stream)")
+    ap.add_argument("--no-tail-stream", action="store_true", help="(the default since round 5; kept for old command lines)")
     ap.add_argument("--no-graph", action="store_true", help="config 4: enqueue every window's calls from Python instead of replaying a captured pass")
     ap.add_argument("--no-compact", action="store_true", help="read the 12 B/event (x, y, dt) plan instead of 6 B/event")
     ap.add_argument("--fractional", action="store_true",
@@ -788,6 +796,42 @@ def run_config2(R):
                     del pl_f, ev_f
                 leg["us_per_iteration"] = min(v["us_per_iteration"] for v in leg["2M_events"].values()
                                               if isinstance(v, dict) and "us_per_iteration" in v)
+                # ... and a recording, window after window (solver.WindowPipeline: raw sensor columns in, windows side by side, one
+                # resident launch each): the loop of the reference's configs/hot_plate1.yaml:47,65,70 (2-DoF, blur 3, Adam x 600) at
+                # BASELINE configs[0]'s size, against the same solver called window by window
+                try:
+                    hh, ww = small
+                    n_w, k_w = 100_000, 16
+                    rs_p = np.random.RandomState(17)
+                    store = ebos.data_loader.RawEventStore({"x": rs_p.randint(0, ww, n_w * k_w).astype(np.int16), "y": rs_p.randint(0, hh, n_w * k_w).astype(np.int16),
+                                                            "t": np.sort(rs_p.randint(0, 8300 * k_w, n_w * k_w)).astype(np.int32) + 10_000_000,
+                                                            "p": rs_p.randint(0, 2, n_w * k_w).astype(bool)})
+                    wins = [(k * n_w, (k + 1) * n_w) for k in range(k_w)]
+                    cfg_p = {"motion_model": "2d-translation", "warp_direction": "first", "parameters": ["trans_x", "trans_y"], "halo": "auto",
+                             "cost_with_weight": {"image_variance": 1.0}, "iwe": {"method": "bilinear_vote", "blur_sigma": 3},
+                             "optimizer": {"method": "Adam", "n_iter": 600, "parameters": {"lr": 0.05}}}
+                    slv = ebos.solver.collections["contrast_maximization"]((hh, ww), (hh, ww), solver_config=cfg_p)
+                    host = [store.load_event(*wnd) for wnd in wins[:3]]
+                    slv.estimate(host[0])
+                    torch.cuda.synchronize()
+                    t4 = time.perf_counter()
+                    for ev_w in host[1:]:
+                        slv.estimate(ev_w)
+                    torch.cuda.synchronize()
+                    one_by_one = (time.perf_counter() - t4) / 2 * 1e3
+                    pipe = ebos.solver.WindowPipeline(slv, n_concurrent=3)
+                    pipe.run(store, wins)
+                    torch.cuda.synchronize()
+                    t4 = time.perf_counter()
+                    pipe.run(store, wins)
+                    torch.cuda.synchronize()
+                    leg["window_pipeline_346x260"] = {"objective": "2-DoF, blur 3, Adam x 600, 100 k events per window", "windows": k_w,
+                                                      "ms_per_window": round((time.perf_counter() - t4) / k_w * 1e3, 2),
+                                                      "ms_per_window_one_by_one": round(one_by_one, 2), "windows_in_flight": pipe.n_concurrent,
+                                                      "tile": list(pipe.tile), "modes": sorted({m for wm in pipe.window_modes for m in wm})}
+                    del store, pipe, slv
+                except Exception as err:
+                    leg["window_pipeline_346x260"] = {"error": repr(err)}
                 extras["solver_iteration"] = leg
                 del plan2, plan_s
             except Exception as err:  # the headline measurement must not depend on the solver layer
@@ -1121,9 +1165,9 @@ def run_config4(R):
             batches.append(ebos.SlabBatch(plans[b0:b0 + a.batch], grids[b0:b0 + a.batch], patch=((ph, pw), (sh, sw)), halo=a.halo,
                                           splits=splits))
 
-        def batch_step():  # accumulate passes back to back on the current stream, combine / finalize passes beside them on `tail`
+        def batch_step():  # accumulate, combine and finalize passes back to back on the current stream (--tail-stream: the latter two beside the next accumulate pass)
             for bt in batches:
-                bt.run(tail_stream=None if a.no_tail_stream else tail.cuda_stream)
+                bt.run(tail_stream=tail.cuda_stream if a.tail_stream and not a.no_tail_stream else None)
 
         batch_step()
         torch.cuda.synchronize()
