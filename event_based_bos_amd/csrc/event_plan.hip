@@ -301,6 +301,11 @@ compact_offsets_kernel(const int32_t* __restrict__ key_offsets, int tile_px, int
 // cfx / cfy (nullable): the fractional parts x - floor(x), y - floor(y) of the source coordinates per slot -- the compact plan of a
 // window of undistorted events (ebos_plan_compact_frac_f32)
 constexpr int kCanonMax = 64;
+// a float's bits as an integer with the floats' order -- a total order (NaNs rank too: no two events take one slot)
+__device__ __forceinline__ int sort_key(float d) {
+  const int b = __float_as_int(d);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
 __global__ void __launch_bounds__(256)
 compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ dts,
                     const int32_t* __restrict__ key_offsets, int tile_h, int tile_w, int tiles_x,
@@ -327,6 +332,7 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
         const int32_t kb = key_offsets[key], ke = key_offsets[key + 1];
         int64_t slot = o;
         if (ke - kb > 1 && ke - kb <= kCanonMax) {
+          const int kdt = sort_key(dt), kfx = sort_key(fx), kfy = sort_key(fy);
           int rank = 0;
           for (int32_t j0 = kb; j0 < ke; j0 += 4) {  // (four events' loads in flight: the longest run's chain of round trips bounds the pass)
             float xj[4], yj[4], dj[4];
@@ -339,7 +345,8 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
             for (int u = 0; u < 4; ++u) {
               const int32_t j = j0 + u;
               const float fxj = xj[u] - (float)(int)xj[u], fyj = yj[u] - (float)(int)yj[u];
-              const bool before = dj[u] < dt || (dj[u] == dt && (fxj < fx || (fxj == fx && (fyj < fy || (fyj == fy && j < src)))));
+              const int kd = sort_key(dj[u]), kx = sort_key(fxj), ky = sort_key(fyj);   // (a total order: NaNs rank too)
+              const bool before = kd < kdt || (kd == kdt && (kx < kfx || (kx == kfx && (ky < kfy || (ky == kfy && j < src)))));
               rank += (j < ke && before) ? 1 : 0;
             }
           }
@@ -407,8 +414,9 @@ compact_canon_hot_kernel(const int32_t* __restrict__ key_offsets, int tile_px, c
           const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
           const bool ascending = (lo & size) == 0;
           const float da = s_dt[lo], xa = s_fx[lo], ya = s_fy[lo], db = s_dt[hi], xb = s_fx[hi], yb = s_fy[hi];
-          const bool a_after_b = da > db || (da == db && (xa > xb || (xa == xb && ya > yb)));
-          const bool b_after_a = db > da || (da == db && (xb > xa || (xa == xb && yb > ya)));
+          const int qa = sort_key(da), qb = sort_key(db), kxa = sort_key(xa), kxb = sort_key(xb), kya = sort_key(ya), kyb = sort_key(yb);
+          const bool a_after_b = qa > qb || (qa == qb && (kxa > kxb || (kxa == kxb && kya > kyb)));
+          const bool b_after_a = qb > qa || (qa == qb && (kxb > kxa || (kxa == kxb && kyb > kya)));
           if (ascending ? a_after_b : b_after_a) {
             s_dt[lo] = db, s_fx[lo] = xb, s_fy[lo] = yb;
             s_dt[hi] = da, s_fx[hi] = xa, s_fy[hi] = ya;

@@ -278,6 +278,13 @@ lean_partition_kernel(LeanIn in, int64_t n, LeanGeom g, int n_chunks, LeanScratc
   }
 }
 
+// a float's bits as an integer with the floats' order -- a TOTAL order: a NaN (a broken timestamp) still gets a rank of its own, where
+// float comparisons would hand several events the same slot
+__device__ __forceinline__ int sort_key(float d) {
+  const int b = __float_as_int(d);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+
 // one workgroup per bin: counting sort of the bin's segment by pixel -> key_offsets of the band, cpix / cdt at their final slots
 __global__ void __launch_bounds__(kLeanBlock)
 lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp_offsets, int32_t* __restrict__ key_offsets,
@@ -417,7 +424,7 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
             const int hi = stride == (size >> 1) ? blk * 2 * stride + (2 * stride - 1 - off) : lo + stride;
             if (hi < L) {
               const float x = v[lo], y = v[hi];
-              if (x > y) v[lo] = y, v[hi] = x;
+              if (sort_key(x) > sort_key(y)) v[lo] = y, v[hi] = x;
             }
           }
           __syncthreads();
@@ -431,12 +438,13 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
       const int pi = ((int)(px >> 8) - r0) * g.tw + (int)(px & 255u);
       const int rb = s_cnt[pi] - c0, re = run_end(pi) - c0;
       const float d = s_dt[i];
+      const int kd = sort_key(d);
       int slot = i;
       if (re - rb > 1 && re - rb <= kLeanCanon) {
         int rank = 0;
         for (int j = rb; j < re; ++j) {
-          const float dj = s_dt[j];
-          rank += (dj < d || (dj == d && j < i)) ? 1 : 0;
+          const int kj = sort_key(s_dt[j]);
+          rank += (kj < kd || (kj == kd && j < i)) ? 1 : 0;
         }
         slot = rb + rank;
       }
