@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           });
           return;
         }
-        for_border(r0, nr, c0, nc, 0, outside);
+        if (!(EBOS_ABL & 524288)) for_border(r0, nr, c0, nc, 0, outside);
         const int rr0 = max(r0, 0), rr1 = min(r0 + nr, H), cc0 = max(c0, 0), cc1 = min(c0 + nc, W);
         if (rr1 > rr0 && cc1 > cc0) for_border(rr0, rr1 - rr0, cc0, cc1 - cc0, lo_b, ring);
       };

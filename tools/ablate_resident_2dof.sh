@@ -2,7 +2,8 @@
 # Timing builds of the resident 2-DoF kernel (32 x 32 unit; cmax_resident_core.h, EBOS_ABL) at the reference YAML's size
 # (346 x 260, 100 k events, integer and fractional coordinates, with and without blur 3) -- as tools/ablate_resident.sh.
 #   tools/ablate_resident_2dof.sh build "0 16384 ..."   (here)      tools/ablate_resident_2dof.sh run "0 16384 ..."   (GPU box)
-# masks of the blur: 16384 forward interior loop, 32768 adjoint interior loop, 65536 forward border fix-up, 131072 adjoint border fix-up
+# masks of the blur: 16384 forward interior loop, 32768 adjoint interior loop, 65536 forward border fix-up, 131072 adjoint border fix-up,
+# 524288 the clearing of what lies outside the image (45 x 80 at 346 x 260, blur 3: 25.2 us whole; 23.4 / 23.1 / - / - / 24.6 without a piece)
 cd "$(dirname "$0")/.."
 MASKS=${2:-"0 16384 32768 65536 131072 245760"}
 UNIT=${UNIT:-32x32}   # the resident 2-DoF unit to rebuild (32x32 | 32x64 | 45x80); run: TILE="45 80" picks the plan's tile
