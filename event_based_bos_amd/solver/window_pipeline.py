@@ -107,7 +107,7 @@ class WindowPipeline(object):
                     elif usable:
                         self.tile = min(usable, key=wgs)
                 fit = max(1, n_cu // wgs(self.tile))
-                self.n_concurrent = -(-self.n_concurrent // fit) * fit
+                self.n_concurrent = -(-self.n_concurrent // fit) * fit   # (whole rounds of the windows that fit side by side)
             self.ingest_stream, self.streams = _pooled_streams(self.device, self.n_concurrent)
 
     # ------------------------------------------------------------------ stages
@@ -220,19 +220,22 @@ class WindowPipeline(object):
             groups = [list(windows[i:i + self.n_concurrent]) for i in range(0, len(windows), self.n_concurrent)]
             pending: List[dict] = []
 
-            def ingest_group(group):
+            def ingest_group(group):   # one event per window: a window's stream waits for ITS plan, not for the group's last one
+                plans, ready = [], []
                 with torch.cuda.stream(ingest):
-                    plans = [self._ingest(store, wnd) for wnd in group]
-                    ready = torch.cuda.Event()
-                    ready.record(ingest)
+                    for wnd in group:
+                        plans.append(self._ingest(store, wnd))
+                        ev = torch.cuda.Event()
+                        ev.record(ingest)
+                        ready.append(ev)
                 return plans, ready
 
             nxt = ingest_group(groups[0]) if groups else None
             resident = self.resident
             for g in range(len(groups)):
                 plans, ready = nxt
-                for st in streams[:len(plans)]:
-                    st.wait_event(ready)
+                for st, ev in zip(streams, ready):
+                    st.wait_event(ev)
                 # A recording whose windows the resident kernel refuses (crowded tiles: status -104, or flows beyond its windows) would
                 # otherwise pay for every window twice -- once here and once, one by one, in the re-solve below: as soon as a launch
                 # of an earlier group is KNOWN to have ended early, the rest of the run takes the four launches
@@ -263,8 +266,8 @@ class WindowPipeline(object):
             for i in range(0, len(self.resident_fallbacks), len(streams)):   # (in groups, like the first pass)
                 ks = self.resident_fallbacks[i:i + len(streams)]
                 plans, ready = ingest_group([pending[k]["window"] for k in ks])
-                for st in streams[:len(plans)]:
-                    st.wait_event(ready)
+                for st, ev in zip(streams, ready):
+                    st.wait_event(ev)
                 for k, redo in zip(ks, self._solve_group(plans, streams, resident=False)):
                     pending[k].update(redo)
             if self.resident_fallbacks:
