@@ -819,7 +819,7 @@ def run_config2(R):
                         slv.estimate(ev_w)
                     torch.cuda.synchronize()
                     one_by_one = (time.perf_counter() - t4) / 2 * 1e3
-                    pipe = ebos.solver.WindowPipeline(slv, n_concurrent=3)
+                    pipe = ebos.solver.WindowPipeline(slv)   # (default: eight windows in flight on a sensor this small)
                     pipe.run(store, wins)
                     torch.cuda.synchronize()
                     t4 = time.perf_counter()

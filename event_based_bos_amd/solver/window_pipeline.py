@@ -62,12 +62,16 @@ RESIDENT_TILES = ((32, 32), (32, 64), (45, 80))   # the tiles with resident kern
 
 
 class WindowPipeline(object):
-    def __init__(self, solver: ContrastMaximization, n_concurrent: int = 3, device="cuda", resident: Optional[bool] = None):
+    def __init__(self, solver: ContrastMaximization, n_concurrent: Optional[int] = None, device="cuda", resident: Optional[bool] = None):
         # the patch-flow solver, or the 2-DoF Adam loop of the reference's shipped YAML (configs/hot_plate1.yaml:47,70)
         self.two_dof = solver.motion_model in ("2d-translation", "rigid-optical-flow")
         if solver.motion_model != "dense-flow" and not (self.two_dof and solver.opt_method == "Adam"):
             raise NotImplementedError("WindowPipeline drives the patch-flow (dense-flow) solver and the 2-DoF Adam loop")
-        self.solver, self.n_concurrent = solver, max(1, int(n_concurrent))
+        # n_concurrent None: three windows in flight -- eight where the resident loops of eight windows fit the device side by side
+        # on the largest resident tile (a small sensor: 346 x 260 takes 2.3 ms per window with eight in flight, 3.2 - 3.5 with four;
+        # at 1280 x 720, where one window fills the device, eight in flight cost 6.3 ms against 5.8 with three)
+        auto_n = n_concurrent is None
+        self.solver, self.n_concurrent = solver, 3 if auto_n else max(1, int(n_concurrent))
         # resident (default: the solver's optimizer.resident, else on unless EBOS_RESIDENT=0): each window's loop as one resident
         # launch where the geometry allows it; False = four launches per iteration, the windows of a group interleaved on streams
         if resident is None:
@@ -97,6 +101,8 @@ class WindowPipeline(object):
                     slides = [] if self.two_dof else [sl for _, sl, _ in solver.pyramid_scales()]
                     usable = [t for t in RESIDENT_TILES   # (every scale's sliding window on the grid-sampling route with this tile)
                               if all(self.lib.ebos_patch_fused_supported(t[0], t[1], 32, int(sl[0]), int(sl[1])) for sl in slides)]
+                    if auto_n and _hip.hw_queues() >= 10 and any(wgs(t) * 8 <= n_cu for t in usable):
+                        self.n_concurrent = 8
                     # (each window in flight needs a hardware queue of its own beside the ingest and the default stream's)
                     want = max(1, min(self.n_concurrent, _hip.hw_queues() - 2))
                     fits = [t for t in usable if wgs(t) * want <= n_cu]

@@ -434,10 +434,13 @@ def test_window_pipeline_picks_the_tile_for_the_windows_in_flight():
     for k, tile in expect.items():
         assert ebos.solver.WindowPipeline(solver, n_concurrent=k).tile == tile, (k, tile)
     assert ebos.solver.WindowPipeline(solver, n_concurrent=4, resident=False).tile == (32, 32)
+    auto = ebos.solver.WindowPipeline(solver)   # the default: eight in flight where eight resident loops fit side by side, else three
+    assert (auto.n_concurrent, auto.tile) == ((8, (45, 80)) if _hip.hw_queues() >= 10 else (4, (32, 32)))
     named = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=dict(cfg, tile=[45, 80]))
     assert ebos.solver.WindowPipeline(named, n_concurrent=3).tile == (45, 80)
     big = ebos.solver.collections["contrast_maximization"]((720, 1280), (720, 1280), solver_config=cfg)
     assert ebos.solver.WindowPipeline(big, n_concurrent=3).tile == (45, 80)
+    assert ebos.solver.WindowPipeline(big).n_concurrent == 3
     rs = np.random.RandomState(5)
     n, k_win = 20_000, 4
     store = ebos.data_loader.RawEventStore({"x": rs.randint(0, w, n * k_win).astype(np.int16), "y": rs.randint(0, h, n * k_win).astype(np.int16),
