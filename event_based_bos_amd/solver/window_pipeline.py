@@ -14,7 +14,9 @@ The reference's driver walks a recording window by window (bos_event.py:144-220)
 Measured on MI355X (tools/bench_pipeline.py, 8 windows x 2 M events at 1280x720, 600 iterations): 45.7 ms per window
 with per-window ``estimate`` on host float64 windows, 43.9 ms with one window at a time (ingest hidden), 35.8 ms with
 two, 26.8 ms with three at once -- and 51.7 ms with four: ROCm multiplexes streams onto 4 hardware queues per process, so
-three solver streams + the ingest stream is the most that runs truly concurrently (the default).
+three solver streams + the ingest stream is the most that runs truly concurrently there (the package asks for 16 queues at
+import since round 5; on a small sensor -- 346 x 260 -- eight windows run side by side as resident launches on 45 x 80 tiles:
+2.3 ms per 600-iteration window, the default there).
 
 Only the objective family of ``fused_loop`` is pipelined; ``run`` raises for any other solver configuration (use
 ``solver.estimate`` per window then).  Across ranks, windows are dealt out with ``sharding.shard_units``.
