@@ -817,7 +817,15 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       // few hundred pixels at most: `ring(r, c)`, the general forms) -- when one loop would take more than one round: the ring's
       // pixels are then spread over the rounds of the large outside part and a wave runs the general form in several of them (3.5 us
       // per pass in a 45 x 80 border tile); a small window keeps the one loop (a second loop's set-up costs it 0.3 us)
-      auto for_border_split = [&](int r0, int nr, int c0, int nc, int lo_b, auto&& outside, auto&& ring) {
+      // (band_r / band_c: how far outside the image the pass's main loop can have left something to clear -- one pixel for a 3 x 3
+      // stencil on a window that is zero outside the image; farther out nothing is visited: 0.6 us of a 45 x 80 border tile's
+      // iteration went into clearing zeros)
+      auto for_border_split = [&](int r0, int nr, int c0, int nc, int lo_b, int band_r, int band_c, auto&& outside, auto&& ring) {
+        {
+          const int r1 = min(r0 + nr, H + band_r), c1 = min(c0 + nc, W + band_c);
+          r0 = max(r0, -band_r), c0 = max(c0, -band_c);
+          nr = max(r1 - r0, 0), nc = max(c1 - c0, 0);
+        }
         const int rt = min(max(lo_b - r0, 0), nr), rb = min(max(r0 + nr - (H - lo_b), 0), nr - rt);
         const int cl_ = min(max(lo_b - c0, 0), nc), cr_ = min(max(c0 + nc - (W - lo_b), 0), nc - cl_);
         if ((rt + rb) * nc + (nr - rt - rb) * (cl_ + cr_) <= kBlock) {
@@ -875,7 +883,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           }
           if (!inner && !(EBOS_ABL & 65536)) {  // (uniform) the pixels beside the image's border, and those outside the valid region
             __syncthreads();
-            for_border_split(boy, bh, box + 3, bw - 6, vlo, [&](int r, int c) { s_b[(r - boy) * bw + (c - box)] = 0.0f; },
+            for_border_split(boy, bh, box + 3, bw - 6, vlo, 1, 1, [&](int r, int c) { s_b[(r - boy) * bw + (c - box)] = 0.0f; },
                              [&](int r, int c) {
                                const bool valid = r >= lo_px && r < H - lo_px && c >= lo_px && c < W - lo_px;
                                const float y = (valid && !(EBOS_ABL & 262144)) ? blur3_fwd_at_dense(x_at, r, c, H, W, bk) : 0.0f;  // (the raw window reaches >= 1 pixel further)
@@ -900,9 +908,13 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             const float4* m = B4 + (rl + 1) * bq + cq + 1;
             const float4 z4 = blur3_interior_quad(m[-bq - 1], m[-bq], m[-bq + 1], m[-1], m[0], m[1], m[bq - 1], m[bq], m[bq + 1], bk);
             // (GradImage::map with the interior weight)
-            const float4 g4 = make_float4(__fmaf_rn(Ga, z4.x, cw_in), __fmaf_rn(Ga, z4.y, cw_in), __fmaf_rn(Ga, z4.z, cw_in), __fmaf_rn(Ga, z4.w, cw_in));
-            reinterpret_cast<float4*>(s_g)[i] = g4;
             const int r = goy + rl, c = gox + 4 * cq;
+            // (a quad that lies outside the image as a whole stages zeros -- the constant term would fill it otherwise, and the
+            // fix-up below then has only the quads across the image's left / right edge to clear)
+            const bool in_img = inner || (r >= 0 && r < H && c + 3 >= 0 && c < W);
+            const float4 g4 = in_img ? make_float4(__fmaf_rn(Ga, z4.x, cw_in), __fmaf_rn(Ga, z4.y, cw_in), __fmaf_rn(Ga, z4.z, cw_in), __fmaf_rn(Ga, z4.w, cw_in))
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4*>(s_g)[i] = g4;
             if (inner || (r >= ilo && r < H - ilo && c >= ilo && c + 3 < W - ilo)) {
               const float m4 = fmaxf(fmaxf(fabsf(g4.x), fabsf(g4.y)), fmaxf(fabsf(g4.z), fabsf(g4.w)));
               gmax_t = fmaxf(gmax_t, (g4.x + g4.y + g4.z + g4.w) == (g4.x + g4.y + g4.z + g4.w) ? m4 : INFINITY);
@@ -923,7 +935,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             Gm.set_blur(bk);
             auto u_at = [&](int r, int c) { return s_b[(r - boy) * bw + (c - box)]; };
             __syncthreads();
-            for_border_split(goy, wb.LH(), gox, gw, ilo, [&](int r, int c) { s_g[(r - goy) * gw + (c - gox)] = 0.0f; },
+            for_border_split(goy, wb.LH(), gox, gw, ilo, 0, 3, [&](int r, int c) { s_g[(r - goy) * gw + (c - gox)] = 0.0f; },   // (quads outside the image: cleared by the loop above)
                              [&](int r, int c) {   // the ring of ilo pixels inside the image
                                const float gv = Gm.map(blur3_adj_at_dense(u_at, r, c, H, W, bk), r, c);  // (s_b: one row / four columns further)
                                s_g[(r - goy) * gw + (c - gox)] = gv;
@@ -1034,7 +1046,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
               vx = s_gx[o], vy = s_gy[o];
             };
             __syncthreads();
-            for_border_split(goy, wb.LH(), gox, gw, 1, [&](int r, int c) { s_g[(r - goy) * gw + (c - gox)] = 0.0f; },
+            for_border_split(goy, wb.LH(), gox, gw, 1, 1, 1, [&](int r, int c) { s_g[(r - goy) * gw + (c - gox)] = 0.0f; },
                              [&](int r, int c) {   // the image's outermost ring
                                const float gv = scale * sobel3_adjoint_ring_dense(gxy, r, c, H, W, lo_px, H - lo_px, lo_px, W - lo_px);
                                s_g[(r - goy) * gw + (c - gox)] = gv;
