@@ -249,7 +249,7 @@ class ContrastMaximizationMixin(object):
             losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
             self.graphed, self.fused, self.loop_mode = loop.graphed, True, loop.last_run_mode
             self.loop_modes.append(loop.last_run_mode)  # (per pyramid scale, coarse to fine)
-            self.history += [float(v) for v in losses.cpu()]
+            self.history += losses.cpu().tolist()   # (one conversion: 600 float() calls cost 0.1 ms of a 12 ms window)
             return loop.theta
         self.fused = False
         if self.opt_method in SCIPY_METHODS:
@@ -281,7 +281,7 @@ class ContrastMaximizationMixin(object):
             opt = torch.optim.Adam([theta], lr=self.lr)
             for it in range(done, n_iter):
                 losses[it] = iteration(opt)
-        self.history += [float(v) for v in losses[:n_iter].cpu()]
+        self.history += losses[:n_iter].cpu().tolist()
         return theta.detach()
 
     def _run_scipy(self, evaluate, theta: torch.Tensor, n_iter: int, value_and_grad=None) -> torch.Tensor:
@@ -390,7 +390,7 @@ class ContrastMaximizationMixin(object):
                                             self.halo, self.lr, capacity=max(n_iter, 1), blur_sigma=self.blur_sigma)
             losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
             self.fused, self.loop_mode = True, loop.last_run_mode
-            self.history += [float(v) for v in losses.cpu()]
+            self.history += losses.cpu().tolist()   # (one conversion: 600 float() calls cost 0.1 ms of a 12 ms window)
             return loop.theta
         self.fused = False
         theta = theta0.clone().requires_grad_(True)
