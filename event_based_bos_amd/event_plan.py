@@ -116,6 +116,17 @@ def _n_cu(device: torch.device) -> int:
 PART_FIXED_EVENTS = 8192
 
 
+def part_fixed_events(n_events: int, n_tiles: int, n_cu: int) -> int:
+    """The fixed work of a work item in events, as ``ebos_plan_parts``' model prices it.  Where the tiles already fill the device, an
+    extra work item is an extra ROUND on some CU, and a round has a floor (set-up, LDS clear, slab store) that does not shrink with
+    the window: measured best on blobs of sigma 50 - 200 px at 1280 x 720 (tools/bench_skew_solver.py; four launches per iteration)
+    were 65 k events at 1 M events, 32 k at 2 M, 8 - 16 k at 5 M, 8 k at 10 M -- i.e. ~6.5e10 / n (sigma 50 px at 2 M events: 88 ->
+    76 us per iteration).  Few tiles on many CUs (a small sensor) keep the constant: their parts spread over idle CUs, no second round."""
+    if 2 * n_tiles <= n_cu:
+        return PART_FIXED_EVENTS
+    return int(min(65536, max(PART_FIXED_EVENTS, 6.5e10 / max(int(n_events), 1))))
+
+
 @dataclass
 class EventPlan:
     """SoA f32 event window on one GPU (optionally binned by source tile)."""
@@ -330,8 +341,8 @@ class EventPlan:
         # (the work items depend on key_offsets only: enqueued in front of the read-back, which then carries their count as well)
         part_table = torch.empty(5 * tiles_y * tiles_x + 1, dtype=torch.int32, device=dev)
         with _hip.on_device(dev):
-            check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), PART_FIXED_EVENTS, ptr(part_table), stream_ptr()),
-                  "ebos_plan_parts")
+            check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), part_fixed_events(n, tiles_y * tiles_x, _n_cu(dev)),
+                                      ptr(part_table), stream_ptr()), "ebos_plan_parts")
         used = fullest = None
         if deferred:
             dropped, fractional = 0, 0
@@ -616,8 +627,8 @@ def _build_lean(source: int, events, raw, image_size, direction, normalize_t, ti
         if rc == -3:  # EBOS_ERR_UNSUPPORTED: geometry outside the LDS sort
             return None
         check(rc, "ebos_plan_lean")
-        check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), PART_FIXED_EVENTS, ptr(part_table), stream_ptr()),
-              "ebos_plan_parts")
+        check(lib.ebos_plan_parts(ptr(key_offsets), H, W, th, tw, _n_cu(dev), part_fixed_events(n, n_tiles, _n_cu(dev)), ptr(part_table),
+                                  stream_ptr()), "ebos_plan_parts")
     dropped, used, fullest = 0, None, None
     if not deferred:  # the one host read-back of the build: (outside the image, fractional sources, work items in use, fullest tile)
         dropped, fractional, used, fullest = (int(v) for v in torch.cat([counts, part_table[n_tiles:n_tiles + 1],
