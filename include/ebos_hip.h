@@ -228,7 +228,9 @@ int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const f
  * the fullest tile; real windows are far from uniform (a schlieren object in front of a static background).
  * ebos_plan_parts cuts heavy tiles into parts: parts(t) = max(1, ceil(load(t) / tau)), where tau balances the
  * longest work item against the average load of a CU:  tau + F = (N + items(tau) F) / n_cu  (n_cu = CUs of the
- * device, F = fixed_events = the per-item fixed work in events, ~8192 measured), within a budget of 2 x tiles work
+ * device, F = fixed_events = the per-item fixed work in events: 8192 for a 10 M-event window or few tiles on many CUs;
+ * where the tiles fill the device an extra item is an extra round and ~6.5e10 / N was measured best -- 32 k at 2 M events,
+ * at most 65536: EventPlan's part_fixed_events), within a budget of 2 x tiles work
  * items.  A uniform window keeps one part per tile.  part_table (int32, out, 5 tiles + 1 entries):
  *     [0, tiles]               part_off: first slab of each tile (part_off[tiles] = work items in use)
  *     [tiles + 1, 3 tiles]     item_tile: tile of each of the 2 x tiles work items, heaviest first (the dispatcher
