@@ -298,3 +298,48 @@ def test_lean_builds_of_one_window_are_identical_and_solve_identically(kind):
         losses.append(loop.run(100).cpu().numpy().copy())
     np.testing.assert_array_equal(losses[0], losses[1])
     np.testing.assert_array_equal(losses[0], losses[2])
+
+
+@pytest.mark.gpu
+def test_lean_build_fuzz_canonical_order_and_same_events_as_the_full_build():
+    """Random sensors, tiles, event counts and distributions (uniform; a hot pixel of up to 15 000 events; a blob that overfills bins; runs
+    of equal timestamps with events outside the image): two lean builds hold identical arrays, every pixel's run is in ascending dt, and
+    the events are those of the full build."""
+    import event_based_bos_amd as ebos
+
+    rs = np.random.RandomState(123)
+    for trial in range(24):
+        H, W = int(rs.randint(40, 800)), int(rs.randint(40, 1300))
+        n = int(rs.choice([2, 7, 1000, 50_000, 400_000, 1_500_000]))
+        kind = rs.randint(0, 4)
+        r, c = rs.randint(0, H, n).astype(np.float64), rs.randint(0, W, n).astype(np.float64)
+        if kind == 1 and n > 10:   # a hot pixel
+            k = min(n // 3, 15000)
+            r[:k], c[:k] = rs.randint(0, H), rs.randint(0, W)
+        elif kind == 2:            # a blob
+            r = np.clip(np.rint(rs.normal(H / 2, H / 12, n)), 0, H - 1)
+            c = np.clip(np.rint(rs.normal(W / 2, W / 12, n)), 0, W - 1)
+        elif kind == 3:            # some events outside the image
+            r[: n // 10] = -3
+        t = rs.uniform(0, 0.5, n)
+        if kind == 3:
+            t = np.round(t, 2)     # ... and runs of equal timestamps
+        ev = np.stack([r, c, t, rs.randint(0, 2, n)], 1)
+        ev = torch.from_numpy(ev[np.argsort(ev[:, 2], kind="stable")]).cuda()
+        tile = [(32, 32), (45, 80), (32, 64), "auto"][rs.randint(0, 4)]
+        plans = [ebos.EventPlan.build(ev, (H, W), "first", True, tile=tile, emit="compact") for _ in range(2)]
+        assert plans[0].lean, (trial, H, W, n, kind, tile)
+        full = ebos.EventPlan.build(ev, (H, W), "first", True, tile=tile, emit="full")
+        used = 4 * int(plans[0].grp_offsets[-1])
+        assert torch.equal(plans[0].cpix[:used], plans[1].cpix[:used]), (trial, H, W, n, kind, tile)
+        assert torch.equal(plans[0].cdt[:used].view(torch.int32), plans[1].cdt[:used].view(torch.int32)), (trial, H, W, n, kind, tile)
+        th, tw = plans[0].tile
+        ko, grp = plans[0].key_offsets.cpu().numpy(), plans[0].grp_offsets.cpu().numpy().astype(np.int64)
+        np.testing.assert_array_equal(ko, full.key_offsets.cpu().numpy())
+        cdt, fdt, cpx, fpx = plans[0].cdt.cpu().numpy(), full.cdt.cpu().numpy(), plans[0].cpix.cpu().numpy(), full.cpix.cpu().numpy()
+        for t_ in range(len(grp) - 1):
+            offs = ko[t_ * th * tw:(t_ + 1) * th * tw + 1] - ko[t_ * th * tw]
+            a, b = 4 * grp[t_], 4 * grp[t_] + offs[-1]
+            runs = np.repeat(np.arange(th * tw), np.diff(offs))
+            np.testing.assert_array_equal(cdt[a:b], fdt[a:b][np.lexsort((fdt[a:b], runs))], err_msg=str((trial, H, W, n, kind, tile)))
+            np.testing.assert_array_equal(cpx[a:b], fpx[a:b])
