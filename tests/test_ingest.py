@@ -343,3 +343,48 @@ def test_lean_build_fuzz_canonical_order_and_same_events_as_the_full_build():
             runs = np.repeat(np.arange(th * tw), np.diff(offs))
             np.testing.assert_array_equal(cdt[a:b], fdt[a:b][np.lexsort((fdt[a:b], runs))], err_msg=str((trial, H, W, n, kind, tile)))
             np.testing.assert_array_equal(cpx[a:b], fpx[a:b])
+
+
+@pytest.mark.gpu
+def test_fractional_compact_layout_fuzz_canonical_order():
+    """The compact layout with fractions per slot (EventPlan.frac_compact): two builds hold identical arrays, every pixel's run is in
+    ascending (dt, fx, fy) -- ranked by the fill for short runs, sorted in LDS for hot pixels of up to 4 096 events --, and the slots are
+    the plan's events (same multiset per pixel as the (x, y, dt) arrays)."""
+    import event_based_bos_amd as ebos
+
+    rs = np.random.RandomState(321)
+    for trial in range(16):
+        H, W = int(rs.randint(40, 500)), int(rs.randint(40, 700))
+        n = int(rs.choice([7, 1000, 50_000, 300_000]))
+        r, c = rs.uniform(0, H - 1, n), rs.uniform(0, W - 1, n)
+        if trial % 3 == 1 and n > 100:   # a hot source pixel with a few distinct fractions
+            k = min(n // 3, 4000)
+            r[:k] = rs.randint(0, H - 1) + rs.choice([0.25, 0.5, 0.75], k)
+            c[:k] = rs.randint(0, W - 1) + rs.choice([0.125, 0.5], k)
+        t = rs.uniform(0, 0.5, n)
+        if trial % 3 == 2:
+            t = np.round(t, 2)           # equal timestamps: the fractions decide
+        ev = np.stack([r, c, t, rs.randint(0, 2, n)], 1)
+        ev = torch.from_numpy(ev[np.argsort(ev[:, 2], kind="stable")]).cuda()
+        tile = [(32, 32), (45, 80), (32, 64), "auto"][rs.randint(0, 4)]
+        plans = [ebos.EventPlan.build(ev, (H, W), "first", True, tile=tile) for _ in range(2)]
+        fa, fb = plans[0].frac_compact, plans[1].frac_compact
+        assert fa is not None and fb is not None
+        used = 4 * int(fa[0][-1])
+        for a, b in zip(fa[1:], fb[1:]):
+            assert torch.equal(a[:used].view(torch.int32) if a.dtype == torch.float32 else a[:used], b[:used].view(torch.int32) if b.dtype == torch.float32 else b[:used]), (trial, H, W, n, tile)
+        th, tw = plans[0].tile
+        ko, grp = plans[0].key_offsets.cpu().numpy(), fa[0].cpu().numpy().astype(np.int64)
+        cdt, cfx, cfy = (a.cpu().numpy() for a in fa[2:])
+        xs, ys, dts = plans[0].x.cpu().numpy(), plans[0].y.cpu().numpy(), plans[0].dt.cpu().numpy()
+        for t_ in range(len(grp) - 1):
+            beg = ko[t_ * th * tw]
+            offs = ko[t_ * th * tw:(t_ + 1) * th * tw + 1] - beg
+            a, b = 4 * grp[t_], 4 * grp[t_] + offs[-1]
+            runs = np.repeat(np.arange(th * tw), np.diff(offs))
+            ex, ey, ed = xs[beg:beg + offs[-1]], ys[beg:beg + offs[-1]], dts[beg:beg + offs[-1]]
+            efx, efy = ex - np.trunc(ex), ey - np.trunc(ey)
+            order = np.lexsort((efy, efx, ed, runs))
+            np.testing.assert_array_equal(cdt[a:b], ed[order], err_msg=str((trial, H, W, n, tile)))
+            np.testing.assert_array_equal(cfx[a:b], efx[order].astype(np.float32))
+            np.testing.assert_array_equal(cfy[a:b], efy[order].astype(np.float32))
