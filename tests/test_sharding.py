@@ -162,12 +162,22 @@ def test_bench_line_contract_single_gpu():
     assert line["unit"] == "Mevents/s" and line["dtype"] == "f32" and line["higher_is_better"] is True
     assert "workload" in line["config"] and "model" not in line["config"]
     r = line["roofline"]
-    # `bound` names the roofline that BINDS when the committed counters were taken on this kernel source (roofline_issue), with the
-    # HBM pricing beside it; "hbm" when there are no counters to say otherwise.  Never "hbm" next to another binding in the summary.
-    assert r["bound"] in ("hbm", "valu_issue", "lds_pipe") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # `roofline` leads with the roofline that BINDS when the committed counters were taken on this kernel source: wave-instructions
+    # per second against the chip's issue rate, frac <= 1; SURVEY 8(d)'s HBM pricing sits beside it in `hbm_algorithmic`.  Without
+    # counters for this source the entry is the HBM one.  Never "hbm" next to another binding in the summary.
+    assert r["bound"] in ("hbm", "valu_issue", "lds_pipe")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
     if r["bound"] != "hbm":
-        assert r["bound"] == line["roofline_summary"]["binding"] == line["roofline_issue"]["bound"] and r["hbm_frac"] == r["frac"]
+        assert r["unit"] == "Gwave-inst/s" and 0 < r["frac"] <= 1.0
+        assert r["bound"] == line["roofline_summary"]["binding"] == line["roofline_issue"]["bound"]
+        assert abs(r["frac"] - line["roofline_issue"]["frac"]) < 2e-3
+        hb = r["hbm_algorithmic"]
+        assert hb["bound"] == "hbm" and hb["unit"] == "GB/s" and hb["peak"] == 8000.0 and r["hbm_algorithmic_frac"] == hb["frac"]
+        assert line["roofline_bwd"]["bound"] == line["roofline_bwd_issue"]["bound"]
+        assert "accumulate" not in line["roofline_bwd"]["traffic_kernel"]
+    else:
+        assert r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert "value_incl_plan_build" in line["config"]["workload"] and "value_hbm_streaming" in line["config"]["workload"]
     for k in ("value_hbm_streaming", "value_incl_plan_build"):   # the regimes a fresh window sees, next to `value`
         assert k in line and line[k] > 0
     assert abs(line["value"] - 400000 * 20 / (line["ms_per_step"] * 20 * 1e-3) / 1e6) < 0.02 * line["value"]
@@ -193,3 +203,19 @@ def test_bench_two_ranks_with_real_kernels_on_one_gpu(config, flags, total_key, 
     if config == 2:  # weak scaling: both ranks' events counted
         assert abs(line["value"] - 2 * 300000 / (line["ms_per_step"] * 1e-3) / 1e6) < 0.02 * line["value"]
         assert len({s["contrast"] for s in line["ranks_seen"]}) == 2  # different windows (seed = rank)
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_time_no_collective():
+    """The clock of a block stops on each rank when ITS steps have drained -- before the barrier (bench.py `timed_blocks`).  Two ranks
+    sharing the one GPU of the box interleave their kernels: at equal events per rank a step may take up to ~2 x the one-rank step,
+    not 2 x plus a barrier per block (VERDICT r05 weak #6 / next #5)."""
+    common = ("--steps", "20", "--warmup", "5", "--min-seconds", "0.3", "--events", "2000000", "--no-cpu-baseline", "--no-extras")
+    one = _bench(*common)
+    two = _bench("--gpus", "2", "--backend", "gloo", *common)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["ms_per_step"] <= 2.2 * one["ms_per_step"] + 0.004, (one["ms_per_step"], two["ms_per_step"])
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    body = src[src.index("def one_block(prof)"):src.index("while sum(blocks)")]
+    # the order in the source: synchronize -> take the time -> barrier -> MAX
+    assert body.index("torch.cuda.synchronize()") < body.index("dt = time.perf_counter() - t0") < body.rindex("self.sync_all()") < body.index("max_over_ranks(dt)")
