@@ -30,23 +30,52 @@ ABI_VERSION = 2
 # shared ones).  The variable is read when the runtime initialises: where the process has not said anything and has not touched the GPU
 # yet, ask for 16 queues (eight windows in flight, beside the ingest and the default stream: 3.1 ms each against 4.1 with four); ``hw_queues()`` is what the pipeline may count on.
 _HW_QUEUES = 4
-if "GPU_MAX_HW_QUEUES" in os.environ:
+
+
+def _runtime_initialised() -> bool:
+    """Has ANY HIP user of this process brought the runtime up already?  The ROCm runtime opens /dev/kfd when it initialises (which
+    is also when it reads GPU_MAX_HW_QUEUES); torch's own ``torch.cuda.is_initialized()`` is its lazy-init flag and stays False after
+    ``torch.cuda.is_available()`` or a ctypes HIP call has initialised the runtime with the default four queues.
+    Unknown (no /proc) counts as initialised: the pipeline then plans for four queues, which is slower but never aliases streams."""
     try:
-        _HW_QUEUES = max(1, int(os.environ["GPU_MAX_HW_QUEUES"]))
-    except ValueError:
-        pass
-else:
-    try:
-        import torch as _torch
-        if not _torch.cuda.is_initialized():
-            os.environ["GPU_MAX_HW_QUEUES"] = "16"
-            _HW_QUEUES = 16
-    except Exception:  # pragma: no cover
-        pass
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                if os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return True
+            except OSError:
+                continue
+        return False
+    except OSError:
+        return True
+
+
+def configure_queues(n: int = 16) -> int:
+    """Ask the HIP runtime for ``n`` hardware queues (GPU_MAX_HW_QUEUES) if that can still take effect -- the variable is not set and
+    the runtime is not up yet -- and return what ``hw_queues()`` reports from now on.  Runs at import with n = 16 unless
+    EBOS_NO_QUEUE_ENV=1 (then the process environment is left alone and the pipeline plans for the default four queues)."""
+    global _HW_QUEUES
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        try:
+            _HW_QUEUES = max(1, int(os.environ["GPU_MAX_HW_QUEUES"]))
+        except ValueError:
+            _HW_QUEUES = 4
+    elif not _runtime_initialised() and not torch.cuda.is_initialized():
+        os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+        _HW_QUEUES = int(n)
+    else:
+        _HW_QUEUES = 4
+    return _HW_QUEUES
+
+
+if os.environ.get("EBOS_NO_QUEUE_ENV", "0") in ("", "0"):
+    configure_queues(16)
+elif "GPU_MAX_HW_QUEUES" in os.environ:
+    configure_queues(0)  # (reads the variable; sets nothing)
 
 
 def hw_queues() -> int:
-    """Hardware queues this process's HIP streams are spread over (GPU_MAX_HW_QUEUES as the runtime saw or will see it)."""
+    """Hardware queues this process's HIP streams are spread over (GPU_MAX_HW_QUEUES as the runtime saw or will see it; 4 when the
+    runtime was already up before this package could ask for more)."""
     return _HW_QUEUES
 
 

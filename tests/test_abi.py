@@ -212,3 +212,35 @@ def test_hardware_queue_default_is_set_before_the_gpu_is_touched():
     assert subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True).stdout.split() == ["16", "16"]
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True).stdout.split() == ["4", "4"]
+    # opt-out: the environment is left alone and the pipeline plans for the runtime's default four queues
+    env.pop("GPU_MAX_HW_QUEUES")
+    env["EBOS_NO_QUEUE_ENV"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True).stdout.split() == ["None", "4"]
+
+
+def test_hardware_queue_count_is_not_inferred_from_torchs_lazy_flag(monkeypatch):
+    """A runtime another HIP user already initialised (``torch.cuda.is_available()``, a ctypes HIP call: /dev/kfd is open,
+    ``torch.cuda.is_initialized()`` still False) has read GPU_MAX_HW_QUEUES already: setting it now does nothing, so the package must
+    not report 16 and must not touch the environment."""
+    from event_based_bos_amd import _hip
+
+    had = os.environ.get("GPU_MAX_HW_QUEUES")
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    saved = _hip._HW_QUEUES
+    try:
+        monkeypatch.setattr(_hip, "_runtime_initialised", lambda: True)
+        assert _hip.configure_queues(16) == 4 and "GPU_MAX_HW_QUEUES" not in os.environ and _hip.hw_queues() == 4
+        monkeypatch.setattr(_hip, "_runtime_initialised", lambda: False)
+        if not torch_cuda_initialised():
+            assert _hip.configure_queues(12) == 12 and os.environ["GPU_MAX_HW_QUEUES"] == "12"
+    finally:
+        _hip._HW_QUEUES = saved
+        os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        if had is not None:
+            os.environ["GPU_MAX_HW_QUEUES"] = had
+
+
+def torch_cuda_initialised():
+    import torch
+
+    return torch.cuda.is_initialized()
