@@ -295,6 +295,11 @@ def roofline_issue(kernel_key, kernel_ms_list, clock_hz, events=None):
         return ent
     if k.get("windows"):  # a batched (persistent) pass: per window / hypothesis of the launch, like kernel_ms
         valu, lds = valu / k["windows"], lds / k["windows"]
+    if events and k.get("events") and int(events) != int(k["events"]):
+        # the counters were collected at another window size: the per-event instruction counts carry over, the launch's totals do not
+        scale = float(events) / float(k["events"])
+        valu, lds = valu * scale, lds * scale
+        ent["counters_scaled_to_events"] = int(events)
     t_valu = valu / (ISSUE["n_cu"] * ISSUE["simd_per_cu"]) * ISSUE["valu_cycles_per_wave_inst"] / clock_hz * 1e3  # ms
     t_lds = lds / ISSUE["n_cu"] * ISSUE["lds_cycles_per_wave_inst"] / clock_hz * 1e3
     bound = "valu_issue" if t_valu >= t_lds else "lds_pipe"

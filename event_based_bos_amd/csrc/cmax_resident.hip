@@ -162,6 +162,10 @@ bool resident_2dof_ok(const ebos_cmax_2dof_problem* q) {
     set_error("resident 2-DoF solve: needs the compact plan (integer source pixels)");
     return false;
   }
+  if ((q->cfx == nullptr) != (q->cfy == nullptr)) {  // (one without the other would launch the fractional kernel on a NULL array)
+    set_error("resident 2-DoF solve: cfx and cfy come together (fractional source coordinates) or not at all");
+    return false;
+  }
   if (q->splits > 1 || q->splits < 0 || q->pad_h != 0 || q->pad_w != 0) {
     set_error("resident 2-DoF solve: one work item per tile and no image padding (splits = %d, pad %dx%d)", q->splits, q->pad_h, q->pad_w);
     return false;

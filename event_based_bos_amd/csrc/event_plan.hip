@@ -369,37 +369,25 @@ compact_fill_kernel(const float* __restrict__ xs, const float* __restrict__ ys, 
 }
 
 // ... and the runs beyond kCanonMax (hot pixels: one sensor pixel firing hundreds of times in a window) are sorted in place by the same
-// key, one workgroup per tile, a bitonic network in LDS per hot run of up to kCanonHot events (longer ones keep their order of
-// arrival).  Equal keys are equal slots, so the network's instability is invisible.  A tile without a hot run -- nearly every tile
-// -- leaves after one pass over its key offsets.
+// key, one workgroup per tile, a bitonic network in LDS over up to kCanonHot events at a time.  Equal keys are equal slots, so the
+// network's instability is invisible.  The hot runs of a tile are taken in the order of their pixel index -- found by a block-wide
+// minimum per pass, as many passes as there are hot runs: no capped list, no dependence on the order atomics arrive in (a noisy sensor
+// with more than 64 hot pixels in a tile used to lose the canonical order silently).  A run LONGER than kCanonHot is sorted
+// by block-level odd-even merge-splitting: its chunks of kCanonHot / 2 events are sorted pairwise (chunk c with c + 1, the smaller half
+// back to c), pairs of alternating parity, as many phases as there are chunks -- which leaves the run sorted, in place, without scratch.
+// A tile without a hot run -- nearly every tile -- leaves after one pass over its key offsets.
 constexpr int kCanonHot = 4096;
 __global__ void __launch_bounds__(1024)
 compact_canon_hot_kernel(const int32_t* __restrict__ key_offsets, int tile_px, const int32_t* __restrict__ grp_offsets,
                          float* __restrict__ cdt, float* __restrict__ cfx, float* __restrict__ cfy) {
   __shared__ float s_dt[kCanonHot], s_fx[kCanonHot], s_fy[kCanonHot];
-  constexpr int kList = 64;
-  __shared__ int s_list[kList];
-  __shared__ int s_n;
+  __shared__ int s_next;
   const int t = blockIdx.x;
   const int32_t* __restrict__ ko = key_offsets + (int64_t)t * tile_px;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  for (int k = threadIdx.x; k < tile_px; k += blockDim.x) {
-    const int len = ko[k + 1] - ko[k];
-    if (len > kCanonMax && len <= kCanonHot) {
-      const int i = atomicAdd(&s_n, 1);
-      if (i < kList) s_list[i] = k;   // (the list's order is the atomics': the runs are independent of each other)
-    }
-  }
-  __syncthreads();
-  const int n_hot = min(s_n, kList);
   const int64_t out0 = (int64_t)grp_offsets[t] * 4;
   const int32_t beg = ko[0];
-  for (int h = 0; h < n_hot; ++h) {
-    const int k = s_list[h];
-    const int32_t kb = ko[k];
-    const int len = ko[k + 1] - kb;
-    const int64_t o0 = out0 + (kb - beg);
+  // sorts cdt / cfx / cfy [o0, o0 + len), len <= kCanonHot, through LDS (block-uniform arguments)
+  auto sort_span = [&](int64_t o0, int len) {
     int n2 = 1;
     while (n2 < len) n2 <<= 1;
     for (int i = threadIdx.x; i < n2; i += blockDim.x) {   // (padding sorts behind every event)
@@ -425,8 +413,38 @@ compact_canon_hot_kernel(const int32_t* __restrict__ key_offsets, int tile_px, c
         __syncthreads();
       }
     }
+    // (an event whose dt is +inf or NaN ranks with / behind the padding: the len smallest keys are the events' unless such values
+    // occur, and then they are equal to the padding's dt only for +inf -- whose fractions the padding's zeros would replace.  Events
+    // carry finite dt = (t - t_ref) / period; the kernels treat NaN dt as an empty slot anyway.)
     for (int i = threadIdx.x; i < len; i += blockDim.x) cdt[o0 + i] = s_dt[i], cfx[o0 + i] = s_fx[i], cfy[o0 + i] = s_fy[i];
     __syncthreads();
+  };
+  int cursor = 0;
+  while (true) {
+    if (threadIdx.x == 0) s_next = 0x7fffffff;
+    __syncthreads();
+    for (int k = cursor + threadIdx.x; k < tile_px; k += blockDim.x) {
+      if (ko[k + 1] - ko[k] > kCanonMax) {   // (a thread's candidates ascend: its first hot pixel is its smallest)
+        atomicMin(&s_next, k);
+        break;
+      }
+    }
+    __syncthreads();
+    const int k = s_next;
+    __syncthreads();   // (everyone has read s_next before the next pass resets it)
+    if (k == 0x7fffffff) break;
+    cursor = k + 1;
+    const int32_t kb = ko[k];
+    const int len = ko[k + 1] - kb;
+    const int64_t o0 = out0 + (kb - beg);
+    if (len <= kCanonHot) {
+      sort_span(o0, len);
+    } else {
+      constexpr int kChunk = kCanonHot / 2;
+      const int m = (len + kChunk - 1) / kChunk;
+      for (int phase = 0; phase < m; ++phase)
+        for (int c = phase & 1; c + 1 < m; c += 2) sort_span(o0 + (int64_t)c * kChunk, min(2 * kChunk, len - c * kChunk));
+    }
   }
 }
 

@@ -622,6 +622,7 @@ static int cmax_2dof_check(const ebos_cmax_2dof_problem* q) {
   EBOS_REQUIRE(q != nullptr && q->steps_done >= 0, "ebos_cmax_2dof_solve: NULL problem or negative steps_done");
   EBOS_REQUIRE(q->key_offsets && ((q->grp_offsets && q->cpix && q->cdt) || (q->xs && q->ys && q->dts) || q->n == 0),
                "ebos_cmax_2dof_solve: NULL plan buffers");
+  EBOS_REQUIRE((q->cfx == nullptr) == (q->cfy == nullptr), "ebos_cmax_2dof_solve: cfx and cfy come together or not at all");
   EBOS_REQUIRE(q->theta && q->d_theta && q->exp_avg && q->exp_avg_sq && q->step && q->iwe && q->variance && q->moments && q->upstream &&
                    q->workspace,
                "ebos_cmax_2dof_solve: NULL buffer");

@@ -209,8 +209,27 @@ class EventPlan:
     @property
     def frac_compact(self):
         """(grp_offsets, cpix, cdt, cfx, cfy) of a plan whose source coordinates are fractional (undistorted events) -- the compact
-        layout with the fractions per slot, read by the resident 2-DoF loop --, or None."""
-        return self.__dict__.get("_frac")
+        layout with the fractions per slot, read by the resident loops and the grid-sampling launches --, or None.  Built on the first
+        access, on the current stream (``ebos_plan_compact_frac_f32``: every source pixel's events in a canonical order, so two builds
+        of one window hold identical slots)."""
+        d = self.__dict__
+        if d.get("_frac") is None and d.get("_frac_pending"):
+            lib = _hip.require_gpu()
+            dev = self.x.device
+            H, W = self.image_size
+            th, tw = self.tile
+            n_tiles = ((H + th - 1) // th) * ((W + tw - 1) // tw)
+            cap = self.n + 3 * n_tiles + 8
+            f_grp = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            f_pix = torch.zeros(cap, dtype=torch.int16, device=dev)
+            f_dt = torch.full((cap,), float("nan"), dtype=torch.float32, device=dev)
+            f_x, f_y = torch.zeros(cap, dtype=torch.float32, device=dev), torch.zeros(cap, dtype=torch.float32, device=dev)
+            with _hip.on_device(dev):
+                check(lib.ebos_plan_compact_frac_f32(ptr(self.x), ptr(self.y), ptr(self.dt), ptr(self.key_offsets), self.n, H, W, th, tw,
+                                                     ptr(f_grp), ptr(f_pix), ptr(f_dt), ptr(f_x), ptr(f_y), cap, stream_ptr()),
+                      "ebos_plan_compact_frac")
+            d["_frac"], d["_frac_pending"] = (f_grp, f_pix, f_dt, f_x, f_y), False
+        return d.get("_frac")
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -362,24 +381,14 @@ class EventPlan:
             with _hip.on_device(dev):
                 check(lib.ebos_plan_compact_f32(ptr(xs), ptr(ys), ptr(dts), ptr(key_offsets), kept, H, W, th, tw,
                                                 ptr(grp_offsets), ptr(cpix), ptr(cdt), cap, stream_ptr()), "ebos_plan_compact")
-        frac = None
-        if fractional > 0 and th <= 256 and tw <= 256:
-            # fractional source coordinates (undistorted events): the compact layout WITH the fractions per slot -- the same
-            # information as (x, y, dt), in the form the resident 2-DoF loop reads (run-time windows, one launch); every other
-            # operator keeps the (x, y, dt) arrays: ``compact`` stays False
-            n_tiles = tiles_y * tiles_x
-            cap = kept + 3 * n_tiles + 8
-            f_grp = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
-            f_pix = torch.zeros(cap, dtype=torch.int16, device=dev)
-            f_dt = torch.full((cap,), float("nan"), dtype=torch.float32, device=dev)
-            f_x, f_y = torch.zeros(cap, dtype=torch.float32, device=dev), torch.zeros(cap, dtype=torch.float32, device=dev)
-            with _hip.on_device(dev):
-                check(lib.ebos_plan_compact_frac_f32(ptr(xs), ptr(ys), ptr(dts), ptr(key_offsets), kept, H, W, th, tw, ptr(f_grp),
-                                                     ptr(f_pix), ptr(f_dt), ptr(f_x), ptr(f_y), cap, stream_ptr()), "ebos_plan_compact_frac")
-            frac = (f_grp, f_pix, f_dt, f_x, f_y)
+        # fractional source coordinates (undistorted events): the compact layout WITH the fractions per slot is built on the first
+        # ``frac_compact`` access (the resident loops and the grid-sampling launches ask; API-parity operators and bench --fractional
+        # never do and no longer pay the rank loop, the hot-pixel pass and 14 B/event: ADVICE r05)
+        frac_pending = bool(fractional > 0 and th <= 256 and tw <= 256)
         out = EventPlan(xs[:kept], ys[:kept], dts[:kept], ps[:kept], self.image_size, kept, self.n_input,
                         (th, tw), key_offsets, src_perm, self.n_dropped + dropped, grp_offsets, cpix, cdt, part_table, self.dt_bound)
-        out.__dict__["_frac"] = frac  # (grp_offsets, cpix, cdt, cfx, cfy) of a window with fractional source coordinates, or None
+        out.__dict__["_frac"] = None          # (grp_offsets, cpix, cdt, cfx, cfy) once built
+        out.__dict__["_frac_pending"] = frac_pending
         out.__dict__["_counts"], out.__dict__["_deferred"] = counts, bool(deferred)
         out.__dict__["_parts_used"], out.__dict__["_fullest_tile"] = used, fullest
         return out

@@ -12,7 +12,8 @@ objective(theta) = - contrast(IWE(warp(events, motion(theta)))) [+ weighted regu
 Everything per event runs in the fused tile-private HIP pipeline on an ``EventPlan`` built once per window.
 YAML keys read (same names as configs/hot_plate1.yaml:46-80 of the reference): warp_direction, motion_model,
 parameters, cost, cost_with_weight, outer_padding, iwe.{method, blur_sigma}, patch.{size, sliding_window, pyramid.{coarsest, finest}},
-optimizer.{method (Adam | CG | BFGS | L-BFGS-B | TNC | SLSQP | grid), n_iter, parameters.lr, options, graph, fused,
+optimizer.{method (Adam | CG | BFGS | L-BFGS-B | TNC | SLSQP | grid | random | TPE | optuna + sampler), sampler, seed, n_iter, parameters.lr,
+options, graph, fused,
 refine_iters}.
 """
 from __future__ import annotations
@@ -94,6 +95,10 @@ class ContrastMaximizationMixin(object):
         self.lr = float((ocfg.get("parameters") or {}).get("lr", 0.05))
         self.scipy_options = dict(ocfg.get("options") or {})
         self.refine_iters = int(ocfg.get("refine_iters", 0))  # 2-DoF models: Adam steps after the grid sweep
+        # optimizer.sampler (configs/hot_plate1.yaml:69, src/solver/generative_max_likelihood.py:215-226): the outer loop of
+        # method "optuna" -- grid / uniform, random, TPE; optimizer.seed (this build's) makes random / TPE draws reproducible
+        self.sampler = ocfg.get("sampler", "grid")
+        self.sampler_seed = ocfg.get("seed", None)
         self.param_ranges = cfg.get("parameters") or {}  # {name: {min, max}} or the reference's list of names (_param_range)
         # solver.halo: "auto" (default) = run-time LDS windows per tile (event_plan.resolve_halo: each work item sizes its window
         # from a bound on its own displacements; BOS flows are a few pixels), bounded by the largest built halo; an integer
@@ -241,12 +246,22 @@ class ContrastMaximizationMixin(object):
 
         if self.fused_loop and fused_loop.supported(self.contrast_terms, self.flow_terms, self.blur_sigma, self.opt_method,
                                                     plan, self.halo, sliding_window):
-            loop = fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta, self.contrast_terms.get("image_variance", 0.0),
-                                             self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
-                                             self.omit_boundary, self.pad, self.halo, self.lr, capacity=n_iter,
-                                             w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0), theta_mask=mask,
-                                             blur_sigma=self.blur_sigma)
-            losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
+            theta_start = theta.detach().clone()   # (a torn resident launch leaves the loop's state partly written: start over from here)
+
+            def make_loop():
+                return fused_loop.FusedPatchLoop(plan, patch_size, sliding_window, theta_start.clone(), self.contrast_terms.get("image_variance", 0.0),
+                                                 self.flow_terms.get("flow_norm", 0.0), self.flow_terms.get("image_gradient", 0.0),
+                                                 self.omit_boundary, self.pad, self.halo, self.lr, capacity=n_iter,
+                                                 w_gradient_magnitude=self.contrast_terms.get("gradient_magnitude", 0.0), theta_mask=mask,
+                                                 blur_sigma=self.blur_sigma)
+
+            loop = make_loop()
+            try:
+                losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
+            except fused_loop.ResidentStateTorn as e:   # as WindowPipeline does: re-solve the window from its start with the four launches
+                logger.warning("%s; re-solving the window with the four launches", e)
+                loop = make_loop()
+                losses = loop.run(n_iter, resident=False)
             self.graphed, self.fused, self.loop_mode = loop.graphed, True, loop.last_run_mode
             self.loop_modes.append(loop.last_run_mode)  # (per pyramid scale, coarse to fine)
             self.history += losses.cpu().tolist()   # (one conversion: 600 float() calls cost 0.1 ms of a 12 ms window)
@@ -386,9 +401,17 @@ class ContrastMaximizationMixin(object):
         """``n_iter`` Adam steps on (trans_x, trans_y) from ``theta0``: natively when the objective allows it (one C call
         enqueues the whole loop, no host synchronisation per iteration), else through autograd."""
         if self._translation_loop_fused(plan):
-            loop = fused_loop.Fused2dofLoop(plan, theta0, self.contrast_terms["image_variance"], self.omit_boundary, self.pad,
-                                            self.halo, self.lr, capacity=max(n_iter, 1), blur_sigma=self.blur_sigma)
-            losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
+            def make_loop():
+                return fused_loop.Fused2dofLoop(plan, theta0.detach().clone(), self.contrast_terms["image_variance"], self.omit_boundary, self.pad,
+                                                self.halo, self.lr, capacity=max(n_iter, 1), blur_sigma=self.blur_sigma)
+
+            loop = make_loop()
+            try:
+                losses = loop.run(n_iter, resident=None if self.resident is None else bool(self.resident) and loop.resident_supported())
+            except fused_loop.ResidentStateTorn as e:   # theta0 is untouched (the loop works on its own copy): start over, four launches
+                logger.warning("%s; re-solving the window with the four launches", e)
+                loop = make_loop()
+                losses = loop.run(n_iter, resident=False)
             self.fused, self.loop_mode = True, loop.last_run_mode
             self.history += losses.cpu().tolist()   # (one conversion: 600 float() calls cost 0.1 ms of a 12 ms window)
             return loop.theta
@@ -403,23 +426,90 @@ class ContrastMaximizationMixin(object):
             self.history.append(float(loss.detach()))
         return theta.detach()
 
+    def _tpe_translation(self, contrast, rx, ry, batch: int = 32, n_candidates: int = 24, gamma: float = 0.25):
+        """``sampler: TPE`` -- a tree-structured Parzen estimator in the shape optuna runs it (src/solver/generative_max_likelihood.py:
+        216-219: ``n_startup_trials = max(10, n_iter // 10)`` uniform draws first), batched for the GPU: each round fits the two Parzen
+        densities (Gaussian kernels on the best ``gamma`` quantile of the trials so far / on the rest, per parameter, bandwidth from
+        the neighbour spacing, plus the uniform prior), draws ``n_candidates`` points per slot from the good density, keeps the one with
+        the largest l(x) / g(x), and evaluates ``batch`` such picks as ONE sweep.  optuna itself is not installed here: the algorithm
+        follows Bergstra et al. 2011 as optuna documents it, trial for trial it is not optuna's stream (parity unpinned)."""
+        rs = np.random.RandomState(self.sampler_seed)
+        lo, hi = np.array([rx["min"], ry["min"]], float), np.array([rx["max"], ry["max"]], float)
+        n_total = max(1, self.n_iter)
+        n_start = min(n_total, max(10, n_total // 10))
+        xs = rs.uniform(lo, hi, (n_start, 2))
+        vals = contrast(torch.from_numpy(xs.astype(np.float32))).double().cpu().numpy()
+
+        def log_parzen(pts, x):  # [m, 2] kernels (+ the prior) -> log density at x [k, 2], product over the two parameters
+            out = np.zeros(len(x))
+            for d in range(2):
+                mu = np.sort(pts[:, d])
+                ext = np.concatenate([[lo[d]], mu, [hi[d]]])
+                sig = np.clip(np.maximum(ext[1:-1] - ext[:-2], ext[2:] - ext[1:-1]), (hi[d] - lo[d]) / min(100.0, 1.0 + len(mu)), hi[d] - lo[d])
+                mu = np.concatenate([mu, [0.5 * (lo[d] + hi[d])]])
+                sig = np.concatenate([sig, [hi[d] - lo[d]]])   # the prior: one wide kernel in the middle of the range
+                z = (x[:, d, None] - mu[None]) / sig[None]
+                out += np.log(np.mean(np.exp(-0.5 * z * z) / (sig[None] * np.sqrt(2 * np.pi)), axis=1) + 1e-300)
+            return out
+
+        while len(xs) < n_total:
+            k = min(batch, n_total - len(xs))
+            order = np.argsort(-vals)                      # maximise the contrast
+            n_good = max(1, int(np.ceil(gamma * len(xs))))
+            good, bad = xs[order[:n_good]], xs[order[n_good:]] if len(xs) > n_good else xs
+            picks = np.empty((k, 2))
+            for j in range(k):
+                comp = rs.randint(0, len(good) + 1, n_candidates)            # (index len(good) = the prior)
+                spread = np.maximum((hi - lo) / max(4.0, np.sqrt(len(good) + 1.0)), 1e-6)
+                centre = np.where((comp == len(good))[:, None], 0.5 * (lo + hi), good[np.minimum(comp, len(good) - 1)])
+                width = np.where((comp == len(good))[:, None], hi - lo, spread)
+                cand = np.clip(centre + rs.standard_normal((n_candidates, 2)) * width, lo, hi)
+                picks[j] = cand[np.argmax(log_parzen(good, cand) - log_parzen(bad, cand))]
+            v = contrast(torch.from_numpy(picks.astype(np.float32))).double().cpu().numpy()
+            xs, vals = np.concatenate([xs, picks]), np.concatenate([vals, v])
+        return torch.from_numpy(xs.astype(np.float32)), torch.from_numpy(vals.astype(np.float32))
+
     def _estimate_translation(self, plan: EventPlan) -> torch.Tensor:
         """``optimizer.method: grid`` -- exhaustive sweep over the parameter ranges (the optuna grid sampler of
-        src/solver/generative_max_likelihood.py:238-255), optionally refined by ``refine_iters`` Adam steps;
+        src/solver/generative_max_likelihood.py:238-255); ``random`` / ``TPE`` (or ``method: optuna`` + ``optimizer.sampler``, :215-226)
+        -- n_iter uniform draws / a batched Parzen-estimator search inside the same ranges; each optionally refined by
+        ``refine_iters`` Adam steps;
         ``Adam`` -- n_iter Adam steps on (trans_x, trans_y) from the warm start (or zero), the loop shape of :306-341."""
         if self.opt_method == "Adam":
             start = self._warm_start()
             theta0 = (torch.zeros(2, dtype=torch.float32, device=plan.device) if start is None else
                       to_gpu(start, device=plan.device, dtype=torch.float32).reshape(2))
             return self._adam_translation(plan, theta0, self.n_iter)
-        if self.opt_method not in ("grid", "sweep"):
-            raise NotImplementedError(f"optimizer.method {self.opt_method!r} for a 2-DoF motion model: Adam or grid")
+        # optimizer.method: "optuna" + optimizer.sampler (src/solver/generative_max_likelihood.py:215-226) or the sampler's name as the
+        # method: grid / uniform (= sweep), random, TPE
+        sampler = self.opt_method
+        if sampler == "optuna":
+            sampler = self.sampler
+        sampler = {"sweep": "grid", "uniform": "grid", "tpe": "TPE"}.get(sampler, sampler)
+        if sampler not in ("grid", "random", "TPE"):
+            raise NotImplementedError(f"optimizer.method {self.opt_method!r} (sampler {self.sampler!r}) for a 2-DoF motion model: "
+                                      "Adam, grid / uniform, random or TPE")
         rx, ry = self._param_range("trans_x"), self._param_range("trans_y")
-        n = max(2, int(round(np.sqrt(max(self.n_iter, 4)))))
-        gx = torch.arange(n, dtype=torch.float32) * ((rx["max"] - rx["min"]) / n) + rx["min"]  # np.arange(min, max, step), :238-255
-        gy = torch.arange(n, dtype=torch.float32) * ((ry["max"] - ry["min"]) / n) + ry["min"]
-        grid = torch.stack(torch.meshgrid(gx, gy, indexing="ij"), -1).reshape(-1, 2).to(plan.device)
-        var = plan.variance_2dof(grid, self.omit_boundary, pad=(self.pad, self.pad), halo=self.halo)
+
+        def contrast(thetas: torch.Tensor) -> torch.Tensor:  # one batched launch sequence for all hypotheses of a round
+            return plan.variance_2dof(thetas.to(plan.device), self.omit_boundary, pad=(self.pad, self.pad), halo=self.halo)
+
+        if sampler == "random":
+            # optuna.samplers.RandomSampler (:220-221): n_iter independent uniform draws inside parameters.{min, max}; all of them
+            # are independent hypotheses, so they are ONE batched sweep (optimizer.seed makes the draws reproducible)
+            rs = np.random.RandomState(self.sampler_seed)
+            draws = rs.uniform([rx["min"], ry["min"]], [rx["max"], ry["max"]], (max(1, self.n_iter), 2))
+            grid = torch.from_numpy(draws.astype(np.float32))
+            var = contrast(grid)
+        elif sampler == "TPE":
+            grid, var = self._tpe_translation(contrast, rx, ry)
+        else:
+            n = max(2, int(round(np.sqrt(max(self.n_iter, 4)))))
+            gx = torch.arange(n, dtype=torch.float32) * ((rx["max"] - rx["min"]) / n) + rx["min"]  # np.arange(min, max, step), :238-255
+            gy = torch.arange(n, dtype=torch.float32) * ((ry["max"] - ry["min"]) / n) + ry["min"]
+            grid = torch.stack(torch.meshgrid(gx, gy, indexing="ij"), -1).reshape(-1, 2)
+            var = contrast(grid)
+        grid = grid.to(plan.device)
         self.history = [float(-v) for v in var.cpu()]
         self.sweep_grid, self.sweep_contrast = grid, var
         theta = grid[int(torch.argmax(var).item())]

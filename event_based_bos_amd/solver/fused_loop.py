@@ -86,6 +86,12 @@ def supported(contrast_terms: Dict[str, float], flow_terms: Dict[str, float], bl
     return method == "Adam" and objective_supported(contrast_terms, flow_terms, blur_sigma, plan, halo, sliding_window)
 
 
+class ResidentStateTorn(RuntimeError):
+    """A resident launch ended with two different verdicts among its workgroups (a wait past its cap AND a hand-over): theta and the
+    optimiser state are partly written.  The loop object is unusable; callers rebuild it from the state they started with and run
+    the four launches (``ContrastMaximization`` and ``WindowPipeline`` both do)."""
+
+
 class FusedPatchLoop(object):
     def __init__(self, plan: EventPlan, patch_size: Tuple[int, int], sliding_window: Tuple[int, int], theta0: torch.Tensor,
                  w_variance: float, w_flow_norm: float = 0.0, w_image_gradient: float = 0.0, omit_boundary: bool = False,
@@ -389,8 +395,8 @@ class FusedPatchLoop(object):
         # that of k iterations then: the launch hands over instead of discarding its work)
         self.resident_iterations = int(self.lib.ebos_cmax_resident_iterations(ptr(self._mailbox), stream_ptr()))
         if self.resident_iterations < 0:
-            raise RuntimeError("resident launch ended with two different verdicts among its workgroups (a wait past its cap AND a "
-                               "hand-over): theta and the optimiser state are partly written -- rebuild the loop from a saved state")
+            raise ResidentStateTorn("resident launch ended with two different verdicts among its workgroups (a wait past its cap AND a "
+                                    "hand-over): theta and the optimiser state are partly written -- rebuild the loop from a saved state")
         return status
 
     def run(self, n_iter: int, native: bool = True, resident: Optional[bool] = None) -> torch.Tensor:
@@ -541,7 +547,7 @@ class Fused2dofLoop(object):
         status = int(self.lib.ebos_cmax_resident_status(ptr(self._mailbox), stream_ptr()))
         self.resident_iterations = int(self.lib.ebos_cmax_resident_iterations(ptr(self._mailbox), stream_ptr()))
         if self.resident_iterations < 0:
-            raise RuntimeError("resident launch ended with two different verdicts among its workgroups: theta and the optimiser "
+            raise ResidentStateTorn("resident launch ended with two different verdicts among its workgroups: theta and the optimiser "
                                "state are partly written -- rebuild the loop from a saved state")
         return status
 

@@ -32,6 +32,7 @@ import torch
 
 from .. import _hip, ops
 from .._hip import check, stream_ptr
+from .._staging import to_gpu
 from ..data_loader import RawEventStore
 from ..event_plan import EventPlan
 from . import fused_loop
@@ -204,9 +205,13 @@ class WindowPipeline(object):
         the natively enqueued four (five) launches per iteration.  Nothing waits for the GPU."""
         s = self.solver
         out = []
+        # the start ``estimate`` honours too: the driver's set_previous_frame_best_estimation (src/solver/base.py:355-361), else zero
+        start = s._warm_start()
+        theta0 = (torch.zeros(2, dtype=torch.float32, device=self.device) if start is None else
+                  to_gpu(start, device=self.device, dtype=torch.float32).reshape(2))
         for w, plan in enumerate(plans):
             with torch.cuda.stream(streams[w]):
-                loop = fused_loop.Fused2dofLoop(plan, torch.zeros(2, dtype=torch.float32, device=self.device), s.contrast_terms["image_variance"], s.omit_boundary, s.pad, s.halo, s.lr,
+                loop = fused_loop.Fused2dofLoop(plan, theta0.clone(), s.contrast_terms["image_variance"], s.omit_boundary, s.pad, s.halo, s.lr,
                                                 capacity=max(s.n_iter, 1), blur_sigma=s.blur_sigma)
                 status, mode = [], "pipeline"
                 if resident and loop.resident_supported():

@@ -817,8 +817,9 @@ typedef struct ebos_cmax_2dof_problem {
   const uint16_t* cpix;
   const float* cdt;
   const float *cfx, *cfy;      /* compact plan of FRACTIONAL source coordinates (ebos_plan_compact_frac_f32): x - floor(x), y - floor(y)
-                                  per slot, laid out like cdt; NULL = integer source pixels.  Read by the resident launch only (the four
-                                  launches then take xs / ys / dts) */
+                                  per slot, laid out like cdt; both or neither (else EBOS_ERR_INVALID_ARG; ..._resident_supported says 0); NULL = integer
+                                  source pixels.  Read by BOTH forms of the loop: ebos_cmax_2dof_solve_f32's launches take the compact
+                                  trio + cfx / cfy when they are given and xs / ys / dts only when the trio is NULL */
   const int32_t* key_offsets;
   int64_t n;
   int H, W, tile_h, tile_w, halo, pad_h, pad_w, omit_boundary;

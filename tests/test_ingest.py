@@ -367,24 +367,57 @@ def test_fractional_compact_layout_fuzz_canonical_order():
         ev = np.stack([r, c, t, rs.randint(0, 2, n)], 1)
         ev = torch.from_numpy(ev[np.argsort(ev[:, 2], kind="stable")]).cuda()
         tile = [(32, 32), (45, 80), (32, 64), "auto"][rs.randint(0, 4)]
-        plans = [ebos.EventPlan.build(ev, (H, W), "first", True, tile=tile) for _ in range(2)]
-        fa, fb = plans[0].frac_compact, plans[1].frac_compact
-        assert fa is not None and fb is not None
-        used = 4 * int(fa[0][-1])
-        for a, b in zip(fa[1:], fb[1:]):
-            assert torch.equal(a[:used].view(torch.int32) if a.dtype == torch.float32 else a[:used], b[:used].view(torch.int32) if b.dtype == torch.float32 else b[:used]), (trial, H, W, n, tile)
-        th, tw = plans[0].tile
-        ko, grp = plans[0].key_offsets.cpu().numpy(), fa[0].cpu().numpy().astype(np.int64)
-        cdt, cfx, cfy = (a.cpu().numpy() for a in fa[2:])
-        xs, ys, dts = plans[0].x.cpu().numpy(), plans[0].y.cpu().numpy(), plans[0].dt.cpu().numpy()
-        for t_ in range(len(grp) - 1):
-            beg = ko[t_ * th * tw]
-            offs = ko[t_ * th * tw:(t_ + 1) * th * tw + 1] - beg
-            a, b = 4 * grp[t_], 4 * grp[t_] + offs[-1]
-            runs = np.repeat(np.arange(th * tw), np.diff(offs))
-            ex, ey, ed = xs[beg:beg + offs[-1]], ys[beg:beg + offs[-1]], dts[beg:beg + offs[-1]]
-            efx, efy = ex - np.trunc(ex), ey - np.trunc(ey)
-            order = np.lexsort((efy, efx, ed, runs))
-            np.testing.assert_array_equal(cdt[a:b], ed[order], err_msg=str((trial, H, W, n, tile)))
-            np.testing.assert_array_equal(cfx[a:b], efx[order].astype(np.float32))
-            np.testing.assert_array_equal(cfy[a:b], efy[order].astype(np.float32))
+        _check_frac_layout(ev, (H, W), tile, (trial, H, W, n, tile))
+
+
+def _check_frac_layout(ev, size, tile, tag):
+    import event_based_bos_amd as ebos
+
+    H, W = size
+    plans = [ebos.EventPlan.build(ev, (H, W), "first", True, tile=tile) for _ in range(2)]
+    assert plans[0].__dict__["_frac"] is None and plans[0].__dict__["_frac_pending"]   # built on the first access, not by the build
+    fa, fb = plans[0].frac_compact, plans[1].frac_compact
+    assert fa is not None and fb is not None and plans[0].frac_compact is fa
+    used = 4 * int(fa[0][-1])
+    for a, b in zip(fa[1:], fb[1:]):
+        assert torch.equal(a[:used].view(torch.int32) if a.dtype == torch.float32 else a[:used], b[:used].view(torch.int32) if b.dtype == torch.float32 else b[:used]), tag
+    th, tw = plans[0].tile
+    ko, grp = plans[0].key_offsets.cpu().numpy(), fa[0].cpu().numpy().astype(np.int64)
+    cdt, cfx, cfy = (a.cpu().numpy() for a in fa[2:])
+    xs, ys, dts = plans[0].x.cpu().numpy(), plans[0].y.cpu().numpy(), plans[0].dt.cpu().numpy()
+    for t_ in range(len(grp) - 1):
+        beg = ko[t_ * th * tw]
+        offs = ko[t_ * th * tw:(t_ + 1) * th * tw + 1] - beg
+        a, b = 4 * grp[t_], 4 * grp[t_] + offs[-1]
+        runs = np.repeat(np.arange(th * tw), np.diff(offs))
+        ex, ey, ed = xs[beg:beg + offs[-1]], ys[beg:beg + offs[-1]], dts[beg:beg + offs[-1]]
+        efx, efy = ex - np.trunc(ex), ey - np.trunc(ey)
+        order = np.lexsort((efy, efx, ed, runs))
+        np.testing.assert_array_equal(cdt[a:b], ed[order], err_msg=str(tag))
+        np.testing.assert_array_equal(cfx[a:b], efx[order].astype(np.float32))
+        np.testing.assert_array_equal(cfy[a:b], efy[order].astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["many_hot_pixels", "very_long_run", "long_run_exact_chunks"])
+def test_fractional_compact_layout_is_canonical_on_noisy_sensors(case):
+    """More than 64 hot pixels in ONE tile (the hot-pixel pass used to canonicalise the first 64 its atomics listed), and a run longer
+    than the 4 096 events one LDS sort holds (used to keep its scatter order): both canonical now."""
+    rs = np.random.RandomState({"many_hot_pixels": 1, "very_long_run": 2, "long_run_exact_chunks": 3}[case])
+    H, W = 90, 160
+    n_bg = 20_000
+    r, c = rs.uniform(0, H - 1, n_bg), rs.uniform(0, W - 1, n_bg)
+    if case == "many_hot_pixels":   # 150 hot pixels of 70 .. 400 events inside the tile at (0, 0) of a 45 x 80 tiling
+        px = rs.choice(45 * 80, 150, replace=False)
+        lens = rs.randint(70, 400, 150)
+        hr = np.repeat(px // 80, lens) + rs.choice([0.0, 0.25, 0.5, 0.75], lens.sum())
+        hc = np.repeat(px % 80, lens) + rs.choice([0.125, 0.5, 0.875], lens.sum())
+    else:
+        k = 11_111 if case == "very_long_run" else 3 * 2048
+        hr = 50 + rs.choice([0.0, 0.25, 0.5, 0.75], k)
+        hc = 100 + rs.choice([0.125, 0.5, 0.875], k)
+    r, c = np.concatenate([r, hr]), np.concatenate([c, hc])
+    t = np.round(rs.uniform(0, 0.5, len(r)), 3)   # many equal timestamps: the fractions decide
+    ev = np.stack([r, c, t, rs.randint(0, 2, len(r))], 1)
+    ev = torch.from_numpy(ev[np.argsort(ev[:, 2], kind="stable")]).cuda()
+    _check_frac_layout(ev, (H, W), (45, 80), case)

@@ -168,7 +168,7 @@ def test_bench_line_contract_single_gpu():
     assert r["bound"] in ("hbm", "valu_issue", "lds_pipe")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
     if r["bound"] != "hbm":
-        assert r["unit"] == "Gwave-inst/s" and 0 < r["frac"] <= 1.0
+        assert r["unit"] == "Gwave-inst/s" and 0 < r["frac"] <= 1.0, r   # (400 k events: a launch this small sits far below its issue roofline)
         assert r["bound"] == line["roofline_summary"]["binding"] == line["roofline_issue"]["bound"]
         assert abs(r["frac"] - line["roofline_issue"]["frac"]) < 2e-3
         hb = r["hbm_algorithmic"]
