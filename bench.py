@@ -591,6 +591,20 @@ def run_config2(R):
             best = ms if attempt == 1 else min(best or ms, ms)
         return pl, first, best
 
+    # the same window as the raw sensor columns a recording holds (src/data_loader/ccs.py:57-66: int16 x / y, int32 microseconds):
+    # the lean build straight from them (EventPlan.build_raw) -- informative, beside the build from the reference's float64 [n, 4]
+    plan_build_raw_ms = None
+    if not general and not a.no_extras and not a.no_compact:
+        raw_cols = [torch.from_numpy(v).to(dev) for v in (ev[:, 1].astype(np.int16), ev[:, 0].astype(np.int16),
+                                                           np.rint(ev[:, 2] * 1e6).astype(np.int32), ev[:, 3].astype(np.uint8))]
+        for attempt in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ebos.EventPlan.build_raw(*raw_cols, (H, W), "first", True, tile=tuple(a.tile), emit="compact")
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            plan_build_raw_ms = ms if attempt <= 1 else min(plan_build_raw_ms, ms)
+        del raw_cols
     _, _, plan_build_full_ms = time_build("full")
     # (per-event weights are permuted like the events: the full build keeps the permutation)
     plan, plan_first_ms, plan_build_ms = time_build("full" if (a.no_compact or a.weighted) else "compact")
@@ -966,6 +980,9 @@ def run_config2(R):
         line["plan_build_first_call_ms"] = round(plan_first_ms, 2)
         # one evaluation of a FRESH window (BASELINE configs[1] read literally): plan build + one step
         line["value_incl_plan_build"] = round(n / (plan_build_ms + ms_per_step) / 1e3, 2)
+        if plan_build_raw_ms is not None:  # ... when the window arrives as raw sensor columns (8 B/event instead of 32)
+            line["plan_build_raw_columns_ms"] = round(plan_build_raw_ms, 3)
+            line["value_incl_plan_build_raw_columns"] = round(n / (plan_build_raw_ms + ms_per_step) / 1e3, 2)
         # the regime a FRESH window sees: distinct windows cycled beyond the 256 MiB Infinity Cache (`value` is the resident window a
         # 600-iteration loop evaluates)
         if "rotating_windows" in extras:
