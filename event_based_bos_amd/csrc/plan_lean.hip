@@ -477,18 +477,26 @@ __device__ __forceinline__ int bitonic16_step(int key, int sub16) {
   const int mn = min(key, other), mx = max(key, other);
   return (low == up) ? mn : mx;
 }
-// sixteen keys, one per lane of a row, ascending by lane
-__device__ __forceinline__ int bitonic16(int key, int sub16) {
+// the keys of lanes 0 .. n - 1 of every row of 16 lanes, ascending by lane, n = the smallest of 2 / 4 / 8 / 16 that holds `longest`
+// (uniform over the wave: the longest run of its four rows); the lanes beyond hold a key that sorts behind every event.  A window of
+// 2 M events has ~2 events per pixel: one or three of the ten stages.
+__device__ __forceinline__ int bitonic16(int key, int sub16, int longest) {
   key = bitonic16_step<2, 1>(key, sub16);
-  key = bitonic16_step<4, 2>(key, sub16);
-  key = bitonic16_step<4, 1>(key, sub16);
-  key = bitonic16_step<8, 4>(key, sub16);
-  key = bitonic16_step<8, 2>(key, sub16);
-  key = bitonic16_step<8, 1>(key, sub16);
-  key = bitonic16_step<16, 8>(key, sub16);
-  key = bitonic16_step<16, 4>(key, sub16);
-  key = bitonic16_step<16, 2>(key, sub16);
-  key = bitonic16_step<16, 1>(key, sub16);
+  if (longest > 2) {
+    key = bitonic16_step<4, 2>(key, sub16);
+    key = bitonic16_step<4, 1>(key, sub16);
+  }
+  if (longest > 4) {
+    key = bitonic16_step<8, 4>(key, sub16);
+    key = bitonic16_step<8, 2>(key, sub16);
+    key = bitonic16_step<8, 1>(key, sub16);
+  }
+  if (longest > 8) {
+    key = bitonic16_step<16, 8>(key, sub16);
+    key = bitonic16_step<16, 4>(key, sub16);
+    key = bitonic16_step<16, 2>(key, sub16);
+    key = bitonic16_step<16, 1>(key, sub16);
+  }
   return key;
 }
 
@@ -513,7 +521,6 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
   uint16_t* a_px = reinterpret_cast<uint16_t*>(s_dt + sort_cap);      // [sort_cap]
   uint16_t* s_px = a_px + sort_cap;                                    // [sort_cap]  (contiguous with a_px)
   __shared__ int32_t s_wave[kSortBlock / kWave];
-  __shared__ int32_t s_carry;
   __shared__ int32_t s_arrived;
   // XCD-aware order: workgroups b and b + 8 share an XCD (its L2), and the runs of CONSECUTIVE bins lie next to each other in every
   // chunk of the staged streams -- a 128-byte line of staged pixels holds the runs of ~8 bins.  With bin = blockIdx the eight bins of
@@ -568,34 +575,28 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
         my_pos = __shfl(wave_base, kWave - 1, kWave) + inc - my_cnt;
       }
       const int64_t wave_chunk0 = blk + (threadIdx.x & ~(kWave - 1));
-      payload_t v[16];
-      int cnt[8], pos[8];
-      int64_t src[8];
       const int i0 = lane & 7;
+      // (sixteen elements of every run per pass: one pass for the runs of a large uniform window; a window of fewer, longer runs --
+      // 2 M events are 512 chunks, ~15 events per run -- takes further passes, each with its sixteen loads in flight: as a rolled
+      // loop of dependent loads behind the first pass they cost a round trip per eight elements)
+      for (int base = 0; __ballot(my_cnt > base) != 0ull; base += 16) {
+        payload_t v[16];
+        int cnt[8], pos[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int r = 8 * k + (lane >> 3);
-        cnt[k] = __shfl(my_cnt, r, kWave);
-        pos[k] = kPos ? __shfl(my_pos, r, kWave) : 0;
-        // (an empty run -- also the lanes beyond the last chunk -- loads the first staged element: mapped, unused)
-        const int off = __shfl(my_off, r, kWave);
-        src[k] = cnt[k] > 0 ? (wave_chunk0 + r) * g.chunk + off : 0;
-        v[2 * k] = load(src[k] + min(i0, max(cnt[k] - 1, 0)));
-        v[2 * k + 1] = load(src[k] + min(i0 + 8, max(cnt[k] - 1, 0)));
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (i0 < cnt[k]) use(v[2 * k], pos[k] + i0);
-        if (i0 + 8 < cnt[k]) use(v[2 * k + 1], pos[k] + i0 + 8);
-      }
-      // (runs beyond 16 events: rolled, and re-derived by shuffle -- cnt / pos / src indexed by a loop variable would live in scratch)
-      if (__ballot(my_cnt > 16) != 0ull) {
-#pragma unroll 1
         for (int k = 0; k < 8; ++k) {
           const int r = 8 * k + (lane >> 3);
-          const int cnt_k = __shfl(my_cnt, r, kWave), off_k = __shfl(my_off, r, kWave), pos_k = kPos ? __shfl(my_pos, r, kWave) : 0;
-          const int64_t src_k = (wave_chunk0 + r) * g.chunk + off_k;
-          for (int i = i0 + 16; i < cnt_k; i += 8) use(load(src_k + i), pos_k + i);
+          cnt[k] = __shfl(my_cnt, r, kWave) - base;
+          pos[k] = (kPos ? __shfl(my_pos, r, kWave) : 0) + base;
+          // (an empty run -- also the lanes beyond the last chunk -- loads the first staged element: mapped, unused)
+          const int off = __shfl(my_off, r, kWave);
+          const int64_t src = cnt[k] > 0 ? (wave_chunk0 + r) * g.chunk + off + base : 0;
+          v[2 * k] = load(src + min(i0, max(cnt[k] - 1, 0)));
+          v[2 * k + 1] = load(src + min(i0 + 8, max(cnt[k] - 1, 0)));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (i0 < cnt[k]) use(v[2 * k], pos[k] + i0);
+          if (i0 + 8 < cnt[k]) use(v[2 * k + 1], pos[k] + i0 + 8);
         }
       }
     }
@@ -645,14 +646,14 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
   }
   __syncthreads();
   EBOS_LSTAMP(1, 1);
-  // exclusive scan of s_cnt [n_pix]
+  // exclusive scan of s_cnt [n_pix]: every thread a stretch of consecutive pixels, ONE scan over the workgroup (a band of a sparse
+  // window is a whole tile, 3 600 pixels: as four rounds of a 1024-wide scan, three barriers each, the step took 4.3 us)
   const int wid = threadIdx.x / kWave;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  for (int start = 0; start < n_pix; start += kSortBlock) {
-    const int i = start + threadIdx.x;
-    const int32_t v = i < n_pix ? s_cnt[i] : 0;
-    int32_t inc = v;
+  {
+    const int per = (n_pix + kSortBlock - 1) / kSortBlock, p0 = threadIdx.x * per;
+    int32_t mine = 0;
+    for (int j = 0; j < per; ++j) mine += p0 + j < n_pix ? s_cnt[p0 + j] : 0;
+    int32_t inc = mine;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
       const int32_t o = __shfl_up(inc, off, kWave);
@@ -660,17 +661,16 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
     }
     if (lane == kWave - 1) s_wave[wid] = inc;
     __syncthreads();
-    int32_t wave_off = 0;
-    for (int k = 0; k < wid; ++k) wave_off += s_wave[k];
-    const int32_t carry = s_carry;
-    if (i < n_pix) {
-      const int32_t ex = carry + wave_off + inc - v;
-      s_cnt[i] = ex;
-      s_cur[i] = ex;
-      key_offsets[first_key + i] = seg0 + ex;
-    }
-    __syncthreads();
-    if (threadIdx.x == kSortBlock - 1) s_carry = carry + wave_off + inc;
+    int32_t run = inc - mine;
+    for (int k = 0; k < wid; ++k) run += s_wave[k];
+    for (int j = 0; j < per; ++j)
+      if (p0 + j < n_pix) {
+        const int32_t c = s_cnt[p0 + j];
+        s_cnt[p0 + j] = run;
+        s_cur[p0 + j] = run;
+        key_offsets[first_key + p0 + j] = seg0 + run;
+        run += c;
+      }
     __syncthreads();
   }
   EBOS_LSTAMP(1, 2);
@@ -786,7 +786,29 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
     // against its run cost ~14 instructions per comparison and a run's length squared of them: ~150 per event, 17 of a workgroup's
     // 35 us (VALU-bound: the latency of the LDS reads was not it -- four reads in flight changed nothing).  Equal keys are equal
     // values: the network's instability is invisible.
-    {
+    // (uniform) a SPARSE chunk -- fewer than four events per pixel: the bands of a 2 M-event window are whole tiles of 3 600 pixels
+    // with ~2 events each -- ranks its events one by one instead: the pass over the pixels costs per PIXEL (57 rounds of dependent LDS
+    // reads for 7 800 events: 21 us), a rank costs the run's length
+    const bool sparse = m < 4 * (p_hi - p_lo);
+    if (sparse) {
+      for (int i = threadIdx.x; i < m; i += kSortBlock) {
+        const unsigned px = (unsigned)s_px[i];
+        const int pi = ((int)(px >> 8) - r0) * g.tw + (int)(px & 255u);
+        const int rb = s_cnt[pi] - c0, re = run_end(pi) - c0;
+        const float d = s_dt[i];
+        int slot = i;
+        if (re - rb > 1 && re - rb <= kLeanCanon) {   // (a hot run stands sorted already: the network above)
+          const int kd = sort_key(d);
+          int rank = 0;
+          for (int j = rb; j < re; ++j) {
+            const int kj = sort_key(s_dt[j]);
+            rank += (kj < kd || (kj == kd && j < i)) ? 1 : 0;
+          }
+          slot = rb + rank;
+        }
+        cdt[out0 + c0 + slot] = d;
+      }
+    } else {
       const int sub16 = lane & 15;
       for (int p0 = p_lo; p0 < p_hi; p0 += kSortBlock / 16) {   // (a row of 16 lanes per pixel; whole waves stay in the loop: DPP reads its neighbours)
         const int pi = p0 + (threadIdx.x >> 4);
@@ -795,7 +817,9 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
         const bool small = L <= 16;
         // (keys as integers with the floats' order; the padding sorts behind every event and is never written back)
         int key = small && sub16 < L ? sort_key(s_dt[rb + sub16]) : 0x7fffffff;
-        key = bitonic16(key, sub16);
+        // (the longest of the wave's four runs, uniform: ballots of the thresholds -- empty and single-event pixels need no network)
+        const int longest = __ballot(small && L > 8) != 0ull ? 16 : (__ballot(small && L > 4) != 0ull ? 8 : (__ballot(small && L > 2) != 0ull ? 4 : (__ballot(small && L > 1) != 0ull ? 2 : 1)));
+        if (longest > 1) key = bitonic16(key, sub16, longest);
         if (small && sub16 < L) cdt[out0 + c0 + rb + sub16] = __int_as_float(key ^ ((key >> 31) & 0x7fffffff));   // (sort_key is its own inverse)
         // a longer run (one pixel in sixty of a uniform window) goes on a list (the cursors' array is free by now)
         if (!small && sub16 == 0) s_cur[atomicAdd(&s_nlong, 1)] = pi;
@@ -804,7 +828,7 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
     __syncthreads();
     // ... and the listed runs, 32 lanes each: every event to the slot of its rank in its run -- O(run) LDS reads per event --; a hot run
     // stands sorted already (the network above) and is copied out.  (In the list's order, which is the atomics': the runs are independent.)
-    {
+    if (!sparse) {
       const int n_long = s_nlong, sub32 = lane & 31;
       for (int q = threadIdx.x >> 5; q < n_long; q += kSortBlock / 32) {
         const int pi = s_cur[q];
