@@ -507,6 +507,98 @@ __device__ __forceinline__ int sort_key(float d) {
   return b ^ ((b >> 31) & 0x7fffffff);
 }
 
+// what a staged record holds: the pixel inside its tile and the timestamp's bits (4 or 8 of them)
+struct LeanRec {
+  unsigned pix;
+  unsigned long long stamp;
+};
+// staged timestamp -> dt in fp64, exactly as events_to_soa_kernel / raw_to_soa_kernel (event_plan.hip): reference time and period from
+// the window's min / max (K1 left them in sc.tm)
+struct LeanClock {
+  double ref, inv_period, tps;
+  bool raw, wide;
+  __device__ __forceinline__ LeanClock(const LeanScratch& sc, const LeanTime& tc) {
+    raw = tc.src == SRC_RAW32 || tc.src == SRC_RAW64;
+    wide = tc.src == SRC_AOS_F64 || tc.src == SRC_RAW64;   // (uniform) 8-byte stamps
+    tps = tc.ticks_per_second;
+    double tmin = unordered(sc.tm[0]), tmax = unordered(sc.tm[1]);
+    if (raw) {
+      tmin = tmin / tps;
+      tmax = tmax / tps;
+    } else if (tc.src == SRC_AOS_F32) {
+      tmin = (double)(float)tmin;  // (exact: they are f32 values)
+      tmax = (double)(float)tmax;
+    }
+    if (tc.ref_mode == EBOS_REF_FIRST) ref = tmin;
+    else if (tc.ref_mode == EBOS_REF_LAST) ref = tmax;
+    else ref = tmin + (tmax - tmin) * tc.ref_fraction;
+    inv_period = tc.normalize_t ? 1.0 / (tmax - tmin) : 1.0;
+  }
+  __device__ __forceinline__ float dt(const LeanRec& r) const {   // (selects, no branches: sixteen of these stand unrolled in the gather)
+    const double t8 = raw ? (double)(long long)r.stamp / tps : __longlong_as_double((long long)r.stamp);
+    const double t4 = raw ? (double)(int32_t)(unsigned)r.stamp / tps : (double)__uint_as_float((unsigned)r.stamp);
+    return (float)(((wide ? t8 : t4) - ref) * inv_period);
+  }
+};
+
+// The events of one bin: one run per chunk of the staged streams, (offset, count) in the bin's row of the table.  A thread owns a
+// chunk's entry; its wave walks the 64 runs eight at a time, EIGHT LANES PER RUN, sixteen elements of every run per pass -- all of them
+// LOADED before the first one is used (sixteen loads in flight: one by one, each followed by the LDS atomic that consumes it, the
+// gather was a chain of ~25 round trips per wave and the bin sort took 200 us for 10 M events).  One pass for the runs of a large
+// uniform window (~6 events); a window of fewer, longer runs -- 2 M events are 512 chunks, ~15 events per run, a whole TILE's runs
+// ~25 -- takes further passes.  load(index into the staged streams) -> payload; use(payload, arrival index): POS hands every element
+// a slot of its own in [0, events of the bin) -- its wave reserves a stretch for its 64 runs (one LDS atomic per wave and BLOCK
+// chunks), a run's elements follow each other inside it.
+template <bool POS, int BLOCK, typename Load, typename Use>
+__device__ __forceinline__ void lean_gather(const LeanScratch& sc, const LeanGeom& g, int bin, int n_chunks, int32_t* s_arrived, Load&& load,
+                                            Use&& use) {
+  typedef decltype(load((int64_t)0)) payload_t;
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned* __restrict__ my_tab = sc.tab + (int64_t)bin * n_chunks;
+  unsigned e_next = (int)threadIdx.x < n_chunks ? my_tab[threadIdx.x] : 0u;
+  for (int blk = 0; blk < n_chunks; blk += BLOCK) {
+    const unsigned e = e_next;
+    const int c_next = blk + BLOCK + threadIdx.x;   // (the next BLOCK chunks' entries travel while these are walked)
+    e_next = c_next < n_chunks ? my_tab[c_next] : 0u;
+    const int my_cnt = (int)(e >> kTabShift), my_off = (int)(e & kTabMask);
+    if (__ballot(my_cnt > 0) == 0ull) continue;   // (uniform per wave)
+    int my_pos = 0;
+    if (POS) {
+      int inc = my_cnt;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(inc, off, kWave);
+        if (lane >= off) inc += o;
+      }
+      int wave_base = 0;
+      if (lane == kWave - 1) wave_base = atomicAdd(s_arrived, inc);
+      my_pos = __shfl(wave_base, kWave - 1, kWave) + inc - my_cnt;
+    }
+    const int64_t wave_chunk0 = blk + (threadIdx.x & ~(kWave - 1));
+    const int i0 = lane & 7;
+    for (int base = 0; __ballot(my_cnt > base) != 0ull; base += 16) {
+      payload_t v[16];
+      int cnt[8], pos[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = 8 * k + (lane >> 3);
+        cnt[k] = __shfl(my_cnt, r, kWave) - base;
+        pos[k] = (POS ? __shfl(my_pos, r, kWave) : 0) + base;
+        // (an empty run -- also the lanes beyond the last chunk -- loads the first staged element: mapped, unused)
+        const int off = __shfl(my_off, r, kWave);
+        const int64_t src = cnt[k] > 0 ? (wave_chunk0 + r) * g.chunk + off + base : 0;
+        v[2 * k] = load(src + min(i0, max(cnt[k] - 1, 0)));
+        v[2 * k + 1] = load(src + min(i0 + 8, max(cnt[k] - 1, 0)));
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (i0 < cnt[k]) use(v[2 * k], pos[k] + i0);
+        if (i0 + 8 < cnt[k]) use(v[2 * k + 1], pos[k] + i0 + 8);
+      }
+    }
+  }
+}
+
 // one workgroup per bin: counting sort of the bin's segment by pixel -> key_offsets of the band, cpix / cdt at their final slots
 __global__ void __launch_bounds__(kSortBlock)
 lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp_offsets, int32_t* __restrict__ key_offsets,
@@ -541,94 +633,16 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
   if (threadIdx.x == 0) s_arrived = 0;
   __syncthreads();
   const bool staged = len <= sort_cap;
-  // The bin's events: one run per chunk of the staged stream, (offset, count) in the table's column of this bin.  A thread owns a
-  // chunk's entry; its wave walks the 64 runs eight at a time, EIGHT LANES PER RUN (a run of a uniform window holds ~8 events: 16
-  // contiguous bytes of pixels, 32 - 64 of timestamps per group and step).  The first two elements a lane owes to each of its eight
-  // runs -- all of a run of up to 16 events -- are LOADED before the first one is used (sixteen loads in flight: one by one, each
-  // followed by the LDS atomic that consumes it, the two gathers were a chain of ~25 round trips per wave and the pass took 200 us
-  // for 10 M events); what a longer run still holds follows in a rolled loop.  load(index into the staged streams) -> payload,
-  // use(payload).
   const int lane = threadIdx.x & (kWave - 1);
-  // use(payload, arrival index): with_pos hands every element a slot of its own in [0, len) -- its wave reserves a stretch for the 64
-  // runs it walks (one LDS atomic per wave and 1024 chunks), a run's elements follow each other inside it
-  auto for_each_staged = [&](auto with_pos, auto&& load, auto&& use) {
-    typedef decltype(load((int64_t)0)) payload_t;
-    constexpr bool kPos = decltype(with_pos)::value;
-    const unsigned* __restrict__ my_tab = sc.tab + (int64_t)bin * n_chunks;
-    unsigned e_next = threadIdx.x < n_chunks ? my_tab[threadIdx.x] : 0u;
-    for (int blk = 0; blk < n_chunks; blk += kSortBlock) {
-      const unsigned e = e_next;
-      const int c_next = blk + kSortBlock + threadIdx.x;   // (the next 1024 chunks' entries travel while these are walked)
-      e_next = c_next < n_chunks ? my_tab[c_next] : 0u;
-      const int my_cnt = (int)(e >> kTabShift), my_off = (int)(e & kTabMask);
-      if (__ballot(my_cnt > 0) == 0ull) continue;   // (uniform per wave)
-      int my_pos = 0;
-      if (kPos) {
-        int inc = my_cnt;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-          const int o = __shfl_up(inc, off, kWave);
-          if (lane >= off) inc += o;
-        }
-        int wave_base = 0;
-        if (lane == kWave - 1) wave_base = atomicAdd(&s_arrived, inc);
-        my_pos = __shfl(wave_base, kWave - 1, kWave) + inc - my_cnt;
-      }
-      const int64_t wave_chunk0 = blk + (threadIdx.x & ~(kWave - 1));
-      const int i0 = lane & 7;
-      // (sixteen elements of every run per pass: one pass for the runs of a large uniform window; a window of fewer, longer runs --
-      // 2 M events are 512 chunks, ~15 events per run -- takes further passes, each with its sixteen loads in flight: as a rolled
-      // loop of dependent loads behind the first pass they cost a round trip per eight elements)
-      for (int base = 0; __ballot(my_cnt > base) != 0ull; base += 16) {
-        payload_t v[16];
-        int cnt[8], pos[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int r = 8 * k + (lane >> 3);
-          cnt[k] = __shfl(my_cnt, r, kWave) - base;
-          pos[k] = (kPos ? __shfl(my_pos, r, kWave) : 0) + base;
-          // (an empty run -- also the lanes beyond the last chunk -- loads the first staged element: mapped, unused)
-          const int off = __shfl(my_off, r, kWave);
-          const int64_t src = cnt[k] > 0 ? (wave_chunk0 + r) * g.chunk + off + base : 0;
-          v[2 * k] = load(src + min(i0, max(cnt[k] - 1, 0)));
-          v[2 * k + 1] = load(src + min(i0 + 8, max(cnt[k] - 1, 0)));
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (i0 < cnt[k]) use(v[2 * k], pos[k] + i0);
-          if (i0 + 8 < cnt[k]) use(v[2 * k + 1], pos[k] + i0 + 8);
-        }
-      }
-    }
-  };
-  // reference time and period in fp64, exactly as events_to_soa_kernel / raw_to_soa_kernel (event_plan.hip)
-  const bool raw = tc.src == SRC_RAW32 || tc.src == SRC_RAW64;
-  double tmin = unordered(sc.tm[0]), tmax = unordered(sc.tm[1]);
-  if (raw) {
-    tmin = tmin / tc.ticks_per_second;
-    tmax = tmax / tc.ticks_per_second;
-  } else if (tc.src == SRC_AOS_F32) {
-    tmin = (double)(float)tmin;  // (exact: they are f32 values)
-    tmax = (double)(float)tmax;
-  }
-  double ref;
-  if (tc.ref_mode == EBOS_REF_FIRST) ref = tmin;
-  else if (tc.ref_mode == EBOS_REF_LAST) ref = tmax;
-  else ref = tmin + (tmax - tmin) * tc.ref_fraction;
-  const double inv_period = tc.normalize_t ? 1.0 / (tmax - tmin) : 1.0;
-  struct Rec {
-    unsigned pix;
-    unsigned long long stamp;
-  };
-  const bool wide = tc.src == SRC_AOS_F64 || tc.src == SRC_RAW64;   // (uniform) 8-byte stamps
-  auto dt_of = [&](const Rec& r) {   // (selects, no branches: sixteen of these stand unrolled in the gather)
-    const double t8 = raw ? (double)(long long)r.stamp / tc.ticks_per_second : __longlong_as_double((long long)r.stamp);
-    const double t4 = raw ? (double)(int32_t)(unsigned)r.stamp / tc.ticks_per_second : (double)__uint_as_float((unsigned)r.stamp);
-    const double ts = wide ? t8 : t4;
-    return (float)((ts - ref) * inv_period);
-  };
+  const LeanClock clock(sc, tc);
+  typedef LeanRec Rec;
+  auto dt_of = [&](const Rec& r) { return clock.dt(r); };
+  const bool wide = clock.wide;
   auto load8 = [&](int64_t i) { return Rec{(unsigned)sc.stage_px[i], static_cast<const unsigned long long*>(sc.stage_t)[i]}; };
   auto load4 = [&](int64_t i) { return Rec{(unsigned)sc.stage_px[i], (unsigned long long)static_cast<const unsigned*>(sc.stage_t)[i]}; };
+  auto for_each_staged = [&](auto with_pos, auto&& load, auto&& use) {
+    lean_gather<decltype(with_pos)::value, kSortBlock>(sc, g, bin, n_chunks, &s_arrived, load, use);
+  };
   if (staged) {
     // ONE gather: pixel and timestamp of every event of the bin, dt, into the arrival buffer; the pixel histogram beside it.  (As two
     // gathers -- pixels for the histogram, then pixels + timestamps for the placement -- the second one's table entries and loads were

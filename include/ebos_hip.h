@@ -242,9 +242,11 @@ int ebos_plan_parts(const int32_t* key_offsets, int H, int W, int tile_h, int ti
 
 /* Lean plan build: the compact plan (below) straight from the window -- AoS float32 / float64 [n, 4] = (x = row, y = col, t, p)
  * as the reference's loader hands it over (src/data_loader/ccs.py:289-297), or the raw sensor columns (:57-66) -- without
- * the SoA arrays and the permutation that only per-event weights and fractional source coordinates need.  Two-level
- * counting sort (chunk -> (tile, row band) -> source pixel) whose scattered writes complete inside the L2 / LDS; no
- * global atomics per event.  Outputs exactly what ebos_bin_events_f32 + ebos_plan_compact_f32 produce:
+ * the SoA arrays and the permutation that only per-event weights and fractional source coordinates need.  The window is read
+ * ONCE: every chunk of it is counting-sorted by (tile, row band) inside LDS and staged as a coalesced stream, one workgroup per
+ * band then gathers its runs, sorts them by source pixel in LDS and puts every pixel's events in ascending dt (two builds of one
+ * window hold identical arrays); no global atomics per event, no scattered writes.  Outputs exactly what ebos_bin_events_f32 +
+ * ebos_plan_compact_f32 produce:
  *     key_offsets [n_keys + 1], grp_offsets [tiles + 1], cpix / cdt [capacity_slots >= n + 3 tiles + 4]
  * (the order of the events inside one source pixel is unspecified in both), plus
  *     counts [2] (device int32): events outside the image (dropped), kept events with a fractional / negative source
@@ -252,14 +254,13 @@ int ebos_plan_parts(const int32_t* key_offsets, int H, int W, int tile_h, int ti
  *     tminmax [2] (device double, nullable): (min t, max t) of the window in seconds.
  *   source: 0 = `events` float32 [n, 4], 1 = `events` float64 [n, 4], 2 / 3 = raw columns with int32 / int64 ticks.
  *   ref_mode: EBOS_REF_FIRST / LAST / FRACTION; dt = (t - t_ref) [/ (tmax - tmin) if normalize_t], evaluated in fp64.
- *   scratch: >= ebos_plan_lean_scratch_bytes(...) bytes (8 B per event + histograms).  1 <= n < 2^31. */
+ *   scratch: >= ebos_plan_lean_scratch_bytes(...) bytes (10 B per event + the chunks' bin tables).  1 <= n < 2^31. */
 size_t ebos_plan_lean_scratch_bytes(int64_t n, int H, int W, int tile_h, int tile_w);
 int ebos_plan_lean(int source, const void* events, const int16_t* col, const int16_t* row, const void* t,
                    double ticks_per_second, int64_t n, int ref_mode, double ref_fraction, int normalize_t, int H, int W,
                    int tile_h, int tile_w, int32_t* key_offsets, int32_t* grp_offsets, uint16_t* cpix, float* cdt,
                    int64_t capacity_slots, int32_t* counts, double* tminmax, void* scratch, size_t scratch_bytes,
                    ebos_stream_t stream);
-
 /* Compact plan: the 6 B/event layout of the tile-private kernels, valid when every source coordinate is a
  * non-negative integer (frac_count == 0; camera events always are).  Per tile t the events occupy the groups
  * [grp_offsets[t], grp_offsets[t+1]) of 4 slots (16-byte vector loads, tiles start on a group boundary):

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--modes", nargs="*", default=["pipeline", "resident", "resident_forced"])
     ap.add_argument("--no-uniform", action="store_true", help="skip the uniform window (for a kernel trace of one distribution)")
+    ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile of the plan (default: choose_tile -- 45 x 80 at 1280 x 720)")
     a = ap.parse_args()
     lib = ebos._hip.require_gpu()
     patch = (24, 32)
@@ -53,9 +54,9 @@ def main():
     for n in a.events:
         for sigma in ([] if a.no_uniform else [None]) + list(a.sigma):
             rs = np.random.RandomState(0)
-            plan = ebos.EventPlan.build(torch.from_numpy(window(n, sigma, rs)).cuda(), (H, W), "first", True, tile="auto", emit="compact")
+            plan = ebos.EventPlan.build(torch.from_numpy(window(n, sigma, rs)).cuda(), (H, W), "first", True, tile=tuple(a.tile) if a.tile else "auto", emit="compact")
             tiles = plan.key_offsets[::plan.tile[0] * plan.tile[1]].diff().float()
-            row = {"events": n, "sigma_px": sigma, "fullest_tile_over_average": round(float(tiles.max() / tiles.mean()), 1)}
+            row = {"events": n, "sigma_px": sigma, "tile": list(plan.tile), "fullest_tile_over_average": round(float(tiles.max() / tiles.mean()), 1)}
             last = {}
             for mode, res, env in (("pipeline", False, None), ("resident", True, None), ("resident_forced", True, "0")):
                 if mode not in a.modes:
