@@ -219,3 +219,17 @@ def test_two_ranks_on_one_gpu_time_no_collective():
     body = src[src.index("def one_block(prof)"):src.index("while sum(blocks)")]
     # the order in the source: synchronize -> take the time -> barrier -> MAX
     assert body.index("torch.cuda.synchronize()") < body.index("dt = time.perf_counter() - t0") < body.rindex("self.sync_all()") < body.index("max_over_ranks(dt)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,flags", [(3, ["--events", "300000", "--cpu-sample", "300000"]), (4, ["--windows", "4", "--events", "200000"]),
+                                          (5, ["--events", "400000"])])
+def test_bench_line_of_the_other_configs_single_gpu(config, flags):
+    """`bench.py --config 3 | 4 | 5` on one GPU prints the contract's line too (a regression of round 6: config 3's line referred to a
+    field only config 2's carries and died after its timed region -- no test ran it)."""
+    line = _bench("--config", str(config), "--steps", "2", "--warmup", "1", "--min-seconds", "0.01", *flags)
+    for k in CONTRACT:
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "workload" in line["config"]
+    assert f"configs[{config - 1}]" in line["config"]["workload"] or "NOT the BASELINE" in line["config"]["workload"]
+    assert line["roofline"]["bound"] in ("hbm", "valu_issue", "lds_pipe") and line["roofline"]["frac"] > 0
