@@ -68,6 +68,19 @@ bool tiles_fit_device(int n_tiles, const char* what) {
   return true;
 }
 
+// outer_padding (src/event_image_converter.py:29-34) inside the resident kernels: every tile's window reaches at least the padding ring
+// (so that the border tile that owns a ring pixel gathers everything deposited there), which has to stay a window the kernel's
+// exchange of halos between direct neighbours covers: less than half a tile, at most the built halo
+bool resident_padding_ok(int pad_h, int pad_w, int tile_h, int tile_w, int halo, const char* what) {
+  const int pw4 = (pad_w + 3) & ~3;   // (windows are whole quads of columns)
+  if (pad_h < 0 || pad_w < 0 || pad_h > halo || pw4 > halo || 2 * pad_h >= tile_h || 2 * pw4 >= tile_w) {
+    set_error("%s: image padding %dx%d does not fit the windows of tile %dx%d halo %d (less than half a tile, at most the halo)", what,
+              pad_h, pad_w, tile_h, tile_w, halo);
+    return false;
+  }
+  return true;
+}
+
 // the geometry / objective a resident launch takes; reason in ebos_last_error otherwise
 bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
   const int halo = decode_halo(q->halo).halo;
@@ -79,10 +92,11 @@ bool resident_problem_ok(const ebos_cmax_patch_problem* q) {
   }
   // splits: 1, or 0 = "adaptive work items" (a table the four-launch pipeline splits crowded tiles by: the resident kernel always
   // runs one workgroup per tile and does not read it -- same objective, slab sums in another order where a tile was split)
-  if (q->splits > 1 || q->splits < 0 || q->pad_h != 0 || q->pad_w != 0) {
-    set_error("resident solve: one work item per tile and no image padding (splits = %d, pad %dx%d)", q->splits, q->pad_h, q->pad_w);
+  if (q->splits > 1 || q->splits < 0) {
+    set_error("resident solve: one work item per tile (splits = %d)", q->splits);
     return false;
   }
+  if (!resident_padding_ok(q->pad_h, q->pad_w, q->tile_h, q->tile_w, halo, "resident solve")) return false;
   if ((q->w_gradient_magnitude != 0.0f) == (q->w_variance != 0.0f)) {
     set_error("resident solve: exactly one of w_variance / w_gradient_magnitude must be non-zero");
     return false;
@@ -166,10 +180,11 @@ bool resident_2dof_ok(const ebos_cmax_2dof_problem* q) {
     set_error("resident 2-DoF solve: cfx and cfy come together (fractional source coordinates) or not at all");
     return false;
   }
-  if (q->splits > 1 || q->splits < 0 || q->pad_h != 0 || q->pad_w != 0) {
-    set_error("resident 2-DoF solve: one work item per tile and no image padding (splits = %d, pad %dx%d)", q->splits, q->pad_h, q->pad_w);
+  if (q->splits > 1 || q->splits < 0) {
+    set_error("resident 2-DoF solve: one work item per tile (splits = %d)", q->splits);
     return false;
   }
+  if (!resident_padding_ok(q->pad_h, q->pad_w, q->tile_h, q->tile_w, halo, "resident 2-DoF solve")) return false;
   if (q->w_variance == 0.0f) {
     set_error("resident 2-DoF solve: w_variance is 0");
     return false;

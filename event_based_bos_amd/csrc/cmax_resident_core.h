@@ -33,6 +33,12 @@
 // and the whole grid leaves; theta and the optimiser state are written back only by a launch that completed, so the host can
 // fall back to the four-launch pipeline from unchanged state (ebos_cmax_resident_status).  Taps beyond the LDS window (the
 // spill path of the four-launch pipeline, global atomics) end the launch the same way: correct for any flow, fast for BOS-sized ones.
+//
+// outer_padding (src/event_image_converter.py:29-34; round 6): the image is [H + 2 pad_h, W + 2 pad_w] while tiles, flow and grid live
+// on the H x W source pixels.  Everything the kernel does in IMAGE coordinates (the own-part decode, the gather, the contrasts' passes,
+// publish, the valid region) runs on the padded image with the tile origins shifted by the padding; every window is widened to at
+// least the padding ring, so that the border tile that OWNS a ring pixel (publishes it, counts its square) has gathered whatever any
+// neighbour deposited there -- a neighbour's larger run-time window was what kept padded problems on the four launches before.
 #pragma once
 #include <algorithm>
 #include <cstdlib>
@@ -120,6 +126,7 @@ struct ResidentArgs {
   EvPtrs ev;
   const int32_t* key_offsets;
   int H, W, tiles_y, tiles_x;
+  int pad_h, pad_w;      // outer_padding of the image (src/event_image_converter.py:29-34): the IWE is [H + 2 pad_h, W + 2 pad_w]
   GridSrc gs;
   float *theta, *d_theta, *exp_avg, *exp_avg_sq;
   const float* theta_mask;
@@ -200,7 +207,7 @@ __device__ __forceinline__ void book_loss(const Args& a, int j, int lane, const 
   R = wave_sum(R);
   if (lane == 0) {
     const int lo_px = a.omit ? 1 : 0;
-    const double n_px = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
+    const double n_px = (double)max(a.H + 2 * a.pad_h - 2 * lo_px, 0) * (double)max(a.W + 2 * a.pad_w - 2 * lo_px, 0);
     const double S = s_hist[(j & 1) * 2], mn = s_hist[(j & 1) * 2 + 1];
     // (gradient magnitude: Q is the sum of the squared Sobel pairs, the contrast their mean -- gradmag_fused_finalize_kernel)
     const float var_f = a.gm ? (float)(Q / n_px) : (float)((Q - S * mn) / (n_px - 1.0));
@@ -436,22 +443,27 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         if (!(EBOS_ABL & 1)) tile_flow_from_cells<TH, TW, 0>(s_lerp + AP, s_lerp + PH + AP, s_cells, gi0, gj0, s_flow_f);
       __syncthreads();
       win = tile_bound_read<TH, TW, HALO, true>(sh.bound, a.dt_bound);
+      // A padded image: every window reaches at least the padding ring (rows pad_h, columns pad_w rounded to the windows' quads), so
+      // that the border tile that OWNS a ring pixel -- publishes it, counts its square -- also gathers it, whatever window the
+      // neighbour that deposits there chose (round 5 left padded problems to the four launches for this; host-checked: <= HALO)
+      win.hr = max(win.hr, a.pad_h);
+      win.hc = max(win.hc, (a.pad_w + 3) & ~3);
       EBOS_RSTAMP(1);
       // (own: what this tile's image holds inside the valid region -- its share of sum(IWE), exact; with the blur: of sum(m . B x),
       // position-weighted)
       auto body = [&](auto& own) {
         if (!(EBOS_ABL & 2048))
         tile_body<TH, TW, HALO, false, ACC_FX, FMT_COMPACT, UNI, !UNI, true, false, FRAC>(tr, win, UNI ? s_cells : s_flow_f, s_acc, sh, ev, a.H, a.W,
-                                                                                    tiles_x, 0, 0, a.slabs, nullptr, nullptr, 0u, nullptr, pre,
+                                                                                    tiles_x, a.pad_h, a.pad_w, a.slabs, nullptr, nullptr, 0u, nullptr, pre,
                                                                                     NoHook{}, own);
       };
       double os;
       if constexpr (CONTRAST == RC_BLURRED_VARIANCE) {
-        OwnSumBlur own{tr.ty * TH - win.HR(), tr.tx * TW - win.HC(), a.omit ? 1 : 0, a.H, a.W, a.blur, 0.0, 0.0};
+        OwnSumBlur own{tr.ty * TH - win.HR() + a.pad_h, tr.tx * TW - win.HC() + a.pad_w, a.omit ? 1 : 0, a.H + 2 * a.pad_h, a.W + 2 * a.pad_w, a.blur, 0.0, 0.0};
         body(own);
         os = own.total();
       } else {
-        OwnSum own{tr.ty * TH - win.HR(), tr.tx * TW - win.HC(), a.omit ? 1 : 0, a.H, a.W, 0.0};
+        OwnSum own{tr.ty * TH - win.HR() + a.pad_h, tr.tx * TW - win.HC() + a.pad_w, a.omit ? 1 : 0, a.H + 2 * a.pad_h, a.W + 2 * a.pad_w, 0.0};
         body(own);
         os = own.acc;
       }
@@ -504,7 +516,8 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       }
       EBOS_RSTAMP(3);
       {  // while the records travel: the own part of the gather below (needs nothing of the others)
-        const int H = a.H, W = a.W, tr0 = ty * TH, tc0 = tx * TW;
+        // (IMAGE coordinates from here on: the padded image [H, W], the tile's origin shifted by the padding)
+        const int H = a.H + 2 * a.pad_h, W = a.W + 2 * a.pad_w, tr0 = ty * TH + a.pad_h, tc0 = tx * TW + a.pad_w;
         const int qw = wx.LW() / 4, n_q = wx.LH() * qw, oy = tr0 - wx.HR(), ox = tc0 - wx.HC();
         const float inv_qw = 1.0f / (float)qw;
         const bool lds_f64 = sh.chk != 0ull;             // (tile_body redid its slice exactly: the LDS image holds doubles)
@@ -516,7 +529,8 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           const int i = threadIdx.x + kq * kBlock;
           const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
           const int r = oy + rl, c = ox + 4 * cq, rr = r - row0, cc = c - col0;
-          const bool ok = i < n_q && r >= 0 && r < H && c >= 0 && c < W && (unsigned)rr < (unsigned)own_lh && (unsigned)cc < (unsigned)own_lw;
+          // (a quad may straddle the image's left / right edge when pad_w is no multiple of 4: its cells outside the image hold zeros)
+          const bool ok = i < n_q && r >= 0 && r < H && c + 3 >= 0 && c < W && (unsigned)rr < (unsigned)own_lh && (unsigned)cc < (unsigned)own_lw;
           if (EBOS_ABL & 8) continue;
           const float4 v = lds_image_cells4(s_acc, own_lh, own_pt, ok ? rr : 0, ok ? cc >> 2 : 0, lds_f64);
           if (ok) own_q[kq] = v;
@@ -568,7 +582,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       __syncthreads();
       if (threadIdx.x == 0) {
         const int lo_px = a.omit ? 1 : 0;
-        const double n_px = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
+        const double n_px = (double)max(a.H + 2 * a.pad_h - 2 * lo_px, 0) * (double)max(a.W + 2 * a.pad_w - 2 * lo_px, 0);
         double S = 0.0;
         for (int k = 0; k < kWaves; ++k) S += s_red[kWaves + k];
         const double mn = n_px > 0.0 ? S / n_px : 0.0;
@@ -616,7 +630,15 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     BwdPreRaw pre_raw;  // the backward sweep's first two chunks per wave, requested here and decoded behind the barrier
     {
       KArgs& a = fresh_args();
-      const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
+      // (IMAGE coordinates: the padded image [H, W]; tile (ty, tx) starts at (tr0, tc0) in it, a neighbour's window at its tile's
+      // origin + padding - its halo)
+      const int pad_h = a.pad_h, pad_w = a.pad_w;
+      const int H = a.H + 2 * pad_h, W = a.W + 2 * pad_w, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x,
+                tr0 = ty * TH + pad_h, tc0 = tx * TW + pad_w;
+      // this tile's OWN pixels (it publishes them and counts their squares): its tile, and for a tile on the border the padding ring
+      // beside it (and, as before, nothing beyond the image for a last tile that is cut)
+      const int or0 = ty == 0 ? 0 : tr0, or1 = ty == a.tiles_y - 1 ? H : tr0 + TH;
+      const int oc0 = tx == 0 ? 0 : tc0, oc1 = tx == tiles_x - 1 ? W : tc0 + TW;
       const int lo_px = a.omit ? 1 : 0;
       const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
       const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
@@ -633,18 +655,19 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       // one quad of the window, assembled: the sum of squares of this tile's own pixels, the image itself when it leaves, the
       // affine map and the quad's place in LDS
       auto finish_quad = [&](int i, int r, int c, bool in, bool live, const float4& v) {
-        // this tile's own pixels (quads lie inside a tile as a whole or outside it)
-        if (live && r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) {
+        // this tile's own pixels (quads lie inside a tile as a whole or outside it; in the padding ring beside a border tile a quad
+        // may straddle the image's edge: per pixel there)
+        if (live && r >= or0 && r < or1 && c + 3 >= oc0 && c < oc1) {
           const float e4[4] = {v.x, v.y, v.z, v.w};
           if (!raw_on && r >= lo_px && r < H - lo_px) {  // (blurred contrast: the sum of squares is the blurred image's, below)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (c + k >= lo_px && c + k < W - lo_px) sq += (double)e4[k] * (double)e4[k];
+              if (c + k >= max(lo_px, oc0) && c + k < min(W - lo_px, oc1)) sq += (double)e4[k] * (double)e4[k];
           }
           if (publish) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (c + k < W) st_sc1(iwe + (int64_t)r * W + c + k, e4[k]);
+              if (c + k >= oc0 && c + k < oc1) st_sc1(iwe + (int64_t)r * W + c + k, e4[k]);
           }
         }
         float4 gq = v;
@@ -711,14 +734,14 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             const int i = threadIdx.x + kq * kBlock;
             const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
             const int r = oy + rl, c = ox + 4 * cq;
-            const bool live = i < n_q && r >= 0 && r < H && c >= 0 && c < W;
+            const bool live = i < n_q && r >= 0 && r < H && c + 3 >= 0 && c < W;
             const int ya = r < tr0 + (TH + 1) / 2 ? ty - 1 : ty, xa = c < tc0 + (TW + 1) / 2 ? tx - 1 : tx;
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
               const int nty = ya + (sl >> 1), ntx = xa + (sl & 1);
               const unsigned w = s_win[(nty - ty + 1) * 3 + (ntx - tx + 1)];   // (0xffffffff: no such tile)
               const int hr = (int)(w & 255u), hc = (int)((w >> 8) & 255u);
-              const int rr = r - (nty * TH - hr), cc = c - (ntx * TW - hc), lw = TW + 2 * hc, lh = TH + 2 * hr;
+              const int rr = r - (nty * TH + pad_h - hr), cc = c - (ntx * TW + pad_w - hc), lw = TW + 2 * hc, lh = TH + 2 * hr;
               const bool is_own = nty == ty && ntx == tx;
               const bool ok = live && w != 0xffffffffu && (unsigned)rr < (unsigned)lh && (unsigned)cc < (unsigned)lw;
               meta[kk] |= (ok ? 1u : 0u) << sl;
@@ -739,7 +762,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
             const int r = oy + rl, c = ox + 4 * cq;
             const bool in = i < n_q;
-            const bool live = in && r >= 0 && r < H && c >= 0 && c < W;
+            const bool live = in && r >= 0 && r < H && c + 3 >= 0 && c < W;
             const unsigned own_slot = (meta[kk] >> 4) & 3u;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -758,7 +781,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
         const int rl = (int)(((float)i + 0.5f) * inv_qw), cq = i - rl * qw;
         const int r = oy + rl, c = ox + 4 * cq;
         const bool in = i < n_q;
-        const bool live = in && r >= 0 && r < H && c >= 0 && c < W;
+        const bool live = in && r >= 0 && r < H && c + 3 >= 0 && c < W;
         float4 part[9];
         bool okk[9];
 #pragma unroll
@@ -767,7 +790,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
           const unsigned w = (unsigned)rfl((int)s_win[k]);
           const int nty = ty + k / 3 - 1, ntx = tx + k % 3 - 1;
           const int hr = (int)(w & 255u), hc = (int)((w >> 8) & 255u);
-          const int row0 = nty * TH - hr, col0 = ntx * TW - hc, lw = TW + 2 * hc, lh = TH + 2 * hr;
+          const int row0 = nty * TH + pad_h - hr, col0 = ntx * TW + pad_w - hc, lw = TW + 2 * hc, lh = TH + 2 * hr;
           const unsigned slab0 = (unsigned)(nty * tiles_x + ntx) * (unsigned)(kLHmax * kLWmax);
           const int rr = r - row0, cc = c - col0;
           okk[k] = live && w != 0xffffffffu && (unsigned)rr < (unsigned)lh && (unsigned)cc < (unsigned)lw;
@@ -866,7 +889,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             const float4 y4 = blur3_interior_quad(m[-bq - 1], m[-bq], m[-bq + 1], m[-1], m[0], m[1], m[bq - 1], m[bq], m[bq + 1], bk);
             reinterpret_cast<float4*>(s_b)[rl * bq + cq] = y4;
             const int r = boy + rl, c = box + 4 * cq;
-            if (r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) {   // this tile's own pixels (the border's: below)
+            if (r >= or0 && r < or1 && c + 3 >= oc0 && c < oc1) {   // this tile's own pixels, the padding ring beside a border tile included (the border's: below)
               if (inner || (r >= vlo && r < H - vlo && c >= vlo && c + 3 < W - vlo)) {
                 sq += ((double)y4.x * (double)y4.x + (double)y4.y * (double)y4.y) + ((double)y4.z * (double)y4.z + (double)y4.w * (double)y4.w);
               } else if (r >= vlo && r < H - vlo) {
@@ -888,7 +911,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
                                const bool valid = r >= lo_px && r < H - lo_px && c >= lo_px && c < W - lo_px;
                                const float y = (valid && !(EBOS_ABL & 262144)) ? blur3_fwd_at_dense(x_at, r, c, H, W, bk) : 0.0f;  // (the raw window reaches >= 1 pixel further)
                                s_b[(r - boy) * bw + (c - box)] = y;
-                               if (r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) sq += (double)y * (double)y;
+                               if (r >= or0 && r < or1 && c >= oc0 && c < oc1) sq += (double)y * (double)y;
                              });
           }
         }
@@ -983,7 +1006,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
             reinterpret_cast<float4*>(s_gx)[rl * bq + cq] = x4;
             reinterpret_cast<float4*>(s_gy)[rl * bq + cq] = y4;
             const int r = boy + rl, c = box + 4 * cq;
-            if (r >= tr0 && r < tr0 + TH && c >= tc0 && c < tc0 + TW) {   // this tile's own stencils: its share of the contrast's value
+            if (r >= or0 && r < or1 && c + 3 >= oc0 && c < oc1) {   // this tile's own stencils (with the padding ring beside a border tile): its share of the contrast's value
               const float e4[4] = {sobel3_energy(x4.x, y4.x), sobel3_energy(x4.y, y4.y), sobel3_energy(x4.z, y4.z), sobel3_energy(x4.w, y4.w)};
               if (inner || (r >= lo_px && r < H - lo_px && c >= lo_px && c + 3 < W - lo_px)) {
                 sq += ((double)e4[0] + (double)e4[1]) + ((double)e4[2] + (double)e4[3]);
@@ -1079,7 +1102,9 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     // neighbours' and mapped in a pass of its own (the four-launch pipeline's staging)
     if (!halo_complete) {
       KArgs& a = fresh_args();
-      const int H = a.H, W = a.W, tiles_x = a.tiles_x, tiles_y = a.tiles_y, ty = tile / tiles_x, tx = tile - ty * tiles_x, tr0 = ty * TH, tc0 = tx * TW;
+      // (IMAGE coordinates, as in G)
+      const int H = a.H + 2 * a.pad_h, W = a.W + 2 * a.pad_w, tiles_x = a.tiles_x, tiles_y = a.tiles_y, ty = tile / tiles_x, tx = tile - ty * tiles_x,
+                tr0 = ty * TH + a.pad_h, tc0 = tx * TW + a.pad_w;
       const int lo_px = a.omit ? 1 : 0;
       const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
       const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
@@ -1138,15 +1163,15 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     double tot_x = 0.0, tot_y = 0.0;  // UNI: this lane's sum of dt * d loss / d(x', y')
     {
       KArgs& a = fresh_args();
-      const int H = a.H, W = a.W, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+      const int H = a.H, W = a.W, pad_h = a.pad_h, pad_w = a.pad_w, tiles_x = a.tiles_x, ty = tile / tiles_x, tx = tile - ty * tiles_x;   // (the sweeps take SOURCE sizes + padding)
       const int lo_px = a.omit ? 1 : 0;
-      const double n_px = (double)max(H - 2 * lo_px, 0) * (double)max(W - 2 * lo_px, 0);
+      const double n_px = (double)max(H + 2 * pad_h - 2 * lo_px, 0) * (double)max(W + 2 * pad_w - 2 * lo_px, 0);
       GradImage G;
       G.g = a.iwe;
       const double ga = 2.0 * (-(double)a.w_contrast) / (n_px - 1.0);
       G.a = (float)ga;
       G.c = (float)(-ga * mean);
-      G.h = H, G.w = W, G.lo = lo_px;
+      G.h = H + 2 * pad_h, G.w = W + 2 * pad_w, G.lo = lo_px;
       if constexpr (blur_on) G.set_blur(a.blur);
       else G.set_blur(Blur3{0.0f, 0.0f});
       EBOS_RSTAMP(9);
@@ -1161,11 +1186,11 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       if constexpr (UNI) {
         // (no scatter: every lane sums dt * d loss / d(x', y') of its events -- the f64 sweep of the four-launch UNIFORM kernel)
         unit.fx = false, unit.scale = 1.0f, unit.limit = 0.0f;
-        fx = bwd_lean_sweeps<TH, TW, HALO, true, false, true>(tr, s_d, s_g, ev, s_cells, H, W, 0, 0, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
+        fx = bwd_lean_sweeps<TH, TW, HALO, true, false, true>(tr, s_d, s_g, ev, s_cells, H, W, pad_h, pad_w, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
                                                              unit, a.dt_bound, pre, false, bsh, NoHook{});
       } else if constexpr (FRAC) {
         unit.fx = false, unit.scale = 1.0f, unit.limit = 0.0f;  // (the general sweep: fractions per slot, f64 accumulators)
-        fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, ev, s_flow_b, H, W, 0, 0, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
+        fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, ev, s_flow_b, H, W, pad_h, pad_w, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
                                                              unit, a.dt_bound, pre, false, bsh, NoHook{});
       } else {
       decode_bgroup(pre.A, pre_raw.A, (unsigned)PW, 0u, (unsigned)(AP * PW + AP));  // (the tile's flow in LDS: element indices, pitch PW)
@@ -1173,7 +1198,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       finish_bgroup<TW>(pre.A);
       finish_bgroup<TW>(pre.B);
       if (!(EBOS_ABL & 32))
-      fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, ev, s_flow_b, H, W, 0, 0, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
+      fx = bwd_lean_sweeps<TH, TW, HALO, false, true, true>(tr, s_d, s_g, ev, s_flow_b, H, W, pad_h, pad_w, G, tot_x, tot_y, ChunkQueue{&s_next}, wb,
                                                            unit, a.dt_bound, pre, true, bsh, NoHook{});
       }
       __syncthreads();
@@ -1434,7 +1459,7 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
     const int lo_px = a.omit ? 1 : 0;
     a.variance[0] = s_adam[2];
     a.moments[0] = s_hist[((n_iter - 1) & 1) * 2 + 1];
-    a.moments[1] = (double)max(a.H - 2 * lo_px, 0) * (double)max(a.W - 2 * lo_px, 0);
+    a.moments[1] = (double)max(a.H + 2 * a.pad_h - 2 * lo_px, 0) * (double)max(a.W + 2 * a.pad_w - 2 * lo_px, 0);
   }
 #endif
 }
@@ -1496,12 +1521,13 @@ int launch_resident(const ResidentArgs& a, void* mailbox, size_t mailbox_total, 
 }
 
 // the kernel's arguments from the C ABI's problem structs (either the patch-flow problem or the 2-DoF one)
-inline void resident_common_args(ResidentArgs& a, int H, int W, int tile_h, int tile_w, void* mailbox, int n_iter, int steps_done,
-                                 double spin_timeout_s, const HaloArg& ha) {
+inline void resident_common_args(ResidentArgs& a, int H, int W, int pad_h, int pad_w, int tile_h, int tile_w, void* mailbox, int n_iter,
+                                 int steps_done, double spin_timeout_s, const HaloArg& ha) {
   const int tiles_y = (H + tile_h - 1) / tile_h, tiles_x = (W + tile_w - 1) / tile_w;
   const MailboxLayout m = mailbox_layout(tiles_y * tiles_x);
   char* mb = reinterpret_cast<char*>(mailbox);
   a.H = H, a.W = W, a.tiles_y = tiles_y, a.tiles_x = tiles_x;
+  a.pad_h = pad_h, a.pad_w = pad_w;
   a.status = reinterpret_cast<unsigned*>(mb + m.off_status);
   a.rec1 = reinterpret_cast<unsigned long long*>(mb + m.off_rec1);
   a.part3 = reinterpret_cast<unsigned long long*>(mb + m.off_part3);
@@ -1522,7 +1548,7 @@ inline void resident_common_args(ResidentArgs& a, int H, int W, int tile_h, int 
 inline ResidentArgs resident_args(const ebos_cmax_patch_problem* q, int n_iter, void* mailbox, double spin_timeout_s) {
   const HaloArg ha = decode_halo(q->halo);
   ResidentArgs a{};
-  resident_common_args(a, q->H, q->W, q->tile_h, q->tile_w, mailbox, n_iter, q->steps_done, spin_timeout_s, ha);
+  resident_common_args(a, q->H, q->W, q->pad_h, q->pad_w, q->tile_h, q->tile_w, mailbox, n_iter, q->steps_done, spin_timeout_s, ha);
   a.ev = EvPtrs{nullptr, nullptr, nullptr, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr, q->cfx, q->cfy};
   a.key_offsets = q->key_offsets;
   a.gs = GridSrc{make_axis(q->gh, q->patch_h, q->slide_h, q->H), make_axis(q->gw, q->patch_w, q->slide_w, q->W)};
@@ -1548,7 +1574,7 @@ inline ResidentArgs resident_args(const ebos_cmax_patch_problem* q, int n_iter, 
 inline ResidentArgs resident_args(const ebos_cmax_2dof_problem* q, int n_iter, void* mailbox, double spin_timeout_s, float w_variance) {
   const HaloArg ha = decode_halo(q->halo);
   ResidentArgs a{};
-  resident_common_args(a, q->H, q->W, q->tile_h, q->tile_w, mailbox, n_iter, q->steps_done, spin_timeout_s, ha);
+  resident_common_args(a, q->H, q->W, q->pad_h, q->pad_w, q->tile_h, q->tile_w, mailbox, n_iter, q->steps_done, spin_timeout_s, ha);
   a.ev = EvPtrs{nullptr, nullptr, nullptr, nullptr, q->grp_offsets, q->cpix, q->cdt, nullptr, nullptr, nullptr, q->cfx, q->cfy};
   a.key_offsets = q->key_offsets;
   a.gs = GridSrc{};

@@ -339,12 +339,14 @@ class FusedPatchLoop(object):
 
     def resident_supported(self) -> bool:
         """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_patch_solve_resident_f32)?  Grid-sampling route, either
-        contrast (the blurred image with the variance only), no padding, a tile / halo with a resident kernel, few enough tiles to
+        contrast (the blurred image with the variance only), image padding below half a tile, a tile / halo with a resident kernel, few enough tiles to
         be co-resident.  (The resident kernel runs one workgroup per tile whatever the plan's work-item table says: against a
         pipeline that split crowded tiles it agrees to rounding, not bit for bit.)"""
         frac = self.plan.frac_compact is not None   # fractional source coordinates: the four launches run the dense route, the resident
         # launch the compact layout with the fractions per slot (62 -> 31 us per iteration at 2 M events)
-        if not (self.sample_grid or frac) or self.splits not in (0, 1) or self.pad != (0, 0):
+        if not (self.sample_grid or frac) or self.splits not in (0, 1):
+            return False
+        if self.pad != (0, 0) and os.environ.get("EBOS_RESIDENT_PAD", "1") == "0":   # (the library checks that the padding fits the windows)
             return False
         if frac and os.environ.get("EBOS_RESIDENT_FRAC", "1") == "0":
             return False
@@ -508,11 +510,13 @@ class Fused2dofLoop(object):
 
     def resident_supported(self) -> bool:
         """Can ``run`` take the ONE-launch resident kernel (ebos_cmax_2dof_solve_resident_f32)?  Compact plan -- of integer source
-        pixels, or with the fractions of undistorted events (``EventPlan.frac_compact``) --, no padding, a tile / halo with a
-        resident kernel."""
+        pixels, or with the fractions of undistorted events (``EventPlan.frac_compact``) --, image padding below half a tile, a tile /
+        halo with a resident kernel."""
         import ctypes
 
-        if not (self.plan.compact or self.plan.frac_compact is not None) or self.splits not in (0, 1) or self.pad != (0, 0):
+        if not (self.plan.compact or self.plan.frac_compact is not None) or self.splits not in (0, 1):
+            return False
+        if self.pad != (0, 0) and os.environ.get("EBOS_RESIDENT_PAD", "1") == "0":   # (the library checks that the padding fits the windows)
             return False
         if self.blur_sigma > 0 and os.environ.get("EBOS_RESIDENT_BLUR", "1") == "0":
             return False

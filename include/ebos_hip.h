@@ -855,7 +855,8 @@ int ebos_cmax_2dof_solve_f32(const ebos_cmax_2dof_problem* problem, int n_iter, 
  *
  *   ebos_cmax_resident_supported   1 when `problem` can run resident: a compact plan -- of the grid-sampling route (grad_partials), or
  *                                  with the fractions of undistorted events (cfx / cfy) --, either contrast (the blurred image with
- *                                  the variance only), splits 0 or 1, no padding, tile / halo with a resident kernel ((45, 80, 32),
+ *                                  the variance only), splits 0 or 1, image padding below half a tile and at most the halo (round 6: the windows
+ *                                  then reach at least the padding ring), tile / halo with a resident kernel ((45, 80, 32),
  *                                  (32, 32, 32), (32, 64, 32)), cell blocks of <= 256 elements per tile, cells whose supports span
  *                                  <= 16 tiles per axis; 0 otherwise (reason: ebos_last_error)
  *   mailbox                        device memory of ebos_cmax_resident_mailbox_bytes(...): flags, records, the status word;
@@ -881,7 +882,7 @@ int ebos_cmax_patch_solve_resident_f32(const ebos_cmax_patch_problem* problem, i
                                        double spin_timeout_s, ebos_stream_t stream);
 /* The 2-DoF Adam loop (ebos_cmax_2dof_solve_f32) as ONE resident launch: same problem struct, same mailbox / spin cap / status
  * protocol as ebos_cmax_patch_solve_resident_f32 (ebos_cmax_resident_status / _iterations read its mailbox too).  Compact plans,
- * splits <= 1, no padding, the tiles (45, 80) / (32, 32) / (32, 64) with halo 32.  Every workgroup sums all tiles' partial pairs of
+ * splits <= 1, image padding below half a tile, the tiles (45, 80) / (32, 32) / (32, 64) with halo 32.  Every workgroup sums all tiles' partial pairs of
  * d loss / d theta itself and steps the two parameters redundantly; with blur_k0 != 0 the gathered window is blurred in LDS
  * (windows up to ~12 px; larger displacements hand over with -102 like a spill). */
 int ebos_cmax_2dof_resident_supported(const ebos_cmax_2dof_problem* problem);

@@ -2011,3 +2011,10 @@ def test_blurred_patch_loop_first_step_vs_oracle_autograd(ebos, omit, pad, sigma
     lo.backward()
     assert abs(losses[0].item() - lo.item()) <= 1e-5 * abs(lo.item())
     assert rel(loop.d_theta.cpu().numpy(), to.grad.numpy()) < 1e-3
+    # ... and the same step as ONE resident launch (round 6: image padding inside the resident kernel too), against the same oracle
+    res = FusedPatchLoop(plan, patch, patch, G(th0, torch.float32), 1.0, 0.002, tv, omit, pad, "auto", lr=0.1, capacity=4, blur_sigma=sigma)
+    assert res.resident_supported(), ebos.load_library().ebos_last_error()
+    l_res = res.run(1, resident=True)
+    assert res.last_run_mode == "resident"
+    assert abs(l_res[0].item() - lo.item()) <= 1e-5 * abs(lo.item())
+    assert rel(res.d_theta.cpu().numpy(), to.grad.numpy()) < 1e-3

@@ -282,7 +282,7 @@ def test_translation_adam_loop_is_native_and_matches_cpu_oracle(blur, omit, pad,
                iwe={"method": "bilinear_vote", "blur_sigma": blur})
     s = ebos.solver.collections["contrast_maximization"]((h, w), (h, w), solver_config=cfg)
     flow = s.estimate(ev)
-    assert s.fused and s.loop_mode in ("pipeline", "resident")
+    assert s.fused and s.loop_mode == "resident"   # (round 6: also with outer_padding -- the windows reach the padding ring)
     theta = torch.zeros(2, dtype=torch.float64, requires_grad=True)
     opt = torch.optim.Adam([theta], lr=0.2)
     tev = torch.from_numpy(ev)
@@ -1534,3 +1534,97 @@ def test_estimate_survives_a_torn_resident_launch(model, monkeypatch):
     flow = s.estimate(ev)
     assert calls == [25] and s.loop_mode == "pipeline" and len(s.history) == 25
     np.testing.assert_array_equal(flow, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,n_ev,patch,pad,omit,contrast", [
+    ((96, 128), 20_000, (24, 32), 2, False, "variance"),     # 12 tiles of 32 x 32: every tile touches the border
+    ((96, 128), 20_000, (24, 32), 3, True, "blur3"),         # pad 3: quads straddle the image's edge
+    ((260, 346), 100_000, (20, 20), 1, True, "variance"),    # partial last tiles, W + 2 pad no multiple of 4
+    ((260, 346), 100_000, (20, 20), 5, False, "blur1"),
+    ((260, 346), 100_000, (20, 20), 2, True, "gm"),
+    ((720, 1280), 400_000, (24, 32), 4, False, "variance"),  # 256 tiles of 45 x 80
+    ((720, 1280), 400_000, (24, 32), 2, True, "gm"),
+    ((720, 640), 300_000, (24, 32), 3, False, "blur3"),      # 230 tiles of 32 x 64
+])
+def test_resident_patch_loop_with_outer_padding(size, n_ev, patch, pad, omit, contrast):
+    """``outer_padding > 0`` (src/event_image_converter.py:29-34) INSIDE the one-launch loop: every window reaches at
+    least the padding ring and the border tiles own it -- publish its pixels, count their squares.  Against the four launches on the
+    same padded problem: the image bit for bit, the first step's loss / gradient and 40 iterations to rounding, for all three
+    contrasts; events near the border so that the ring is really hit."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import FusedPatchLoop
+
+    h, w = size
+    rs = np.random.RandomState(23)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    a, b, c = n_ev // 6, n_ev // 3, n_ev // 2
+    ev[:a, 0] = rs.randint(0, 3, a)                              # crowd the top rows / left columns / bottom rows: their taps land in the ring
+    ev[a:b, 1] = rs.randint(0, 3, b - a)
+    ev[b:c, 0] = h - 1 - rs.randint(0, 3, c - b)
+    ev = ev[np.argsort(ev[:, 2], kind="stable")]
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="compact")
+    gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+    theta0 = torch.from_numpy(rs.uniform(-3, 3, (2, gh, gw))).float()
+    n_iter = 40
+    w_var, w_gm, sigma = (0.0, 1.0, 0.0) if contrast == "gm" else (1.0, 0.0, {"variance": 0.0, "blur1": 1.0, "blur3": 3.0}[contrast])
+
+    def make():
+        return FusedPatchLoop(plan, patch, patch, theta0, w_var, 0.001, 0.01, omit, pad, "auto", lr=0.02, capacity=n_iter + 20,
+                              w_gradient_magnitude=w_gm, blur_sigma=sigma)
+
+    ref, res = make(), make()
+    assert res.resident_supported(), ebos.load_library().ebos_last_error()
+    l1_ref = ref.run(1, resident=False).cpu().numpy()
+    l1_res = res.run(1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.resident_status == 0 and res.resident_iterations == 1
+    assert ref.iwe.shape == (h + 2 * pad, w + 2 * pad)
+    ring = torch.ones_like(ref.iwe, dtype=torch.bool)
+    ring[pad:-pad, pad:-pad] = False
+    assert float(ref.iwe[ring].abs().sum()) > 0                     # (the ring holds mass: the test exercises it)
+    assert torch.equal(ref.iwe, res.iwe)                            # the padded image: same bits, ring included
+    np.testing.assert_allclose(l1_res, l1_ref, rtol=1e-6)
+    np.testing.assert_allclose(res.d_theta.cpu().numpy(), ref.d_theta.cpu().numpy(), rtol=1e-4, atol=1e-8)
+    l_ref = ref.run(n_iter - 1, resident=False).cpu().numpy()
+    l_res = res.run(n_iter - 1, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.t == n_iter
+    print("max rel loss deviation", np.abs(l_res / l_ref - 1).max(), "theta", (res.theta - ref.theta).abs().max().item())
+    np.testing.assert_allclose(l_res, l_ref, rtol=2e-5)
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=5e-3)
+    np.testing.assert_allclose(res.variance.cpu().numpy(), ref.variance.cpu().numpy(), rtol=2e-5)
+    if contrast != "gm":   # (the variance's moments: mean and pixel count of the padded image; the gradient magnitude has none)
+        assert torch.equal(ref.moments[:, 1], res.moments[:, 1]) and float(res.moments[0, 1]) == (h + 2 * pad - 2 * omit) * (w + 2 * pad - 2 * omit)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,n_ev,pad,omit,sigma,frac", [((60, 78), 9_000, 2, False, 3.0, False), ((60, 78), 9_000, 1, True, 0.0, True),
+                                                          ((260, 346), 100_000, 3, False, 3.0, False), ((720, 1280), 300_000, 5, True, 1.0, True)])
+def test_resident_2dof_loop_with_outer_padding(size, n_ev, pad, omit, sigma, frac):
+    """The 2-DoF Adam loop with ``outer_padding`` as one resident launch: the four launches' trajectory (losses to 1e-6, theta to
+    1e-4 px), for integer and fractional source coordinates, with and without the blur."""
+    import event_based_bos_amd as ebos
+    from event_based_bos_amd.solver.fused_loop import Fused2dofLoop
+
+    h, w = size
+    rs = np.random.RandomState(29)
+    ev = np.stack([rs.randint(0, h, n_ev), rs.randint(0, w, n_ev), np.sort(rs.uniform(0, 0.5, n_ev)), rs.randint(0, 2, n_ev)], 1).astype(np.float64)
+    a, b = n_ev // 5, n_ev // 3
+    ev[:a, 0] = rs.randint(0, 2, a)
+    ev[a:b, 1] = w - 1 - rs.randint(0, 2, b - a)
+    if frac:
+        ev[:, :2] = np.clip(ev[:, :2] + rs.uniform(-0.45, 0.45, (n_ev, 2)), 0, [h - 1, w - 1])
+    ev = ev[np.argsort(ev[:, 2], kind="stable")]
+    plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (h, w), "first", True, tile="auto", emit="full" if frac else "compact")
+    n_iter = 40
+
+    def make():
+        return Fused2dofLoop(plan, torch.tensor([1.5, -1.0]), 1.0, omit, pad, "auto", lr=0.05, capacity=n_iter + 4, blur_sigma=sigma)
+
+    ref, res = make(), make()
+    assert res.resident_supported(), ebos.load_library().ebos_last_error()
+    l_ref = ref.run(n_iter, resident=False).cpu().numpy()
+    l_res = res.run(n_iter, resident=True).cpu().numpy()
+    assert res.last_run_mode == "resident" and res.resident_status == 0
+    assert torch.equal(ref.iwe, res.iwe) or float((ref.iwe - res.iwe).abs().max()) <= 1e-5 * float(ref.iwe.abs().max())
+    np.testing.assert_allclose(l_res, l_ref, rtol=2e-6)
+    np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), rtol=0, atol=1e-4)
