@@ -695,15 +695,10 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
       s_px[pos] = (uint16_t)pix;
       s_dt[pos] = a_dt[i];
     }
-  } else {  // an overfull bin (a window far from uniform): gathered again, straight to its final slots
-    auto place = [&](const Rec& r, int) {
-      const int32_t pos = atomicAdd(&s_cur[((int)(r.pix >> 8) - r0) * g.tw + (int)(r.pix & 255u)], 1);
-      cpix[out0 + pos] = (uint16_t)r.pix;
-      cdt[out0 + pos] = dt_of(r);
-    };
-    if (wide) for_each_staged(std::false_type{}, load8, place);
-    else for_each_staged(std::false_type{}, load4, place);
   }
+  // (an overfull bin -- a window far from uniform, or one of more than ~20 M events, whose bins are not cut finer than a (chunk, bin)
+  // run of ~4 events allows -- is gathered AGAIN per chunk of whole pixels below, only that chunk's pixels kept: the runs come out of
+  // the L2 / Infinity Cache, and nothing is scattered to memory and read back)
   __syncthreads();
   EBOS_LSTAMP(1, 3);
   // The cursors hand out a pixel's slots in the order the atomics arrive: two builds of one window differ in it, and a kernel that
@@ -711,7 +706,7 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
   // gradient -- which an optimiser amplifies: two solves of one window drifted apart after a few dozen iterations.  So every pixel's
   // run leaves in ascending dt (equal dt: equal slots whatever their order): an event takes the slot of its RANK in its run, counted
   // over the run in LDS (O(run) reads per event); a hot pixel (a run beyond kLeanCanon) is first sorted in place by the whole
-  // workgroup, a bitonic network.  A staged bin is ranked where it stands; an overfull one comes back from memory in chunks of whole
+  // workgroup, a bitonic network.  A staged bin is ranked where it stands; an overfull one is gathered again in chunks of whole
   // pixels (a run that does not fit the staging area on its own keeps its order of arrival).
   if (!staged) {   // an overfull bin re-stages chunks of whole pixels in the WHOLE staging area (both buffers: 2 x sort_cap events)
     s_dt = a_dt;
@@ -734,31 +729,32 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
         else hi = mid;
       }
       p_hi = lo;
-      if (p_hi == p_lo) {   // one run larger than the staging area: left as it arrived
-        p_lo += 1;
-        continue;
-      }
     }
+    // (one run larger than the staging area on its own: straight to its slots of the segment, in the order it arrives)
+    const bool direct = p_hi == p_lo;
+    if (direct) p_hi = p_lo + 1;
     const int c1 = p_hi < n_pix ? s_cnt[p_hi] : len, m = c1 - c0;
     if (threadIdx.x == 0) s_nhot = 0, s_nlong = 0;
-    if (!staged) {
-      __threadfence();
+    if (!staged) {   // this chunk's pixels out of the bin's runs, each event to its pixel's next slot of the staging area
       __syncthreads();
-      // (written by this workgroup a moment ago: not from this CU's L1; eight loads per thread in flight -- one at a time the ~20
-      // round trips of a chunk were most of an overfull bin's time)
-      constexpr int kU = 8;
-      for (int i0 = threadIdx.x; i0 < m; i0 += kU * kSortBlock) {
-        unsigned v[kU];
-        uint16_t q[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          const int i = min(i0 + u * kSortBlock, m - 1);
-          v[u] = __hip_atomic_load(reinterpret_cast<unsigned*>(cdt + out0 + c0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          q[u] = __hip_atomic_load(cpix + out0 + c0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      auto keep = [&](const Rec& r, int) {
+        const int pi = ((int)(r.pix >> 8) - r0) * g.tw + (int)(r.pix & 255u);
+        if (pi >= p_lo && pi < p_hi) {
+          const int32_t pos = atomicAdd(&s_cur[pi], 1);
+          if (direct) {
+            cpix[out0 + pos] = (uint16_t)r.pix;
+            cdt[out0 + pos] = dt_of(r);
+          } else {
+            s_px[pos - c0] = (uint16_t)r.pix;
+            s_dt[pos - c0] = dt_of(r);
+          }
         }
-#pragma unroll
-        for (int u = 0; u < kU; ++u)
-          if (i0 + u * kSortBlock < m) s_dt[i0 + u * kSortBlock] = __int_as_float((int)v[u]), s_px[i0 + u * kSortBlock] = q[u];
+      };
+      if (wide) for_each_staged(std::false_type{}, load8, keep);
+      else for_each_staged(std::false_type{}, load4, keep);
+      if (direct) {
+        p_lo = p_hi;
+        continue;
       }
     }
     __syncthreads();
@@ -771,8 +767,7 @@ lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp
     EBOS_LSTAMP(1, 5);
     // every slot its pixel (a run's slots all carry it): stored FIRST -- the stores travel while the runs are put in order (behind the
     // sorts they were 5 us of a workgroup's 30: a store's way to memory, waited for with nothing else to do)
-    if (staged)
-      for (int i = threadIdx.x; i < m; i += kSortBlock) cpix[out0 + i] = s_px[i];
+    for (int i = threadIdx.x; i < m; i += kSortBlock) cpix[out0 + c0 + i] = s_px[i];
     const int n_hot = min(s_nhot, kHotList);
     for (int h = 0; h < n_hot; ++h) {   // (uniform) a hot pixel: bitonic network with every comparator ascending -- the first stage of
       const int pi = s_hot[h];          // a merge pairs i with its mirror image in the block, the others i with i + stride --, so the
@@ -894,15 +889,22 @@ inline LeanLayout lean_layout(int64_t n, int H, int W, int th, int tw) {
   else c = std::min<int64_t>(kResident, std::max<int64_t>(1, (n + kLeanBlock - 1) / kLeanBlock));
   L.chunk = (int)(((std::max<int64_t>(n, 1) + c - 1) / c + 7) & ~(int64_t)7);
   L.n_chunks = (int)((std::max<int64_t>(n, 1) + L.chunk - 1) / L.chunk);
-  // row bands per tile: as few as keep the average bin inside the LDS staging of the bin sort (uniform windows then never
-  // take the global-scatter branch); at most one band per row
+  // Row bands per tile: as FEW as leave the average bin about two chunks of the bin sort's staging area (sort_cap events are staged
+  // and ranked in one go, 2 x sort_cap per chunk of an overfull bin's pixels); at most one band per row.  Fewer bins are longer
+  // (chunk, bin) runs -- chunk / n_bins events each -- and a smaller table: what the stage kernel writes per chunk, the totals kernel
+  // reads and the bin sort's gather walks.  Round 6 first cut the bins to FIT the staging (one gather): a 10 M-event window on 240
+  // tiles got 1920 bins and runs of 4 events, a 50 M-event one 8192 bins and runs of ONE (as many table entries as events; its bin
+  // sort alone took 2.25 ms).  With 240 bins (runs of 34) every bin is gathered 3 times (histogram + two chunks of its pixels, out
+  // of the L2 / Infinity Cache) and the 10 M build is still 12 % shorter (0.350 -> 0.307 ms; 5 M 0.235 -> 0.204, 20 M 0.82 -> 0.72,
+  // 50 M 3.25 -> 2.43 ms; tools/bench_plan_build.py, profiles/r06_plan_build.json).
+  constexpr double kBinFill = 3.3;
   for (int sub = 1;; sub *= 2) {
     if (sub > th) sub = th;
     L.sub = sub;
     L.pix_cap = ((th + sub - 1) / sub + 1) * tw;
     const long long room = (long long)kSortLds - (long long)L.pix_cap * 8;
     L.sort_cap = room > 0 ? (int)(room / 12) & ~1 : 0;   // (two staging buffers: arrival order, sorted by pixel)
-    if (sub == th || ((double)n / ((double)n_tiles * sub) <= 0.8 * L.sort_cap)) break;
+    if (sub == th || ((double)n / ((double)n_tiles * sub) <= kBinFill * L.sort_cap)) break;
   }
   L.n_bins = n_tiles * L.sub;
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };

@@ -244,3 +244,21 @@ def torch_cuda_initialised():
     import torch
 
     return torch.cuda.is_initialized()
+
+
+def test_lean_plan_scratch_is_sized_per_event_and_monotonic(lib):
+    """``ebos_plan_lean_scratch_bytes`` (a host-only query): the staged streams of the single-read build -- 2 B of pixel + up to 8 B of
+    timestamp per event, chunks of equal length -- plus the chunks' bin table and partials; never less than 10 B per event, never
+    shrinking with the window, zero for a bad geometry."""
+    import ctypes as C
+
+    fn = lib.ebos_plan_lean_scratch_bytes
+    fn.restype, fn.argtypes = C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+    prev = 0
+    for n in (1, 7, 1000, 100_000, 2_000_000, 10_000_000, 50_000_000):
+        b = int(fn(n, 720, 1280, 45, 80))
+        assert b >= 10 * n and b >= prev, (n, b, prev)
+        assert b <= 16 * n + 64 * 1024 * 1024, (n, b)      # (+ the table: chunks x bins x 4 B -- 4 B per event where a 50 M-event window needs 8192 bins)
+        prev = b
+    assert int(fn(100_000, 260, 346, 32, 32)) >= 10 * 100_000
+    assert int(fn(-1, 720, 1280, 45, 80)) == 0 and int(fn(10, 0, 1280, 45, 80)) == 0 and int(fn(10, 720, 1280, 0, 80)) == 0

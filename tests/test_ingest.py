@@ -346,6 +346,49 @@ def test_lean_build_fuzz_canonical_order_and_same_events_as_the_full_build():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["two_chunks", "dense", "one_run_beyond_the_staging_area"])
+def test_lean_build_of_dense_windows_gathers_overfull_bins_in_chunks(case):
+    """Windows beyond ~10 k events per tile leave the bins LARGER than the bin sort's LDS staging on purpose (fewer, longer (chunk, bin)
+    runs: the stage kernel's table and the gather were what the build cost): an overfull bin is gathered once for its histogram and once
+    per chunk of whole pixels.  Same arrays from two builds, every run in ascending dt, the events of the full build; a single run larger
+    than the whole staging area (a pixel firing 30 000 times) is written in the order it arrives -- same events, order unspecified."""
+    import event_based_bos_amd as ebos
+
+    H, W, tile = 128, 128, (64, 64)
+    n = {"two_chunks": 120_000, "dense": 900_000, "one_run_beyond_the_staging_area": 150_000}[case]
+    rs = np.random.RandomState(31)
+    r, c = rs.randint(0, H, n).astype(np.float64), rs.randint(0, W, n).astype(np.float64)
+    if case == "one_run_beyond_the_staging_area":
+        r[:30_000], c[:30_000] = 70, 9
+    ev = np.stack([r, c, rs.uniform(0, 0.5, n), rs.randint(0, 2, n)], 1)
+    ev = torch.from_numpy(ev[np.argsort(ev[:, 2], kind="stable")]).cuda()
+    plans = [ebos.EventPlan.build(ev, (H, W), "first", True, tile=tile, emit="compact") for _ in range(2)]
+    full = ebos.EventPlan.build(ev, (H, W), "first", True, tile=tile, emit="full")
+    assert plans[0].lean and plans[0].tile == tile
+    th, tw = tile
+    ko, grp = plans[0].key_offsets.cpu().numpy(), plans[0].grp_offsets.cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(ko, full.key_offsets.cpu().numpy())
+    cdt, cdt2, fdt = plans[0].cdt.cpu().numpy(), plans[1].cdt.cpu().numpy(), full.cdt.cpu().numpy()
+    cpx, cpx2, fpx = plans[0].cpix.cpu().numpy(), plans[1].cpix.cpu().numpy(), full.cpix.cpu().numpy()
+    for t_ in range(len(grp) - 1):
+        offs = ko[t_ * th * tw:(t_ + 1) * th * tw + 1] - ko[t_ * th * tw]
+        a, b = 4 * grp[t_], 4 * grp[t_] + offs[-1]
+        runs = np.repeat(np.arange(th * tw), np.diff(offs))
+        want = fdt[a:b][np.lexsort((fdt[a:b], runs))]
+        np.testing.assert_array_equal(cpx[a:b], fpx[a:b])
+        np.testing.assert_array_equal(cpx2[a:b], fpx[a:b])
+        if case == "one_run_beyond_the_staging_area":
+            giant = np.diff(offs) >= 30_000
+            keep = ~giant[runs]
+            np.testing.assert_array_equal(cdt[a:b][keep], want[keep])
+            np.testing.assert_array_equal(cdt2[a:b][keep], want[keep])
+            np.testing.assert_array_equal(cdt[a:b][np.lexsort((cdt[a:b], runs))], want)
+        else:
+            np.testing.assert_array_equal(cdt[a:b], want)
+            np.testing.assert_array_equal(cdt2[a:b], want)
+
+
+@pytest.mark.gpu
 def test_fractional_compact_layout_fuzz_canonical_order():
     """The compact layout with fractions per slot (EventPlan.frac_compact): two builds hold identical arrays, every pixel's run is in
     ascending (dt, fx, fy) -- ranked by the fill for short runs, sorted in LDS for hot pixels of up to 4 096 events --, and the slots are

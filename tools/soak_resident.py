@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--launches", type=int, default=200)
 ap.add_argument("--iters", type=int, default=60)
 ap.add_argument("--variants", nargs="*", default=["plain", "blur", "gm", "frac", "2dof", "2dof_blur_frac"])
+ap.add_argument("--pad", type=int, default=0, help="outer_padding of the image (round 6: inside the resident kernels too)")
 a = ap.parse_args()
 cases = [((720, 1280), 400_000, (24, 32)), ((260, 346), 100_000, (20, 20)), ((720, 640), 300_000, (24, 32)), ((96, 128), 20_000, (24, 32))]
 t0 = time.time()
@@ -32,9 +33,9 @@ for variant in a.variants:
 
         def make():
             if variant.startswith("2dof"):
-                return Fused2dofLoop(plan, torch.tensor([1.5, -2.5]), 1.0, False, 0, "auto", lr=0.05, capacity=a.iters,
+                return Fused2dofLoop(plan, torch.tensor([1.5, -2.5]), 1.0, False, a.pad, "auto", lr=0.05, capacity=a.iters,
                                      blur_sigma=3.0 if "blur" in variant else 0.0)
-            return FusedPatchLoop(plan, patch, patch, theta0, 0.0 if variant == "gm" else 1.0, 0.001, 0.01, halo="auto", lr=0.02 if variant != "plain" else 0.1,
+            return FusedPatchLoop(plan, patch, patch, theta0, 0.0 if variant == "gm" else 1.0, 0.001, 0.01, False, a.pad, halo="auto", lr=0.02 if variant != "plain" else 0.1,
                                   capacity=a.iters, w_gradient_magnitude=1.0 if variant == "gm" else 0.0, blur_sigma=1.0 if variant == "blur" else 0.0)
         ref = None
         streams = [torch.cuda.Stream() for _ in range(3)]
