@@ -141,6 +141,7 @@ SIGNATURES = {
     "ebos_iwe_2dof_slab_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P, _P]),
     "ebos_iwe_2dof_slab_batch_f32": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _I, _I, _P, _P, _P, _P, _P]),
     "ebos_plan_parts": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "ebos_plan_facts": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ebos_iwe_2dof_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "ebos_iwe_dense_tiled_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "ebos_variance_dense_job_f32": (_I, [_P, _P, _P, _P, _P, _P]),

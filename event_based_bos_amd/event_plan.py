@@ -366,8 +366,7 @@ class EventPlan:
         if deferred:
             dropped, fractional = 0, 0
         else:  # the ONE host read-back of the build: (outside the image, fractional sources, work items in use, fullest tile)
-            dropped, fractional, used, fullest = (int(v) for v in torch.cat([counts, part_table[tiles_y * tiles_x:tiles_y * tiles_x + 1],
-                                                                             _fullest_tile(key_offsets, th * tw)]).tolist())
+            dropped, fractional, used, fullest = _plan_facts(lib, key_offsets, H, W, th, tw, counts, part_table)
         kept = n - dropped
         src_perm = perm[:kept] if self.perm is None else self.perm[perm[:kept].long()]
         grp_offsets = cpix = cdt = None
@@ -640,8 +639,7 @@ def _build_lean(source: int, events, raw, image_size, direction, normalize_t, ti
                                   stream_ptr()), "ebos_plan_parts")
     dropped, used, fullest = 0, None, None
     if not deferred:  # the one host read-back of the build: (outside the image, fractional sources, work items in use, fullest tile)
-        dropped, fractional, used, fullest = (int(v) for v in torch.cat([counts, part_table[n_tiles:n_tiles + 1],
-                                                                         _fullest_tile(key_offsets, th * tw)]).tolist())
+        dropped, fractional, used, fullest = _plan_facts(lib, key_offsets, H, W, th, tw, counts, part_table)
         if fractional:
             return None  # fractional (undistorted) source coordinates: the (x, y, dt) format of the full build
     plan = EventPlan(None, None, None, None, (H, W), n - dropped, n, (th, tw), key_offsets, None, dropped, grp_offsets, cpix, cdt,
@@ -651,9 +649,12 @@ def _build_lean(source: int, events, raw, image_size, direction, normalize_t, ti
     return plan
 
 
-def _fullest_tile(key_offsets: torch.Tensor, tile_px: int) -> torch.Tensor:
-    """[1] int32: events of the fullest source tile (part of the build's one read-back)."""
-    return key_offsets[::tile_px].diff().max().reshape(1).to(torch.int32)
+def _plan_facts(lib, key_offsets: torch.Tensor, H: int, W: int, th: int, tw: int, counts: torch.Tensor, part_table: torch.Tensor):
+    """(outside the image, fractional sources, work items in use, events of the fullest tile): ``ebos_plan_facts`` + one 16-byte copy."""
+    facts = torch.empty(4, dtype=torch.int32, device=key_offsets.device)
+    with _hip.on_device(key_offsets.device):
+        check(lib.ebos_plan_facts(ptr(key_offsets), H, W, th, tw, ptr(counts), ptr(part_table), ptr(facts), stream_ptr()), "ebos_plan_facts")
+    return tuple(int(v) for v in facts.tolist())
 
 
 def _check_flow(plan: EventPlan, flow: torch.Tensor) -> torch.Tensor:

@@ -240,6 +240,15 @@ int ebos_bin_events_f32(const float* x, const float* y, const float* dt, const f
 int ebos_plan_parts(const int32_t* key_offsets, int H, int W, int tile_h, int tile_w, int n_cu, int fixed_events,
                     int32_t* part_table, ebos_stream_t stream);
 
+/* What the host wants to know about a freshly built plan, as four int32 side by side (one small launch, one 16-byte copy):
+ *     facts[0] = counts[0]   events outside the image (dropped)      facts[2] = part_table[tiles]  work items in use
+ *     facts[1] = counts[1]   events with fractional source pixels    facts[3] = events of the fullest source tile
+ * counts = {oob_count, frac_count} of ebos_bin_events_f32 / the counts pair of ebos_plan_lean (NULL: 0), part_table of
+ * ebos_plan_parts (NULL: 0).  The reference has no counterpart: its loader crops on the host (src/solver/patch_eklt.py:262-281);
+ * the fullest tile decides between the resident solver kernel and the four launches (solver/fused_loop.py: crowded_for_resident). */
+int ebos_plan_facts(const int32_t* key_offsets, int H, int W, int tile_h, int tile_w, const int32_t* counts,
+                    const int32_t* part_table, int32_t* facts, ebos_stream_t stream);
+
 /* Lean plan build: the compact plan (below) straight from the window -- AoS float32 / float64 [n, 4] = (x = row, y = col, t, p)
  * as the reference's loader hands it over (src/data_loader/ccs.py:289-297), or the raw sensor columns (:57-66) -- without
  * the SoA arrays and the permutation that only per-event weights and fractional source coordinates need.  The window is read

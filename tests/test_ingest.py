@@ -346,6 +346,27 @@ def test_lean_build_fuzz_canonical_order_and_same_events_as_the_full_build():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("emit", ["full", "compact"])
+def test_plan_facts_read_back(emit):
+    """ebos_plan_facts (the build's one read-back: dropped, fractional, work items in use, fullest tile) against the plan's own arrays."""
+    import event_based_bos_amd as ebos
+
+    h, w, n, tile = 180, 240, 60_000, (45, 80)
+    x, y, t, p = O.synth_raw_columns(n, h, w, seed=21)
+    x[::41] = w + 1            # outside the image
+    x[: n // 2] %= 60          # one crowded corner
+    y[: n // 2] %= 30
+    store = ebos.data_loader.RawEventStore({"x": x, "y": y, "t": t, "p": p})
+    plan = store.plan(0, n, (h, w), "first", True, tile=tile, emit=emit)
+    dropped = int(((x >= w) | (x < 0) | (y >= h) | (y < 0)).sum())
+    assert plan.counts() == (dropped, 0) and plan.n == n - dropped
+    ko = plan.key_offsets.cpu().numpy().astype(np.int64)
+    n_tiles = (len(ko) - 1) // (tile[0] * tile[1])
+    assert plan.__dict__["_fullest_tile"] == int(np.diff(ko[:: tile[0] * tile[1]]).max())
+    assert plan.__dict__["_parts_used"] == int(plan.part_table[n_tiles])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["two_chunks", "dense", "one_run_beyond_the_staging_area"])
 def test_lean_build_of_dense_windows_gathers_overfull_bins_in_chunks(case):
     """Windows beyond ~10 k events per tile leave the bins LARGER than the bin sort's LDS staging on purpose (fewer, longer (chunk, bin)
