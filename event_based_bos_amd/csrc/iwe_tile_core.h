@@ -2520,37 +2520,44 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
   // DYN: the window decides WHERE the upstream tile is, and its bound -- (2) / the tile's flow values / theta -- is one round trip
   // away.  The SMALLEST window (4 px: what a converged BOS flow needs) is therefore staged speculatively with everything else;
   // only a tile whose bound asks for more stages again, one round trip later.
-  constexpr int kStage = (kLHmax * kLWmax + kBlock - 1) / kBlock;
+  // Thread -> (row r_off + k x rows-per-pass, column c) of the window, rows-per-pass = kBlock / LW whole rows: a thread's column,
+  // its clamp and its validity are found ONCE, its rows step by a constant, and its LDS slot is threadIdx + k x (rows-per-pass x LW).
+  // (A flat index i = threadIdx + k x kBlock per element cost a division, two clamps, four validity compares and a 64-bit address
+  // per element and pass: ~32 instructions x 16 elements of the ~750 a thread spends outside the event loop at 10 M events.)
+  constexpr int kRowsMin = kBlock / kLWmax;
+  constexpr int kStage = (kLHmax + kRowsMin - 1) / kRowsMin;
   constexpr int kSpecHalo = HALO < 4 ? HALO : 4;
-  constexpr int kSpecStage = DYN ? ((TH + 2 * kSpecHalo) * (TW + 2 * kSpecHalo) + kBlock - 1) / kBlock : 1;
+  constexpr int kSpecStage = DYN ? ((TH + 2 * kSpecHalo) + kBlock / (TW + 2 * kSpecHalo) - 1) / (kBlock / (TW + 2 * kSpecHalo)) : 1;
+  static_assert(kRowsMin >= 1 && kSpecStage <= kStage, "a window row fits a pass");
   float raw[kStage], raw_spec[kSpecStage];  // (two register sets: the real window's loads must not wait for the speculative ones)
   Win<TH, TW, HALO, DYN> win{HALO, HALO};
   bool spec_hit = false;
   auto stage_loads = [&](float* dst, int n_stage) {
-    const int LW = win.LW(), n_px = win.LH() * LW, oy = tr0 - win.HR(), ox = tc0 - win.HC();
-    const float inv_lw = 1.0f / (float)LW;
+    const int LW = win.LW(), LH = win.LH(), rpp = kBlock / LW;
+    const int r_off = DYN ? (int)(((float)threadIdx.x + 0.5f) * (1.0f / (float)LW)) : (int)threadIdx.x / LW, c = (int)threadIdx.x - r_off * LW;
+    const int C = min(max(tc0 - win.HC() + c + pad_w, 0), G.w - 1), R0 = tr0 - win.HR() + pad_h + r_off;
+    const float* col = g_image + C;
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
-      if (k >= n_stage || (DYN && k * kBlock >= n_px)) break;  // (uniform)
-      const int i = min((int)threadIdx.x + k * kBlock, n_px - 1);
-      const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
-      const int R = min(max(oy + rl + pad_h, 0), G.h - 1), C = min(max(ox + cl + pad_w, 0), G.w - 1);
-      dst[k] = g_image[(int64_t)R * G.w + C];
+      if (k >= n_stage || k * rpp >= LH) break;  // (uniform)
+      const int R = min(max(R0 + k * rpp, 0), G.h - 1);   // (rows past the window and the idle threads of a pass: clamped, unused)
+      dst[k] = col[(int64_t)R * G.w];
     }
   };
   auto stage_store = [&](const float* src, int n_stage) {  // affine map of the upstream image (the variance gradient), zero outside the valid region
-    const int LW = win.LW(), n_px = win.LH() * LW, oy = tr0 - win.HR(), ox = tc0 - win.HC();
-    const float inv_lw = 1.0f / (float)LW;
+    const int LW = win.LW(), LH = win.LH(), rpp = kBlock / LW;
+    const int r_off = DYN ? (int)(((float)threadIdx.x + 0.5f) * (1.0f / (float)LW)) : (int)threadIdx.x / LW, c = (int)threadIdx.x - r_off * LW;
+    const int C = tc0 - win.HC() + c + pad_w, R0 = tr0 - win.HR() + pad_h + r_off;
+    const bool col_ok = r_off < rpp, col_valid = C >= G.lo && C < G.w - G.lo;
+    float* dstc = s_g + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
-      if (k >= n_stage || (DYN && k * kBlock >= n_px)) break;
-      const int i = threadIdx.x + k * kBlock;
-      const int rl = DYN ? (int)(((float)i + 0.5f) * inv_lw) : i / LW, cl = i - rl * LW;
-      const int R = oy + rl + pad_h, C = ox + cl + pad_w;
-      const bool valid = R >= G.lo && R < G.h - G.lo && C >= G.lo && C < G.w - G.lo;
+      if (k >= n_stage || k * rpp >= LH) break;
+      const int R = R0 + k * rpp;
+      const bool valid = col_valid && R >= G.lo && R < G.h - G.lo;
       const float gv = valid ? G.map(src[k], R, C) : 0.0f;
-      if (i < n_px) {
-        s_g[i] = gv;
+      if (col_ok && r_off + k * rpp < LH) {
+        dstc[k * rpp * LW] = gv;
         gmax_t = fmaxf(gmax_t, gv == gv ? fabsf(gv) : INFINITY);  // (a NaN counts as Inf: such a tile takes the f64 path)
         gsum_t += fabsf(gv);
       }
