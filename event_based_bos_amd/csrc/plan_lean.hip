@@ -896,7 +896,7 @@ inline LeanLayout lean_layout(int64_t n, int H, int W, int th, int tw) {
   // tiles got 1920 bins and runs of 4 events, a 50 M-event one 8192 bins and runs of ONE (as many table entries as events; its bin
   // sort alone took 2.25 ms).  With 240 bins (runs of 34) every bin is gathered 3 times (histogram + two chunks of its pixels, out
   // of the L2 / Infinity Cache) and the 10 M build is still 12 % shorter (0.350 -> 0.307 ms; 5 M 0.235 -> 0.204, 20 M 0.82 -> 0.72,
-  // 50 M 3.25 -> 2.43 ms; tools/bench_plan_build.py, profiles/r06_plan_build.json).
+  // 50 M 3.25 -> 2.43 ms; tools/bench_plan_build.py, profiles/r06p_plan_bins_sweep.json).
   constexpr double kBinFill = 3.3;
   for (int sub = 1;; sub *= 2) {
     if (sub > th) sub = th;

@@ -32,7 +32,7 @@ buf = (ctypes.c_ulonglong * (2 * 8192 * 8))()
 lib.ebos_debug_read_lean_stamps(buf, 2 * 8192 * 8)
 st = np.array(buf[:], dtype=np.float64).reshape(2, 8192, 8) * 10.0  # ns
 for which, name, phases in ((0, "lean_stage_kernel", ["clear hist", "load events + bin", "LDS rank atomics", "scan bins + table row", "scatter into LDS", "stream out + partial"]),
-                            (1, "lean_bin_sort_kernel", ["clear", "gather (pixels, dt, histogram)", "scan + key_offsets", "arrival order -> pixel order (LDS)", "canonical order + write (whole)"])):
+                            (1, "lean_bin_sort_kernel", ["clear", "gather 1 (histogram; a bin that fits: + pixels, dt)", "scan + key_offsets", "arrival order -> pixel order (LDS)", "canonical order + write (whole)"])):
     s = st[which]
     live = s[:, 0] > 0
     s = s[live]
@@ -45,6 +45,6 @@ for which, name, phases in ((0, "lean_stage_kernel", ["clear hist", "load events
     d = s[:, (np_ - 1)] - s[:, 0]
     print(f"  {'workgroup total':38s} median {np.median(d)/1e3:6.2f} us  min {d.min()/1e3:6.2f}  max {d.max()/1e3:6.2f}")
     if which == 1 and s[:, 5].max() > 0:   # inside the canonical-order step (its last chunk): hot-run detection | 16-lane sorts | ranks + pixels | barrier
-        for nm, a, b in (("  . to hot-run detection", 3, 5), ("  . pixel stores + hot-run networks", 5, 6), ("  . 16-lane sorts, ranks of long runs", 6, 7), ("  . closing barrier (drains the stores)", 7, 4)):
+        for nm, a, b in (("  . (overfull bin: gather 2, the chunk's pixels) to hot-run detection", 3, 5), ("  . pixel stores + hot-run networks", 5, 6), ("  . 16-lane sorts, ranks of long runs", 6, 7), ("  . closing barrier (drains the stores)", 7, 4)):
             d = s[:, b] - s[:, a]
             print(f"  {nm:38s} median {np.median(d)/1e3:6.2f} us  min {d.min()/1e3:6.2f}  max {d.max()/1e3:6.2f}")
