@@ -29,11 +29,28 @@ __device__ unsigned long long g_stamps_bwd[4096 * 8];
   do {                                                                                  \
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); \
   } while (0)
+#ifndef EBOS_STAMPS_SETUP
 #define EBOS_STAMP_BWD(k)                                                                   \
   do {                                                                                      \
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps_bwd[blockIdx.x * 8 + (k)] = wall_clock64(); \
   } while (0)
+#define EBOS_STAMP_BWD_S(k) \
+  do {                      \
+  } while (0)
+#else  // -DEBOS_STAMPS_SETUP: slots 2 .. 7 take the sub-steps of the backward kernel's set-up instead (tools/stamp_phases_bwd.py --setup)
+#define EBOS_STAMP_BWD(k)                                                                                          \
+  do {                                                                                                             \
+    if ((k) < 2 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamps_bwd[blockIdx.x * 8 + (k)] = wall_clock64();    \
+  } while (0)
+#define EBOS_STAMP_BWD_S(k)                                                                                       \
+  do {                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps_bwd[blockIdx.x * 8 + (k)] = wall_clock64();               \
+  } while (0)
+#endif
 #else
+#define EBOS_STAMP_BWD_S(k) \
+  do {                      \
+  } while (0)
 #define EBOS_STAMP(k) \
   do {                \
   } while (0)
@@ -2586,8 +2603,10 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       sq += mj.partials[2 * i + 1];
     }
   }
+  EBOS_STAMP_BWD_S(2);
   TileGrid tg{};
   if (GRID) tg = tile_grid_begin<TH, TW, AP>(flow_arg, gs, tr0, tc0, H, W, s_lerp);  // (the partials' loads fly over its barrier)
+  EBOS_STAMP_BWD_S(3);
   if (DYN) {
     float mu, mv;
     if (UNIFORM) {
@@ -2601,6 +2620,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
     }
     tile_bound_post(mu, mv, s_bound);
   }
+  EBOS_STAMP_BWD_S(4);
   if (var_mj) {
     __shared__ double red_m[2 * kBlock / kWave];
     block_sum2(sm, sq, red_m);
@@ -2633,6 +2653,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       G.c = (float)(-a * var_moments[0]);
     }
   }
+  EBOS_STAMP_BWD_S(5);
   if (DYN) {
     const Win<TH, TW, HALO, DYN> need = tile_bound_read<TH, TW, HALO, DYN>(s_bound, dt_bound);
     spec_hit = need.hr <= win.hr && need.hc <= win.hc;
@@ -2641,6 +2662,7 @@ iwe_dense_tiled_bwd_kernel(EvPtrs ev, const int32_t* __restrict__ key_offsets, c
       stage_loads(raw, kStage);
     }
   }
+  EBOS_STAMP_BWD_S(6);
   if (kPre && has_events) {
     const unsigned pitch = GRID ? (unsigned)PW : 4u * (unsigned)W, shift = GRID ? 0u : 2u, base = GRID ? (unsigned)(AP * PW + AP) : 0u;
     decode_bgroup(pre.A, pre_raw.A, pitch, shift, base);

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Phase breakdown of the GRID backward kernel (iwe_dense_tiled_bwd_kernel<..., GRID>) and the GRID forward kernel inside the
-solver loop, from in-kernel stamps (diagnostic build: EBOS_EXTRA_FLAGS=-DEBOS_STAMPS python -m event_based_bos_amd.build --force).
+solver loop (run it with EBOS_RESIDENT=0: the resident kernel has its own tool), from in-kernel stamps of the diagnostic twin of the library:
+    EBOS_STAMPS_MORE="" bash tools/build_stamps_lib.sh;  EBOS_HIP_LIBRARY=$PWD/event_based_bos_amd/lib/libebos_stamps.so EBOS_RESIDENT=0 python tools/stamp_phases_bwd.py
+(--setup: the twin built with EBOS_STAMPS_MORE=-DEBOS_STAMPS_SETUP; the default twin's -DEBOS_STAMPS_EPI overwrites slots 1 and 2).
 wall_clock64 ticks at 100 MHz."""
 import argparse, ctypes, os, sys
 import numpy as np, torch
@@ -13,6 +15,7 @@ from bench import H, W, synth_window
 ap = argparse.ArgumentParser()
 ap.add_argument("--events", type=int, default=2_000_000)
 ap.add_argument("--dense", action="store_true", help="the dense-field backward kernel (plan.variance_and_grad_dense) instead of the solver loop's")
+ap.add_argument("--setup", action="store_true", help="library built with -DEBOS_STAMPS_SETUP: the sub-steps of the backward kernel's set-up")
 ap.add_argument("--halo", type=lambda v: v if v == "auto" else int(v), default=32)
 a = ap.parse_args()
 lib = _hip.require_gpu()
@@ -40,6 +43,18 @@ loop = FusedPatchLoop(plan, (24, 32), (24, 32), torch.zeros((2, gh, gw)), 1.0, 0
 loop.run(40)
 torch.cuda.synchronize()
 n = 256
+if a.setup:
+    buf = (ctypes.c_ulonglong * (n * 8))()
+    raw.ebos_debug_read_stamps_bwd(buf, n * 8)
+    st = np.array(buf[:], dtype=np.float64).reshape(n, 8) * 10.0
+    order = [0, 2, 3, 4, 5, 6]
+    names = ["loads issued (staging, events, partials)", "interpolation tables + barrier + cell load issued", "window bound posted",
+             "partials reduced (two barriers), mean published", "window known, (re)staging issued"]
+    print(f"backward set-up, {a.events} events (slot 0 -> 1 of the usual table)")
+    for (i0, i1), nm in zip(zip(order[:-1], order[1:]), names):
+        d = st[:, i1] - st[:, i0]
+        print(f"  {nm:52s} median {np.median(d) / 1e3:6.2f} us   min {d.min() / 1e3:6.2f}   max {d.max() / 1e3:6.2f}")
+    sys.exit(0)
 for name, fn, names in (("backward", raw.ebos_debug_read_stamps_bwd,
                          ["variance partials reduce", "clear + upstream staging + tile flow", "main loop (lane-0 wave)", "wait for other waves",
                           "addend / flow_norm / weights", "tile adjoint + store"]),
