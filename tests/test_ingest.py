@@ -364,6 +364,14 @@ def test_plan_facts_read_back(emit):
     n_tiles = (len(ko) - 1) // (tile[0] * tile[1])
     assert plan.__dict__["_fullest_tile"] == int(np.diff(ko[:: tile[0] * tile[1]]).max())
     assert plan.__dict__["_parts_used"] == int(plan.part_table[n_tiles])
+    if emit == "full":   # the C entry on its own: counts / part_table are optional (NULL: zeros), the fullest tile always comes
+        from event_based_bos_amd import _hip
+        from event_based_bos_amd._hip import check, ptr, stream_ptr
+
+        facts = torch.full((4,), -1, dtype=torch.int32, device="cuda")
+        check(_hip.require_gpu().ebos_plan_facts(ptr(plan.key_offsets), h, w, tile[0], tile[1], None, None, ptr(facts), stream_ptr()), "ebos_plan_facts")
+        assert facts.tolist() == [0, 0, 0, plan.__dict__["_fullest_tile"]]
+        assert _hip.require_gpu().ebos_plan_facts(None, h, w, tile[0], tile[1], None, None, ptr(facts), stream_ptr()) != 0   # NULL key_offsets: refused
 
 
 @pytest.mark.gpu
