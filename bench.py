@@ -990,7 +990,7 @@ def run_config2(R):
         # the three regimes of one workload, stated where the driver's line names the workload
         line["config"]["workload"] += (f" | regimes [Mevents/s]: value = window resident from step to step (the CMax loop re-reads one window hundreds "
                                        f"of times) {line['value']:.0f}; value_hbm_streaming = distinct windows cycled beyond the Infinity Cache "
-                                       f"{line.get('value_hbm_streaming', float('nan')):.0f}; value_incl_plan_build = a fresh window, plan build + one step "
+                                       f"{(format(line['value_hbm_streaming'], '.0f') if 'value_hbm_streaming' in line else 'not measured (--no-extras)')}; value_incl_plan_build = a fresh window, plan build + one step "
                                        f"{line['value_incl_plan_build']:.0f}")
         line["contrast"] = contrast
         line.update(extras)

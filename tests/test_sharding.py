@@ -206,6 +206,33 @@ def test_bench_two_ranks_with_real_kernels_on_one_gpu(config, flags, total_key, 
 
 
 @pytest.mark.gpu
+def test_bench_under_torchrun_with_the_rccl_backend():
+    """The driver's N > 1 command form (`python -m torch.distributed.run ... bench.py --gpus N`) with the backend it will use -- "nccl" IS
+    RCCL on ROCm -- as far as a one-GPU box goes: a world of ONE rank.  Rendezvous with `device_id`, barrier, MAX all-reduce of a device
+    tensor and the object gather all run through RCCL; the two-rank tests above use gloo (two ranks cannot share a GPU under RCCL)."""
+    import json
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--min-seconds", "0.01", "--events", "300000",
+           "--no-cpu-baseline", "--no-extras"]
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=e)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["ranks_seen"][0]["rank"] == 0
+    assert "not measured" in line["config"]["workload"]   # (--no-extras: the streaming regime is not quoted as nan)
+
+
+@pytest.mark.gpu
 def test_two_ranks_on_one_gpu_time_no_collective():
     """The clock of a block stops on each rank when ITS steps have drained -- before the barrier (bench.py `timed_blocks`).  Two ranks
     sharing the one GPU of the box interleave their kernels: at equal events per rank a step may take up to ~2 x the one-rank step,
