@@ -3,7 +3,8 @@
 The reference reads CCS recordings from HDF5 (``raw_events/{x: int16, y: int16, t: int32 us, p: bool}``,
 src/data_loader/ccs.py:57-66) and hands every window to the solver as a float64 ``[n, 4]`` array
 ``(row = y, col = x, t / 1e6, p)`` (:289-297).  ``h5py`` is not part of this image, so the store keeps the same
-four columns in an uncompressed ``.npz`` (keys ``raw_events_x/y/t/p``) -- and, more to the point, it can hand a
+four columns in an uncompressed ``.npz`` (keys ``raw_events_x/y/t/p``; an ``.hdf5`` path is read directly where ``h5py`` exists,
+``_hdf5.py``) -- and, more to the point, it can hand a
 window to the GPU *as raw columns* (9 B/event instead of 32 B/event over PCIe), where ``EventPlan.build_raw``
 expands it with the same fp64 time arithmetic.
 
@@ -36,6 +37,10 @@ class RawEventStore(object):
     def __init__(self, source: Union[str, Dict[str, np.ndarray]]):
         if isinstance(source, dict):
             data = source
+        elif str(source).lower().endswith((".hdf5", ".h5")):   # the reference's own recordings, read as its h5py_loader does (needs h5py)
+            from ._hdf5 import read_raw_events
+
+            data = read_raw_events(str(source), wide_time=True)
         else:
             with np.load(source) as f:
                 data = {k: f["raw_events_" + k] for k, _ in COLUMNS}
@@ -63,6 +68,19 @@ class RawEventStore(object):
 
     def __len__(self) -> int:
         return len(self.event_data["x"])
+
+    # (what set_sequence leaves on the reference's loader, src/data_loader/ccs.py:213-217)
+    @property
+    def min_ts(self) -> float:
+        return self.event_data["t"].min() / self.TICKS_PER_SECOND
+
+    @property
+    def max_ts(self) -> float:
+        return self.event_data["t"].max() / self.TICKS_PER_SECOND
+
+    @property
+    def data_duration(self) -> float:
+        return self.max_ts - self.min_ts
 
     # ------------------------------------------------------------------ reference-format window
     def _check(self, start_index: int, end_index: int) -> None:

@@ -15,7 +15,8 @@ functions were run with only ``torchvision...resize`` / ``gaussian_blur`` shimme
 primitives (``make_golden.py --upsample`` -> ``golden_upsample.npz``, labelled shimmed):
 the arithmetic around those two calls is pinned, their insides are not ("shimmed" parity,
 short of full) -- see ``gaussian_blur3_torch`` and ``upsample_patch_flow``.  The raw-column
-loader restatement (``events_from_raw_columns``) stays "parity unpinned" (needs h5py).
+loader restatement (``events_from_raw_columns``) is pinned by ``golden_loader.npz``: the
+reference's loader run with the real h5py (``tests/golden/make_golden_loader.py``).
 
 Conventions (reference src/data_loader/ccs.py:293-296, src/warp.py:334):
   event = (x, y, t, p);  x = ROW (height) coordinate, y = COLUMN (width) coordinate;
@@ -447,8 +448,8 @@ def iwe_2dof(events: torch.Tensor, theta: torch.Tensor, image_size, pad=(0, 0),
 def events_from_raw_columns(x, y, t, p, start_index: int, end_index: int) -> np.ndarray:
     """CcsDataLoader.load_event_from_hdf, src/data_loader/ccs.py:275-297, on the raw columns of
     h5py_loader (:57-66: x int16 = column, y int16 = row, t int32 microseconds, p bool).
-    PARITY UNPINNED against the reference loader itself (it needs h5py and a recording; neither is
-    in this image) -- the restatement is the five assignments of :292-296."""
+    Pinned (round 6) by tests/golden/golden_loader.npz: the reference's loader itself, run with the real h5py of the container's
+    Anaconda interpreter on a synthetic recording (tests/golden/make_golden_loader.py; tests/test_loader_golden.py)."""
     n_events = end_index - start_index
     events = np.zeros((n_events, 4), dtype=np.float64)
     if len(x) <= start_index:

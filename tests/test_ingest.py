@@ -1,5 +1,7 @@
 """Event ingest: the raw-column store against the oracle's restatement of the reference loader,
 and -- on the GPU -- the raw-column plan against the plan of the float64 window (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -72,6 +74,31 @@ def test_raw_plan_equals_float64_plan(direction, normalize, t64):
     iwe = plan.iwe_dense(torch.from_numpy(flow).float().cuda())
     expect = O.iwe_dense(torch.from_numpy(store.load_event(a, b)), torch.from_numpy(flow), (H, W))
     assert O.rel_l2(iwe.cpu().numpy(), expect.numpy()) < 1e-4  # north_star tolerance, fp32 path vs fp64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("emit", ["full", "compact"])
+def test_raw_ingest_of_the_reference_loaders_recording(emit):
+    """The raw columns of the recording the REFERENCE's loader read (tests/golden/golden_loader.npz: its h5py_loader's arrays and its
+    load_event windows, src/data_loader/ccs.py:48-66, 247-297) through the device-side ingest: the SoA of the plan is the reference
+    window bit for bit, and the IWE of the fused path is the oracle's on the reference's own [n, 4] array."""
+    import event_based_bos_amd as ebos
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_loader.npz")) as f:
+        g = {k: f[k] for k in f.files}
+    h, w = (int(v) for v in g["size"])
+    store = ebos.data_loader.RawEventStore({k: g["file_" + k] for k in "xytp"})   # (as they sit in the HDF5 file: uint16 / int64 / uint8)
+    a, b = (int(v) for v in g["windows"][1])
+    window = g["window1"]                                                            # the reference loader's load_event(a, b)
+    ref = ebos.EventPlan.build(torch.from_numpy(window).cuda(), (h, w), "first", True, tile=None)
+    raw = ebos.EventPlan.build_raw(*store.load_raw(a, b), (h, w), "first", True, tile=None)
+    for name in ("x", "y", "dt", "p"):
+        assert torch.equal(getattr(raw, name), getattr(ref, name)), name
+    flow = O.synth_dense_flow(h, w, seed=5, max_val=6.0)
+    plan = store.plan(a, b, (h, w), "first", True, tile="auto", emit=emit)
+    iwe = plan.iwe_dense(torch.from_numpy(flow).float().cuda(), halo=32 if emit == "compact" else "auto")
+    expect = O.iwe_dense(torch.from_numpy(window), torch.from_numpy(flow), (h, w))
+    assert O.rel_l2(iwe.cpu().numpy(), expect.numpy()) < 1e-4
 
 
 @pytest.mark.gpu
