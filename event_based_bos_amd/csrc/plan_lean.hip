@@ -604,7 +604,8 @@ __global__ void __launch_bounds__(kSortBlock)
 lean_bin_sort_kernel(LeanGeom g, LeanScratch sc, const int32_t* __restrict__ grp_offsets, int32_t* __restrict__ key_offsets,
                      uint16_t* __restrict__ cpix, float* __restrict__ cdt, int pix_cap, int sort_cap, int n_chunks, LeanTime tc) {
   // sort_cap: events of one bin staged in LDS, TWICE (6 B each: as they arrive from the gather, then sorted by pixel); a larger bin
-  // takes the two-gather route and scatters to global memory
+  // (lean_layout leaves most bins of a window beyond ~10 k events per tile larger, on purpose) is gathered once for its histogram and
+  // once per chunk of whole pixels, 2 x sort_cap events of the whole staging area at a time
   extern __shared__ int32_t s_raw[];
   int32_t* s_cnt = s_raw;                 // [pix_cap]  events per pixel of the band, then exclusive offsets
   int32_t* s_cur = s_raw + pix_cap;       // [pix_cap]  cursors

@@ -198,7 +198,7 @@ def test_lean_plan_is_the_compact_part_of_the_full_plan(case):
     if case == "oob":
         x[::53] = w + 2
         y[7::61] = -1
-    if case == "skew":  # most events in one corner: bins beyond the LDS staging take the global-scatter branch
+    if case == "skew":  # most events in one corner: bins far beyond the LDS staging are gathered chunk by chunk of their pixels
         n = 400_000
         x, y, t, p = O.synth_raw_columns(n, h, w, seed=13)
         x[: n * 3 // 4] = x[: n * 3 // 4] % 70
