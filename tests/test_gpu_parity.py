@@ -1989,6 +1989,57 @@ def test_blur3_variance_adjoint_pass_vs_oracle(ebos, shape, omit, sigma):
                                                        _hip.stream_ptr()), "blur3")
 
 
+@pytest.mark.parametrize("model", ["patch", "2dof", "dense"])
+def test_windows_with_empty_tiles_vs_oracle(ebos, model):
+    """A static background: every event in the top-left quarter of the sensor, three quarters of the tiles EMPTY (the short cuts of
+    DESIGN 4.5 #91: a slab of zeros under the smallest window in the forward kernel; no upstream window, no mean in the backward
+    kernel -- whose epilogue still owes the regularisers' adjoint on the empty tiles' pixels).  Loss and gradient of one step of the
+    four-launch patch-flow loop (both regularisers on) and of the 2-DoF loop, and value + flow gradient of the dense call, against the
+    fp64 oracle's autograd."""
+    from event_based_bos_amd.solver.fused_loop import Fused2dofLoop, FusedPatchLoop
+
+    h, w, n = 192, 256, 60_000
+    ev = O.synth_events(n, h // 2, w // 2, seed=31)            # rows < 96, columns < 128 of a 192 x 256 sensor
+    plan = ebos.EventPlan.build(G(ev), (h, w), "first", True, tile=(32, 32), emit="compact")
+    tiles = plan.key_offsets[::32 * 32].diff()
+    assert int((tiles == 0).sum()) >= 30 and int((tiles > 0).sum()) >= 12
+    if model == "patch":
+        patch = (24, 32)
+        gh, gw = ebos.solver.patch_grid_shape((h, w), patch, patch)
+        th0 = np.random.RandomState(32).uniform(-3.0, 3.0, (2, gh, gw))
+        loop = FusedPatchLoop(plan, patch, patch, G(th0, torch.float32), 1.0, 0.002, 0.01, False, 0, "auto", lr=0.1, capacity=4)
+        losses = loop.run(1, resident=False)
+        to = torch.from_numpy(th0).float().double().requires_grad_(True)
+        dense = O.upsample_patch_flow(to, (h, w), patch, patch)
+        lo = O.image_variance(O.iwe_dense(torch.from_numpy(ev), dense, (h, w)), False) + 0.002 * O.flow_norm(dense) \
+            + 0.01 * O.image_gradient_tv(dense, torch.ones((h, w), dtype=torch.float64))
+        lo.backward()
+        assert abs(losses[0].item() - lo.item()) <= 1e-5 * abs(lo.item())
+        assert rel(loop.d_theta.cpu().numpy(), to.grad.numpy()) < 1e-3
+    elif model == "2dof":
+        th0 = np.array([1.5, -2.25])
+        loop = Fused2dofLoop(plan, torch.tensor(th0, dtype=torch.float32), 1.0, False, 0, "auto", lr=0.05, capacity=4)
+        losses = loop.run(1, resident=False)
+        to = torch.from_numpy(th0).float().double().requires_grad_(True)
+        dense = torch.stack([-to[0] * torch.ones((h, w), dtype=torch.float64), -to[1] * torch.ones((h, w), dtype=torch.float64)])
+        lo = O.image_variance(O.iwe_dense(torch.from_numpy(ev), dense, (h, w)), False)
+        lo.backward()
+        assert abs(losses[0].item() - lo.item()) <= 1e-5 * abs(lo.item())
+        assert rel(loop.d_theta.cpu().numpy().reshape(-1), to.grad.numpy()) < 1e-3
+    else:
+        fl = O.synth_dense_flow(h, w, seed=33, max_val=5.0)
+        for halo in ("auto", 32):
+            f = G(fl, torch.float32).requires_grad_(True)
+            v = plan.contrast_dense(f, halo=halo)
+            v.backward()
+            fo = torch.from_numpy(fl).float().double().requires_grad_(True)
+            vo = -O.image_variance(O.iwe_dense(torch.from_numpy(ev), fo, (h, w)), False)   # (the oracle's cost is -variance)
+            vo.backward()
+            assert abs(v.item() - vo.item()) <= 1e-5 * abs(vo.item())
+            assert rel(f.grad.cpu().numpy(), fo.grad.numpy()) < 1e-3
+            assert float(f.grad[:, h // 2 + 8:, :].abs().max()) == 0.0   # no event, no gradient: the empty tiles' rows
+
+
 @pytest.mark.parametrize("omit,pad,sigma,tv", [(False, 0, 1.0, 0.0), (True, 0, 3.0, 0.01), (False, 3, 3.0, 0.0)])
 def test_blurred_patch_loop_first_step_vs_oracle_autograd(ebos, omit, pad, sigma, tv):
     """One iteration of the native patch-flow loop with iwe.blur_sigma > 0 (combine -> blur image pass -> GRID backward with the
