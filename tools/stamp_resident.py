@@ -17,6 +17,7 @@ ap.add_argument("--size", type=int, nargs=2, default=[720, 1280])
 ap.add_argument("--patch", type=int, nargs=2, default=[24, 32])
 ap.add_argument("--iters", type=int, default=60)
 ap.add_argument("--flow-max", type=float, default=0.0)
+ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile (the diagnostic twin instruments the 45 x 80 kernels only)")
 ap.add_argument("--blur", type=float, default=0.0, help="iwe.blur_sigma of the objective (0: none)")
 a = ap.parse_args()
 lib = _hip.require_gpu()
@@ -24,7 +25,7 @@ raw = ctypes.CDLL(os.environ.get("EBOS_HIP_LIBRARY", _hip.LIB_PATH))
 H, W = a.size
 rs = np.random.RandomState(3)
 ev = np.stack([rs.randint(0, H, a.events), rs.randint(0, W, a.events), np.sort(rs.uniform(0, 0.5, a.events)), rs.randint(0, 2, a.events)], 1).astype(np.float64)
-plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile="auto", emit="compact")
+plan = ebos.EventPlan.build(torch.from_numpy(ev).cuda(), (H, W), "first", True, tile=tuple(a.tile) if a.tile else "auto", emit="compact")
 gh, gw = ebos.solver.patch_grid_shape((H, W), a.patch, a.patch)
 theta0 = torch.zeros((2, gh, gw)) if a.flow_max == 0 else (torch.rand((2, gh, gw), generator=torch.Generator().manual_seed(1)) * 2 - 1) * a.flow_max
 loop = FusedPatchLoop(plan, a.patch, a.patch, theta0, 1.0, 0.001, 0.0, lr=0.02 if a.blur else 0.1, capacity=a.iters + 8, halo="auto", blur_sigma=a.blur)
