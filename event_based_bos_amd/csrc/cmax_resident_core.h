@@ -143,7 +143,8 @@ struct ResidentArgs {
   float* variance;
   double* moments;
   unsigned long long cap_ticks;
-  float max_imbalance;   // leave with RES_IMBALANCED when (events of the fullest tile) > max_imbalance x (events of the average tile); 0: never
+  float max_imbalance;   // > 0: leave with RES_IMBALANCED when (events of the fullest tile) > max_imbalance x (events of the average tile);
+                         // < 0: the default rule (fullest tile > 60 k + 0.8 % of the window on >= 128 tiles, the ratio rules otherwise); 0: never
   Blur3 blur;            // k0 != 0: the contrast of the 3-tap blurred image (iwe.blur_sigma > 0, blur3.h)
   int gm;                // the gradient-magnitude contrast (sobel3.h) instead of the variance; patch-flow problems only
 };
@@ -609,9 +610,17 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       // (>= 32 k events on the fullest tile: below that nothing is slow.  Second rule, from profiles/r05m_skew_solver.json: a fullest
       // tile of >= 120 k events that is more than 3 x the average one -- 10 M events in a blob of sigma 200 px: 242 k, 6.2 x -- took
       // 315 us per iteration here against 116 with the pipeline's split tiles; at 2 M events the same blob, 48 k, still wins here)
+      // Round 6, with both sides measured again (profiles/r06t_crowding_rule.json; the accumulate loop merges same-cell events now,
+      // the launches skip empty tiles): on a sensor of >= 128 tiles the launches win once the fullest tile holds more than
+      // 60 k + 0.8 % of the window's events -- 1 M events: ~68 k, 2 M: ~76 k, 5 M: ~100 k --; the two ratio rules refused a 1 M-event
+      // window at 12 x (41 k events: 45.7 us here against 58.7) and kept a 2 M-event one at 10.7 x (84 k: 68.3 against 63.8).
+      // max_imbalance > 0 (EBOS_RESIDENT_MAX_IMBALANCE) keeps the ratio rules with that ratio; smaller sensors keep them too.
       const float imb_ratio = (float)s_imb[0] * (float)n_tiles / fmaxf((float)s_imb[1], 1.0f);
-      if (it == 0 && a.max_imbalance > 0.0f && s_imb[0] >= 512 &&
-          (imb_ratio > a.max_imbalance || (s_imb[0] >= 1875 && imb_ratio > 0.25f * a.max_imbalance))) {
+      const float ratio_cap = a.max_imbalance > 0.0f ? a.max_imbalance : 12.0f;
+      const bool by_ratio = s_imb[0] >= 512 && (imb_ratio > ratio_cap || (s_imb[0] >= 1875 && imb_ratio > 0.25f * ratio_cap));
+      const bool by_count = (float)s_imb[0] > 60000.0f / 64.0f + 0.008f * (float)s_imb[1];
+      const bool crowded = (a.max_imbalance < 0.0f && n_tiles >= 128) ? by_count : by_ratio;
+      if (it == 0 && a.max_imbalance != 0.0f && crowded) {
         if (threadIdx.x == 0) raise_status(a.status, (unsigned)RES_IMBALANCED);
         s_ok_local = false;
       }
@@ -1541,7 +1550,7 @@ inline void resident_common_args(ResidentArgs& a, int H, int W, int pad_h, int p
   a.cap_ticks = ticks < 1.0e3 ? 1000ull : (ticks > 9.0e18 ? 9000000000000000000ull : (unsigned long long)ticks);
   // one workgroup per tile: a window whose fullest tile holds more than this many times the average tile's events is the
   // pipeline's (adaptive work items); EBOS_RESIDENT_MAX_IMBALANCE overrides (0: never refuse)
-  a.max_imbalance = 12.0f;
+  a.max_imbalance = -1.0f;   // (< 0: the kernel's own rule; > 0: the ratio rules with this ratio; 0: never refuse)
   if (const char* e = getenv("EBOS_RESIDENT_MAX_IMBALANCE")) a.max_imbalance = (float)atof(e);
 }
 

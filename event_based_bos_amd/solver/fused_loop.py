@@ -60,6 +60,8 @@ def crowded_for_resident(plan: EventPlan) -> bool:
         return False
     H, W = plan.image_size
     n_tiles = ((H + plan.tile[0] - 1) // plan.tile[0]) * ((W + plan.tile[1] - 1) // plan.tile[1])
+    if n_tiles >= 128:   # measured on both routes (profiles/r06t_crowding_rule.json): 1 M events ~68 k, 2 M ~76 k, 5 M ~100 k
+        return fullest > 60_000 + 0.008 * plan.n
     ratio = fullest * n_tiles / max(plan.n, 1)
     return fullest >= 512 * 64 and (ratio > 12.0 or (fullest >= 1875 * 64 and ratio > 3.0))
 

@@ -1100,9 +1100,9 @@ def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
 @pytest.mark.gpu
 def test_resident_loop_leaves_crowded_windows_to_the_pipeline():
     """The resident kernel runs ONE workgroup per tile; the four-launch pipeline splits crowded tiles over several work items.  A
-    window whose fullest tile holds more than 12 x the average tile's events (and >= 32 k of them) ends the resident launch in its
-    first iteration (status -104, nothing changed) and the pipeline runs -- 184 against 95 us per iteration measured with 2 M events
-    in a Gaussian blob of sigma 100 px.  The verdict is the kernel's own (every workgroup sees every tile's count in the records of
+    window whose fullest tile holds more than 60 k + 0.8 % of the window's events (sensors of >= 128 tiles; smaller ones: more than
+    12 x the average tile's events and >= 32 k of them) ends the resident launch in its first iteration (status -104, nothing changed)
+    and the pipeline runs -- 120 against 61 us per iteration measured with 2 M events in a Gaussian blob of sigma 100 px.  The verdict is the kernel's own (every workgroup sees every tile's count in the records of
     the first all-to-all): it also covers plans built without a host read-back."""
     import torch
 
