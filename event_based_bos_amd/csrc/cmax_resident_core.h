@@ -144,7 +144,7 @@ struct ResidentArgs {
   double* moments;
   unsigned long long cap_ticks;
   float max_imbalance;   // > 0: leave with RES_IMBALANCED when (events of the fullest tile) > max_imbalance x (events of the average tile);
-                         // < 0: the default rule (fullest tile > 60 k + 0.8 % of the window on >= 128 tiles, the ratio rules otherwise); 0: never
+                         // < 0: the default rule (fullest tile > 60 k + 0.8 % of the window on >= 128 tiles, > 85 k on smaller sensors); 0: never
   Blur3 blur;            // k0 != 0: the contrast of the 3-tap blurred image (iwe.blur_sigma > 0, blur3.h)
   int gm;                // the gradient-magnitude contrast (sobel3.h) instead of the variance; patch-flow problems only
 };
@@ -611,15 +611,17 @@ __global__ void __launch_bounds__(kBlock) cmax_resident_kernel(ResidentArgs a_un
       // tile of >= 120 k events that is more than 3 x the average one -- 10 M events in a blob of sigma 200 px: 242 k, 6.2 x -- took
       // 315 us per iteration here against 116 with the pipeline's split tiles; at 2 M events the same blob, 48 k, still wins here)
       // Round 6, with both sides measured again (profiles/r06t_crowding_rule.json; the accumulate loop merges same-cell events now,
-      // the launches skip empty tiles): on a sensor of >= 128 tiles the launches win once the fullest tile holds more than
+      // the launches skip empty tiles): on a sensor of >= 128 tiles (1280 x 720) the launches win once the fullest tile holds more than
       // 60 k + 0.8 % of the window's events -- 1 M events: ~68 k, 2 M: ~76 k, 5 M: ~100 k --; the two ratio rules refused a 1 M-event
       // window at 12 x (41 k events: 45.7 us here against 58.7) and kept a 2 M-event one at 10.7 x (84 k: 68.3 against 63.8).
-      // max_imbalance > 0 (EBOS_RESIDENT_MAX_IMBALANCE) keeps the ratio rules with that ratio; smaller sensors keep them too.
+      // On a small sensor (346 x 260: 99 tiles of 32 x 32) the launches are slower and the cross-over sits at ~85 k events on the
+      // fullest tile whatever the window (100 k – 1 M events); the ratio rules had refused a 100 k-event window at 41 x (48.2 us here
+      // against 57.7) and kept a 1 M-event one at 11.4 x (115 k events: 98.2 against 69.7).
+      // max_imbalance > 0 (EBOS_RESIDENT_MAX_IMBALANCE): the ratio rules with that ratio.
       const float imb_ratio = (float)s_imb[0] * (float)n_tiles / fmaxf((float)s_imb[1], 1.0f);
-      const float ratio_cap = a.max_imbalance > 0.0f ? a.max_imbalance : 12.0f;
-      const bool by_ratio = s_imb[0] >= 512 && (imb_ratio > ratio_cap || (s_imb[0] >= 1875 && imb_ratio > 0.25f * ratio_cap));
-      const bool by_count = (float)s_imb[0] > 60000.0f / 64.0f + 0.008f * (float)s_imb[1];
-      const bool crowded = (a.max_imbalance < 0.0f && n_tiles >= 128) ? by_count : by_ratio;
+      const bool by_ratio = s_imb[0] >= 512 && (imb_ratio > a.max_imbalance || (s_imb[0] >= 1875 && imb_ratio > 0.25f * a.max_imbalance));
+      const bool by_count = n_tiles >= 128 ? (float)s_imb[0] > 60000.0f / 64.0f + 0.008f * (float)s_imb[1] : s_imb[0] > 85000 / 64;
+      const bool crowded = a.max_imbalance < 0.0f ? by_count : by_ratio;
       if (it == 0 && a.max_imbalance != 0.0f && crowded) {
         if (threadIdx.x == 0) raise_status(a.status, (unsigned)RES_IMBALANCED);
         s_ok_local = false;

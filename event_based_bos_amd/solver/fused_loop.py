@@ -53,17 +53,16 @@ def blur_taps(sigma: float) -> Tuple[float, float]:
 
 def crowded_for_resident(plan: EventPlan) -> bool:
     """The resident kernels' own refusal rule (RES_IMBALANCED, csrc/cmax_resident_core.h: one workgroup per tile waits for the fullest
-    tile) applied on the host where the plan knows its fullest tile: such a window goes to the launches without a refused launch and
+    tile -- ~0.5 ns per event of it on top of the uniform iteration) applied on the host where the plan knows its fullest tile: such a window goes to the launches without a refused launch and
     a status read-back first.  ``EBOS_RESIDENT_MAX_IMBALANCE`` (the kernel's override) switches the host check off."""
     fullest = plan.__dict__.get("_fullest_tile")
     if fullest is None or plan.tile is None or "EBOS_RESIDENT_MAX_IMBALANCE" in os.environ:
         return False
     H, W = plan.image_size
     n_tiles = ((H + plan.tile[0] - 1) // plan.tile[0]) * ((W + plan.tile[1] - 1) // plan.tile[1])
-    if n_tiles >= 128:   # measured on both routes (profiles/r06t_crowding_rule.json): 1 M events ~68 k, 2 M ~76 k, 5 M ~100 k
-        return fullest > 60_000 + 0.008 * plan.n
-    ratio = fullest * n_tiles / max(plan.n, 1)
-    return fullest >= 512 * 64 and (ratio > 12.0 or (fullest >= 1875 * 64 and ratio > 3.0))
+    # measured on both routes (profiles/r06t_crowding_rule.json): at 1280 x 720 the cross-over sits at ~68 k events on the fullest tile
+    # of a 1 M-event window, ~76 k at 2 M, ~100 k at 5 M; at 346 x 260 (slower launches) at ~85 k whatever the window
+    return fullest > (60_000 + 0.008 * plan.n if n_tiles >= 128 else 85_000)
 
 
 def blur_supported(plan: EventPlan, halo, sliding_window, contrast_terms: Dict[str, float]) -> bool:

@@ -881,9 +881,9 @@ int ebos_cmax_2dof_solve_f32(const ebos_cmax_2dof_problem* problem, int n_iter, 
  *                                  two different ones, ebos_cmax_resident_iterations returns -1: the state is partly written.
  *   ebos_cmax_resident_status      synchronises `stream`, returns EBOS_OK or a negative code (-101 spin cap, -102 spill,
  *                                  -103 geometry, -104 a crowded window: on a sensor of >= 128 tiles the fullest tile holds more
- *                                  than 60 k + 0.8 % of the window's events; on smaller ones more than 12 x the average tile's
- *                                  (and >= 32 k), or >= 120 k events and more than 3 x -- the kernel's own verdict in its first
- *                                  iteration; EBOS_RESIDENT_MAX_IMBALANCE = r > 0: the ratio rules with r, 0 = never); on a negative code run
+ *                                  than 60 k + 0.8 % of the window's events, on smaller ones more than 85 k -- the kernel's own
+ *                                  verdict in its first iteration; EBOS_RESIDENT_MAX_IMBALANCE = r > 0: more than r x the average
+ *                                  tile's events (and >= 32 k), or >= 120 k and more than r / 4 x; 0 = never); on a negative code run
  *                                  ebos_cmax_patch_solve_f32 with the same problem.  -102 is also how the blurred and the
  *                                  gradient-magnitude loops hand over when the windows outgrow their LDS regions (~12 px).  */
 size_t ebos_cmax_resident_mailbox_bytes(int H, int W, int tile_h, int tile_w);

@@ -532,7 +532,7 @@ def test_window_pipeline_matches_per_window_estimates(n_concurrent, pyramid):
 @pytest.mark.gpu
 def test_window_pipeline_reads_the_first_groups_verdicts_in_order():
     """the early verdict at the second group is read AFTER the first group's side streams have finished.
-    Windows whose events crowd one tile (> 12 x the average tile, >= 32 k events) make the resident launches of group 0 really
+    Windows whose events crowd one tile (> 85 k events on a sensor of < 128 tiles) make the resident launches of group 0 really
     end with -104: the later groups must then run as four launches from the start (no second solve), and the results are those
     of a pipeline that never tried the resident kernel."""
     import event_based_bos_amd as ebos
@@ -541,7 +541,7 @@ def test_window_pipeline_reads_the_first_groups_verdicts_in_order():
     rs = np.random.RandomState(3)
     cols, rows, ts, ps, bounds = [], [], [], [], [0]
     for k in range(4):
-        n_c, n_u = 45_000, 15_000
+        n_c, n_u = 120_000, 15_000   # (> 85 k events on one tile of a small sensor: the launches' window)
         r = np.concatenate([rs.randint(100, 125, n_c), rs.randint(0, h, n_u)])
         c = np.concatenate([rs.randint(200, 222, n_c), rs.randint(0, w, n_u)])
         rows.append(r); cols.append(c); ps.append(rs.randint(0, 2, len(r)))

@@ -45,10 +45,15 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--modes", nargs="*", default=["pipeline", "resident", "resident_forced"])
     ap.add_argument("--no-uniform", action="store_true", help="skip the uniform window (for a kernel trace of one distribution)")
+    ap.add_argument("--size", type=int, nargs=2, default=None, help="sensor H W (default 720 1280)")
+    ap.add_argument("--patch", type=int, nargs=2, default=[24, 32])
     ap.add_argument("--tile", type=int, nargs=2, default=None, help="source tile of the plan (default: choose_tile -- 45 x 80 at 1280 x 720)")
     a = ap.parse_args()
+    global H, W
+    if a.size:
+        H, W = a.size
     lib = ebos._hip.require_gpu()
-    patch = (24, 32)
+    patch = tuple(a.patch)
     gh, gw = ebos.solver.patch_grid_shape((H, W), patch, patch)
     rows = []
     for n in a.events:
