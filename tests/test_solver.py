@@ -1097,6 +1097,33 @@ def test_resident_loop_ends_on_a_spill_and_the_pipeline_takes_over():
     np.testing.assert_allclose(res.theta.cpu().numpy(), ref.theta.cpu().numpy(), atol=1e-2)
 
 
+def test_crowded_window_rule_follows_the_measured_cross_overs():
+    """`crowded_for_resident` (the host's copy of the resident kernels' own verdict) on the windows of profiles/r06t_crowding_rule.json:
+    every window goes where it was measured faster.  (1280 x 720 on 45 x 80 tiles: 256 tiles; 346 x 260 on 32 x 32: 99.)"""
+    import types
+
+    from event_based_bos_amd.solver.fused_loop import crowded_for_resident
+
+    def plan(size, tile, n, ratio):
+        n_tiles = -(-size[0] // tile[0]) * -(-size[1] // tile[1])
+        p = types.SimpleNamespace(image_size=size, tile=tile, n=n)
+        p.__dict__["_fullest_tile"] = int(ratio * n / n_tiles)
+        return p
+
+    big, small = ((720, 1280), (45, 80)), ((260, 346), (32, 32))
+    # (events, fullest / average tile, faster on the four launches?)
+    for n, ratio, launches in [(1_000_000, 10.6, False), (1_000_000, 21.4, True), (2_000_000, 8.5, False), (2_000_000, 10.7, True),
+                               (2_000_000, 21.4, True), (5_000_000, 4.1, False), (5_000_000, 6.2, True), (10_000_000, 2.0, False),
+                               (10_000_000, 6.2, True)]:
+        assert crowded_for_resident(plan(*big, n, ratio)) == launches, (n, ratio)
+    for n, ratio, launches in [(100_000, 41.0, False), (300_000, 23.3, False), (300_000, 40.9, True), (1_000_000, 5.6, False),
+                               (1_000_000, 11.4, True)]:
+        assert crowded_for_resident(plan(*small, n, ratio)) == launches, (n, ratio)
+    unknown = plan(*big, 2_000_000, 30.0)
+    unknown.__dict__["_fullest_tile"] = None   # a plan built without its read-back: the kernel decides in its first iteration
+    assert not crowded_for_resident(unknown)
+
+
 @pytest.mark.gpu
 def test_resident_loop_leaves_crowded_windows_to_the_pipeline():
     """The resident kernel runs ONE workgroup per tile; the four-launch pipeline splits crowded tiles over several work items.  A
